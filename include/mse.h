@@ -1,0 +1,162 @@
+/*
+ * mse.h -- C ABI of libmse_hip.so: the MI355X (gfx950) scoring hot path of meme-search-engine.
+ *
+ * Drop-in boundary.  Every entry point names the reference interface it replaces (paths are
+ * relative to the reference checkout).  A Rust maintainer binds these with an `extern "C"`
+ * block (INTEGRATION.md shows the stubs); nothing here mentions torch, HIP or C++ types.
+ *
+ * Conventions
+ *   - All functions returning `int` return 0 on success, non-zero on failure; the message is
+ *     available from mse_last_error() (thread-local).  Nothing aborts or throws across the ABI.
+ *   - f16 data is passed as uint16_t IEEE binary16 bit patterns (Rust `half::f16` is
+ *     repr(transparent) over u16).
+ *   - Scores are i64 fixed point, `(f32 * 2^32) as i64`, exactly as diskann::vector produces
+ *     (diskann/src/vector.rs:46-47,408-416).
+ *   - Pointers named *_dev are device (HBM) pointers; all others are host pointers.  The caller
+ *     owns every buffer it passes in; the library keeps no caller pointer after a call returns
+ *     except for the *_wrap_device constructors, which borrow.
+ *   - Handles are thread-compatible: an mse_base / mse_codes / mse_pq / mse_index may be shared
+ *     read-only by any number of threads; each searching thread owns its own mse_searcher
+ *     (mirrors the reference: one `Scratch` + `Rc<Index>` per thread over shared `Arc` maps,
+ *     src/query_disk_index.rs:714-731).
+ *   - Tie order: equal scores are ordered by ascending id (the reference leaves it unspecified:
+ *     sort_unstable_by_key, src/query_disk_index.rs:271).
+ */
+#ifndef MSE_H
+#define MSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define MSE_ID_NONE 0xFFFFFFFFu
+
+/* ---- runtime ------------------------------------------------------------------------- */
+const char* mse_last_error(void);
+int mse_device_count(void);
+int mse_set_device(int ordinal);                 /* selects the HIP device for this thread */
+int mse_device_synchronize(void);
+int mse_device_mem_info(size_t* free_bytes, size_t* total_bytes);
+const char* mse_version(void);
+
+/* ---- fixed-point scale: diskann/src/vector.rs:408-416 ---------------------------------- */
+int64_t mse_scale_dot_f32(float x);              /* scale_dot_result */
+int64_t mse_scale_dot_f64(double x);             /* scale_dot_result_f64 */
+
+/* ---- base vectors: diskann::vector::VectorList (vector.rs:118-186) kept resident in HBM - */
+typedef struct mse_base mse_base;
+mse_base* mse_base_from_host(const uint16_t* data, size_t n_rows, size_t d);      /* copies */
+mse_base* mse_base_wrap_device(const void* data_dev, size_t n_rows, size_t d);    /* borrows */
+mse_base* mse_base_generate(uint32_t seed, uint64_t first_row, size_t n_rows, size_t d); /* synthetic rows made on the device */
+void mse_base_free(mse_base* b);
+size_t mse_base_len(const mse_base* b);
+size_t mse_base_dim(const mse_base* b);
+const void* mse_base_device_ptr(const mse_base* b);
+int mse_base_read_rows(const mse_base* b, size_t first_row, size_t n_rows, uint16_t* out); /* D2H, for spot checks */
+
+/* fast_dot_noprefetch(x, y) / fast_dot(x, y, _) -- diskann/src/vector.rs:255-306,192-252.
+ * Host slices in, one i64 out, computed on the device in the reference's summation order. */
+int mse_fast_dot_f16(const uint16_t* x, const uint16_t* y, size_t n, int64_t* out);
+
+/* ---- searcher: per-thread scratch + stream (reference: `Scratch`, lib.rs:157-175 and
+ * query_disk_index.rs:116-123) --------------------------------------------------------- */
+typedef struct mse_searcher mse_searcher;
+mse_searcher* mse_searcher_new(const mse_base* b);
+void mse_searcher_free(mse_searcher* s);
+/* HIP stream the searcher launches on (void* = hipStream_t); default: its own stream. */
+int mse_searcher_set_stream(mse_searcher* s, void* hip_stream);
+void* mse_searcher_stream(const mse_searcher* s);
+
+#define MSE_MODE_AUTO 0   /* exact scan for <= 8 queries, batched MFMA scan above that */
+#define MSE_MODE_EXACT 1  /* every row scored in the reference order on the vector ALU */
+#define MSE_MODE_MFMA 2   /* f16 MFMA scan for candidates + exact re-score + certificate */
+
+/* Brute-force top-k: the scan + ranking of `evaluate` (src/query_disk_index.rs:262-273) for a
+ * batch of f16 queries.  scores/ids are [nq][k], best first; unfilled slots (k > n_rows) hold
+ * INT64_MIN / MSE_ID_NONE.  Returned ids/scores are identical in every mode. */
+int mse_bruteforce_topk_f16(mse_searcher* s, const uint16_t* queries, size_t nq, size_t k, int mode,
+                            int64_t* scores, uint32_t* ids);
+/* Same with device-resident queries/outputs, asynchronous on the searcher's stream.
+ * id_offset is added to every returned id (global id = local id + shard offset). */
+int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t nq, size_t k, int mode,
+                                uint64_t id_offset, void* scores_dev, void* ids_dev);
+/* All n_rows exact scores of one query (what `matches` holds before the sort, :263-269). */
+int mse_bruteforce_scores_f16(mse_searcher* s, const uint16_t* query, int64_t* scores);
+/* rank[i] = position of row ids[i] in the (score desc, id asc) order of one query; the
+ * rank lookup of evaluate (:271-273,309-316). */
+int mse_bruteforce_ranks_f16(mse_searcher* s, const uint16_t* query, const uint32_t* ids, size_t n_ids,
+                             uint32_t* ranks);
+/* Gather-and-score: out[i] = fast_dot(query, base[ids[i]]) -- the neighbour loop of the in-RAM
+ * search (diskann/src/lib.rs:201-207) and the fetched-node re-score (query_disk_index.rs:168-169).
+ * ids >= n_rows give INT64_MIN. */
+int mse_score_rows_f16(mse_searcher* s, const uint32_t* ids, size_t n_ids, const uint16_t* query, int64_t* out);
+/* statistics of the last MFMA-mode call: number of queries whose certificate needed a wider
+ * candidate set, and the widest group count used. */
+int mse_searcher_last_stats(const mse_searcher* s, uint32_t* n_widened, uint32_t* max_groups);
+
+/* ---- flat in-memory index: FAISS IndexScalarQuantizer(QT_fp16, INNER_PRODUCT) as used by
+ * src/main.rs:822 (new), :858,:892 (add), :900 (search), :1015,:1053 (ntotal) -------------- */
+typedef struct mse_index mse_index;
+mse_index* mse_index_new(int d);
+void mse_index_free(mse_index* idx);
+int mse_index_add(mse_index* idx, const float* x, size_t n);            /* fp32 -> fp16 RNE, appended */
+size_t mse_index_ntotal(const mse_index* idx);
+/* distances [nq][k] descending, labels [nq][k], -1 where fewer than k vectors exist (:908). */
+int mse_index_search(mse_index* idx, const float* queries, size_t nq, size_t k, float* distances, int64_t* labels);
+
+/* ---- product quantiser: diskann::vector::ProductQuantizer (vector.rs:308-406) ------------ */
+typedef struct mse_pq mse_pq;
+mse_pq* mse_pq_load(const float* centroids, size_t n_centroids, const float* transform, size_t n_dims,
+                    size_t n_dims_per_code);
+void mse_pq_free(mse_pq* pq);
+int mse_pq_apply_transform(mse_pq* pq, const float* x, size_t n, float* out);          /* :320-329 */
+int mse_pq_quantize_batch(mse_pq* pq, const float* x, size_t n, uint8_t* codes);       /* :331-364 */
+int mse_pq_preprocess_query(mse_pq* pq, const float* query, float* lut);               /* :367-384, lut[n_chunks*n_centroids] */
+int mse_pq_adc(mse_pq* pq, const float* lut, const uint8_t* codes, size_t n, int64_t* out); /* :387-405 */
+
+/* PQ codes (+ optional descriptor bytes) resident in HBM: the mmap'd index.pq-codes.bin /
+ * index.descriptor-codes.bin of src/query_disk_index.rs:686-709. */
+typedef struct mse_codes mse_codes;
+mse_codes* mse_codes_from_host(const uint8_t* codes, size_t n, size_t code_size, const uint8_t* descriptors,
+                               size_t n_descriptors);
+void mse_codes_free(mse_codes* c);
+size_t mse_codes_len(const mse_codes* c);
+/* out[i] = adc(lut, codes[ids[i]]) + descriptor_product(scales, ids[i])   (query_disk_index.rs:189-203,135-142);
+ * scales may be NULL (no descriptor bias). */
+int mse_pq_adc_gather(mse_pq* pq, const mse_codes* c, const float* lut, const float* scales, const uint32_t* ids,
+                      size_t n_ids, int64_t* out);
+/* Full ADC scan of all codes, top-r by approximate score, exact re-score against `base` with the
+ * f16 query, final top-k (BASELINE config 5).  base may be NULL: then scores are the ADC scores. */
+int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,
+                     const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
+/* descriptor_product (src/query_disk_index.rs:135-142) for one id, host-side helper. */
+int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id);
+
+/* ---- NeighbourBuffer: diskann/src/lib.rs:74-155 (host) ----------------------------------- */
+typedef struct mse_nb mse_nb;
+mse_nb* mse_nb_new(size_t cap);
+void mse_nb_free(mse_nb* b);
+void mse_nb_clear(mse_nb* b);
+size_t mse_nb_len(const mse_nb* b);
+size_t mse_nb_cap(const mse_nb* b);
+void mse_nb_insert(mse_nb* b, uint32_t id, int64_t score);
+int mse_nb_next_unvisited(mse_nb* b, uint32_t* id);       /* 1 and *id, or 0 when none */
+const uint32_t* mse_nb_ids(const mse_nb* b);
+const int64_t* mse_nb_scores(const mse_nb* b);
+
+/* In-RAM Vamana greedy search: diskann::greedy_search (lib.rs:183-211).  Traversal on the host,
+ * neighbour scoring on the device (gather-and-score).  adj is [n][max_deg], deg[n].  Results
+ * are left in `buf`, best first.  *n_distances receives GreedySearchCounters.distances. */
+int mse_greedy_search(mse_searcher* s, const uint32_t* adj, const uint32_t* deg, size_t max_deg, uint32_t start,
+                      const uint16_t* query, int base_vectors_only, uint32_t query_breakpoint, mse_nb* buf,
+                      size_t* n_distances);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSE_H */

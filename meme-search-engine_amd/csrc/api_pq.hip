@@ -1,0 +1,361 @@
+// C ABI, part 2: evaluator ranks, flat fp16 index (FAISS SQfp16-IP semantics), product quantiser.
+#include "../../include/mse.h"
+#include "runtime.h"
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace mse;
+
+struct mse_index {
+    int d = 0;
+    size_t n = 0, cap = 0;
+    uint16_t* codes = nullptr;   // [cap][d] fp16, device
+    mse_searcher* scratch = nullptr;
+    std::mutex mu;               // add() is exclusive; searches take it too (scratch is shared)
+};
+
+struct mse_pq {
+    size_t n_centroids = 0, d = 0, dpc = 0, n_chunks = 0;
+    float* centroids = nullptr;  // device [n_centroids][d]
+    float* transform = nullptr;  // device [d][d]
+    std::mutex mu;
+    DevBuf a, b, c;              // call scratch (guarded by mu)
+};
+
+struct mse_codes {
+    uint8_t* codes = nullptr;    // device [n][code_size]
+    uint8_t* desc = nullptr;     // device [n][n_desc] or null
+    size_t n = 0, code_size = 0, n_desc = 0;
+};
+
+extern "C" {
+
+// ---- evaluator ranks (src/query_disk_index.rs:271-273,309-316) ---------------------------------
+int mse_bruteforce_ranks_f16(mse_searcher* s, const uint16_t* query, const uint32_t* ids, size_t n_ids,
+                             uint32_t* ranks) {
+    if (!s || !s->base) return fail("null searcher");
+    const mse_base* b = s->base;
+    if (n_ids == 0) return 0;
+    const size_t d = b->d;
+    hipStream_t st = s->stream;
+    if (s->q_stage.ensure(8 * d * 2) || s->scores.ensure(std::max<size_t>(b->n, 1) * 8)) return -1;
+    MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, 8 * d * 2, st));
+    MSE_HIP_TRY(hipMemcpyAsync(s->q_stage.p, query, d * 2, hipMemcpyHostToDevice, st));
+    if (launch_scan_exact(b->dev, b->n, (int)d, s->q_stage.p, 1, false, s->scores.as<int64_t>(), b->n, nullptr, s->n_cu,
+                          st)) return -1;
+    const size_t chunk = (size_t)rank_max_targets();
+    if (s->cand_ids.ensure(chunk * 4) || s->cand_scores.ensure(chunk * 8)) return -1;
+    std::vector<unsigned long long> counts(chunk);
+    for (size_t o = 0; o < n_ids; o += chunk) {
+        const size_t m = std::min(chunk, n_ids - o);
+        for (size_t i = 0; i < m; i++)
+            if (ids[o + i] >= b->n) return fail("rank: id out of range");
+        MSE_HIP_TRY(hipMemcpyAsync(s->cand_ids.p, ids + o, m * 4, hipMemcpyHostToDevice, st));
+        MSE_HIP_TRY(hipMemsetAsync(s->cand_scores.p, 0, m * 8, st));
+        if (launch_rank(s->scores.as<int64_t>(), b->n, s->cand_ids.as<uint32_t>(), (int)m,
+                        s->cand_scores.as<unsigned long long>(), s->n_cu, st)) return -1;
+        MSE_HIP_TRY(hipMemcpyAsync(counts.data(), s->cand_scores.p, m * 8, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < m; i++) ranks[o + i] = (uint32_t)counts[i];
+    }
+    return 0;
+}
+
+// ---- flat index -----------------------------------------------------------------------------------
+mse_index* mse_index_new(int d) {
+    if (d <= 0 || d % 64 != 0 || d > D_MAX) {
+        fail("index width must be a positive multiple of 64");
+        return nullptr;
+    }
+    mse_index* idx = new (std::nothrow) mse_index();
+    if (!idx) { fail("out of host memory"); return nullptr; }
+    idx->d = d;
+    idx->scratch = scratch_searcher_new();
+    if (!idx->scratch) { delete idx; return nullptr; }
+    return idx;
+}
+void mse_index_free(mse_index* idx) {
+    if (!idx) return;
+    if (idx->scratch) mse_searcher_free(idx->scratch);
+    if (idx->codes) (void)hipFree(idx->codes);
+    delete idx;
+}
+size_t mse_index_ntotal(const mse_index* idx) { return idx ? idx->n : 0; }
+
+int mse_index_add(mse_index* idx, const float* x, size_t n) {
+    if (!idx) return fail("null index");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> g(idx->mu);
+    const size_t d = idx->d;
+    hipStream_t st = idx->scratch->stream;
+    if (idx->n + n > 0xFFFFFFFEull) return fail("index full");
+    if (idx->n + n > idx->cap) {
+        size_t ncap = std::max<size_t>(idx->cap * 2, idx->n + n);
+        ncap = std::max<size_t>(ncap, 1024);
+        uint16_t* np = nullptr;
+        MSE_HIP_TRY(hipMalloc((void**)&np, ncap * d * 2));
+        if (idx->n) MSE_HIP_TRY(hipMemcpyAsync(np, idx->codes, idx->n * d * 2, hipMemcpyDeviceToDevice, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        if (idx->codes) (void)hipFree(idx->codes);
+        idx->codes = np;
+        idx->cap = ncap;
+    }
+    // fp32 rows are staged on the device and narrowed there (RNE), as FAISS QT_fp16 encodes them
+    DevBuf& stage = idx->scratch->misc;
+    if (stage.ensure(n * d * 4)) return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(stage.p, x, n * d * 4, hipMemcpyHostToDevice, st));
+    if (launch_f32_to_f16(stage.as<float>(), n * d, idx->codes + idx->n * d, st)) return -1;
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    idx->n += n;
+    return 0;
+}
+
+int mse_index_search(mse_index* idx, const float* queries, size_t nq, size_t k, float* distances, int64_t* labels) {
+    if (!idx) return fail("null index");
+    if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    std::lock_guard<std::mutex> g(idx->mu);
+    mse_searcher* s = idx->scratch;
+    hipStream_t st = s->stream;
+    const size_t d = idx->d, n = idx->n;
+    for (size_t i = 0; i < nq * k; i++) { distances[i] = -FLT_MAX; labels[i] = -1; }
+    if (n == 0) return 0;
+    std::vector<uint32_t> ids_h(8 * k);
+    std::vector<float> dist_h(8 * k);
+    for (size_t q0 = 0; q0 < nq; q0 += 8) {
+        const int nqp = (int)std::min<size_t>(8, nq - q0);
+        if (s->q_stage.ensure(8 * d * 4) || s->scores.ensure((size_t)nqp * n * 4)) return -1;
+        MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, 8 * d * 4, st));
+        MSE_HIP_TRY(hipMemcpyAsync(s->q_stage.p, queries + q0 * d, (size_t)nqp * d * 4, hipMemcpyHostToDevice, st));
+        if (launch_scan_exact(idx->codes, n, (int)d, s->q_stage.p, nqp, true, nullptr, n, s->scores.as<float>(), s->n_cu,
+                              st)) return -1;
+        if (s->sel_keys.ensure((size_t)nqp * k * 4)) return -1;
+        uint32_t* sel = nullptr;
+        LevelRef l0{KEY_F32, s->scores.p, n, 1, n, false, 0};
+        if (descend(s, l0, nqp, (int)k, &sel, s->sel_keys.p)) return -1;
+        MSE_HIP_TRY(hipMemcpyAsync(ids_h.data(), sel, (size_t)nqp * k * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipMemcpyAsync(dist_h.data(), s->sel_keys.p, (size_t)nqp * k * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < (size_t)nqp * k; i++) {
+            if (ids_h[i] == ID_NONE) continue;
+            distances[q0 * k + i] = dist_h[i];
+            labels[q0 * k + i] = (int64_t)ids_h[i];
+        }
+    }
+    return 0;
+}
+
+// ---- product quantiser ----------------------------------------------------------------------------
+mse_pq* mse_pq_load(const float* centroids, size_t n_centroids, const float* transform, size_t n_dims,
+                    size_t n_dims_per_code) {
+    if (n_centroids == 0 || n_centroids > 256) { fail("at most 256 centroids (vector.rs:337)"); return nullptr; }
+    if (n_dims == 0 || n_dims_per_code == 0 || n_dims % n_dims_per_code != 0) {
+        fail("n_dims must be a positive multiple of n_dims_per_code");
+        return nullptr;
+    }
+    if ((n_dims / n_dims_per_code) * n_centroids * 4 > 160 * 1024) { fail("PQ table exceeds LDS"); return nullptr; }
+    mse_pq* pq = new (std::nothrow) mse_pq();
+    if (!pq) { fail("out of host memory"); return nullptr; }
+    pq->n_centroids = n_centroids; pq->d = n_dims; pq->dpc = n_dims_per_code; pq->n_chunks = n_dims / n_dims_per_code;
+    if (hipMalloc((void**)&pq->centroids, n_centroids * n_dims * 4) != hipSuccess ||
+        hipMalloc((void**)&pq->transform, n_dims * n_dims * 4) != hipSuccess ||
+        hipMemcpy(pq->centroids, centroids, n_centroids * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pq->transform, transform, n_dims * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        mse_pq_free(pq);
+        fail("device allocation/copy failed for the quantiser");
+        return nullptr;
+    }
+    return pq;
+}
+void mse_pq_free(mse_pq* pq) {
+    if (!pq) return;
+    if (pq->centroids) (void)hipFree(pq->centroids);
+    if (pq->transform) (void)hipFree(pq->transform);
+    delete pq;
+}
+
+int mse_pq_apply_transform(mse_pq* pq, const float* x, size_t n, float* out) {
+    if (!pq) return fail("null quantiser");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    const size_t bytes = n * pq->d * 4;
+    if (pq->a.ensure(bytes) || pq->b.ensure(bytes)) return -1;
+    MSE_HIP_TRY(hipMemcpy(pq->a.p, x, bytes, hipMemcpyHostToDevice));
+    if (launch_pq_transform(pq->transform, (int)pq->d, pq->a.as<float>(), n, pq->b.as<float>(), nullptr)) return -1;
+    MSE_HIP_TRY(hipMemcpy(out, pq->b.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mse_pq_quantize_batch(mse_pq* pq, const float* x, size_t n, uint8_t* codes) {
+    if (!pq) return fail("null quantiser");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    const size_t bytes = n * pq->d * 4;
+    if (pq->a.ensure(bytes) || pq->b.ensure(bytes) || pq->c.ensure(n * pq->n_chunks)) return -1;
+    MSE_HIP_TRY(hipMemcpy(pq->a.p, x, bytes, hipMemcpyHostToDevice));
+    if (launch_pq_transform(pq->transform, (int)pq->d, pq->a.as<float>(), n, pq->b.as<float>(), nullptr)) return -1;
+    if (launch_pq_quantize(pq->centroids, (int)pq->n_centroids, (int)pq->d, (int)pq->dpc, pq->b.as<float>(), n,
+                           pq->c.as<uint8_t>(), nullptr)) return -1;
+    MSE_HIP_TRY(hipMemcpy(codes, pq->c.p, n * pq->n_chunks, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// device LUT build into pq->c (needs pq->mu held); query_dev = fp32 [d] on device
+static int build_lut_locked(mse_pq* pq, const float* query_dev, hipStream_t st) {
+    if (pq->b.ensure(pq->d * 4) || pq->c.ensure(pq->n_chunks * pq->n_centroids * 4)) return -1;
+    if (launch_pq_transform(pq->transform, (int)pq->d, query_dev, 1, pq->b.as<float>(), st)) return -1;
+    return launch_pq_lut(pq->centroids, (int)pq->n_centroids, (int)pq->d, (int)pq->dpc, pq->b.as<float>(),
+                         pq->c.as<float>(), st);
+}
+
+int mse_pq_preprocess_query(mse_pq* pq, const float* query, float* lut) {
+    if (!pq) return fail("null quantiser");
+    std::lock_guard<std::mutex> g(pq->mu);
+    if (pq->a.ensure(pq->d * 4)) return -1;
+    MSE_HIP_TRY(hipMemcpy(pq->a.p, query, pq->d * 4, hipMemcpyHostToDevice));
+    if (build_lut_locked(pq, pq->a.as<float>(), nullptr)) return -1;
+    MSE_HIP_TRY(hipMemcpy(lut, pq->c.p, pq->n_chunks * pq->n_centroids * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mse_pq_adc(mse_pq* pq, const float* lut, const uint8_t* codes, size_t n, int64_t* out) {
+    if (!pq) return fail("null quantiser");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    const size_t lut_bytes = pq->n_chunks * pq->n_centroids * 4;
+    if (pq->a.ensure(lut_bytes) || pq->b.ensure(n * pq->n_chunks) || pq->c.ensure(n * 8)) return -1;
+    MSE_HIP_TRY(hipMemcpy(pq->a.p, lut, lut_bytes, hipMemcpyHostToDevice));
+    MSE_HIP_TRY(hipMemcpy(pq->b.p, codes, n * pq->n_chunks, hipMemcpyHostToDevice));
+    if (launch_pq_adc(pq->a.as<float>(), (int)pq->n_chunks, (int)pq->n_centroids, pq->b.as<uint8_t>(), n, nullptr, n,
+                      nullptr, 0, nullptr, pq->c.as<int64_t>(), device_cu_count(), nullptr)) return -1;
+    MSE_HIP_TRY(hipMemcpy(out, pq->c.p, n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+mse_codes* mse_codes_from_host(const uint8_t* codes, size_t n, size_t code_size, const uint8_t* descriptors,
+                               size_t n_descriptors) {
+    if (code_size == 0) { fail("code_size must be positive"); return nullptr; }
+    mse_codes* c = new (std::nothrow) mse_codes();
+    if (!c) { fail("out of host memory"); return nullptr; }
+    c->n = n; c->code_size = code_size; c->n_desc = descriptors ? n_descriptors : 0;
+    bool ok = hipMalloc((void**)&c->codes, std::max<size_t>(n * code_size, 16)) == hipSuccess;
+    if (ok && n) ok = hipMemcpy(c->codes, codes, n * code_size, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && c->n_desc) {
+        ok = hipMalloc((void**)&c->desc, std::max<size_t>(n * c->n_desc, 16)) == hipSuccess;
+        if (ok && n) ok = hipMemcpy(c->desc, descriptors, n * c->n_desc, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) { mse_codes_free(c); fail("device allocation/copy failed for PQ codes"); return nullptr; }
+    return c;
+}
+void mse_codes_free(mse_codes* c) {
+    if (!c) return;
+    if (c->codes) (void)hipFree(c->codes);
+    if (c->desc) (void)hipFree(c->desc);
+    delete c;
+}
+size_t mse_codes_len(const mse_codes* c) { return c ? c->n : 0; }
+
+int mse_pq_adc_gather(mse_pq* pq, const mse_codes* c, const float* lut, const float* scales, const uint32_t* ids,
+                      size_t n_ids, int64_t* out) {
+    if (!pq || !c) return fail("null quantiser or codes");
+    if (c->code_size != pq->n_chunks) return fail("code size does not match the quantiser");
+    if (n_ids == 0) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    const size_t lut_bytes = pq->n_chunks * pq->n_centroids * 4;
+    const size_t sc_bytes = c->n_desc * 4;
+    if (pq->a.ensure(lut_bytes + 256 + sc_bytes) || pq->b.ensure(n_ids * 4) || pq->c.ensure(n_ids * 8)) return -1;
+    float* scales_dev = nullptr;
+    MSE_HIP_TRY(hipMemcpy(pq->a.p, lut, lut_bytes, hipMemcpyHostToDevice));
+    if (scales && c->n_desc) {
+        scales_dev = reinterpret_cast<float*>(pq->a.as<char>() + ((lut_bytes + 255) & ~(size_t)255));
+        MSE_HIP_TRY(hipMemcpy(scales_dev, scales, sc_bytes, hipMemcpyHostToDevice));
+    }
+    MSE_HIP_TRY(hipMemcpy(pq->b.p, ids, n_ids * 4, hipMemcpyHostToDevice));
+    if (launch_pq_adc(pq->a.as<float>(), (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, pq->b.as<uint32_t>(),
+                      n_ids, scales_dev ? c->desc : nullptr, (int)c->n_desc, scales_dev, pq->c.as<int64_t>(),
+                      device_cu_count(), nullptr)) return -1;
+    MSE_HIP_TRY(hipMemcpy(out, pq->c.p, n_ids * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,
+                     const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
+    if (!pq || !c) return fail("null quantiser or codes");
+    if (c->code_size != pq->n_chunks) return fail("code size does not match the quantiser");
+    if (k == 0) return 0;
+    if (r < k) r = k;
+    if (r > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
+    for (size_t i = 0; i < k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
+    if (c->n == 0) return 0;
+    mse_searcher* s = s_or_null;
+    mse_searcher* tmp = nullptr;
+    if (!s) { tmp = scratch_searcher_new(); if (!tmp) return -1; s = tmp; }
+    if (s->base && s->base->n != c->n) { if (tmp) mse_searcher_free(tmp); return fail("base and codes differ in length"); }
+    std::lock_guard<std::mutex> g(pq->mu);
+    hipStream_t st = s->stream;
+    const size_t d = pq->d;
+    int rc = -1;
+    do {
+        // query (fp32) + scales to the device; LUT built on the device
+        const size_t sc_bytes = c->n_desc * 4;
+        if (pq->a.ensure(d * 4 + 256 + sc_bytes)) break;
+        if (hipMemcpyAsync(pq->a.p, query_f32, d * 4, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
+        float* scales_dev = nullptr;
+        if (scales && c->n_desc) {
+            scales_dev = reinterpret_cast<float*>(pq->a.as<char>() + ((d * 4 + 255) & ~(size_t)255));
+            if (hipMemcpyAsync(scales_dev, scales, sc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
+        }
+        if (build_lut_locked(pq, pq->a.as<float>(), st)) break;
+        // full ADC scan
+        if (s->scores.ensure(c->n * 8)) break;
+        if (launch_pq_adc(pq->c.as<float>(), (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, nullptr, c->n,
+                          scales_dev ? c->desc : nullptr, (int)c->n_desc, scales_dev, s->scores.as<int64_t>(), s->n_cu, st))
+            break;
+        // top-r by approximate score
+        if (s->sel_keys.ensure(r * 8)) break;
+        uint32_t* sel = nullptr;
+        LevelRef l0{KEY_I64, s->scores.p, c->n, 1, c->n, false, 0};
+        if (descend(s, l0, 1, (int)r, &sel, s->sel_keys.p)) break;
+        const uint32_t* final_ids = sel;
+        const int64_t* final_scores = s->sel_keys.as<int64_t>();
+        if (s->base) {
+            // exact re-score: f16(query) . base[id] (+ descriptor bias), query_disk_index.rs:168-170,477
+            const mse_base* b = s->base;
+            if (b->d != d) { fail("base width differs from the quantiser"); break; }
+            if (s->q_stage.ensure(8 * d * 2) || s->cand_scores.ensure(r * 8) || s->misc.ensure(k * 4) ||
+                s->gkeys.ensure(k * 8)) break;
+            if (launch_f32_to_f16(pq->a.as<float>(), d, s->q_stage.as<uint16_t>(), st)) break;
+            if (launch_score_rows(b->dev, b->n, (int)d, s->q_stage.p, false, sel, r, r, s->cand_scores.as<int64_t>(),
+                                  nullptr, st)) break;
+            if (launch_add_descriptor(sel, r, scales_dev ? c->desc : nullptr, (int)c->n_desc, c->n, scales_dev,
+                                      s->cand_scores.as<int64_t>(), st)) break;
+            SelectArgs a{};
+            a.kind = KEY_I64; a.list_ids = sel; a.list_keys = s->cand_scores.p; a.list_stride = r; a.n_list = r;
+            a.k = (int)k; a.out_ids = s->misc.as<uint32_t>(); a.out_keys = s->gkeys.p; a.out_stride = k; a.nq = 1;
+            if (launch_select(a, st)) break;
+            final_ids = s->misc.as<uint32_t>();
+            final_scores = s->gkeys.as<int64_t>();
+        }
+        if (hipMemcpyAsync(ids, final_ids, k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(scores, final_scores, k * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
+        for (size_t i = 0; i < k; i++)
+            if (ids[i] == MSE_ID_NONE) scores[i] = INT64_MIN;
+        rc = 0;
+    } while (0);
+    if (tmp) mse_searcher_free(tmp);
+    return rc;
+}
+
+int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id) {
+    // src/query_disk_index.rs:135-142 (host helper; the device paths fold the same sum into their kernels)
+    int64_t r = 0;
+    for (size_t j = 0; j < n_descriptors; j++)
+        r += scale_dot_result(scales[j] * (float)descriptors[(size_t)id * n_descriptors + j]);
+    return r;
+}
+
+}  // extern "C"

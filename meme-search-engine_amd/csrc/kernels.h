@@ -1,0 +1,89 @@
+// Internal launch interface between the translation units of libmse_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace mse {
+
+constexpr uint32_t ID_NONE = 0xFFFFFFFFu;
+constexpr int TOPK_KMAX = 2048;    // largest k (incl. margin) one selection can return
+constexpr int TOPK_FANOUT = 256;   // children per tournament group
+constexpr int GROUP_ROWS = 32;     // base rows per group maximum written by the MFMA scan
+
+// ---- scan_exact.hip ------------------------------------------------------------------------
+int launch_scan_exact(const uint16_t* base, size_t n_rows, int d, const void* queries_dev, int nq, bool q_is_f32,
+                      int64_t* scores, size_t score_stride, float* fscores, int n_cu, hipStream_t stream);
+int launch_score_rows(const uint16_t* base, size_t n_rows, int d, const void* queries_dev, bool q_is_f32,
+                      const uint32_t* ids_dev, size_t n_pairs, size_t pairs_per_query, int64_t* out, float* fout,
+                      hipStream_t stream);
+
+// ---- gen.hip ---------------------------------------------------------------------------------
+int launch_generate_rows(uint16_t* out, uint32_t seed, uint64_t row0, size_t n_rows, int d, hipStream_t stream);
+// *out_max_norm_bits = max over rows of ||row||_2 (float bits, atomicMax on non-negative floats); zero it first
+int launch_row_norm_max(const uint16_t* base, size_t n_rows, int d, uint32_t* out_max_norm_bits, hipStream_t stream);
+// eps[q] = factor * ||query_q||_2 * max_norm   (queries f16 [nq][d])
+int launch_query_eps(const uint16_t* queries, int nq, int d, const uint32_t* max_norm_bits, float factor, float* eps,
+                     hipStream_t stream);
+
+// ---- topk.hip --------------------------------------------------------------------------------
+enum KeyKind { KEY_I64 = 0, KEY_F32 = 1, KEY_U64 = 2, KEY_U32 = 3 };
+// out[q][g] = max over in[q][g*F .. (g+1)*F) as order-preserving unsigned keys
+// (u64 keys for KEY_I64/KEY_U64 input, u32 keys for KEY_F32/KEY_U32 input).
+int launch_reduce_max(KeyKind kind, const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride,
+                      size_t n_out, int nq, hipStream_t stream);
+struct SelectArgs {
+    KeyKind kind;            // type of `in` / `list_keys`
+    const void* in;          // level array, [nq][in_stride]
+    size_t in_stride, n_in;
+    const uint32_t* parents; // [nq][par_stride] group ids (ID_NONE = empty), or nullptr
+    size_t par_stride, n_par;
+    int fanout;              // children per parent
+    const uint32_t* list_ids;  // explicit candidates [nq][list_stride] (with list_keys), or nullptr
+    const void* list_keys;
+    size_t list_stride, n_list;
+    int k;                   // number to select (<= TOPK_KMAX)
+    uint32_t* out_ids;       // [nq][out_stride], best first, padded with ID_NONE
+    void* out_keys;          // optional: raw keys (same type as `in`) of the selected, [nq][out_stride]
+    size_t out_stride;
+    int nq;
+};
+int launch_select(const SelectArgs& a, hipStream_t stream);
+// same, with element (q, i) of `in` at in[q*in_stride + i*in_estride] (group-major level arrays)
+int launch_select_strided(const SelectArgs& a, size_t in_estride, hipStream_t stream);
+// group-major float level [n_in][nq_pad] -> query-major u32 keys [nq][out_stride]
+int launch_reduce_max_gq(const float* in, int nq_pad, size_t n_in, uint32_t* out, size_t out_stride, size_t n_out,
+                         int nq, hipStream_t stream);
+// ids[q][p*group + r] = parents[q][p]*group + r (ID_NONE if parent empty or row >= n_rows)
+int launch_expand_groups(const uint32_t* parents, size_t par_stride, size_t n_par, int group, size_t n_rows,
+                         uint32_t* ids, size_t ids_stride, int nq, hipStream_t stream);
+// final packaging: out_scores[q][i] = keys (i64) ; out_ids[q][i] = ids + id_offset ; certificate margin
+int launch_finalize(const uint32_t* sel_ids, const int64_t* sel_scores, size_t sel_stride, int k, int nq,
+                    uint64_t id_offset, int64_t* out_scores, uint32_t* out_ids, size_t out_stride,
+                    const float* group_keys, size_t gk_stride, int kg, size_t n_groups, const float* eps,
+                    float* margin, hipStream_t stream);
+
+// ---- pq.hip ----------------------------------------------------------------------------------
+int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream);
+int launch_pq_lut(const float* centroids, int n_centroids, int d, int dpc, const float* t, float* lut,
+                  hipStream_t stream);
+int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t n,
+                       uint8_t* codes, hipStream_t stream);
+int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t* codes, size_t n_codes,
+                  const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, const float* scales, int64_t* out,
+                  int n_cu, hipStream_t stream);
+int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,
+                          const float* scales, int64_t* out, hipStream_t stream);
+int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stream);
+int rank_max_targets();
+int launch_rank(const int64_t* scores, size_t n, const uint32_t* targets, int m, unsigned long long* counts, int n_cu,
+                hipStream_t stream);
+
+// ---- scan_mfma.hip ---------------------------------------------------------------------------
+// group_max[q_pad_index][g] layout: [n_groups][nq_pad] floats (group-major), nq_pad multiple of 32
+int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
+                     void* packed_scratch, float* group_max, int n_cu, hipStream_t stream);
+size_t mfma_packed_bytes(int d);
+int mfma_query_tile();  // queries handled per pass
+
+}  // namespace mse

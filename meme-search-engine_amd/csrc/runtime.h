@@ -1,0 +1,68 @@
+// Host-side objects behind the opaque C handles.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include <mutex>
+#include <vector>
+
+namespace mse {
+
+// growable device buffer (grows by hipMalloc + free; contents are NOT preserved)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    ~DevBuf() { release(); }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+int device_cu_count();
+
+// one level of the selection tournament (topk.hip)
+struct LevelRef {
+    KeyKind kind;
+    const void* ptr;
+    size_t q_stride, e_stride, n;  // element (q, i) lives at ptr[q*q_stride + i*e_stride]
+    bool group_major;              // float [n][nq_pad] as written by the MFMA scan
+    int nq_pad;
+};
+
+}  // namespace mse
+
+struct mse_searcher;
+namespace mse {
+// Tournament descent: ids of the k best level-0 entries per query in *sel_out ([nq][k], best first);
+// their raw keys in keys_out when it is not null.  Uses the searcher's scratch and stream.
+int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_out, void* keys_out);
+// workspace-only searcher (no base vectors): scratch + stream for the PQ scan
+mse_searcher* scratch_searcher_new();
+}  // namespace mse
+
+struct mse_base {
+    const uint16_t* dev = nullptr;
+    size_t n = 0, d = 0;
+    bool owned = false;
+    int n_cu = 256;
+    // max row norm (float bits) for the MFMA certificate, computed on first use
+    mutable std::mutex norm_mu;
+    mutable uint32_t* norm_bits_dev = nullptr;
+    mutable bool norm_ready = false;
+};
+
+struct mse_searcher {
+    const mse_base* base = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    mse::DevBuf q_stage;      // padded queries for one pass
+    mse::DevBuf scores;       // [pass_q][n] i64 / f32 level 0 (exact mode)
+    mse::DevBuf levels[6];    // tournament levels above level 0
+    mse::DevBuf sel_a, sel_b; // selected ids ping-pong
+    mse::DevBuf sel_keys;     // keys of the final selection
+    mse::DevBuf out_scores, out_ids;  // device outputs for the host-pointer API
+    mse::DevBuf gmax;         // MFMA group maxima [n_groups][nq_pad]
+    mse::DevBuf cand_ids, cand_scores, gkeys, eps, margin;
+    mse::DevBuf misc, qpacked;
+    uint32_t last_widened = 0, last_max_groups = 0;
+};

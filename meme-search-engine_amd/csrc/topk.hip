@@ -1,0 +1,369 @@
+// Deterministic top-k selection over score arrays: a tournament of group maxima plus an exact
+// radix select, ordering candidates by (score descending, id ascending).
+//
+// The reference ranks brute-force scores with a full sort (src/query_disk_index.rs:271) and
+// FAISS keeps a heap (src/main.rs:900); both only define "the k largest".  Ties among equal
+// scores are unspecified there (sort_unstable) and fixed here as lower id first.
+//
+// Structure: level 0 is the per-row score array (or per-32-row group maxima from the MFMA scan).
+// `reduce_max` builds levels of 256-way group maxima until a level is small; `select` picks the k
+// best entries of the top level, then of the children of those, and so on down.  The k best rows
+// always lie inside the k best groups of every level (a group ranked ahead of row r's group holds
+// a row ranked ahead of r), so the descent is exact, not heuristic.
+//
+// `select` = one workgroup per query; 96-bit composite key (sortable score, ~id) is unique per
+// candidate, so an MSB-first byte-wise radix select finds the exact k-th composite, and the
+// selected set is {composite >= threshold}.  No data-dependent early exits: cost depends only on
+// the candidate count.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+namespace mse {
+namespace {
+
+__device__ __forceinline__ uint64_t key_of(int64_t v) { return sortable_i64(v); }
+__device__ __forceinline__ uint64_t key_of(uint64_t v) { return v; }
+__device__ __forceinline__ uint32_t key_of(float v) { return sortable_f32_bits(__float_as_uint(v)); }
+__device__ __forceinline__ uint32_t key_of(uint32_t v) { return v; }
+
+template <typename T> struct KeyT;
+template <> struct KeyT<int64_t> { using type = uint64_t; };
+template <> struct KeyT<uint64_t> { using type = uint64_t; };
+template <> struct KeyT<float> { using type = uint32_t; };
+template <> struct KeyT<uint32_t> { using type = uint32_t; };
+
+template <typename K> __device__ __forceinline__ K wave_max(K v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        K other = __shfl_xor(v, o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+// one wave per output group; F must be 256
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_max_kernel(const T* __restrict__ in, size_t in_stride, size_t n_in,
+                                                         typename KeyT<T>::type* __restrict__ out, size_t out_stride,
+                                                         size_t n_out, int nq) {
+    using K = typename KeyT<T>::type;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const size_t total = n_out * (size_t)nq;
+    if (wave >= total) return;
+    const size_t q = wave / n_out, g = wave % n_out;
+    const T* src = in + q * in_stride;
+    K best = 0;
+    const size_t lo = g * TOPK_FANOUT;
+#pragma unroll
+    for (int u = 0; u < TOPK_FANOUT / 64; u++) {
+        const size_t i = lo + (size_t)u * 64 + lane;
+        if (i < n_in) {
+            const K k = key_of(src[i]);
+            best = k > best ? k : best;
+        }
+    }
+    best = wave_max(best);
+    if (lane == 0) out[q * out_stride + g] = best;
+}
+
+// group-major float input [n_in][nq_pad] (as written by the MFMA scan): thread = (query, out group)
+__global__ __launch_bounds__(256) void reduce_max_gq_kernel(const float* __restrict__ in, int nq_pad, size_t n_in,
+                                                            uint32_t* __restrict__ out, size_t out_stride,
+                                                            size_t n_out, int nq) {
+    const int q = blockIdx.y * blockDim.x + threadIdx.x;
+    const size_t g = blockIdx.x;
+    if (q >= nq || g >= n_out) return;
+    const size_t lo = g * TOPK_FANOUT;
+    const size_t hi = lo + TOPK_FANOUT < n_in ? lo + TOPK_FANOUT : n_in;
+    uint32_t best = 0;
+    for (size_t i = lo; i < hi; i++) {
+        const uint32_t k = key_of(in[i * nq_pad + q]);
+        best = k > best ? k : best;
+    }
+    out[(size_t)q * out_stride + g] = best;
+}
+
+struct Composite {
+    uint64_t hi;  // sortable score key (u32 keys occupy the top 32 bits)
+    uint32_t lo;  // ~id, so that a lower id is a larger composite
+};
+__device__ __forceinline__ bool ge(const Composite& a, const Composite& b) {
+    return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo);
+}
+__device__ __forceinline__ bool gt(const Composite& a, const Composite& b) {
+    return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);
+}
+// digit positions 11..4 = bytes of hi (MSB first), 3..0 = bytes of lo
+__device__ __forceinline__ int digit_of(const Composite& c, int pos) {
+    return pos >= 4 ? (int)((c.hi >> (8 * (pos - 4))) & 0xff) : (int)((c.lo >> (8 * pos)) & 0xff);
+}
+__device__ __forceinline__ bool match_above(const Composite& c, const Composite& p, int pos) {
+    // digits strictly above `pos` equal
+    if (pos >= 11) return true;
+    if (pos >= 4) {
+        const int sh = 8 * (pos - 4 + 1);
+        return (c.hi >> sh) == (p.hi >> sh);
+    }
+    if (c.hi != p.hi) return false;
+    if (pos == 3) return true;
+    const int sh = 8 * (pos + 1);
+    return (c.lo >> sh) == (p.lo >> sh);
+}
+
+constexpr int SEL_THREADS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_t in_estride) {
+    using K = typename KeyT<T>::type;
+    constexpr bool K32 = sizeof(K) == 4;
+    __shared__ uint32_t s_parents[TOPK_KMAX];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint64_t s_sel_hi[TOPK_KMAX];
+    __shared__ uint32_t s_sel_lo[TOPK_KMAX];
+    __shared__ uint64_t s_prefix_hi;
+    __shared__ uint32_t s_prefix_lo;
+    __shared__ uint32_t s_need, s_count, s_valid;
+
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T* in = reinterpret_cast<const T*>(a.in) + (size_t)q * a.in_stride;
+    const bool use_list = a.list_ids != nullptr;
+    const bool use_par = !use_list && a.parents != nullptr;
+    const uint32_t* list_ids = use_list ? a.list_ids + (size_t)q * a.list_stride : nullptr;
+    const T* list_keys = use_list ? reinterpret_cast<const T*>(a.list_keys) + (size_t)q * a.list_stride : nullptr;
+    size_t M;
+    if (use_list) M = a.n_list;
+    else if (use_par) M = a.n_par * (size_t)a.fanout;
+    else M = a.n_in;
+
+    if (use_par)
+        for (size_t i = tid; i < a.n_par; i += SEL_THREADS) s_parents[i] = a.parents[(size_t)q * a.par_stride + i];
+    if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_count = 0; s_valid = 0; }
+    __syncthreads();
+
+    auto load = [&](size_t c, Composite& out) -> bool {
+        uint32_t id;
+        K key;
+        if (use_list) {
+            id = list_ids[c];
+            if (id == ID_NONE) return false;
+            key = key_of(list_keys[c]);
+        } else if (use_par) {
+            const uint32_t p = s_parents[c / a.fanout];
+            if (p == ID_NONE) return false;
+            const size_t child = (size_t)p * a.fanout + (c % a.fanout);
+            if (child >= a.n_in) return false;
+            id = (uint32_t)child;
+            key = key_of(in[child * in_estride]);
+        } else {
+            id = (uint32_t)c;
+            key = key_of(in[c * in_estride]);
+        }
+        out.hi = K32 ? ((uint64_t)key << 32) : (uint64_t)key;
+        out.lo = ~id;
+        return true;
+    };
+
+    // count valid candidates
+    {
+        uint32_t local = 0;
+        Composite c;
+        for (size_t i = tid; i < M; i += SEL_THREADS) local += load(i, c) ? 1u : 0u;
+        if (local) atomicAdd(&s_valid, local);
+    }
+    __syncthreads();
+    const uint32_t n_valid = s_valid;
+    const uint32_t k_eff = n_valid < (uint32_t)a.k ? n_valid : (uint32_t)a.k;
+    const bool take_all = n_valid <= (uint32_t)a.k;
+    if (tid == 0) s_need = k_eff;
+    __syncthreads();
+
+    if (!take_all) {
+        for (int pos = 11; pos >= 0; pos--) {
+            if (K32 && pos >= 4 && pos < 8) continue;  // low half of `hi` is zero for 32-bit keys
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            const Composite prefix{s_prefix_hi, s_prefix_lo};
+            Composite c;
+            for (size_t i = tid; i < M; i += SEL_THREADS)
+                if (load(i, c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t need = s_need, cum = 0;
+                int b = 255;
+                for (; b > 0; b--) {
+                    if (cum + s_hist[b] >= need) break;
+                    cum += s_hist[b];
+                }
+                s_need = need - cum;
+                if (pos >= 4) s_prefix_hi |= (uint64_t)b << (8 * (pos - 4));
+                else s_prefix_lo |= (uint32_t)b << (8 * pos);
+            }
+            __syncthreads();
+        }
+    }
+    const Composite thr{take_all ? 0ull : s_prefix_hi, take_all ? 0u : s_prefix_lo};
+    {
+        Composite c;
+        for (size_t i = tid; i < M; i += SEL_THREADS)
+            if (load(i, c) && ge(c, thr)) {
+                const uint32_t p = atomicAdd(&s_count, 1u);
+                if (p < (uint32_t)TOPK_KMAX) { s_sel_hi[p] = c.hi; s_sel_lo[p] = c.lo; }
+            }
+    }
+    __syncthreads();
+    const uint32_t n_sel = s_count < (uint32_t)a.k ? s_count : (uint32_t)a.k;
+    uint32_t* out_ids = a.out_ids + (size_t)q * a.out_stride;
+    T* out_keys = a.out_keys ? reinterpret_cast<T*>(a.out_keys) + (size_t)q * a.out_stride : nullptr;
+    // rank sort (composites are unique)
+    for (uint32_t i = tid; i < n_sel; i += SEL_THREADS) {
+        const Composite me{s_sel_hi[i], s_sel_lo[i]};
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n_sel; j++) rank += gt(Composite{s_sel_hi[j], s_sel_lo[j]}, me) ? 1u : 0u;
+        out_ids[rank] = ~me.lo;
+        if (out_keys) {
+            if constexpr (sizeof(T) == 8) {
+                if constexpr (std::is_same<T, int64_t>::value) out_keys[rank] = unsortable_i64(me.hi);
+                else out_keys[rank] = (T)me.hi;
+            } else {
+                const uint32_t k32 = (uint32_t)(me.hi >> 32);
+                if constexpr (std::is_same<T, float>::value) out_keys[rank] = __uint_as_float(unsortable_f32_bits(k32));
+                else out_keys[rank] = (T)k32;
+            }
+        }
+    }
+    for (uint32_t i = n_sel + tid; i < (uint32_t)a.k; i += SEL_THREADS) {
+        out_ids[i] = ID_NONE;
+        if (out_keys) {
+            if constexpr (std::is_same<T, int64_t>::value) out_keys[i] = INT64_MIN;
+            else if constexpr (std::is_same<T, float>::value) out_keys[i] = -__builtin_inff();
+            else out_keys[i] = 0;
+        }
+    }
+}
+
+__global__ void expand_groups_kernel(const uint32_t* __restrict__ parents, size_t par_stride, size_t n_par, int group,
+                                     size_t n_rows, uint32_t* __restrict__ ids, size_t ids_stride, int nq) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_q = n_par * (size_t)group;
+    if (i >= per_q * (size_t)nq) return;
+    const size_t q = i / per_q, r = i % per_q;
+    const uint32_t p = parents[q * par_stride + r / group];
+    uint32_t id = ID_NONE;
+    if (p != ID_NONE) {
+        const size_t row = (size_t)p * group + (r % group);
+        if (row < n_rows) id = (uint32_t)row;
+    }
+    ids[q * ids_stride + r] = id;
+}
+
+__global__ void finalize_kernel(const uint32_t* __restrict__ sel_ids, const int64_t* __restrict__ sel_scores,
+                                size_t sel_stride, int k, int nq, uint64_t id_offset, int64_t* __restrict__ out_scores,
+                                uint32_t* __restrict__ out_ids, size_t out_stride, const float* __restrict__ group_keys,
+                                size_t gk_stride, int kg, size_t n_groups, const float* __restrict__ eps,
+                                float* __restrict__ margin) {
+    const int q = blockIdx.x;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint32_t id = sel_ids[(size_t)q * sel_stride + i];
+        out_ids[(size_t)q * out_stride + i] = id == ID_NONE ? ID_NONE : (uint32_t)(id + id_offset);
+        out_scores[(size_t)q * out_stride + i] = id == ID_NONE ? INT64_MIN : sel_scores[(size_t)q * sel_stride + i];
+    }
+    if (threadIdx.x == 0 && margin) {
+        // Certificate for the approximate (MFMA) candidate stage: every row outside the kg selected
+        // groups has approximate score <= g = key of the worst selected group; its exact score is
+        // <= g + eps.  If the exact k-th best score exceeds that, no excluded row can enter the top k.
+        float m;
+        if ((size_t)kg >= n_groups) {
+            m = __builtin_inff();  // every group was re-scored exactly
+        } else {
+            const float g = group_keys[(size_t)q * gk_stride + (kg - 1)];
+            const uint32_t idk = sel_ids[(size_t)q * sel_stride + (k - 1)];
+            if (idk == ID_NONE) {
+                m = -__builtin_inff();
+            } else {
+                const float sk = (float)((double)sel_scores[(size_t)q * sel_stride + (k - 1)] / 4294967296.0);
+                m = sk - (g + eps[q]);
+            }
+        }
+        margin[q] = m;
+    }
+}
+
+template <typename T>
+int launch_reduce_t(const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride, size_t n_out, int nq,
+                    hipStream_t stream) {
+    const size_t waves = n_out * (size_t)nq;
+    const size_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffull) return fail("reduce_max: grid too large");
+    hipLaunchKernelGGL(reduce_max_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const T*>(in), in_stride, n_in,
+                       reinterpret_cast<typename KeyT<T>::type*>(out), out_stride, n_out, nq);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int launch_reduce_max(KeyKind kind, const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride,
+                      size_t n_out, int nq, hipStream_t stream) {
+    if (n_out == 0 || nq == 0) return 0;
+    switch (kind) {
+        case KEY_I64: return launch_reduce_t<int64_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
+        case KEY_U64: return launch_reduce_t<uint64_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
+        case KEY_F32: return launch_reduce_t<float>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
+        case KEY_U32: return launch_reduce_t<uint32_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
+    }
+    return fail("reduce_max: bad key kind");
+}
+
+int launch_reduce_max_gq(const float* in, int nq_pad, size_t n_in, uint32_t* out, size_t out_stride, size_t n_out,
+                         int nq, hipStream_t stream) {
+    if (n_out == 0 || nq == 0) return 0;
+    if (n_out > 0x7fffffffull) return fail("reduce_max_gq: grid too large");
+    const int threads = 64;
+    hipLaunchKernelGGL(reduce_max_gq_kernel, dim3((unsigned)n_out, (unsigned)((nq + threads - 1) / threads)),
+                       dim3(threads), 0, stream, in, nq_pad, n_in, out, out_stride, n_out, nq);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_select_strided(const SelectArgs& a, size_t in_estride, hipStream_t stream) {
+    if (a.nq == 0 || a.k == 0) return 0;
+    if (a.k > TOPK_KMAX) return fail("select: k exceeds TOPK_KMAX");
+    if (a.parents && a.n_par > (size_t)TOPK_KMAX) return fail("select: too many parents");
+    switch (a.kind) {
+        case KEY_I64: hipLaunchKernelGGL(select_kernel<int64_t>, dim3(a.nq), dim3(SEL_THREADS), 0, stream, a, in_estride); break;
+        case KEY_U64: hipLaunchKernelGGL(select_kernel<uint64_t>, dim3(a.nq), dim3(SEL_THREADS), 0, stream, a, in_estride); break;
+        case KEY_F32: hipLaunchKernelGGL(select_kernel<float>, dim3(a.nq), dim3(SEL_THREADS), 0, stream, a, in_estride); break;
+        case KEY_U32: hipLaunchKernelGGL(select_kernel<uint32_t>, dim3(a.nq), dim3(SEL_THREADS), 0, stream, a, in_estride); break;
+    }
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_select(const SelectArgs& a, hipStream_t stream) { return launch_select_strided(a, 1, stream); }
+
+int launch_expand_groups(const uint32_t* parents, size_t par_stride, size_t n_par, int group, size_t n_rows,
+                         uint32_t* ids, size_t ids_stride, int nq, hipStream_t stream) {
+    const size_t total = n_par * (size_t)group * (size_t)nq;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(expand_groups_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, parents,
+                       par_stride, n_par, group, n_rows, ids, ids_stride, nq);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_finalize(const uint32_t* sel_ids, const int64_t* sel_scores, size_t sel_stride, int k, int nq,
+                    uint64_t id_offset, int64_t* out_scores, uint32_t* out_ids, size_t out_stride,
+                    const float* group_keys, size_t gk_stride, int kg, size_t n_groups, const float* eps,
+                    float* margin, hipStream_t stream) {
+    if (nq == 0 || k == 0) return 0;
+    hipLaunchKernelGGL(finalize_kernel, dim3(nq), dim3(256), 0, stream, sel_ids, sel_scores, sel_stride, k, nq,
+                       id_offset, out_scores, out_ids, out_stride, group_keys, gk_stride, kg, n_groups, eps, margin);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mse

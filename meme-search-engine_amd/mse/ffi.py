@@ -1,0 +1,116 @@
+"""ctypes binding of libmse_hip.so (include/mse.h).
+
+This is the only way the Python host layer reaches the device: every compute entry point
+below calls the C ABI.  There is NO CPU fallback -- if the shared library is missing or a call
+fails, an exception is raised (MseError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmse_hip.so")
+
+
+class MseError(RuntimeError):
+    pass
+
+
+_lib = None
+
+u8p, u16p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)
+f32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int64)
+sz, vp = C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/mse.h
+SIGNATURES = {
+    "mse_last_error": (C.c_char_p, []),
+    "mse_device_count": (C.c_int, []),
+    "mse_set_device": (C.c_int, [C.c_int]),
+    "mse_device_synchronize": (C.c_int, []),
+    "mse_device_mem_info": (C.c_int, [C.POINTER(sz), C.POINTER(sz)]),
+    "mse_version": (C.c_char_p, []),
+    "mse_scale_dot_f32": (C.c_int64, [C.c_float]),
+    "mse_scale_dot_f64": (C.c_int64, [C.c_double]),
+    "mse_base_from_host": (vp, [u16p, sz, sz]),
+    "mse_base_wrap_device": (vp, [vp, sz, sz]),
+    "mse_base_generate": (vp, [C.c_uint32, C.c_uint64, sz, sz]),
+    "mse_base_free": (None, [vp]),
+    "mse_base_len": (sz, [vp]),
+    "mse_base_dim": (sz, [vp]),
+    "mse_base_device_ptr": (vp, [vp]),
+    "mse_base_read_rows": (C.c_int, [vp, sz, sz, u16p]),
+    "mse_fast_dot_f16": (C.c_int, [u16p, u16p, sz, i64p]),
+    "mse_searcher_new": (vp, [vp]),
+    "mse_searcher_free": (None, [vp]),
+    "mse_searcher_set_stream": (C.c_int, [vp, vp]),
+    "mse_searcher_stream": (vp, [vp]),
+    "mse_bruteforce_topk_f16": (C.c_int, [vp, u16p, sz, sz, C.c_int, i64p, u32p]),
+    "mse_bruteforce_topk_f16_dev": (C.c_int, [vp, vp, sz, sz, C.c_int, C.c_uint64, vp, vp]),
+    "mse_bruteforce_scores_f16": (C.c_int, [vp, u16p, i64p]),
+    "mse_bruteforce_ranks_f16": (C.c_int, [vp, u16p, u32p, sz, u32p]),
+    "mse_score_rows_f16": (C.c_int, [vp, u32p, sz, u16p, i64p]),
+    "mse_searcher_last_stats": (C.c_int, [vp, u32p, u32p]),
+    "mse_index_new": (vp, [C.c_int]),
+    "mse_index_free": (None, [vp]),
+    "mse_index_add": (C.c_int, [vp, f32p, sz]),
+    "mse_index_ntotal": (sz, [vp]),
+    "mse_index_search": (C.c_int, [vp, f32p, sz, sz, f32p, i64p]),
+    "mse_pq_load": (vp, [f32p, sz, f32p, sz, sz]),
+    "mse_pq_free": (None, [vp]),
+    "mse_pq_apply_transform": (C.c_int, [vp, f32p, sz, f32p]),
+    "mse_pq_quantize_batch": (C.c_int, [vp, f32p, sz, u8p]),
+    "mse_pq_preprocess_query": (C.c_int, [vp, f32p, f32p]),
+    "mse_pq_adc": (C.c_int, [vp, f32p, u8p, sz, i64p]),
+    "mse_codes_from_host": (vp, [u8p, sz, sz, u8p, sz]),
+    "mse_codes_free": (None, [vp]),
+    "mse_codes_len": (sz, [vp]),
+    "mse_pq_adc_gather": (C.c_int, [vp, vp, f32p, f32p, u32p, sz, i64p]),
+    "mse_pq_scan_topk": (C.c_int, [vp, vp, vp, f32p, f32p, sz, sz, i64p, u32p]),
+    "mse_descriptor_product": (C.c_int64, [f32p, sz, u8p, C.c_uint32]),
+    "mse_nb_new": (vp, [sz]),
+    "mse_nb_free": (None, [vp]),
+    "mse_nb_clear": (None, [vp]),
+    "mse_nb_len": (sz, [vp]),
+    "mse_nb_cap": (sz, [vp]),
+    "mse_nb_insert": (None, [vp, C.c_uint32, C.c_int64]),
+    "mse_nb_next_unvisited": (C.c_int, [vp, u32p]),
+    "mse_nb_ids": (u32p, [vp]),
+    "mse_nb_scores": (i64p, [vp]),
+    "mse_greedy_search": (C.c_int, [vp, u32p, u32p, sz, C.c_uint32, u16p, C.c_int, C.c_uint32, vp, C.POINTER(sz)]),
+}
+
+
+def lib():
+    """Load libmse_hip.so; raises MseError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MseError(
+                f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                "(make -C meme-search-engine_amd/csrc).  There is no CPU fallback.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the machine
+            raise MseError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    msg = lib().mse_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what="call"):
+    if rc != 0:
+        raise MseError(f"{what} failed: {last_error()}")
+
+
+def check_ptr(p, what="call"):
+    if not p:
+        raise MseError(f"{what} failed: {last_error()}")
+    return p

@@ -1,0 +1,176 @@
+"""Host mirror of `diskann::vector` (reference: diskann/src/vector.rs) over the C ABI.
+
+Names, argument meaning and error behaviour follow the Rust module so that tests read like
+tests of the reference.  f16 vectors are numpy uint16 arrays of IEEE binary16 bit patterns
+(np.float16 arrays are accepted and viewed as bits).  All arithmetic happens on the device.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+from .ffi import MseError, check, check_ptr
+
+SCALE = 4294967296.0  # vector.rs:46
+ID_NONE = 0xFFFFFFFF
+
+MODE_AUTO, MODE_EXACT, MODE_MFMA = 0, 1, 2
+
+
+def _bits(a):
+    a = np.asarray(a)
+    if a.dtype == np.float16:
+        a = a.view(np.uint16)
+    if a.dtype != np.uint16:
+        raise TypeError("f16 vectors must be np.float16 or np.uint16 bit patterns")
+    return np.ascontiguousarray(a)
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def scale_dot_result(x):
+    """vector.rs:408-411"""
+    return int(ffi.lib().mse_scale_dot_f32(float(x)))
+
+
+def scale_dot_result_f64(x):
+    """vector.rs:413-416"""
+    return int(ffi.lib().mse_scale_dot_f64(float(x)))
+
+
+def fast_dot_noprefetch(x, y):
+    """vector.rs:255-306.  len % 64 == 0 is required (debug_assert at :259)."""
+    x, y = _bits(x).reshape(-1), _bits(y).reshape(-1)
+    if x.size != y.size:
+        raise MseError("fast_dot: length mismatch")
+    out = C.c_int64()
+    check(ffi.lib().mse_fast_dot_f16(_p(x, C.c_uint16), _p(y, C.c_uint16), x.size, C.byref(out)), "fast_dot")
+    return int(out.value)
+
+
+def fast_dot(x, y, prefetch=None):
+    """vector.rs:192-252: same arithmetic; the third vector is only prefetched."""
+    return fast_dot_noprefetch(x, y)
+
+
+class VectorList:
+    """vector.rs:118-186: row-major contiguous f16 rows, here resident in HBM."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keep = keepalive
+
+    @classmethod
+    def from_f16s(cls, f16s, d):
+        a = _bits(f16s).reshape(-1)
+        if a.size % d != 0:
+            raise MseError("from_f16s: data length is not a multiple of d")  # assert at vector.rs:174
+        n = a.size // d
+        return cls(check_ptr(ffi.lib().mse_base_from_host(_p(a, C.c_uint16), n, d), "mse_base_from_host"))
+
+    @classmethod
+    def generate(cls, seed, first_row, n_rows, d=1152):
+        """Synthetic unit-norm rows made on the device (bit-identical to oracle.gen_rows_f16)."""
+        return cls(check_ptr(ffi.lib().mse_base_generate(seed, first_row, n_rows, d), "mse_base_generate"))
+
+    @classmethod
+    def wrap_device(cls, dev_ptr, n_rows, d, keepalive=None):
+        return cls(check_ptr(ffi.lib().mse_base_wrap_device(dev_ptr, n_rows, d), "mse_base_wrap_device"), keepalive)
+
+    def __len__(self):
+        return int(ffi.lib().mse_base_len(self._h))
+
+    @property
+    def d_emb(self):
+        return int(ffi.lib().mse_base_dim(self._h))
+
+    @property
+    def device_ptr(self):
+        return ffi.lib().mse_base_device_ptr(self._h)
+
+    def rows(self, first, n):
+        out = np.empty((n, self.d_emb), np.uint16)
+        check(ffi.lib().mse_base_read_rows(self._h, first, n, _p(out, C.c_uint16)), "mse_base_read_rows")
+        return out
+
+    def __getitem__(self, i):
+        return self.rows(i, 1)[0]
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_base_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Searcher:
+    """Per-thread scratch + stream (reference `Scratch`: lib.rs:157-175, query_disk_index.rs:116-123)."""
+
+    def __init__(self, vecs: VectorList):
+        self.vecs = vecs
+        self._h = check_ptr(ffi.lib().mse_searcher_new(vecs._h), "mse_searcher_new")
+
+    def set_stream(self, hip_stream):
+        check(ffi.lib().mse_searcher_set_stream(self._h, hip_stream), "set_stream")
+
+    def bruteforce_topk(self, queries, k, mode=MODE_AUTO):
+        """Brute-force scan + ranking of `evaluate` (query_disk_index.rs:262-273) for a query batch.
+        Returns (scores int64 [nq,k], ids uint32 [nq,k])."""
+        d = self.vecs.d_emb
+        q = _bits(queries).reshape(-1, d)
+        nq = q.shape[0]
+        scores = np.empty((nq, k), np.int64)
+        ids = np.empty((nq, k), np.uint32)
+        check(ffi.lib().mse_bruteforce_topk_f16(self._h, _p(q, C.c_uint16), nq, k, mode, _p(scores, C.c_int64),
+                                                _p(ids, C.c_uint32)), "bruteforce_topk")
+        return scores, ids
+
+    def bruteforce_topk_dev(self, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO, id_offset=0):
+        check(ffi.lib().mse_bruteforce_topk_f16_dev(self._h, queries_dev, nq, k, mode, id_offset, scores_dev, ids_dev),
+              "bruteforce_topk_dev")
+
+    def scores(self, query):
+        q = _bits(query).reshape(-1)
+        out = np.empty(len(self.vecs), np.int64)
+        check(ffi.lib().mse_bruteforce_scores_f16(self._h, _p(q, C.c_uint16), _p(out, C.c_int64)), "bruteforce_scores")
+        return out
+
+    def ranks(self, query, ids):
+        q = _bits(query).reshape(-1)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.empty(ids.size, np.uint32)
+        check(ffi.lib().mse_bruteforce_ranks_f16(self._h, _p(q, C.c_uint16), _p(ids, C.c_uint32), ids.size,
+                                                 _p(out, C.c_uint32)), "bruteforce_ranks")
+        return out
+
+    def score_rows(self, ids, query):
+        """out[i] = fast_dot(query, vecs[ids[i]]) (lib.rs:201-207, query_disk_index.rs:168-169)."""
+        q = _bits(query).reshape(-1)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.empty(ids.size, np.int64)
+        check(ffi.lib().mse_score_rows_f16(self._h, _p(ids, C.c_uint32), ids.size, _p(q, C.c_uint16), _p(out, C.c_int64)),
+              "score_rows")
+        return out
+
+    def last_stats(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(ffi.lib().mse_searcher_last_stats(self._h, C.byref(a), C.byref(b)), "last_stats")
+        return {"widened_queries": int(a.value), "max_groups": int(b.value)}
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_searcher_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
