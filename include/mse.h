@@ -94,6 +94,14 @@ int mse_bruteforce_ranks_f16(mse_searcher* s, const uint16_t* query, const uint3
  * search (diskann/src/lib.rs:201-207) and the fetched-node re-score (query_disk_index.rs:168-169).
  * ids >= n_rows give INT64_MIN. */
 int mse_score_rows_f16(mse_searcher* s, const uint32_t* ids, size_t n_ids, const uint16_t* query, int64_t* out);
+/* k-way merge of per-shard results after the all-gather (multi-GPU, one process per GPU):
+ * gathered_* are device arrays laid out [n_shards][nq][k] (what ncclAllGather produces from each
+ * rank's [nq][k]); out_* are device [nq][k].  Asynchronous on the searcher's stream. */
+int mse_merge_topk_dev(mse_searcher* s, const void* gathered_scores_dev, const void* gathered_ids_dev,
+                       size_t n_shards, size_t nq, size_t k, void* out_scores_dev, void* out_ids_dev);
+/* HIP-event timing of the scan kernel (the HBM-bound kernel) on the searcher's stream: returns the
+ * totals accumulated so far, then sets the mode: enable 0 = off, 1 = on, 2 = on and reset totals. */
+int mse_searcher_scan_timing(mse_searcher* s, int enable, double* total_ms, uint64_t* launches);
 /* statistics of the last MFMA-mode call: number of queries whose certificate needed a wider
  * candidate set, and the widest group count used. */
 int mse_searcher_last_stats(const mse_searcher* s, uint32_t* n_widened, uint32_t* max_groups);

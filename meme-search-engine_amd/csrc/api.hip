@@ -139,7 +139,8 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
     if (s->gmax.ensure(n_groups * (size_t)nq_pad * 4)) return -1;
     if (s->qpacked.ensure(mfma_packed_bytes(d))) return -1;
     if (launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>(), nq_pad, s->qpacked.p, s->gmax.as<float>(), s->n_cu,
-                         st)) return -1;
+                         st, s->timing ? s->ev0 : nullptr, s->timing ? s->ev1 : nullptr)) return -1;
+    bool timing_pending = s->timing;
     if (s->eps.ensure((size_t)nq_pass * 4) || s->margin.ensure((size_t)nq_pass * 4)) return -1;
     // |mfma score - exact-order score| <= 2 * gamma_1151 * sum|x_i q_i| <= 1.4e-4 * |x||q|; doubled again
     // because the matrix core's internal rounding is not documented.
@@ -174,6 +175,11 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
                             s->margin.as<float>(), st)) return -1;
         MSE_HIP_TRY(hipMemcpyAsync(margin_h.data(), s->margin.p, (size_t)nq_pass * 4, hipMemcpyDeviceToHost, st));
         MSE_HIP_TRY(hipStreamSynchronize(st));
+        if (timing_pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) { s->scan_ms_total += ms; s->scan_launches++; }
+            timing_pending = false;
+        }
         uint32_t bad = 0;
         for (int i = 0; i < nq_pass; i++) bad += !(margin_h[i] > 0.0f);
         s->last_max_groups = std::max<uint32_t>(s->last_max_groups, (uint32_t)kg_eff);
@@ -323,6 +329,8 @@ mse_searcher* mse_searcher_new(const mse_base* b) {
 void mse_searcher_free(mse_searcher* s) {
     if (!s) return;
     if (s->own_stream && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
 }
 int mse_searcher_set_stream(mse_searcher* s, void* hip_stream) {
@@ -333,6 +341,18 @@ int mse_searcher_set_stream(mse_searcher* s, void* hip_stream) {
     return 0;
 }
 void* mse_searcher_stream(const mse_searcher* s) { return s ? (void*)s->stream : nullptr; }
+int mse_searcher_scan_timing(mse_searcher* s, int enable, double* total_ms, uint64_t* launches) {
+    if (!s) return fail("null searcher");
+    if (total_ms) *total_ms = s->scan_ms_total;
+    if (launches) *launches = s->scan_launches;
+    if (enable && !s->ev0) {
+        MSE_HIP_TRY(hipEventCreate(&s->ev0));
+        MSE_HIP_TRY(hipEventCreate(&s->ev1));
+    }
+    if (enable == 2) { s->scan_ms_total = 0.0; s->scan_launches = 0; }
+    s->timing = enable != 0;
+    return 0;
+}
 int mse_searcher_last_stats(const mse_searcher* s, uint32_t* n_widened, uint32_t* max_groups) {
     if (!s) return fail("null searcher");
     if (n_widened) *n_widened = s->last_widened;
@@ -397,6 +417,27 @@ int mse_bruteforce_topk_f16(mse_searcher* s, const uint16_t* queries, size_t nq,
     MSE_HIP_TRY(hipMemcpyAsync(ids, s->out_ids.p, nq * k * 4, hipMemcpyDeviceToHost, s->stream));
     MSE_HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
+}
+
+int mse_merge_topk_dev(mse_searcher* s, const void* gathered_scores_dev, const void* gathered_ids_dev,
+                       size_t n_shards, size_t nq, size_t k, void* out_scores_dev, void* out_ids_dev) {
+    if (!s) return fail("null searcher");
+    if (nq == 0 || k == 0 || n_shards == 0) return 0;
+    if (k > (size_t)TOPK_KMAX) return fail("k too large");
+    if (s->misc.ensure(nq * k * 4) || s->sel_keys.ensure(nq * k * 8)) return -1;
+    SelectArgs a{};
+    a.kind = KEY_I64;
+    a.list_ids = reinterpret_cast<const uint32_t*>(gathered_ids_dev);
+    a.list_keys = gathered_scores_dev;
+    a.list_stride = k;                 // query q starts k records into each shard block
+    a.list_chunk = k;
+    a.list_chunk_stride = nq * k;      // next shard
+    a.n_list = n_shards * k;
+    a.k = (int)k; a.out_ids = s->misc.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = k; a.nq = (int)nq;
+    if (launch_select(a, s->stream)) return -1;
+    return launch_finalize(s->misc.as<uint32_t>(), s->sel_keys.as<int64_t>(), k, (int)k, (int)nq, 0,
+                           reinterpret_cast<int64_t*>(out_scores_dev), reinterpret_cast<uint32_t*>(out_ids_dev), k,
+                           nullptr, 0, 0, 0, nullptr, nullptr, s->stream);
 }
 
 int mse_bruteforce_scores_f16(mse_searcher* s, const uint16_t* query, int64_t* scores) {

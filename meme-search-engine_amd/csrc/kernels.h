@@ -42,6 +42,7 @@ struct SelectArgs {
     const uint32_t* list_ids;  // explicit candidates [nq][list_stride] (with list_keys), or nullptr
     const void* list_keys;
     size_t list_stride, n_list;
+    size_t list_chunk = 0, list_chunk_stride = 0;  // if list_chunk != 0: candidate c lives at (c / chunk) * chunk_stride + c % chunk
     int k;                   // number to select (<= TOPK_KMAX)
     uint32_t* out_ids;       // [nq][out_stride], best first, padded with ID_NONE
     void* out_keys;          // optional: raw keys (same type as `in`) of the selected, [nq][out_stride]
@@ -82,7 +83,8 @@ int launch_rank(const int64_t* scores, size_t n, const uint32_t* targets, int m,
 // ---- scan_mfma.hip ---------------------------------------------------------------------------
 // group_max[q_pad_index][g] layout: [n_groups][nq_pad] floats (group-major), nq_pad multiple of 32
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
-                     void* packed_scratch, float* group_max, int n_cu, hipStream_t stream);
+                     void* packed_scratch, float* group_max, int n_cu, hipStream_t stream,
+                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);  // events bracket the scan kernel only
 size_t mfma_packed_bytes(int d);
 int mfma_query_tile();  // queries handled per pass
 

@@ -65,4 +65,9 @@ struct mse_searcher {
     mse::DevBuf cand_ids, cand_scores, gkeys, eps, margin;
     mse::DevBuf misc, qpacked;
     uint32_t last_widened = 0, last_max_groups = 0;
+    // optional HIP-event timing of the dominant (scan) kernel, for bench.py's roofline line
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double scan_ms_total = 0.0;
+    uint64_t scan_launches = 0;
 };

@@ -148,18 +148,21 @@ size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * QT_SLOTS * sizeof(ui
 
 // packed_scratch: mfma_packed_bytes(d) bytes of device scratch owned by the caller (per searcher)
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
-                     void* packed_scratch, float* group_max, int n_cu, hipStream_t stream) {
+                     void* packed_scratch, float* group_max, int n_cu, hipStream_t stream, hipEvent_t ev_begin,
+                     hipEvent_t ev_end) {
     if (n_rows == 0) return 0;
     if (d % 64 != 0 || d <= 0 || d > D_MAX) return fail("vector width must be a positive multiple of 64");
     if (nq_pad != BN) return fail("scan_mfma: query tile must be padded to 128");
     uint4* packed = reinterpret_cast<uint4*>(packed_scratch);
     hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, packed);
+    if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
     const size_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     size_t grid = (size_t)n_cu * 2;
     if (grid > n_tiles) grid = n_tiles;
     hipLaunchKernelGGL(scan_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, base, n_rows, d, packed, group_max,
                        nq_pad, n_tiles);
     MSE_HIP_TRY(hipGetLastError());
+    if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));
     return 0;
 }
 

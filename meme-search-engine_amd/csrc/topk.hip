@@ -147,9 +147,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
         uint32_t id;
         K key;
         if (use_list) {
-            id = list_ids[c];
+            const size_t ci = a.list_chunk ? (c / a.list_chunk) * a.list_chunk_stride + (c % a.list_chunk) : c;
+            id = list_ids[ci];
             if (id == ID_NONE) return false;
-            key = key_of(list_keys[c]);
+            key = key_of(list_keys[ci]);
         } else if (use_par) {
             const uint32_t p = s_parents[c / a.fanout];
             if (p == ID_NONE) return false;

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mse_bruteforce_scores_f16": (C.c_int, [vp, u16p, i64p]),
     "mse_bruteforce_ranks_f16": (C.c_int, [vp, u16p, u32p, sz, u32p]),
     "mse_score_rows_f16": (C.c_int, [vp, u32p, sz, u16p, i64p]),
+    "mse_merge_topk_dev": (C.c_int, [vp, vp, vp, sz, sz, sz, vp, vp]),
+    "mse_searcher_scan_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mse_searcher_last_stats": (C.c_int, [vp, u32p, u32p]),
     "mse_index_new": (vp, [C.c_int]),
     "mse_index_free": (None, [vp]),

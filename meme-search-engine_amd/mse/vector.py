@@ -136,6 +136,11 @@ class Searcher:
         check(ffi.lib().mse_bruteforce_topk_f16_dev(self._h, queries_dev, nq, k, mode, id_offset, scores_dev, ids_dev),
               "bruteforce_topk_dev")
 
+    def merge_topk_dev(self, gathered_scores_dev, gathered_ids_dev, n_shards, nq, k, out_scores_dev, out_ids_dev):
+        """k-way merge of all-gathered [n_shards][nq][k] shard results (device pointers)."""
+        check(ffi.lib().mse_merge_topk_dev(self._h, gathered_scores_dev, gathered_ids_dev, n_shards, nq, k,
+                                           out_scores_dev, out_ids_dev), "merge_topk_dev")
+
     def scores(self, query):
         q = _bits(query).reshape(-1)
         out = np.empty(len(self.vecs), np.int64)
@@ -159,6 +164,13 @@ class Searcher:
               "score_rows")
         return out
 
+    def scan_timing(self, enable):
+        """HIP-event totals of the scan kernel so far -> (total_ms, launches); then set mode
+        (0 off, 1 on, 2 on + reset)."""
+        ms, n = C.c_double(), C.c_uint64()
+        check(ffi.lib().mse_searcher_scan_timing(self._h, enable, C.byref(ms), C.byref(n)), "scan_timing")
+        return float(ms.value), int(n.value)
+
     def last_stats(self):
         a, b = C.c_uint32(), C.c_uint32()
         check(ffi.lib().mse_searcher_last_stats(self._h, C.byref(a), C.byref(b)), "last_stats")
@@ -174,3 +186,129 @@ class Searcher:
             self.close()
         except Exception:
             pass
+
+
+class QueryLUT:
+    """vector.rs:316-317: chunk-major table [n_chunks][n_centroids] of f32."""
+
+    def __init__(self, table):
+        self.table = np.ascontiguousarray(table, np.float32)
+
+
+class ProductQuantizer:
+    """vector.rs:308-406.  Fields as serialised in opq.msgpack (diskann/aopq_train.py:87-93)."""
+
+    def __init__(self, centroids, transform, n_dims_per_code, n_dims):
+        centroids = np.ascontiguousarray(centroids, np.float32).reshape(-1)
+        transform = np.ascontiguousarray(transform, np.float32).reshape(-1)
+        if transform.size != n_dims * n_dims:
+            raise MseError("transform must be n_dims x n_dims")  # assert_eq at vector.rs:334
+        if centroids.size % n_dims != 0:
+            raise MseError("centroids must be rows of n_dims")
+        self.n_dims, self.n_dims_per_code = n_dims, n_dims_per_code
+        self.n_centroids = centroids.size // n_dims
+        self.n_chunks = n_dims // n_dims_per_code
+        self._h = check_ptr(ffi.lib().mse_pq_load(_p(centroids, C.c_float), self.n_centroids, _p(transform, C.c_float),
+                                                  n_dims, n_dims_per_code), "mse_pq_load")
+
+    @classmethod
+    def from_msgpack(cls, blob):
+        import msgpack
+        m = msgpack.unpackb(blob, raw=False)
+        return cls(m["centroids"], m["transform"], m["n_dims_per_code"], m["n_dims"])
+
+    def apply_transform(self, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.n_dims)
+        out = np.empty_like(x)
+        check(ffi.lib().mse_pq_apply_transform(self._h, _p(x, C.c_float), x.shape[0], _p(out, C.c_float)),
+              "apply_transform")
+        return out
+
+    def quantize_batch(self, x):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.n_dims)
+        codes = np.empty((x.shape[0], self.n_chunks), np.uint8)
+        check(ffi.lib().mse_pq_quantize_batch(self._h, _p(x, C.c_float), x.shape[0], _p(codes, C.c_uint8)),
+              "quantize_batch")
+        return codes
+
+    def preprocess_query(self, query):
+        q = np.ascontiguousarray(query, np.float32).reshape(self.n_dims)
+        lut = np.empty((self.n_chunks, self.n_centroids), np.float32)
+        check(ffi.lib().mse_pq_preprocess_query(self._h, _p(q, C.c_float), _p(lut, C.c_float)), "preprocess_query")
+        return QueryLUT(lut)
+
+    def asymmetric_dot_product(self, lut, pq_vectors):
+        table = lut.table if isinstance(lut, QueryLUT) else np.ascontiguousarray(lut, np.float32)
+        codes = np.ascontiguousarray(pq_vectors, np.uint8).reshape(-1, self.n_chunks)
+        out = np.empty(codes.shape[0], np.int64)
+        check(ffi.lib().mse_pq_adc(self._h, _p(table, C.c_float), _p(codes, C.c_uint8), codes.shape[0],
+                                   _p(out, C.c_int64)), "asymmetric_dot_product")
+        return out
+
+    def adc_gather(self, codes, lut, ids, scales=None):
+        table = lut.table if isinstance(lut, QueryLUT) else np.ascontiguousarray(lut, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32)
+        out = np.empty(ids.size, np.int64)
+        check(ffi.lib().mse_pq_adc_gather(self._h, codes._h, _p(table, C.c_float),
+                                          _p(sc, C.c_float) if sc is not None else None, _p(ids, C.c_uint32), ids.size,
+                                          _p(out, C.c_int64)), "adc_gather")
+        return out
+
+    def scan_topk(self, codes, query_f32, r, k, searcher=None, scales=None):
+        q = np.ascontiguousarray(query_f32, np.float32).reshape(self.n_dims)
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32)
+        scores = np.empty(k, np.int64)
+        ids = np.empty(k, np.uint32)
+        check(ffi.lib().mse_pq_scan_topk(self._h, codes._h, searcher._h if searcher is not None else None,
+                                         _p(q, C.c_float), _p(sc, C.c_float) if sc is not None else None, r, k,
+                                         _p(scores, C.c_int64), _p(ids, C.c_uint32)), "pq_scan_topk")
+        return scores, ids
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_pq_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Codes:
+    """PQ codes (+ descriptor bytes) in HBM: index.pq-codes.bin / index.descriptor-codes.bin
+    (query_disk_index.rs:686-709)."""
+
+    def __init__(self, codes, descriptors=None):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        n, cs = codes.shape
+        if descriptors is not None:
+            descriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(n, -1)
+            nd = descriptors.shape[1]
+            dp = _p(descriptors, C.c_uint8)
+        else:
+            nd, dp = 0, None
+        self._h = check_ptr(ffi.lib().mse_codes_from_host(_p(codes, C.c_uint8), n, cs, dp, nd), "mse_codes_from_host")
+
+    def __len__(self):
+        return int(ffi.lib().mse_codes_len(self._h))
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_codes_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def descriptor_product(scales, descriptors, idx):
+    """query_disk_index.rs:135-142"""
+    s = np.ascontiguousarray(scales, np.float32)
+    d = np.ascontiguousarray(descriptors, np.uint8)
+    return int(ffi.lib().mse_descriptor_product(_p(s, C.c_float), s.size, _p(d, C.c_uint8), int(idx)))

@@ -1,0 +1,173 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/mse.h declares, the host-only entry points behave like the reference, and the compute
+entry points fail loudly (no CPU fallback) when there is no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "mse.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mse_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(mse):
+    from mse import ffi
+    names = declared_functions()
+    assert len(names) > 50
+    L = C.CDLL(ffi.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/mse.h but not exported: {missing}"
+    unbound = [n for n in names if n not in ffi.SIGNATURES]
+    assert not unbound, f"declared but not bound in mse/ffi.py: {unbound}"
+    extra = [n for n in ffi.SIGNATURES if n not in names]
+    assert not extra, f"bound but not declared: {extra}"
+
+
+def test_only_mse_symbols_are_public(mse):
+    import subprocess
+    from mse import ffi
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ffi.LIB_PATH], text=True)
+    public = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert all(p.startswith("mse_") or p in ("_init", "_fini") for p in public), public
+
+
+def test_scale_dot_matches_oracle(mse, orc):
+    for v in (0.0, 1.0, -1.0, 0.5, 1e-10, -3e-10, 1e30, -1e30, float("nan"), float("inf"), 0.123456789):
+        assert mse.scale_dot_result(v) == orc.lib().orc_scale_dot_result(v)
+        assert mse.scale_dot_result_f64(v) == orc.lib().orc_scale_dot_result_f64(v)
+
+
+def test_neighbour_buffer_matches_oracle_trace(mse, orc):
+    g = np.load(os.path.join(GOLDEN, "neighbour_buffer_trace.npz"))
+    nb = mse.NeighbourBuffer(int(g["cap"]))
+    assert nb.cap() == int(g["cap"])
+    for step, (op, a, b) in enumerate(g["ops"]):
+        if op == 0:
+            nb.insert(int(a), int(b))
+        else:
+            r = nb.next_unvisited()
+            assert (-1 if r is None else r) == int(a)
+        n = int(g["lens"][step])
+        assert len(nb) == n
+        assert np.array_equal(nb.ids, g["ids"][step, :n])
+        assert np.array_equal(nb.scores, g["scores"][step, :n])
+    nb.clear()
+    assert len(nb) == 0 and nb.next_unvisited() is None
+
+
+def test_neighbour_buffer_random_against_oracle(mse, orc):
+    rng = np.random.default_rng(9)
+    for cap in (1, 2, 7, 64):
+        a, b = mse.NeighbourBuffer(cap), orc.NeighbourBuffer(cap)
+        for _ in range(500):
+            if rng.random() < 0.75:
+                i, s = int(rng.integers(0, 40)), int(rng.integers(-5, 5)) << 20
+                a.insert(i, s)
+                b.insert(i, s)
+            else:
+                assert a.next_unvisited() == b.next_unvisited()
+            assert np.array_equal(a.ids, b.ids) and np.array_equal(a.scores, b.scores)
+
+
+def test_descriptor_product_matches_oracle(mse, orc):
+    rng = np.random.default_rng(10)
+    desc = rng.integers(0, 256, size=(50, 4), dtype=np.uint8)
+    scales = (rng.standard_normal(4) / 512).astype(np.float32)
+    for i in (0, 7, 49):
+        assert mse.descriptor_product(scales, desc, i) == orc.descriptor_product(scales, desc, i)
+
+
+def test_get_total_embedding(mse, orc):
+    rng = np.random.default_rng(12)
+    d = 64
+    embs = orc.f16_bits(rng.standard_normal((3, d)).astype(np.float32))
+    calls = []
+
+    def server(batch):
+        calls.append(batch)
+        if "images" in batch:
+            return [embs[0].tobytes()]
+        return [embs[1].tobytes(), embs[2].tobytes()]
+
+    raw = rng.standard_normal(d).astype(np.float32)
+    terms = [{"image": b"bmpbytes", "weight": 2.0}, {"text": "cat"}, {"text": "dog", "weight": -0.5},
+             {"embedding": raw.tolist(), "weight": 0.25}, {"predefined_embedding": "nsfw", "weight": 1.5},
+             {"predefined_embedding": "missing"}]
+    pre = {"nsfw": rng.standard_normal(d).astype(np.float32)}
+    got = mse.get_total_embedding(terms, d, server, pre)
+    # images batch first, then text (common.rs:252-266)
+    assert list(calls[0]) == ["images"] and calls[1] == {"text": ["cat", "dog"]}
+    want = raw * np.float32(0.25) + pre["nsfw"] * np.float32(1.5)
+    want = want + orc.total_embedding(embs, np.array([2.0, 1.0, -0.5], np.float32))
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert mse.decode_fp16_buffer(embs[0].tobytes()).dtype == np.float32
+    assert np.array_equal(mse.chunk_fp16_buffer(embs[0].tobytes()), embs[0])
+
+
+def test_shape_violations_are_errors_not_ub(mse):
+    from mse import ffi
+    L = ffi.lib()
+    # widths must be multiples of 64 (fast_dot debug_assert, vector.rs:197,259)
+    assert not L.mse_base_wrap_device(None, 10, 100)
+    assert "multiple of 64" in ffi.last_error()
+    assert not L.mse_index_new(100)
+    # more than 256 centroids (vector.rs:337)
+    c = np.zeros((257, 64), np.float32)
+    t = np.zeros((64, 64), np.float32)
+    assert not L.mse_pq_load(c.ctypes.data_as(ffi.f32p), 257, t.ctypes.data_as(ffi.f32p), 64, 16)
+    assert "256" in ffi.last_error()
+    with pytest.raises(mse.MseError):
+        mse.ProductQuantizer(np.zeros((4, 64), np.float32), np.zeros(10, np.float32), 16, 64)   # transform.len() != d*d (:334)
+    with pytest.raises(mse.MseError):
+        mse.VectorList.from_f16s(np.zeros(100, np.uint16), 64)                                     # assert at :174
+    with pytest.raises(mse.MseError):
+        mse.fast_dot(np.zeros(64, np.uint16), np.zeros(128, np.uint16))
+
+
+def test_compute_fails_loudly_without_a_device(mse):
+    from mse import ffi
+    if ffi.lib().mse_device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(mse.MseError):
+        mse.VectorList.from_f16s(np.zeros((4, 64), np.uint16), 64)
+    with pytest.raises(mse.MseError):
+        mse.fast_dot(np.zeros(64, np.uint16), np.zeros(64, np.uint16))
+    with pytest.raises(mse.MseError):
+        mse.ScalarQuantizerIndex(64).add(np.zeros((1, 64), np.float32))
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "meme-search-engine_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import orc" not in text and "liboracle" not in text and "from oracle" not in text, (dirpath, f)
+
+
+def test_shard_ranges_and_merge(mse, orc):
+    from mse import shard
+    for n, w in ((10, 3), (100000000, 8), (7, 8), (0, 2)):
+        spans = [shard.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    import torch
+    rng = np.random.default_rng(13)
+    scores = rng.integers(-5, 5, size=(6, 24)).astype(np.int64)
+    ids = rng.permutation(10000)[:6 * 24].reshape(6, 24).astype(np.uint32)
+    ids[2, 5:9] = 0xFFFFFFFF
+    s_np, i_np = shard.merge_topk_numpy(scores, ids, 10)
+    s_t, i_t = shard.merge_topk_torch(torch.from_numpy(scores), torch.from_numpy(ids.astype(np.int64)), 10)
+    assert np.array_equal(s_np, s_t.numpy()) and np.array_equal(i_np, i_t.numpy().astype(np.uint32))
+    for q in range(6):
+        valid = ids[q] != 0xFFFFFFFF
+        order = np.lexsort((ids[q][valid], -scores[q][valid]))[:10]
+        assert np.array_equal(i_np[q], ids[q][valid][order])

@@ -1,0 +1,226 @@
+"""Parity of the HIP brute-force path with the CPU oracle, through the C ABI (mse package).
+Bit-exact bar: i64 scores and returned indices."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SEED_BASE, SEED_QUERY
+
+pytestmark = pytest.mark.gpu
+D = 1152
+
+
+def h(x):
+    return np.asarray(x, np.float16).view(np.uint16)
+
+
+def test_native_library_is_loaded(gpu, mse):
+    from mse import ffi
+    assert os.path.exists(ffi.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libmse_hip.so" in maps
+    assert b"gfx950" in ffi.lib().mse_version()
+
+
+def test_generator_is_bit_identical_to_oracle(gpu, mse, orc):
+    for d, n, first in ((1152, 1000, 0), (1152, 64, 123456789012), (64, 300, 5), (4096, 10, 0)):
+        vl = mse.VectorList.generate(SEED_BASE, first, n, d)
+        assert np.array_equal(vl.rows(0, n), orc.gen_rows_f16(SEED_BASE, first, n, d))
+
+
+def test_fast_dot_known_answers(gpu, mse, orc):
+    ones = np.full(D, 0x3C00, np.uint16)
+    assert mse.fast_dot_noprefetch(ones, ones) == D << 32
+    y = h(np.arange(1, D + 1) / 1024.0)
+    for e in (0, 7, 8, 15, 16, 24, 31, 32, 63, 777, D - 1):
+        x = np.zeros(D, np.uint16)
+        x[e] = h(2.0)
+        assert mse.fast_dot(x, y, y) == orc.fast_dot(x, y)
+    rng = np.random.default_rng(1)
+    # arbitrary bit patterns incl. f16 subnormals, large magnitudes (no inf/nan), both signs
+    x = rng.integers(0, 0x7BFF, size=(40, D), dtype=np.uint16) | (rng.integers(0, 2, size=(40, D), dtype=np.uint16) << 15)
+    for i in range(0, 40, 2):
+        assert mse.fast_dot_noprefetch(x[i], x[i + 1]) == orc.fast_dot(x[i], x[i + 1])
+    # reduction tree order: one live step so the 32 products are the 32 accumulator slots
+    for seed in range(10):
+        r = np.random.default_rng(seed)
+        a = np.zeros(64, np.float16)
+        b = np.zeros(64, np.float16)
+        a[:32] = (2.0 ** r.integers(-10, 14, 32)) * r.uniform(1.0, 2.0, 32) * r.choice([1.0, -1.0], 32)
+        b[:32] = 1.0
+        assert mse.fast_dot(h(a), h(b)) == orc.fast_dot(h(a), h(b))
+    # saturation / NaN of `as i64`
+    big = np.full(64, h(60000.0), np.uint16)
+    assert mse.fast_dot(big, big) == orc.fast_dot(big, big) == (1 << 63) - 1
+    nan = big.copy()
+    nan[3] = 0x7E00
+    assert mse.fast_dot(nan, big) == orc.fast_dot(nan, big) == 0
+
+
+def test_golden_fixture(gpu, mse):
+    g = np.load(os.path.join(GOLDEN, "bruteforce_256x1152.npz"))
+    vl = mse.VectorList.generate(int(g["seed_base"]), 0, 256)
+    assert np.array_equal(vl.rows(0, 8), g["base_head"])
+    s = mse.Searcher(vl)
+    for i in range(8):
+        assert np.array_equal(s.scores(g["queries"][i]), g["scores"][i])
+    for mode in (mse.MODE_EXACT, mse.MODE_MFMA, mse.MODE_AUTO):
+        sc, ids = s.bruteforce_topk(g["queries"], 10, mode)
+        assert np.array_equal(sc, g["top_scores"]) and np.array_equal(ids, g["top_ids"])
+
+
+@pytest.mark.parametrize("n,d", [(1, 1152), (63, 1152), (64, 1152), (65, 1152), (1000, 64), (1000, 1024),
+                                 (4097, 1152), (20000, 1152), (70000, 256)])
+def test_scores_match_oracle(gpu, mse, orc, n, d):
+    base = orc.gen_rows_f16(SEED_BASE, 0, n, d)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 3, d)
+    vl = mse.VectorList.from_f16s(base, d)
+    s = mse.Searcher(vl)
+    for i in range(3):
+        assert np.array_equal(s.scores(q[i]), orc.score_all(base, q[i]))
+    ids = np.random.default_rng(0).integers(0, n, 100).astype(np.uint32)
+    assert np.array_equal(s.score_rows(ids, q[0]), orc.score_rows(base, ids, q[0]))
+    r = s.ranks(q[1], ids[:20])
+    assert np.array_equal(r, orc.ranks_from_scores(orc.score_all(base, q[1]))[ids[:20]])
+
+
+@pytest.mark.parametrize("mode", ["exact", "mfma"])
+@pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (5, 3, 10), (31, 2, 10), (33, 9, 5), (1000, 17, 10), (5000, 1, 1000),
+                                    (20000, 130, 10), (40000, 8, 100)])
+def test_topk_matches_oracle(gpu, mse, orc, mode, n, nq, k):
+    base = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    m = mse.MODE_EXACT if mode == "exact" else mse.MODE_MFMA
+    sc, ids = s.bruteforce_topk(q, k, m)
+    ws, wi = orc.bruteforce_topk(base, q, k)
+    assert np.array_equal(ids, wi)
+    assert np.array_equal(sc, ws)
+
+
+def test_ties_break_by_lower_id(gpu, mse, orc):
+    # duplicated rows => exactly equal scores; order must be (score desc, id asc) in every mode
+    rows = orc.gen_rows_f16(SEED_BASE, 0, 40)
+    base = np.concatenate([rows] * 30)            # 1200 rows, each distinct row appears 30 times
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 20)
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    ws, wi = orc.bruteforce_topk(base, q, 64)
+    for mode in (mse.MODE_EXACT, mse.MODE_MFMA):
+        sc, ids = s.bruteforce_topk(q, 64, mode)
+        assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    assert np.all(wi[:, 1] == wi[:, 0] + 40)      # the tie really is resolved by id
+
+
+def test_unnormalised_and_adversarial_data(gpu, mse, orc):
+    # large norms, sorted-by-score layouts (worst case for threshold schemes), constant rows
+    rng = np.random.default_rng(5)
+    q = orc.f16_bits((rng.standard_normal((12, D)) * 3).astype(np.float32))
+    base_f = (rng.standard_normal((6000, D)) * rng.uniform(0.01, 20, (6000, 1))).astype(np.float32)
+    order = np.argsort(base_f @ orc.f16_to_f32(q[0]))          # ascending: best rows arrive last
+    base = orc.f16_bits(base_f[order])
+    base[100:200] = base[100]                                   # a run of identical rows
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    ws, wi = orc.bruteforce_topk(base, q, 10)
+    for mode in (mse.MODE_EXACT, mse.MODE_MFMA):
+        sc, ids = s.bruteforce_topk(q, 10, mode)
+        assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
+def test_empty_and_degenerate_inputs(gpu, mse, orc):
+    vl = mse.VectorList.from_f16s(np.zeros((0, D), np.uint16), D)
+    s = mse.Searcher(vl)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 2)
+    sc, ids = s.bruteforce_topk(q, 3)
+    assert np.all(ids == 0xFFFFFFFF) and np.all(sc == -(1 << 63))
+    base = orc.gen_rows_f16(SEED_BASE, 0, 10)
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    sc, ids = s.bruteforce_topk(q[:0], 3)
+    assert sc.shape == (0, 3)
+    assert list(s.score_rows(np.array([3, 99, 0xFFFFFFFF], np.uint32), q[0])[1:]) == [-(1 << 63)] * 2
+    with pytest.raises(mse.MseError):
+        s.bruteforce_topk(q, 5000)
+
+
+def test_certificate_widens_on_near_ties(gpu, mse, orc):
+    # many rows whose scores differ by less than the certified error bound: the MFMA stage cannot
+    # separate them, the certificate must fail and the search must widen (or fall back) and still
+    # return the exact answer
+    rng = np.random.default_rng(7)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 16)
+    proto = orc.f16_to_f32(orc.gen_rows_f16(SEED_BASE, 0, 1)[0])
+    base_f = np.tile(proto, (3000, 1))
+    flip = rng.integers(0, D, 3000)
+    base_f[np.arange(3000), flip] *= (1.0 + 2.0 ** -9)         # one-ulp-ish perturbations of one row
+    base = orc.f16_bits(base_f)
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    ws, wi = orc.bruteforce_topk(base, q, 10)
+    sc, ids = s.bruteforce_topk(q, 10, mse.MODE_MFMA)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    st = s.last_stats()
+    assert st["widened_queries"] > 0 and st["max_groups"] > 18
+
+
+def test_sharded_equals_whole(gpu, mse, orc):
+    # the multi-GPU decomposition on one device: two shards with id offsets + device merge
+    import torch
+    from mse import shard
+    n, nq, k = 30000, 20, 10
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    whole = mse.Searcher(mse.VectorList.generate(SEED_BASE, 0, n))
+    ws, wi = whole.bruteforce_topk(q, k, mse.MODE_MFMA)
+    qd = torch.from_numpy(q.view(np.int16)).cuda()
+    gs = torch.empty((2, nq, k), dtype=torch.int64, device="cuda")
+    gi = torch.empty((2, nq, k), dtype=torch.int32, device="cuda")
+    searchers = []
+    for r in range(2):
+        lo, hi = shard.shard_range(n, r, 2)
+        sr = mse.Searcher(mse.VectorList.generate(SEED_BASE, lo, hi - lo))
+        sr.bruteforce_topk_dev(qd.data_ptr(), nq, k, gs[r].data_ptr(), gi[r].data_ptr(), mse.MODE_MFMA, id_offset=lo)
+        searchers.append(sr)
+    from mse import ffi
+    ffi.check(ffi.lib().mse_device_synchronize())
+    out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    searchers[0].merge_topk_dev(gs.data_ptr(), gi.data_ptr(), 2, nq, k, out_s.data_ptr(), out_i.data_ptr())
+    ffi.check(ffi.lib().mse_device_synchronize())
+    assert np.array_equal(out_s.cpu().numpy(), ws)
+    assert np.array_equal(out_i.cpu().numpy().view(np.uint32), wi)
+    # and the torch-side merge used by the gloo test agrees with the device merge
+    ms, mi = shard.merge_topk_torch(gs.permute(1, 0, 2).reshape(nq, 2 * k), gi.permute(1, 0, 2).reshape(nq, 2 * k), k)
+    assert np.array_equal(ms.cpu().numpy(), ws) and np.array_equal(mi.cpu().numpy().astype(np.uint32), wi)
+
+
+def test_full_size_properties_1e7(gpu, mse, orc):
+    """BASELINE config 3 size (1e7 x 1152): size-independent properties instead of an oracle scan."""
+    n, nq, k = 10_000_000, 136, 10
+    vl = mse.VectorList.generate(SEED_BASE, 0, n)
+    s = mse.Searcher(vl)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    # plant known winners: queries 0..3 are exact copies of rows deep inside the base
+    planted = [0, 4_999_999, 9_999_999, 1234567]
+    for j, r in enumerate(planted):
+        q[j] = orc.gen_rows_f16(SEED_BASE, r, 1)[0]
+    sm, im = s.bruteforce_topk(q, k, mse.MODE_MFMA)
+    se, ie = s.bruteforce_topk(q[:8], k, mse.MODE_EXACT)
+    assert np.array_equal(im[:8], ie) and np.array_equal(sm[:8], se)           # two independent kernels agree
+    assert [int(im[j, 0]) for j in range(4)] == planted                        # a row is its own best match
+    assert np.all(sm[:, :-1] >= sm[:, 1:])                                     # sorted
+    assert np.all(im < n) and all(len(set(r)) == k for r in im.tolist())       # valid, distinct
+    # returned scores are the oracle's scores of the returned rows (rows regenerated on the host)
+    for qi in (0, 5, 77, 135):
+        for j in (0, 3, 9):
+            row = orc.gen_rows_f16(SEED_BASE, int(im[qi, j]), 1)[0]
+            assert orc.fast_dot(q[qi], row) == int(sm[qi, j])
+    # k-th score bounds every non-returned row: check on a random sample of rows with the oracle
+    rng = np.random.default_rng(3)
+    sample = rng.integers(0, n, 300)
+    rows = np.stack([orc.gen_rows_f16(SEED_BASE, int(r), 1)[0] for r in sample])
+    for qi in (5, 77):
+        sc = orc.score_all(rows, q[qi])
+        outside = ~np.isin(sample, im[qi])
+        assert np.all(sc[outside] <= sm[qi, -1])
+    # idempotence
+    sm2, im2 = s.bruteforce_topk(q, k, mse.MODE_MFMA)
+    assert np.array_equal(sm, sm2) and np.array_equal(im, im2)
+    assert s.last_stats()["widened_queries"] == 0

@@ -1,0 +1,173 @@
+"""Parity of the HIP product-quantiser, flat index and graph-search paths with the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SEED_BASE, SEED_QUERY, SEED_CENTRES, make_pq
+
+pytestmark = pytest.mark.gpu
+D = 1152
+
+
+def clustered_rows(orc, n, n_centres=64, noise=0.3, seed=0):
+    """Unit rows around `n_centres` unit centres (iid Gaussian data is not quantisable)."""
+    rng = np.random.default_rng(seed)
+    centres = orc.f16_to_f32(orc.gen_rows_f16(SEED_CENTRES, 0, n_centres))
+    x = centres[rng.integers(0, n_centres, n)] + rng.standard_normal((n, D)).astype(np.float32) * np.float32(noise / np.sqrt(D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+def train_pq(orc, sample, dpc=18, n_centroids=256, iters=4, seed=1):
+    """Tiny OPQ-shaped codec: random orthonormal transform, per-subspace max-inner-product k-means."""
+    rng = np.random.default_rng(seed)
+    d = sample.shape[1]
+    T = np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)
+    t = sample @ T.T                                   # rows = T x
+    n_chunks = d // dpc
+    cents = np.zeros((n_centroids, d), np.float32)
+    for i in range(n_chunks):
+        sub = t[:, i * dpc:(i + 1) * dpc]
+        c = sub[rng.choice(len(sub), n_centroids, replace=False)].copy()
+        for _ in range(iters):
+            a = np.argmax(sub @ c.T, axis=1)
+            for j in range(n_centroids):
+                m = sub[a == j]
+                if len(m):
+                    c[j] = m.mean(axis=0)
+        cents[:, i * dpc:(i + 1) * dpc] = c
+    return cents, T
+
+
+def test_golden_adc(gpu, mse):
+    g = np.load(os.path.join(GOLDEN, "pq_adc_4096.npz"))
+    pq = mse.ProductQuantizer(np.zeros((256, D), np.float32), np.eye(D, dtype=np.float32), 18, D)
+    got = pq.asymmetric_dot_product(g["lut"], g["codes"])
+    assert np.array_equal(got, g["adc"])
+    codes = mse.Codes(g["codes"], g["desc"])
+    ids = np.arange(4096, dtype=np.uint32)[::-1].copy()
+    assert np.array_equal(pq.adc_gather(codes, g["lut"], ids, g["scales"]), g["adc_desc"][::-1])
+    assert np.array_equal(pq.adc_gather(codes, g["lut"], ids[:100]), g["adc"][::-1][:100])
+
+
+@pytest.mark.parametrize("d,dpc,nc", [(1152, 18, 256), (128, 16, 8), (64, 16, 4)])
+def test_codec_matches_oracle(gpu, mse, orc, d, dpc, nc):
+    cents, T, _, _ = make_pq(orc, d, dpc, nc)
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((70, d)) / np.sqrt(d)).astype(np.float32)
+    opq, gpq = orc.PQ(cents, T, dpc, d), mse.ProductQuantizer(cents, T, dpc, d)
+    assert np.array_equal(gpq.apply_transform(x), opq.apply_transform(x))          # same k-ascending fma order
+    assert np.array_equal(gpq.quantize_batch(x), opq.quantize_batch(x))
+    lut_g, lut_o = gpq.preprocess_query(x[0]).table, opq.preprocess_query(x[0])
+    assert np.array_equal(lut_g, lut_o)
+    codes = opq.quantize_batch(x)
+    assert np.array_equal(gpq.asymmetric_dot_product(lut_g, codes), opq.asymmetric_dot_product(lut_o, codes))
+
+
+def test_quantize_tie_rule_and_errors(gpu, mse, orc):
+    d, dpc = 64, 16
+    T = np.eye(d, dtype=np.float32)
+    cents = np.zeros((4, d), np.float32)
+    cents[1] = 1.0
+    cents[2] = 1.0
+    cents[3] = -1.0
+    pq = mse.ProductQuantizer(cents, T, dpc, d)
+    assert list(pq.quantize_batch(np.ones((1, d), np.float32))[0]) == [1] * 4     # first max wins (vector.rs:353-358)
+    assert list(pq.quantize_batch(np.zeros((1, d), np.float32))[0]) == [0] * 4
+    assert list(pq.quantize_batch(-np.ones((1, d), np.float32))[0]) == [3] * 4
+
+
+def test_pq_scan_rerank_recall(gpu, mse, orc):
+    """BASELINE config 5 at test size: ADC scan -> top-r -> fp16 exact re-score -> top-10; recall@10
+    against the oracle's brute force, and bit parity of every stage with the oracle pipeline."""
+    n, r, k = 20000, 200, 10
+    x = clustered_rows(orc, n)
+    cents, T = train_pq(orc, x[:4000])
+    base = orc.f16_bits(x)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    assert np.array_equal(gpq.quantize_batch(orc.f16_to_f32(base[:512])), codes[:512])
+    desc = np.random.default_rng(2).integers(0, 256, size=(n, 4), dtype=np.uint8)
+    scales = np.array([0.5, 0, -0.25, 0], np.float32) / np.float32(512)
+    gcodes = mse.Codes(codes, desc)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    queries = clustered_rows(orc, 12, seed=9)
+    hits = 0
+    for qv in queries:
+        qh = orc.f16_bits(qv)
+        # oracle pipeline
+        lut = opq.preprocess_query(qv)
+        approx = opq.adc_desc(lut, codes, desc, scales)
+        _, cand = orc.topk_from_scores(approx, r)
+        exact = orc.score_rows(base, cand, qh) + np.array([orc.descriptor_product(scales, desc, int(c)) for c in cand])
+        order = np.lexsort((cand, -exact))[:k]
+        sc, ids = gpq.scan_topk(gcodes, qv, r, k, searcher, scales)
+        assert np.array_equal(ids, cand[order]) and np.array_equal(sc, exact[order])
+        # without re-score: plain ADC ranking
+        sc2, ids2 = gpq.scan_topk(gcodes, qv, r, k, None, scales)
+        ws, wi = orc.topk_from_scores(approx, k)
+        assert np.array_equal(ids2, wi) and np.array_equal(sc2, ws)
+        # recall against exact brute force on the same scoring (dot + descriptor bias)
+        truth = orc.score_all(base, qh) + np.array([orc.descriptor_product(scales, desc, i) for i in range(n)])
+        ranks = orc.ranks_from_scores(truth)
+        hits += int(np.sum(ranks[ids] < k))
+    recall = hits / (k * len(queries))
+    assert recall >= 0.9, recall
+
+
+@pytest.mark.parametrize("n,d", [(0, 128), (1, 128), (777, 128), (3000, 1152), (20000, 256)])
+def test_flat_index_matches_oracle(gpu, mse, orc, n, d):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    idx = mse.ScalarQuantizerIndex(d)
+    for lo in range(0, n, 1024):                           # INDEX_ADD_BATCH (src/main.rs:815)
+        idx.add(x[lo:lo + 1024])
+    assert idx.ntotal() == n
+    q = rng.standard_normal((11, d)).astype(np.float32)    # queries are NOT unit norm (common.rs:215-274)
+    res = idx.search(q, 7)
+    codes = orc.f16_bits(x)
+    wd, wl = orc.index_search(codes, q, 7, order=0)
+    assert np.array_equal(res.labels, wl)
+    assert np.array_equal(res.distances, wd)
+    if n >= 7:
+        # FAISS's own (scalar, non-AVX2 build) summation order ranks this data identically
+        _, l1 = orc.index_search(codes, q, 7, order=1)
+        assert np.array_equal(res.labels, l1)
+    assert np.all(res.labels[:, min(n, 7):] == -1)
+
+
+def test_index_large_k_default_of_server(gpu, mse, orc):
+    # handle_request uses k = 1000 by default (src/main.rs:952)
+    rng = np.random.default_rng(5)
+    d, n = 128, 5000
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    idx = mse.ScalarQuantizerIndex(d)
+    idx.add(x)
+    q = rng.standard_normal((1, d)).astype(np.float32)
+    res = idx.search(q, 1000)
+    wd, wl = orc.index_search(orc.f16_bits(x), q, 1000, order=0)
+    assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
+
+
+def test_greedy_search_matches_oracle(gpu, mse, orc):
+    rng = np.random.default_rng(6)
+    n, deg, L = 3000, 16, 64
+    vecs = orc.gen_rows_f16(SEED_BASE, 0, n)
+    # navigable-ish random graph: nearest few by a cheap projection + random long edges
+    adj = rng.integers(0, n, size=(n, deg), dtype=np.uint32)
+    degs = rng.integers(deg // 2, deg + 1, size=n).astype(np.uint32)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    graph = mse.IndexGraph(adj, degs)
+    for qi in range(4):
+        q = orc.gen_rows_f16(SEED_QUERY, qi, 1)[0]
+        buf, dist = mse.greedy_search(searcher, 0, False, q, graph, L)
+        obuf, odist = orc.greedy_search(vecs, adj, degs, 0, q, L)
+        assert dist == odist
+        assert np.array_equal(buf.ids, obuf.ids) and np.array_equal(buf.scores, obuf.scores)
+    # base_vectors_only: ids >= breakpoint are never scored (OOD-DiskANN rule, lib.rs:196-199)
+    q = orc.gen_rows_f16(SEED_QUERY, 9, 1)[0]
+    buf, dist = mse.greedy_search(searcher, 0, True, q, graph, L, query_breakpoint=2000)
+    obuf, odist = orc.greedy_search(vecs, adj, degs, 0, q, L, True, 2000)
+    assert dist == odist and np.array_equal(buf.ids, obuf.ids)
+    assert np.all(buf.ids[buf.ids != 0] < 2000)

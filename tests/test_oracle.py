@@ -1,0 +1,354 @@
+"""Pins the CPU oracle (oracle/mse_oracle.c) with hand-derivable known answers and the committed
+fixtures.  The reference ships no golden vectors for this path, so these known
+answers are derived by hand from the reference's source (file:line in each test)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SEED_BASE, SEED_QUERY
+
+ONE = 0x3C00  # f16 1.0
+D = 1152
+
+
+def h(x):
+    return np.asarray(x, np.float16).view(np.uint16)
+
+
+def test_built_with_reference_intrinsics(orc):
+    # the reference's kernel is AVX2+F16C+FMA (diskann/src/vector.rs:192-306); so is the oracle here
+    assert orc.lib().orc_have_avx2() == 1
+
+
+def test_scale_dot_result_rust_as_cast(orc):
+    # vector.rs:408-416: `(x * SCALE) as i64` -- truncation toward zero, saturation, NaN -> 0
+    L = orc.lib()
+    assert L.orc_scale_dot_result(1.0) == 1 << 32
+    assert L.orc_scale_dot_result(-1.0) == -(1 << 32)
+    assert L.orc_scale_dot_result(0.5) == 1 << 31
+    assert L.orc_scale_dot_result(np.float32(1e-10)) == 0                 # 0.4294 truncates to 0
+    assert L.orc_scale_dot_result(np.float32(-3e-10)) == -1               # -1.288 truncates toward zero
+    assert L.orc_scale_dot_result(np.float32(1e30)) == (1 << 63) - 1      # saturates
+    assert L.orc_scale_dot_result(np.float32(-1e30)) == -(1 << 63)
+    assert L.orc_scale_dot_result(float("nan")) == 0
+    assert L.orc_scale_dot_result(float("inf")) == (1 << 63) - 1
+    assert L.orc_scale_dot_result_f64(0.25) == 1 << 30
+    assert L.orc_scale_dot_result_f64(float("nan")) == 0
+
+
+def test_f16_conversions_match_ieee(orc):
+    allh = np.arange(65536, dtype=np.uint16)
+    a = orc.f16_to_f32(allh)
+    b = allh.view(np.float16).astype(np.float32)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    rng = np.random.default_rng(0)
+    f = (rng.standard_normal(100000) * 10.0 ** rng.integers(-9, 5, 100000)).astype(np.float32)
+    f = np.concatenate([f, np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.96e-8, 2.98e-8, 2.99e-8], np.float32)])
+    with np.errstate(over="ignore"):
+        assert np.array_equal(orc.f16_bits(f), f.astype(np.float16).view(np.uint16))
+
+
+def test_fast_dot_all_ones(orc):
+    ones = np.full(D, ONE, np.uint16)
+    assert orc.fast_dot(ones, ones) == D << 32
+    assert orc.fast_dot_scalar(ones, ones) == D << 32
+
+
+def test_fast_dot_one_hot_hits_every_accumulator_slot(orc):
+    # element e lands in accumulator (e mod 32)/8, lane e mod 8 (vector.rs:279-291); a one-hot
+    # product must come through the whole reduction tree untouched
+    y = h(np.arange(1, D + 1) / 1024.0)
+    for e in list(range(0, 64)) + [D - 1, D - 32, 777]:
+        x = np.zeros(D, np.uint16)
+        x[e] = h(2.0)
+        want = int(np.float32(2.0) * np.float32(np.float16((e + 1) / 1024.0)) * np.float32(2 ** 32))
+        assert orc.fast_dot(x, y) == want == orc.fast_dot_scalar(x, y)
+
+
+def test_fast_dot_reduction_tree_order(orc):
+    # One non-zero step (n = 64, second step zero): the 32 products ARE the 32 accumulator slots.
+    # Expected value computed literally from the reduction at vector.rs:295-303; a different
+    # association (plain left-to-right) must disagree for at least some inputs, or the test is blind.
+    f = np.float32
+    differs = 0
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        mags = (2.0 ** rng.integers(-10, 14, 32)) * rng.uniform(1.0, 2.0, 32) * rng.choice([1.0, -1.0], 32)
+        x = np.zeros(64, np.float16)
+        x[:32] = mags
+        y = np.zeros(64, np.float16)
+        y[:32] = 1.0
+        acc = x[:32].astype(np.float32)
+        a = [f(acc[l] + acc[8 + l]) for l in range(8)]
+        b = [f(acc[16 + l] + acc[24 + l]) for l in range(8)]
+        hh = [f(a[0] + a[1]), f(a[2] + a[3]), f(b[0] + b[1]), f(b[2] + b[3]),
+              f(a[4] + a[5]), f(a[6] + a[7]), f(b[4] + b[5]), f(b[6] + b[7])]
+        s = [f(hh[0] + hh[4]), f(hh[1] + hh[5]), f(hh[2] + hh[6]), f(hh[3] + hh[7])]
+        want = f(f(f(s[0] + s[1]) + s[2]) + s[3])
+        assert np.float32(orc.fast_dot_f32(h(x), h(y))) == want
+        naive = f(0)
+        for v in acc:
+            naive = f(naive + v)
+        differs += int(naive != want)
+    assert differs > 5
+
+
+def test_fast_dot_uses_fused_multiply_add(orc):
+    # acc = fma(x, y, acc): with x*y needing more than 24 bits relative to acc the fused and the
+    # unfused results differ (vector.rs:288 `_mm256_fmadd_ps`)
+    x = np.zeros(64, np.float16)
+    y = np.zeros(64, np.float16)
+    x[0], y[0] = 1.0, 1.0               # step 0: acc slot0 = 1
+    x[32], y[32] = np.float16(2.0 ** -12 + 2.0 ** -22 * 0), np.float16(2.0 ** -12)
+    x[32] = np.float16(1.0009765625 * 2.0 ** -12)   # (1+2^-10) * 2^-12
+    y[32] = np.float16(1.0009765625 * 2.0 ** -12)
+    prod_exact = (1.0009765625 * 2.0 ** -12) ** 2
+    want = np.float32(1.0 + prod_exact)              # single rounding
+    assert np.float32(orc.fast_dot_f32(h(x), h(y))) == want
+
+
+def test_avx_and_scalar_restatements_agree(orc):
+    base = orc.gen_rows_f16(SEED_BASE, 0, 128)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 4)
+    for i in range(128):
+        for j in range(4):
+            assert orc.fast_dot(base[i], q[j]) == orc.fast_dot_scalar(base[i], q[j])
+    # denormal halves and large values
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 0x7BFF, size=(16, 1152), dtype=np.uint16) | (rng.integers(0, 2, size=(16, 1152), dtype=np.uint16) << 15)
+    for i in range(0, 16, 2):
+        assert orc.fast_dot(x[i], x[i + 1]) == orc.fast_dot_scalar(x[i], x[i + 1])
+
+
+def test_generator_is_unit_norm_and_deterministic(orc):
+    a = orc.gen_rows_f16(SEED_BASE, 5, 3)
+    b = orc.gen_rows_f16(SEED_BASE, 0, 8)[5:8]
+    assert np.array_equal(a, b)
+    n = np.linalg.norm(orc.f16_to_f32(a).astype(np.float64), axis=1)
+    assert np.all(np.abs(n - 1.0) < 5e-4)
+    ints = orc.gen_row_ints(SEED_BASE, 0)
+    assert ints.min() >= -131070 and ints.max() <= 131070 and abs(float(ints.mean())) < 5000
+
+
+def test_golden_bruteforce(orc):
+    g = np.load(os.path.join(GOLDEN, "bruteforce_256x1152.npz"))
+    base = orc.gen_rows_f16(int(g["seed_base"]), 0, 256)
+    assert np.array_equal(base[:8], g["base_head"])
+    q = orc.gen_rows_f16(int(g["seed_query"]), 0, 8)
+    assert np.array_equal(q, g["queries"])
+    for i in range(8):
+        assert np.array_equal(orc.score_all(base, q[i]), g["scores"][i])
+    s, ids = orc.bruteforce_topk(base, q, 10)
+    assert np.array_equal(s, g["top_scores"]) and np.array_equal(ids, g["top_ids"])
+    # top-k really is the sorted head of the scores, ties by id
+    for i in range(8):
+        order = np.lexsort((np.arange(256), -g["scores"][i]))[:10]
+        assert np.array_equal(order.astype(np.uint32), ids[i])
+
+
+def test_topk_tie_break_and_padding(orc):
+    scores = np.array([5, 9, 9, 1, 9, -3], np.int64)
+    s, ids = orc.topk_from_scores(scores, 4)
+    assert list(ids) == [1, 2, 4, 0] and list(s) == [9, 9, 9, 5]
+    base = orc.gen_rows_f16(SEED_BASE, 0, 3)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 1)
+    s, ids = orc.bruteforce_topk(base, q, 5)
+    assert list(ids[0][3:]) == [0xFFFFFFFF] * 2 and list(s[0][3:]) == [-(1 << 63)] * 2
+
+
+def test_ranks_and_recall(orc):
+    # src/query_disk_index.rs:271-273,321-326
+    scores = np.array([10, 50, 50, 7, 99], np.int64)
+    r = orc.ranks_from_scores(scores)
+    assert list(r) == [3, 1, 2, 4, 0]
+    assert orc.recall_at_k(r, np.array([4, 1, 3], np.uint32), 3) == pytest.approx(2 / 3)
+
+
+def test_descriptor_product(orc):
+    # src/query_disk_index.rs:135-142: integer sum of per-term truncations
+    scales = np.array([1.0 / 512, -0.5 / 512], np.float32)
+    desc = np.array([[0, 0], [255, 3]], np.uint8)
+    want = int(np.float32(scales[0] * np.float32(255)) * np.float32(2 ** 32)) + int(np.float32(scales[1] * np.float32(3)) * np.float32(2 ** 32))
+    assert orc.descriptor_product(scales, desc, 1) == want
+    assert orc.descriptor_product(scales, desc, 0) == 0
+
+
+def test_adc_is_sequential_fp32_sum(orc):
+    g = np.load(os.path.join(GOLDEN, "pq_adc_4096.npz"))
+    lut, codes = g["lut"], g["codes"]
+    pq = orc.PQ(np.zeros((256, D), np.float32), np.eye(D, dtype=np.float32), 18, D)
+    got = pq.asymmetric_dot_product(lut, codes)
+    assert np.array_equal(got, g["adc"])
+    # literal restatement of vector.rs:393-404 for a few vectors
+    for j in (0, 1, 17, 4095):
+        s = np.float32(0)
+        for i in range(64):
+            s = np.float32(s + lut[i, codes[j, i]])
+        assert got[j] == int(np.float32(s * np.float32(2 ** 32)))
+    assert np.array_equal(pq.adc_desc(lut, codes, g["desc"], g["scales"]), g["adc_desc"])
+
+
+def test_quantize_first_max_wins_and_transform_orientation(orc):
+    d, dpc = 64, 16
+    # transform = permutation-like matrix so orientation T.x (not T^T.x) is visible (vector.rs:326)
+    T = np.zeros((d, d), np.float32)
+    for i in range(d):
+        T[i, (i + 1) % d] = 1.0       # (T x)[i] = x[i+1]
+    cents = np.zeros((4, d), np.float32)
+    cents[1, :] = 1.0
+    cents[2, :] = 1.0                 # duplicates of centroid 1 -> tie; first must win (:353-358)
+    cents[3, :] = -1.0
+    pq = orc.PQ(cents, T, dpc, d)
+    x = np.arange(d, dtype=np.float32)[None, :]
+    t = pq.apply_transform(x)
+    assert np.array_equal(t[0], np.roll(x[0], -1))
+    codes = pq.quantize_batch(np.ones((1, d), np.float32))
+    assert list(codes[0]) == [1, 1, 1, 1]
+    codes = pq.quantize_batch(-np.ones((1, d), np.float32))
+    assert list(codes[0]) == [3, 3, 3, 3]
+    codes = pq.quantize_batch(np.zeros((1, d), np.float32))   # all scores 0 -> first centroid
+    assert list(codes[0]) == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        orc.PQ(np.zeros((257, d), np.float32), T, dpc, d).quantize_batch(x)   # assert at :337
+
+
+def test_preprocess_query_matches_definition(orc):
+    rng = np.random.default_rng(2)
+    d, dpc, nc = 128, 16, 8
+    T = np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)
+    cents = rng.standard_normal((nc, d)).astype(np.float32)
+    pq = orc.PQ(cents, T, dpc, d)
+    q = rng.standard_normal(d).astype(np.float32)
+    lut = pq.preprocess_query(q)
+    t = (T.astype(np.float64) @ q.astype(np.float64))
+    want = np.einsum("iu,jiu->ij", t.reshape(d // dpc, dpc), cents.astype(np.float64).reshape(nc, d // dpc, dpc))
+    assert np.allclose(lut, want, rtol=1e-4, atol=1e-4)   # the transform itself is an fp32 GEMV
+
+
+def test_select_shard_last_max(orc):
+    # position_max_by_key returns the LAST maximum (src/query_disk_index.rs:254-256,447-450)
+    cents = np.array([[1, 0], [0, 1], [1, 0]], np.float32)
+    assert orc.select_shard(cents, np.array([1.0, 0.0], np.float32)) == 2
+    assert orc.select_shard(cents, np.array([0.0, 1.0], np.float32)) == 1
+
+
+def python_nb(cap):
+    """Literal Python restatement of diskann/src/lib.rs:93-147 for cross-checking the C oracle."""
+    state = {"ids": [], "scores": [], "visited": [], "next": None}
+
+    def search(score):
+        size = len(state["scores"])
+        if size == 0:
+            return 0
+        base = 0
+        while size > 1:
+            half = size // 2
+            mid = base + half
+            if not (score > state["scores"][mid]):
+                base = mid
+            size -= half
+        if score == state["scores"][base]:
+            return base
+        return base + (1 if score < state["scores"][base] else 0)
+
+    def insert(idx, score):
+        n = len(state["ids"])
+        if n == cap and state["scores"][n - 1] > score:
+            return
+        loc = search(score)
+        if loc < n and state["ids"][loc] == idx:
+            return
+        state["ids"].insert(loc, idx)
+        state["scores"].insert(loc, score)
+        state["visited"].insert(loc, 0)
+        del state["ids"][cap:], state["scores"][cap:], state["visited"][cap:]
+        state["next"] = loc if state["next"] is None else min(loc, state["next"])
+
+    def next_unvisited():
+        if state["next"] is None:
+            return None
+        cur = state["next"]
+        old = cur
+        state["visited"][cur] = 1
+        while cur < len(state["ids"]) and state["visited"][cur]:
+            cur += 1
+        state["next"] = None if cur == len(state["ids"]) else cur
+        return state["ids"][old]
+
+    return state, insert, next_unvisited
+
+
+def test_neighbour_buffer_trace(orc):
+    g = np.load(os.path.join(GOLDEN, "neighbour_buffer_trace.npz"))
+    nb = orc.NeighbourBuffer(int(g["cap"]))
+    state, insert, next_unvisited = python_nb(int(g["cap"]))
+    for step, (op, a, b) in enumerate(g["ops"]):
+        if op == 0:
+            nb.insert(int(a), int(b))
+            insert(int(a), int(b))
+        else:
+            r = nb.next_unvisited()
+            r2 = next_unvisited()
+            assert (-1 if r is None else r) == int(a) == (-1 if r2 is None else r2)
+        n = int(g["lens"][step])
+        assert len(nb) == n == len(state["ids"])
+        assert np.array_equal(nb.ids, g["ids"][step, :n]) and list(nb.ids) == state["ids"]
+        assert np.array_equal(nb.scores, g["scores"][step, :n]) and list(nb.scores) == state["scores"]
+        assert np.array_equal(nb.visited, g["visited"][step, :n])
+
+
+def test_neighbour_buffer_rules(orc):
+    nb = orc.NeighbourBuffer(3)
+    for idx, s in ((1, 10), (2, 30), (3, 20)):
+        nb.insert(idx, s)
+    assert list(nb.ids) == [2, 3, 1]
+    nb.insert(4, 5)            # full and worse than the last -> rejected (lib.rs:118)
+    assert list(nb.ids) == [2, 3, 1]
+    nb.insert(5, 10)           # full, EQUAL to the last -> proceeds, then truncated away or kept per search
+    assert len(nb) == 3
+    nb.insert(2, 30)           # same id found at its slot -> ignored (lib.rs:127-129)
+    assert list(nb.ids)[:1] == [2]
+    assert nb.next_unvisited() == 2 and nb.next_unvisited() == 3
+    nb.insert(9, 100)          # better than everything: becomes next unvisited
+    assert nb.next_unvisited() == 9
+
+
+def test_greedy_search_visits_and_orders(orc):
+    rng = np.random.default_rng(4)
+    n, deg = 300, 8
+    vecs = orc.gen_rows_f16(SEED_BASE, 0, n)
+    adj = rng.integers(0, n, size=(n, deg), dtype=np.uint32)
+    degs = np.full(n, deg, np.uint32)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 1)[0]
+    nb, dist = orc.greedy_search(vecs, adj, degs, 0, q, 32)
+    s = nb.scores
+    assert np.all(s[:-1] >= s[1:]) and dist > 0
+    exact = orc.score_all(vecs, q)
+    assert np.array_equal(exact[nb.ids], s)
+
+
+def test_index_semantics(orc):
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((500, 128)) / np.sqrt(128)).astype(np.float32)
+    codes = orc.f16_bits(x)
+    q = rng.standard_normal((3, 128)).astype(np.float32)
+    d0, l0 = orc.index_search(codes, q, 7, order=0)
+    d1, l1 = orc.index_search(codes, q, 7, order=1)
+    assert np.array_equal(l0, l1)                      # both summation orders rank this data identically
+    assert np.allclose(d0, d1, rtol=1e-5, atol=1e-6)
+    want = orc.f16_to_f32(codes).astype(np.float64) @ q.astype(np.float64).T
+    assert np.array_equal(np.argsort(-want[:, 0], kind="stable")[:7], l0[0])
+    d, l = orc.index_search(codes[:3], q[:1], 5, order=0)
+    assert list(l[0][3:]) == [-1, -1]
+
+
+def test_total_embedding(orc):
+    rng = np.random.default_rng(8)
+    e = orc.f16_bits(rng.standard_normal((3, 64)).astype(np.float32))
+    w = np.array([1.0, -0.5, 2.0], np.float32)
+    got = orc.total_embedding(e, w)
+    want = np.zeros(64, np.float32)
+    for i in range(3):
+        want += orc.f16_to_f32(e[i]) * w[i]
+    assert np.array_equal(got, want)
