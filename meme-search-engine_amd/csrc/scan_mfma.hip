@@ -7,22 +7,33 @@
 // (scan_exact.hip) and a certificate (topk.hip::finalize_kernel) proves that no row outside the
 // candidate groups can belong to the exact top-k; otherwise the caller widens the candidate set.
 //
-// Kernel: C[row, query] = sum_k X[row,k] * Q[query,k] with v_mfma_f32_16x16x32_f16.
+// Kernel: C[row, query] = sum_k X[row,k] * Q[query,k] with v_mfma_f32_16x16x32_f16, 8 waves per workgroup,
+// one workgroup per CU (128 KiB of LDS), persistent grid-stride over 256-row tiles.
 //   - a wave owns 32 base rows (two 16-row MFMA tiles, A operand) x 128 queries (eight 16-query column
 //     tiles, B operand; each B fragment read from LDS feeds two MFMAs).
-//   - base rows go HBM -> VGPR directly (no LDS round trip for the streamed operand).  The 16x16x32 A
-//     layout puts FOUR lanes on one matrix row (lane = row + 16*g, g = 8-element k group), so one
-//     global_load_dwordx4 reads 64 contiguous bytes from each of 16 rows.  (The 32x32x16 shape puts two
-//     lanes on a row, 32 B per row per instruction: measured ~4.0 TB/s at every prefetch depth and
-//     occupancy; this shape: 4.4-4.7 TB/s at 4 waves per workgroup.)
-//   - queries are re-tiled once per search into K-block-major, XOR-swizzled 16 KiB tiles
-//     (pack_queries_kernel) so that a tile is a linear copy into LDS and ds_read_b128 of the B fragments
-//     is bank-conflict free; tiles are double buffered in LDS, one barrier per 64-element K block.
-//     A workgroup of W waves shares one tile for 32*W rows: L2->LDS query traffic is 128/(32*W) of the
-//     HBM traffic, and it competes with the HBM stream for the CU's outstanding-miss slots, so W = 8.
+//   - base rows are streamed HBM -> LDS by the DMA path (global_load_lds, no VGPR staging).  Each wave DMAs
+//     exactly the 32 rows x 128 B it will consume into its OWN ring of S stages (4 KiB each), so the
+//     streamed operand needs no barrier: an LDS-DMA is ordered for a ds_read only by the issuing wave's
+//     vmcnt, and that wait is counted by hand (the loads of a K block are always issued in the same order).
+//     One DMA instruction moves 8 rows x 128 B, i.e. whole cache lines.  The LDS image of a DMA is
+//     lane-linear, so the bank-conflict swizzle is applied to the SOURCE address: LDS slot (row, s) holds
+//     global 16-byte piece s ^ f(row), f(row) = (row >> 1) & 7, and the A-fragment ds_read_b128 applies the
+//     same involution (measured SQ_LDS_BANK_CONFLICT = 0).
+//   - queries are re-tiled once per search into K-block-major, identically swizzled 16 KiB tiles
+//     (pack_queries_kernel); a tile is DMA'd linearly into a double buffer (2 instructions per wave), one
+//     barrier per 64-element K block.  The tile is shared by 256 rows, so L2->LDS query traffic is half the
+//     HBM traffic (it competes with the HBM stream for the CU's outstanding-miss slots).
 //   - epilogue per 32-row group: max over the rows of each query column -> group_max[group][q]
 //     (the level-0 array of the selection tournament).  4 bytes written per 32*2304 bytes read.
-// Roofline: HBM.  Algorithmic bytes = 2*d per base row per pass of <= 128 queries.
+// Roofline: HBM.  Algorithmic bytes = 2*d per base row per pass of <= 128 queries; PMC FETCH_SIZE (x2 on
+// gfx950, KiB) = 1.007 x that.
+//
+// Measured on MI355X at 1e7 x 1152 (profiles/): earlier variants of this kernel, kept here as a record of
+// what did not work --  32x32x16 MFMA with lane = row (32 B per row per load instruction): 3.9-4.2 TB/s at
+// every prefetch depth and occupancy; 16x16x32 with register-staged rows (64 B per row per instruction):
+// 4.4-4.7 TB/s at 4 waves, 5.0-5.2 TB/s at 8 waves per workgroup; non-temporal loads on partial lines: -25 %;
+// this DMA variant: 5.3-5.6 TB/s.  Ordinary (compiler-scheduled) loads are sunk next to their first use by
+// hipcc, which leaves them no flight time; hence hand-issued DMA + counted waits.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -37,6 +48,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BN = 128;           // queries per pass
 constexpr int KB = 64;            // contraction elements per K block
 constexpr int QT_SLOTS = BN * 8;  // 16-byte slots per query tile (16 KiB)
+constexpr int QT_BYTES = QT_SLOTS * 16;
+constexpr int W = 8;              // waves per workgroup
+constexpr int TILE_ROWS = 32 * W;
+constexpr int QI = QT_SLOTS / (W * 64);  // DMA instructions per wave per query tile (2)
 
 // packed[kb][q][slot ^ ((q>>1)&7)] = 16-byte slot `slot` of K block kb of query q
 __global__ void pack_queries_kernel(const uint16_t* __restrict__ queries, int d, uint4* __restrict__ packed) {
@@ -53,103 +68,70 @@ __global__ void pack_queries_kernel(const uint16_t* __restrict__ queries, int d,
 
 __device__ __forceinline__ half8 as_half8(const u32x4& v) { return __builtin_bit_cast(half8, v); }
 
-// ---- hand-issued global loads ------------------------------------------------------------------------
-// hipcc schedules an ordinary global load next to its first use; in this loop that is BELOW the MFMA block
-// of the same iteration, which leaves the load no flight time.  sched_barrier / sched_group_barrier /
-// volatile / asm memory clobbers either do not move the loads or cost more than they give (serialised
-// ds_read->MFMA, vmcnt(0) after every volatile load, spills).  So every VMEM load of the main loop is
-// issued by inline asm in program order and the vmcnt waits are counted by hand: per K block each lane
-// issues QL query-tile loads, then 4 base-row loads, always in that order.  Loads return in order, so
-// "at most N outstanding" identifies which ones have landed; the epilogue's stores share the counter
-// but can only make a wait stricter.  `vm_wait<N>` carries the registers it guards as in/out operands, so
-// the compiler cannot move their first use above the wait (cdna_hip_programming.md 5.7).
-template <int OFF> __device__ __forceinline__ void gload(u32x4& dst, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(dst) : "v"(p), "n"(OFF));
+// s_waitcnt vmcnt(N) placed by hand: the "memory" clobber keeps LDS reads below it, the sched_barrier keeps
+// register-only MFMAs from being hoisted above it (cdna_hip_programming.md 5.4 rule 18).
+template <int N> __device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
-template <int N> __device__ __forceinline__ void vm_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
-}
-template <int N> __device__ __forceinline__ void vm_wait(u32x4& a, u32x4& b) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-template <int N> __device__ __forceinline__ void vm_wait(u32x4& a) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N));
-}
-template <int N, int QL> __device__ __forceinline__ void vm_wait_q(u32x4 (&q)[QL]) {
-    if constexpr (QL == 4) vm_wait<N>(q[0], q[1], q[2], q[3]);
-    else if constexpr (QL == 2) vm_wait<N>(q[0], q[1]);
-    else vm_wait<N>(q[0]);
+// one LDS-DMA instruction: 16 bytes per lane, LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// P = depth of the register ring of X K-blocks (P-1 blocks in flight beyond the one being consumed);
-// nkb must be a multiple of P so that ring slots are compile-time constants.  W = waves per workgroup.
-template <int P, int W>
+// S = stages in each wave's ring of X K-blocks (S-1 blocks in flight beyond the one being consumed);
+// nkb must be a multiple of S so that stage indices are compile-time constants.
+template <int S>
 __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
                                                            const uint4* __restrict__ packed_ro,
                                                            float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
-    constexpr int THREADS = W * 64;
-    constexpr int TILE_ROWS = 32 * W;
-    constexpr int QL = QT_SLOTS / THREADS;  // query-tile slots copied per thread: 4 / 2 / 1
-    static_assert(QL == 4 || QL == 2 || QL == 1, "W must be 4, 8 or 16");
-    __shared__ u32x4 lds[2][QT_SLOTS];
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS in one object (5.x trap (a))
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int nkb = d / KB;
-    const int row_u4 = d / 8;  // 16-byte units per row
+    const size_t row_bytes = (size_t)d * 2;
     const int swz = (i >> 1) & 7;
     const size_t n_groups = (n_rows + 31) / 32;
-    const u32x4* packed = reinterpret_cast<const u32x4*>(packed_ro) + tid;  // this lane's first slot in a tile
+    char* const qbase = smem;                                     // [2][16 KiB] query tiles
+    char* const xbase = smem + 2 * QT_BYTES + wave * (S * 4096);  // this wave's ring: S stages x 4 KiB
+    const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)(wave * QI * 64 + lane) * 16;
 
     size_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
 
-    // pointer to this lane's 16-byte piece of K block 0 for its row in row tile rt
-    auto row_ptr = [&](size_t t, int rt) -> const u32x4* {
-        size_t row = t * TILE_ROWS + wave * 32 + rt * 16 + i;
+    // global source of this lane for DMA instruction u of a stage: row 8u + (lane>>3), piece (lane&7) ^ f(row).
+    // Rows past the end are clamped to the last row: they only duplicate a row of the same (last) group.
+    auto src_ptr = [&](size_t t, int u) -> const char* {
+        const int r = 8 * u + (lane >> 3);
+        size_t row = t * TILE_ROWS + wave * 32 + r;
         if (row >= n_rows) row = n_rows - 1;
-        return reinterpret_cast<const u32x4*>(base) + row * (size_t)row_u4 + g;
+        const int piece = (lane & 7) ^ ((r >> 1) & 7);
+        return reinterpret_cast<const char*>(base) + row * row_bytes + piece * 16;
     };
-    // one K block for this lane: [row tile][k step] -> bytes ks*64 + g*16 of the block
-    auto load_block = [&](u32x4(&dst)[4], const u32x4* p0, const u32x4* p1, int kblock) {
-        const u32x4* a0 = p0 + (size_t)kblock * 8;
-        const u32x4* a1 = p1 + (size_t)kblock * 8;
-        gload<0>(dst[0], a0);
-        gload<64>(dst[1], a0);
-        gload<0>(dst[2], a1);
-        gload<64>(dst[3], a1);
+    auto dma_x = [&](const char* (&rp)[4], int kblock, int stage) {
+        char* dst = xbase + stage * 4096;
+#pragma unroll
+        for (int u = 0; u < 4; u++) dma16(rp[u] + (size_t)kblock * 128, dst + u * 1024);
     };
-    // this thread's QL slots of query tile kblock (slot index tid + THREADS*u)
-    auto load_qtile = [&](u32x4(&dst)[QL], int kblock) {
-        const u32x4* src = packed + (size_t)kblock * QT_SLOTS;
-        if constexpr (QL == 4) {  // byte offsets 0 / 4096 / 8192 / 12288 (13-bit signed immediates)
-            gload<-4096>(dst[0], src + 256);
-            gload<0>(dst[1], src + 256);
-            gload<-4096>(dst[2], src + 768);
-            gload<0>(dst[3], src + 768);
-        } else if constexpr (QL == 2) {  // 0 / 8192
-            gload<0>(dst[0], src);
-            gload<0>(dst[1], src + 512);
-        } else {
-            gload<0>(dst[0], src);
-        }
+    auto dma_q = [&](int kblock, int qb) {
+        const char* src = packed + (size_t)kblock * QT_BYTES;
+        char* dst = qbase + qb * QT_BYTES + wave * (QI * 1024);
+#pragma unroll
+        for (int u = 0; u < QI; u++) dma16(src + u * 1024, dst + u * 1024);
     };
 
-    // prologue: query tile 0 into LDS buffer 0; X blocks 0..P-2 of the first tile into the ring.
-    // The counted waits in the loop assume the steady-state issue pattern, so drain the prologue completely.
-    u32x4 qreg[QL];
-    load_qtile(qreg, 0);
-    const u32x4* xp0 = row_ptr(tile, 0);
-    const u32x4* xp1 = row_ptr(tile, 1);
-    u32x4 xr[P][4];
+    const char* rp[4];
+    const char* rn[4];
 #pragma unroll
-    for (int j = 0; j < P - 1; j++) load_block(xr[j], xp0, xp1, j % nkb);
-    vm_wait_q<0, QL>(qreg);
+    for (int u = 0; u < 4; u++) rp[u] = src_ptr(tile, u);
+    // prologue: query tile 0 and X blocks 0..S-2; drained completely so the counted waits start in steady state
+    dma_q(0, 0);
 #pragma unroll
-    for (int j = 0; j < P - 1; j++) vm_wait<0>(xr[j][0], xr[j][1], xr[j][2], xr[j][3]);
-#pragma unroll
-    for (int u = 0; u < QL; u++) lds[0][tid + THREADS * u] = qreg[u];
-    __syncthreads();
+    for (int j = 0; j < S - 1; j++) dma_x(rp, j % nkb, j);
+    vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
 
     int buf = 0;
     while (true) {
@@ -163,29 +145,33 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
 
         const size_t next_tile = tile + gridDim.x;
         const bool has_next_tile = next_tile < n_tiles;
-        const u32x4* xn0 = has_next_tile ? row_ptr(next_tile, 0) : xp0;
-        const u32x4* xn1 = has_next_tile ? row_ptr(next_tile, 1) : xp1;
-
-        for (int kb0 = 0; kb0 < nkb; kb0 += P) {
 #pragma unroll
-            for (int j = 0; j < P; j++) {
-                const int kb = kb0 + j;
-                // ---- issue this iteration's loads: next query tile (QL), then the X block P-1 steps ahead (4)
-                load_qtile(qreg, kb + 1 == nkb ? 0 : kb + 1);
-                {
-                    const int kf = kb + P - 1;
-                    const bool wrap = kf >= nkb;
-                    load_block(xr[(j + P - 1) % P], wrap ? xn0 : xp0, wrap ? xn1 : xp1, wrap ? kf - nkb : kf);
-                }
-                // the X block consumed now was issued P-1 iterations ago: everything issued after it may stay in flight
-                vm_wait<(QL + 4) * (P - 1)>(xr[j][0], xr[j][1], xr[j][2], xr[j][3]);
+        for (int u = 0; u < 4; u++) rn[u] = has_next_tile ? src_ptr(next_tile, u) : rp[u];
 
-                // B fragments: software pipelined two column tiles ahead of the MFMAs that consume them
-                const u32x4* qt = lds[buf] + i * 8;
-                const int slot_a = g ^ swz, slot_b = (4 + g) ^ swz;  // k step 0 / 1
+        for (int kb0 = 0; kb0 < nkb; kb0 += S) {
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                const int kb = kb0 + j;
+                // ---- issue, always in this order: next query tile (QI), then the X block S-1 steps ahead (4)
+                dma_q(kb + 1 == nkb ? 0 : kb + 1, buf ^ 1);
+                {
+                    const int kf = kb + S - 1;
+                    if (kf >= nkb) dma_x(rn, kf - nkb, (j + S - 1) % S);  // first blocks of the next tile
+                    else dma_x(rp, kf, (j + S - 1) % S);
+                }
+                // the X block consumed now was issued S-1 iterations ago: everything issued after it may fly on.
+                // (DMAs return in order; the epilogue's stores share the counter and only make a wait stricter.)
+                vm_wait<(QI + 4) * (S - 1)>();
+
+                const u32x4* xs = reinterpret_cast<const u32x4*>(xbase + j * 4096) + i * 8;
+                const u32x4* qt = reinterpret_cast<const u32x4*>(qbase + buf * QT_BYTES) + i * 8;
+                const int slot_a = g ^ swz, slot_b = (4 + g) ^ swz;  // k step 0 / 1 of the K block
+                // B fragments are software pipelined one column-tile pair ahead of the MFMAs that consume them
                 u32x4 bq[2][2];
                 bq[0][0] = qt[0 * 128 + slot_a];
                 bq[0][1] = qt[1 * 128 + slot_a];
+                const half8 a00 = as_half8(xs[slot_a]), a10 = as_half8(xs[128 + slot_a]);  // row tile 0 / 1, k step 0
+                const half8 a01 = as_half8(xs[slot_b]), a11 = as_half8(xs[128 + slot_b]);  // k step 1
 #pragma unroll
                 for (int t = 0; t < 8; t++) {  // t = ks*4 + column-tile pair
                     const int ks = t >> 2, cp = t & 3;
@@ -195,8 +181,8 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
                         bq[(t + 1) & 1][1] = qt[(cp2 * 2 + 1) * 128 + (ks2 ? slot_b : slot_a)];
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the reads for t+1 ahead of the MFMAs of t
-                    const half8 a0 = as_half8(xr[j][ks]);
-                    const half8 a1 = as_half8(xr[j][2 + ks]);
+                    const half8 a0 = ks ? a01 : a00;
+                    const half8 a1 = ks ? a11 : a10;
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const half8 b = as_half8(bq[t & 1][e]);
@@ -205,11 +191,11 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
                         acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc[1][ct], 0, 0, 0);
                     }
                 }
-                // query tile for the next K block: only the 4 X loads issued after it may remain outstanding
-                vm_wait_q<4, QL>(qreg);
-#pragma unroll
-                for (int u = 0; u < QL; u++) lds[buf ^ 1][tid + THREADS * u] = qreg[u];
-                __syncthreads();
+                // next query tile: this wave's share has landed once only the 4 X DMAs issued after it remain;
+                // the barrier then makes every wave's share visible to all.  It also separates this iteration's
+                // reads of tile `buf` from the DMA that overwrites it two iterations later.
+                vm_wait<4>();
+                __builtin_amdgcn_s_barrier();
                 buf ^= 1;
             }
         }
@@ -227,27 +213,37 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
 
         if (!has_next_tile) break;
         tile = next_tile;
-        xp0 = xn0;
-        xp1 = xn1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) rp[u] = rn[u];
     }
-    // drain the loads still in flight before the wave ends (their destination registers die with it)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    vm_wait<0>();  // nothing may still be writing this workgroup's LDS when it is released
 }
 
-template <int P, int W>
-void launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
-                    float* group_max, int nq_pad) {
-    const size_t n_tiles = (n_rows + 32 * W - 1) / (32 * W);
+template <int S>
+int launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
+                   float* group_max, int nq_pad) {
+    const size_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     if (grid > n_tiles) grid = n_tiles;
-    hipLaunchKernelGGL((scan_mfma_kernel<P, W>), dim3((unsigned)grid), dim3(W * 64), 0, stream, base, n_rows, d, packed,
+    const size_t lds = 2 * QT_BYTES + (size_t)W * S * 4096;  // 128 KiB at S = 3
+    int dev = 0;
+    MSE_HIP_TRY(hipGetDevice(&dev));
+    static bool attr_set[64] = {};
+    if (dev < 64 && !attr_set[dev]) {
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_mfma_kernel<S>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((scan_mfma_kernel<S>), dim3((unsigned)grid), dim3(W * 64), lds, stream, base, n_rows, d, packed,
                        group_max, nq_pad, n_tiles);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 }  // namespace
 
 int mfma_query_tile() { return BN; }
 
-size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * QT_SLOTS * sizeof(uint4); }
+size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * QT_BYTES; }
 
 // packed_scratch: mfma_packed_bytes(d) bytes of device scratch owned by the caller (per searcher)
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
@@ -260,24 +256,16 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, packed);
     if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
     const int nkb = d / KB;
-    // developer knobs (defaults are the shipped configuration)
-    static const int env_p = getenv("MSE_SCAN_P") ? atoi(getenv("MSE_SCAN_P")) : 0;
-    static const int env_w = getenv("MSE_SCAN_W") ? atoi(getenv("MSE_SCAN_W")) : 8;
-    static const int env_wg = getenv("MSE_SCAN_WG") ? atoi(getenv("MSE_SCAN_WG")) : 1;
-    const size_t grid = (size_t)n_cu * env_wg;
-    int P = nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;
-    if (env_p && nkb % env_p == 0) P = env_p;
-#define MSE_LAUNCH(PP, WW) launch_variant<PP, WW>(grid, stream, base, n_rows, d, packed, group_max, nq_pad)
-#define MSE_LAUNCH_W(WW)                                                             \
-    do {                                                                             \
-        if (P == 3) MSE_LAUNCH(3, WW); else if (P == 2) MSE_LAUNCH(2, WW); else MSE_LAUNCH(1, WW); \
-    } while (0)
-    if (env_w == 4) MSE_LAUNCH_W(4);
-    else if (env_w == 16) MSE_LAUNCH_W(16);
-    else MSE_LAUNCH_W(8);
-#undef MSE_LAUNCH_W
-#undef MSE_LAUNCH
-    MSE_HIP_TRY(hipGetLastError());
+    // developer knob: ring depth (default 3 when the K-block count allows it)
+    static const int env_s = getenv("MSE_SCAN_S") ? atoi(getenv("MSE_SCAN_S")) : 0;
+    int S = nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;
+    if (env_s >= 1 && env_s <= 3 && nkb % env_s == 0) S = env_s;
+    const size_t grid = (size_t)n_cu;  // one 128-KiB workgroup per CU
+    int rc;
+    if (S == 3) rc = launch_variant<3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (S == 2) rc = launch_variant<2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else rc = launch_variant<1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    if (rc) return rc;
     if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));
     return 0;
 }
