@@ -171,6 +171,15 @@ def main():
         avg_scan_ms = scan_ms / max(scan_launches, 1)
         bytes_per_launch = (hi - lo) * D * 2
         achieved = bytes_per_launch / (avg_scan_ms * 1e-3) / 1e9 if scan_launches else None
+        # HBM traffic from the PMC passes (collected offline, one counter per rocprofv3 run -- it cannot be read
+        # inside a timed run); only reported when this run is the profiled configuration
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm["rows"] == hi - lo and pm["queries_per_launch"] == min(nq, 128):
+                traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "queries/sec over 1e8x1152 index @ recall@10>=0.95 (exact brute force: recall 1.0)",
             "value": qps,
@@ -190,7 +199,8 @@ def main():
                        "parallelism": f"row-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms,
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms,
                          "launches_timed": scan_launches},
             "verified_vs_exact_kernel": verified,
             "certificate": stats,
