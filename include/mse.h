@@ -163,6 +163,38 @@ int mse_greedy_search(mse_searcher* s, const uint32_t* adj, const uint32_t* deg,
                       const uint16_t* query, int base_vectors_only, uint32_t query_breakpoint, mse_nb* buf,
                       size_t* n_distances);
 
+/* ---- SigLIP ViT image tower: the in-process seam of clip_server.py, `fast_image_fns[batch](images NCHW
+ * fp16 on device) -> [batch, 1152]` (clip_server.py:31,66-82,105-112), plus the normalisation and fp16
+ * serialisation of do_inference / run_inference (clip_server.py:115,166).  Graph: aitemplate/model.py:13-123;
+ * hyper-parameters aitemplate/run.py:47-55; weight names clip_server.py:40-57 without the "visual." prefix. */
+typedef struct mse_siglip mse_siglip;
+typedef struct mse_siglip_config {
+    int img_size;    /* 384 */
+    int patch_size;  /* 14 */
+    int in_chans;    /* 3 */
+    int emb_dim;     /* 1152 */
+    int depth;       /* 27 */
+    int num_heads;   /* 16 */
+    int mlp_dim;     /* 4304 */
+    float eps;       /* LayerNorm epsilon, 1e-6 */
+    int gelu_tanh;   /* 0 = erf GELU (timm / AITemplate "gelu"), 1 = tanh approximation (HF / big_vision) */
+    int max_batch;   /* `max_batch_size` of clip_server_config.json */
+} mse_siglip_config;
+mse_siglip* mse_siglip_create(const mse_siglip_config* cfg);
+void mse_siglip_destroy(mse_siglip* m);
+int mse_siglip_n_weights(const mse_siglip* m);
+const char* mse_siglip_weight_name(const mse_siglip* m, int idx);   /* names the engine expects, sorted */
+/* fp32 host tensor in its state-dict shape (e.g. qkv.weight [3456,1152], patch_embed.proj.weight [1152,3,14,14]) */
+int mse_siglip_set_weight(mse_siglip* m, const char* name, const float* data, const size_t* shape, int ndim);
+int mse_siglip_finalize(mse_siglip* m);                              /* fails if a weight is missing */
+/* images: [batch,3,H,W], dtype 0 = f32 / 1 = f16, already normalised (x/127.5 - 1); batch > max_batch is an
+ * error (the reference asserts, clip_server.py:139).  Outputs (either may be NULL) are host [batch, emb_dim]. */
+int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on_device, int batch, int normalize,
+                            float* out_f32, uint16_t* out_f16);
+const void* mse_siglip_output_device(const mse_siglip* m, int which);  /* device result of the last call: 0 f32, 1 f16 */
+void* mse_siglip_stream(const mse_siglip* m);
+int mse_siglip_debug_residual(mse_siglip* m, float* out);             /* test hook: residual stream after the last block */
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -1,0 +1,44 @@
+// Internal launch interface of the SigLIP kernels (siglip_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <algorithm>
+
+namespace mse {
+namespace siglip {
+
+enum { GEMM_EPI_BF16 = 0, GEMM_EPI_GELU = 1, GEMM_EPI_RESID = 2, GEMM_EPI_PATCH = 3, GEMM_EPI_QKV = 4 };
+
+struct GemmLaunch {
+    const uint16_t* x = nullptr;   // [M][K] bf16
+    const uint16_t* w = nullptr;   // [N][K] bf16
+    const float* bias = nullptr;   // [N]
+    int M = 0, N = 0, K = 0, m_valid = 0;
+    uint16_t* out_bf16 = nullptr; int ldo = 0;
+    float* resid = nullptr; int ldr = 0;
+    const float* pos = nullptr; int tokens = 0;
+    uint16_t *q = nullptr, *k = nullptr, *vt = nullptr;
+    int heads = 0, dh = 0, dh_pad = 0, n_pad = 0, dv_pad = 0;
+    int gelu_tanh = 0;
+};
+
+int gemm_bm();
+int gemm_bn();
+int gemm_bk();
+int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
+int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int width, size_t rows,
+                     uint16_t* out, int ldo, float* out_f32, hipStream_t st);
+int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, uint16_t* out, hipStream_t st);
+int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
+                     int dh_pad, int dv_pad, uint16_t* out, int ldo, hipStream_t st);
+int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, float* out,
+                          int ldo, hipStream_t st);
+int launch_small_linear(const float* x, int ldx, const uint16_t* w, int ldw, const float* bias, int K, int N, int B, int act,
+                        const float* res, int ldres, float* y, int ldy, hipStream_t st);
+int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, float* out_f32, uint16_t* out_f16, hipStream_t st);
+int launch_f32_to_bf16_pad(const float* in, int rows, int cols, int ld_in, uint16_t* out, int rows_pad, int cols_pad,
+                           hipStream_t st);
+
+}  // namespace siglip
+}  // namespace mse

@@ -1,0 +1,298 @@
+// C ABI of the SigLIP image engine: the in-process seam the reference fills with its AITemplate engines,
+// `fast_image_fns[batch](images NCHW fp16 on device) -> [batch, 1152]` (clip_server.py:31,66-82,105-112),
+// followed by the L2 normalisation and fp16 serialisation of do_inference / run_inference
+// (clip_server.py:115,166).  Weights are addressed by the timm state-dict names the reference's loader maps
+// (clip_server.py:40-57, without the "visual." prefix).
+#include "../../include/mse.h"
+#include "runtime.h"
+#include "siglip.h"
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mse;
+using namespace mse::siglip;
+
+namespace {
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+struct Block {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    uint16_t *wqkv, *wproj, *w1, *w2;
+    float *bqkv, *bproj, *b1, *b2;
+};
+
+struct Slot {
+    enum Kind { F32, BF16_PAD } kind;
+    void* dst;
+    size_t rows, cols;          // logical shape of the source (product of leading dims, last dim)
+    size_t rows_pad, cols_pad;  // destination shape for BF16_PAD
+    bool loaded = false;
+};
+
+}  // namespace
+
+struct mse_siglip {
+    mse_siglip_config cfg{};
+    int tokens = 0, D = 0, H = 0, dh = 0, mlp = 0, mlp_pad = 0, kpe = 0, kpe_pad = 0;
+    int n_pad = 0, dh_pad = 96, dv_pad = 80;
+    int max_batch = 0;
+    size_t m_pad = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    std::map<std::string, Slot> slots;
+    bool finalized = false;
+    // parameters
+    uint16_t* wpe = nullptr; float* bpe = nullptr; float* pos = nullptr;
+    std::vector<Block> blocks;
+    float *lnf_g = nullptr, *lnf_b = nullptr;
+    float* latent = nullptr; uint16_t *wq = nullptr, *wkv = nullptr, *wpp = nullptr, *wp1 = nullptr, *wp2 = nullptr;
+    float *bq = nullptr, *bkv = nullptr, *bpp = nullptr, *lnp_g = nullptr, *lnp_b = nullptr, *bp1 = nullptr, *bp2 = nullptr;
+    float* qlat = nullptr;
+    // activations
+    void* img_dev = nullptr;
+    uint16_t *patches = nullptr, *h = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *kvb = nullptr;
+    float *x = nullptr, *pool_a = nullptr, *pool_o = nullptr, *pool_ln = nullptr, *pool_h = nullptr, *pool_f = nullptr;
+    float* out_f32 = nullptr; uint16_t* out_f16 = nullptr;
+    float* stage = nullptr; size_t stage_elems = 0;
+    int last_batch = 0;
+
+    template <typename T> T* dalloc(size_t n, bool zero = false) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n * sizeof(T), 256)) != hipSuccess) return nullptr;
+        if (zero && hipMemset(p, 0, std::max<size_t>(n * sizeof(T), 256)) != hipSuccess) return nullptr;
+        allocs.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+    void add_f32(const std::string& name, float** dst, size_t rows, size_t cols, size_t cols_pad = 0) {
+        const size_t cp = cols_pad ? cols_pad : cols;
+        *dst = dalloc<float>(rows * cp, true);
+        slots[name] = Slot{Slot::F32, *dst, rows, cols, rows, cp};
+    }
+    void add_bf16(const std::string& name, uint16_t** dst, size_t rows, size_t cols, size_t rows_pad, size_t cols_pad) {
+        *dst = dalloc<uint16_t>(rows_pad * cols_pad, true);
+        slots[name] = Slot{Slot::BF16_PAD, *dst, rows, cols, rows_pad, cols_pad};
+    }
+};
+
+extern "C" {
+
+mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
+    if (!c) { fail("null config"); return nullptr; }
+    // 384 / 14 = 27 patches per side: the stride-14 convolution simply ignores the last 6 pixels
+    if (c->emb_dim % 128 || c->num_heads <= 0 || c->emb_dim / c->num_heads != 72 || c->patch_size <= 0 ||
+        c->img_size < c->patch_size || c->max_batch <= 0) {
+        fail("siglip: unsupported geometry (emb_dim % 128 == 0, head_dim == 72 required)");
+        return nullptr;
+    }
+    mse_siglip* m = new (std::nothrow) mse_siglip();
+    if (!m) { fail("out of host memory"); return nullptr; }
+    m->cfg = *c;
+    const int g = c->img_size / c->patch_size;
+    m->tokens = g * g; m->D = c->emb_dim; m->H = c->num_heads; m->dh = m->D / m->H; m->mlp = c->mlp_dim;
+    m->mlp_pad = (int)round_up(m->mlp, 128);
+    m->kpe = c->in_chans * c->patch_size * c->patch_size; m->kpe_pad = (int)round_up(m->kpe, 64);
+    m->n_pad = (int)round_up(m->tokens, 32);
+    m->max_batch = c->max_batch;
+    m->m_pad = round_up((size_t)m->max_batch * m->tokens, 256);
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
+    const size_t D = m->D, MP = m->mlp_pad;
+    // parameters (names: clip_server.py:40-57)
+    m->add_bf16("trunk.patch_embed.proj.weight", &m->wpe, D, m->kpe, D, m->kpe_pad);
+    m->add_f32("trunk.patch_embed.proj.bias", &m->bpe, 1, D);
+    m->add_f32("trunk.pos_embed", &m->pos, m->tokens, D);
+    m->blocks.resize(c->depth);
+    for (int i = 0; i < c->depth; i++) {
+        Block& b = m->blocks[i];
+        const std::string p = "trunk.blocks." + std::to_string(i) + ".";
+        m->add_f32(p + "norm1.weight", &b.ln1_g, 1, D); m->add_f32(p + "norm1.bias", &b.ln1_b, 1, D);
+        m->add_bf16(p + "attn.qkv.weight", &b.wqkv, 3 * D, D, 3 * D, D); m->add_f32(p + "attn.qkv.bias", &b.bqkv, 1, 3 * D);
+        m->add_bf16(p + "attn.proj.weight", &b.wproj, D, D, D, D); m->add_f32(p + "attn.proj.bias", &b.bproj, 1, D);
+        m->add_f32(p + "norm2.weight", &b.ln2_g, 1, D); m->add_f32(p + "norm2.bias", &b.ln2_b, 1, D);
+        m->add_bf16(p + "mlp.fc1.weight", &b.w1, m->mlp, D, MP, D); m->add_f32(p + "mlp.fc1.bias", &b.b1, 1, m->mlp, MP);
+        m->add_bf16(p + "mlp.fc2.weight", &b.w2, D, m->mlp, D, MP); m->add_f32(p + "mlp.fc2.bias", &b.b2, 1, D);
+    }
+    m->add_f32("trunk.norm.weight", &m->lnf_g, 1, D); m->add_f32("trunk.norm.bias", &m->lnf_b, 1, D);
+    const std::string ap = "trunk.attn_pool.";
+    m->add_f32(ap + "latent", &m->latent, 1, D);
+    m->add_bf16(ap + "q.weight", &m->wq, D, D, D, D); m->add_f32(ap + "q.bias", &m->bq, 1, D);
+    m->add_bf16(ap + "kv.weight", &m->wkv, 2 * D, D, 2 * D, D); m->add_f32(ap + "kv.bias", &m->bkv, 1, 2 * D);
+    m->add_bf16(ap + "proj.weight", &m->wpp, D, D, D, D); m->add_f32(ap + "proj.bias", &m->bpp, 1, D);
+    m->add_f32(ap + "norm.weight", &m->lnp_g, 1, D); m->add_f32(ap + "norm.bias", &m->lnp_b, 1, D);
+    m->add_bf16(ap + "mlp.fc1.weight", &m->wp1, m->mlp, D, m->mlp, D); m->add_f32(ap + "mlp.fc1.bias", &m->bp1, 1, m->mlp);
+    m->add_bf16(ap + "mlp.fc2.weight", &m->wp2, D, m->mlp, D, m->mlp); m->add_f32(ap + "mlp.fc2.bias", &m->bp2, 1, D);
+    // activations
+    const size_t B = m->max_batch, M = m->m_pad, BH = B * m->H;
+    m->img_dev = m->dalloc<float>(B * c->in_chans * c->img_size * c->img_size);
+    m->patches = m->dalloc<uint16_t>(M * m->kpe_pad, true);
+    m->x = m->dalloc<float>(M * D, true);
+    m->h = m->dalloc<uint16_t>(M * D, true);
+    m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
+    m->qb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
+    m->kb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
+    m->vtb = m->dalloc<uint16_t>(BH * m->dv_pad * m->n_pad, true);
+    m->kvb = m->dalloc<uint16_t>(M * 2 * D, true);
+    m->qlat = m->dalloc<float>(D, true);
+    m->pool_a = m->dalloc<float>(B * D); m->pool_o = m->dalloc<float>(B * D); m->pool_ln = m->dalloc<float>(B * D);
+    m->pool_h = m->dalloc<float>(B * m->mlp); m->pool_f = m->dalloc<float>(B * D);
+    m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
+    bool ok = m->img_dev && m->patches && m->x && m->h && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat &&
+              m->pool_a && m->pool_o && m->pool_ln && m->pool_h && m->pool_f && m->out_f32 && m->out_f16;
+    for (auto& kv : m->slots) ok = ok && kv.second.dst;
+    if (!ok) { mse_siglip_destroy(m); fail("siglip: device allocation failed"); return nullptr; }
+    return m;
+}
+
+void mse_siglip_destroy(mse_siglip* m) {
+    if (!m) return;
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stage) (void)hipFree(m->stage);
+    delete m;
+}
+
+int mse_siglip_n_weights(const mse_siglip* m) { return m ? (int)m->slots.size() : 0; }
+
+// name of weight #idx (sorted), or NULL; lets a loader enumerate what the engine expects
+const char* mse_siglip_weight_name(const mse_siglip* m, int idx) {
+    if (!m || idx < 0 || idx >= (int)m->slots.size()) return nullptr;
+    auto it = m->slots.begin();
+    std::advance(it, idx);
+    return it->first.c_str();
+}
+
+int mse_siglip_set_weight(mse_siglip* m, const char* name, const float* data, const size_t* shape, int ndim) {
+    if (!m || !name || !data) return fail("siglip_set_weight: null argument");
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) return fail(std::string("siglip: unknown weight '") + name + "'");
+    Slot& s = it->second;
+    size_t total = 1;
+    for (int i = 0; i < ndim; i++) total *= shape[i];
+    if (total != s.rows * s.cols) return fail(std::string("siglip: wrong size for '") + name + "'");
+    if (m->stage_elems < total) {
+        if (m->stage) (void)hipFree(m->stage);
+        m->stage = nullptr;
+        MSE_HIP_TRY(hipMalloc((void**)&m->stage, total * 4));
+        m->stage_elems = total;
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(m->stage, data, total * 4, hipMemcpyHostToDevice, m->stream));
+    if (s.kind == Slot::F32) {
+        if (s.cols_pad == s.cols) {
+            MSE_HIP_TRY(hipMemcpyAsync(s.dst, m->stage, total * 4, hipMemcpyDeviceToDevice, m->stream));
+        } else {
+            MSE_HIP_TRY(hipMemcpy2DAsync(s.dst, s.cols_pad * 4, m->stage, s.cols * 4, s.cols * 4, s.rows, hipMemcpyDeviceToDevice,
+                                         m->stream));
+        }
+    } else {
+        if (launch_f32_to_bf16_pad(m->stage, (int)s.rows, (int)s.cols, (int)s.cols, reinterpret_cast<uint16_t*>(s.dst),
+                                   (int)s.rows_pad, (int)s.cols_pad, m->stream)) return -1;
+    }
+    MSE_HIP_TRY(hipStreamSynchronize(m->stream));
+    s.loaded = true;
+    m->finalized = false;
+    return 0;
+}
+
+int mse_siglip_finalize(mse_siglip* m) {
+    if (!m) return fail("null engine");
+    for (auto& kv : m->slots)
+        if (!kv.second.loaded) return fail("siglip: weight '" + kv.first + "' was never set");
+    // the pooling query does not depend on the input: q = Linear(latent)   (model.py:94-95)
+    if (launch_small_linear(m->latent, m->D, m->wq, m->D, m->bq, m->D, m->D, 1, 0, nullptr, 0, m->qlat, m->D, m->stream)) return -1;
+    MSE_HIP_TRY(hipStreamSynchronize(m->stream));
+    m->finalized = true;
+    return 0;
+}
+
+int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on_device, int batch, int normalize,
+                            float* out_f32, uint16_t* out_f16) {
+    if (!m) return fail("null engine");
+    if (!m->finalized) return fail("siglip: call mse_siglip_finalize after loading the weights");
+    if (batch <= 0 || batch > m->max_batch) return fail("siglip: batch exceeds max_batch");  // clip_server.py:139
+    if (dtype != 0 && dtype != 1) return fail("siglip: dtype must be 0 (f32) or 1 (f16)");
+    hipStream_t st = m->stream;
+    const mse_siglip_config& c = m->cfg;
+    const size_t img_elems = (size_t)batch * c.in_chans * c.img_size * c.img_size;
+    const void* img = images;
+    if (!on_device) {
+        MSE_HIP_TRY(hipMemcpyAsync(m->img_dev, images, img_elems * (dtype ? 2 : 4), hipMemcpyHostToDevice, st));
+        img = m->img_dev;
+    }
+    const int D = m->D, T = m->tokens;
+    const int M = batch * T;
+    const int Mp = (int)round_up(M, 256);
+    const int gelu_tanh = c.gelu_tanh;
+    // PatchEmbedder + PositionalEmbeddings (model.py:57-80,122)
+    if (launch_patchify(img, dtype, batch, c.in_chans, c.img_size, c.img_size, c.patch_size, m->kpe_pad, m->patches, st)) return -1;
+    {
+        GemmLaunch g; g.x = m->patches; g.w = m->wpe; g.bias = m->bpe; g.M = Mp; g.N = D; g.K = m->kpe_pad; g.m_valid = M;
+        g.resid = m->x; g.ldr = D; g.pos = m->pos; g.tokens = T;
+        if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
+    }
+    for (int i = 0; i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
+        const Block& b = m->blocks[i];
+        if (launch_layernorm(m->x, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
+            g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+            g.dv_pad = m->dv_pad;
+            if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
+        }
+        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M;
+            g.resid = m->x; g.ldr = D;
+            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+        }
+        if (launch_layernorm(m->x, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
+            g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
+            if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
+        }
+        {
+            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M;
+            g.resid = m->x; g.ldr = D;
+            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+        }
+    }
+    if (launch_layernorm(m->x, D, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
+    // MAPHead (model.py:82-111)
+    {
+        GemmLaunch g; g.x = m->h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
+        g.out_bf16 = m->kvb; g.ldo = 2 * D;
+        if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
+    }
+    if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, m->pool_a, D, st)) return -1;
+    if (launch_small_linear(m->pool_a, D, m->wpp, D, m->bpp, D, D, batch, 0, nullptr, 0, m->pool_o, D, st)) return -1;
+    if (launch_layernorm(m->pool_o, D, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
+    if (launch_small_linear(m->pool_ln, D, m->wp1, D, m->bp1, D, m->mlp, batch, gelu_tanh ? 2 : 1, nullptr, 0, m->pool_h, m->mlp,
+                            st)) return -1;
+    if (launch_small_linear(m->pool_h, m->mlp, m->wp2, m->mlp, m->bp2, m->mlp, D, batch, 0, m->pool_o, D, m->pool_f, D, st))
+        return -1;
+    // features /= norm (clip_server.py:115); fp16 rows are what the server serialises (clip_server.py:166)
+    if (launch_l2norm(m->pool_f, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
+    if (out_f32) MSE_HIP_TRY(hipMemcpyAsync(out_f32, m->out_f32, (size_t)batch * D * 4, hipMemcpyDeviceToHost, st));
+    if (out_f16) MSE_HIP_TRY(hipMemcpyAsync(out_f16, m->out_f16, (size_t)batch * D * 2, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    m->last_batch = batch;
+    return 0;
+}
+
+// device pointer to the [batch][emb] fp32 (which = 0) / fp16 (which = 1) result of the last call
+const void* mse_siglip_output_device(const mse_siglip* m, int which) { return m ? (which ? (const void*)m->out_f16 : (const void*)m->out_f32) : nullptr; }
+
+void* mse_siglip_stream(const mse_siglip* m) { return m ? (void*)m->stream : nullptr; }
+
+// test hook: the residual stream ([batch*tokens][emb] fp32) as left by the last forward (after the last block)
+int mse_siglip_debug_residual(mse_siglip* m, float* out) {
+    if (!m || !m->last_batch) return fail("siglip: no forward has run");
+    MSE_HIP_TRY(hipMemcpy(out, m->x, (size_t)m->last_batch * m->tokens * m->D * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,578 @@
+// SigLIP ViT-SO400M/14 image tower kernels (bf16 inputs, fp32 accumulation) for gfx950.
+//
+// Graph being executed: the reference's own restatement of the model, aitemplate/model.py:13-123
+// (PatchEmbedder, PositionalEmbeddings, 27 x Encoder1DBlock, final LayerNorm, MAPHead); hyper-parameters
+// aitemplate/run.py:47-55; weight names clip_server.py:40-57.  The fused ops the reference's AITemplate
+// engine uses map to the kernels here: Conv2dBias(k=s=14) -> patchify + GEMM(+bias+pos), LayerNorm,
+// Linear(+bias), Linear specialization="gelu", Linear specialization="add" (bias + residual),
+// mem-efficient MultiheadAttention -> flash-style attention, ScaledDotProductAttention 1x729 -> pool kernel.
+//
+// GEMM  C[m][n] = sum_k X[m][k] * Wt[n][k]  (both operands K-contiguous), v_mfma_f32_16x16x32_bf16 with the
+// WEIGHT rows as the MFMA A operand and the activation rows as B, so a lane of the accumulator holds four
+// consecutive n for one m (8-byte bf16 / 16-byte fp32 stores).  Workgroup = 8 waves, tile 256 (m) x 128 (n),
+// K step 64; both operand tiles are streamed L2/HBM -> LDS by LDS-DMA into a 3-stage ring with hand-counted
+// vmcnt waits and one barrier per K step (the structure scan_mfma.hip measures at 5.6 TB/s); the
+// bank-conflict swizzle is applied on the DMA source address.  MFMA bound; roofline = 2.5 PFLOP/s dense bf16.
+#include "common.h"
+#include "siglip.h"
+
+namespace mse {
+namespace siglip {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 as_bf8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round to nearest even, NaN kept quiet
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+template <int N> __device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------------------------------------
+constexpr int BM = 256, BN = 128, BK = 64, GW = 8, GS = 3;
+constexpr int XT_BYTES = BM * BK * 2;  // 32 KiB
+constexpr int WT_BYTES = BN * BK * 2;  // 16 KiB
+constexpr int STAGE_BYTES = XT_BYTES + WT_BYTES;
+
+struct GemmArgs {
+    const uint16_t* x;    // [M_pad][K] bf16 activations
+    const uint16_t* w;    // [N_pad][K] bf16 weights (row n = output feature n)
+    const float* bias;    // [N_pad]
+    int M, N, K;          // padded sizes: M % 256 == 0, N % 128 == 0, K % 64 == 0
+    int m_valid;          // rows < m_valid are real
+    // epilogue targets
+    uint16_t* out_bf16;   // EPI_BF16 / EPI_GELU: [M][ldo]
+    int ldo;
+    float* resid;         // EPI_RESID: x[M][ldr] += acc + bias ; EPI_PATCH: x = acc + bias + pos
+    int ldr;
+    const float* pos;     // EPI_PATCH: [tokens][ldr]
+    int tokens;           // tokens per image (729)
+    uint16_t *q, *k, *vt; // EPI_QKV scatter targets
+    int heads, dh, dh_pad, n_pad, dv_pad;  // attention geometry
+    int gelu_tanh;
+};
+
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4 };
+
+template <int EPI>
+__global__ __launch_bounds__(GW * 64) void gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int swz = (i >> 1) & 7;
+    const int wm = wave >> 1, wn = wave & 1;  // 4 (m) x 2 (n) waves, each 64 x 64
+    const int n_blocks = a.N / BN, m_blocks = a.M / BM;
+    // XCD-aware order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous run of
+    // tiles (bijective form), n fastest, so that an activation tile is reused out of that XCD's L2
+    const int nwg = n_blocks * m_blocks;
+    int b = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8, idx = b / 8;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int mb = b / n_blocks, nb = b % n_blocks;
+    const size_t m0 = (size_t)mb * BM, n0 = (size_t)nb * BN;
+    const size_t kbytes = (size_t)a.K * 2;
+
+    // DMA sources: X tile = 32 instructions (8 rows x 128 B each) -> 4 per wave; W tile = 16 -> 2 per wave
+    const char* xsrc[4];
+    const char* wsrc[2];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int r = (wave * 4 + u) * 8 + (lane >> 3);
+        xsrc[u] = reinterpret_cast<const char*>(a.x) + (m0 + r) * kbytes + (((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int r = (wave * 2 + u) * 8 + (lane >> 3);
+        wsrc[u] = reinterpret_cast<const char*>(a.w) + (n0 + r) * kbytes + (((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    }
+    auto issue = [&](int kstep, int stage) {
+        char* xs = smem + stage * STAGE_BYTES;
+        char* ws = xs + XT_BYTES;
+#pragma unroll
+        for (int u = 0; u < 4; u++) dma16(xsrc[u] + (size_t)kstep * (BK * 2), xs + (wave * 4 + u) * 1024);
+#pragma unroll
+        for (int u = 0; u < 2; u++) dma16(wsrc[u] + (size_t)kstep * (BK * 2), ws + (wave * 2 + u) * 1024);
+    };
+
+    float4v acc[4][4];  // [n tile][m tile]
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[nt][mt][r] = 0.0f;
+
+    const int nk = a.K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt must have landed: at most the 6 DMAs of stage kt+1 may still be in flight
+        if (kt + 1 < nk) vm_wait<6>(); else vm_wait<0>();
+        __builtin_amdgcn_s_barrier();  // every wave's share is in LDS; everyone has finished reading stage kt-1
+        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % GS);
+        const char* xs = smem + (kt % GS) * STAGE_BYTES;
+        const u32x4* xt = reinterpret_cast<const u32x4*>(xs) + (wm * 64 + i) * 8;
+        const u32x4* wt = reinterpret_cast<const u32x4*>(xs + XT_BYTES) + (wn * 64 + i) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int slot = (ks * 4 + g) ^ swz;
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                af[t] = as_bf8(wt[t * 128 + slot]);
+                bfr[t] = as_bf8(xt[t * 128 + slot]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds m = m0 + wm*64 + mt*16 + i, n = n0 + wn*64 + nt*16 + 4g + r
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        const size_t m = m0 + wm * 64 + mt * 16 + i;
+        const bool mok = m < (size_t)a.m_valid;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int n = (int)n0 + wn * 64 + nt * 16 + 4 * g;
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+            float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y;
+            float v2 = acc[nt][mt][2] + bv.z, v3 = acc[nt][mt][3] + bv.w;
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+                if constexpr (EPI == EPI_GELU) {
+                    if (a.gelu_tanh) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+                    else { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                }
+                if (!mok) { v0 = v1 = v2 = v3 = 0.0f; }
+                uint2 o{pack2(v0, v1), pack2(v2, v3)};
+                *reinterpret_cast<uint2*>(a.out_bf16 + m * a.ldo + n) = o;
+            } else if constexpr (EPI == EPI_RESID) {
+                if (mok) {
+                    float4* p = reinterpret_cast<float4*>(a.resid + m * a.ldr + n);
+                    float4 x = *p;
+                    x.x += v0; x.y += v1; x.z += v2; x.w += v3;
+                    *p = x;
+                }
+            } else if constexpr (EPI == EPI_PATCH) {
+                if (mok) {
+                    const int tok = (int)(m % a.tokens);
+                    const float4 pv = *reinterpret_cast<const float4*>(a.pos + (size_t)tok * a.ldr + n);
+                    *reinterpret_cast<float4*>(a.resid + m * a.ldr + n) = float4{v0 + pv.x, v1 + pv.y, v2 + pv.z, v3 + pv.w};
+                }
+            } else {  // EPI_QKV: n in [0, 3*D): which = n / D, head = (n % D) / dh, e = (n % D) % dh
+                if (mok) {
+                    const int D = a.heads * a.dh;
+                    const int bi = (int)(m / a.tokens), tok = (int)(m % a.tokens);
+                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int nn = n + r;
+                        const int which = nn / D, rem = nn % D, head = rem / a.dh, e = rem % a.dh;
+                        const size_t bh = (size_t)bi * a.heads + head;
+                        if (which == 0) a.q[(bh * a.n_pad + tok) * a.dh_pad + e] = f2bf(vv[r]);
+                        else if (which == 1) a.k[(bh * a.n_pad + tok) * a.dh_pad + e] = f2bf(vv[r]);
+                        else a.vt[(bh * a.dv_pad + e) * a.n_pad + tok] = f2bf(vv[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over rows of `width` fp32 -> bf16 (one wave per row)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int width, size_t rows,
+                                                        uint16_t* __restrict__ out, int ldo, float* __restrict__ out_f32) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float s = 0.0f, ss = 0.0f;
+    for (int c = lane * 4; c < width; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        s += v.x + v.y + v.z + v.w;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)width;
+    for (int c = lane * 4; c < width; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss / (float)width + eps);
+    for (int c = lane * 4; c < width; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+        const float y0 = (v.x - mean) * rstd * gm.x + bt.x, y1 = (v.y - mean) * rstd * gm.y + bt.y;
+        const float y2 = (v.z - mean) * rstd * gm.z + bt.z, y3 = (v.w - mean) * rstd * gm.w + bt.w;
+        if (out) *reinterpret_cast<uint2*>(out + row * ldo + c) = uint2{pack2(y0, y1), pack2(y2, y3)};
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * ldo + c) = float4{y0, y1, y2, y3};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// patchify: NCHW image (fp16 / fp32) -> [B*tokens][K_pad] bf16 rows ordered (c, ky, kx) like the conv weight
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, int Wd, int P, int k_pad,
+                                uint16_t* __restrict__ out) {
+    const int gw = Wd / P, gh = H / P, tokens = gw * gh, kk = C * P * P;
+    const size_t total = (size_t)B * tokens * k_pad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx % k_pad);
+        const size_t row = idx / k_pad;
+        float v = 0.0f;
+        if (col < kk) {
+            const int b = (int)(row / tokens), t = (int)(row % tokens);
+            const int py = t / gw, px = t % gw;
+            const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+            v = (float)img[(((size_t)b * C + c) * H + py * P + ky) * Wd + px * P + kx];
+        }
+        out[idx] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Self attention, flash style, "swapped" products so that all softmax state is per lane:
+//   St[key][query] = K . Q^T   (A = K rows, B = Q rows)     -> lane (query = lane&15) holds 4 keys per 16-key tile
+//   Ot[e][query]  += Vt . P^T  (A = Vt rows, B = P)          -> lane (query) holds e = 16t + 4g + r
+// The contraction index of the second product is the key index in the order the first product leaves it in
+// registers (keys {4g..4g+3} of tile 0, then of tile 1), so P never moves between lanes; Vt is read in the
+// same order.  One wave = 16 queries; K / Vt fragments come straight from L2 (they are re-read by every
+// query block of the same (image, head)).  dh = 72 is padded to 96 for Q.K^T (3 MFMA k steps of 32) and to
+// 80 for the output (5 row tiles of 16).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                        const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
+                                                        int dh, int dh_pad, int dv_pad, float scale_log2e,
+                                                        uint16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int qblocks = (tokens + 63) / 64;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    const int q0 = qb * 64 + wave * 16;
+    if (q0 >= tokens) return;
+    const uint16_t* qp = q + ((size_t)bh * n_pad + q0 + i) * dh_pad;
+    const uint16_t* kp = k + (size_t)bh * n_pad * dh_pad;
+    const uint16_t* vp = vt + (size_t)bh * dv_pad * n_pad;
+    // Q fragments (B operand): lane (query i, k group g) -> dh 32*ks + 8g .. +8
+    bf16x8 qf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++) qf[ks] = as_bf8(*reinterpret_cast<const u32x4*>(qp + ks * 32 + g * 8));
+    float4v o[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[t][r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+    for (int kt = 0; kt < n_pad; kt += 32) {
+        float4v s[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) s[h2][r] = 0.0f;
+            const uint16_t* krow = kp + (size_t)(kt + h2 * 16 + i) * dh_pad;
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                const bf16x8 kf = as_bf8(*reinterpret_cast<const u32x4*>(krow + ks * 32 + g * 8));
+                s[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[h2], 0, 0, 0);
+            }
+        }
+        // lane holds St[key = kt + 16*h2 + 4g + r][query i]; mask padded keys
+        float mx = -1e30f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = kt + h2 * 16 + 4 * g + r;
+                s[h2][r] = key < tokens ? s[h2][r] * scale_log2e : -1e30f;
+                mx = fmaxf(mx, s[h2][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.0f;
+        float p[8];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                p[h2 * 4 + r] = exp2f(s[h2][r] - m_new);
+                psum += p[h2 * 4 + r];
+            }
+        psum += __shfl_xor(psum, 16);
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        const u32x4 pb{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])};
+        const bf16x8 pf = as_bf8(pb);
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[t][r] *= alpha;
+            // A operand: Vt row e = 16t + i, contraction slots = keys {kt+4g..+3, kt+16+4g..+3}
+            const uint16_t* vrow = vp + (size_t)(t * 16 + i) * n_pad + kt + 4 * g;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+            const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+        }
+    }
+    const int tok = q0 + i;
+    if (tok < tokens) {
+        const float inv = 1.0f / l_run;
+        const int b = bh / heads, hd = bh % heads;
+        uint16_t* op = out + ((size_t)b * tokens + tok) * ldo + hd * dh;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const int e = t * 16 + 4 * g;
+            if (e < dh) *reinterpret_cast<uint2*>(op + e) = uint2{pack2(o[t][0] * inv, o[t][1] * inv), pack2(o[t][2] * inv, o[t][3] * inv)};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention pooling (MAP head): one latent query per image, 16 heads, keys/values = kv projection of the
+// tokens (model.py:93-101).  One workgroup per (image, head); fp32 math on the vector ALU (1x729 is tiny).
+// kv: [B*tokens][2*D] bf16 (k = cols [0,D), v = cols [D,2D)); qlat: [D] fp32 (probe already projected).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_attention_kernel(const uint16_t* __restrict__ kv, int ldkv,
+                                                             const float* __restrict__ qlat, int heads, int dh,
+                                                             int tokens, float scale, float* __restrict__ out, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sc = sm;             // [tokens]
+    float* red = sm + tokens;   // [256]
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int D = heads * dh;
+    const int tid = threadIdx.x;
+    const float* qh = qlat + hd * dh;
+    float lmax = -1e30f;
+    for (int t = tid; t < tokens; t += blockDim.x) {
+        const uint16_t* kr = kv + ((size_t)b * tokens + t) * ldkv + hd * dh;
+        float s = 0.0f;
+        for (int e = 0; e < dh; e++) s = fmaf(qh[e], bf2f(kr[e]), s);
+        s *= scale;
+        sc[t] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    red[tid] = lmax;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    __syncthreads();
+    float lsum = 0.0f;
+    for (int t = tid; t < tokens; t += blockDim.x) {
+        const float p = expf(sc[t] - mx);
+        sc[t] = p;
+        lsum += p;
+    }
+    red[tid] = lsum;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+    // out[e] = sum_t p[t] * v[t][e]: thread e handles one output feature
+    for (int e = tid; e < dh; e += blockDim.x) {
+        float acc = 0.0f;
+        for (int t = 0; t < tokens; t++) acc = fmaf(sc[t], bf2f(kv[((size_t)b * tokens + t) * ldkv + D + hd * dh + e]), acc);
+        out[(size_t)b * ldo + hd * dh + e] = acc * inv;
+    }
+}
+
+// small dense layer on the vector ALU for the B-row tail of the MAP head: y[b][n] = act(x[b] . w[n] + bias[n]) (+ res)
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int ldx, const uint16_t* __restrict__ w,
+                                                           int ldw, const float* __restrict__ bias, int K, int N, int B,
+                                                           int act /*0 none, 1 gelu erf, 2 gelu tanh*/,
+                                                           const float* __restrict__ res, int ldres, float* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wid >= (size_t)B * N) return;
+    const int b = (int)(wid / N), n = (int)(wid % N);
+    const float* xr = x + (size_t)b * ldx;
+    const uint16_t* wr = w + (size_t)n * ldw;
+    float s = 0.0f;
+    for (int kk = lane; kk < K; kk += 64) s = fmaf(xr[kk], bf2f(wr[kk]), s);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        s += bias[n];
+        if (act == 1) s = gelu_erf(s); else if (act == 2) s = gelu_tanh(s);
+        if (res) s += res[(size_t)b * ldres + n];
+        y[(size_t)b * ldy + n] = s;
+    }
+}
+
+__global__ void l2norm_kernel(const float* __restrict__ x, int ldx, int width, int B, int normalize, float* __restrict__ out_f32,
+                              uint16_t* __restrict__ out_f16) {
+    const int b = blockIdx.x, lane = threadIdx.x;  // 64 threads
+    float ss = 0.0f;
+    for (int c = lane; c < width; c += 64) { const float v = x[(size_t)b * ldx + c]; ss = fmaf(v, v, ss); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    const float inv = normalize ? 1.0f / sqrtf(ss) : 1.0f;
+    for (int c = lane; c < width; c += 64) {
+        const float v = x[(size_t)b * ldx + c] * inv;
+        if (out_f32) out_f32[(size_t)b * width + c] = v;
+        if (out_f16) { const _Float16 h = (_Float16)v; out_f16[(size_t)b * width + c] = __builtin_bit_cast(uint16_t, h); }
+    }
+}
+
+__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, int cols, int ld_in, uint16_t* __restrict__ out,
+                                       int rows_pad, int cols_pad) {
+    const size_t total = (size_t)rows_pad * cols_pad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / cols_pad), c = (int)(idx % cols_pad);
+        out[idx] = (r < rows && c < cols) ? f2bf(in[(size_t)r * ld_in + c]) : (uint16_t)0;
+    }
+}
+
+template <int EPI> int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)GS * STAGE_BYTES;
+    int dev = 0;
+    MSE_HIP_TRY(hipGetDevice(&dev));
+    static bool attr_set[64] = {};
+    if (dev < 64 && !attr_set[dev]) {
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), lds, st, a);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int gemm_bm() { return BM; }
+int gemm_bn() { return BN; }
+int gemm_bk() { return BK; }
+
+int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
+    if (g.M % BM || g.N % BN || g.K % BK) return fail("gemm: sizes must be padded to 256 x 128 x 64");
+    GemmArgs a{};
+    a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid;
+    a.out_bf16 = g.out_bf16; a.ldo = g.ldo; a.resid = g.resid; a.ldr = g.ldr; a.pos = g.pos; a.tokens = g.tokens;
+    a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
+    a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh;
+    switch (epi) {
+        case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, st);
+        case EPI_GELU: return launch_gemm_t<EPI_GELU>(a, st);
+        case EPI_RESID: return launch_gemm_t<EPI_RESID>(a, st);
+        case EPI_PATCH: return launch_gemm_t<EPI_PATCH>(a, st);
+        case EPI_QKV: return launch_gemm_t<EPI_QKV>(a, st);
+    }
+    return fail("gemm: unknown epilogue");
+}
+
+int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int width, size_t rows,
+                     uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
+    if (rows == 0) return 0;
+    if (width % 4) return fail("layernorm: width must be a multiple of 4");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, width,
+                       rows, out, ldo, out_f32);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, uint16_t* out, hipStream_t st) {
+    const size_t total = (size_t)B * (H / P) * (W / P) * k_pad;
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
+    if (is_f16)
+        hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const _Float16*>(img), B,
+                           C, H, W, P, k_pad, out);
+    else
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(img), B, C, H,
+                           W, P, k_pad, out);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
+                     int dh_pad, int dv_pad, uint16_t* out, int ldo, hipStream_t st) {
+    if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
+    const int qblocks = (tokens + 63) / 64;
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
+                       dh, dh_pad, dv_pad, scale_log2e, out, ldo);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, float* out,
+                          int ldo, hipStream_t st) {
+    const size_t lds = (size_t)(tokens + 256) * 4;
+    hipLaunchKernelGGL(pool_attention_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, st, kv, ldkv, qlat, heads, dh, tokens,
+                       1.0f / sqrtf((float)dh), out, ldo);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_small_linear(const float* x, int ldx, const uint16_t* w, int ldw, const float* bias, int K, int N, int B, int act,
+                        const float* res, int ldres, float* y, int ldy, hipStream_t st) {
+    const size_t waves = (size_t)B * N;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, ldx, w, ldw, bias, K, N, B, act,
+                       res, ldres, y, ldy);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, float* out_f32, uint16_t* out_f16, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(B), dim3(64), 0, st, x, ldx, width, B, normalize, out_f32, out_f16);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_f32_to_bf16_pad(const float* in, int rows, int cols, int ld_in, uint16_t* out, int rows_pad, int cols_pad,
+                           hipStream_t st) {
+    const size_t total = (size_t)rows_pad * cols_pad;
+    if (total == 0) return 0;
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535);
+    hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(blocks), dim3(256), 0, st, in, rows, cols, ld_in, out, rows_pad, cols_pad);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace siglip
+}  // namespace mse

@@ -79,7 +79,24 @@ SIGNATURES = {
     "mse_nb_ids": (u32p, [vp]),
     "mse_nb_scores": (i64p, [vp]),
     "mse_greedy_search": (C.c_int, [vp, u32p, u32p, sz, C.c_uint32, u16p, C.c_int, C.c_uint32, vp, C.POINTER(sz)]),
+    "mse_siglip_create": (vp, [vp]),
+    "mse_siglip_destroy": (None, [vp]),
+    "mse_siglip_n_weights": (C.c_int, [vp]),
+    "mse_siglip_weight_name": (C.c_char_p, [vp, C.c_int]),
+    "mse_siglip_set_weight": (C.c_int, [vp, C.c_char_p, f32p, C.POINTER(sz), C.c_int]),
+    "mse_siglip_finalize": (C.c_int, [vp]),
+    "mse_siglip_encode_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, u16p]),
+    "mse_siglip_output_device": (vp, [vp, C.c_int]),
+    "mse_siglip_stream": (vp, [vp]),
+    "mse_siglip_debug_residual": (C.c_int, [vp, f32p]),
 }
+
+
+class SiglipConfig(C.Structure):
+    """mse_siglip_config (include/mse.h)"""
+    _fields_ = [("img_size", C.c_int), ("patch_size", C.c_int), ("in_chans", C.c_int), ("emb_dim", C.c_int),
+                ("depth", C.c_int), ("num_heads", C.c_int), ("mlp_dim", C.c_int), ("eps", C.c_float),
+                ("gelu_tanh", C.c_int), ("max_batch", C.c_int)]
 
 
 def lib():

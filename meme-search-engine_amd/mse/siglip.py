@@ -1,0 +1,105 @@
+"""SigLIP image engine: host-side loader + the `fast_image_fns` seam of the reference's clip_server.py.
+
+`SiglipImageEngine.from_state_dict` plays the role of `load_pretrained` + `generate_wrapper`
+(clip_server.py:40-82): it takes an open_clip/timm state dict (keys `visual.trunk.*`), hands every tensor to
+the HIP engine by name, and returns a callable `engine(images[b,3,384,384]) -> features[b,1152]`.
+PyTorch is used only to read weights (any mapping name -> array-like works); all arithmetic runs in
+libmse_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+from .ffi import MseError, check, check_ptr
+
+SO400M_384 = dict(img_size=384, patch_size=14, in_chans=3, emb_dim=1152, depth=27, num_heads=16, mlp_dim=4304)  # aitemplate/run.py:47-55
+
+
+def _to_numpy_f32(t):
+    if hasattr(t, "detach"):
+        t = t.detach().float().cpu().numpy()
+    return np.ascontiguousarray(t, np.float32)
+
+
+class SiglipImageEngine:
+    def __init__(self, config=None, max_batch=32, eps=1e-6, gelu="erf"):
+        cfg = dict(SO400M_384 if config is None else config)
+        self.cfg = cfg
+        self.max_batch = max_batch
+        c = ffi.SiglipConfig(cfg["img_size"], cfg["patch_size"], cfg["in_chans"], cfg["emb_dim"], cfg["depth"],
+                             cfg["num_heads"], cfg["mlp_dim"], eps, 1 if gelu == "tanh" else 0, max_batch)
+        self._h = check_ptr(ffi.lib().mse_siglip_create(C.byref(c)), "mse_siglip_create")
+        self.embedding_size = cfg["emb_dim"]
+
+    def weight_names(self):
+        L = ffi.lib()
+        return [L.mse_siglip_weight_name(self._h, i).decode() for i in range(L.mse_siglip_n_weights(self._h))]
+
+    def set_weight(self, name, tensor):
+        a = _to_numpy_f32(tensor)
+        shape = (C.c_size_t * a.ndim)(*a.shape)
+        check(ffi.lib().mse_siglip_set_weight(self._h, name.encode(), a.ctypes.data_as(ffi.f32p), shape, a.ndim),
+              f"set_weight({name})")
+
+    @classmethod
+    def from_state_dict(cls, state, config=None, max_batch=32, eps=1e-6, gelu="erf"):
+        """state: mapping of open_clip names (`visual.trunk.blocks.0.attn.qkv.weight`, ...) or the same without
+        the `visual.` prefix.  Missing tensors are an error (the engine refuses to run half-loaded)."""
+        eng = cls(config, max_batch, eps, gelu)
+        for name in eng.weight_names():
+            key = name if name in state else "visual." + name
+            if key not in state:
+                raise MseError(f"state dict lacks '{name}'")
+            eng.set_weight(name, state[key])
+        check(ffi.lib().mse_siglip_finalize(eng._h), "siglip_finalize")
+        return eng
+
+    def encode_image(self, images, normalize=True, out="f32"):
+        """images: [b,3,H,W] float32 or float16 numpy array, already normalised (x/127.5-1).
+        Returns float32 [b, emb] (out="f32") or the IEEE fp16 bit patterns the server serialises (out="f16")."""
+        a = np.asarray(images)
+        if a.dtype == np.float16:
+            dtype = 1
+        else:
+            a = a.astype(np.float32, copy=False)
+            dtype = 0
+        a = np.ascontiguousarray(a)
+        b = a.shape[0]
+        if b > self.max_batch:
+            raise MseError(f"max batch size is {self.max_batch}")   # assert at clip_server.py:139
+        of32 = np.empty((b, self.embedding_size), np.float32) if out == "f32" else None
+        of16 = np.empty((b, self.embedding_size), np.uint16) if out == "f16" else None
+        check(ffi.lib().mse_siglip_encode_image(self._h, a.ctypes.data_as(C.c_void_p), dtype, 0, b, int(normalize),
+                                                of32.ctypes.data_as(ffi.f32p) if of32 is not None else None,
+                                                of16.ctypes.data_as(ffi.u16p) if of16 is not None else None),
+              "siglip_encode_image")
+        return of32 if out == "f32" else of16
+
+    def encode_image_device(self, dev_ptr, batch, dtype_f16=True, normalize=True):
+        """Images already resident in HBM (the `fast_image_fns` call shape); result stays on the device:
+        returns (device pointer to [batch, emb] f32, device pointer to the fp16 copy)."""
+        check(ffi.lib().mse_siglip_encode_image(self._h, dev_ptr, 1 if dtype_f16 else 0, 1, batch, int(normalize), None, None),
+              "siglip_encode_image")
+        L = ffi.lib()
+        return L.mse_siglip_output_device(self._h, 0), L.mse_siglip_output_device(self._h, 1)
+
+    def __call__(self, images):
+        return self.encode_image(images)
+
+    def debug_residual(self, batch):
+        n = (self.cfg["img_size"] // self.cfg["patch_size"]) ** 2
+        out = np.empty((batch * n, self.embedding_size), np.float32)
+        check(ffi.lib().mse_siglip_debug_residual(self._h, out.ctypes.data_as(ffi.f32p)), "debug_residual")
+        return out.reshape(batch, n, self.embedding_size)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ffi.lib().mse_siglip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

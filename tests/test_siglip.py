@@ -1,0 +1,99 @@
+"""SigLIP image tower: (CPU) the oracle restatement of aitemplate/model.py against the committed outputs of
+an independent implementation (HF transformers, tests/golden/make_siglip_golden.py); (GPU) the HIP engine
+against the oracle.  Tolerance from BASELINE.json north_star: cosine within 1e-3 of the fp32 reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+torch.set_grad_enabled(False)
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (a * b).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import siglip_ref
+    return siglip_ref
+
+
+def test_oracle_matches_independent_implementation(ref):
+    g = np.load(os.path.join(GOLDEN, "siglip_hf_depth2.npz"))
+    cfg = dict(ref.CONFIG, depth=int(g["depth"]))
+    sd = ref.synthetic_weights(cfg, seed=int(g["seed_weights"]))
+    img = ref.synthetic_images(2, cfg, seed=int(g["seed_images"]))
+    out = ref.encode_image(img, sd, cfg, gelu=str(g["gelu"]), eps=float(g["eps"]), normalize=False).numpy()
+    assert np.abs(out - g["pooled"]).max() < 2e-5 * np.abs(g["pooled"]).max() + 1e-5
+    assert np.all(cosine(out, g["pooled"]) > 1 - 1e-6)
+
+
+def test_oracle_structure(ref):
+    # shapes, normalisation and the two GELU flavours of SURVEY Appendix C
+    cfg = dict(ref.CONFIG, depth=1)
+    sd = ref.synthetic_weights(cfg)
+    assert set(sd) == set(ref.param_shapes(cfg))
+    img = ref.synthetic_images(1, cfg)
+    assert img.shape == (1, 3, 384, 384) and float(img.min()) >= -1.0 and float(img.max()) <= 1.0
+    taps = {}
+    f = ref.encode_image(img, sd, cfg, taps=taps)
+    assert f.shape == (1, 1152) and abs(float(f.norm()) - 1.0) < 1e-5
+    assert taps["embed"].shape == (1, 729, 1152)
+    f2 = ref.encode_image(img, sd, cfg, gelu="tanh")
+    assert 1 - 1e-3 < float(cosine(f.numpy(), f2.numpy())[0]) < 1.0     # close but not identical
+
+
+def test_engine_rejects_bad_use(mse):
+    from mse import ffi, siglip
+    if ffi.lib().mse_device_count() > 0:
+        pytest.skip("needs no device")
+    with pytest.raises(mse.MseError):
+        siglip.SiglipImageEngine(dict(siglip.SO400M_384, depth=1), max_batch=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,gelu,batch", [(2, "tanh", 2), (2, "erf", 3), (27, "erf", 2)])
+def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
+    from mse import siglip
+    cfg = dict(ref.CONFIG, depth=depth)
+    sd = ref.synthetic_weights(cfg)
+    img = ref.synthetic_images(batch, cfg)
+    taps = {}
+    want = ref.encode_image(img, sd, cfg, gelu=gelu, normalize=True, taps=taps).numpy()
+    eng = siglip.SiglipImageEngine.from_state_dict({"visual." + k: v for k, v in sd.items()},
+                                                   dict(siglip.SO400M_384, depth=depth), max_batch=4, gelu=gelu)
+    got = eng.encode_image(img.numpy())
+    resid = eng.debug_residual(batch)
+    cos_resid = cosine(resid.reshape(batch, -1), taps[f"block{depth - 1}"].numpy().reshape(batch, -1))
+    assert np.all(cos_resid > 1 - 1e-3), cos_resid
+    cos = cosine(got, want)
+    assert np.all(cos > 1 - 1e-3), cos                                    # north_star tolerance
+    assert np.all(np.abs(np.linalg.norm(got, axis=1) - 1) < 1e-3)
+    # fp16 serialisation path (clip_server.py:166) and fp16 inputs (the server feeds .half() images, :140)
+    got16 = eng.encode_image(img.numpy().astype(np.float16), out="f16").view(np.float16).astype(np.float32)
+    assert np.all(cosine(got16, want) > 1 - 1e-3)
+    # smaller batch after a larger one (stale padded rows must not leak)
+    got1 = eng.encode_image(img.numpy()[:1])
+    assert np.all(cosine(got1, want[:1]) > 1 - 1e-3)
+    with pytest.raises(mse.MseError):
+        eng.encode_image(np.zeros((5, 3, 384, 384), np.float32))           # > max_batch (clip_server.py:139)
+
+
+@pytest.mark.gpu
+def test_engine_requires_all_weights(gpu, mse, ref):
+    from mse import siglip
+    cfg = dict(ref.CONFIG, depth=1)
+    sd = ref.synthetic_weights(cfg)
+    sd.pop("trunk.blocks.0.mlp.fc2.bias")
+    with pytest.raises(mse.MseError):
+        siglip.SiglipImageEngine.from_state_dict(sd, dict(siglip.SO400M_384, depth=1), max_batch=1)
+    eng = siglip.SiglipImageEngine(dict(siglip.SO400M_384, depth=1), max_batch=1)
+    with pytest.raises(mse.MseError):
+        eng.set_weight("trunk.norm.weight", np.zeros(7, np.float32))       # wrong size
+    with pytest.raises(mse.MseError):
+        eng.encode_image(np.zeros((1, 3, 384, 384), np.float32))           # not finalised
