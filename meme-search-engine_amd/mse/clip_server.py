@@ -1,0 +1,227 @@
+"""Embedding server with the wire contract of the reference's clip_server.py, backed by the HIP engine.
+
+Contract (reference clip_server.py) -- kept byte compatible:
+  POST /        body = msgpack map {"images": [bytes, ...]} or {"text": [str, ...]}          (:151-170)
+                200 -> msgpack array of bin, each `embedding_size * 2` bytes little-endian fp16,
+                       L2-normalised                                                          (:115,166)
+                500 -> msgpack string with the error text; batch > max_batch_size and a body with
+                       neither key are errors                                                  (:136-146,167-170)
+                a full request queue raises queue.Full out of the handler (put_nowait, :161)
+  GET  /config  msgpack map {"model", "batch", "image_size": [w, h], "embedding_size"}        (:176-183)
+  GET  /        204                                                                            (:185-187)
+  GET  /metrics Prometheus text: modelserver_total_items{model,modality},
+                modelserver_inftime{model,batch_size}, modelserver_batchcount{model}           (:86-88,189-191)
+  request bodies up to 64 MiB                                                                  (:148)
+Thread structure mirrors the reference: aiohttp handler -> preprocessing thread -> inference thread, two
+bounded queues of 10 (:125,130).  Configuration = JSON file given as argv[1] with the reference's keys
+(`device`, `model`, `model_path`, `model_name`, `max_batch_size`, `port`).
+
+The model call is the seam the reference fills with `fast_image_fns` / `model.encode_image`
+(:66-82,105-114): here `engine.encode_image(images fp16 NCHW) -> [b, emb] f32`.  The engine is injected, so
+the contract is testable without a GPU (tests/test_clip_server.py uses a stand-in engine).
+"""
+import asyncio
+import collections
+import io
+import json
+import queue
+import sys
+import threading
+import traceback
+
+import msgpack
+import numpy as np
+
+InferenceParameters = collections.namedtuple("InferenceParameters", ["text", "images", "callback"])
+
+
+def preprocess_image(data: bytes, size):
+    """open_clip's preprocess for ViT-SO400M-14-SigLIP-384 as the reference relies on it:
+    decode, RGB, resize to (w, h) if needed (bicubic, squash), ToTensor, Normalize(mean=std=0.5), .half().
+    Clients already send 384x384 24-bit BMP (src/common.rs:50-53), so the resize is normally the identity."""
+    from PIL import Image
+    im = Image.open(io.BytesIO(data)).convert("RGB")
+    if im.size != tuple(size):
+        im = im.resize(tuple(size), Image.BICUBIC)
+    a = np.asarray(im, dtype=np.float32)                     # [h, w, 3]
+    a = a / np.float32(127.5) - np.float32(1.0)               # (x/255 - 0.5) / 0.5
+    return np.ascontiguousarray(a.transpose(2, 0, 1)).astype(np.float16)
+
+
+class ClipServer:
+    def __init__(self, config, image_engine, text_engine=None, tokenizer=None, registry=None):
+        from prometheus_client import CollectorRegistry, Counter, Histogram
+        self.config = config
+        self.bs = int(config["max_batch_size"])
+        self.model_name = config["model_name"]
+        self.image_engine = image_engine
+        self.text_engine = text_engine
+        self.tokenizer = tokenizer
+        self.image_size = tuple(getattr(image_engine, "image_size", (384, 384)))
+        self.embedding_size = int(image_engine.embedding_size)
+        self.registry = registry or CollectorRegistry()
+        self.items_ctr = Counter("modelserver_total_items", "Items run through model server", ["model", "modality"],
+                                 registry=self.registry)
+        self.inference_time_hist = Histogram("modelserver_inftime", "Time running inference", ["model", "batch_size"],
+                                             registry=self.registry)
+        self.batch_count_ctr = Counter("modelserver_batchcount", "Inference batches run", ["model"], registry=self.registry)
+        self.iq = queue.Queue(10)
+        self.pq = queue.Queue(10)
+        self._threads = []
+        self._stop = object()
+
+    # ---- inference thread (clip_server.py:91-128) ----
+    def do_inference(self, params):
+        text, images, callback = params
+        try:
+            if text is not None:
+                if self.text_engine is None:
+                    raise RuntimeError("text tower not loaded")
+                self.items_ctr.labels(self.model_name, "text").inc(text.shape[0])
+                with self.inference_time_hist.labels(self.model_name + "-text", text.shape[0]).time():
+                    features = np.asarray(self.text_engine.encode_text(text), np.float32)
+                    features = features / np.linalg.norm(features, axis=-1, keepdims=True)
+            elif images is not None:
+                with self.inference_time_hist.labels(self.model_name + "-image", images.shape[0]).time():
+                    self.items_ctr.labels(self.model_name, "image").inc(images.shape[0])
+                    # the engine normalises on the device; result rows are unit norm like `features /= norm`
+                    features = np.asarray(self.image_engine.encode_image(images), np.float32)
+            else:
+                raise AssertionError("images or text required")
+            self.batch_count_ctr.labels(self.model_name).inc()
+            callback(True, features)
+        except Exception as e:  # noqa: BLE001 - the reference reports every failure as a 500 string
+            traceback.print_exc()
+            callback(False, str(e))
+
+    def infer_thread(self):
+        while True:
+            item = self.iq.get()
+            if item is self._stop:
+                return
+            self.do_inference(item)
+
+    # ---- preprocessing thread (clip_server.py:131-146) ----
+    def preprocessing_thread(self):
+        while True:
+            item = self.pq.get()
+            if item is self._stop:
+                return
+            text, images, callback = item
+            try:
+                if text:
+                    assert len(text) <= self.bs, f"max batch size is {self.bs}"
+                    if self.tokenizer is None:
+                        raise RuntimeError("tokenizer not available")
+                    text = np.asarray(self.tokenizer(text))
+                    images = None
+                elif images:
+                    assert len(images) <= self.bs, f"max batch size is {self.bs}"
+                    images = np.stack([preprocess_image(im, self.image_size) for im in images])
+                    text = None
+                else:
+                    assert False, "images or text required"
+                self.iq.put(InferenceParameters(text, images, callback))
+            except Exception as e:  # noqa: BLE001
+                traceback.print_exc()
+                callback(False, str(e))
+
+    def start_threads(self):
+        for fn in (self.infer_thread, self.preprocessing_thread):
+            th = threading.Thread(target=fn, daemon=True)
+            th.start()
+            self._threads.append(th)
+
+    def stop_threads(self):
+        self.pq.put(self._stop)
+        self.iq.put(self._stop)
+
+    # ---- HTTP (clip_server.py:148-200) ----
+    def make_app(self):
+        from aiohttp import web
+        from prometheus_client import generate_latest
+        app = web.Application(client_max_size=2 ** 26)
+        routes = web.RouteTableDef()
+
+        @routes.post("/")
+        async def run_inference(request):
+            loop = asyncio.get_event_loop()
+            data = msgpack.loads(await request.read())
+            event = asyncio.Event()
+            results = None
+
+            def callback(*argv):
+                nonlocal results
+                results = argv
+                loop.call_soon_threadsafe(lambda: event.set())
+
+            self.pq.put_nowait(InferenceParameters(data.get("text"), data.get("images"), callback))
+            await event.wait()
+            body_data = results[1]
+            if results[0]:
+                status = 200
+                body_data = [x.astype("float16").tobytes() for x in body_data]
+            else:
+                status = 500
+            return web.Response(body=msgpack.dumps(body_data), status=status, content_type="application/msgpack")
+
+        @routes.get("/config")
+        async def config(request):
+            return web.Response(body=msgpack.dumps({
+                "model": self.config["model"],
+                "batch": self.bs,
+                "image_size": self.image_size,
+                "embedding_size": self.embedding_size,
+            }), status=200, content_type="application/msgpack")
+
+        @routes.get("/")
+        async def health(request):
+            return web.Response(status=204)
+
+        @routes.get("/metrics")
+        async def metrics(request):
+            return web.Response(body=generate_latest(self.registry))
+
+        app.router.add_routes(routes)
+        return app
+
+
+def load_engine(config):
+    """Build the HIP image engine from the reference's config keys.  `model_path` may point to a safetensors
+    or torch checkpoint with open_clip names; without it the server refuses to start unless
+    `synthetic_weights` is set (random weights: only useful for contract / throughput tests)."""
+    from .siglip import SiglipImageEngine, synthetic_state_dict, SO400M_384
+    cfg = dict(SO400M_384)
+    cfg.update(config.get("model_config", {}))
+    path = config.get("model_path")
+    if path:
+        if path.endswith(".safetensors"):
+            from safetensors.numpy import load_file
+            state = load_file(path)
+        else:
+            import torch
+            state = torch.load(path, map_location="cpu")
+            state = state.get("state_dict", state)
+    elif config.get("synthetic_weights"):
+        state = synthetic_state_dict(cfg, seed=int(config.get("synthetic_weights_seed", 0x5EED0005)))
+    else:
+        raise SystemExit("config needs model_path (open_clip checkpoint) or synthetic_weights: true")
+    eng = SiglipImageEngine.from_state_dict(state, cfg, max_batch=int(config["max_batch_size"]),
+                                            gelu=config.get("gelu", "erf"), eps=float(config.get("layer_norm_eps", 1e-6)))
+    eng.image_size = (cfg["img_size"], cfg["img_size"])
+    return eng
+
+
+def main(argv):
+    from aiohttp import web
+    with open(argv[1], "r") as f:
+        config = json.load(f)
+    server = ClipServer(config, load_engine(config))
+    print("Model loaded")
+    server.start_threads()
+    print("Ready")
+    web.run_app(server.make_app(), host="", port=int(config["port"]), print=None)
+
+
+if __name__ == "__main__":
+    main(sys.argv)

@@ -16,6 +16,44 @@ from .ffi import MseError, check, check_ptr
 SO400M_384 = dict(img_size=384, patch_size=14, in_chans=3, emb_dim=1152, depth=27, num_heads=16, mlp_dim=4304)  # aitemplate/run.py:47-55
 
 
+def weight_shapes(cfg):
+    """open_clip/timm tensor names (without `visual.`) and shapes of the image tower (clip_server.py:40-57)."""
+    d, m, p, c = cfg["emb_dim"], cfg["mlp_dim"], cfg["patch_size"], cfg["in_chans"]
+    n = (cfg["img_size"] // p) ** 2
+    s = {"trunk.patch_embed.proj.weight": (d, c, p, p), "trunk.patch_embed.proj.bias": (d,), "trunk.pos_embed": (1, n, d),
+         "trunk.norm.weight": (d,), "trunk.norm.bias": (d,), "trunk.attn_pool.latent": (1, 1, d),
+         "trunk.attn_pool.q.weight": (d, d), "trunk.attn_pool.q.bias": (d,), "trunk.attn_pool.kv.weight": (2 * d, d),
+         "trunk.attn_pool.kv.bias": (2 * d,), "trunk.attn_pool.proj.weight": (d, d), "trunk.attn_pool.proj.bias": (d,),
+         "trunk.attn_pool.norm.weight": (d,), "trunk.attn_pool.norm.bias": (d,), "trunk.attn_pool.mlp.fc1.weight": (m, d),
+         "trunk.attn_pool.mlp.fc1.bias": (m,), "trunk.attn_pool.mlp.fc2.weight": (d, m), "trunk.attn_pool.mlp.fc2.bias": (d,)}
+    for i in range(cfg["depth"]):
+        b = f"trunk.blocks.{i}."
+        s.update({b + "norm1.weight": (d,), b + "norm1.bias": (d,), b + "attn.qkv.weight": (3 * d, d),
+                  b + "attn.qkv.bias": (3 * d,), b + "attn.proj.weight": (d, d), b + "attn.proj.bias": (d,),
+                  b + "norm2.weight": (d,), b + "norm2.bias": (d,), b + "mlp.fc1.weight": (m, d), b + "mlp.fc1.bias": (m,),
+                  b + "mlp.fc2.weight": (d, m), b + "mlp.fc2.bias": (d,)})
+    return s
+
+
+def synthetic_state_dict(cfg, seed=0x5EED0005):
+    """Random-init weights of the named architecture (no checkpoint can be downloaded offline): linears
+    N(0, 1/fan_in), LayerNorm gain ~ 1, small biases.  Used by bench.py and by the server's
+    `synthetic_weights` mode; results are architecture-faithful timings, not meaningful embeddings."""
+    out = {}
+    for idx, (name, shape) in enumerate(sorted(weight_shapes(cfg).items())):
+        g = np.random.Generator(np.random.Philox(key=seed + idx))
+        if name.endswith("norm.weight") or ".norm1.weight" in name or ".norm2.weight" in name:
+            w = 1.0 + 0.1 * g.standard_normal(shape, dtype=np.float32)
+        elif name.endswith(".bias") or name.endswith("pos_embed"):
+            w = 0.02 * g.standard_normal(shape, dtype=np.float32)
+        elif name.endswith("latent"):
+            w = g.standard_normal(shape, dtype=np.float32)
+        else:
+            w = g.standard_normal(shape, dtype=np.float32) / np.float32(np.sqrt(np.prod(shape[1:])))
+        out[name] = w.astype(np.float32)
+    return out
+
+
 def _to_numpy_f32(t):
     if hasattr(t, "detach"):
         t = t.detach().float().cpu().numpy()

@@ -1,0 +1,38 @@
+"""SigLIP image tower throughput on one GPU: batch of synthetic images resident in HBM, seeded synthetic
+weights (no checkpoint or dataset is available offline).  Prints img/s and MFMA utilisation."""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "meme-search-engine_amd"))
+import torch
+import mse
+from mse import siglip, ffi
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    depth = int(sys.argv[3]) if len(sys.argv) > 3 else 27
+    cfg = dict(siglip.SO400M_384, depth=depth)
+    eng = siglip.SiglipImageEngine(cfg, max_batch=batch)
+    rng = np.random.default_rng(0)
+    shapes = {}
+    # cheap random weights straight on the host (fan-in scaled), enough for timing
+    for name in eng.weight_names():
+        pass
+    from oracle import siglip_ref as ref   # weight generator only (bench helper; not part of the timed path)
+    sd = ref.synthetic_weights(dict(ref.CONFIG, depth=depth))
+    for name in eng.weight_names():
+        eng.set_weight(name, sd[name])
+    ffi.check(ffi.lib().mse_siglip_finalize(eng._h))
+    img = torch.empty((batch, 3, 384, 384), dtype=torch.float16, device="cuda").uniform_(-1, 1)
+    torch.cuda.synchronize()
+    eng.encode_image_device(img.data_ptr(), batch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.encode_image_device(img.data_ptr(), batch)
+    dt = (time.perf_counter() - t0) / steps
+    gflop_img = 0.988 + depth * 24.647 + 3.9
+    print(f"batch {batch} depth {depth}: {dt*1e3:.1f} ms/batch  {batch/dt:.0f} img/s  {batch/dt*gflop_img/1e3:.0f} TFLOP/s "
+          f"({batch/dt*gflop_img*1e9/2.5e15*100:.1f}% of 2.5 PF)")
+
+main()

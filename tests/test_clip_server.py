@@ -1,0 +1,157 @@
+"""The clip_server HTTP contract (reference clip_server.py:148-200) exercised the way the
+reference's Rust clients use it (src/common.rs:61-96): msgpack in, msgpack out.  The CPU tests inject a
+stand-in engine (the contract does not depend on the model); the GPU test runs the HIP engine behind it."""
+import asyncio
+import io
+import threading
+
+import msgpack
+import numpy as np
+import pytest
+
+D = 1152
+
+
+class StandInEngine:
+    """Deterministic fake of the model seam: feature = f(mean pixel), unit norm."""
+    embedding_size = D
+    image_size = (384, 384)
+
+    def encode_image(self, images):
+        assert images.dtype == np.float16 and images.shape[1:] == (3, 384, 384)
+        m = images.astype(np.float32).mean(axis=(1, 2, 3))
+        f = np.cos(np.arange(D, dtype=np.float32)[None, :] * (1.0 + m[:, None]))
+        return f / np.linalg.norm(f, axis=1, keepdims=True)
+
+
+def bmp_bytes(seed, size=(384, 384)):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    im = Image.fromarray(rng.integers(0, 256, size=(size[1], size[0], 3), dtype=np.uint8), "RGB")
+    buf = io.BytesIO()
+    im.save(buf, format="BMP")           # clients send 24-bit BMP (src/common.rs:50-53)
+    return buf.getvalue()
+
+
+CONFIG = {"device": "cuda:0", "model": "ViT-SO400M-14-SigLIP-384", "model_name": "siglip-so400m-14-384",
+          "max_batch_size": 4, "port": 0}
+
+
+def run_with_server(server, coro_fn):
+    from aiohttp.test_utils import TestClient, TestServer
+
+    async def go():
+        client = TestClient(TestServer(server.make_app()))
+        await client.start_server()
+        try:
+            return await coro_fn(client)
+        finally:
+            await client.close()
+
+    server.start_threads()
+    try:
+        return asyncio.new_event_loop().run_until_complete(go())
+    finally:
+        server.stop_threads()
+
+
+def test_wire_contract(mse):
+    from mse.clip_server import ClipServer, preprocess_image
+    srv = ClipServer(CONFIG, StandInEngine())
+    images = [bmp_bytes(1), bmp_bytes(2), bmp_bytes(3)]
+
+    async def scenario(client):
+        out = {}
+        r = await client.get("/config")
+        out["config"] = (r.status, r.content_type, msgpack.loads(await r.read()))
+        r = await client.get("/")
+        out["health"] = r.status
+        body = msgpack.dumps({"images": images})                      # EmbeddingRequest::Images, to_vec_named
+        r = await client.post("/", data=body, headers={"Content-Type": "application/msgpack"})
+        out["images"] = (r.status, r.content_type, msgpack.loads(await r.read()))
+        r = await client.post("/", data=msgpack.dumps({"images": images + images}))   # 6 > max_batch_size
+        out["too_many"] = (r.status, msgpack.loads(await r.read()))
+        r = await client.post("/", data=msgpack.dumps({"nothing": 1}))
+        out["neither"] = (r.status, msgpack.loads(await r.read()))
+        r = await client.post("/", data=msgpack.dumps({"text": ["a cat"]}))            # no text tower loaded
+        out["text"] = (r.status, msgpack.loads(await r.read()))
+        r = await client.post("/", data=msgpack.dumps({"images": [b"not an image"]}))
+        out["garbage"] = (r.status, msgpack.loads(await r.read()))
+        r = await client.get("/metrics")
+        out["metrics"] = (r.status, (await r.read()).decode())
+        return out
+
+    out = run_with_server(srv, scenario)
+    status, ctype, cfg = out["config"]
+    assert status == 200 and ctype == "application/msgpack"
+    assert cfg == {"model": CONFIG["model"], "batch": 4, "image_size": [384, 384], "embedding_size": D}
+    assert out["health"] == 204
+    status, ctype, rows = out["images"]
+    assert status == 200 and ctype == "application/msgpack" and isinstance(rows, list) and len(rows) == 3
+    assert all(isinstance(r, bytes) and len(r) == D * 2 for r in rows)                 # 2304-byte fp16 rows
+    got = np.stack([np.frombuffer(r, "<f2").astype(np.float32) for r in rows])
+    want = StandInEngine().encode_image(np.stack([preprocess_image(b, (384, 384)) for b in images]))
+    assert np.array_equal(got, want.astype(np.float16).astype(np.float32))
+    assert np.all(np.abs(np.linalg.norm(got, axis=1) - 1) < 2e-3)
+    for key in ("too_many", "neither", "text", "garbage"):
+        status, msg = out[key]
+        assert status == 500 and isinstance(msg, str) and msg                           # msgpack string, :167-170
+    assert "max batch size is 4" in out["too_many"][1]
+    status, text = out["metrics"]
+    assert status == 200
+    for name in ("modelserver_total_items_total", "modelserver_inftime", "modelserver_batchcount_total"):
+        assert name in text
+    assert 'modality="image"' in text and 'model="siglip-so400m-14-384"' in text
+
+
+def test_preprocess_matches_reference_normalisation(mse):
+    from mse.clip_server import preprocess_image
+    from PIL import Image
+    a = np.zeros((384, 384, 3), np.uint8)
+    a[..., 0], a[..., 1], a[..., 2] = 0, 255, 51
+    buf = io.BytesIO()
+    Image.fromarray(a, "RGB").save(buf, format="BMP")
+    x = preprocess_image(buf.getvalue(), (384, 384))
+    assert x.shape == (3, 384, 384) and x.dtype == np.float16
+    assert float(x[0, 0, 0]) == -1.0 and float(x[1, 5, 7]) == 1.0                      # (v/255 - 0.5) / 0.5
+    assert abs(float(x[2, 0, 0]) - (51 / 127.5 - 1)) < 1e-3
+    small = io.BytesIO()
+    Image.fromarray(a[:100, :50], "RGB").save(small, format="PNG")
+    assert preprocess_image(small.getvalue(), (384, 384)).shape == (3, 384, 384)      # resized when needed
+
+
+def test_queue_full_raises_like_put_nowait(mse):
+    import queue
+    from mse.clip_server import ClipServer, InferenceParameters
+    srv = ClipServer(CONFIG, StandInEngine())
+    for _ in range(10):
+        srv.pq.put_nowait(InferenceParameters(None, [b"x"], lambda *a: None))
+    with pytest.raises(queue.Full):                                                     # clip_server.py:161
+        srv.pq.put_nowait(InferenceParameters(None, [b"x"], lambda *a: None))
+
+
+@pytest.mark.gpu
+def test_server_with_hip_engine(gpu, mse):
+    from oracle import siglip_ref as ref
+    import torch
+    from mse import siglip
+    from mse.clip_server import ClipServer, preprocess_image
+    cfg = dict(siglip.SO400M_384, depth=2)
+    state = siglip.synthetic_state_dict(cfg)
+    eng = siglip.SiglipImageEngine.from_state_dict(state, cfg, max_batch=4)
+    eng.image_size = (384, 384)
+    srv = ClipServer(CONFIG, eng)
+    images = [bmp_bytes(7), bmp_bytes(8)]
+
+    async def scenario(client):
+        r = await client.post("/", data=msgpack.dumps({"images": images}))
+        return r.status, msgpack.loads(await r.read())
+
+    status, rows = run_with_server(srv, scenario)
+    assert status == 200 and len(rows) == 2
+    got = np.stack([np.frombuffer(r, "<f2").astype(np.float32) for r in rows])
+    x = torch.from_numpy(np.stack([preprocess_image(b, (384, 384)) for b in images]).astype(np.float32))
+    sd = {k: torch.from_numpy(v) for k, v in state.items()}
+    want = ref.encode_image(x, sd, dict(ref.CONFIG, depth=2)).numpy()
+    cos = (got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)
+    assert np.all(cos > 1 - 1e-3), cos
