@@ -15,6 +15,7 @@
 // bank-conflict swizzle is applied on the DMA source address.  MFMA bound; roofline = 2.5 PFLOP/s dense bf16.
 #include "common.h"
 #include "siglip.h"
+#include <cstdlib>
 
 namespace mse {
 namespace siglip {
@@ -43,7 +44,20 @@ __device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below bf16 resolution by four orders of magnitude): one
+// reciprocal, one exp2, eight fused multiply-adds instead of libm's ~30-instruction erff in the GEMM epilogue
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = 1.0f - p * t * e;
+    const float erf_v = x < 0.0f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf_v);
+}
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return 0.5f * x * (1.0f + tanhf(u));
@@ -63,6 +77,7 @@ struct GemmArgs {
     const float* bias;    // [N_pad]
     int M, N, K;          // padded sizes: M % 256 == 0, N % 128 == 0, K % 64 == 0
     int m_valid;          // rows < m_valid are real
+    int n_off;            // column offset of this launch inside the full output (w and bias are pre-offset)
     // epilogue targets
     uint16_t* out_bf16;   // EPI_BF16 / EPI_GELU: [M][ldo]
     int ldo;
@@ -76,6 +91,52 @@ struct GemmArgs {
 };
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4 };
+
+// One accumulator quad of the epilogue: row m, columns n..n+3 (n = column inside this launch; a.n_off is
+// added for the output address), acc = raw MFMA sums.
+template <int EPI>
+__device__ __forceinline__ void store_quad(const GemmArgs& a, size_t m, int n, const float4v& acc) {
+    const bool mok = m < (size_t)a.m_valid;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+    float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
+    n += a.n_off;
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        if constexpr (EPI == EPI_GELU) {
+            if (a.gelu_tanh) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+            else { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+        }
+        if (!mok) { v0 = v1 = v2 = v3 = 0.0f; }
+        *reinterpret_cast<uint2*>(a.out_bf16 + m * a.ldo + n) = uint2{pack2(v0, v1), pack2(v2, v3)};
+    } else if constexpr (EPI == EPI_RESID) {
+        if (mok) {
+            float4* p = reinterpret_cast<float4*>(a.resid + m * a.ldr + n);
+            float4 x = *p;
+            x.x += v0; x.y += v1; x.z += v2; x.w += v3;
+            *p = x;
+        }
+    } else if constexpr (EPI == EPI_PATCH) {
+        if (mok) {
+            const int tok = (int)(m % a.tokens);
+            const float4 pv = *reinterpret_cast<const float4*>(a.pos + (size_t)tok * a.ldr + n);
+            *reinterpret_cast<float4*>(a.resid + m * a.ldr + n) = float4{v0 + pv.x, v1 + pv.y, v2 + pv.z, v3 + pv.w};
+        }
+    } else {  // EPI_QKV: n in [0, 3*D): which = n / D, head = (n % D) / dh, e = (n % D) % dh
+        if (mok) {
+            const int D = a.heads * a.dh;
+            const int bi = (int)(m / a.tokens), tok = (int)(m % a.tokens);
+            // n is a multiple of 4 and dh % 4 == 0, so the four values share (which, head)
+            const int which = n / D, rem = n % D, head = rem / a.dh, e = rem % a.dh;
+            const size_t bh = (size_t)bi * a.heads + head;
+            if (which < 2) {
+                uint16_t* dst = (which == 0 ? a.q : a.k) + (bh * a.n_pad + tok) * a.dh_pad + e;
+                *reinterpret_cast<uint2*>(dst) = uint2{pack2(v0, v1), pack2(v2, v3)};
+            } else {
+                uint16_t* dst = a.vt + (bh * a.dv_pad + e) * a.n_pad + tok;
+                dst[0] = f2bf(v0); dst[a.n_pad] = f2bf(v1); dst[2 * (size_t)a.n_pad] = f2bf(v2); dst[3 * (size_t)a.n_pad] = f2bf(v3);
+            }
+        }
+    }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(GW * 64) void gemm_kernel(GemmArgs a) {
@@ -128,83 +189,161 @@ __global__ __launch_bounds__(GW * 64) void gemm_kernel(GemmArgs a) {
             for (int r = 0; r < 4; r++) acc[nt][mt][r] = 0.0f;
 
     const int nk = a.K / BK;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    for (int kt = 0; kt < nk; kt++) {
-        // stage kt must have landed: at most the 6 DMAs of stage kt+1 may still be in flight
-        if (kt + 1 < nk) vm_wait<6>(); else vm_wait<0>();
-        __builtin_amdgcn_s_barrier();  // every wave's share is in LDS; everyone has finished reading stage kt-1
-        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % GS);
-        const char* xs = smem + (kt % GS) * STAGE_BYTES;
+    const int slot0 = g ^ swz, slot1 = (4 + g) ^ swz;  // k step 0 / 1 of a stage
+    auto load_frags = [&](bf16x8(&af)[4], bf16x8(&bfr)[4], int stage, int slot) {
+        const char* xs = smem + stage * STAGE_BYTES;
         const u32x4* xt = reinterpret_cast<const u32x4*>(xs) + (wm * 64 + i) * 8;
         const u32x4* wt = reinterpret_cast<const u32x4*>(xs + XT_BYTES) + (wn * 64 + i) * 8;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int slot = (ks * 4 + g) ^ swz;
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                af[t] = as_bf8(wt[t * 128 + slot]);
-                bfr[t] = as_bf8(xt[t * 128 + slot]);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+        for (int t = 0; t < 4; t++) {
+            af[t] = as_bf8(wt[t * 128 + slot]);
+            bfr[t] = as_bf8(xt[t * 128 + slot]);
         }
+    };
+    auto mma = [&](const bf16x8(&af)[4], const bf16x8(&bfr)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+    };
+    // Half-step software pipeline: the fragments of the NEXT 32-wide k step are read from LDS while the
+    // MFMAs of the current one run, and the wait + barrier for the next stage sit between the two k steps of
+    // a stage, so neither the LDS latency nor the DMA wait is exposed at the head of an MFMA block.
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) vm_wait<12>(); else if (nk > 1) vm_wait<6>(); else vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(a0, b0, 0, slot0);
+    for (int kt = 0; kt < nk; kt++) {
+        load_frags(a1, b1, kt % GS, slot1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            // this wave's reads of stage kt (issued above, a whole MFMA block ago) are complete, so after the
+            // barrier stage kt's buffer can be refilled; its share of stage kt+1 has landed once only the 6
+            // DMAs of stage kt+2 remain outstanding
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (kt + 2 < nk) vm_wait<6>(); else vm_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) issue(kt + 3, kt % GS);
+            load_frags(a0, b0, (kt + 1) % GS, slot0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // epilogue: lane holds m = m0 + wm*64 + mt*16 + i, n = n0 + wn*64 + nt*16 + 4g + r
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        const size_t m = m0 + wm * 64 + mt * 16 + i;
-        const bool mok = m < (size_t)a.m_valid;
+    for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            const int n = (int)n0 + wn * 64 + nt * 16 + 4 * g;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-            float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y;
-            float v2 = acc[nt][mt][2] + bv.z, v3 = acc[nt][mt][3] + bv.w;
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-                if constexpr (EPI == EPI_GELU) {
-                    if (a.gelu_tanh) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
-                    else { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-                }
-                if (!mok) { v0 = v1 = v2 = v3 = 0.0f; }
-                uint2 o{pack2(v0, v1), pack2(v2, v3)};
-                *reinterpret_cast<uint2*>(a.out_bf16 + m * a.ldo + n) = o;
-            } else if constexpr (EPI == EPI_RESID) {
-                if (mok) {
-                    float4* p = reinterpret_cast<float4*>(a.resid + m * a.ldr + n);
-                    float4 x = *p;
-                    x.x += v0; x.y += v1; x.z += v2; x.w += v3;
-                    *p = x;
-                }
-            } else if constexpr (EPI == EPI_PATCH) {
-                if (mok) {
-                    const int tok = (int)(m % a.tokens);
-                    const float4 pv = *reinterpret_cast<const float4*>(a.pos + (size_t)tok * a.ldr + n);
-                    *reinterpret_cast<float4*>(a.resid + m * a.ldr + n) = float4{v0 + pv.x, v1 + pv.y, v2 + pv.z, v3 + pv.w};
-                }
-            } else {  // EPI_QKV: n in [0, 3*D): which = n / D, head = (n % D) / dh, e = (n % D) % dh
-                if (mok) {
-                    const int D = a.heads * a.dh;
-                    const int bi = (int)(m / a.tokens), tok = (int)(m % a.tokens);
-                    const float vv[4] = {v0, v1, v2, v3};
+        for (int nt = 0; nt < 4; nt++)
+            store_quad<EPI>(a, m0 + wm * 64 + mt * 16 + i, (int)n0 + wn * 64 + nt * 16 + 4 * g, acc[nt][mt]);
+}
+
+// ---- 256 x 256 tile -----------------------------------------------------------------------------------------
+// Measured with rocprofv3 PMC on the 256 x 128 kernel above (profiles/r01_pmc_siglip_gemm.txt): the CU's
+// L1-miss path delivers only ~13 B/clk (one 128-B request per ~9 cycles, L2 hits and misses alike), i.e.
+// ~8 TB/s over the chip, and TCP_PENDING_STALL is 50 % of kernel time; at 87 flop per fetched byte that caps
+// the kernel near 700 TFLOP/s.  A 256 x 256 tile fetches half as many bytes per flop (128 flop/B).  8 waves as
+// 4 (m) x 2 (n), each 64 x 128 -> 32 accumulator tiles = 128 VGPRs; K step 32 (rows of 64 B: one DMA
+// instruction covers 16 rows), 4-stage ring of 32 KiB stages, one barrier per K step.
+// Swizzle for 64-byte rows: LDS slot (row, s) holds global 16-byte piece s ^ T[(row >> 2) & 3], T = {0,3,2,1},
+// which makes every ds_read_b128 service group hit 16 distinct 16-byte bank slots.
+constexpr int B2 = 256, BK2 = 32, GS2 = 4;
+constexpr int T2_BYTES = B2 * BK2 * 2;        // 16 KiB per operand tile
+constexpr int STAGE2_BYTES = 2 * T2_BYTES;    // 32 KiB
+
+__device__ __forceinline__ int swz64(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }  // T = {0,3,2,1}
+
+template <int EPI>
+__global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int slot = g ^ swz64(i);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 (m) x 2 (n) waves, each 64 (m) x 128 (n)
+    const int n_blocks = a.N / B2, m_blocks = a.M / B2;
+    const int nwg = n_blocks * m_blocks;
+    int b = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8, idx = b / 8;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int mb = b / n_blocks, nb = b % n_blocks;
+    const size_t m0 = (size_t)mb * B2, n0 = (size_t)nb * B2;
+    const size_t kbytes = (size_t)a.K * 2;
+    // DMA: each operand tile = 16 instructions of 16 rows x 64 B; a wave issues instructions 2w, 2w+1 of both
+    const char* xsrc[2];
+    const char* wsrc[2];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int nn = n + r;
-                        const int which = nn / D, rem = nn % D, head = rem / a.dh, e = rem % a.dh;
-                        const size_t bh = (size_t)bi * a.heads + head;
-                        if (which == 0) a.q[(bh * a.n_pad + tok) * a.dh_pad + e] = f2bf(vv[r]);
-                        else if (which == 1) a.k[(bh * a.n_pad + tok) * a.dh_pad + e] = f2bf(vv[r]);
-                        else a.vt[(bh * a.dv_pad + e) * a.n_pad + tok] = f2bf(vv[r]);
-                    }
-                }
+    for (int u = 0; u < 2; u++) {
+        const int r = (wave * 2 + u) * 16 + (lane >> 2);
+        const int piece = (lane & 3) ^ swz64(r);
+        xsrc[u] = reinterpret_cast<const char*>(a.x) + (m0 + r) * kbytes + piece * 16;
+        wsrc[u] = reinterpret_cast<const char*>(a.w) + (n0 + r) * kbytes + piece * 16;
+    }
+    auto issue = [&](int kstep, int stage) {
+        char* xs = smem + stage * STAGE2_BYTES;
+        char* ws = xs + T2_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; u++) dma16(xsrc[u] + (size_t)kstep * (BK2 * 2), xs + (wave * 2 + u) * 1024);
+#pragma unroll
+        for (int u = 0; u < 2; u++) dma16(wsrc[u] + (size_t)kstep * (BK2 * 2), ws + (wave * 2 + u) * 1024);
+    };
+
+    float4v acc[8][4];  // [n tile][m tile]
+#pragma unroll
+    for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[nt][mt][r] = 0.0f;
+
+    const int nk = a.K / BK2;
+    // prologue: three stages in flight
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt landed (this wave's share): the younger stages (4 DMAs each) may still be in flight
+        const int younger = nk - 1 - kt;
+        if (younger >= 2) vm_wait<8>(); else if (younger == 1) vm_wait<4>(); else vm_wait<0>();
+        __builtin_amdgcn_s_barrier();  // all shares visible; everyone is done reading stage kt-1
+        // the 4 DMA pieces of stage kt+3 (into the buffer stage kt-1 occupied) are spread over the MFMA block
+        // instead of being issued in one burst by all eight waves at once
+        const bool more = kt + 3 < nk;
+        char* nxs = smem + ((kt + 3) % GS2) * STAGE2_BYTES;
+        const size_t koff = (size_t)(kt + 3) * (BK2 * 2);
+        const char* xs = smem + (kt % GS2) * STAGE2_BYTES;
+        const u32x4* xt = reinterpret_cast<const u32x4*>(xs) + (wm * 64 + i) * 4 + slot;
+        const u32x4* wt = reinterpret_cast<const u32x4*>(xs + T2_BYTES) + (wn * 128 + i) * 4 + slot;
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) bfr[t] = as_bf8(xt[t * 64]);
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++) {
+            const bf16x8 af = as_bf8(wt[nt * 64]);
+            if (more && (nt & 1) == 0) {
+                const int u = (nt >> 1) & 1;
+                if (nt < 4) dma16(xsrc[u] + koff, nxs + (wave * 2 + u) * 1024);
+                else dma16(wsrc[u] + koff, nxs + T2_BYTES + (wave * 2 + u) * 1024);
             }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[mt], acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++)
+            store_quad<EPI>(a, m0 + wm * 64 + mt * 16 + i, (int)n0 + wn * 128 + nt * 16 + 4 * g, acc[nt][mt]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -272,96 +411,157 @@ __global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, 
 //   Ot[e][query]  += Vt . P^T  (A = Vt rows, B = P)          -> lane (query) holds e = 16t + 4g + r
 // The contraction index of the second product is the key index in the order the first product leaves it in
 // registers (keys {4g..4g+3} of tile 0, then of tile 1), so P never moves between lanes; Vt is read in the
-// same order.  One wave = 16 queries; K / Vt fragments come straight from L2 (they are re-read by every
-// query block of the same (image, head)).  dh = 72 is padded to 96 for Q.K^T (3 MFMA k steps of 32) and to
-// 80 for the output (5 row tiles of 16).
+// same order.  A wave owns 32 queries (two 16-query tiles, so every K / Vt fragment feeds two MFMAs); the
+// four waves of a workgroup share 32-key K / Vt tiles through a double-buffered LDS stage (row strides 224 B /
+// 80 B chosen so that ds_read_b128 / ds_read_b64 of the fragments are bank-conflict free).  dh = 72 is padded
+// to 96 for Q.K^T (3 MFMA k steps of 32) and to 80 for the output (5 row tiles of 16).
 // ---------------------------------------------------------------------------------------------------------
+constexpr int ATT_KROW = 224, ATT_VROW = 80;             // LDS row strides in bytes
+constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * ATT_VROW;
+
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                         int dh, int dh_pad, int dv_pad, float scale_log2e,
                                                         uint16_t* __restrict__ out, int ldo) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (ATT_KTILE + ATT_VTILE)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int qblocks = (tokens + 63) / 64;
+    const int qblocks = (tokens + 127) / 128;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const int q0 = qb * 64 + wave * 16;
-    if (q0 >= tokens) return;
-    const uint16_t* qp = q + ((size_t)bh * n_pad + q0 + i) * dh_pad;
+    const int q0 = qb * 128 + wave * 32;
     const uint16_t* kp = k + (size_t)bh * n_pad * dh_pad;
     const uint16_t* vp = vt + (size_t)bh * dv_pad * n_pad;
-    // Q fragments (B operand): lane (query i, k group g) -> dh 32*ks + 8g .. +8
-    bf16x8 qf[3];
+    // Q fragments (B operand): lane (query i, k group g) -> dh 32*ks + 8g .. +8.  Rows past n_pad are clamped.
+    bf16x8 qf[2][3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ks++) qf[ks] = as_bf8(*reinterpret_cast<const u32x4*>(qp + ks * 32 + g * 8));
-    float4v o[5];
+    for (int qt = 0; qt < 2; qt++) {
+        int qrow = q0 + qt * 16 + i;
+        if (qrow >= n_pad) qrow = n_pad - 1;
+        const uint16_t* qp = q + ((size_t)bh * n_pad + qrow) * dh_pad;
 #pragma unroll
-    for (int t = 0; t < 5; t++)
+        for (int ks = 0; ks < 3; ks++) qf[qt][ks] = as_bf8(*reinterpret_cast<const u32x4*>(qp + ks * 32 + g * 8));
+    }
+    // staging: K tile = 32 rows x 192 B = 384 chunks of 16 B, Vt tile = 80 rows x 64 B = 320 chunks
+    const int kc1 = tid + 256, vc1 = tid + 256;
+    const bool k2 = kc1 < 384, v2 = vc1 < 320;
+    auto kaddr = [&](int c, int kt) { return kp + (size_t)(kt + c / 12) * dh_pad + (c % 12) * 8; };
+    auto vaddr = [&](int c, int kt) { return vp + (size_t)(c / 4) * n_pad + kt + (c % 4) * 8; };
+    auto klds = [&](int c, int b) { return lds + b * (ATT_KTILE + ATT_VTILE) + (c / 12) * ATT_KROW + (c % 12) * 16; };
+    auto vlds = [&](int c, int b) { return lds + b * (ATT_KTILE + ATT_VTILE) + ATT_KTILE + (c / 4) * ATT_VROW + (c % 4) * 16; };
+    u32x4 kr0, kr1{}, vr0, vr1{};
+    kr0 = *reinterpret_cast<const u32x4*>(kaddr(tid, 0));
+    if (k2) kr1 = *reinterpret_cast<const u32x4*>(kaddr(kc1, 0));
+    vr0 = *reinterpret_cast<const u32x4*>(vaddr(tid, 0));
+    if (v2) vr1 = *reinterpret_cast<const u32x4*>(vaddr(vc1, 0));
+    *reinterpret_cast<u32x4*>(klds(tid, 0)) = kr0;
+    if (k2) *reinterpret_cast<u32x4*>(klds(kc1, 0)) = kr1;
+    *reinterpret_cast<u32x4*>(vlds(tid, 0)) = vr0;
+    if (v2) *reinterpret_cast<u32x4*>(vlds(vc1, 0)) = vr1;
+    __syncthreads();
+
+    float4v o[2][5];
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[t][r] = 0.0f;
-    float m_run = -1e30f, l_run = 0.0f;
+    for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+        for (int t = 0; t < 5; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[qt][t][r] = 0.0f;
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.0f, 0.0f};
+    int buf = 0;
     for (int kt = 0; kt < n_pad; kt += 32) {
-        float4v s[2];
+        const bool more = kt + 32 < n_pad;
+        if (more) {
+            kr0 = *reinterpret_cast<const u32x4*>(kaddr(tid, kt + 32));
+            if (k2) kr1 = *reinterpret_cast<const u32x4*>(kaddr(kc1, kt + 32));
+            vr0 = *reinterpret_cast<const u32x4*>(vaddr(tid, kt + 32));
+            if (v2) vr1 = *reinterpret_cast<const u32x4*>(vaddr(vc1, kt + 32));
+        }
+        const char* kl = lds + buf * (ATT_KTILE + ATT_VTILE);
+        const char* vl = kl + ATT_KTILE;
+        float4v s[2][2];
 #pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
+        for (int qt = 0; qt < 2; qt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) s[h2][r] = 0.0f;
-            const uint16_t* krow = kp + (size_t)(kt + h2 * 16 + i) * dh_pad;
+            for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) s[qt][h2][r] = 0.0f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
             for (int ks = 0; ks < 3; ks++) {
-                const bf16x8 kf = as_bf8(*reinterpret_cast<const u32x4*>(krow + ks * 32 + g * 8));
-                s[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[h2], 0, 0, 0);
+                const bf16x8 kf = as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
+                s[0][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][h2], 0, 0, 0);
+                s[1][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][h2], 0, 0, 0);
             }
+        bf16x8 pf[2];
+        float alpha[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++) {
+            // lane holds St[key = kt + 16*h2 + 4g + r][query]; padded keys are masked out
+            float mx = -1e30f;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = kt + h2 * 16 + 4 * g + r;
+                    s[qt][h2][r] = key < tokens ? s[qt][h2][r] * scale_log2e : -1e30f;
+                    mx = fmaxf(mx, s[qt][h2][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qt], mx);
+            alpha[qt] = exp2f(m_run[qt] - m_new);
+            float psum = 0.0f;
+            float p[8];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    p[h2 * 4 + r] = exp2f(s[qt][h2][r] - m_new);
+                    psum += p[h2 * 4 + r];
+                }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            l_run[qt] = l_run[qt] * alpha[qt] + psum;
+            m_run[qt] = m_new;
+            pf[qt] = as_bf8(u32x4{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])});
         }
-        // lane holds St[key = kt + 16*h2 + 4g + r][query i]; mask padded keys
-        float mx = -1e30f;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int key = kt + h2 * 16 + 4 * g + r;
-                s[h2][r] = key < tokens ? s[h2][r] * scale_log2e : -1e30f;
-                mx = fmaxf(mx, s[h2][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        float psum = 0.0f;
-        float p[8];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                p[h2 * 4 + r] = exp2f(s[h2][r] - m_new);
-                psum += p[h2 * 4 + r];
-            }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        const u32x4 pb{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])};
-        const bf16x8 pf = as_bf8(pb);
 #pragma unroll
         for (int t = 0; t < 5; t++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[t][r] *= alpha;
-            // A operand: Vt row e = 16t + i, contraction slots = keys {kt+4g..+3, kt+16+4g..+3}
-            const uint16_t* vrow = vp + (size_t)(t * 16 + i) * n_pad + kt + 4 * g;
+            // A operand: Vt row e = 16t + i, contraction slots = keys {4g..+3, 16+4g..+3} of this tile
+            const char* vrow = vl + (t * 16 + i) * ATT_VROW + g * 8;
             const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 32);
             const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
-        }
-    }
-    const int tok = q0 + i;
-    if (tok < tokens) {
-        const float inv = 1.0f / l_run;
-        const int b = bh / heads, hd = bh % heads;
-        uint16_t* op = out + ((size_t)b * tokens + tok) * ldo + hd * dh;
 #pragma unroll
-        for (int t = 0; t < 5; t++) {
-            const int e = t * 16 + 4 * g;
-            if (e < dh) *reinterpret_cast<uint2*>(op + e) = uint2{pack2(o[t][0] * inv, o[t][1] * inv), pack2(o[t][2] * inv, o[t][3] * inv)};
+            for (int qt = 0; qt < 2; qt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[qt][t][r] *= alpha[qt];
+                o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
+            }
+        }
+        if (more) {
+            *reinterpret_cast<u32x4*>(klds(tid, buf ^ 1)) = kr0;
+            if (k2) *reinterpret_cast<u32x4*>(klds(kc1, buf ^ 1)) = kr1;
+            *reinterpret_cast<u32x4*>(vlds(tid, buf ^ 1)) = vr0;
+            if (v2) *reinterpret_cast<u32x4*>(vlds(vc1, buf ^ 1)) = vr1;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int b = bh / heads, hd = bh % heads;
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+        const int tok = q0 + qt * 16 + i;
+        if (tok < tokens) {
+            const float inv = 1.0f / l_run[qt];
+            uint16_t* op = out + ((size_t)b * tokens + tok) * ldo + hd * dh;
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const int e = t * 16 + 4 * g;
+                if (e < dh)
+                    *reinterpret_cast<uint2*>(op + e) = uint2{pack2(o[qt][t][0] * inv, o[qt][t][1] * inv), pack2(o[qt][t][2] * inv, o[qt][t][3] * inv)};
+            }
         }
     }
 }
@@ -466,19 +666,36 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, i
     }
 }
 
-template <int EPI> int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)GS * STAGE_BYTES;
+template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
     int dev = 0;
     MSE_HIP_TRY(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev < 64 && !attr_set[dev]) {
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, GS * STAGE_BYTES));
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, GS2 * STAGE2_BYTES));
         attr_set[dev] = true;
     }
-    const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
-    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), lds, st, a);
-    MSE_HIP_TRY(hipGetLastError());
+    static const bool force128 = getenv("MSE_GEMM_128") != nullptr;   // developer knob: old tile only
+    const int n256 = force128 ? 0 : (a_in.N / B2) * B2;
+    if (n256 > 0) {
+        GemmArgs a = a_in;
+        a.N = n256;
+        const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), GS2 * STAGE2_BYTES, st, a);
+        MSE_HIP_TRY(hipGetLastError());
+    }
+    if (n256 < a_in.N) {  // remaining 128 columns (N = 1152, 3456) on the 256 x 128 tile
+        GemmArgs a = a_in;
+        a.N = a_in.N - n256;
+        a.n_off = n256;
+        a.w = a_in.w + (size_t)n256 * a_in.K;
+        a.bias = a_in.bias + n256;
+        const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+        hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), GS * STAGE_BYTES, st, a);
+        MSE_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -491,7 +708,7 @@ int gemm_bk() { return BK; }
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     if (g.M % BM || g.N % BN || g.K % BK) return fail("gemm: sizes must be padded to 256 x 128 x 64");
     GemmArgs a{};
-    a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid;
+    a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid; a.n_off = 0;
     a.out_bf16 = g.out_bf16; a.ldo = g.ldo; a.resid = g.resid; a.ldr = g.ldr; a.pos = g.pos; a.tokens = g.tokens;
     a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
     a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh;
@@ -531,7 +748,7 @@ int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
                      int dh_pad, int dv_pad, uint16_t* out, int ldo, hipStream_t st) {
     if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
-    const int qblocks = (tokens + 63) / 64;
+    const int qblocks = (tokens + 127) / 128;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
                        dh, dh_pad, dv_pad, scale_log2e, out, ldo);
