@@ -194,6 +194,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
 const void* mse_siglip_output_device(const mse_siglip* m, int which);  /* device result of the last call: 0 f32, 1 f16 */
 void* mse_siglip_stream(const mse_siglip* m);
 int mse_siglip_debug_residual(mse_siglip* m, float* out);             /* test hook: residual stream after the last block */
+int mse_debug_gemm_ms(int M, int N, int K, int ablation, int iters, float* ms_out); /* developer hook: GEMM timing/ablation */
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

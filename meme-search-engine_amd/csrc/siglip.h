@@ -27,6 +27,7 @@ int gemm_bm();
 int gemm_bn();
 int gemm_bk();
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
+int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int width, size_t rows,
                      uint16_t* out, int ldo, float* out_f32, hipStream_t st);
 int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, uint16_t* out, hipStream_t st);

@@ -288,6 +288,29 @@ const void* mse_siglip_output_device(const mse_siglip* m, int which) { return m 
 
 void* mse_siglip_stream(const mse_siglip* m) { return m ? (void*)m->stream : nullptr; }
 
+// developer hook: average ms of the fc1-shaped GEMM (bias + GELU) over `iters` launches with ablation `abl`
+int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
+    if (M % 256 || N % 256 || K % 64) return fail("debug gemm: M, N multiples of 256, K of 64");
+    DevBuf x, w, bias, out;
+    if (x.ensure((size_t)M * K * 2) || w.ensure((size_t)N * K * 2) || bias.ensure((size_t)N * 4) || out.ensure((size_t)M * N * 2)) return -1;
+    MSE_HIP_TRY(hipMemset(x.p, 0x3c, (size_t)M * K * 2));   // bf16 0x3c3c ~ 0.0115
+    MSE_HIP_TRY(hipMemset(w.p, 0x3c, (size_t)N * K * 2));
+    MSE_HIP_TRY(hipMemset(bias.p, 0, (size_t)N * 4));
+    GemmLaunch g; g.x = x.as<uint16_t>(); g.w = w.as<uint16_t>(); g.bias = bias.as<float>(); g.M = M; g.N = N; g.K = K;
+    g.m_valid = M; g.out_bf16 = out.as<uint16_t>(); g.ldo = N;
+    hipEvent_t e0, e1;
+    MSE_HIP_TRY(hipEventCreate(&e0)); MSE_HIP_TRY(hipEventCreate(&e1));
+    if (launch_gemm256_ablation(abl, g, nullptr)) return -1;
+    MSE_HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; i++) if (launch_gemm256_ablation(abl, g, nullptr)) return -1;
+    MSE_HIP_TRY(hipEventRecord(e1, nullptr));
+    MSE_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0; MSE_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
 // test hook: the residual stream ([batch*tokens][emb] fp32) as left by the last forward (after the last block)
 int mse_siglip_debug_residual(mse_siglip* m, float* out) {
     if (!m || !m->last_batch) return fail("siglip: no forward has run");

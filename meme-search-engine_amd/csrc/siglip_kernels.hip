@@ -257,10 +257,12 @@ __global__ __launch_bounds__(GW * 64) void gemm_kernel(GemmArgs a) {
 constexpr int B2 = 256, BK2 = 32, GS2 = 4;
 constexpr int T2_BYTES = B2 * BK2 * 2;        // 16 KiB per operand tile
 constexpr int STAGE2_BYTES = 2 * T2_BYTES;    // 32 KiB
+constexpr int LDS256_BYTES = 8 * 64 * 272;   // max(4 stages = 128 KiB, epilogue staging = 136 KiB)
 
 __device__ __forceinline__ int swz64(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }  // T = {0,3,2,1}
 
-template <int EPI>
+// ABL: developer ablation (0 = shipped kernel, 1 = no MFMA, 2 = no DMA in the loop, 3 = no LDS fragment reads)
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -312,11 +314,11 @@ __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
     for (int kt = 0; kt < nk; kt++) {
         // stage kt landed (this wave's share): the younger stages (4 DMAs each) may still be in flight
         const int younger = nk - 1 - kt;
-        if (younger >= 2) vm_wait<8>(); else if (younger == 1) vm_wait<4>(); else vm_wait<0>();
+        if (ABL == 2) vm_wait<0>(); else if (younger >= 2) vm_wait<8>(); else if (younger == 1) vm_wait<4>(); else vm_wait<0>();
         __builtin_amdgcn_s_barrier();  // all shares visible; everyone is done reading stage kt-1
         // the 4 DMA pieces of stage kt+3 (into the buffer stage kt-1 occupied) are spread over the MFMA block
         // instead of being issued in one burst by all eight waves at once
-        const bool more = kt + 3 < nk;
+        const bool more = kt + 3 < nk && ABL != 2;
         char* nxs = smem + ((kt + 3) % GS2) * STAGE2_BYTES;
         const size_t koff = (size_t)(kt + 3) * (BK2 * 2);
         const char* xs = smem + (kt % GS2) * STAGE2_BYTES;
@@ -324,26 +326,68 @@ __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
         const u32x4* wt = reinterpret_cast<const u32x4*>(xs + T2_BYTES) + (wn * 128 + i) * 4 + slot;
         bf16x8 bfr[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) bfr[t] = as_bf8(xt[t * 64]);
+        for (int t = 0; t < 4; t++) bfr[t] = as_bf8(ABL == 3 ? u32x4{(uint32_t)kt, 1u, 2u, (uint32_t)t} : xt[t * 64]);
+        // all 12 fragments of the step are requested up front (a read issued between MFMA groups and pinned
+        // there by a sched_barrier serialises ds_read -> wait -> MFMA: measured 2600 cycles per step even with
+        // the DMA removed); the LDS latency is then paid once per step and hidden by the SIMD's other wave
+        bf16x8 af[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++) af[nt] = as_bf8(ABL == 3 ? u32x4{(uint32_t)nt, 3u, (uint32_t)kt, 5u} : wt[nt * 64]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < 8; nt++) {
-            const bf16x8 af = as_bf8(wt[nt * 64]);
             if (more && (nt & 1) == 0) {
                 const int u = (nt >> 1) & 1;
                 if (nt < 4) dma16(xsrc[u] + koff, nxs + (wave * 2 + u) * 1024);
                 else dma16(wsrc[u] + koff, nxs + T2_BYTES + (wave * 2 + u) * 1024);
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[mt], acc[nt][mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int mt = 0; mt < 4; mt++) {
+                if (ABL == 1) { asm volatile("" ::"v"(af[nt]), "v"(bfr[mt])); acc[nt][mt][0] += 1.0f; }
+                else acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+            }
+            if (nt & 1) __builtin_amdgcn_sched_barrier(0);  // keeps the DMA pieces spread over the MFMA block
         }
     }
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        // bf16 outputs go through LDS so that global stores are whole 256-byte row segments (a lane's quad is
+        // only 8 bytes of one row: stored directly, a 128-byte line is written by four separate instructions;
+        // ablation showed that epilogue, not MFMA or DMA, bounded the kernel).  Per wave: 64 rows x 128 cols bf16
+        // with a 272-byte row stride (16 rows x 8 bytes land on distinct banks up to 2-way).
+        constexpr int EROW = 272;
+        __syncthreads();  // every wave is done with the operand stages
+        char* et = smem + wave * (64 * EROW);
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+        for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 8; nt++)
-            store_quad<EPI>(a, m0 + wm * 64 + mt * 16 + i, (int)n0 + wn * 128 + nt * 16 + 4 * g, acc[nt][mt]);
+            for (int nt = 0; nt < 8; nt++) {
+                const int nl = nt * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 128 + nl);
+                float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z, v3 = acc[nt][mt][3] + bv.w;
+                if constexpr (EPI == EPI_GELU) {
+                    if (a.gelu_tanh) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
+                    else { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                }
+                *reinterpret_cast<uint2*>(et + (mt * 16 + i) * EROW + nl * 2) = uint2{pack2(v0, v1), pack2(v2, v3)};
+            }
+        // own region only: a wave-level wait is enough (no other wave touches it)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int rsub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int row = it * 4 + rsub;
+            const size_t m = m0 + wm * 64 + row;
+            u32x4 v = *reinterpret_cast<const u32x4*>(et + row * EROW + chunk * 16);
+            if (m >= (size_t)a.m_valid) v = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(a.out_bf16 + m * a.ldo + a.n_off + n0 + wn * 128 + chunk * 8) = v;
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 8; nt++)
+                store_quad<EPI>(a, m0 + wm * 64 + mt * 16 + i, (int)n0 + wn * 128 + nt * 16 + 4 * g, acc[nt][mt]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -674,7 +718,7 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, GS * STAGE_BYTES));
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, GS2 * STAGE2_BYTES));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
         attr_set[dev] = true;
     }
     static const bool force128 = getenv("MSE_GEMM_128") != nullptr;   // developer knob: old tile only
@@ -683,7 +727,7 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         GemmArgs a = a_in;
         a.N = n256;
         const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), GS2 * STAGE2_BYTES, st, a);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
         MSE_HIP_TRY(hipGetLastError());
     }
     if (n256 < a_in.N) {  // remaining 128 columns (N = 1152, 3456) on the 256 x 128 tile
@@ -700,6 +744,25 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
 }
 
 }  // namespace
+
+// developer entry: time the 256x256 GELU GEMM alone with an ablation variant (scripts/gemm_ablate.py)
+int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
+    GemmArgs a{};
+    a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid; a.n_off = 0;
+    a.out_bf16 = g.out_bf16; a.ldo = g.ldo;
+    const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
+    const size_t lds = LDS256_BYTES;
+#define MSE_ABL(X)                                                                                              \
+    case X:                                                                                                     \
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_GELU, X>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, X>), dim3(grid), dim3(GW * 64), lds, st, a);               \
+        break;
+    switch (abl) { MSE_ABL(0) MSE_ABL(1) MSE_ABL(2) MSE_ABL(3) default: return fail("bad ablation"); }
+#undef MSE_ABL
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int gemm_bm() { return BM; }
 int gemm_bn() { return BN; }

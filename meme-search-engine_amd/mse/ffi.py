@@ -89,6 +89,7 @@ SIGNATURES = {
     "mse_siglip_output_device": (vp, [vp, C.c_int]),
     "mse_siglip_stream": (vp, [vp]),
     "mse_siglip_debug_residual": (C.c_int, [vp, f32p]),
+    "mse_debug_gemm_ms": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
 }
 
 
