@@ -62,6 +62,45 @@ def cpu_baseline(n_rows, k):
     }
 
 
+def siglip_bench(args, world, rank):
+    """BASELINE configs[1]: SigLIP-SO400M/14-384 image tower, batch 256 random 384x384 images, bf16, one
+    replica per GPU.  Random-init weights of the named architecture (no checkpoint offline); images already
+    resident in HBM as fp16 NCHW (what clip_server's preprocessing thread hands to the model).  One step = one
+    full forward of the batch incl. L2 normalisation and fp16 output rows."""
+    import torch
+    from mse import siglip
+    cfg = dict(siglip.SO400M_384)
+    batch = args.siglip_batch
+    eng = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=batch)
+    img = torch.empty((batch, 3, cfg["img_size"], cfg["img_size"]), dtype=torch.float16, device="cuda").uniform_(-1, 1)
+    torch.cuda.synchronize()
+    eng.encode_image_device(img.data_ptr(), batch)            # warm-up (encode_image synchronises its stream)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.siglip_steps):
+        eng.encode_image_device(img.data_ptr(), batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    eng.close()
+    per_gpu = batch * args.siglip_steps / dt
+    gflop_img = 0.988 + 27 * 24.647 + 3.9                     # SURVEY 8(d): 670.4 GFLOP per image
+    tflops = per_gpu * gflop_img / 1e3
+    return {"metric": "SigLIP img-embeds/sec/GPU", "value": per_gpu, "unit": "images/s/GPU", "total_images_per_s": per_gpu * world,
+            "ms_per_batch": dt / args.siglip_steps * 1e3, "dtype": "bf16 (fp32 accumulate, fp32 residual stream)",
+            "config": {"workload": f"SigLIP-SO400M/14-384 image tower, batch {batch} random 384x384, 1 replica per GPU",
+                       "weights": "random-init (seeded), architecture of ViT-SO400M-14-SigLIP-384"},
+            "steps": args.siglip_steps, "scaling": "weak (replicas)",
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
+                         "flop_per_image": gflop_img * 1e9, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +110,9 @@ def main():
     ap.add_argument("--queries", type=int, default=128, help="queries per step (one scan pass per 128)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-siglip", action="store_true", help="skip the SigLIP image-tower leg")
+    ap.add_argument("--siglip-batch", type=int, default=256)
+    ap.add_argument("--siglip-steps", type=int, default=3)
     args = ap.parse_args()
 
     import numpy as np
@@ -165,6 +207,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # ---- second half of BASELINE.json's metric: SigLIP image embeds/s/GPU (replicas, no collective) ----
+    siglip_line = None
+    if not args.no_siglip:
+        siglip_line = siglip_bench(args, world, rank)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = nq * args.steps / elapsed
@@ -205,6 +252,8 @@ def main():
             "verified_vs_exact_kernel": verified,
             "certificate": stats,
         }
+        if siglip_line:
+            line["siglip"] = siglip_line
         if note:
             line["note"] = note
         if world == 1 and not args.no_cpu_baseline:

@@ -6,7 +6,7 @@ mkdir -p $OUT
 i=0
 for c in "$@"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- python /root/repo/bench.py --rows 1e7 --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pass$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pass$i -o pmc -- python /root/repo/bench.py --rows 1e7 --steps 4 --warmup 1 --no-cpu-baseline --no-siglip > $OUT/pass$i.log 2>&1
   f=$(find $OUT/pass$i -name "*counter_collection.csv" | head -1)
   echo "== pass $i: $c -> $f"
   python - "$f" <<'PY'
