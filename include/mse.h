@@ -196,6 +196,34 @@ void* mse_siglip_stream(const mse_siglip* m);
 int mse_siglip_debug_residual(mse_siglip* m, float* out);             /* test hook: residual stream after the last block */
 int mse_debug_gemm_ms(int M, int N, int K, int ablation, int iters, float* ms_out); /* developer hook: GEMM timing/ablation */
 
+/* ---- SigLIP text tower: `model.encode_text(tokens)` + normalisation + fp16 serialisation
+ * (clip_server.py:98-99,128-131,166).  open_clip's TextTransformer is a third-party dependency not vendored in
+ * the reference; geometry from misc/clip_accursed.py:31-55 and clip_server.py:107,182: width 1152, 27 layers,
+ * 16 heads, mlp 4304, context 64, vocabulary 32000, no causal mask, last position pooled, Linear projection with
+ * bias.  Weight names are open_clip's (`text.token_embedding.weight`, `text.transformer.resblocks.N. ...`).
+ * Tokenisation (sentencepiece, pad id 1, clip_server.py:129) stays on the host. */
+typedef struct mse_siglip_text mse_siglip_text;
+typedef struct mse_siglip_text_config {
+    int width;           /* 1152 */
+    int layers;          /* 27 */
+    int heads;           /* 16 */
+    int mlp_dim;         /* 4304 */
+    int context_length;  /* 64 */
+    int vocab_size;      /* 32000 */
+    float eps;           /* 1e-6 */
+    int gelu_tanh;       /* 0 erf, 1 tanh approximation */
+    int max_batch;
+} mse_siglip_text_config;
+mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* cfg);
+void mse_siglip_text_destroy(mse_siglip_text* m);
+int mse_siglip_text_n_weights(const mse_siglip_text* m);
+const char* mse_siglip_text_weight_name(const mse_siglip_text* m, int idx);
+int mse_siglip_text_set_weight(mse_siglip_text* m, const char* name, const float* data, const size_t* shape, int ndim);
+int mse_siglip_text_finalize(mse_siglip_text* m);
+/* tokens: host int64 [batch, context_length]; outputs (either may be NULL) are host [batch, width]. */
+int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize, float* out_f32,
+                           uint16_t* out_f16);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

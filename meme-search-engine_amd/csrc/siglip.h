@@ -38,6 +38,8 @@ int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B
 int launch_small_linear(const float* x, int ldx, const uint16_t* w, int ldw, const float* bias, int K, int N, int B, int act,
                         const float* res, int ldres, float* y, int ldy, hipStream_t st);
 int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, float* out_f32, uint16_t* out_f16, hipStream_t st);
+int launch_embed_tokens(const int64_t* tokens, const float* tok_emb, const float* pos, int vocab, int ctx, int D, size_t rows,
+                        float* x, hipStream_t st);
 int launch_f32_to_bf16_pad(const float* in, int rows, int cols, int ld_in, uint16_t* out, int rows_pad, int cols_pad,
                            hipStream_t st);
 

@@ -701,6 +701,23 @@ __global__ void l2norm_kernel(const float* __restrict__ x, int ldx, int width, i
     }
 }
 
+// text tower input: x[b*ctx + t] = token_embedding[tokens[b][t]] + positional_embedding[t]  (fp32 residual stream)
+__global__ void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
+                                    const float* __restrict__ pos, int vocab, int ctx, int D, size_t rows,
+                                    float* __restrict__ x) {
+    const size_t row = blockIdx.x;
+    if (row >= rows) return;
+    int64_t tk = tokens[row];
+    if (tk < 0 || tk >= vocab) tk = 0;
+    const float4* e = reinterpret_cast<const float4*>(tok_emb + (size_t)tk * D);
+    const float4* p = reinterpret_cast<const float4*>(pos + (size_t)(row % ctx) * D);
+    float4* o = reinterpret_cast<float4*>(x + row * D);
+    for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+        const float4 a = e[c], b = p[c];
+        o[c] = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+    }
+}
+
 __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, int cols, int ld_in, uint16_t* __restrict__ out,
                                        int rows_pad, int cols_pad) {
     const size_t total = (size_t)rows_pad * cols_pad;
@@ -840,6 +857,14 @@ int launch_small_linear(const float* x, int ldx, const uint16_t* w, int ldw, con
 int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, float* out_f32, uint16_t* out_f16, hipStream_t st) {
     if (B == 0) return 0;
     hipLaunchKernelGGL(l2norm_kernel, dim3(B), dim3(64), 0, st, x, ldx, width, B, normalize, out_f32, out_f16);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_embed_tokens(const int64_t* tokens, const float* tok_emb, const float* pos, int vocab, int ctx, int D, size_t rows,
+                        float* x, hipStream_t st) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)rows), dim3(128), 0, st, tokens, tok_emb, pos, vocab, ctx, D, rows, x);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

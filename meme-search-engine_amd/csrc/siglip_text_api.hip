@@ -1,0 +1,217 @@
+// C ABI of the SigLIP text tower: `model.encode_text(tokens)` of clip_server.py:98 followed by the
+// normalisation (:99) and fp16 serialisation (:166).  The reference holds no restatement of this tower (it is
+// open_clip's TextTransformer, third-party and absent): known from the repository are the output width
+// (model.text.text_projection.out_features, clip_server.py:107,182) and the constants of
+// misc/clip_accursed.py:31-55 (width 1152, 27 layers, context 64, vocabulary 32000, pad id 1).  Published
+// architecture: token + positional embedding, pre-LN blocks WITHOUT causal mask, final LayerNorm, the last
+// position pooled, Linear projection with bias.  Weight names follow open_clip (`text.*`).  The blocks run on
+// the same kernels as the image tower (siglip_kernels.hip).  Tokenisation stays on the host (Python).
+#include "../../include/mse.h"
+#include "runtime.h"
+#include "siglip.h"
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mse;
+using namespace mse::siglip;
+
+namespace {
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+struct TBlock {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    uint16_t *wqkv, *wproj, *w1, *w2;
+    float *bqkv, *bproj, *b1, *b2;
+};
+struct TSlot {
+    bool bf16;
+    void* dst;
+    size_t rows, cols, rows_pad, cols_pad;
+    bool loaded = false;
+};
+
+}  // namespace
+
+struct mse_siglip_text {
+    mse_siglip_text_config cfg{};
+    int D = 0, H = 0, dh = 0, mlp = 0, mlp_pad = 0, ctx = 0, n_pad = 0, dh_pad = 96, dv_pad = 80;
+    int max_batch = 0;
+    size_t m_pad = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    std::map<std::string, TSlot> slots;
+    bool finalized = false;
+    float *tok_emb = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *bproj = nullptr;
+    uint16_t* wproj = nullptr;
+    std::vector<TBlock> blocks;
+    int64_t* tokens_dev = nullptr;
+    float *x = nullptr, *pooled = nullptr, *feat = nullptr, *out_f32 = nullptr;
+    uint16_t *h = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *out_f16 = nullptr;
+    float* stage = nullptr; size_t stage_elems = 0;
+
+    template <typename T> T* dalloc(size_t n, bool zero = false) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n * sizeof(T), 256)) != hipSuccess) return nullptr;
+        if (zero && hipMemset(p, 0, std::max<size_t>(n * sizeof(T), 256)) != hipSuccess) return nullptr;
+        allocs.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+    void add_f32(const std::string& name, float** dst, size_t rows, size_t cols, size_t cols_pad = 0) {
+        const size_t cp = cols_pad ? cols_pad : cols;
+        *dst = dalloc<float>(rows * cp, true);
+        slots[name] = TSlot{false, *dst, rows, cols, rows, cp};
+    }
+    void add_bf16(const std::string& name, uint16_t** dst, size_t rows, size_t cols, size_t rows_pad, size_t cols_pad) {
+        *dst = dalloc<uint16_t>(rows_pad * cols_pad, true);
+        slots[name] = TSlot{true, *dst, rows, cols, rows_pad, cols_pad};
+    }
+};
+
+extern "C" {
+
+mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
+    if (!c) { fail("null config"); return nullptr; }
+    if (c->width % 128 || c->heads <= 0 || c->width / c->heads != 72 || c->context_length % 32 || c->context_length <= 0 ||
+        c->vocab_size <= 0 || c->max_batch <= 0) {
+        fail("siglip text: unsupported geometry (width % 128 == 0, head_dim == 72, context % 32 == 0 required)");
+        return nullptr;
+    }
+    mse_siglip_text* m = new (std::nothrow) mse_siglip_text();
+    if (!m) { fail("out of host memory"); return nullptr; }
+    m->cfg = *c;
+    m->D = c->width; m->H = c->heads; m->dh = m->D / m->H; m->mlp = c->mlp_dim; m->mlp_pad = (int)round_up(m->mlp, 128);
+    m->ctx = c->context_length; m->n_pad = m->ctx; m->max_batch = c->max_batch;
+    m->m_pad = round_up((size_t)m->max_batch * m->ctx, 256);
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
+    const size_t D = m->D, MP = m->mlp_pad;
+    m->add_f32("text.token_embedding.weight", &m->tok_emb, c->vocab_size, D);
+    m->add_f32("text.positional_embedding", &m->pos, m->ctx, D);
+    m->blocks.resize(c->layers);
+    for (int i = 0; i < c->layers; i++) {
+        TBlock& b = m->blocks[i];
+        const std::string p = "text.transformer.resblocks." + std::to_string(i) + ".";
+        m->add_f32(p + "ln_1.weight", &b.ln1_g, 1, D); m->add_f32(p + "ln_1.bias", &b.ln1_b, 1, D);
+        m->add_bf16(p + "attn.in_proj_weight", &b.wqkv, 3 * D, D, 3 * D, D); m->add_f32(p + "attn.in_proj_bias", &b.bqkv, 1, 3 * D);
+        m->add_bf16(p + "attn.out_proj.weight", &b.wproj, D, D, D, D); m->add_f32(p + "attn.out_proj.bias", &b.bproj, 1, D);
+        m->add_f32(p + "ln_2.weight", &b.ln2_g, 1, D); m->add_f32(p + "ln_2.bias", &b.ln2_b, 1, D);
+        m->add_bf16(p + "mlp.c_fc.weight", &b.w1, m->mlp, D, MP, D); m->add_f32(p + "mlp.c_fc.bias", &b.b1, 1, m->mlp, MP);
+        m->add_bf16(p + "mlp.c_proj.weight", &b.w2, D, m->mlp, D, MP); m->add_f32(p + "mlp.c_proj.bias", &b.b2, 1, D);
+    }
+    m->add_f32("text.ln_final.weight", &m->lnf_g, 1, D); m->add_f32("text.ln_final.bias", &m->lnf_b, 1, D);
+    m->add_bf16("text.text_projection.weight", &m->wproj, D, D, D, D); m->add_f32("text.text_projection.bias", &m->bproj, 1, D);
+    const size_t B = m->max_batch, M = m->m_pad, BH = B * m->H;
+    m->tokens_dev = m->dalloc<int64_t>(B * m->ctx);
+    m->x = m->dalloc<float>(M * D, true);
+    m->h = m->dalloc<uint16_t>(M * D, true);
+    m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
+    m->qb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
+    m->kb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
+    m->vtb = m->dalloc<uint16_t>(BH * m->dv_pad * m->n_pad, true);
+    m->pooled = m->dalloc<float>(B * D); m->feat = m->dalloc<float>(B * D);
+    m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
+    bool ok = m->tokens_dev && m->x && m->h && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
+    for (auto& kv : m->slots) ok = ok && kv.second.dst;
+    if (!ok) { mse_siglip_text_destroy(m); fail("siglip text: device allocation failed"); return nullptr; }
+    return m;
+}
+
+void mse_siglip_text_destroy(mse_siglip_text* m) {
+    if (!m) return;
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->stage) (void)hipFree(m->stage);
+    delete m;
+}
+
+int mse_siglip_text_n_weights(const mse_siglip_text* m) { return m ? (int)m->slots.size() : 0; }
+const char* mse_siglip_text_weight_name(const mse_siglip_text* m, int idx) {
+    if (!m || idx < 0 || idx >= (int)m->slots.size()) return nullptr;
+    auto it = m->slots.begin();
+    std::advance(it, idx);
+    return it->first.c_str();
+}
+
+int mse_siglip_text_set_weight(mse_siglip_text* m, const char* name, const float* data, const size_t* shape, int ndim) {
+    if (!m || !name || !data) return fail("siglip_text_set_weight: null argument");
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) return fail(std::string("siglip text: unknown weight '") + name + "'");
+    TSlot& s = it->second;
+    size_t total = 1;
+    for (int i = 0; i < ndim; i++) total *= shape[i];
+    if (total != s.rows * s.cols) return fail(std::string("siglip text: wrong size for '") + name + "'");
+    if (m->stage_elems < total) {
+        if (m->stage) (void)hipFree(m->stage);
+        m->stage = nullptr;
+        MSE_HIP_TRY(hipMalloc((void**)&m->stage, total * 4));
+        m->stage_elems = total;
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(m->stage, data, total * 4, hipMemcpyHostToDevice, m->stream));
+    if (!s.bf16) {
+        if (s.cols_pad == s.cols) MSE_HIP_TRY(hipMemcpyAsync(s.dst, m->stage, total * 4, hipMemcpyDeviceToDevice, m->stream));
+        else MSE_HIP_TRY(hipMemcpy2DAsync(s.dst, s.cols_pad * 4, m->stage, s.cols * 4, s.cols * 4, s.rows, hipMemcpyDeviceToDevice, m->stream));
+    } else if (launch_f32_to_bf16_pad(m->stage, (int)s.rows, (int)s.cols, (int)s.cols, reinterpret_cast<uint16_t*>(s.dst),
+                                      (int)s.rows_pad, (int)s.cols_pad, m->stream)) {
+        return -1;
+    }
+    MSE_HIP_TRY(hipStreamSynchronize(m->stream));
+    s.loaded = true;
+    m->finalized = false;
+    return 0;
+}
+
+int mse_siglip_text_finalize(mse_siglip_text* m) {
+    if (!m) return fail("null engine");
+    for (auto& kv : m->slots)
+        if (!kv.second.loaded) return fail("siglip text: weight '" + kv.first + "' was never set");
+    m->finalized = true;
+    return 0;
+}
+
+int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize, float* out_f32, uint16_t* out_f16) {
+    if (!m) return fail("null engine");
+    if (!m->finalized) return fail("siglip text: call mse_siglip_text_finalize after loading the weights");
+    if (batch <= 0 || batch > m->max_batch) return fail("siglip text: batch exceeds max_batch");  // clip_server.py:136
+    hipStream_t st = m->stream;
+    const mse_siglip_text_config& c = m->cfg;
+    const int D = m->D, T = m->ctx, M = batch * T, Mp = (int)round_up(M, 256);
+    MSE_HIP_TRY(hipMemcpyAsync(m->tokens_dev, tokens, (size_t)M * 8, hipMemcpyHostToDevice, st));
+    if (launch_embed_tokens(m->tokens_dev, m->tok_emb, m->pos, c.vocab_size, T, D, M, m->x, st)) return -1;
+    for (int i = 0; i < c.layers; i++) {
+        const TBlock& b = m->blocks[i];
+        if (launch_layernorm(m->x, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
+            g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+            g.dv_pad = m->dv_pad;
+            if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
+        }
+        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M; g.resid = m->x; g.ldr = D;
+            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+        }
+        if (launch_layernorm(m->x, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
+            g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
+            if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
+        }
+        {
+            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M; g.resid = m->x; g.ldr = D;
+            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+        }
+    }
+    // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
+    if (launch_layernorm(m->x + (size_t)(T - 1) * D, T * D, m->lnf_g, m->lnf_b, c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
+    if (launch_small_linear(m->pooled, D, m->wproj, D, m->bproj, D, D, batch, 0, nullptr, 0, m->feat, D, st)) return -1;
+    if (launch_l2norm(m->feat, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
+    if (out_f32) MSE_HIP_TRY(hipMemcpyAsync(out_f32, m->out_f32, (size_t)batch * D * 4, hipMemcpyDeviceToHost, st));
+    if (out_f16) MSE_HIP_TRY(hipMemcpyAsync(out_f16, m->out_f16, (size_t)batch * D * 2, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

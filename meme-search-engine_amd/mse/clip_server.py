@@ -186,37 +186,92 @@ class ClipServer:
         return app
 
 
-def load_engine(config):
+class SiglipTokenizer:
+    """`open_clip.get_tokenizer("ViT-SO400M-14-SigLIP-384")` as clip_server.py:100,129 uses it: text is
+    canonicalised (lower case, punctuation removed, whitespace collapsed), encoded with the c4_en sentencepiece
+    model, an end marker equal to the pad id (1) is appended, and rows are truncated / padded to the context
+    length.  The sentencepiece model file is not redistributable from here: `tokenizer_path` in the config."""
+
+    def __init__(self, model_path=None, context_length=64, pad_id=1, model_proto=None):
+        import sentencepiece
+        self.sp = (sentencepiece.SentencePieceProcessor(model_proto=model_proto) if model_proto is not None
+                   else sentencepiece.SentencePieceProcessor(model_file=model_path))
+        self.context_length = context_length
+        self.pad_id = pad_id
+
+    @staticmethod
+    def canonicalize(text):
+        import string
+        text = text.translate(str.maketrans("", "", string.punctuation)).lower()
+        return " ".join(text.split())
+
+    def __call__(self, texts):
+        from .siglip import pad_tokens
+        if isinstance(texts, str):
+            texts = [texts]
+        rows = []
+        for t in texts:
+            ids = self.sp.encode(self.canonicalize(t))[: self.context_length - 1]
+            rows.append(ids + [self.pad_id])
+        return pad_tokens(rows, self.context_length, self.pad_id)
+
+
+def _load_state(config):
+    path = config.get("model_path")
+    if not path:
+        return None
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+        return load_file(path)
+    import torch
+    state = torch.load(path, map_location="cpu")
+    return state.get("state_dict", state)
+
+
+def load_engine(config, state=None):
     """Build the HIP image engine from the reference's config keys.  `model_path` may point to a safetensors
     or torch checkpoint with open_clip names; without it the server refuses to start unless
     `synthetic_weights` is set (random weights: only useful for contract / throughput tests)."""
     from .siglip import SiglipImageEngine, synthetic_state_dict, SO400M_384
     cfg = dict(SO400M_384)
     cfg.update(config.get("model_config", {}))
-    path = config.get("model_path")
-    if path:
-        if path.endswith(".safetensors"):
-            from safetensors.numpy import load_file
-            state = load_file(path)
-        else:
-            import torch
-            state = torch.load(path, map_location="cpu")
-            state = state.get("state_dict", state)
-    elif config.get("synthetic_weights"):
+    state = state if state is not None else _load_state(config)
+    if state is None:
+        if not config.get("synthetic_weights"):
+            raise SystemExit("config needs model_path (open_clip checkpoint) or synthetic_weights: true")
         state = synthetic_state_dict(cfg, seed=int(config.get("synthetic_weights_seed", 0x5EED0005)))
-    else:
-        raise SystemExit("config needs model_path (open_clip checkpoint) or synthetic_weights: true")
     eng = SiglipImageEngine.from_state_dict(state, cfg, max_batch=int(config["max_batch_size"]),
                                             gelu=config.get("gelu", "erf"), eps=float(config.get("layer_norm_eps", 1e-6)))
     eng.image_size = (cfg["img_size"], cfg["img_size"])
     return eng
 
 
+def load_text_engine(config, state=None):
+    """The text tower (`model.encode_text`, clip_server.py:98) and its tokenizer.  Returns (engine, tokenizer);
+    the tokenizer is None when the config has no `tokenizer_path` (text requests then answer 500)."""
+    from .siglip import SiglipTextEngine, synthetic_text_state_dict, SO400M_TEXT
+    cfg = dict(SO400M_TEXT)
+    cfg.update(config.get("text_config", {}))
+    state = state if state is not None else _load_state(config)
+    if state is None:
+        if not config.get("synthetic_weights"):
+            raise SystemExit("config needs model_path (open_clip checkpoint) or synthetic_weights: true")
+        state = synthetic_text_state_dict(cfg, seed=int(config.get("synthetic_weights_seed", 0x5EED0005)) + 1)
+    eng = SiglipTextEngine.from_state_dict(state, cfg, max_batch=int(config["max_batch_size"]),
+                                           gelu=config.get("gelu", "erf"), eps=float(config.get("layer_norm_eps", 1e-6)))
+    tok = None
+    if config.get("tokenizer_path"):
+        tok = SiglipTokenizer(config["tokenizer_path"], cfg["context_length"])
+    return eng, tok
+
+
 def main(argv):
     from aiohttp import web
     with open(argv[1], "r") as f:
         config = json.load(f)
-    server = ClipServer(config, load_engine(config))
+    state = _load_state(config)
+    text_engine, tokenizer = load_text_engine(config, state)
+    server = ClipServer(config, load_engine(config, state), text_engine, tokenizer)
     print("Model loaded")
     server.start_threads()
     print("Ready")

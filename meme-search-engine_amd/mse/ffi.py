@@ -90,7 +90,21 @@ SIGNATURES = {
     "mse_siglip_stream": (vp, [vp]),
     "mse_siglip_debug_residual": (C.c_int, [vp, f32p]),
     "mse_debug_gemm_ms": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+    "mse_siglip_text_create": (vp, [vp]),
+    "mse_siglip_text_destroy": (None, [vp]),
+    "mse_siglip_text_n_weights": (C.c_int, [vp]),
+    "mse_siglip_text_weight_name": (C.c_char_p, [vp, C.c_int]),
+    "mse_siglip_text_set_weight": (C.c_int, [vp, C.c_char_p, f32p, C.POINTER(sz), C.c_int]),
+    "mse_siglip_text_finalize": (C.c_int, [vp]),
+    "mse_siglip_text_encode": (C.c_int, [vp, i64p, C.c_int, C.c_int, f32p, u16p]),
 }
+
+
+class SiglipTextConfig(C.Structure):
+    """mse_siglip_text_config (include/mse.h)"""
+    _fields_ = [("width", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
+                ("context_length", C.c_int), ("vocab_size", C.c_int), ("eps", C.c_float), ("gelu_tanh", C.c_int),
+                ("max_batch", C.c_int)]
 
 
 class SiglipConfig(C.Structure):

@@ -141,3 +141,115 @@ class SiglipImageEngine:
             self.close()
         except Exception:
             pass
+
+
+# ---- text tower ------------------------------------------------------------------------------------------------
+SO400M_TEXT = dict(width=1152, layers=27, heads=16, mlp_dim=4304, context_length=64, vocab_size=32000)  # misc/clip_accursed.py:31-55
+PAD_ID = 1                                                                                                # clip_server.py:129 (sentencepiece pad)
+
+
+def text_weight_shapes(cfg):
+    """open_clip tensor names and shapes of the text tower (`model.text`, clip_server.py:98,107)."""
+    d, m = cfg["width"], cfg["mlp_dim"]
+    s = {"text.token_embedding.weight": (cfg["vocab_size"], d), "text.positional_embedding": (cfg["context_length"], d),
+         "text.ln_final.weight": (d,), "text.ln_final.bias": (d,), "text.text_projection.weight": (d, d),
+         "text.text_projection.bias": (d,)}
+    for i in range(cfg["layers"]):
+        b = f"text.transformer.resblocks.{i}."
+        s.update({b + "ln_1.weight": (d,), b + "ln_1.bias": (d,), b + "attn.in_proj_weight": (3 * d, d),
+                  b + "attn.in_proj_bias": (3 * d,), b + "attn.out_proj.weight": (d, d), b + "attn.out_proj.bias": (d,),
+                  b + "ln_2.weight": (d,), b + "ln_2.bias": (d,), b + "mlp.c_fc.weight": (m, d), b + "mlp.c_fc.bias": (m,),
+                  b + "mlp.c_proj.weight": (d, m), b + "mlp.c_proj.bias": (d,)})
+    return s
+
+
+def synthetic_text_state_dict(cfg, seed=0x5EED0006):
+    """Random-init text tower (see synthetic_state_dict)."""
+    out = {}
+    for idx, (name, shape) in enumerate(sorted(text_weight_shapes(cfg).items())):
+        g = np.random.Generator(np.random.Philox(key=seed + idx))
+        if ".ln_1.weight" in name or ".ln_2.weight" in name or name.endswith("ln_final.weight"):
+            w = 1.0 + 0.1 * g.standard_normal(shape, dtype=np.float32)
+        elif name.endswith("bias") or name.endswith("positional_embedding"):
+            w = 0.02 * g.standard_normal(shape, dtype=np.float32)
+        elif name.endswith("token_embedding.weight"):
+            w = g.standard_normal(shape, dtype=np.float32)
+        else:
+            w = g.standard_normal(shape, dtype=np.float32) / np.float32(np.sqrt(shape[1]))
+        out[name] = w.astype(np.float32)
+    return out
+
+
+def pad_tokens(token_lists, context_length=64, pad_id=PAD_ID):
+    """What open_clip's SigLIP tokenizer wrapper does after sentencepiece: truncate to the context length and
+    pad with the pad id (clip_server.py:129 `tokenizer(texts)`); returns int64 [n, context_length]."""
+    out = np.full((len(token_lists), context_length), pad_id, np.int64)
+    for i, t in enumerate(token_lists):
+        t = list(t)[:context_length]
+        out[i, :len(t)] = t
+    return out
+
+
+class SiglipTextEngine:
+    def __init__(self, config=None, max_batch=32, eps=1e-6, gelu="erf"):
+        cfg = dict(SO400M_TEXT if config is None else config)
+        self.cfg = cfg
+        self.max_batch = max_batch
+        c = ffi.SiglipTextConfig(cfg["width"], cfg["layers"], cfg["heads"], cfg["mlp_dim"], cfg["context_length"],
+                                 cfg["vocab_size"], eps, 1 if gelu == "tanh" else 0, max_batch)
+        self._h = check_ptr(ffi.lib().mse_siglip_text_create(C.byref(c)), "mse_siglip_text_create")
+        self.embedding_size = cfg["width"]
+        self.context_length = cfg["context_length"]
+
+    def weight_names(self):
+        L = ffi.lib()
+        return [L.mse_siglip_text_weight_name(self._h, i).decode() for i in range(L.mse_siglip_text_n_weights(self._h))]
+
+    def set_weight(self, name, tensor):
+        a = _to_numpy_f32(tensor)
+        shape = (C.c_size_t * a.ndim)(*a.shape)
+        check(ffi.lib().mse_siglip_text_set_weight(self._h, name.encode(), a.ctypes.data_as(ffi.f32p), shape, a.ndim),
+              f"text set_weight({name})")
+
+    @classmethod
+    def from_state_dict(cls, state, config=None, max_batch=32, eps=1e-6, gelu="erf"):
+        """state: open_clip state dict (keys `text.*`); missing tensors are an error."""
+        eng = cls(config, max_batch, eps, gelu)
+        for name in eng.weight_names():
+            if name not in state:
+                raise MseError(f"state dict lacks '{name}'")
+            eng.set_weight(name, state[name])
+        check(ffi.lib().mse_siglip_text_finalize(eng._h), "siglip_text_finalize")
+        return eng
+
+    def encode_text(self, tokens, normalize=True, out="f32"):
+        """tokens: int [b, context_length] (already tokenised and padded).  Returns float32 [b, width] or fp16 bits."""
+        t = np.ascontiguousarray(np.asarray(tokens), np.int64)
+        if t.ndim != 2 or t.shape[1] != self.context_length:
+            raise MseError(f"tokens must be [batch, {self.context_length}]")
+        b = t.shape[0]
+        if b > self.max_batch:
+            raise MseError(f"max batch size is {self.max_batch}")
+        if t.min() < 0 or t.max() >= self.cfg["vocab_size"]:
+            raise MseError("token id outside the vocabulary")
+        of32 = np.empty((b, self.embedding_size), np.float32) if out == "f32" else None
+        of16 = np.empty((b, self.embedding_size), np.uint16) if out == "f16" else None
+        check(ffi.lib().mse_siglip_text_encode(self._h, t.ctypes.data_as(ffi.i64p), b, int(normalize),
+                                               of32.ctypes.data_as(ffi.f32p) if of32 is not None else None,
+                                               of16.ctypes.data_as(ffi.u16p) if of16 is not None else None),
+              "siglip_text_encode")
+        return of32 if out == "f32" else of16
+
+    def __call__(self, tokens):
+        return self.encode_text(tokens)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ffi.lib().mse_siglip_text_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

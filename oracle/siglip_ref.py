@@ -169,3 +169,97 @@ def to_hf_state_dict(sd, cfg):
         for nm in ("fc1", "fc2"):
             out[h + f"mlp.{nm}.weight"], out[h + f"mlp.{nm}.bias"] = sd[b + f"mlp.{nm}.weight"], sd[b + f"mlp.{nm}.bias"]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Text tower (`model.encode_text`, clip_server.py:98).  The reference holds NO restatement of it: it comes from
+# open_clip (third-party, absent).  Known from the repo: output width = model.text.text_projection.out_features
+# (clip_server.py:107,182); width 1152, 27 layers, ctx 64, vocab 32000, sentencepiece c4_en, pad id 1
+# (misc/clip_accursed.py:31-55).  Published architecture restated: token + positional
+# embedding, the same pre-LN blocks WITHOUT a causal mask, final LayerNorm, the LAST position pooled,
+# Linear projection with bias.  Key names follow open_clip's TextTransformer; cross-checked against
+# HuggingFace SiglipTextModel (independent implementation) by tests/golden/make_siglip_golden.py.
+# ---------------------------------------------------------------------------------------------------------
+TEXT_CONFIG = dict(vocab_size=32000, context_length=64, width=1152, layers=27, heads=16, mlp_dim=4304)
+
+
+def text_param_shapes(cfg):
+    d, m = cfg["width"], cfg["mlp_dim"]
+    s = {"text.token_embedding.weight": (cfg["vocab_size"], d), "text.positional_embedding": (cfg["context_length"], d),
+         "text.ln_final.weight": (d,), "text.ln_final.bias": (d,),
+         "text.text_projection.weight": (d, d), "text.text_projection.bias": (d,)}
+    for i in range(cfg["layers"]):
+        b = f"text.transformer.resblocks.{i}."
+        s.update({b + "ln_1.weight": (d,), b + "ln_1.bias": (d,), b + "attn.in_proj_weight": (3 * d, d),
+                  b + "attn.in_proj_bias": (3 * d,), b + "attn.out_proj.weight": (d, d), b + "attn.out_proj.bias": (d,),
+                  b + "ln_2.weight": (d,), b + "ln_2.bias": (d,), b + "mlp.c_fc.weight": (m, d), b + "mlp.c_fc.bias": (m,),
+                  b + "mlp.c_proj.weight": (d, m), b + "mlp.c_proj.bias": (d,)})
+    return s
+
+
+def synthetic_text_weights(cfg, seed=0x5EED0006):
+    out = {}
+    for idx, (name, shape) in enumerate(sorted(text_param_shapes(cfg).items())):
+        g = np.random.Generator(np.random.Philox(key=seed + idx))
+        if ".ln_" in name and name.endswith("weight"):
+            w = 1.0 + 0.1 * g.standard_normal(shape)
+        elif name.endswith("bias"):
+            w = 0.02 * g.standard_normal(shape)
+        elif name.endswith("token_embedding.weight"):
+            w = 0.5 * g.standard_normal(shape)
+        elif name.endswith("positional_embedding"):
+            w = 0.1 * g.standard_normal(shape)
+        else:
+            w = g.standard_normal(shape) / math.sqrt(shape[1])
+        out[name] = torch.from_numpy(w.astype(np.float32))
+    return out
+
+
+def synthetic_tokens(batch, cfg, seed=0x5EED0007):
+    g = np.random.Generator(np.random.Philox(key=seed))
+    t = g.integers(2, cfg["vocab_size"], size=(batch, cfg["context_length"]), dtype=np.int64)
+    lens = g.integers(3, cfg["context_length"], size=batch)
+    for i, n in enumerate(lens):
+        t[i, n:] = 1                                        # pad id 1 (misc/clip_accursed.py:55)
+    return torch.from_numpy(t)
+
+
+def encode_text(tokens, sd, cfg=TEXT_CONFIG, gelu="erf", eps=1e-6, normalize=True):
+    d, heads = cfg["width"], cfg["heads"]
+    dh = d // heads
+    B, n = tokens.shape
+    x = sd["text.token_embedding.weight"][tokens] + sd["text.positional_embedding"][:n]
+    for i in range(cfg["layers"]):
+        b = f"text.transformer.resblocks.{i}."
+        h = _ln(x, sd[b + "ln_1.weight"], sd[b + "ln_1.bias"], eps)
+        qkv = (h @ sd[b + "attn.in_proj_weight"].T + sd[b + "attn.in_proj_bias"]).reshape(B, n, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        att = torch.softmax((qkv[0] @ qkv[1].transpose(-1, -2)) / math.sqrt(dh), dim=-1)   # no causal mask
+        o = (att @ qkv[2]).transpose(1, 2).reshape(B, n, d)
+        x = x + (o @ sd[b + "attn.out_proj.weight"].T + sd[b + "attn.out_proj.bias"])
+        h = _ln(x, sd[b + "ln_2.weight"], sd[b + "ln_2.bias"], eps)
+        h = _gelu(h @ sd[b + "mlp.c_fc.weight"].T + sd[b + "mlp.c_fc.bias"], gelu)
+        x = x + (h @ sd[b + "mlp.c_proj.weight"].T + sd[b + "mlp.c_proj.bias"])
+    x = _ln(x, sd["text.ln_final.weight"], sd["text.ln_final.bias"], eps)
+    feat = x[:, -1, :] @ sd["text.text_projection.weight"].T + sd["text.text_projection.bias"]   # last position
+    if normalize:
+        feat = feat / feat.norm(dim=-1, keepdim=True)                                           # clip_server.py:99
+    return feat
+
+
+def text_to_hf_state_dict(sd, cfg):
+    d = cfg["width"]
+    out = {"embeddings.token_embedding.weight": sd["text.token_embedding.weight"],
+           "embeddings.position_embedding.weight": sd["text.positional_embedding"],
+           "final_layer_norm.weight": sd["text.ln_final.weight"], "final_layer_norm.bias": sd["text.ln_final.bias"],
+           "head.weight": sd["text.text_projection.weight"], "head.bias": sd["text.text_projection.bias"]}
+    for i in range(cfg["layers"]):
+        b, h = f"text.transformer.resblocks.{i}.", f"encoder.layers.{i}."
+        w, bb = sd[b + "attn.in_proj_weight"], sd[b + "attn.in_proj_bias"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            out[h + f"self_attn.{nm}.weight"], out[h + f"self_attn.{nm}.bias"] = w[j * d:(j + 1) * d], bb[j * d:(j + 1) * d]
+        out[h + "self_attn.out_proj.weight"], out[h + "self_attn.out_proj.bias"] = sd[b + "attn.out_proj.weight"], sd[b + "attn.out_proj.bias"]
+        out[h + "layer_norm1.weight"], out[h + "layer_norm1.bias"] = sd[b + "ln_1.weight"], sd[b + "ln_1.bias"]
+        out[h + "layer_norm2.weight"], out[h + "layer_norm2.bias"] = sd[b + "ln_2.weight"], sd[b + "ln_2.bias"]
+        out[h + "mlp.fc1.weight"], out[h + "mlp.fc1.bias"] = sd[b + "mlp.c_fc.weight"], sd[b + "mlp.c_fc.bias"]
+        out[h + "mlp.fc2.weight"], out[h + "mlp.fc2.bias"] = sd[b + "mlp.c_proj.weight"], sd[b + "mlp.c_proj.bias"]
+    return out

@@ -43,5 +43,26 @@ def main():
     print("pooled", pooled.shape, float(np.abs(pooled).mean()), missing)
 
 
+def text():
+    """Same for the text tower: HF SiglipTextModel on seeded weights and token ids (depth 2)."""
+    from transformers import SiglipTextConfig, SiglipTextModel
+    torch.set_grad_enabled(False)
+    cfg = dict(ref.TEXT_CONFIG, layers=2)
+    sd = ref.synthetic_text_weights(cfg, seed=0x5EED0006)
+    hf_cfg = SiglipTextConfig(hidden_size=cfg["width"], intermediate_size=cfg["mlp_dim"], num_hidden_layers=cfg["layers"],
+                              num_attention_heads=cfg["heads"], vocab_size=cfg["vocab_size"],
+                              max_position_embeddings=cfg["context_length"], attn_implementation="eager",
+                              bos_token_id=None, eos_token_id=None, pad_token_id=1)
+    model = SiglipTextModel(hf_cfg).eval()
+    target = model.text_model if hasattr(model, "text_model") else model
+    target.load_state_dict(ref.text_to_hf_state_dict(sd, cfg), strict=True)
+    tokens = ref.synthetic_tokens(3, cfg, seed=0x5EED0007)
+    pooled = model(input_ids=tokens).pooler_output.numpy()
+    np.savez_compressed(os.path.join(OUT, "siglip_text_hf_depth2.npz"), pooled=pooled.astype(np.float32), layers=2,
+                        seed_weights=0x5EED0006, seed_tokens=0x5EED0007, gelu="tanh", eps=1e-6)
+    print("text pooled", pooled.shape, float(np.abs(pooled).mean()))
+
+
 if __name__ == "__main__":
     main()
+    text()

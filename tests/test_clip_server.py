@@ -104,6 +104,54 @@ def test_wire_contract(mse):
     assert 'modality="image"' in text and 'model="siglip-so400m-14-384"' in text
 
 
+class StandInTextEngine:
+    embedding_size = D
+
+    def encode_text(self, tokens):
+        assert tokens.dtype == np.int64 and tokens.shape[1] == 64
+        f = np.cos(np.arange(D, dtype=np.float32)[None, :] * (1.0 + (tokens != 1).sum(1, keepdims=True)))
+        return f / np.linalg.norm(f, axis=1, keepdims=True)
+
+
+def tiny_tokenizer():
+    import sentencepiece as spm
+    from mse.clip_server import SiglipTokenizer
+    corpus = ["a cat sitting on a mat", "the quick brown fox jumps over the lazy dog", "meme search engine",
+              "hello world this is a test"] * 20
+    model = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(corpus), model_writer=model, vocab_size=40, model_type="unigram",
+                                   pad_id=1, eos_id=2, unk_id=0, bos_id=-1, minloglevel=2)
+    return SiglipTokenizer(model_proto=model.getvalue())
+
+
+def test_text_requests(mse):
+    from mse.clip_server import ClipServer
+    tok = tiny_tokenizer()
+    t = tok(["A cat, sitting!  ", "x " * 200])
+    assert t.shape == (2, 64) and t.dtype == np.int64
+    assert np.array_equal(t[0], tok(["a cat sitting"])[0])                      # canonicalised: case, punctuation, spaces
+    n0 = int((t[0] != 1).sum())
+    assert 0 < n0 < 63 and np.all(t[0, n0:] == 1)                               # end marker == pad id 1, then padding
+    assert t[1, 63] == 1 and np.all(t[1, :63] != 1)                             # truncated to 63 + end marker
+    srv = ClipServer(CONFIG, StandInEngine(), StandInTextEngine(), tok)
+
+    async def scenario(client):
+        r = await client.post("/", data=msgpack.dumps({"text": ["a cat", "the lazy dog jumps"]}))   # EmbeddingRequest::Text
+        a = (r.status, msgpack.loads(await r.read()))
+        r = await client.post("/", data=msgpack.dumps({"text": ["x"] * 5}))
+        b = (r.status, msgpack.loads(await r.read()))
+        r = await client.get("/metrics")
+        return a, b, (await r.read()).decode()
+
+    (status, rows), (status5, msg5), metrics = run_with_server(srv, scenario)
+    assert status == 200 and len(rows) == 2 and all(len(r) == D * 2 for r in rows)
+    got = np.stack([np.frombuffer(r, "<f2").astype(np.float32) for r in rows])
+    want = StandInTextEngine().encode_text(tok(["a cat", "the lazy dog jumps"]))
+    assert np.allclose(got, want.astype(np.float16).astype(np.float32), atol=1e-3)
+    assert status5 == 500 and "max batch size is 4" in msg5
+    assert 'modality="text"' in metrics
+
+
 def test_preprocess_matches_reference_normalisation(mse):
     from mse.clip_server import preprocess_image
     from PIL import Image
@@ -140,14 +188,27 @@ def test_server_with_hip_engine(gpu, mse):
     state = siglip.synthetic_state_dict(cfg)
     eng = siglip.SiglipImageEngine.from_state_dict(state, cfg, max_batch=4)
     eng.image_size = (384, 384)
-    srv = ClipServer(CONFIG, eng)
+    tcfg = dict(siglip.SO400M_TEXT, layers=2)
+    tstate = siglip.synthetic_text_state_dict(tcfg)
+    teng = siglip.SiglipTextEngine.from_state_dict(tstate, tcfg, max_batch=4)
+    tok = tiny_tokenizer()
+    srv = ClipServer(CONFIG, eng, teng, tok)
     images = [bmp_bytes(7), bmp_bytes(8)]
+    texts = ["a cat sitting on a mat", "hello world", "the quick brown fox"]
 
     async def scenario(client):
         r = await client.post("/", data=msgpack.dumps({"images": images}))
-        return r.status, msgpack.loads(await r.read())
+        a = r.status, msgpack.loads(await r.read())
+        r = await client.post("/", data=msgpack.dumps({"text": texts}))
+        return a, (r.status, msgpack.loads(await r.read()))
 
-    status, rows = run_with_server(srv, scenario)
+    (status, rows), (tstatus, trows) = run_with_server(srv, scenario)
+    assert tstatus == 200 and len(trows) == 3
+    tgot = np.stack([np.frombuffer(r, "<f2").astype(np.float32) for r in trows])
+    tsd = {k: torch.from_numpy(v) for k, v in tstate.items()}
+    twant = ref.encode_text(torch.from_numpy(tok(texts)), tsd, dict(ref.TEXT_CONFIG, layers=2)).numpy()
+    tcos = (tgot * twant).sum(1) / np.linalg.norm(tgot, axis=1) / np.linalg.norm(twant, axis=1)
+    assert np.all(tcos > 1 - 1e-3), tcos
     assert status == 200 and len(rows) == 2
     got = np.stack([np.frombuffer(r, "<f2").astype(np.float32) for r in rows])
     x = torch.from_numpy(np.stack([preprocess_image(b, (384, 384)) for b in images]).astype(np.float32))

@@ -48,6 +48,28 @@ def test_oracle_structure(ref):
     assert 1 - 1e-3 < float(cosine(f.numpy(), f2.numpy())[0]) < 1.0     # close but not identical
 
 
+def test_text_oracle_matches_independent_implementation(ref):
+    g = np.load(os.path.join(GOLDEN, "siglip_text_hf_depth2.npz"))
+    cfg = dict(ref.TEXT_CONFIG, layers=int(g["layers"]))
+    sd = ref.synthetic_text_weights(cfg, seed=int(g["seed_weights"]))
+    tok = ref.synthetic_tokens(3, cfg, seed=int(g["seed_tokens"]))
+    assert tok.shape == (3, 64) and int(tok.min()) >= 0 and int(tok.max()) < 32000
+    assert (tok[:, -1] == 1).any()                      # some rows end in padding (pad id 1), as real captions do
+    out = ref.encode_text(tok, sd, cfg, gelu=str(g["gelu"]), eps=float(g["eps"]), normalize=False).numpy()
+    assert np.abs(out - g["pooled"]).max() < 2e-5 * np.abs(g["pooled"]).max() + 1e-5
+    assert np.all(cosine(out, g["pooled"]) > 1 - 1e-6)
+
+
+def test_text_host_side(mse):
+    from mse import siglip
+    from oracle import siglip_ref
+    assert {k: tuple(v) for k, v in siglip.text_weight_shapes(siglip.SO400M_TEXT).items()} == \
+        {k: tuple(v) for k, v in siglip_ref.text_param_shapes(siglip_ref.TEXT_CONFIG).items()}
+    t = siglip.pad_tokens([[5, 6, 7], list(range(100, 200))])
+    assert t.shape == (2, 64) and t.dtype == np.int64
+    assert t[0].tolist() == [5, 6, 7] + [1] * 61 and t[1].tolist() == list(range(100, 164))
+
+
 def test_engine_rejects_bad_use(mse):
     from mse import ffi, siglip
     if ffi.lib().mse_device_count() > 0:
@@ -82,6 +104,34 @@ def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
     assert np.all(cosine(got1, want[:1]) > 1 - 1e-3)
     with pytest.raises(mse.MseError):
         eng.encode_image(np.zeros((5, 3, 384, 384), np.float32))           # > max_batch (clip_server.py:139)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,gelu,batch", [(2, "tanh", 3), (27, "erf", 5)])
+def test_text_engine_matches_oracle(gpu, mse, ref, layers, gelu, batch):
+    from mse import siglip
+    cfg = dict(ref.TEXT_CONFIG, layers=layers)
+    sd = ref.synthetic_text_weights(cfg)
+    tok = ref.synthetic_tokens(batch, cfg)
+    want = ref.encode_text(tok, sd, cfg, gelu=gelu, normalize=True).numpy()
+    eng = siglip.SiglipTextEngine.from_state_dict(sd, dict(siglip.SO400M_TEXT, layers=layers), max_batch=8, gelu=gelu)
+    got = eng.encode_text(tok.numpy())
+    cos = cosine(got, want)
+    assert np.all(cos > 1 - 1e-3), cos                                    # north_star tolerance
+    assert np.all(np.abs(np.linalg.norm(got, axis=1) - 1) < 1e-3)
+    got16 = eng.encode_text(tok.numpy(), out="f16").view(np.float16).astype(np.float32)
+    assert np.all(cosine(got16, want) > 1 - 1e-3)
+    raw = eng.encode_text(tok.numpy(), normalize=False)
+    want_raw = ref.encode_text(tok, sd, cfg, gelu=gelu, normalize=False).numpy()
+    assert np.all(np.abs(np.linalg.norm(raw, axis=1) / np.linalg.norm(want_raw, axis=1) - 1) < 2e-2)
+    got1 = eng.encode_text(tok.numpy()[1:2])                              # smaller batch after a larger one
+    assert np.all(cosine(got1, want[1:2]) > 1 - 1e-3)
+    with pytest.raises(mse.MseError):
+        eng.encode_text(np.ones((9, 64), np.int64))                        # > max_batch
+    with pytest.raises(mse.MseError):
+        eng.encode_text(np.ones((1, 32), np.int64))                        # wrong context length
+    with pytest.raises(mse.MseError):
+        eng.encode_text(np.full((1, 64), 32000, np.int64))                 # outside the vocabulary
 
 
 @pytest.mark.gpu
