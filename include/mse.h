@@ -163,6 +163,25 @@ int mse_greedy_search(mse_searcher* s, const uint32_t* adj, const uint32_t* deg,
                       const uint16_t* query, int base_vectors_only, uint32_t query_breakpoint, mse_nb* buf,
                       size_t* n_distances);
 
+/* Disk-index beam search: query_disk_index::greedy_search (src/query_disk_index.rs:144-212) with the records of
+ * index.bin (node.vector = the searcher's base rows, node.vertices = adj/deg, node.url.len() > 0 = has_url, NULL
+ * meaning "all"), index.pq-codes.bin and index.descriptor-codes.bin (`c`) resident in HBM.  One batched device
+ * submission per beam iteration; traversal on the host in the reference's order, including its quirks (entry
+ * point inserted with score 0, :153; the pre-buffer is cleared per beam iteration, not per node, :157).
+ * lut = mse_pq_preprocess_query output; scales = DescriptorScales (:463-471) or NULL.  Results: `buf` (best first),
+ * the visited list in fetch order (ids + exact scores incl. bias; at most visited_cap written, *n_visited is the
+ * full count), *cmps and *pq_cmps = the returned `(cmps, pq_cmps)` (:211). */
+int mse_disk_greedy_search(mse_searcher* s, mse_pq* pq, const mse_codes* c, const uint32_t* adj, const uint32_t* deg,
+                           size_t max_deg, const uint8_t* has_url, uint32_t start, const uint16_t* query, const float* lut,
+                           const float* scales, int disable_pq, size_t beamwidth, mse_nb* buf, uint32_t* visited_ids,
+                           int64_t* visited_scores, size_t visited_cap, size_t* n_visited, size_t* cmps, size_t* pq_cmps);
+/* Shard / entry-point selection (src/query_disk_index.rs:254-256,447-450): argmax over shard centroids of
+ * scale_dot_result_f64(dot_f32(centroid, query)), LAST maximum on ties (position_max_by_key). */
+int mse_select_shard(const float* centroids, size_t n_shards, size_t d, const float* query, size_t* shard_out);
+/* medioid (diskann/src/lib.rs:52-68): row with the largest `dot` (vector.rs:49-52) against the f16-rounded running
+ * mean of all rows; last maximum on ties. */
+int mse_medioid(const mse_base* b, uint32_t* id_out);
+
 /* ---- SigLIP ViT image tower: the in-process seam of clip_server.py, `fast_image_fns[batch](images NCHW
  * fp16 on device) -> [batch, 1152]` (clip_server.py:31,66-82,105-112), plus the normalisation and fp16
  * serialisation of do_inference / run_inference (clip_server.py:115,166).  Graph: aitemplate/model.py:13-123;

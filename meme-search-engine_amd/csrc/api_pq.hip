@@ -17,20 +17,6 @@ struct mse_index {
     std::mutex mu;               // add() is exclusive; searches take it too (scratch is shared)
 };
 
-struct mse_pq {
-    size_t n_centroids = 0, d = 0, dpc = 0, n_chunks = 0;
-    float* centroids = nullptr;  // device [n_centroids][d]
-    float* transform = nullptr;  // device [d][d]
-    std::mutex mu;
-    DevBuf a, b, c;              // call scratch (guarded by mu)
-};
-
-struct mse_codes {
-    uint8_t* codes = nullptr;    // device [n][code_size]
-    uint8_t* desc = nullptr;     // device [n][n_desc] or null
-    size_t n = 0, code_size = 0, n_desc = 0;
-};
-
 extern "C" {
 
 // ---- evaluator ranks (src/query_disk_index.rs:271-273,309-316) ---------------------------------

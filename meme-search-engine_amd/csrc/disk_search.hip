@@ -1,0 +1,210 @@
+// The disk-index beam search of query-disk-index with every array HBM-resident, plus the two small selectors
+// around it (shard / entry-point choice, medioid).
+//
+//   mse_disk_greedy_search  src/query_disk_index.rs:144-212  (+ :83-97 next_several_unvisited, :101-104, :135-142)
+//   mse_select_shard        src/query_disk_index.rs:254-256,447-450
+//   mse_medioid             diskann/src/lib.rs:52-68 (+ `dot`, diskann/src/vector.rs:49-52)
+//
+// The reference fetches one 4 KiB record per visited node from NVMe (io_uring, a whole beam in flight) and
+// gathers PQ codes from an mmap.  Here the record vectors (mse_base), PQ codes and descriptor bytes (mse_codes)
+// live in HBM; one beam iteration is ONE batched submission: exact fast_dot of the beam's nodes, ADC of every
+// neighbour that became fresh in this iteration, descriptor bias for both, one device->host copy.  The
+// traversal (NeighbourBuffer, visited sets) stays on the host and is replayed in the reference's order.
+#include "../../include/mse.h"
+#include "runtime.h"
+#include <hip/hip_fp16.h>
+#include <algorithm>
+#include <vector>
+
+using namespace mse;
+
+namespace {
+
+__global__ void shard_keys_kernel(const float* __restrict__ centroids, int n_shards, int d, const float* __restrict__ q,
+                                  int64_t* __restrict__ keys) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_shards) return;
+    double acc = 0.0;
+    for (int k = 0; k < d; k++) acc = acc + (double)centroids[(size_t)s * d + k] * (double)q[k];
+    keys[s] = scale_dot_result_f64(acc);
+}
+
+// running mean of lib.rs:55-58, one thread per component; rows are read coalesced (consecutive components)
+__global__ void centroid_kernel(const uint16_t* __restrict__ base, size_t n, int d, uint16_t* __restrict__ mean) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d) return;
+    const __half* b = reinterpret_cast<const __half*>(base);
+    float c = 0.0f;
+    for (size_t r = 0; r < n; r++) {
+        const float w = 1.0f / (float)(r + 1);
+        const float diff = __half2float(b[r * d + k]) - c;
+        const float step = diff * w;
+        c = c + step;
+    }
+    reinterpret_cast<__half*>(mean)[k] = __float2half_rn(c);
+}
+
+// `dot` (vector.rs:49-52) in the order the oracle states for simsimd: exact products, f64 sum in index order
+__global__ void dot_f64_rows_kernel(const uint16_t* __restrict__ base, size_t n, int d, const uint16_t* __restrict__ y,
+                                    int64_t* __restrict__ out) {
+    extern __shared__ float ys[];
+    for (int k = threadIdx.x; k < d; k += blockDim.x) ys[k] = __half2float(reinterpret_cast<const __half*>(y)[k]);
+    __syncthreads();
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint4* row = reinterpret_cast<const uint4*>(base + r * d);
+    double acc = 0.0;
+    for (int c = 0; c < d / 8; c++) {
+        const uint4 v = row[c];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float lo = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xffffu)));
+            const float hi = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+            acc = acc + (double)lo * (double)ys[c * 8 + 2 * j];
+            acc = acc + (double)hi * (double)ys[c * 8 + 2 * j + 1];
+        }
+    }
+    out[r] = scale_dot_result_f64(acc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mse_select_shard(const float* centroids, size_t n_shards, size_t d, const float* query, size_t* shard_out) {
+    if (!centroids || !query || !shard_out) return fail("select_shard: null argument");
+    if (n_shards == 0) return fail("select_shard: no shards");
+    DevBuf c, q, k;
+    if (c.ensure(n_shards * d * 4) || q.ensure(d * 4) || k.ensure(n_shards * 8)) return -1;
+    MSE_HIP_TRY(hipMemcpy(c.p, centroids, n_shards * d * 4, hipMemcpyHostToDevice));
+    MSE_HIP_TRY(hipMemcpy(q.p, query, d * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(shard_keys_kernel, dim3((unsigned)((n_shards + 63) / 64)), dim3(64), 0, nullptr, c.as<float>(),
+                       (int)n_shards, (int)d, q.as<float>(), k.as<int64_t>());
+    MSE_HIP_TRY(hipGetLastError());
+    std::vector<int64_t> keys(n_shards);
+    MSE_HIP_TRY(hipMemcpy(keys.data(), k.p, n_shards * 8, hipMemcpyDeviceToHost));
+    size_t best = 0;
+    for (size_t s = 1; s < n_shards; s++)
+        if (keys[s] >= keys[best]) best = s;  // position_max_by_key: the LAST maximum
+    *shard_out = best;
+    return 0;
+}
+
+int mse_medioid(const mse_base* b, uint32_t* id_out) {
+    if (!b || !id_out) return fail("medioid: null argument");
+    if (b->n == 0) return fail("medioid: empty vector list");
+    const size_t n = b->n;
+    const int d = (int)b->d;
+    if (d % 8) return fail("medioid: d must be a multiple of 8");
+    DevBuf mean, keys;
+    if (mean.ensure((size_t)d * 2) || keys.ensure(n * 8)) return -1;
+    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, nullptr, b->dev, n, d, mean.as<uint16_t>());
+    MSE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dot_f64_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)d * 4, nullptr, b->dev, n, d,
+                       mean.as<uint16_t>(), keys.as<int64_t>());
+    MSE_HIP_TRY(hipGetLastError());
+    std::vector<int64_t> h(n);
+    MSE_HIP_TRY(hipMemcpy(h.data(), keys.p, n * 8, hipMemcpyDeviceToHost));
+    size_t best = 0;
+    for (size_t r = 1; r < n; r++)
+        if (h[r] >= h[best]) best = r;       // Iterator::max_by keeps the last maximum
+    *id_out = (uint32_t)best;
+    return 0;
+}
+
+int mse_disk_greedy_search(mse_searcher* s, mse_pq* pq, const mse_codes* c, const uint32_t* adj, const uint32_t* deg,
+                           size_t max_deg, const uint8_t* has_url, uint32_t start, const uint16_t* query, const float* lut,
+                           const float* scales, int disable_pq, size_t beamwidth, mse_nb* buf, uint32_t* visited_ids,
+                           int64_t* visited_scores, size_t visited_cap, size_t* n_visited_out, size_t* cmps_out,
+                           size_t* pq_cmps_out) {
+    if (!s || !s->base || !pq || !c || !buf || !adj || !deg || !query || !lut) return fail("disk_greedy_search: null argument");
+    const mse_base* b = s->base;
+    const size_t n = b->n, d = b->d;
+    if (c->n != n) return fail("disk_greedy_search: codes and vectors differ in length");
+    if (c->code_size != pq->n_chunks) return fail("disk_greedy_search: code size does not match the quantiser");
+    if (start >= n) return fail("disk_greedy_search: start node out of range");
+    if (beamwidth == 0) return fail("disk_greedy_search: beamwidth must be positive");
+    hipStream_t st = s->stream;
+    const bool bias = scales && c->n_desc && c->desc;
+    const size_t lut_bytes = pq->n_chunks * pq->n_centroids * 4;
+    const size_t max_batch = beamwidth * (max_deg + 1);
+    // device scratch of the searcher: [query | lut | scales], ids, scores
+    const size_t q_off = 0, lut_off = (d * 2 + 255) & ~(size_t)255, sc_off = lut_off + ((lut_bytes + 255) & ~(size_t)255);
+    if (s->q_stage.ensure(std::max<size_t>(sc_off + c->n_desc * 4 + 256, 8 * d * 2)) || s->cand_ids.ensure(max_batch * 4) ||
+        s->cand_scores.ensure(max_batch * 8))
+        return -1;
+    char* stage = s->q_stage.as<char>();
+    MSE_HIP_TRY(hipMemcpyAsync(stage + q_off, query, d * 2, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(stage + lut_off, lut, lut_bytes, hipMemcpyHostToDevice, st));
+    if (bias) MSE_HIP_TRY(hipMemcpyAsync(stage + sc_off, scales, c->n_desc * 4, hipMemcpyHostToDevice, st));
+    const float* lut_dev = reinterpret_cast<const float*>(stage + lut_off);
+    const float* scales_dev = bias ? reinterpret_cast<const float*>(stage + sc_off) : nullptr;
+    uint32_t* ids_dev = s->cand_ids.as<uint32_t>();
+    int64_t* sc_dev = s->cand_scores.as<int64_t>();
+
+    std::vector<uint8_t> visited_adjacent(n, 0), visited(n, 0);
+    std::vector<uint32_t> batch;          // [beam nodes | fresh neighbours of this iteration]
+    std::vector<size_t> seg_end;          // pre-buffer length after each beam node
+    std::vector<int64_t> sc;
+    batch.reserve(max_batch);
+    sc.resize(max_batch);
+    size_t cmps = 0, pq_cmps = 0, n_visited = 0;
+    mse_nb_clear(buf);
+    mse_nb_insert(buf, start, 0);          // :153 -- the entry point enters with score 0
+    visited_adjacent[start] = 1;
+    for (;;) {
+        batch.clear();
+        seg_end.clear();
+        uint32_t p;
+        while (batch.size() < beamwidth && mse_nb_next_unvisited(buf, &p)) batch.push_back(p);   // :83-97
+        const size_t npts = batch.size();
+        if (npts == 0) break;
+        for (size_t j = 0; j < npts; j++) {   // :184-188 for every node of the beam, in fetch order
+            const uint32_t pt = batch[j];
+            for (uint32_t e = 0; e < deg[pt]; e++) {
+                const uint32_t nb = adj[(size_t)pt * max_deg + e];
+                if (nb >= n) return fail("graph edge points outside the index");
+                if (!visited_adjacent[nb]) { visited_adjacent[nb] = 1; batch.push_back(nb); }
+            }
+            seg_end.push_back(batch.size() - npts);
+        }
+        const size_t npre = batch.size() - npts;
+        MSE_HIP_TRY(hipMemcpyAsync(ids_dev, batch.data(), batch.size() * 4, hipMemcpyHostToDevice, st));
+        const size_t n_exact = disable_pq ? batch.size() : npts;
+        if (launch_score_rows(b->dev, n, (int)d, stage + q_off, false, ids_dev, n_exact, n_exact, sc_dev, nullptr, st)) return -1;
+        if (bias && launch_add_descriptor(ids_dev, n_exact, c->desc, (int)c->n_desc, n, scales_dev, sc_dev, st)) return -1;
+        if (!disable_pq && npre &&
+            launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, n, ids_dev + npts, npre,
+                          bias ? c->desc : nullptr, (int)c->n_desc, scales_dev, sc_dev + npts, s->n_cu, st))
+            return -1;
+        MSE_HIP_TRY(hipMemcpyAsync(sc.data(), sc_dev, batch.size() * 8, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        for (size_t j = 0; j < npts; j++) {   // replay :165-208
+            const uint32_t pt = batch[j];
+            cmps++;
+            if (!visited[pt]) {
+                visited[pt] = 1;
+                if (!has_url || has_url[pt]) {
+                    if (n_visited < visited_cap) {
+                        if (visited_ids) visited_ids[n_visited] = pt;
+                        if (visited_scores) visited_scores[n_visited] = sc[j];
+                    }
+                    n_visited++;
+                }
+            }
+            // neighbour_pre_buffer is cleared per beam iteration, not per node (:157): node j re-inserts everything
+            // gathered so far in this iteration
+            for (size_t i = 0; i < seg_end[j]; i++) {
+                mse_nb_insert(buf, batch[npts + i], sc[npts + i]);
+                if (!disable_pq) pq_cmps++;
+            }
+        }
+    }
+    if (n_visited_out) *n_visited_out = n_visited;
+    if (cmps_out) *cmps_out = cmps;
+    if (pq_cmps_out) *pq_cmps_out = pq_cmps;
+    return 0;
+}
+
+}  // extern "C"

@@ -71,3 +71,17 @@ struct mse_searcher {
     double scan_ms_total = 0.0;
     uint64_t scan_launches = 0;
 };
+
+struct mse_pq {
+    size_t n_centroids = 0, d = 0, dpc = 0, n_chunks = 0;
+    float* centroids = nullptr;  // device [n_centroids][d]
+    float* transform = nullptr;  // device [d][d]
+    std::mutex mu;
+    mse::DevBuf a, b, c;              // call scratch (guarded by mu)
+};
+
+struct mse_codes {
+    uint8_t* codes = nullptr;    // device [n][code_size]
+    uint8_t* desc = nullptr;     // device [n][n_desc] or null
+    size_t n = 0, code_size = 0, n_desc = 0;
+};

@@ -63,6 +63,61 @@ class IndexGraph:
         self.deg = np.ascontiguousarray(deg, np.uint32)
 
 
+def medioid(vecs):
+    """lib.rs:52-68: id of the row closest to the (f16-rounded, running-mean) centroid."""
+    out = C.c_uint32()
+    check(ffi.lib().mse_medioid(vecs._h, C.byref(out)), "medioid")
+    return int(out.value)
+
+
+def select_shard(centroids, query):
+    """query_disk_index.rs:254-256,447-450: index of the shard whose centroid has the largest dot with the query
+    (last maximum on ties)."""
+    c = np.ascontiguousarray(centroids, np.float32)
+    q = np.ascontiguousarray(query, np.float32).reshape(-1)
+    if c.ndim != 2 or c.shape[1] != q.size:
+        raise MseError("centroids must be [n_shards, d]")
+    out = C.c_size_t()
+    check(ffi.lib().mse_select_shard(_p(c, C.c_float), c.shape[0], c.shape[1], _p(q, C.c_float), C.byref(out)), "select_shard")
+    return int(out.value)
+
+
+class DiskSearchResult:
+    """What query_disk_index::greedy_search leaves behind: the Scratch's neighbour buffer and visited list
+    (ids + exact scores, fetch order) and the returned (cmps, pq_cmps)."""
+
+    def __init__(self, buffer, visited_ids, visited_scores, cmps, pq_cmps):
+        self.neighbour_buffer = buffer
+        self.visited_ids = visited_ids
+        self.visited_scores = visited_scores
+        self.cmps = cmps
+        self.pq_cmps = pq_cmps
+
+
+def disk_greedy_search(searcher: Searcher, quantizer, codes, graph: IndexGraph, start, query, query_preprocessed,
+                       descriptor_scales=None, disable_pq=False, beamwidth=1, search_list=1000, has_url=None):
+    """query_disk_index.rs:144-212 with the index HBM-resident.  `searcher` wraps the record vectors, `codes` the PQ
+    codes + descriptor bytes, `graph` the adjacency, `query_preprocessed` a QueryLUT, `search_list` = capacity of
+    the NeighbourBuffer (config.search_list / 1000 in evaluate, :288)."""
+    q = _bits(query).reshape(-1)
+    table = getattr(query_preprocessed, "table", query_preprocessed)
+    table = np.ascontiguousarray(table, np.float32)
+    sc = None if descriptor_scales is None else np.ascontiguousarray(descriptor_scales, np.float32)
+    hu = None if has_url is None else np.ascontiguousarray(has_url, np.uint8)
+    n = len(codes)
+    buf = NeighbourBuffer(search_list)
+    vids = np.empty(n, np.uint32)
+    vsc = np.empty(n, np.int64)
+    nv, cm, pc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(ffi.lib().mse_disk_greedy_search(
+        searcher._h, quantizer._h, codes._h, _p(graph.adj, C.c_uint32), _p(graph.deg, C.c_uint32), graph.adj.shape[1],
+        _p(hu, C.c_uint8) if hu is not None else None, int(start), _p(q, C.c_uint16), _p(table, C.c_float),
+        _p(sc, C.c_float) if sc is not None else None, int(bool(disable_pq)), int(beamwidth), buf._h,
+        _p(vids, C.c_uint32), _p(vsc, C.c_int64), n, C.byref(nv), C.byref(cm), C.byref(pc)), "disk_greedy_search")
+    k = int(nv.value)
+    return DiskSearchResult(buf, vids[:k].copy(), vsc[:k].copy(), int(cm.value), int(pc.value))
+
+
 def greedy_search(searcher: Searcher, start, base_vectors_only, query, graph: IndexGraph, l,
                   query_breakpoint=0xFFFFFFFF):
     """lib.rs:183-211.  Returns (NeighbourBuffer, distances); results are buffer.ids, best first."""

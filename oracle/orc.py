@@ -70,6 +70,10 @@ def lib():
             "orc_nb_insert": (None, [C.c_void_p, C.c_uint32, C.c_int64]),
             "orc_nb_next_unvisited": (C.c_int, [C.c_void_p, u32p]),
             "orc_greedy_search": (sz, [u16p, sz, sz, u32p, u32p, sz, C.c_uint32, u16p, C.c_int, C.c_uint32, C.c_void_p]),
+            "orc_disk_greedy_search": (sz, [u16p, sz, sz, u32p, u32p, sz, u8p, u8p, sz, sz, u8p, sz, C.c_uint32, u16p, f32p,
+                                            f32p, C.c_int, sz, C.c_void_p, u32p, i64p, sz, C.POINTER(sz), C.POINTER(sz)]),
+            "orc_centroid_f16": (None, [u16p, sz, sz, u16p]),
+            "orc_medioid": (C.c_uint32, [u16p, sz, sz]),
             "orc_index_ip": (C.c_float, [u16p, f32p, sz, C.c_int]),
             "orc_index_search": (None, [u16p, sz, sz, f32p, sz, sz, C.c_int, f32p, i64p]),
             "orc_total_embedding": (None, [u16p, f32p, sz, sz, f32p]),
@@ -292,6 +296,42 @@ def greedy_search(vecs, adj, deg, start, query, cap, base_vectors_only=False, qu
     dist = lib().orc_greedy_search(_p(vecs, C.c_uint16), n, d, _p(adj, C.c_uint32), _p(deg, C.c_uint32), adj.shape[1],
                                    start, _p(query, C.c_uint16), int(base_vectors_only), query_breakpoint, nb._h)
     return nb, int(dist)
+
+
+def disk_greedy_search(vecs, adj, deg, codes, descriptors, start, query, lut, scales=None, disable_pq=False, beamwidth=1,
+                       cap=1000, has_url=None, n_centroids=256):
+    """src/query_disk_index.rs:144-212; returns (buffer, visited_ids, visited_scores, cmps, pq_cmps)."""
+    vecs, adj, deg, query = _c(vecs, np.uint16), _c(adj, np.uint32), _c(deg, np.uint32), _c(query, np.uint16)
+    codes, lut = _c(codes, np.uint8), _c(lut, np.float32)
+    n, d = vecs.shape
+    nd = 0
+    if descriptors is not None:
+        descriptors = _c(descriptors, np.uint8).reshape(n, -1)
+        nd = descriptors.shape[1]
+    sc = None if scales is None else _c(scales, np.float32)
+    hu = None if has_url is None else _c(has_url, np.uint8)
+    nb = NeighbourBuffer(cap)
+    vids, vsc = np.empty(n, np.uint32), np.empty(n, np.int64)
+    cm, pc = C.c_size_t(), C.c_size_t()
+    nv = lib().orc_disk_greedy_search(
+        _p(vecs, C.c_uint16), n, d, _p(adj, C.c_uint32), _p(deg, C.c_uint32), adj.shape[1],
+        _p(hu, C.c_uint8) if hu is not None else None, _p(codes, C.c_uint8), codes.shape[1], n_centroids,
+        _p(descriptors, C.c_uint8) if descriptors is not None else None, nd, start, _p(query, C.c_uint16),
+        _p(lut, C.c_float), _p(sc, C.c_float) if sc is not None else None, int(disable_pq), beamwidth, nb._h,
+        _p(vids, C.c_uint32), _p(vsc, C.c_int64), n, C.byref(cm), C.byref(pc))
+    return nb, vids[:nv].copy(), vsc[:nv].copy(), int(cm.value), int(pc.value)
+
+
+def centroid_f16(vecs):
+    vecs = _c(vecs, np.uint16)
+    out = np.empty(vecs.shape[1], np.uint16)
+    lib().orc_centroid_f16(_p(vecs, C.c_uint16), vecs.shape[0], vecs.shape[1], _p(out, C.c_uint16))
+    return out
+
+
+def medioid(vecs):
+    vecs = _c(vecs, np.uint16)
+    return int(lib().orc_medioid(_p(vecs, C.c_uint16), vecs.shape[0], vecs.shape[1]))
 
 
 def index_search(codes, q, k, order=0):

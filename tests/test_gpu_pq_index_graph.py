@@ -171,3 +171,82 @@ def test_greedy_search_matches_oracle(gpu, mse, orc):
     obuf, odist = orc.greedy_search(vecs, adj, degs, 0, q, L, True, 2000)
     assert dist == odist and np.array_equal(buf.ids, obuf.ids)
     assert np.all(buf.ids[buf.ids != 0] < 2000)
+
+
+def knn_graph(x, deg, rng, long_edges=4):
+    """Small navigable graph for the beam-search tests: nearest neighbours by dot product + a few random edges."""
+    n = len(x)
+    s = x @ x.T
+    np.fill_diagonal(s, -np.inf)
+    near = np.argsort(-s, axis=1)[:, :deg - long_edges]
+    adj = np.concatenate([near, rng.integers(0, n, size=(n, long_edges))], axis=1).astype(np.uint32)
+    degs = rng.integers(deg - 2, deg + 1, size=n).astype(np.uint32)
+    return adj, degs
+
+
+@pytest.mark.parametrize("beamwidth,disable_pq,use_scales", [(1, False, True), (4, False, True), (3, True, True), (4, False, False)])
+def test_disk_greedy_search_matches_oracle(gpu, mse, orc, beamwidth, disable_pq, use_scales):
+    """query_disk_index::greedy_search (src/query_disk_index.rs:144-212): neighbour buffer, visited list in fetch order
+    and both counters are bit-identical to the oracle, including the pre-buffer quirk for beamwidth > 1."""
+    rng = np.random.default_rng(11)
+    n, deg, L = 2500, 12, 48
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:2000], iters=2)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    scales = (np.array([0.5, 0, -0.25, 1.0], np.float32) / np.float32(512)) if use_scales else None
+    has_url = (rng.random(n) > 0.1).astype(np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    gcodes = mse.Codes(codes, desc)
+    graph = mse.IndexGraph(adj, degs)
+    total_recall = 0
+    for qi in range(3):
+        qv = clustered_rows(orc, 1, n_centres=32, seed=100 + qi)[0]
+        qh = orc.f16_bits(qv)
+        lut = opq.preprocess_query(qv)
+        start = int(rng.integers(0, n))
+        res = mse.disk_greedy_search(searcher, gpq, gcodes, graph, start, qh, mse.QueryLUT(lut), scales, disable_pq, beamwidth,
+                                     search_list=L, has_url=has_url)
+        obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, desc, start, qh, lut, scales, disable_pq,
+                                                              beamwidth, L, has_url)
+        assert (res.cmps, res.pq_cmps) == (ocm, opc)
+        assert np.array_equal(res.neighbour_buffer.ids, obuf.ids) and np.array_equal(res.neighbour_buffer.scores, obuf.scores)
+        assert np.array_equal(res.visited_ids, ovids) and np.array_equal(res.visited_scores, ovsc)
+        assert res.cmps >= len(res.visited_ids) > 0 and np.all(has_url[res.visited_ids] == 1)
+        if disable_pq:
+            assert res.pq_cmps == 0
+        # the search is useful, not only self-consistent: visited list reaches most of the true top-10
+        truth = orc.score_all(base, qh)
+        if scales is not None:
+            truth = truth + np.array([orc.descriptor_product(scales, desc, i) for i in range(n)])
+        truth[has_url == 0] = np.iinfo(np.int64).min
+        top = np.argsort(truth, kind="stable")[::-1][:10]
+        total_recall += len(set(top.tolist()) & set(res.visited_ids.tolist()))
+    assert total_recall >= 15, total_recall
+    # errors: edge outside the index, start outside the index
+    bad = adj.copy()
+    bad[start, 0] = n + 5
+    with pytest.raises(mse.MseError):
+        mse.disk_greedy_search(searcher, gpq, gcodes, mse.IndexGraph(bad, degs), start, qh, mse.QueryLUT(lut))
+    with pytest.raises(mse.MseError):
+        mse.disk_greedy_search(searcher, gpq, gcodes, graph, n, qh, mse.QueryLUT(lut))
+
+
+def test_select_shard_and_medioid(gpu, mse, orc):
+    rng = np.random.default_rng(12)
+    cents = rng.standard_normal((42, D)).astype(np.float32)          # kmeans.py:10 -> 42 shards
+    for i in range(6):
+        q = rng.standard_normal(D).astype(np.float32)
+        assert mse.select_shard(cents, q) == orc.select_shard(cents, q)
+    cents[17] = cents[5]                                             # exact tie: position_max_by_key keeps the LAST maximum
+    q = (cents[5] * 3).astype(np.float32)
+    assert mse.select_shard(cents, q) == orc.select_shard(cents, q) == 17
+    for n in (1, 2, 777, 5000):
+        vecs = orc.gen_rows_f16(SEED_BASE, 3, n)
+        vl = mse.VectorList.from_f16s(vecs, D)
+        assert mse.medioid(vl) == orc.medioid(vecs)
+    dup = np.concatenate([vecs[:10], vecs[:10]])                     # every row twice: the later copy wins ties
+    assert mse.medioid(mse.VectorList.from_f16s(dup, D)) == orc.medioid(dup) >= 10

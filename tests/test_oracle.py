@@ -352,3 +352,79 @@ def test_total_embedding(orc):
     for i in range(3):
         want += orc.f16_to_f32(e[i]) * w[i]
     assert np.array_equal(got, want)
+
+
+def test_disk_greedy_search_against_literal_restatement(orc):
+    """src/query_disk_index.rs:144-212 restated literally in Python (sets, lists) on a small index; pins the start
+    score of 0, the per-iteration pre-buffer, both counters and the visited-list rule."""
+    rng = np.random.default_rng(21)
+    n, d, deg, L, nch = 300, 64, 6, 24, 4
+    vecs = orc.f16_bits((rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32))
+    adj = rng.integers(0, n, size=(n, deg), dtype=np.uint32)
+    degs = rng.integers(1, deg + 1, size=n).astype(np.uint32)
+    codes = rng.integers(0, 16, size=(n, nch), dtype=np.uint8)
+    lut = rng.standard_normal((nch, 16)).astype(np.float32)
+    desc = rng.integers(0, 256, size=(n, 2), dtype=np.uint8)
+    scales = np.array([0.001, -0.002], np.float32)
+    has_url = (rng.random(n) > 0.2).astype(np.uint8)
+    q = orc.f16_bits((rng.standard_normal(d) / np.sqrt(d)).astype(np.float32))
+
+    def bias(i):
+        return sum(int(orc.lib().orc_scale_dot_result(np.float32(scales[j]) * np.float32(desc[i, j]))) for j in range(2))
+
+    def adc(i):
+        s = np.float32(0)
+        for c in range(nch):
+            s = np.float32(s + lut[c, codes[i, c]])
+        return int(orc.lib().orc_scale_dot_result(s))
+
+    for beam, disable_pq in [(1, False), (3, False), (2, True)]:
+        buf = orc.NeighbourBuffer(L)
+        buf.insert(7, 0)
+        visited_adjacent, visited, vlist, cmps, pq_cmps = {7}, set(), [], 0, 0
+        while True:
+            pts = []
+            for _ in range(beam):
+                p = buf.next_unvisited()
+                if p is None:
+                    break
+                pts.append(p)
+            if not pts:
+                break
+            pre = []
+            for pt in pts:
+                score = orc.fast_dot(q, vecs[pt]) + bias(pt)
+                cmps += 1
+                if pt not in visited:
+                    visited.add(pt)
+                    if has_url[pt]:
+                        vlist.append((pt, score))
+                for nb in adj[pt, :degs[pt]]:
+                    if int(nb) not in visited_adjacent:
+                        visited_adjacent.add(int(nb))
+                        pre.append(int(nb))
+                for nb in pre:
+                    if disable_pq:
+                        buf.insert(nb, orc.fast_dot(q, vecs[nb]) + bias(nb))
+                    else:
+                        buf.insert(nb, adc(nb) + bias(nb))
+                        pq_cmps += 1
+        got, vids, vsc, cm, pc = orc.disk_greedy_search(vecs, adj, degs, codes, desc, 7, q, lut, scales, disable_pq, beam, L,
+                                                       has_url, n_centroids=16)
+        assert (cm, pc) == (cmps, pq_cmps)
+        assert np.array_equal(got.ids, buf.ids) and np.array_equal(got.scores, buf.scores)
+        assert vids.tolist() == [v[0] for v in vlist] and vsc.tolist() == [v[1] for v in vlist]
+        if beam > 1 and not disable_pq:
+            assert pq_cmps > len(visited_adjacent) - 1          # the quirk: some neighbours are scored more than once
+
+
+def test_medioid_running_mean(orc):
+    rng = np.random.default_rng(22)
+    vecs = orc.f16_bits((rng.standard_normal((37, 64)) / 8).astype(np.float32))
+    c = np.zeros(64, np.float32)
+    for i, v in enumerate(orc.f16_to_f32(vecs)):                   # lib.rs:55-58
+        c = (c + (v - c) * np.float32(1.0 / np.float32(i + 1))).astype(np.float32)
+    assert np.array_equal(orc.centroid_f16(vecs), orc.f16_bits(c))
+    keys = [orc.dot_f64(v, orc.f16_bits(c)) for v in vecs]
+    want = max(range(37), key=lambda i: (keys[i], i))             # last maximum
+    assert orc.medioid(vecs) == want
