@@ -26,14 +26,15 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 as_bf8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round to nearest even, NaN kept quiet
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// round to nearest even in hardware (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2v){a, b}, bf16x2));
+}
+__device__ __forceinline__ uint32_t pack2(float2v v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
 
 template <int N> __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -61,6 +62,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return 0.5f * x * (1.0f + tanhf(u));
+}
+
+// GELU in the GEMM epilogues: x * sigmoid(u(x)), u an odd polynomial -- 5 packed-f32 operations, one exp2 and one
+// reciprocal per element (the A&S erf above costs three times the vector-ALU work, and the fc1 epilogue is ALU bound).
+//   tanh flavour: u = 2 * 0.79788456 (x + 0.044715 x^3)                      (the identity 0.5 (1 + tanh v) = sigmoid(2 v))
+//   erf  flavour: u = 1.59501574 x + 0.0740113143 x^3 - 7.03036941e-4 x^5     (minimax fit of x Phi(x) on [-8, 8]:
+//                 |error| <= 2.6e-5 absolute, i.e. below bf16 rounding for every output above 0.007 in magnitude)
+// x^2 is clamped at 50 so that u stays monotone; coefficients are pre-multiplied by -log2(e).
+struct GeluC { float a, b, c; };
+__device__ __forceinline__ GeluC gelu_coef(int tanh_flavour) {
+    constexpr float L = -1.4426950408889634f;
+    return tanh_flavour ? GeluC{L * 1.5957691216f, L * 0.0713548163f, 0.0f}
+                        : GeluC{L * 1.59501574f, L * 7.40113143e-02f, L * -7.03036941e-04f};
+}
+__device__ __forceinline__ float2v gelu2(float2v x, const GeluC& k) {
+    float2v s = __builtin_elementwise_min(x * x, (float2v){50.0f, 50.0f});
+    float2v t = __builtin_elementwise_fma(s, (float2v){k.c, k.c}, (float2v){k.b, k.b});
+    t = __builtin_elementwise_fma(t, s, (float2v){k.a, k.a});
+    const float2v u = t * x;
+    const float2v d = (float2v){__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + 1.0f;
+    return x * (float2v){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -102,8 +124,9 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, size_t m, int n, c
     n += a.n_off;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
         if constexpr (EPI == EPI_GELU) {
-            if (a.gelu_tanh) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
-            else { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            const GeluC gc = gelu_coef(a.gelu_tanh);
+            const float2v lo = gelu2((float2v){v0, v1}, gc), hi = gelu2((float2v){v2, v3}, gc);
+            v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
         }
         if (!mok) { v0 = v1 = v2 = v3 = 0.0f; }
         *reinterpret_cast<uint2*>(a.out_bf16 + m * a.ldo + n) = uint2{pack2(v0, v1), pack2(v2, v3)};
@@ -355,6 +378,7 @@ __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
         // ablation showed that epilogue, not MFMA or DMA, bounded the kernel).  Per wave: 64 rows x 128 cols bf16
         // with a 272-byte row stride (16 rows x 8 bytes land on distinct banks up to 2-way).
         constexpr int EROW = 272;
+        const GeluC gc = gelu_coef(a.gelu_tanh);
         __syncthreads();  // every wave is done with the operand stages
         char* et = smem + wave * (64 * EROW);
 #pragma unroll
@@ -364,11 +388,9 @@ __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
                 const int nl = nt * 16 + 4 * g;
                 const float4 bv = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 128 + nl);
                 float v0 = acc[nt][mt][0] + bv.x, v1 = acc[nt][mt][1] + bv.y, v2 = acc[nt][mt][2] + bv.z, v3 = acc[nt][mt][3] + bv.w;
-                if constexpr (EPI == EPI_GELU) {
-                    if (a.gelu_tanh) { v0 = gelu_tanh(v0); v1 = gelu_tanh(v1); v2 = gelu_tanh(v2); v3 = gelu_tanh(v3); }
-                    else { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-                }
-                *reinterpret_cast<uint2*>(et + (mt * 16 + i) * EROW + nl * 2) = uint2{pack2(v0, v1), pack2(v2, v3)};
+                float2v lo = {v0, v1}, hi = {v2, v3};
+                if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc); hi = gelu2(hi, gc); }
+                *reinterpret_cast<uint2*>(et + (mt * 16 + i) * EROW + nl * 2) = uint2{pack2(lo), pack2(hi)};
             }
         // own region only: a wave-level wait is enough (no other wave touches it)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -387,6 +409,198 @@ __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 8; nt++)
                 store_quad<EPI>(a, m0 + wm * 64 + mt * 16 + i, (int)n0 + wn * 128 + nt * 16 + 4 * g, acc[nt][mt]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 GEMM, two wave groups in ping-pong ("8 phases per two K tiles").
+//
+// Why a second 256x256 kernel: gemm256_kernel streams 64-byte row pieces (BK = 32), i.e. HALF cache lines, so
+// every 128-byte line costs two requests on the CU's L1-miss path, and its eight waves run in lockstep, so the
+// LDS fragment reads of a K step and its MFMAs never overlap.  Here
+//   * BK = 64: every LDS-DMA request is a whole 128-byte line (8 lanes x 16 B, permuted by the swizzle);
+//   * waves are 2 (m) x 4 (n), wave tile 128 (m) x 64 (n); the two m-halves (waves w and w+4 share a SIMD) run one
+//     barrier apart, so on every SIMD one wave issues MFMAs while the other reads its fragments and issues DMA;
+//   * a K tile is staged as four 16 KiB units (128 rows x 128 B): Rq0/Rq1 = the activation rows of quadrant 0/1
+//     of both m-halves, Cq0/Cq1 = the weight rows of quadrant 0/1 of all four n-quarters; one unit is re-staged
+//     per phase, two or more phases after its last read, and waited for (counted vmcnt, three units in flight)
+//     at least one phase before its next read.  Two K tiles are resident (128 KiB).
+// Phase p of K tile t (accumulator quadrant, fragment reads, unit re-staged):
+//   0: (Rq0,Cq0)  reads Cq0 (4) + Rq0 (8)   stages Cq1[t+1]
+//   1: (Rq0,Cq1)  reads Cq1 (4)             stages Rq1[t+1]
+//   2: (Rq1,Cq1)  reads Rq1 (8)             stages Rq0[t+2]
+//   3: (Rq1,Cq0)  -                         stages Cq0[t+2]
+// Each phase: fragment reads, DMA issue, vmcnt wait | barrier | lgkmcnt(0), 16 MFMAs | barrier.
+// LDS swizzle for 128-byte rows: slot (row, s) holds global 16-byte piece s ^ ((row >> 1) & 7) -- every
+// ds_read_b128 service group then touches 16 distinct 16-byte bank slots (same map as scan_mfma.hip).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int P8_UNIT = 128 * 128;   // 16 KiB
+constexpr int P8_BUF = 4 * P8_UNIT;  // one K tile: [Rq0 | Cq0 | Cq1 | Rq1]
+constexpr int P8_EROW = 144;         // epilogue staging row: 64 bf16 + 16 B pad
+constexpr int LDS8P_BYTES = 8 * 128 * P8_EROW;  // 144 KiB >= 2 * P8_BUF
+enum { U_RQ0 = 0, U_CQ0 = 1, U_CQ1 = 2, U_RQ1 = 3 };
+
+// ABL (developer ablation): 0 shipped, 1 no MFMA, 2 no DMA in the loop, 3 no LDS fragment reads, 4 no epilogue math/stores
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int n_blocks = a.N / 256, m_blocks = a.M / 256;
+    const int nwg = n_blocks * m_blocks;
+    int b = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8, idx = b / 8;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int mb = b / n_blocks, nb = b % n_blocks;
+    const size_t m0 = (size_t)mb * 256, n0 = (size_t)nb * 256;
+    const size_t kbytes = (size_t)a.K * 2;
+
+    // DMA sources: a unit is 16 wave-instructions of 8 rows x 128 B; this wave issues instructions 2w, 2w+1
+    const char* rsrc[2];  // quadrant 0 of the activation rows; quadrant 1 = + 64 rows
+    const char* csrc[2];  // quadrant 0 of the weight rows;     quadrant 1 = + 32 rows
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int u = wave * 16 + j * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((u >> 1) & 7);
+        rsrc[j] = reinterpret_cast<const char*>(a.x) + (m0 + (size_t)(u >> 6) * 128 + (u & 63)) * kbytes + piece * 16;
+        csrc[j] = reinterpret_cast<const char*>(a.w) + (n0 + (size_t)(u >> 5) * 64 + (u & 31)) * kbytes + piece * 16;
+    }
+    const size_t rq1 = 64 * kbytes, cq1 = 32 * kbytes;
+    auto issue = [&](int unit, int kt) {
+        char* dst = smem + (kt & 1) * P8_BUF + unit * P8_UNIT + wave * 2048;
+        const size_t koff = (size_t)kt * 128;
+        const bool is_r = unit == U_RQ0 || unit == U_RQ1;
+        const size_t qoff = unit == U_RQ1 ? rq1 : (unit == U_CQ1 ? cq1 : 0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) dma16((is_r ? rsrc[j] : csrc[j]) + qoff + koff, dst + j * 1024);
+    };
+
+    // fragment addresses: row (.. + i), k step ks -> piece 4 ks + g, swizzled by (i >> 1)
+    const int foff0 = i * 128 + ((g ^ (i >> 1)) & 7) * 16;
+    const int foff1 = i * 128 + (((4 + g) ^ (i >> 1)) & 7) * 16;
+    const int r_off = wr * 64 * 128, c_off = wc * 32 * 128;
+
+    float4v acc[4][8];  // [n tile of 16][m tile of 16]
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[ct][rt][r] = 0.0f;
+
+    const int nk = a.K / 64;
+    // prologue: the six units the steady-state schedule would have issued before phase 0
+    issue(U_RQ0, 0); issue(U_CQ0, 0); issue(U_CQ1, 0); issue(U_RQ1, 0);
+    if (nk > 1) { issue(U_RQ0, 1); issue(U_CQ0, 1); vm_wait<8>(); } else { vm_wait<4>(); }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second m-half runs one barrier behind the first
+
+    bf16x8 rf[4][2], cf0[2][2], cf1[2][2];
+    auto read_r = [&](const char* unit_base) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (ABL == 3) { rf[t][0] = as_bf8(u32x4{(uint32_t)t, 1u, 2u, 3u}); rf[t][1] = rf[t][0]; continue; }
+            rf[t][0] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + r_off + t * 2048 + foff0));
+            rf[t][1] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + r_off + t * 2048 + foff1));
+        }
+    };
+    auto read_c = [&](const char* unit_base, bf16x8 (&cf)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (ABL == 3) { cf[t][0] = as_bf8(u32x4{(uint32_t)t, 5u, 6u, 7u}); cf[t][1] = cf[t][0]; continue; }
+            cf[t][0] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + c_off + t * 2048 + foff0));
+            cf[t][1] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + c_off + t * 2048 + foff1));
+        }
+    };
+#define P8_MFMA(CF, CT0, RT0)                                                                                       \
+    do {                                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ct++)                                                        \
+                _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                  \
+                    if (ABL == 1) { asm volatile("" ::"v"(CF[ct][ks]), "v"(rf[rt][ks])); acc[CT0 + ct][RT0 + rt][0] += 1.0f; } \
+                    else acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CF[ct][ks], rf[rt][ks], \
+                                                                                      acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
+                }                                                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                               \
+    } while (0)
+#define P8_STAGE(COND, UNIT, KT)                                                                                    \
+    do {                                                                                                            \
+        if ((COND) && ABL != 2) { issue(UNIT, KT); vm_wait<6>(); } else { vm_wait<0>(); }                           \
+    } while (0)
+
+    for (int t = 0; t < nk; t++) {
+        const char* buf = smem + (t & 1) * P8_BUF;
+        // phase 0
+        read_c(buf + U_CQ0 * P8_UNIT, cf0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_r(buf + U_RQ0 * P8_UNIT);
+        P8_STAGE(t + 1 < nk, U_CQ1, t + 1);
+        P8_MFMA(cf0, 0, 0);
+        // phase 1
+        read_c(buf + U_CQ1 * P8_UNIT, cf1);
+        P8_STAGE(t + 1 < nk, U_RQ1, t + 1);
+        P8_MFMA(cf1, 2, 0);
+        // phase 2
+        read_r(buf + U_RQ1 * P8_UNIT);
+        P8_STAGE(t + 2 < nk, U_RQ0, t + 2);
+        P8_MFMA(cf1, 2, 4);
+        // phase 3
+        P8_STAGE(t + 2 < nk, U_CQ0, t + 2);
+        P8_MFMA(cf0, 0, 4);
+    }
+#undef P8_MFMA
+#undef P8_STAGE
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two halves: every LDS read and DMA is complete
+
+    const size_t wm0 = m0 + (size_t)wr * 128;
+    const int wn0 = (int)n0 + wc * 64;
+    if constexpr (ABL == 4) {
+        float s = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) s += acc[ct][rt][0] + acc[ct][rt][1] + acc[ct][rt][2] + acc[ct][rt][3];
+        if (s == 12345.678f) a.out_bf16[0] = 1;
+    } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        // bf16 outputs leave through LDS so that every global store instruction writes whole 128-byte row segments
+        char* et = smem + wave * (128 * P8_EROW);
+        const GeluC gc = gelu_coef(a.gelu_tanh);
+#pragma unroll
+        for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                const int nl = ct * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + wn0 + nl);
+                float v0 = acc[ct][rt][0] + bv.x, v1 = acc[ct][rt][1] + bv.y, v2 = acc[ct][rt][2] + bv.z, v3 = acc[ct][rt][3] + bv.w;
+                float2v lo = {v0, v1}, hi = {v2, v3};
+                if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc); hi = gelu2(hi, gc); }
+                *reinterpret_cast<uint2*>(et + (rt * 16 + i) * P8_EROW + nl * 2) = uint2{pack2(lo), pack2(hi)};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own region only
+        const int rsub = lane >> 3, chunk = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int row = it * 8 + rsub;
+            const size_t m = wm0 + row;
+            u32x4 v = *reinterpret_cast<const u32x4*>(et + row * P8_EROW + chunk * 16);
+            if (m >= (size_t)a.m_valid) v = u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(a.out_bf16 + m * a.ldo + a.n_off + wn0 + chunk * 8) = v;
+        }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) store_quad<EPI>(a, wm0 + rt * 16 + i, wn0 + ct * 16 + 4 * g, acc[ct][rt]);
     }
 }
 
@@ -736,15 +950,19 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, GS * STAGE_BYTES));
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
         attr_set[dev] = true;
     }
-    static const bool force128 = getenv("MSE_GEMM_128") != nullptr;   // developer knob: old tile only
+    static const bool force128 = getenv("MSE_GEMM_128") != nullptr;   // developer knobs: older kernels only
+    static const bool old256 = getenv("MSE_GEMM_OLD256") != nullptr;
     const int n256 = force128 ? 0 : (a_in.N / B2) * B2;
     if (n256 > 0) {
         GemmArgs a = a_in;
         a.N = n256;
         const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
+        if (old256 || a.K < 128) hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
+        else hipLaunchKernelGGL(gemm8p_kernel<EPI>, dim3(grid), dim3(512), LDS8P_BYTES, st, a);
         MSE_HIP_TRY(hipGetLastError());
     }
     if (n256 < a_in.N) {  // remaining 128 columns (N = 1152, 3456) on the 256 x 128 tile
@@ -775,7 +993,23 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
         hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, X>), dim3(grid), dim3(GW * 64), lds, st, a);               \
         break;
-    switch (abl) { MSE_ABL(0) MSE_ABL(1) MSE_ABL(2) MSE_ABL(3) default: return fail("bad ablation"); }
+    switch (abl) {
+        MSE_ABL(0) MSE_ABL(1) MSE_ABL(2) MSE_ABL(3)
+#define MSE_ABL8(X)                                                                                             \
+    case 10 + X:                                                                                                \
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_GELU, X>),              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));              \
+        hipLaunchKernelGGL((gemm8p_kernel<EPI_GELU, X>), dim3(grid), dim3(512), LDS8P_BYTES, st, a);            \
+        break;
+        MSE_ABL8(0) MSE_ABL8(1) MSE_ABL8(2) MSE_ABL8(3) MSE_ABL8(4)
+#undef MSE_ABL8
+        case 20:  // plain bf16 epilogue (no GELU)
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_BF16, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
+            hipLaunchKernelGGL((gemm8p_kernel<EPI_BF16, 0>), dim3(grid), dim3(512), LDS8P_BYTES, st, a);
+            break;
+        default: return fail("bad ablation");
+    }
 #undef MSE_ABL
     MSE_HIP_TRY(hipGetLastError());
     return 0;
