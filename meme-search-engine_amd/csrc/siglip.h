@@ -30,11 +30,13 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
 int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int width, size_t rows,
                      uint16_t* out, int ldo, float* out_f32, hipStream_t st);
-int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, uint16_t* out, hipStream_t st);
+// token rows of image b are rows b * tstride + t (t < tokens; the rest of the stride is padding)
+int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
+                    hipStream_t st);
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
-                     int dh_pad, int dv_pad, uint16_t* out, int ldo, hipStream_t st);
-int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, float* out,
-                          int ldo, hipStream_t st);
+                     int dh_pad, int dv_pad, uint16_t* out, int ldo, int tstride, hipStream_t st);
+int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, int tstride,
+                          float* out, int ldo, hipStream_t st);
 int launch_small_linear(const float* x, int ldx, const uint16_t* w, int ldw, const float* bias, int K, int N, int B, int act,
                         const float* res, int ldres, float* y, int ldy, hipStream_t st);
 int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, float* out_f32, uint16_t* out_f16, hipStream_t st);

@@ -98,13 +98,16 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->kpe = c->in_chans * c->patch_size * c->patch_size; m->kpe_pad = (int)round_up(m->kpe, 64);
     m->n_pad = (int)round_up(m->tokens, 32);
     m->max_batch = c->max_batch;
-    m->m_pad = round_up((size_t)m->max_batch * m->tokens, 256);
+    // token rows of image b are rows b * n_pad + t of every [M][..] buffer: images start on 32-row boundaries, so
+    // 8- and 16-token pieces never straddle two images (the transposed V scatter of the QKV epilogue needs that)
+    m->m_pad = round_up((size_t)m->max_batch * m->n_pad, 256);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
     const size_t D = m->D, MP = m->mlp_pad;
     // parameters (names: clip_server.py:40-57)
     m->add_bf16("trunk.patch_embed.proj.weight", &m->wpe, D, m->kpe, D, m->kpe_pad);
     m->add_f32("trunk.patch_embed.proj.bias", &m->bpe, 1, D);
-    m->add_f32("trunk.pos_embed", &m->pos, m->tokens, D);
+    m->pos = m->dalloc<float>((size_t)m->n_pad * D, true);   // padded to the row stride (EPI_PATCH indexes it by m % n_pad)
+    m->slots["trunk.pos_embed"] = Slot{Slot::F32, m->pos, (size_t)m->tokens, D, (size_t)m->tokens, D};
     m->blocks.resize(c->depth);
     for (int i = 0; i < c->depth; i++) {
         Block& b = m->blocks[i];
@@ -222,27 +225,27 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         MSE_HIP_TRY(hipMemcpyAsync(m->img_dev, images, img_elems * (dtype ? 2 : 4), hipMemcpyHostToDevice, st));
         img = m->img_dev;
     }
-    const int D = m->D, T = m->tokens;
-    const int M = batch * T;
+    const int D = m->D, T = m->tokens, TS = m->n_pad;
+    const int M = batch * TS;   // rows incl. the (finite, never read as keys) padding rows of every image
     const int Mp = (int)round_up(M, 256);
     const int gelu_tanh = c.gelu_tanh;
     // PatchEmbedder + PositionalEmbeddings (model.py:57-80,122)
-    if (launch_patchify(img, dtype, batch, c.in_chans, c.img_size, c.img_size, c.patch_size, m->kpe_pad, m->patches, st)) return -1;
+    if (launch_patchify(img, dtype, batch, c.in_chans, c.img_size, c.img_size, c.patch_size, m->kpe_pad, TS, m->patches, st)) return -1;
     {
         GemmLaunch g; g.x = m->patches; g.w = m->wpe; g.bias = m->bpe; g.M = Mp; g.N = D; g.K = m->kpe_pad; g.m_valid = M;
-        g.resid = m->x; g.ldr = D; g.pos = m->pos; g.tokens = T;
+        g.resid = m->x; g.ldr = D; g.pos = m->pos; g.tokens = TS;
         if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
     }
     for (int i = 0; i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
         const Block& b = m->blocks[i];
         if (launch_layernorm(m->x, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
         {
-            GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
+            GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
             g.dv_pad = m->dv_pad;
             if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
         }
-        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, st)) return -1;
+        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M;
             g.resid = m->x; g.ldr = D;
@@ -267,7 +270,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         g.out_bf16 = m->kvb; g.ldo = 2 * D;
         if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
     }
-    if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, m->pool_a, D, st)) return -1;
+    if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, m->pool_a, D, st)) return -1;
     if (launch_small_linear(m->pool_a, D, m->wpp, D, m->bpp, D, D, batch, 0, nullptr, 0, m->pool_o, D, st)) return -1;
     if (launch_layernorm(m->pool_o, D, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
     if (launch_small_linear(m->pool_ln, D, m->wp1, D, m->bp1, D, m->mlp, batch, gelu_tanh ? 2 : 1, nullptr, 0, m->pool_h, m->mlp,
@@ -314,7 +317,8 @@ int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
 // test hook: the residual stream ([batch*tokens][emb] fp32) as left by the last forward (after the last block)
 int mse_siglip_debug_residual(mse_siglip* m, float* out) {
     if (!m || !m->last_batch) return fail("siglip: no forward has run");
-    MSE_HIP_TRY(hipMemcpy(out, m->x, (size_t)m->last_batch * m->tokens * m->D * 4, hipMemcpyDeviceToHost));
+    MSE_HIP_TRY(hipMemcpy2D(out, (size_t)m->tokens * m->D * 4, m->x, (size_t)m->n_pad * m->D * 4, (size_t)m->tokens * m->D * 4,
+                            m->last_batch, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -441,7 +441,8 @@ constexpr int LDS8P_BYTES = 8 * 128 * P8_EROW;  // 144 KiB >= 2 * P8_BUF
 enum { U_RQ0 = 0, U_CQ0 = 1, U_CQ1 = 2, U_RQ1 = 3 };
 
 // ABL (developer ablation): 0 shipped, 1 no MFMA, 2 no DMA in the loop, 3 no LDS fragment reads, 4 no epilogue math/stores
-template <int EPI, int ABL = 0>
+// VSWAP (EPI_QKV only): the launch covers V columns, which are wanted transposed -- MFMA operands swapped
+template <int EPI, int ABL = 0, bool VSWAP = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -492,6 +493,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[ct][rt][r] = 0.0f;
 
+    // V columns of the QKV projection are wanted transposed ([head dim][token]): for those tiles the MFMA operands are
+    // swapped, so an accumulator lane holds four consecutive TOKENS of one column instead of four columns of one token
+    constexpr bool vswap = VSWAP;
     const int nk = a.K / 64;
     // prologue: the six units the steady-state schedule would have issued before phase 0
     issue(U_RQ0, 0); issue(U_CQ0, 0); issue(U_CQ1, 0); issue(U_RQ1, 0);
@@ -522,13 +526,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
-            _Pragma("unroll") for (int ct = 0; ct < 2; ct++)                                                        \
-                _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                  \
-                    if (ABL == 1) { asm volatile("" ::"v"(CF[ct][ks]), "v"(rf[rt][ks])); acc[CT0 + ct][RT0 + rt][0] += 1.0f; } \
-                    else acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CF[ct][ks], rf[rt][ks], \
+        if constexpr (vswap) {                                                                                      \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                        \
+                _Pragma("unroll") for (int ct = 0; ct < 2; ct++)                                                    \
+                    _Pragma("unroll") for (int rt = 0; rt < 4; rt++)                                                \
+                        acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[rt][ks], CF[ct][ks],  \
                                                                                       acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
-                }                                                                                                   \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                        \
+                _Pragma("unroll") for (int ct = 0; ct < 2; ct++)                                                    \
+                    _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                              \
+                        if (ABL == 1) { asm volatile("" ::"v"(CF[ct][ks]), "v"(rf[rt][ks])); acc[CT0 + ct][RT0 + rt][0] += 1.0f; } \
+                        else acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CF[ct][ks], rf[rt][ks], \
+                                                                                      acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
+                    }                                                                                               \
+        }                                                                                                           \
         __builtin_amdgcn_s_setprio(0);                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_barrier();                                                                               \
@@ -596,11 +608,114 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
             if (m >= (size_t)a.m_valid) v = u32x4{0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4*>(a.out_bf16 + m * a.ldo + a.n_off + wn0 + chunk * 8) = v;
         }
-    } else {
+    } else if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
+        // fp32 residual stream: staged through LDS (two halves of 64 rows, 256 B + 16 B pad per row) so that every global
+        // load / store instruction covers whole 256-byte row segments instead of 16 rows x 64 B
+        constexpr int FROW = 272;
+        char* et = smem + wave * (128 * P8_EROW);
 #pragma unroll
-        for (int rt = 0; rt < 8; rt++)
+        for (int half = 0; half < 2; half++) {
 #pragma unroll
-            for (int ct = 0; ct < 4; ct++) store_quad<EPI>(a, wm0 + rt * 16 + i, wn0 + ct * 16 + 4 * g, acc[ct][rt]);
+            for (int rq = 0; rq < 4; rq++)
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) {
+                    const int nl = ct * 16 + 4 * g;
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + wn0 + nl);
+                    const float4v& c = acc[ct][half * 4 + rq];
+                    *reinterpret_cast<float4*>(et + (rq * 16 + i) * FROW + nl * 4) = float4{c[0] + bv.x, c[1] + bv.y, c[2] + bv.z, c[3] + bv.w};
+                }
+            const int rsub = lane >> 4, chunk = lane & 15;
+            float4 v[16];
+#pragma unroll
+            for (int it = 0; it < 16; it++) v[it] = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * FROW + chunk * 16);
+            if constexpr (EPI == EPI_RESID) {
+                float4 x[16];
+#pragma unroll
+                for (int it = 0; it < 16; it++) {
+                    const size_t m = wm0 + half * 64 + it * 4 + rsub;
+                    x[it] = m < (size_t)a.m_valid ? *reinterpret_cast<const float4*>(a.resid + m * a.ldr + a.n_off + wn0 + chunk * 4)
+                                                  : float4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int it = 0; it < 16; it++) {
+                    const size_t m = wm0 + half * 64 + it * 4 + rsub;
+                    if (m < (size_t)a.m_valid)
+                        *reinterpret_cast<float4*>(a.resid + m * a.ldr + a.n_off + wn0 + chunk * 4) =
+                            float4{x[it].x + v[it].x, x[it].y + v[it].y, x[it].z + v[it].z, x[it].w + v[it].w};
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 16; it++) {
+                    const size_t m = wm0 + half * 64 + it * 4 + rsub;
+                    if (m < (size_t)a.m_valid) {
+                        const int tok = (int)(m % a.tokens);
+                        const float4 pv = *reinterpret_cast<const float4*>(a.pos + (size_t)tok * a.ldr + a.n_off + wn0 + chunk * 4);
+                        *reinterpret_cast<float4*>(a.resid + m * a.ldr + a.n_off + wn0 + chunk * 4) =
+                            float4{v[it].x + pv.x, v[it].y + pv.y, v[it].z + pv.z, v[it].w + pv.w};
+                    }
+                }
+            }
+        }
+    } else {  // EPI_QKV: scatter to the attention layouts, 16-byte pieces through LDS
+        char* et = smem + wave * (128 * P8_EROW);
+        const int D = a.heads * a.dh;
+        const int ncol = (int)a.n_off + wn0;              // first output column of this wave
+        const int which = ncol / D;                       // 0 q, 1 k, 2 v (uniform: D % 64 == 0)
+        const int rem0 = ncol - which * D, head0 = rem0 / a.dh, e0 = rem0 - head0 * a.dh;
+        const int bi0 = (int)(wm0 / a.tokens), tok0 = (int)(wm0 - (size_t)bi0 * a.tokens);
+        if constexpr (!vswap) {
+            // lane: token (rt*16 + i), columns ct*16 + 4g .. +3  ->  staging [token][64 columns] bf16
+#pragma unroll
+            for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) {
+                    const int nl = ct * 16 + 4 * g;
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + wn0 + nl);
+                    const float4v& c = acc[ct][rt];
+                    *reinterpret_cast<uint2*>(et + (rt * 16 + i) * P8_EROW + nl * 2) =
+                        uint2{pack2(c[0] + bv.x, c[1] + bv.y), pack2(c[2] + bv.z, c[3] + bv.w)};
+                }
+            const int rsub = lane >> 3, chunk = lane & 7;
+            int e = e0 + chunk * 8, head = head0;
+            if (e >= a.dh) { e -= a.dh; head++; }          // dh = 72 > 64: at most one wrap, and 8 | dh keeps a piece in one head
+            uint16_t* base = which == 0 ? a.q : a.k;
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int row = it * 8 + rsub;
+                int tok = tok0 + row, bi = bi0;
+                if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+                if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+                const u32x4 v = *reinterpret_cast<const u32x4*>(et + row * P8_EROW + chunk * 16);
+                if (wm0 + row < (size_t)a.m_valid)
+                    *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * a.dh_pad + e) = v;
+            }
+        } else {
+            // lane: column (ct*16 + i), tokens rt*16 + 4g .. +3  ->  staging [column][128 tokens] bf16 (256 B + 16 B pad)
+            constexpr int VROW = 272;
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                const float bv = a.bias[wn0 + ct * 16 + i];
+#pragma unroll
+                for (int rt = 0; rt < 8; rt++) {
+                    const float4v& c = acc[ct][rt];
+                    *reinterpret_cast<uint2*>(et + (ct * 16 + i) * VROW + (rt * 16 + 4 * g) * 2) =
+                        uint2{pack2(c[0] + bv, c[1] + bv), pack2(c[2] + bv, c[3] + bv)};
+                }
+            }
+            const int rsub = lane >> 4, chunk = lane & 15;  // 16 pieces of 8 tokens per column
+            int tok = tok0 + chunk * 8, bi = bi0;
+            if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+            if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+            const bool ok = wm0 + chunk * 8 < (size_t)a.m_valid;
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int col = it * 4 + rsub;
+                int e = e0 + col, head = head0;
+                if (e >= a.dh) { e -= a.dh; head++; }
+                const u32x4 v = *reinterpret_cast<const u32x4*>(et + col * VROW + chunk * 16);
+                if (ok) *reinterpret_cast<u32x4*>(a.vt + (((size_t)bi * a.heads + head) * a.dv_pad + e) * a.n_pad + tok) = v;
+            }
+        }
     }
 }
 
@@ -645,16 +760,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // patchify: NCHW image (fp16 / fp32) -> [B*tokens][K_pad] bf16 rows ordered (c, ky, kx) like the conv weight
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, int Wd, int P, int k_pad,
+__global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, int Wd, int P, int k_pad, int tstride,
                                 uint16_t* __restrict__ out) {
     const int gw = Wd / P, gh = H / P, tokens = gw * gh, kk = C * P * P;
-    const size_t total = (size_t)B * tokens * k_pad;
+    const size_t total = (size_t)B * tstride * k_pad;  // rows b * tstride + t; rows t >= tokens are zero padding
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(idx % k_pad);
         const size_t row = idx / k_pad;
         float v = 0.0f;
-        if (col < kk) {
-            const int b = (int)(row / tokens), t = (int)(row % tokens);
+        const int b = (int)(row / tstride), t = (int)(row % tstride);
+        if (col < kk && t < tokens) {
             const int py = t / gw, px = t % gw;
             const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
             v = (float)img[(((size_t)b * C + c) * H + py * P + ky) * Wd + px * P + kx];
@@ -680,7 +795,7 @@ constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * ATT_VROW;
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                         int dh, int dh_pad, int dv_pad, float scale_log2e,
-                                                        uint16_t* __restrict__ out, int ldo) {
+                                                        uint16_t* __restrict__ out, int ldo, int tstride) {
     __shared__ __attribute__((aligned(16))) char lds[2 * (ATT_KTILE + ATT_VTILE)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -813,7 +928,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
         const int tok = q0 + qt * 16 + i;
         if (tok < tokens) {
             const float inv = 1.0f / l_run[qt];
-            uint16_t* op = out + ((size_t)b * tokens + tok) * ldo + hd * dh;
+            uint16_t* op = out + ((size_t)b * tstride + tok) * ldo + hd * dh;
 #pragma unroll
             for (int t = 0; t < 5; t++) {
                 const int e = t * 16 + 4 * g;
@@ -831,7 +946,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_attention_kernel(const uint16_t* __restrict__ kv, int ldkv,
                                                              const float* __restrict__ qlat, int heads, int dh,
-                                                             int tokens, float scale, float* __restrict__ out, int ldo) {
+                                                             int tokens, int tstride, float scale, float* __restrict__ out,
+                                                             int ldo) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sc = sm;             // [tokens]
     float* red = sm + tokens;   // [256]
@@ -841,7 +957,7 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const uint16_t* __r
     const float* qh = qlat + hd * dh;
     float lmax = -1e30f;
     for (int t = tid; t < tokens; t += blockDim.x) {
-        const uint16_t* kr = kv + ((size_t)b * tokens + t) * ldkv + hd * dh;
+        const uint16_t* kr = kv + ((size_t)b * tstride + t) * ldkv + hd * dh;
         float s = 0.0f;
         for (int e = 0; e < dh; e++) s = fmaf(qh[e], bf2f(kr[e]), s);
         s *= scale;
@@ -872,7 +988,7 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const uint16_t* __r
     // out[e] = sum_t p[t] * v[t][e]: thread e handles one output feature
     for (int e = tid; e < dh; e += blockDim.x) {
         float acc = 0.0f;
-        for (int t = 0; t < tokens; t++) acc = fmaf(sc[t], bf2f(kv[((size_t)b * tokens + t) * ldkv + D + hd * dh + e]), acc);
+        for (int t = 0; t < tokens; t++) acc = fmaf(sc[t], bf2f(kv[((size_t)b * tstride + t) * ldkv + D + hd * dh + e]), acc);
         out[(size_t)b * ldo + hd * dh + e] = acc * inv;
     }
 }
@@ -961,8 +1077,31 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         GemmArgs a = a_in;
         a.N = n256;
         const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
-        if (old256 || a.K < 128) hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
-        else hipLaunchKernelGGL(gemm8p_kernel<EPI>, dim3(grid), dim3(512), LDS8P_BYTES, st, a);
+        // the ping-pong kernel's QKV scatter works on 8-token / 8-column pieces and WG-uniform q/k/v tiles
+        const bool qkv_ok = EPI != EPI_QKV || (a.tokens % 8 == 0 && a.tokens >= 64 && a.n_pad % 8 == 0 && a.dh % 8 == 0 && a.dh >= 64 &&
+                                               (a.heads * a.dh) % 64 == 0 && (2 * a.heads * a.dh) % 256 == 0 && a.m_valid % 8 == 0);
+        if (old256 || a.K < 128 || !qkv_ok) {
+            hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
+        } else if constexpr (EPI == EPI_QKV) {
+            // q and k columns [0, 2D) with the usual operand order, v columns [2D, n256) with swapped operands
+            const int nqk = 2 * a.heads * a.dh;
+            GemmArgs aq = a;
+            aq.N = std::min(nqk, n256);
+            hipLaunchKernelGGL((gemm8p_kernel<EPI, 0, false>), dim3((unsigned)((aq.M / B2) * (aq.N / B2))), dim3(512), LDS8P_BYTES, st, aq);
+            if (n256 > nqk) {
+                GemmArgs av = a;
+                av.N = n256 - nqk; av.n_off = nqk; av.w = a.w + (size_t)nqk * a.K; av.bias = a.bias + nqk;
+                static bool vattr[64] = {};
+                if (dev < 64 && !vattr[dev]) {
+                    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, 0, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
+                    vattr[dev] = true;
+                }
+                hipLaunchKernelGGL((gemm8p_kernel<EPI, 0, true>), dim3((unsigned)((av.M / B2) * (av.N / B2))), dim3(512), LDS8P_BYTES, st, av);
+            }
+        } else {
+            hipLaunchKernelGGL(gemm8p_kernel<EPI>, dim3(grid), dim3(512), LDS8P_BYTES, st, a);
+        }
         MSE_HIP_TRY(hipGetLastError());
     }
     if (n256 < a_in.N) {  // remaining 128 columns (N = 1152, 3456) on the 256 x 128 tile
@@ -1046,35 +1185,36 @@ int launch_layernorm(const float* x, int ldx, const float* gamma, const float* b
     return 0;
 }
 
-int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, uint16_t* out, hipStream_t st) {
-    const size_t total = (size_t)B * (H / P) * (W / P) * k_pad;
+int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
+                    hipStream_t st) {
+    const size_t total = (size_t)B * tstride * k_pad;
     unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
     if (is_f16)
         hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const _Float16*>(img), B,
-                           C, H, W, P, k_pad, out);
+                           C, H, W, P, k_pad, tstride, out);
     else
         hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(img), B, C, H,
-                           W, P, k_pad, out);
+                           W, P, k_pad, tstride, out);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
-                     int dh_pad, int dv_pad, uint16_t* out, int ldo, hipStream_t st) {
+                     int dh_pad, int dv_pad, uint16_t* out, int ldo, int tstride, hipStream_t st) {
     if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
     const int qblocks = (tokens + 127) / 128;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
-                       dh, dh_pad, dv_pad, scale_log2e, out, ldo);
+                       dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, float* out,
-                          int ldo, hipStream_t st) {
+int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, int tstride,
+                          float* out, int ldo, hipStream_t st) {
     const size_t lds = (size_t)(tokens + 256) * 4;
     hipLaunchKernelGGL(pool_attention_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, st, kv, ldkv, qlat, heads, dh, tokens,
-                       1.0f / sqrtf((float)dh), out, ldo);
+                       tstride, 1.0f / sqrtf((float)dh), out, ldo);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -188,7 +188,7 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
             g.dv_pad = m->dv_pad;
             if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
         }
-        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, st)) return -1;
+        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, T, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M; g.resid = m->x; g.ldr = D;
             if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
