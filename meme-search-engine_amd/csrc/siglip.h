@@ -28,8 +28,9 @@ int gemm_bn();
 int gemm_bk();
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
-int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int width, size_t rows,
-                     uint16_t* out, int ldo, float* out_f32, hipStream_t st);
+// delta (optional, bf16 [rows][ldd]): x += delta is applied and written back before normalising
+int launch_layernorm(float* x, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps, int width,
+                     size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st);
 // token rows of image b are rows b * tstride + t (t < tokens; the rest of the stride is padding)
 int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
                     hipStream_t st);

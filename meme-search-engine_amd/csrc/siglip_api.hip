@@ -55,7 +55,7 @@ struct mse_siglip {
     float* qlat = nullptr;
     // activations
     void* img_dev = nullptr;
-    uint16_t *patches = nullptr, *h = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *kvb = nullptr;
+    uint16_t *patches = nullptr, *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *kvb = nullptr;
     float *x = nullptr, *pool_a = nullptr, *pool_o = nullptr, *pool_ln = nullptr, *pool_h = nullptr, *pool_f = nullptr;
     float* out_f32 = nullptr; uint16_t* out_f16 = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
@@ -134,16 +134,17 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->patches = m->dalloc<uint16_t>(M * m->kpe_pad, true);
     m->x = m->dalloc<float>(M * D, true);
     m->h = m->dalloc<uint16_t>(M * D, true);
+    m->dlt = m->dalloc<uint16_t>(M * D, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
-    m->qb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
-    m->kb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
-    m->vtb = m->dalloc<uint16_t>(BH * m->dv_pad * m->n_pad, true);
+    m->qb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * m->dh_pad, true);   // one image of slack (rows of the M padding)
+    m->kb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * m->dh_pad, true);
+    m->vtb = m->dalloc<uint16_t>((BH + m->H) * m->dv_pad * m->n_pad, true);
     m->kvb = m->dalloc<uint16_t>(M * 2 * D, true);
     m->qlat = m->dalloc<float>(D, true);
     m->pool_a = m->dalloc<float>(B * D); m->pool_o = m->dalloc<float>(B * D); m->pool_ln = m->dalloc<float>(B * D);
     m->pool_h = m->dalloc<float>(B * m->mlp); m->pool_f = m->dalloc<float>(B * D);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
-    bool ok = m->img_dev && m->patches && m->x && m->h && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat &&
+    bool ok = m->img_dev && m->patches && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat &&
               m->pool_a && m->pool_o && m->pool_ln && m->pool_h && m->pool_f && m->out_f32 && m->out_f16;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_destroy(m); fail("siglip: device allocation failed"); return nullptr; }
@@ -238,7 +239,8 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
     }
     for (int i = 0; i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
         const Block& b = m->blocks[i];
-        if (launch_layernorm(m->x, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        // x += (fc2 output of the previous block), then LayerNorm
+        if (launch_layernorm(m->x, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
@@ -248,10 +250,10 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M;
-            g.resid = m->x; g.ldr = D;
-            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
-        if (launch_layernorm(m->x, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        if (launch_layernorm(m->x, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
         {
             GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
             g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
@@ -259,11 +261,11 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         }
         {
             GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M;
-            g.resid = m->x; g.ldr = D;
-            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
     }
-    if (launch_layernorm(m->x, D, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
+    if (launch_layernorm(m->x, D, c.depth ? m->dlt : nullptr, D, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
     // MAPHead (model.py:82-111)
     {
         GemmLaunch g; g.x = m->h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
@@ -272,7 +274,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
     }
     if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, m->pool_a, D, st)) return -1;
     if (launch_small_linear(m->pool_a, D, m->wpp, D, m->bpp, D, D, batch, 0, nullptr, 0, m->pool_o, D, st)) return -1;
-    if (launch_layernorm(m->pool_o, D, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
+    if (launch_layernorm(m->pool_o, D, nullptr, 0, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
     if (launch_small_linear(m->pool_ln, D, m->wp1, D, m->bp1, D, m->mlp, batch, gelu_tanh ? 2 : 1, nullptr, 0, m->pool_h, m->mlp,
                             st)) return -1;
     if (launch_small_linear(m->pool_h, m->mlp, m->wp2, m->mlp, m->bp2, m->mlp, D, batch, 0, m->pool_o, D, m->pool_f, D, st))

@@ -722,37 +722,59 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm over rows of `width` fp32 -> bf16 (one wave per row)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, int width, size_t rows,
-                                                        uint16_t* __restrict__ out, int ldo, float* __restrict__ out_f32) {
+// `delta` (optional, bf16 [rows][ldd]): the residual branch output of the preceding GEMM; x += delta is applied here
+// (and written back), so that GEMM's epilogue is a plain bf16 store instead of an fp32 read-modify-write.
+// The row is held in registers (width <= 2048): one read of x, one optional write.
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int ldx, const uint16_t* __restrict__ delta, int ldd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        int width, size_t rows, uint16_t* __restrict__ out, int ldo,
+                                                        float* __restrict__ out_f32) {
     const int lane = threadIdx.x & 63;
     const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
-    const float* xr = x + row * ldx;
+    float* xr = x + row * ldx;
+    float4 v[8];
     float s = 0.0f, ss = 0.0f;
-    for (int c = lane * 4; c < width; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        s += v.x + v.y + v.z + v.w;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = lane * 4 + j * 256;
+        v[j] = float4{0.f, 0.f, 0.f, 0.f};
+        if (c < width) {
+            v[j] = *reinterpret_cast<const float4*>(xr + c);
+            if (delta) {
+                const uint2 d = *reinterpret_cast<const uint2*>(delta + row * ldd + c);
+                v[j].x += __uint_as_float(d.x << 16); v[j].y += __uint_as_float(d.x & 0xffff0000u);
+                v[j].z += __uint_as_float(d.y << 16); v[j].w += __uint_as_float(d.y & 0xffff0000u);
+                *reinterpret_cast<float4*>(xr + c) = v[j];
+            }
+            s += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)width;
-    for (int c = lane * 4; c < width; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = lane * 4 + j * 256;
+        if (c < width) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
     const float rstd = rsqrtf(ss / (float)width + eps);
-    for (int c = lane * 4; c < width; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-        const float y0 = (v.x - mean) * rstd * gm.x + bt.x, y1 = (v.y - mean) * rstd * gm.y + bt.y;
-        const float y2 = (v.z - mean) * rstd * gm.z + bt.z, y3 = (v.w - mean) * rstd * gm.w + bt.w;
-        if (out) *reinterpret_cast<uint2*>(out + row * ldo + c) = uint2{pack2(y0, y1), pack2(y2, y3)};
-        if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * ldo + c) = float4{y0, y1, y2, y3};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = lane * 4 + j * 256;
+        if (c < width) {
+            const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+            const float y0 = (v[j].x - mean) * rstd * gm.x + bt.x, y1 = (v[j].y - mean) * rstd * gm.y + bt.y;
+            const float y2 = (v[j].z - mean) * rstd * gm.z + bt.z, y3 = (v[j].w - mean) * rstd * gm.w + bt.w;
+            if (out) *reinterpret_cast<uint2*>(out + row * ldo + c) = uint2{pack2(y0, y1), pack2(y2, y3)};
+            if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * ldo + c) = float4{y0, y1, y2, y3};
+        }
     }
 }
 
@@ -1175,12 +1197,12 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     return fail("gemm: unknown epilogue");
 }
 
-int launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, int width, size_t rows,
-                     uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
+int launch_layernorm(float* x, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps, int width,
+                     size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
     if (rows == 0) return 0;
-    if (width % 4) return fail("layernorm: width must be a multiple of 4");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, gamma, beta, eps, width,
-                       rows, out, ldo, out_f32);
+    if (width % 4 || width > 2048) return fail("layernorm: width must be a multiple of 4, at most 2048");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, eps,
+                       width, rows, out, ldo, out_f32);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -49,7 +49,7 @@ struct mse_siglip_text {
     std::vector<TBlock> blocks;
     int64_t* tokens_dev = nullptr;
     float *x = nullptr, *pooled = nullptr, *feat = nullptr, *out_f32 = nullptr;
-    uint16_t *h = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *out_f16 = nullptr;
+    uint16_t *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *out_f16 = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
 
     template <typename T> T* dalloc(size_t n, bool zero = false) {
@@ -106,13 +106,14 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->tokens_dev = m->dalloc<int64_t>(B * m->ctx);
     m->x = m->dalloc<float>(M * D, true);
     m->h = m->dalloc<uint16_t>(M * D, true);
+    m->dlt = m->dalloc<uint16_t>(M * D, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
     m->qb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
     m->kb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
     m->vtb = m->dalloc<uint16_t>(BH * m->dv_pad * m->n_pad, true);
     m->pooled = m->dalloc<float>(B * D); m->feat = m->dalloc<float>(B * D);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
-    bool ok = m->tokens_dev && m->x && m->h && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
+    bool ok = m->tokens_dev && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_text_destroy(m); fail("siglip text: device allocation failed"); return nullptr; }
     return m;
@@ -181,7 +182,8 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     if (launch_embed_tokens(m->tokens_dev, m->tok_emb, m->pos, c.vocab_size, T, D, M, m->x, st)) return -1;
     for (int i = 0; i < c.layers; i++) {
         const TBlock& b = m->blocks[i];
-        if (launch_layernorm(m->x, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        // x += (fc2 output of the previous block), then LayerNorm
+        if (launch_layernorm(m->x, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
@@ -190,22 +192,25 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
         }
         if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, T, st)) return -1;
         {
-            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M; g.resid = m->x; g.ldr = D;
-            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M;
+            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
-        if (launch_layernorm(m->x, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        if (launch_layernorm(m->x, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
         {
             GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
             g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
             if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
         }
         {
-            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M; g.resid = m->x; g.ldr = D;
-            if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M;
+            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
     }
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
-    if (launch_layernorm(m->x + (size_t)(T - 1) * D, T * D, m->lnf_g, m->lnf_b, c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
+    if (launch_layernorm(m->x + (size_t)(T - 1) * D, T * D, c.layers ? m->dlt + (size_t)(T - 1) * D : nullptr, T * D, m->lnf_g, m->lnf_b,
+                         c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
     if (launch_small_linear(m->pooled, D, m->wproj, D, m->bproj, D, D, batch, 0, nullptr, 0, m->feat, D, st)) return -1;
     if (launch_l2norm(m->feat, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
     if (out_f32) MSE_HIP_TRY(hipMemcpyAsync(out_f32, m->out_f32, (size_t)batch * D * 4, hipMemcpyDeviceToHost, st));
