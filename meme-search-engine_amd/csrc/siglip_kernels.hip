@@ -17,6 +17,8 @@
 #include "siglip.h"
 #include <cstdlib>
 
+namespace mse { int device_cu_count(); }  // runtime.h
+
 namespace mse {
 namespace siglip {
 namespace {
@@ -43,6 +45,12 @@ template <int N> __device__ __forceinline__ void vm_wait() {
 __device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane offset: keeps tile bases out of the
+// vector registers.  M0 = LDS byte address of the wave's 1 KiB destination; one wait state after the M0 write.
+__device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below bf16 resolution by four orders of magnitude): one
@@ -720,6 +728,265 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Persistent form of the ping-pong GEMM: one workgroup per CU walks output tiles v, v + grid, ... and the
+// LDS-DMA schedule runs straight across tile seams (the units of the next tile's first two K tiles are issued
+// during the last two K tiles of the current one), so no tile pays a prologue, and the epilogue's global
+// stores (bf16 only: every epilogue here is store-only) drain behind the next tile's main loop.
+// LDS: 128 KiB operand ring + 4 KiB of private epilogue staging per wave (XOR-swizzled, no padding) = 160 KiB.
+// vmcnt bookkeeping: loads and stores retire in order on one counter, every wave issues exactly PP_STORES
+// stores per tile (unconditional: padding rows exist in every destination), so the counted waits of the first
+// K tile after an epilogue allow PP_STORES more operations in flight.  Waits: the unit read in phase p+1 must
+// be complete at phase p's wait; with the issue order above that leaves four younger units (8 DMAs) in flight.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PP_STAGE = 4096;
+constexpr int PP_STORES = 16;
+constexpr int LDSPP_BYTES = 2 * P8_BUF + 8 * PP_STAGE;   // 160 KiB
+
+template <int EPI, bool VSWAP>
+__global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int n_blocks = a.N / 256, m_blocks = a.M / 256;
+    const int ntiles = n_blocks * m_blocks;
+    const int G = (int)gridDim.x;
+    const uint32_t kbytes = (uint32_t)a.K * 2;
+    const int nk = a.K / 64;
+
+    auto tile_of = [&](int v, size_t& m0, size_t& n0) {   // XCD-aware order: the 32 workgroups of an XCD take neighbouring tiles
+        const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = v % 8, idx = v / 8;
+        const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        m0 = (size_t)(b / n_blocks) * 256;
+        n0 = (size_t)(b % n_blocks) * 256;
+    };
+    // DMA source offsets of this lane inside a tile (row offset + swizzled 16-byte piece); the tile bases are wave-uniform
+    uint32_t roff[2], coff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int u = wave * 16 + j * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((u >> 1) & 7);
+        roff[j] = (uint32_t)((u >> 6) * 128 + (u & 63)) * kbytes + piece * 16;
+        coff[j] = (uint32_t)((u >> 5) * 64 + (u & 31)) * kbytes + piece * 16;
+    }
+    const uint32_t rq1 = 64 * kbytes, cq1 = 32 * kbytes;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int unit, int kt, int ring, const char* xb, const char* wb) {
+        const uint32_t dst = lds0 + (ring & 1) * P8_BUF + unit * P8_UNIT + wave * 2048;
+        const bool is_r = unit == U_RQ0 || unit == U_RQ1;
+        const uint32_t qoff = (unit == U_RQ1 ? rq1 : (unit == U_CQ1 ? cq1 : 0u)) + (uint32_t)kt * 128u;
+        const char* sb = (is_r ? xb : wb) + qoff;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 2; j++) dma16_s(sb, is_r ? roff[j] : coff[j], dst + j * 1024);
+    };
+    const int foff0 = i * 128 + ((g ^ (i >> 1)) & 7) * 16;
+    const int foff1 = i * 128 + (((4 + g) ^ (i >> 1)) & 7) * 16;
+    const int r_off = wr * 64 * 128, c_off = wc * 32 * 128;
+    char* const et = smem + 2 * P8_BUF + wave * PP_STAGE;
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;
+    size_t m0, n0, m0n = 0, n0n = 0;
+    tile_of(v, m0, n0);
+    bool has_next = v + G < ntiles;
+    if (has_next) tile_of(v + G, m0n, n0n);
+    const char* xb = reinterpret_cast<const char*>(a.x) + m0 * kbytes;
+    const char* wb = reinterpret_cast<const char*>(a.w) + n0 * kbytes;
+    const char* xbn = reinterpret_cast<const char*>(a.x) + m0n * kbytes;
+    const char* wbn = reinterpret_cast<const char*>(a.w) + n0n * kbytes;
+
+    // prologue of the first tile only
+    issue(U_RQ0, 0, 0, xb, wb); issue(U_CQ0, 0, 0, xb, wb); issue(U_CQ1, 0, 0, xb, wb); issue(U_RQ1, 0, 0, xb, wb);
+    issue(U_RQ0, 1, 1, xb, wb); issue(U_CQ0, 1, 1, xb, wb);
+    vm_wait<8>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    float4v acc[4][8];
+    bf16x8 rf[4][2], cf0[2][2], cf1[2][2];
+    auto read_r = [&](const char* unit_base) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            rf[t][0] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + r_off + t * 2048 + foff0));
+            rf[t][1] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + r_off + t * 2048 + foff1));
+        }
+    };
+    auto read_c = [&](const char* unit_base, bf16x8 (&cf)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            cf[t][0] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + c_off + t * 2048 + foff0));
+            cf[t][1] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + c_off + t * 2048 + foff1));
+        }
+    };
+#define PP_MFMA(CF, CT0, RT0)                                                                                       \
+    do {                                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ct++)                                                        \
+                _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                  \
+                    if constexpr (VSWAP)                                                                            \
+                        acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[rt][ks], CF[ct][ks],  \
+                                                                                      acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
+                    else                                                                                            \
+                        acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CF[ct][ks], rf[rt][ks],  \
+                                                                                      acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
+                }                                                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                               \
+    } while (0)
+    // stage the unit of K tile t + AHEAD (this tile's, or the next tile's once past the seam), then the counted wait
+#define PP_STAGE_UNIT(UNIT, AHEAD, DO_WAIT)                                                                         \
+    do {                                                                                                            \
+        const int kk = t + AHEAD;                                                                                   \
+        bool issued = true;                                                                                         \
+        if (kk < nk) issue(UNIT, kk, ring + AHEAD, xb, wb);                                                         \
+        else if (has_next) issue(UNIT, kk - nk, ring + AHEAD, xbn, wbn);                                            \
+        else issued = false;                                                                                        \
+        if (DO_WAIT) {                                                                                              \
+            if (!issued) vm_wait<0>();                                                                              \
+            else if (after_epilogue) vm_wait<8 + PP_STORES>();                                                      \
+            else vm_wait<8>();                                                                                      \
+        }                                                                                                           \
+    } while (0)
+
+    int ring = 0;   // running K tile count: LDS buffer = ring & 1
+    for (int iter = 0;; iter++) {
+        // accumulators start at the bias: the loads sit at the tile start, where the wave is about to wait for the
+        // K tile 0 units anyway, and the epilogue needs no global load at all
+        {
+            const int wn0b = (int)n0 + wc * 64;
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                float4v b4;
+                if constexpr (VSWAP) {
+                    const float bs = a.bias[wn0b + ct * 16 + i];
+                    b4 = float4v{bs, bs, bs, bs};
+                } else {
+                    const float4 bq = *reinterpret_cast<const float4*>(a.bias + wn0b + ct * 16 + 4 * g);
+                    b4 = float4v{bq.x, bq.y, bq.z, bq.w};
+                }
+#pragma unroll
+                for (int rt = 0; rt < 8; rt++) acc[ct][rt] = b4;
+            }
+        }
+        for (int t = 0; t < nk; t++, ring++) {
+            const bool after_epilogue = iter > 0 && t == 0;
+            const char* buf = smem + (ring & 1) * P8_BUF;
+            // phase 0
+            read_c(buf + U_CQ0 * P8_UNIT, cf0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_r(buf + U_RQ0 * P8_UNIT);
+            PP_STAGE_UNIT(U_CQ1, 1, true);
+            PP_MFMA(cf0, 0, 0);
+            // phase 1
+            read_c(buf + U_CQ1 * P8_UNIT, cf1);
+            PP_STAGE_UNIT(U_RQ1, 1, true);
+            PP_MFMA(cf1, 2, 0);
+            // phase 2
+            read_r(buf + U_RQ1 * P8_UNIT);
+            PP_STAGE_UNIT(U_RQ0, 2, false);
+            PP_MFMA(cf1, 2, 4);
+            // phase 3
+            PP_STAGE_UNIT(U_CQ0, 2, true);
+            PP_MFMA(cf0, 0, 4);
+        }
+
+        // ---- epilogue: exactly PP_STORES global stores per wave, all unconditional --------------------------------
+        const size_t wm0 = m0 + (size_t)wr * 128;
+        const int wn0 = (int)n0 + wc * 64;
+        if constexpr (!VSWAP) {
+            // staging rounds of 32 rows x 64 columns bf16 (128-byte rows, 16-byte pieces XOR-swizzled by row & 7)
+            const GeluC gc = gelu_coef(a.gelu_tanh);
+            const int rsub = lane >> 3, chunk = lane & 7;
+            // QKV scatter geometry (8-column pieces stay inside one head: 8 | dh)
+            int which = 0, head = 0, e = 0, bi0 = 0, tok0 = 0;
+            if constexpr (EPI == EPI_QKV) {
+                const int D = a.heads * a.dh, ncol = a.n_off + wn0;
+                which = ncol / D;
+                const int rem0 = ncol - which * D;
+                head = rem0 / a.dh;
+                e = rem0 - head * a.dh + chunk * 8;
+                if (e >= a.dh) { e -= a.dh; head++; }
+                bi0 = (int)(wm0 / a.tokens);
+                tok0 = (int)(wm0 - (size_t)bi0 * a.tokens);
+            }
+#pragma unroll
+            for (int rd = 0; rd < 4; rd++) {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct++) {
+                        const float4v& c = acc[ct][rd * 2 + rr];
+                        float2v lo = {c[0], c[1]}, hi = {c[2], c[3]};
+                        if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc); hi = gelu2(hi, gc); }
+                        const int row = rr * 16 + i, pc = (ct * 2 + (g >> 1)) ^ (row & 7);
+                        *reinterpret_cast<uint2*>(et + row * 128 + pc * 16 + (g & 1) * 8) = uint2{pack2(lo), pack2(hi)};
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int row = it * 8 + rsub;
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(et + row * 128 + ((chunk ^ (row & 7)) * 16));
+                    const int mrow = rd * 32 + row;
+                    if constexpr (EPI == EPI_QKV) {
+                        int tok = tok0 + mrow, bi = bi0;
+                        if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+                        if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+                        uint16_t* base = which == 0 ? a.q : a.k;
+                        *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * a.dh_pad + e) = val;
+                    } else {
+                        *reinterpret_cast<u32x4*>(a.out_bf16 + (wm0 + mrow) * a.ldo + a.n_off + wn0 + chunk * 8) = val;
+                    }
+                }
+            }
+        } else {
+            // V columns: lane holds column (ct*16 + i), tokens rt*16 + 4g .. +3; rounds of 16 columns x 128 tokens
+            const int D = a.heads * a.dh, ncol = a.n_off + wn0;
+            const int rem0 = ncol - 2 * D, head0 = rem0 / a.dh, e0 = rem0 - head0 * a.dh;
+            const int bi0 = (int)(wm0 / a.tokens), tok0 = (int)(wm0 - (size_t)bi0 * a.tokens);
+            const int rsub = lane >> 4, chunk = lane & 15;
+            int tok = tok0 + chunk * 8, bi = bi0;
+            if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+            if (tok >= a.tokens) { tok -= a.tokens; bi++; }
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+#pragma unroll
+                for (int rt = 0; rt < 8; rt++) {
+                    const float4v& c = acc[ct][rt];
+                    const int pc = (rt * 2 + (g >> 1)) ^ i;
+                    *reinterpret_cast<uint2*>(et + i * 256 + pc * 16 + (g & 1) * 8) = uint2{pack2(c[0], c[1]), pack2(c[2], c[3])};
+                }
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int cl = it * 4 + rsub;   // column inside this round
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(et + cl * 256 + ((chunk ^ cl) * 16));
+                    int e = e0 + ct * 16 + cl, head = head0;
+                    if (e >= a.dh) { e -= a.dh; head++; }
+                    *reinterpret_cast<u32x4*>(a.vt + (((size_t)bi * a.heads + head) * a.dv_pad + e) * a.n_pad + tok) = val;
+                }
+            }
+        }
+
+        if (!has_next) break;
+        v += G;
+        m0 = m0n; n0 = n0n; xb = xbn; wb = wbn;
+        has_next = v + G < ntiles;
+        if (has_next) {
+            tile_of(v + G, m0n, n0n);
+            xbn = reinterpret_cast<const char*>(a.x) + m0n * kbytes;
+            wbn = reinterpret_cast<const char*>(a.w) + n0n * kbytes;
+        }
+    }
+#undef PP_MFMA
+#undef PP_STAGE_UNIT
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LayerNorm over rows of `width` fp32 -> bf16 (one wave per row)
 // ---------------------------------------------------------------------------------------------------------
 // `delta` (optional, bf16 [rows][ldd]): the residual branch output of the preceding GEMM; x += delta is applied here
@@ -1102,24 +1369,36 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         // the ping-pong kernel's QKV scatter works on 8-token / 8-column pieces and WG-uniform q/k/v tiles
         const bool qkv_ok = EPI != EPI_QKV || (a.tokens % 8 == 0 && a.tokens >= 64 && a.n_pad % 8 == 0 && a.dh % 8 == 0 && a.dh >= 64 &&
                                                (a.heads * a.dh) % 64 == 0 && (2 * a.heads * a.dh) % 256 == 0 && a.m_valid % 8 == 0);
+        static const bool nopersist = getenv("MSE_GEMM_NOPERSIST") != nullptr;
+        constexpr bool store_only = EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV;
+        const unsigned cus = (unsigned)mse::device_cu_count();
         if (old256 || a.K < 128 || !qkv_ok) {
             hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
-        } else if constexpr (EPI == EPI_QKV) {
-            // q and k columns [0, 2D) with the usual operand order, v columns [2D, n256) with swapped operands
-            const int nqk = 2 * a.heads * a.dh;
+        } else if constexpr (store_only) {
+            // persistent ping-pong kernel; for QKV the q/k columns [0, 2D) and the (transposed) v columns are two launches
+            static bool pattr[64] = {};
+            if (dev < 64 && !pattr[dev]) {
+                MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
+                MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
+                MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, 0, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
+                pattr[dev] = true;
+            }
+            const bool persist = !nopersist && a.K >= 256;
+            const int nqk = EPI == EPI_QKV ? std::min(2 * a.heads * a.dh, n256) : n256;
             GemmArgs aq = a;
-            aq.N = std::min(nqk, n256);
-            hipLaunchKernelGGL((gemm8p_kernel<EPI, 0, false>), dim3((unsigned)((aq.M / B2) * (aq.N / B2))), dim3(512), LDS8P_BYTES, st, aq);
+            aq.N = nqk;
+            const unsigned tq = (unsigned)((aq.M / B2) * (aq.N / B2));
+            if (persist) hipLaunchKernelGGL((gemm8pp_kernel<EPI, false>), dim3(std::min(tq, cus)), dim3(512), LDSPP_BYTES, st, aq);
+            else hipLaunchKernelGGL((gemm8p_kernel<EPI, 0, false>), dim3(tq), dim3(512), LDS8P_BYTES, st, aq);
             if (n256 > nqk) {
                 GemmArgs av = a;
                 av.N = n256 - nqk; av.n_off = nqk; av.w = a.w + (size_t)nqk * a.K; av.bias = a.bias + nqk;
-                static bool vattr[64] = {};
-                if (dev < 64 && !vattr[dev]) {
-                    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, 0, true>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
-                    vattr[dev] = true;
-                }
-                hipLaunchKernelGGL((gemm8p_kernel<EPI, 0, true>), dim3((unsigned)((av.M / B2) * (av.N / B2))), dim3(512), LDS8P_BYTES, st, av);
+                const unsigned tv = (unsigned)((av.M / B2) * (av.N / B2));
+                if (persist) hipLaunchKernelGGL((gemm8pp_kernel<EPI, true>), dim3(std::min(tv, cus)), dim3(512), LDSPP_BYTES, st, av);
+                else hipLaunchKernelGGL((gemm8p_kernel<EPI, 0, true>), dim3(tv), dim3(512), LDS8P_BYTES, st, av);
             }
         } else {
             hipLaunchKernelGGL(gemm8p_kernel<EPI>, dim3(grid), dim3(512), LDS8P_BYTES, st, a);
@@ -1164,6 +1443,12 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
         break;
         MSE_ABL8(0) MSE_ABL8(1) MSE_ABL8(2) MSE_ABL8(3) MSE_ABL8(4)
 #undef MSE_ABL8
+        case 30:  // persistent ping-pong kernel
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI_GELU, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
+            hipLaunchKernelGGL((gemm8pp_kernel<EPI_GELU, false>), dim3(std::min(grid, (unsigned)mse::device_cu_count())), dim3(512),
+                               LDSPP_BYTES, st, a);
+            break;
         case 20:  // plain bf16 epilogue (no GELU)
             MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_BF16, 0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
