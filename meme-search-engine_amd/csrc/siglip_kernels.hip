@@ -118,6 +118,7 @@ struct GemmArgs {
     uint16_t *q, *k, *vt; // EPI_QKV scatter targets
     int heads, dh, dh_pad, n_pad, dv_pad;  // attention geometry
     int gelu_tanh;
+    int stagger;          // persistent kernel: 64-cycle sleep units per K tile and XCD index at start (0 = none)
 };
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4 };
@@ -742,7 +743,7 @@ constexpr int PP_STAGE = 4096;
 constexpr int PP_STORES = 16;
 constexpr int LDSPP_BYTES = 2 * P8_BUF + 8 * PP_STAGE;   // 160 KiB
 
-template <int EPI, bool VSWAP>
+template <int EPI, bool VSWAP, int ABL = 0>   // ABL (developer): 1 = no global stores, 2 = no epilogue at all
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -758,8 +759,12 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     auto tile_of = [&](int v, size_t& m0, size_t& n0) {   // XCD-aware order: the 32 workgroups of an XCD take neighbouring tiles
         const int q8 = ntiles / 8, r8 = ntiles % 8, xcd = v % 8, idx = v / 8;
         const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-        m0 = (size_t)(b / n_blocks) * 256;
-        n0 = (size_t)(b % n_blocks) * 256;
+        // b enumerates bands of 8 m-blocks, m fastest inside a band: the 32 tiles an XCD works on at one time are then
+        // 8 (m) x 4 (n) instead of 2 x 16 -- 12 operand panels through its L2 instead of 18
+        const int band = b / (8 * n_blocks), r = b - band * 8 * n_blocks;
+        const int rows = min(8, m_blocks - band * 8);
+        m0 = (size_t)(band * 8 + r % rows) * 256;
+        n0 = (size_t)(r / rows) * 256;
     };
     // DMA source offsets of this lane inside a tile (row offset + swizzled 16-byte piece); the tile bases are wave-uniform
     uint32_t roff[2], coff[2];
@@ -796,12 +801,17 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     const char* xbn = reinterpret_cast<const char*>(a.x) + m0n * kbytes;
     const char* wbn = reinterpret_cast<const char*>(a.w) + n0n * kbytes;
 
+    // De-synchronise the XCDs by an eighth of a tile each: otherwise all 256 CUs reach their epilogues together and
+    // the chip alternates between "every CU stores, no MFMA" and "every CU computes, HBM idle".
+    if (a.stagger) {
+        const int xcd = blockIdx.x & 7;
+        for (int r = 0; r < xcd * nk * a.stagger; r++) __builtin_amdgcn_s_sleep(1);
+    }
     // prologue of the first tile only
     issue(U_RQ0, 0, 0, xb, wb); issue(U_CQ0, 0, 0, xb, wb); issue(U_CQ1, 0, 0, xb, wb); issue(U_RQ1, 0, 0, xb, wb);
     issue(U_RQ0, 1, 1, xb, wb); issue(U_CQ0, 1, 1, xb, wb);
     vm_wait<8>();
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();
 
     float4v acc[4][8];
     bf16x8 rf[4][2], cf0[2][2], cf1[2][2];
@@ -874,8 +884,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                 for (int rt = 0; rt < 8; rt++) acc[ct][rt] = b4;
             }
         }
+        // the second m-half runs one barrier behind the first inside a tile; the halves are re-aligned before the
+        // epilogue so that both run it at the same time (two waves per SIMD hide each other's LDS round trips)
+        if (wr == 1) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; t++, ring++) {
-            const bool after_epilogue = iter > 0 && t == 0;
+            const bool after_epilogue = iter > 0 && (t == 0 || (ABL == 3 && t <= 2));   // ABL 3: timing experiment only (racy)
             const char* buf = smem + (ring & 1) * P8_BUF;
             // phase 0
             read_c(buf + U_CQ0 * P8_UNIT, cf0);
@@ -896,10 +909,18 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             PP_MFMA(cf0, 0, 4);
         }
 
+        if (wr == 0) __builtin_amdgcn_s_barrier();
         // ---- epilogue: exactly PP_STORES global stores per wave, all unconditional --------------------------------
         const size_t wm0 = m0 + (size_t)wr * 128;
         const int wn0 = (int)n0 + wc * 64;
-        if constexpr (!VSWAP) {
+        if constexpr (ABL == 2) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) sacc += acc[ct][rt][0] + acc[ct][rt][1] + acc[ct][rt][2] + acc[ct][rt][3];
+            if (sacc == 12345.678f) a.out_bf16[0] = 1;
+        } else if constexpr (!VSWAP) {
             // staging rounds of 32 rows x 64 columns bf16 (128-byte rows, 16-byte pieces XOR-swizzled by row & 7)
             const GeluC gc = gelu_coef(a.gelu_tanh);
             const int rsub = lane >> 3, chunk = lane & 7;
@@ -938,6 +959,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                         if (tok >= a.tokens) { tok -= a.tokens; bi++; }
                         uint16_t* base = which == 0 ? a.q : a.k;
                         *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * a.dh_pad + e) = val;
+                    } else if constexpr (ABL == 1) {
+                        if (val[0] == 0x12345678u) a.out_bf16[0] = 1;
                     } else {
                         *reinterpret_cast<u32x4*>(a.out_bf16 + (wm0 + mrow) * a.ldo + a.n_off + wn0 + chunk * 8) = val;
                     }
@@ -983,7 +1006,6 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     }
 #undef PP_MFMA
 #undef PP_STAGE_UNIT
-    if (wr == 0) __builtin_amdgcn_s_barrier();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1387,6 +1409,8 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
                 pattr[dev] = true;
             }
             const bool persist = !nopersist && a.K >= 256;
+            static const int stagger = getenv("MSE_GEMM_STAGGER") ? atoi(getenv("MSE_GEMM_STAGGER")) : 0;
+            a.stagger = stagger;
             const int nqk = EPI == EPI_QKV ? std::min(2 * a.heads * a.dh, n256) : n256;
             GemmArgs aq = a;
             aq.N = nqk;
@@ -1444,11 +1468,21 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
         MSE_ABL8(0) MSE_ABL8(1) MSE_ABL8(2) MSE_ABL8(3) MSE_ABL8(4)
 #undef MSE_ABL8
         case 30:  // persistent ping-pong kernel
+            a.stagger = getenv("MSE_GEMM_STAGGER") ? atoi(getenv("MSE_GEMM_STAGGER")) : 0;
             MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI_GELU, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
             hipLaunchKernelGGL((gemm8pp_kernel<EPI_GELU, false>), dim3(std::min(grid, (unsigned)mse::device_cu_count())), dim3(512),
                                LDSPP_BYTES, st, a);
             break;
+#define MSE_ABLP(CODE, E, X)                                                                                    \
+    case CODE:                                                                                                  \
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<E, false, X>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));              \
+        hipLaunchKernelGGL((gemm8pp_kernel<E, false, X>), dim3(std::min(grid, (unsigned)mse::device_cu_count())), dim3(512), \
+                           LDSPP_BYTES, st, a);                                                                 \
+        break;
+        MSE_ABLP(31, EPI_GELU, 1) MSE_ABLP(32, EPI_GELU, 2) MSE_ABLP(33, EPI_BF16, 0) MSE_ABLP(34, EPI_GELU, 3)
+#undef MSE_ABLP
         case 20:  // plain bf16 epilogue (no GELU)
             MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_BF16, 0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
