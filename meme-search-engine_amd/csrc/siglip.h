@@ -20,9 +20,11 @@ struct GemmLaunch {
     const float* pos = nullptr; int tokens = 0;
     uint16_t *q = nullptr, *k = nullptr, *vt = nullptr;
     int heads = 0, dh = 0, dh_pad = 0, n_pad = 0, dv_pad = 0;
+    int kdh_pad = 0;               // k row stride in elements (attention_k_stride()); 0 = dh_pad
     int gelu_tanh = 0;
 };
 
+int attention_k_stride();   // row stride (elements) launch_attention expects of the K buffer
 int gemm_bm();
 int gemm_bn();
 int gemm_bk();

@@ -137,7 +137,7 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->dlt = m->dalloc<uint16_t>(M * D, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
     m->qb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * m->dh_pad, true);   // one image of slack (rows of the M padding)
-    m->kb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * m->dh_pad, true);
+    m->kb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * attention_k_stride(), true);   // 224-byte rows (attention DMA)
     m->vtb = m->dalloc<uint16_t>((BH + m->H) * m->dv_pad * m->n_pad, true);
     m->kvb = m->dalloc<uint16_t>(M * 2 * D, true);
     m->qlat = m->dalloc<float>(D, true);
@@ -244,7 +244,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
-            g.dv_pad = m->dv_pad;
+            g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
             if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
         }
         if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;

@@ -116,7 +116,8 @@ struct GemmArgs {
     const float* pos;     // EPI_PATCH: [tokens][ldr]
     int tokens;           // tokens per image (729)
     uint16_t *q, *k, *vt; // EPI_QKV scatter targets
-    int heads, dh, dh_pad, n_pad, dv_pad;  // attention geometry
+    int heads, dh, dh_pad, n_pad, dv_pad;  // attention geometry (dh_pad = q row stride)
+    int kdh_pad;                           // k row stride in elements (112: the 224-byte rows the attention DMA wants)
     int gelu_tanh;
     int stagger;          // persistent kernel: 64-cycle sleep units per K tile and XCD index at start (0 = none)
 };
@@ -160,7 +161,7 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, size_t m, int n, c
             const int which = n / D, rem = n % D, head = rem / a.dh, e = rem % a.dh;
             const size_t bh = (size_t)bi * a.heads + head;
             if (which < 2) {
-                uint16_t* dst = (which == 0 ? a.q : a.k) + (bh * a.n_pad + tok) * a.dh_pad + e;
+                uint16_t* dst = (which == 0 ? a.q : a.k) + (bh * a.n_pad + tok) * (which == 0 ? a.dh_pad : a.kdh_pad) + e;
                 *reinterpret_cast<uint2*>(dst) = uint2{pack2(v0, v1), pack2(v2, v3)};
             } else {
                 uint16_t* dst = a.vt + (bh * a.dv_pad + e) * a.n_pad + tok;
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                 if (tok >= a.tokens) { tok -= a.tokens; bi++; }
                 const u32x4 v = *reinterpret_cast<const u32x4*>(et + row * P8_EROW + chunk * 16);
                 if (wm0 + row < (size_t)a.m_valid)
-                    *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * a.dh_pad + e) = v;
+                    *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * (which == 0 ? a.dh_pad : a.kdh_pad) + e) = v;
             }
         } else {
             // lane: column (ct*16 + i), tokens rt*16 + 4g .. +3  ->  staging [column][128 tokens] bf16 (256 B + 16 B pad)
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                         if (tok >= a.tokens) { tok -= a.tokens; bi++; }
                         if (tok >= a.tokens) { tok -= a.tokens; bi++; }
                         uint16_t* base = which == 0 ? a.q : a.k;
-                        *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * a.dh_pad + e) = val;
+                        *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * (which == 0 ? a.dh_pad : a.kdh_pad) + e) = val;
                     } else if constexpr (ABL == 1) {
                         if (val[0] == 0x12345678u) a.out_bf16[0] = 1;
                     } else {
@@ -1100,21 +1101,32 @@ __global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, 
 // 80 B chosen so that ds_read_b128 / ds_read_b64 of the fragments are bank-conflict free).  dh = 72 is padded
 // to 96 for Q.K^T (3 MFMA k steps of 32) and to 80 for the output (5 row tiles of 16).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int ATT_KROW = 224, ATT_VROW = 80;             // LDS row strides in bytes
-constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * ATT_VROW;
+// Staging: K and Vt tiles of 32 keys travel L2/HBM -> LDS by LDS-DMA into a 3-stage ring (no staging registers, one
+// barrier per tile, hand-counted vmcnt).  An LDS-DMA image is lane-linear, so
+//   * K rows are 224 bytes apart ALREADY IN GLOBAL MEMORY (k row stride 112 elements, written so by the QKV
+//     epilogue): a 32-key tile is 7 contiguous KiB and the copy keeps the conflict-free 224-byte row stride;
+//   * Vt rows (64 bytes per tile) are fetched with their four 16-byte pieces permuted on the SOURCE side,
+//     LDS slot (row, s) <- piece s ^ ((row >> 2) & 3), which makes the ds_read_b64 pairs of the PV operand conflict free.
+// A workgroup is 8 waves = 256 queries of one (image, head): the K / Vt stream is shared by twice as many queries as
+// with 4 waves.  Waves 0-6 issue the 7 K pieces, waves 0-4 the 5 Vt pieces of each tile.
+constexpr int ATT_KROW = 224;
+constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * 64;
+constexpr int ATT_STAGE = ATT_KTILE + ATT_VTILE;   // 12 KiB
+constexpr int ATT_KSTRIDE = ATT_KROW / 2;           // k row stride in elements (global)
 
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                         int dh, int dh_pad, int dv_pad, float scale_log2e,
                                                         uint16_t* __restrict__ out, int ldo, int tstride) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * (ATT_KTILE + ATT_VTILE)];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) char lds[3 * ATT_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int qblocks = (tokens + 127) / 128;
+    const int qblocks = (tokens + 255) / 256;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const int q0 = qb * 128 + wave * 32;
-    const uint16_t* kp = k + (size_t)bh * n_pad * dh_pad;
-    const uint16_t* vp = vt + (size_t)bh * dv_pad * n_pad;
+    const int q0 = qb * 256 + wave * 32;
+    const char* kp = reinterpret_cast<const char*>(k) + (size_t)bh * n_pad * ATT_KROW;
+    const char* vp = reinterpret_cast<const char*>(vt + (size_t)bh * dv_pad * n_pad);
     // Q fragments (B operand): lane (query i, k group g) -> dh 32*ks + 8g .. +8.  Rows past n_pad are clamped.
     bf16x8 qf[2][3];
 #pragma unroll
@@ -1125,23 +1137,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) qf[qt][ks] = as_bf8(*reinterpret_cast<const u32x4*>(qp + ks * 32 + g * 8));
     }
-    // staging: K tile = 32 rows x 192 B = 384 chunks of 16 B, Vt tile = 80 rows x 64 B = 320 chunks
-    const int kc1 = tid + 256, vc1 = tid + 256;
-    const bool k2 = kc1 < 384, v2 = vc1 < 320;
-    auto kaddr = [&](int c, int kt) { return kp + (size_t)(kt + c / 12) * dh_pad + (c % 12) * 8; };
-    auto vaddr = [&](int c, int kt) { return vp + (size_t)(c / 4) * n_pad + kt + (c % 4) * 8; };
-    auto klds = [&](int c, int b) { return lds + b * (ATT_KTILE + ATT_VTILE) + (c / 12) * ATT_KROW + (c % 12) * 16; };
-    auto vlds = [&](int c, int b) { return lds + b * (ATT_KTILE + ATT_VTILE) + ATT_KTILE + (c / 4) * ATT_VROW + (c % 4) * 16; };
-    u32x4 kr0, kr1{}, vr0, vr1{};
-    kr0 = *reinterpret_cast<const u32x4*>(kaddr(tid, 0));
-    if (k2) kr1 = *reinterpret_cast<const u32x4*>(kaddr(kc1, 0));
-    vr0 = *reinterpret_cast<const u32x4*>(vaddr(tid, 0));
-    if (v2) vr1 = *reinterpret_cast<const u32x4*>(vaddr(vc1, 0));
-    *reinterpret_cast<u32x4*>(klds(tid, 0)) = kr0;
-    if (k2) *reinterpret_cast<u32x4*>(klds(kc1, 0)) = kr1;
-    *reinterpret_cast<u32x4*>(vlds(tid, 0)) = vr0;
-    if (v2) *reinterpret_cast<u32x4*>(vlds(vc1, 0)) = vr1;
-    __syncthreads();
+    // DMA pieces of this wave: K piece `wave` (1 KiB of the contiguous 7 KiB tile), Vt rows 16*wave .. +15
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t koff = (uint32_t)(wave * 1024 + lane * 16);
+    const uint32_t voff = (uint32_t)((wave * 16 + (lane >> 2)) * n_pad * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    const int n_mine = wave < 5 ? 2 : (wave < 7 ? 1 : 0);
+    auto issue = [&](int tile) {
+        const uint32_t st = lds0 + (tile % 3) * ATT_STAGE;
+        if (wave < 7) dma16_s(kp + (size_t)tile * ATT_KTILE, koff, st + wave * 1024);
+        if (wave < 5) dma16_s(vp + (size_t)tile * 64, voff, st + ATT_KTILE + wave * 1024);
+    };
+    const int nt = n_pad / 32;
+    issue(0);
+    if (nt > 1) issue(1);
 
     float4v o[2][5];
 #pragma unroll
@@ -1151,16 +1159,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
             for (int r = 0; r < 4; r++) o[qt][t][r] = 0.0f;
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.0f, 0.0f};
-    int buf = 0;
-    for (int kt = 0; kt < n_pad; kt += 32) {
-        const bool more = kt + 32 < n_pad;
-        if (more) {
-            kr0 = *reinterpret_cast<const u32x4*>(kaddr(tid, kt + 32));
-            if (k2) kr1 = *reinterpret_cast<const u32x4*>(kaddr(kc1, kt + 32));
-            vr0 = *reinterpret_cast<const u32x4*>(vaddr(tid, kt + 32));
-            if (v2) vr1 = *reinterpret_cast<const u32x4*>(vaddr(vc1, kt + 32));
+    const int vsw = (i >> 2) & 3;   // read-side swizzle of the Vt rows this lane reads (rows t*16 + i)
+    for (int kt = 0, tile = 0; kt < n_pad; kt += 32, tile++) {
+        // own pieces of this tile have landed (the next tile's may still be in flight), then everyone's are visible
+        if (tile + 1 < nt) {
+            if (n_mine == 2) vm_wait<2>(); else if (n_mine == 1) vm_wait<1>(); else vm_wait<0>();
+        } else {
+            vm_wait<0>();
         }
-        const char* kl = lds + buf * (ATT_KTILE + ATT_VTILE);
+        __builtin_amdgcn_s_barrier();
+        if (tile + 2 < nt) issue(tile + 2);   // into the stage tile-1 used: every wave is past its reads of it
+        const char* kl = lds + (tile % 3) * ATT_STAGE;
         const char* vl = kl + ATT_KTILE;
         float4v s[2][2];
 #pragma unroll
@@ -1194,14 +1203,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run[qt], mx);
-            alpha[qt] = exp2f(m_run[qt] - m_new);
+            alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
             float psum = 0.0f;
             float p[8];
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    p[h2 * 4 + r] = exp2f(s[qt][h2][r] - m_new);
+                    p[h2 * 4 + r] = __builtin_amdgcn_exp2f(s[qt][h2][r] - m_new);
                     psum += p[h2 * 4 + r];
                 }
             psum += __shfl_xor(psum, 16);
@@ -1213,9 +1222,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
         for (int t = 0; t < 5; t++) {
             // A operand: Vt row e = 16t + i, contraction slots = keys {4g..+3, 16+4g..+3} of this tile
-            const char* vrow = vl + (t * 16 + i) * ATT_VROW + g * 8;
-            const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 32);
+            const char* vrow = vl + (t * 16 + i) * 64 + (g & 1) * 8;
+            const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((g >> 1) ^ vsw) * 16));
+            const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((2 + (g >> 1)) ^ vsw) * 16));
             const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
@@ -1224,14 +1233,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
             }
         }
-        if (more) {
-            *reinterpret_cast<u32x4*>(klds(tid, buf ^ 1)) = kr0;
-            if (k2) *reinterpret_cast<u32x4*>(klds(kc1, buf ^ 1)) = kr1;
-            *reinterpret_cast<u32x4*>(vlds(tid, buf ^ 1)) = vr0;
-            if (v2) *reinterpret_cast<u32x4*>(vlds(vc1, buf ^ 1)) = vr1;
-        }
-        __syncthreads();
-        buf ^= 1;
     }
     const int b = bh / heads, hd = bh % heads;
 #pragma unroll
@@ -1495,6 +1496,7 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
     return 0;
 }
 
+int attention_k_stride() { return ATT_KSTRIDE; }
 int gemm_bm() { return BM; }
 int gemm_bn() { return BN; }
 int gemm_bk() { return BK; }
@@ -1505,7 +1507,7 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid; a.n_off = 0;
     a.out_bf16 = g.out_bf16; a.ldo = g.ldo; a.resid = g.resid; a.ldr = g.ldr; a.pos = g.pos; a.tokens = g.tokens;
     a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
-    a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh;
+    a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh; a.kdh_pad = g.kdh_pad ? g.kdh_pad : g.dh_pad;
     switch (epi) {
         case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, st);
         case EPI_GELU: return launch_gemm_t<EPI_GELU>(a, st);
@@ -1543,9 +1545,9 @@ int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
                      int dh_pad, int dv_pad, uint16_t* out, int ldo, int tstride, hipStream_t st) {
     if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
-    const int qblocks = (tokens + 127) / 128;
+    const int qblocks = (tokens + 255) / 256;
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad,
                        dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
     MSE_HIP_TRY(hipGetLastError());
     return 0;

@@ -108,9 +108,10 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->h = m->dalloc<uint16_t>(M * D, true);
     m->dlt = m->dalloc<uint16_t>(M * D, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
-    m->qb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
-    m->kb = m->dalloc<uint16_t>(BH * m->n_pad * m->dh_pad, true);
-    m->vtb = m->dalloc<uint16_t>(BH * m->dv_pad * m->n_pad, true);
+    // + 4 sequences of slack: the GEMM epilogues store the rows of the M padding (up to 255) unconditionally
+    m->qb = m->dalloc<uint16_t>((BH + 4 * m->H) * m->n_pad * m->dh_pad, true);
+    m->kb = m->dalloc<uint16_t>((BH + 4 * m->H) * m->n_pad * attention_k_stride(), true);
+    m->vtb = m->dalloc<uint16_t>((BH + 4 * m->H) * m->dv_pad * m->n_pad, true);
     m->pooled = m->dalloc<float>(B * D); m->feat = m->dalloc<float>(B * D);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
     bool ok = m->tokens_dev && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
@@ -187,7 +188,7 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
-            g.dv_pad = m->dv_pad;
+            g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
             if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
         }
         if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, T, st)) return -1;
