@@ -148,6 +148,11 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
               m->pool_a && m->pool_o && m->pool_ln && m->pool_h && m->pool_f && m->out_f32 && m->out_f16;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_destroy(m); fail("siglip: device allocation failed"); return nullptr; }
+    (void)hipDeviceSynchronize();   // the zero fills above ran on the null stream; m->stream does not wait for it
+    if (launch_vt_ones_row(m->vtb, BH + m->H, m->dh, m->dv_pad, m->n_pad, m->stream) || hipStreamSynchronize(m->stream) != hipSuccess) {
+        mse_siglip_destroy(m);
+        return nullptr;
+    }
     return m;
 }
 

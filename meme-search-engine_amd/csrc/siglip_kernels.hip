@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
         for (int t = 0; t < 5; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) o[qt][t][r] = 0.0f;
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.0f, 0.0f};
+    float m_run[2] = {-1e30f, -1e30f};
     const int vsw = (i >> 2) & 3;   // read-side swizzle of the Vt rows this lane reads (rows t*16 + i)
     for (int kt = 0, tile = 0; kt < n_pad; kt += 32, tile++) {
         // own pieces of this tile have landed (the next tile's may still be in flight), then everyone's are visible
@@ -1186,37 +1186,47 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
                 s[0][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][h2], 0, 0, 0);
                 s[1][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][h2], 0, 0, 0);
             }
-        bf16x8 pf[2];
-        float alpha[2];
+        // lane holds St[key = kt + 16*h2 + 4g + r][query] (raw, unscaled); only the last tile has padded keys to mask
+        if (kt + 32 > tokens) {
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (kt + h2 * 16 + 4 * g + r >= tokens) s[qt][h2][r] = -1e30f;
+        }
+        float mnew[2];
 #pragma unroll
         for (int qt = 0; qt < 2; qt++) {
-            // lane holds St[key = kt + 16*h2 + 4g + r][query]; padded keys are masked out
-            float mx = -1e30f;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; h2++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int key = kt + h2 * 16 + 4 * g + r;
-                    s[qt][h2][r] = key < tokens ? s[qt][h2][r] * scale_log2e : -1e30f;
-                    mx = fmaxf(mx, s[qt][h2][r]);
-                }
+            float mx = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
+                             fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qt], mx);
-            alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-            float psum = 0.0f;
+            mnew[qt] = fmaxf(m_run[qt], mx * scale_log2e);
+        }
+        // The running maximum is only raised (and O rescaled) when it would grow by more than 2^8: otherwise the old one
+        // is kept and p = exp2(s - m_old) <= 256 -- the rescale multiplies leave most iterations.  The row sums ride in
+        // the PV product itself: row 72 of Vt is all ones (set once by the engine), so O^T row 72 accumulates sum(p).
+        if (__any((mnew[0] - m_run[0] > 8.0f) || (mnew[1] - m_run[1] > 8.0f))) {
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew[qt]);
+                m_run[qt] = mnew[qt];
+#pragma unroll
+                for (int t = 0; t < 5; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[qt][t][r] *= alpha;
+            }
+        }
+        bf16x8 pf[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++) {
             float p[8];
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    p[h2 * 4 + r] = __builtin_amdgcn_exp2f(s[qt][h2][r] - m_new);
-                    psum += p[h2 * 4 + r];
-                }
-            psum += __shfl_xor(psum, 16);
-            psum += __shfl_xor(psum, 32);
-            l_run[qt] = l_run[qt] * alpha[qt] + psum;
-            m_run[qt] = m_new;
+                for (int r = 0; r < 4; r++) p[h2 * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
             pf[qt] = as_bf8(u32x4{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])});
         }
 #pragma unroll
@@ -1227,19 +1237,17 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
             const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((2 + (g >> 1)) ^ vsw) * 16));
             const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) o[qt][t][r] *= alpha[qt];
-                o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
-            }
+            for (int qt = 0; qt < 2; qt++) o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
         }
     }
     const int b = bh / heads, hd = bh % heads;
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
         const int tok = q0 + qt * 16 + i;
+        // sum(p) of query i sits in O^T row dh (= 72 = 64 + 4*2 + 0): tile 4, lane group g = 2, element 0
+        const float lsum = __shfl(o[qt][4][0], 32 + i);
         if (tok < tokens) {
-            const float inv = 1.0f / l_run[qt];
+            const float inv = 1.0f / lsum;
             uint16_t* op = out + ((size_t)b * tstride + tok) * ldo + hd * dh;
 #pragma unroll
             for (int t = 0; t < 5; t++) {
@@ -1249,6 +1257,13 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
             }
         }
     }
+}
+
+// Row `dh` of every Vt matrix = 1.0 (the attention kernel reads sum(p) out of the PV product)
+__global__ void vt_ones_row_kernel(uint16_t* __restrict__ vt, size_t n_mats, int dv_pad, int n_pad, int row) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_mats * n_pad) return;
+    vt[(idx / n_pad * dv_pad + row) * n_pad + idx % n_pad] = 0x3F80;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1549,6 +1564,14 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad,
                        dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_vt_ones_row(uint16_t* vt, size_t n_mats, int dh, int dv_pad, int n_pad, hipStream_t st) {
+    if (dh != 72 || dv_pad != 80) return fail("attention: the row-sum row assumes dh 72, dv_pad 80");
+    const size_t total = n_mats * n_pad;
+    hipLaunchKernelGGL(vt_ones_row_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, vt, n_mats, dv_pad, n_pad, dh);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

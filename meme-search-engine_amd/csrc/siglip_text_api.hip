@@ -117,6 +117,11 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     bool ok = m->tokens_dev && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_text_destroy(m); fail("siglip text: device allocation failed"); return nullptr; }
+    (void)hipDeviceSynchronize();   // the zero fills above ran on the null stream; m->stream does not wait for it
+    if (launch_vt_ones_row(m->vtb, BH + 4 * m->H, m->dh, m->dv_pad, m->n_pad, m->stream) || hipStreamSynchronize(m->stream) != hipSuccess) {
+        mse_siglip_text_destroy(m);
+        return nullptr;
+    }
     return m;
 }
 
