@@ -1114,7 +1114,14 @@ constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * 64;
 constexpr int ATT_STAGE = ATT_KTILE + ATT_VTILE;   // 12 KiB
 constexpr int ATT_KSTRIDE = ATT_KROW / 2;           // k row stride in elements (global)
 
-__global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__device__ __forceinline__ float max3f(float a, float b, float c) {   // one instruction, no canonicalising pre-pass
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <int NW>   // waves per workgroup (4 or 8); NW * 32 queries share the K / Vt stream
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                         int dh, int dh_pad, int dv_pad, float scale_log2e,
                                                         uint16_t* __restrict__ out, int ldo, int tstride) {
@@ -1122,9 +1129,9 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int qblocks = (tokens + 255) / 256;
+    const int qblocks = (tokens + NW * 32 - 1) / (NW * 32);
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const int q0 = qb * 256 + wave * 32;
+    const int q0 = qb * (NW * 32) + wave * 32;
     const char* kp = reinterpret_cast<const char*>(k) + (size_t)bh * n_pad * ATT_KROW;
     const char* vp = reinterpret_cast<const char*>(vt + (size_t)bh * dv_pad * n_pad);
     // Q fragments (B operand): lane (query i, k group g) -> dh 32*ks + 8g .. +8.  Rows past n_pad are clamped.
@@ -1137,15 +1144,25 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) qf[qt][ks] = as_bf8(*reinterpret_cast<const u32x4*>(qp + ks * 32 + g * 8));
     }
-    // DMA pieces of this wave: K piece `wave` (1 KiB of the contiguous 7 KiB tile), Vt rows 16*wave .. +15
+    // DMA pieces of a tile: 7 K pieces (1 KiB each of the contiguous 7 KiB tile) and 5 Vt pieces (16 rows x 64 B each).
+    // NW = 8: wave w issues K piece w (w < 7) and Vt piece w (w < 5); NW = 4: piece ids w, w+4, w+8 of {K0..K6, V0..V4}.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-    const uint32_t koff = (uint32_t)(wave * 1024 + lane * 16);
-    const uint32_t voff = (uint32_t)((wave * 16 + (lane >> 2)) * n_pad * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
-    const int n_mine = wave < 5 ? 2 : (wave < 7 ? 1 : 0);
+    const uint32_t vlane = (uint32_t)((lane >> 2) * n_pad * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    const int n_mine = NW == 4 ? 3 : (wave < 5 ? 2 : (wave < 7 ? 1 : 0));
     auto issue = [&](int tile) {
         const uint32_t st = lds0 + (tile % 3) * ATT_STAGE;
-        if (wave < 7) dma16_s(kp + (size_t)tile * ATT_KTILE, koff, st + wave * 1024);
-        if (wave < 5) dma16_s(vp + (size_t)tile * 64, voff, st + ATT_KTILE + wave * 1024);
+        const char* kb = kp + (size_t)tile * ATT_KTILE;
+        const char* vb = vp + (size_t)tile * 64;
+        auto piece = [&](int id) {   // id: wave-uniform
+            if (id < 7) dma16_s(kb, (uint32_t)(id * 1024 + lane * 16), st + id * 1024);
+            else dma16_s(vb, (uint32_t)((id - 7) * 16 * n_pad * 2) + vlane, st + ATT_KTILE + (id - 7) * 1024);
+        };
+        if constexpr (NW == 4) {
+            piece(wave); piece(wave + 4); piece(wave + 8);
+        } else {
+            if (wave < 7) piece(wave);
+            if (wave < 5) piece(7 + wave);
+        }
     };
     const int nt = n_pad / 32;
     issue(0);
@@ -1163,7 +1180,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
     for (int kt = 0, tile = 0; kt < n_pad; kt += 32, tile++) {
         // own pieces of this tile have landed (the next tile's may still be in flight), then everyone's are visible
         if (tile + 1 < nt) {
-            if (n_mine == 2) vm_wait<2>(); else if (n_mine == 1) vm_wait<1>(); else vm_wait<0>();
+            if (n_mine == 3) vm_wait<3>(); else if (n_mine == 2) vm_wait<2>(); else if (n_mine == 1) vm_wait<1>(); else vm_wait<0>();
         } else {
             vm_wait<0>();
         }
@@ -1199,11 +1216,13 @@ __global__ __launch_bounds__(512) void attention_kernel(const uint16_t* __restri
         float mnew[2];
 #pragma unroll
         for (int qt = 0; qt < 2; qt++) {
-            float mx = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
-                             fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            mnew[qt] = fmaxf(m_run[qt], mx * scale_log2e);
+            float mx = max3f(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
+            mx = max3f(mx, s[qt][0][3], s[qt][1][0]);
+            mx = max3f(mx, s[qt][1][1], s[qt][1][2]);
+            mx = max3f(mx, s[qt][1][3], mx);
+            mx = max3f(mx, __shfl_xor(mx, 16), mx);
+            mx = max3f(mx, __shfl_xor(mx, 32), mx);
+            mnew[qt] = max3f(m_run[qt], mx * scale_log2e, m_run[qt]);
         }
         // The running maximum is only raised (and O rescaled) when it would grow by more than 2^8: otherwise the old one
         // is kept and p = exp2(s - m_old) <= 256 -- the rescale multiplies leave most iterations.  The row sums ride in
@@ -1560,10 +1579,17 @@ int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
                      int dh_pad, int dv_pad, uint16_t* out, int ldo, int tstride, hipStream_t st) {
     if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
-    const int qblocks = (tokens + 255) / 256;
+    static const int nw = getenv("MSE_ATT_WAVES") ? atoi(getenv("MSE_ATT_WAVES")) : 8;   // developer knob
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad,
-                       dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+    if (nw == 8) {
+        const int qblocks = (tokens + 255) / 256;
+        hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad,
+                           dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+    } else {
+        const int qblocks = (tokens + 127) / 128;
+        hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
+                           dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+    }
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
