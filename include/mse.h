@@ -175,6 +175,10 @@ int mse_disk_greedy_search(mse_searcher* s, mse_pq* pq, const mse_codes* c, cons
                            size_t max_deg, const uint8_t* has_url, uint32_t start, const uint16_t* query, const float* lut,
                            const float* scales, int disable_pq, size_t beamwidth, mse_nb* buf, uint32_t* visited_ids,
                            int64_t* visited_scores, size_t visited_cap, size_t* n_visited, size_t* cmps, size_t* pq_cmps);
+/* Result de-duplication of the visited list (src/query_disk_index.rs:482-527): S = V V^T over the visited rows
+ * (ids into the searcher's base, visit order), greedy keep-first filter with S[i][j] > threshold (0.95, :99) against
+ * already kept rows.  keep[i] = 1 for survivors. */
+int mse_dedup_visited(mse_searcher* s, const uint32_t* ids, size_t n, float threshold, uint8_t* keep);
 /* Shard / entry-point selection (src/query_disk_index.rs:254-256,447-450): argmax over shard centroids of
  * scale_dot_result_f64(dot_f32(centroid, query)), LAST maximum on ties (position_max_by_key). */
 int mse_select_shard(const float* centroids, size_t n_shards, size_t d, const float* query, size_t* shard_out);

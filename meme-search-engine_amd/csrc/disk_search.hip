@@ -68,9 +68,59 @@ __global__ void dot_f64_rows_kernel(const uint16_t* __restrict__ base, size_t n,
     out[r] = scale_dot_result_f64(acc);
 }
 
+// bit (i, j) = [ dot_f32(row ids[i], row ids[j]) > threshold ] for j < i; one wave per (i, block of 64 j); the dot is a
+// k-ascending fp32 FMA chain over the widened f16 rows (the order the oracle states for the reference's sgemm)
+__global__ __launch_bounds__(256) void sim_bits_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
+                                                       const uint32_t* __restrict__ ids, int n, float threshold,
+                                                       unsigned long long* __restrict__ bits, int words) {
+    const int lane = threadIdx.x & 63;
+    const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = (int)(wid / words), w = (int)(wid % words);
+    if (i >= n) return;
+    if (w * 64 >= i) { if (lane == 0) bits[(size_t)i * words + w] = 0ull; return; }
+    const int j = w * 64 + lane;
+    bool hit = false;
+    if (j < i) {
+        const __half* a = reinterpret_cast<const __half*>(base) + (size_t)ids[i] * d;
+        const __half* b = reinterpret_cast<const __half*>(base) + (size_t)ids[j] * d;
+        float s = 0.0f;
+        for (int k = 0; k < d; k++) s = fmaf(__half2float(a[k]), __half2float(b[k]), s);
+        hit = s > threshold;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) bits[(size_t)i * words + w] = m;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mse_dedup_visited(mse_searcher* s, const uint32_t* ids, size_t n, float threshold, uint8_t* keep) {
+    if (!s || !s->base || !ids || !keep) return fail("dedup_visited: null argument");
+    if (n == 0) return 0;
+    if (n > 65535) return fail("dedup_visited: more than 65535 visited rows");
+    const mse_base* b = s->base;
+    for (size_t i = 0; i < n; i++)
+        if (ids[i] >= b->n) return fail("dedup_visited: id outside the index");
+    const int words = (int)((n + 63) / 64);
+    hipStream_t st = s->stream;
+    if (s->cand_ids.ensure(n * 4) || s->misc.ensure(n * (size_t)words * 8)) return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(s->cand_ids.p, ids, n * 4, hipMemcpyHostToDevice, st));
+    const size_t waves = n * (size_t)words;
+    hipLaunchKernelGGL(sim_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, b->dev, b->n, (int)b->d,
+                       s->cand_ids.as<uint32_t>(), (int)n, threshold, s->misc.as<unsigned long long>(), words);
+    MSE_HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> bits(n * (size_t)words), kept((size_t)words, 0ull);
+    MSE_HIP_TRY(hipMemcpyAsync(bits.data(), s->misc.p, bits.size() * 8, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; i++) {   // greedy keep-first filter in visit order (:514-527)
+        bool dropped = false;
+        for (int w = 0; w < words && !dropped; w++) dropped = (bits[i * words + w] & kept[w]) != 0ull;
+        keep[i] = dropped ? 0 : 1;
+        if (!dropped) kept[i / 64] |= 1ull << (i % 64);
+    }
+    return 0;
+}
 
 int mse_select_shard(const float* centroids, size_t n_shards, size_t d, const float* query, size_t* shard_out) {
     if (!centroids || !query || !shard_out) return fail("select_shard: null argument");

@@ -82,6 +82,18 @@ def select_shard(centroids, query):
     return int(out.value)
 
 
+DUPLICATES_THRESHOLD = 0.95   # query_disk_index.rs:99
+
+
+def dedup_visited(searcher: Searcher, visited_ids, threshold=DUPLICATES_THRESHOLD):
+    """query_disk_index.rs:482-527: boolean keep mask over the visited list (visit order)."""
+    ids = np.ascontiguousarray(visited_ids, np.uint32)
+    keep = np.zeros(ids.size, np.uint8)
+    check(ffi.lib().mse_dedup_visited(searcher._h, _p(ids, C.c_uint32), ids.size, float(threshold), _p(keep, C.c_uint8)),
+          "dedup_visited")
+    return keep.astype(bool)
+
+
 class DiskSearchResult:
     """What query_disk_index::greedy_search leaves behind: the Scratch's neighbour buffer and visited list
     (ids + exact scores, fetch order) and the returned (cmps, pq_cmps)."""

@@ -72,6 +72,7 @@ def lib():
             "orc_greedy_search": (sz, [u16p, sz, sz, u32p, u32p, sz, C.c_uint32, u16p, C.c_int, C.c_uint32, C.c_void_p]),
             "orc_disk_greedy_search": (sz, [u16p, sz, sz, u32p, u32p, sz, u8p, u8p, sz, sz, u8p, sz, C.c_uint32, u16p, f32p,
                                             f32p, C.c_int, sz, C.c_void_p, u32p, i64p, sz, C.POINTER(sz), C.POINTER(sz)]),
+            "orc_dedup_keep": (None, [u16p, sz, sz, C.c_float, u8p]),
             "orc_centroid_f16": (None, [u16p, sz, sz, u16p]),
             "orc_medioid": (C.c_uint32, [u16p, sz, sz]),
             "orc_index_ip": (C.c_float, [u16p, f32p, sz, C.c_int]),
@@ -320,6 +321,14 @@ def disk_greedy_search(vecs, adj, deg, codes, descriptors, start, query, lut, sc
         _p(lut, C.c_float), _p(sc, C.c_float) if sc is not None else None, int(disable_pq), beamwidth, nb._h,
         _p(vids, C.c_uint32), _p(vsc, C.c_int64), n, C.byref(cm), C.byref(pc))
     return nb, vids[:nv].copy(), vsc[:nv].copy(), int(cm.value), int(pc.value)
+
+
+def dedup_keep(vecs, threshold=0.95):
+    """src/query_disk_index.rs:482-527: keep mask over the visited vectors (visit order)."""
+    vecs = _c(vecs, np.uint16)
+    keep = np.zeros(vecs.shape[0], np.uint8)
+    lib().orc_dedup_keep(_p(vecs, C.c_uint16), vecs.shape[0], vecs.shape[1], threshold, _p(keep, C.c_uint8))
+    return keep
 
 
 def centroid_f16(vecs):

@@ -250,3 +250,25 @@ def test_select_shard_and_medioid(gpu, mse, orc):
         assert mse.medioid(vl) == orc.medioid(vecs)
     dup = np.concatenate([vecs[:10], vecs[:10]])                     # every row twice: the later copy wins ties
     assert mse.medioid(mse.VectorList.from_f16s(dup, D)) == orc.medioid(dup) >= 10
+
+
+def test_dedup_visited_matches_oracle(gpu, mse, orc):
+    """query_disk_index.rs:482-527: near-duplicates (dot > 0.95 with an already kept row) are dropped, first one wins."""
+    rng = np.random.default_rng(13)
+    n = 900
+    x = clustered_rows(orc, n, n_centres=40, noise=0.05)            # tight clusters: many pairs above 0.95
+    x[100] = x[3]; x[500] = x[3]; x[501] = x[499]                     # exact duplicates as well
+    base = orc.f16_bits(x)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    for m in (1, 65, 300):
+        ids = rng.permutation(n)[:m].astype(np.uint32)
+        keep = mse.dedup_visited(searcher, ids)
+        want = orc.dedup_keep(base[ids]).astype(bool)
+        assert np.array_equal(keep, want)
+        assert keep[0] and (m < 65 or not keep.all())
+    sims = x[ids][keep] @ x[ids][keep].T
+    np.fill_diagonal(sims, 0)
+    assert sims.max() <= 0.95 + 1e-3                                 # survivors are mutually dissimilar
+    assert mse.dedup_visited(searcher, np.empty(0, np.uint32)).size == 0
+    with pytest.raises(mse.MseError):
+        mse.dedup_visited(searcher, np.array([n], np.uint32))

@@ -428,3 +428,17 @@ def test_medioid_running_mean(orc):
     keys = [orc.dot_f64(v, orc.f16_bits(c)) for v in vecs]
     want = max(range(37), key=lambda i: (keys[i], i))             # last maximum
     assert orc.medioid(vecs) == want
+
+
+def test_dedup_keep_rule(orc):
+    # query_disk_index.rs:514-527: compared only against rows already KEPT, first occurrence wins
+    d = 64
+    e = np.eye(d, dtype=np.float32)
+    a, b = e[0], e[1]
+    near_a = (a * 0.96 + b * 0.28).astype(np.float32); near_a /= np.linalg.norm(near_a)
+    near2 = (near_a * 0.96 + e[2] * 0.28).astype(np.float32); near2 /= np.linalg.norm(near2)     # close to near_a, not to a
+    rows = orc.f16_bits(np.stack([a, near_a, near2, b, a]))
+    sims = orc.f16_to_f32(rows) @ orc.f16_to_f32(rows).T
+    assert sims[1, 0] > 0.95 and sims[2, 1] > 0.95 and sims[2, 0] < 0.95
+    # near_a is dropped (dup of a); near2 is similar only to the DROPPED near_a, so it is kept; last row duplicates a
+    assert orc.dedup_keep(rows).tolist() == [1, 0, 1, 1, 0]
