@@ -214,6 +214,9 @@ int mse_siglip_finalize(mse_siglip* m);                              /* fails if
  * error (the reference asserts, clip_server.py:139).  Outputs (either may be NULL) are host [batch, emb_dim]. */
 int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on_device, int batch, int normalize,
                             float* out_f32, uint16_t* out_f16);
+/* Same from decoded RGB bytes [batch][H][W][3] (host): the ToTensor / Normalize(0.5, 0.5) / .half() / stack steps of the
+ * preprocessing thread (clip_server.py:131-146) run on the device; x / 127.5 - 1 in fp32, fp16 round-to-nearest-even. */
+int mse_siglip_encode_rgb8(mse_siglip* m, const uint8_t* rgb_hwc, int batch, int normalize, float* out_f32, uint16_t* out_f16);
 const void* mse_siglip_output_device(const mse_siglip* m, int which);  /* device result of the last call: 0 f32, 1 f16 */
 void* mse_siglip_stream(const mse_siglip* m);
 int mse_siglip_debug_residual(mse_siglip* m, float* out);             /* test hook: residual stream after the last block */

@@ -217,6 +217,19 @@ int mse_siglip_finalize(mse_siglip* m) {
     return 0;
 }
 
+// Decoded RGB bytes in, features out: the ToTensor / Normalize / .half() / stack / H2D steps of the reference's
+// preprocessing thread (clip_server.py:131-146) run on the device, and the PCIe copy is the u8 image (1 B/element)
+int mse_siglip_encode_rgb8(mse_siglip* m, const uint8_t* rgb_hwc, int batch, int normalize, float* out_f32, uint16_t* out_f16) {
+    if (!m || !rgb_hwc) return fail("null engine or image");
+    if (batch <= 0 || batch > m->max_batch) return fail("siglip: batch exceeds max_batch");
+    const mse_siglip_config& c = m->cfg;
+    const size_t elems = (size_t)batch * c.in_chans * c.img_size * c.img_size;
+    uint8_t* u8 = reinterpret_cast<uint8_t*>(m->img_dev) + 2 * (size_t)m->max_batch * c.in_chans * c.img_size * c.img_size;
+    MSE_HIP_TRY(hipMemcpyAsync(u8, rgb_hwc, elems, hipMemcpyHostToDevice, m->stream));
+    if (launch_rgb8_to_nchw_f16(u8, m->img_dev, batch, c.in_chans, c.img_size, c.img_size, m->stream)) return -1;
+    return mse_siglip_encode_image(m, m->img_dev, 1, 1, batch, normalize, out_f32, out_f16);
+}
+
 int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on_device, int batch, int normalize,
                             float* out_f32, uint16_t* out_f16) {
     if (!m) return fail("null engine");

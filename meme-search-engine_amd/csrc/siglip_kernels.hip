@@ -1278,6 +1278,17 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     }
 }
 
+// open_clip's preprocess after decoding (clip_server.py:140-141): ToTensor + Normalize(mean = std = 0.5) + .half(), i.e.
+// u8 HWC RGB -> fp16 NCHW, value x / 127.5 - 1 evaluated in fp32 (correctly rounded divide) and rounded to nearest even
+__global__ void rgb8_to_nchw_f16_kernel(const uint8_t* __restrict__ in, _Float16* __restrict__ out, int C, int H, int W, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H), c = (int)((idx / ((size_t)W * H)) % C);
+    const size_t b = idx / ((size_t)W * H * C);
+    const float v = (float)in[((b * H + y) * W + x) * C + c] / 127.5f - 1.0f;
+    out[idx] = (_Float16)v;
+}
+
 // Row `dh` of every Vt matrix = 1.0 (the attention kernel reads sum(p) out of the PV product)
 __global__ void vt_ones_row_kernel(uint16_t* __restrict__ vt, size_t n_mats, int dv_pad, int n_pad, int row) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1590,6 +1601,15 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
         hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
                            dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
     }
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_rgb8_to_nchw_f16(const uint8_t* in, void* out, int B, int C, int H, int W, hipStream_t st) {
+    const size_t total = (size_t)B * C * H * W;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(rgb8_to_nchw_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in,
+                       reinterpret_cast<_Float16*>(out), C, H, W, total);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

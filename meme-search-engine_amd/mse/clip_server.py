@@ -48,6 +48,16 @@ def preprocess_image(data: bytes, size):
     return np.ascontiguousarray(a.transpose(2, 0, 1)).astype(np.float16)
 
 
+def decode_image(data: bytes, size):
+    """The host half of preprocess_image: decode, RGB, resize if needed -> uint8 [h, w, 3].  The arithmetic half
+    (x/127.5 - 1, fp16, NCHW) then runs on the device (SiglipImageEngine.encode_rgb8)."""
+    from PIL import Image
+    im = Image.open(io.BytesIO(data)).convert("RGB")
+    if im.size != tuple(size):
+        im = im.resize(tuple(size), Image.BICUBIC)
+    return np.asarray(im, dtype=np.uint8)
+
+
 class ClipServer:
     def __init__(self, config, image_engine, text_engine=None, tokenizer=None, registry=None):
         from prometheus_client import CollectorRegistry, Counter, Histogram
@@ -85,7 +95,10 @@ class ClipServer:
                 with self.inference_time_hist.labels(self.model_name + "-image", images.shape[0]).time():
                     self.items_ctr.labels(self.model_name, "image").inc(images.shape[0])
                     # the engine normalises on the device; result rows are unit norm like `features /= norm`
-                    features = np.asarray(self.image_engine.encode_image(images), np.float32)
+                    if images.dtype == np.uint8:    # decoded bytes: normalisation / fp16 / NCHW happen on the device
+                        features = np.asarray(self.image_engine.encode_rgb8(images), np.float32)
+                    else:
+                        features = np.asarray(self.image_engine.encode_image(images), np.float32)
             else:
                 raise AssertionError("images or text required")
             self.batch_count_ctr.labels(self.model_name).inc()
@@ -117,7 +130,10 @@ class ClipServer:
                     images = None
                 elif images:
                     assert len(images) <= self.bs, f"max batch size is {self.bs}"
-                    images = np.stack([preprocess_image(im, self.image_size) for im in images])
+                    if hasattr(self.image_engine, "encode_rgb8"):
+                        images = np.stack([decode_image(im, self.image_size) for im in images])
+                    else:
+                        images = np.stack([preprocess_image(im, self.image_size) for im in images])
                     text = None
                 else:
                     assert False, "images or text required"

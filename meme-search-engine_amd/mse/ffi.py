@@ -91,6 +91,7 @@ SIGNATURES = {
     "mse_siglip_set_weight": (C.c_int, [vp, C.c_char_p, f32p, C.POINTER(sz), C.c_int]),
     "mse_siglip_finalize": (C.c_int, [vp]),
     "mse_siglip_encode_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, u16p]),
+    "mse_siglip_encode_rgb8": (C.c_int, [vp, u8p, C.c_int, C.c_int, f32p, u16p]),
     "mse_siglip_output_device": (vp, [vp, C.c_int]),
     "mse_siglip_stream": (vp, [vp]),
     "mse_siglip_debug_residual": (C.c_int, [vp, f32p]),

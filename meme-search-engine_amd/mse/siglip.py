@@ -114,6 +114,24 @@ class SiglipImageEngine:
               "siglip_encode_image")
         return of32 if out == "f32" else of16
 
+    def encode_rgb8(self, images_u8, normalize=True, out="f32"):
+        """images_u8: decoded RGB bytes [b,H,W,3] uint8.  ToTensor / Normalize(0.5) / .half() (clip_server.py:140-141) run
+        on the device; the result equals encode_image(preprocessed fp16 NCHW) bit for bit."""
+        a = np.ascontiguousarray(images_u8, np.uint8)
+        s = self.cfg["img_size"]
+        if a.ndim != 4 or a.shape[1:] != (s, s, self.cfg["in_chans"]):
+            raise MseError(f"images must be [batch, {s}, {s}, {self.cfg['in_chans']}] uint8")
+        b = a.shape[0]
+        if b > self.max_batch:
+            raise MseError(f"max batch size is {self.max_batch}")
+        of32 = np.empty((b, self.embedding_size), np.float32) if out == "f32" else None
+        of16 = np.empty((b, self.embedding_size), np.uint16) if out == "f16" else None
+        check(ffi.lib().mse_siglip_encode_rgb8(self._h, a.ctypes.data_as(ffi.u8p), b, int(normalize),
+                                               of32.ctypes.data_as(ffi.f32p) if of32 is not None else None,
+                                               of16.ctypes.data_as(ffi.u16p) if of16 is not None else None),
+              "siglip_encode_rgb8")
+        return of32 if out == "f32" else of16
+
     def encode_image_device(self, dev_ptr, batch, dtype_f16=True, normalize=True):
         """Images already resident in HBM (the `fast_image_fns` call shape); result stays on the device:
         returns (device pointer to [batch, emb] f32, device pointer to the fp16 copy)."""

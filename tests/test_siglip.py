@@ -135,6 +135,22 @@ def test_text_engine_matches_oracle(gpu, mse, ref, layers, gelu, batch):
 
 
 @pytest.mark.gpu
+def test_device_preprocessing_equals_host_preprocessing(gpu, mse, ref):
+    """encode_rgb8 (ToTensor / Normalize / .half() on the device) == encode_image(host-preprocessed fp16 NCHW), bit for bit."""
+    from mse import siglip
+    cfg = dict(siglip.SO400M_384, depth=1)
+    eng = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=3)
+    u8 = np.random.default_rng(5).integers(0, 256, size=(3, 384, 384, 3), dtype=np.uint8)
+    u8[0, :2, :2] = [[[0, 255, 51], [1, 2, 3]], [[127, 128, 129], [254, 253, 252]]]
+    host = (u8.astype(np.float32) / np.float32(127.5) - np.float32(1.0)).transpose(0, 3, 1, 2).astype(np.float16)
+    a = eng.encode_rgb8(u8, out="f16")
+    b = eng.encode_image(np.ascontiguousarray(host), out="f16")
+    assert np.array_equal(a, b)
+    with pytest.raises(mse.MseError):
+        eng.encode_rgb8(np.zeros((1, 100, 100, 3), np.uint8))
+
+
+@pytest.mark.gpu
 def test_engine_requires_all_weights(gpu, mse, ref):
     from mse import siglip
     cfg = dict(ref.CONFIG, depth=1)
