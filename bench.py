@@ -93,7 +93,7 @@ def siglip_bench(args, world, rank):
     gflop_img = 0.988 + 27 * 24.647 + 3.9                     # 670.4 GFLOP per image
     tflops = per_gpu * gflop_img / 1e3
     return {"metric": "SigLIP img-embeds/sec/GPU", "value": per_gpu, "unit": "images/s/GPU", "total_images_per_s": per_gpu * world,
-            "ms_per_batch": dt / args.siglip_steps * 1e3, "dtype": "bf16 (fp32 accumulate, fp32 residual stream)",
+            "ms_per_batch": dt / args.siglip_steps * 1e3, "dtype": "bf16 (fp32 accumulate; fp16 residual stream, fp32 LayerNorm/softmax/GELU)",
             "config": {"workload": f"SigLIP-SO400M/14-384 image tower, batch {batch} random 384x384, 1 replica per GPU",
                        "weights": "random-init (seeded), architecture of ViT-SO400M-14-SigLIP-384"},
             "steps": args.siglip_steps, "scaling": "weak (replicas)",

@@ -31,8 +31,9 @@ int gemm_bk();
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
 // delta (optional, bf16 [rows][ldd]): x += delta is applied and written back before normalising
-int launch_layernorm(float* x, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps, int width,
-                     size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st);
+// x: fp32 rows, or fp16 rows (x_is_f16: the towers' residual stream)
+int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,
+                     int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st);
 // token rows of image b are rows b * tstride + t (t < tokens; the rest of the stride is padding)
 int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
                     hipStream_t st);
@@ -48,7 +49,7 @@ int launch_small_linear(const float* x, int ldx, const uint16_t* w, int ldw, con
                         const float* res, int ldres, float* y, int ldy, hipStream_t st);
 int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, float* out_f32, uint16_t* out_f16, hipStream_t st);
 int launch_embed_tokens(const int64_t* tokens, const float* tok_emb, const float* pos, int vocab, int ctx, int D, size_t rows,
-                        float* x, hipStream_t st);
+                        uint16_t* x_f16, hipStream_t st);
 int launch_f32_to_bf16_pad(const float* in, int rows, int cols, int ld_in, uint16_t* out, int rows_pad, int cols_pad,
                            hipStream_t st);
 

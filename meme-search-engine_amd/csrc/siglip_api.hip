@@ -56,7 +56,8 @@ struct mse_siglip {
     // activations
     void* img_dev = nullptr;
     uint16_t *patches = nullptr, *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *kvb = nullptr;
-    float *x = nullptr, *pool_a = nullptr, *pool_o = nullptr, *pool_ln = nullptr, *pool_h = nullptr, *pool_f = nullptr;
+    uint16_t* x = nullptr;   // residual stream [M][D], fp16
+    float *pool_a = nullptr, *pool_o = nullptr, *pool_ln = nullptr, *pool_h = nullptr, *pool_f = nullptr;
     float* out_f32 = nullptr; uint16_t* out_f16 = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
     int last_batch = 0;
@@ -132,7 +133,7 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     const size_t B = m->max_batch, M = m->m_pad, BH = B * m->H;
     m->img_dev = m->dalloc<float>(B * c->in_chans * c->img_size * c->img_size);
     m->patches = m->dalloc<uint16_t>(M * m->kpe_pad, true);
-    m->x = m->dalloc<float>(M * D, true);
+    m->x = m->dalloc<uint16_t>(M * D, true);   // residual stream, fp16
     m->h = m->dalloc<uint16_t>(M * D, true);
     m->dlt = m->dalloc<uint16_t>(M * D, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
@@ -252,13 +253,13 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
     if (launch_patchify(img, dtype, batch, c.in_chans, c.img_size, c.img_size, c.patch_size, m->kpe_pad, TS, m->patches, st)) return -1;
     {
         GemmLaunch g; g.x = m->patches; g.w = m->wpe; g.bias = m->bpe; g.M = Mp; g.N = D; g.K = m->kpe_pad; g.m_valid = M;
-        g.resid = m->x; g.ldr = D; g.pos = m->pos; g.tokens = TS;
+        g.out_bf16 = m->x; g.ldo = D; g.ldr = D; g.pos = m->pos; g.tokens = TS;   // writes the fp16 residual stream
         if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
     }
     for (int i = 0; i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
         const Block& b = m->blocks[i];
         // x += (fc2 output of the previous block), then LayerNorm
-        if (launch_layernorm(m->x, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
@@ -271,7 +272,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
             g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
-        if (launch_layernorm(m->x, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
+        if (launch_layernorm(m->x, 1, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
         {
             GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
             g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
@@ -283,7 +284,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
     }
-    if (launch_layernorm(m->x, D, c.depth ? m->dlt : nullptr, D, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
+    if (launch_layernorm(m->x, 1, D, c.depth ? m->dlt : nullptr, D, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
     // MAPHead (model.py:82-111)
     {
         GemmLaunch g; g.x = m->h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
@@ -292,7 +293,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
     }
     if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, m->pool_a, D, st)) return -1;
     if (launch_small_linear(m->pool_a, D, m->wpp, D, m->bpp, D, D, batch, 0, nullptr, 0, m->pool_o, D, st)) return -1;
-    if (launch_layernorm(m->pool_o, D, nullptr, 0, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
+    if (launch_layernorm(m->pool_o, 0, D, nullptr, 0, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
     if (launch_small_linear(m->pool_ln, D, m->wp1, D, m->bp1, D, m->mlp, batch, gelu_tanh ? 2 : 1, nullptr, 0, m->pool_h, m->mlp,
                             st)) return -1;
     if (launch_small_linear(m->pool_h, m->mlp, m->wp2, m->mlp, m->bp2, m->mlp, D, batch, 0, m->pool_o, D, m->pool_f, D, st))
@@ -337,8 +338,14 @@ int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
 // test hook: the residual stream ([batch*tokens][emb] fp32) as left by the last forward (after the last block)
 int mse_siglip_debug_residual(mse_siglip* m, float* out) {
     if (!m || !m->last_batch) return fail("siglip: no forward has run");
-    MSE_HIP_TRY(hipMemcpy2D(out, (size_t)m->tokens * m->D * 4, m->x, (size_t)m->n_pad * m->D * 4, (size_t)m->tokens * m->D * 4,
+    std::vector<uint16_t> h16((size_t)m->last_batch * m->tokens * m->D);
+    MSE_HIP_TRY(hipMemcpy2D(h16.data(), (size_t)m->tokens * m->D * 2, m->x, (size_t)m->n_pad * m->D * 2, (size_t)m->tokens * m->D * 2,
                             m->last_batch, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < h16.size(); e++) {   // fp16 -> fp32 (exact)
+        _Float16 hv;
+        memcpy(&hv, &h16[e], 2);
+        out[e] = (float)hv;
+    }
     return 0;
 }
 

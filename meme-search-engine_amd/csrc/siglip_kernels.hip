@@ -111,7 +111,8 @@ struct GemmArgs {
     // epilogue targets
     uint16_t* out_bf16;   // EPI_BF16 / EPI_GELU: [M][ldo]
     int ldo;
-    float* resid;         // EPI_RESID: x[M][ldr] += acc + bias ; EPI_PATCH: x = acc + bias + pos
+    float* resid;         // EPI_RESID: x[M][ldr] += acc + bias (fp32; unused by the towers since the residual adds moved into LayerNorm)
+                          // EPI_PATCH: out_bf16[M][ldo] (as FP16: the residual stream) = acc + bias + pos[tok][ldr]
     int ldr;
     const float* pos;     // EPI_PATCH: [tokens][ldr]
     int tokens;           // tokens per image (729)
@@ -151,7 +152,9 @@ __device__ __forceinline__ void store_quad(const GemmArgs& a, size_t m, int n, c
         if (mok) {
             const int tok = (int)(m % a.tokens);
             const float4 pv = *reinterpret_cast<const float4*>(a.pos + (size_t)tok * a.ldr + n);
-            *reinterpret_cast<float4*>(a.resid + m * a.ldr + n) = float4{v0 + pv.x, v1 + pv.y, v2 + pv.z, v3 + pv.w};
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));   // residual stream is fp16 (out_bf16 / ldo carry it)
+            *reinterpret_cast<half4v*>(a.out_bf16 + m * a.ldo + n) =
+                half4v{(_Float16)(v0 + pv.x), (_Float16)(v1 + pv.y), (_Float16)(v2 + pv.z), (_Float16)(v3 + pv.w)};
         }
     } else {  // EPI_QKV: n in [0, 3*D): which = n / D, head = (n % D) / dh, e = (n % D) % dh
         if (mok) {
@@ -660,8 +663,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                     if (m < (size_t)a.m_valid) {
                         const int tok = (int)(m % a.tokens);
                         const float4 pv = *reinterpret_cast<const float4*>(a.pos + (size_t)tok * a.ldr + a.n_off + wn0 + chunk * 4);
-                        *reinterpret_cast<float4*>(a.resid + m * a.ldr + a.n_off + wn0 + chunk * 4) =
-                            float4{v[it].x + pv.x, v[it].y + pv.y, v[it].z + pv.z, v[it].w + pv.w};
+                        typedef _Float16 half4v __attribute__((ext_vector_type(4)));   // fp16 residual stream
+                        *reinterpret_cast<half4v*>(a.out_bf16 + m * a.ldo + a.n_off + wn0 + chunk * 4) =
+                            half4v{(_Float16)(v[it].x + pv.x), (_Float16)(v[it].y + pv.y), (_Float16)(v[it].z + pv.z), (_Float16)(v[it].w + pv.w)};
                     }
                 }
             }
@@ -1015,14 +1019,18 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
 // `delta` (optional, bf16 [rows][ldd]): the residual branch output of the preceding GEMM; x += delta is applied here
 // (and written back), so that GEMM's epilogue is a plain bf16 store instead of an fp32 read-modify-write.
 // The row is held in registers (width <= 2048): one read of x, one optional write.
-__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, int ldx, const uint16_t* __restrict__ delta, int ldd,
+// XT = float, or _Float16 for the residual stream of the towers (the reference's engines keep it in fp16 too,
+// aitemplate/run.py; the sum x + delta is formed in fp32 and the statistics use the unrounded value).
+template <typename XT>
+__global__ __launch_bounds__(256) void layernorm_kernel(XT* __restrict__ x, int ldx, const uint16_t* __restrict__ delta, int ldd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         int width, size_t rows, uint16_t* __restrict__ out, int ldo,
                                                         float* __restrict__ out_f32) {
     const int lane = threadIdx.x & 63;
     const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
-    float* xr = x + row * ldx;
+    XT* xr = x + row * ldx;
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
     float4 v[8];
     float s = 0.0f, ss = 0.0f;
 #pragma unroll
@@ -1030,12 +1038,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, i
         const int c = lane * 4 + j * 256;
         v[j] = float4{0.f, 0.f, 0.f, 0.f};
         if (c < width) {
-            v[j] = *reinterpret_cast<const float4*>(xr + c);
+            if constexpr (sizeof(XT) == 4) {
+                v[j] = *reinterpret_cast<const float4*>(xr + c);
+            } else {
+                const half4v hv = *reinterpret_cast<const half4v*>(xr + c);
+                v[j] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            }
             if (delta) {
                 const uint2 d = *reinterpret_cast<const uint2*>(delta + row * ldd + c);
                 v[j].x += __uint_as_float(d.x << 16); v[j].y += __uint_as_float(d.x & 0xffff0000u);
                 v[j].z += __uint_as_float(d.y << 16); v[j].w += __uint_as_float(d.y & 0xffff0000u);
-                *reinterpret_cast<float4*>(xr + c) = v[j];
+                if constexpr (sizeof(XT) == 4) *reinterpret_cast<float4*>(xr + c) = v[j];
+                else *reinterpret_cast<half4v*>(xr + c) = half4v{(_Float16)v[j].x, (_Float16)v[j].y, (_Float16)v[j].z, (_Float16)v[j].w};
             }
             s += v[j].x + v[j].y + v[j].z + v[j].w;
         }
@@ -1388,20 +1402,21 @@ __global__ void l2norm_kernel(const float* __restrict__ x, int ldx, int width, i
     }
 }
 
-// text tower input: x[b*ctx + t] = token_embedding[tokens[b][t]] + positional_embedding[t]  (fp32 residual stream)
+// text tower input: x[b*ctx + t] = token_embedding[tokens[b][t]] + positional_embedding[t]  (fp16 residual stream)
 __global__ void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ tok_emb,
                                     const float* __restrict__ pos, int vocab, int ctx, int D, size_t rows,
-                                    float* __restrict__ x) {
+                                    _Float16* __restrict__ x) {
     const size_t row = blockIdx.x;
     if (row >= rows) return;
     int64_t tk = tokens[row];
     if (tk < 0 || tk >= vocab) tk = 0;
     const float4* e = reinterpret_cast<const float4*>(tok_emb + (size_t)tk * D);
     const float4* p = reinterpret_cast<const float4*>(pos + (size_t)(row % ctx) * D);
-    float4* o = reinterpret_cast<float4*>(x + row * D);
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    half4v* o = reinterpret_cast<half4v*>(x + row * D);
     for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
         const float4 a = e[c], b = p[c];
-        o[c] = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        o[c] = half4v{(_Float16)(a.x + b.x), (_Float16)(a.y + b.y), (_Float16)(a.z + b.z), (_Float16)(a.w + b.w)};
     }
 }
 
@@ -1563,12 +1578,16 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     return fail("gemm: unknown epilogue");
 }
 
-int launch_layernorm(float* x, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps, int width,
-                     size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
+int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,
+                     int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
     if (rows == 0) return 0;
     if (width % 4 || width > 2048) return fail("layernorm: width must be a multiple of 4, at most 2048");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, eps,
-                       width, rows, out, ldo, out_f32);
+    if (x_is_f16)
+        hipLaunchKernelGGL(layernorm_kernel<_Float16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<_Float16*>(x),
+                           ldx, delta, ldd, gamma, beta, eps, width, rows, out, ldo, out_f32);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<float*>(x), ldx,
+                           delta, ldd, gamma, beta, eps, width, rows, out, ldo, out_f32);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1648,9 +1667,10 @@ int launch_l2norm(const float* x, int ldx, int width, int B, int normalize, floa
 }
 
 int launch_embed_tokens(const int64_t* tokens, const float* tok_emb, const float* pos, int vocab, int ctx, int D, size_t rows,
-                        float* x, hipStream_t st) {
+                        uint16_t* x_f16, hipStream_t st) {
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)rows), dim3(128), 0, st, tokens, tok_emb, pos, vocab, ctx, D, rows, x);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)rows), dim3(128), 0, st, tokens, tok_emb, pos, vocab, ctx, D, rows,
+                       reinterpret_cast<_Float16*>(x_f16));
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -48,7 +48,8 @@ struct mse_siglip_text {
     uint16_t* wproj = nullptr;
     std::vector<TBlock> blocks;
     int64_t* tokens_dev = nullptr;
-    float *x = nullptr, *pooled = nullptr, *feat = nullptr, *out_f32 = nullptr;
+    uint16_t* x = nullptr;   // residual stream [M][D], fp16
+    float *pooled = nullptr, *feat = nullptr, *out_f32 = nullptr;
     uint16_t *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *out_f16 = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
 
@@ -104,7 +105,7 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->add_bf16("text.text_projection.weight", &m->wproj, D, D, D, D); m->add_f32("text.text_projection.bias", &m->bproj, 1, D);
     const size_t B = m->max_batch, M = m->m_pad, BH = B * m->H;
     m->tokens_dev = m->dalloc<int64_t>(B * m->ctx);
-    m->x = m->dalloc<float>(M * D, true);
+    m->x = m->dalloc<uint16_t>(M * D, true);
     m->h = m->dalloc<uint16_t>(M * D, true);
     m->dlt = m->dalloc<uint16_t>(M * D, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
@@ -189,7 +190,7 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     for (int i = 0; i < c.layers; i++) {
         const TBlock& b = m->blocks[i];
         // x += (fc2 output of the previous block), then LayerNorm
-        if (launch_layernorm(m->x, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
@@ -202,7 +203,7 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
             g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
-        if (launch_layernorm(m->x, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
+        if (launch_layernorm(m->x, 1, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
         {
             GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
             g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
@@ -215,7 +216,7 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
         }
     }
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
-    if (launch_layernorm(m->x + (size_t)(T - 1) * D, T * D, c.layers ? m->dlt + (size_t)(T - 1) * D : nullptr, T * D, m->lnf_g, m->lnf_b,
+    if (launch_layernorm(m->x + (size_t)(T - 1) * D, 1, T * D, c.layers ? m->dlt + (size_t)(T - 1) * D : nullptr, T * D, m->lnf_g, m->lnf_b,
                          c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
     if (launch_small_linear(m->pooled, D, m->wproj, D, m->bproj, D, D, batch, 0, nullptr, 0, m->feat, D, st)) return -1;
     if (launch_l2norm(m->feat, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
