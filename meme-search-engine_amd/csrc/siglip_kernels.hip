@@ -1127,6 +1127,20 @@ constexpr int ATT_KROW = 224;
 constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * 64;
 constexpr int ATT_STAGE = ATT_KTILE + ATT_VTILE;   // 12 KiB
 constexpr int ATT_KSTRIDE = ATT_KROW / 2;           // k row stride in elements (global)
+constexpr int ATT_NS = 3;                           // ring stages: tiles t+1 .. t+3 are in flight while tile t is consumed
+
+__device__ __forceinline__ void vm_wait_n(int n) {   // n: wave-uniform, 0..9
+    switch (n) {
+        case 0: vm_wait<0>(); break;
+        case 1: vm_wait<1>(); break;
+        case 2: vm_wait<2>(); break;
+        case 3: vm_wait<3>(); break;
+        case 4: vm_wait<4>(); break;
+        case 5: vm_wait<5>(); break;
+        case 6: vm_wait<6>(); break;
+        default: vm_wait<9>(); break;   // 9 = 3 tiles x 3 pieces; 7 and 8 never occur
+    }
+}
 
 __device__ __forceinline__ float max3f(float a, float b, float c) {   // one instruction, no canonicalising pre-pass
     float d;
@@ -1134,12 +1148,12 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {   // one ins
     return d;
 }
 
-template <int NW>   // waves per workgroup (4 or 8); NW * 32 queries share the K / Vt stream
+template <int NW, int ABL = 0>   // waves per workgroup (4 or 8); NW * 32 queries share the K / Vt stream.  ABL: timing ablations
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                         int dh, int dh_pad, int dv_pad, float scale_log2e,
                                                         uint16_t* __restrict__ out, int ldo, int tstride) {
-    __shared__ __attribute__((aligned(16))) char lds[3 * ATT_STAGE];
+    __shared__ __attribute__((aligned(16))) char lds[ATT_NS * ATT_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -1164,7 +1178,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     const uint32_t vlane = (uint32_t)((lane >> 2) * n_pad * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
     const int n_mine = NW == 4 ? 3 : (wave < 5 ? 2 : (wave < 7 ? 1 : 0));
     auto issue = [&](int tile) {
-        const uint32_t st = lds0 + (tile % 3) * ATT_STAGE;
+        const uint32_t st = lds0 + (tile % ATT_NS) * ATT_STAGE;
         const char* kb = kp + (size_t)tile * ATT_KTILE;
         const char* vb = vp + (size_t)tile * 64;
         auto piece = [&](int id) {   // id: wave-uniform
@@ -1179,8 +1193,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         }
     };
     const int nt = n_pad / 32;
-    issue(0);
-    if (nt > 1) issue(1);
+    for (int t0 = 0; t0 < ATT_NS - 1 && t0 < nt; t0++) issue(t0);
 
     float4v o[2][5];
 #pragma unroll
@@ -1193,14 +1206,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
     const int vsw = (i >> 2) & 3;   // read-side swizzle of the Vt rows this lane reads (rows t*16 + i)
     for (int kt = 0, tile = 0; kt < n_pad; kt += 32, tile++) {
         // own pieces of this tile have landed (the next tile's may still be in flight), then everyone's are visible
-        if (tile + 1 < nt) {
-            if (n_mine == 3) vm_wait<3>(); else if (n_mine == 2) vm_wait<2>(); else if (n_mine == 1) vm_wait<1>(); else vm_wait<0>();
-        } else {
-            vm_wait<0>();
-        }
+        vm_wait_n(min(ATT_NS - 2, nt - 1 - tile) * n_mine);
         __builtin_amdgcn_s_barrier();
-        if (tile + 2 < nt) issue(tile + 2);   // into the stage tile-1 used: every wave is past its reads of it
-        const char* kl = lds + (tile % 3) * ATT_STAGE;
+        if (tile + ATT_NS - 1 < nt) issue(tile + ATT_NS - 1);   // into the stage tile-1 used: every wave is past its reads of it
+        const char* kl = lds + (tile % ATT_NS) * ATT_STAGE;
         const char* vl = kl + ATT_KTILE;
         float4v s[2][2];
 #pragma unroll
@@ -1214,6 +1223,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 #pragma unroll
             for (int ks = 0; ks < 3; ks++) {
                 const bf16x8 kf = as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
+                if (ABL == 2) { s[0][h2][0] += __builtin_bit_cast(float, (uint32_t)kf[0] << 16); continue; }
                 s[0][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][h2], 0, 0, 0);
                 s[1][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][h2], 0, 0, 0);
             }
@@ -1230,6 +1240,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         float mnew[2];
 #pragma unroll
         for (int qt = 0; qt < 2; qt++) {
+            if (ABL == 1) { mnew[qt] = m_run[qt]; continue; }
             float mx = max3f(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
             mx = max3f(mx, s[qt][0][3], s[qt][1][0]);
             mx = max3f(mx, s[qt][1][1], s[qt][1][2]);
@@ -1259,7 +1270,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) p[h2 * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
+                for (int r = 0; r < 4; r++)
+                    p[h2 * 4 + r] = ABL == 1 ? s[qt][h2][r] : __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
             pf[qt] = as_bf8(u32x4{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])});
         }
 #pragma unroll
@@ -1270,7 +1282,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
             const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((2 + (g >> 1)) ^ vsw) * 16));
             const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
+            for (int qt = 0; qt < 2; qt++) {
+                if (ABL == 2) { o[qt][t][0] += __builtin_bit_cast(float, (uint32_t)vf[0] << 16) + __builtin_bit_cast(float, (uint32_t)pf[qt][0] << 16); continue; }
+                o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
+            }
         }
     }
     const int b = bh / heads, hd = bh % heads;
@@ -1279,6 +1294,167 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         const int tok = q0 + qt * 16 + i;
         // sum(p) of query i sits in O^T row dh (= 72 = 64 + 4*2 + 0): tile 4, lane group g = 2, element 0
         const float lsum = __shfl(o[qt][4][0], 32 + i);
+        if (tok < tokens) {
+            const float inv = 1.0f / lsum;
+            uint16_t* op = out + ((size_t)b * tstride + tok) * ldo + hd * dh;
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const int e = t * 16 + 4 * g;
+                if (e < dh)
+                    *reinterpret_cast<uint2*>(op + e) = uint2{pack2(o[qt][t][0] * inv, o[qt][t][1] * inv), pack2(o[qt][t][2] * inv, o[qt][t][3] * inv)};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Same attention with 64-key ring stages: one barrier and one counted wait per 64 keys, the two 32-key halves of a
+// stage are consumed back to back (the second half's K fragments can be read while the first half's softmax runs).
+// Stage = K 64 rows x 224 B (14 contiguous KiB) + Vt 80 rows x 128 B (10 KiB, pieces swizzled by (row >> 1) & 7 on
+// the source side like the GEMM operands); 24 pieces per stage, three per wave.  n_pad need only be a multiple of 32:
+// the last stage may be half used (the DMA then reads 32 rows / 64 bytes past the matrix, inside the slack the
+// engines allocate, and the half is skipped).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AT6_KT = 64 * ATT_KROW;          // 14336
+constexpr int AT6_VT = 80 * 128;               // 10240
+constexpr int AT6_STAGE = AT6_KT + AT6_VT;     // 24 KiB
+constexpr int AT6_NS = 3;
+
+__global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                          const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
+                                                          int dh, int dh_pad, int dv_pad, float scale_log2e,
+                                                          uint16_t* __restrict__ out, int ldo, int tstride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // AT6_NS * AT6_STAGE bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int qblocks = (tokens + 255) / 256;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    const int q0 = qb * 256 + wave * 32;
+    const char* kp = reinterpret_cast<const char*>(k) + (size_t)bh * n_pad * ATT_KROW;
+    const char* vp = reinterpret_cast<const char*>(vt + (size_t)bh * dv_pad * n_pad);
+    bf16x8 qf[2][3];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+        int qrow = q0 + qt * 16 + i;
+        if (qrow >= n_pad) qrow = n_pad - 1;
+        const uint16_t* qp = q + ((size_t)bh * n_pad + qrow) * dh_pad;
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) qf[qt][ks] = as_bf8(*reinterpret_cast<const u32x4*>(qp + ks * 32 + g * 8));
+    }
+    // pieces 0..13: K (1 KiB each of the contiguous stage), 14..23: Vt rows 8v .. 8v+7; wave w issues w, w+8, w+16
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    auto issue = [&](int tile) {
+        const uint32_t st = lds0 + (tile % AT6_NS) * AT6_STAGE;
+        const char* kb = kp + (size_t)tile * AT6_KT;
+        const char* vb = vp + (size_t)tile * 128;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int id = wave + 8 * j;
+            if (id < 14) {
+                dma16_s(kb, (uint32_t)(id * 1024 + lane * 16), st + id * 1024);
+            } else {
+                const int v = id - 14, row = 8 * v + (lane >> 3);
+                dma16_s(vb, (uint32_t)(row * n_pad * 2 + (((lane & 7) ^ ((row >> 1) & 7)) * 16)), st + AT6_KT + v * 1024);
+            }
+        }
+    };
+    const int nt = (n_pad + 63) / 64;
+    for (int t0 = 0; t0 < AT6_NS - 1 && t0 < nt; t0++) issue(t0);
+
+    float4v o[2][5];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+        for (int t = 0; t < 5; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[qt][t][r] = 0.0f;
+    float m_run[2] = {-1e30f, -1e30f};
+    const int vsw = (i >> 1) & 7;   // read-side swizzle of the Vt rows this lane reads (rows t*16 + i)
+    for (int tile = 0; tile < nt; tile++) {
+        vm_wait_n(min(AT6_NS - 2, nt - 1 - tile) * 3);
+        __builtin_amdgcn_s_barrier();
+        if (tile + AT6_NS - 1 < nt) issue(tile + AT6_NS - 1);
+        const char* kst = lds + (tile % AT6_NS) * AT6_STAGE;
+        const char* vst = kst + AT6_KT;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int kt = tile * 64 + hh * 32;
+            if (kt >= n_pad) break;
+            const char* kl = kst + hh * 32 * ATT_KROW;
+            float4v s[2][2];
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s[qt][h2][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const bf16x8 kf = as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
+                    s[0][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][h2], 0, 0, 0);
+                    s[1][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][h2], 0, 0, 0);
+                }
+            if (kt + 32 > tokens) {
+#pragma unroll
+                for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (kt + h2 * 16 + 4 * g + r >= tokens) s[qt][h2][r] = -1e30f;
+            }
+            float mnew[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                float mx = max3f(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
+                mx = max3f(mx, s[qt][0][3], s[qt][1][0]);
+                mx = max3f(mx, s[qt][1][1], s[qt][1][2]);
+                mx = max3f(mx, s[qt][1][3], mx);
+                mx = max3f(mx, __shfl_xor(mx, 16), mx);
+                mx = max3f(mx, __shfl_xor(mx, 32), mx);
+                mnew[qt] = max3f(m_run[qt], mx * scale_log2e, m_run[qt]);
+            }
+            if (__any((mnew[0] - m_run[0] > 8.0f) || (mnew[1] - m_run[1] > 8.0f))) {   // see attention_kernel
+#pragma unroll
+                for (int qt = 0; qt < 2; qt++) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew[qt]);
+                    m_run[qt] = mnew[qt];
+#pragma unroll
+                    for (int t = 0; t < 5; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o[qt][t][r] *= alpha;
+                }
+            }
+            bf16x8 pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                float p[8];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p[h2 * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
+                pf[qt] = as_bf8(u32x4{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])});
+            }
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                // Vt row e = 16t + i; keys {4g..+3} and {16+4g..+3} of this half = 8-byte halves of pieces hh*4 + (g>>1), +2
+                const char* vrow = vst + (t * 16 + i) * 128 + (g & 1) * 8;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + (g >> 1)) ^ vsw) * 16));
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + 2 + (g >> 1)) ^ vsw) * 16));
+                const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
+#pragma unroll
+                for (int qt = 0; qt < 2; qt++) o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
+            }
+        }
+    }
+    const int b = bh / heads, hd = bh % heads;
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+        const int tok = q0 + qt * 16 + i;
+        const float lsum = __shfl(o[qt][4][0], 32 + i);   // row dh = 72 of O^T holds sum(p)
         if (tok < tokens) {
             const float inv = 1.0f / lsum;
             uint16_t* op = out + ((size_t)b * tstride + tok) * ldo + hd * dh;
@@ -1611,7 +1787,26 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
     if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
     static const int nw = getenv("MSE_ATT_WAVES") ? atoi(getenv("MSE_ATT_WAVES")) : 8;   // developer knob
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-    if (nw == 8) {
+    static const int abl = getenv("MSE_ATT_ABL") ? atoi(getenv("MSE_ATT_ABL")) : 0;
+    static const bool tile32 = getenv("MSE_ATT_TILE32") != nullptr;   // developer knob: the 32-key-stage kernel
+    if (!tile32 && abl == 0) {
+        const int qblocks = (tokens + 255) / 256;
+        static bool attr_done = false;
+        if (!attr_done) {
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            AT6_NS * AT6_STAGE));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(attention64_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(512), AT6_NS * AT6_STAGE, st, q, k, vt, heads,
+                           tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (abl == 1 || abl == 2) {
+        const int qblocks = (tokens + 255) / 256;
+        if (abl == 1) hipLaunchKernelGGL((attention_kernel<8, 1>), dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        else hipLaunchKernelGGL((attention_kernel<8, 2>), dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+    } else if (nw == 8) {
         const int qblocks = (tokens + 255) / 256;
         hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad,
                            dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
