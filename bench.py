@@ -89,6 +89,20 @@ def siglip_bench(args, world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     eng.close()
+    # text tower (clip_server.py:98): batch of 256 token rows, random-init weights; small next to the image tower
+    import numpy as np
+    tcfg = dict(siglip.SO400M_TEXT)
+    teng = siglip.SiglipTextEngine.from_state_dict(siglip.synthetic_text_state_dict(tcfg), tcfg, max_batch=256)
+    tok = np.random.default_rng(7).integers(2, tcfg["vocab_size"], size=(256, tcfg["context_length"]), dtype=np.int64)
+    teng.encode_text(tok)
+    tt0 = time.perf_counter()
+    for _ in range(5):
+        teng.encode_text(tok)
+    text_dt = (time.perf_counter() - tt0) / 5
+    teng.close()
+    text = {"metric": "SigLIP text-embeds/sec/GPU", "value": 256 / text_dt, "unit": "texts/s/GPU", "ms_per_batch": text_dt * 1e3,
+            "config": {"workload": "SigLIP-SO400M text tower, batch 256 x 64 tokens (host token ids in, host features out)"},
+            "tflops": 256 / text_dt * 27 * 1.968e9 / 1e12}
     per_gpu = batch * args.siglip_steps / dt
     gflop_img = 0.988 + 27 * 24.647 + 3.9                     # 670.4 GFLOP per image
     tflops = per_gpu * gflop_img / 1e3
@@ -96,7 +110,7 @@ def siglip_bench(args, world, rank):
             "ms_per_batch": dt / args.siglip_steps * 1e3, "dtype": "bf16 (fp32 accumulate; fp16 residual stream, fp32 LayerNorm/softmax/GELU)",
             "config": {"workload": f"SigLIP-SO400M/14-384 image tower, batch {batch} random 384x384, 1 replica per GPU",
                        "weights": "random-init (seeded), architecture of ViT-SO400M-14-SigLIP-384"},
-            "steps": args.siglip_steps, "scaling": "weak (replicas)",
+            "steps": args.siglip_steps, "scaling": "weak (replicas)", "text_tower": text,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
                          "flop_per_image": gflop_img * 1e9, "traffic": None}}
 
