@@ -227,10 +227,11 @@ mse_codes* mse_codes_from_host(const uint8_t* codes, size_t n, size_t code_size,
     mse_codes* c = new (std::nothrow) mse_codes();
     if (!c) { fail("out of host memory"); return nullptr; }
     c->n = n; c->code_size = code_size; c->n_desc = descriptors ? n_descriptors : 0;
-    bool ok = hipMalloc((void**)&c->codes, std::max<size_t>(n * code_size, 16)) == hipSuccess;
+    // + 4 KiB / 256 B of slack: the full-scan kernel fetches whole groups of 64 vectors (pq.hip)
+    bool ok = hipMalloc((void**)&c->codes, n * code_size + 4096) == hipSuccess;
     if (ok && n) ok = hipMemcpy(c->codes, codes, n * code_size, hipMemcpyHostToDevice) == hipSuccess;
     if (ok && c->n_desc) {
-        ok = hipMalloc((void**)&c->desc, std::max<size_t>(n * c->n_desc, 16)) == hipSuccess;
+        ok = hipMalloc((void**)&c->desc, n * c->n_desc + 256) == hipSuccess;
         if (ok && n) ok = hipMemcpy(c->desc, descriptors, n * c->n_desc, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { mse_codes_free(c); fail("device allocation/copy failed for PQ codes"); return nullptr; }

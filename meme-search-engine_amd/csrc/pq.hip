@@ -3,6 +3,8 @@
 // evaluator (src/query_disk_index.rs:271-273).
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace mse {
 namespace {
@@ -112,6 +114,92 @@ __global__ __launch_bounds__(256) void pq_adc_kernel(const float* __restrict__ l
     }
 }
 
+// Full ADC scan (64 chunks x 256 centroids, the reference's 64 x 8-bit codec): same arithmetic as pq_adc_kernel
+// -- one lane owns one vector and adds its 64 table entries in chunk order -- but
+//   * 16 waves per workgroup share ONE copy of the 64 KiB table (4 waves per SIMD hide the LDS gather latency);
+//   * codes arrive by LDS-DMA as whole 4 KiB groups of 64 vectors (coalesced 1 KiB requests instead of 64 lanes
+//     x 16 B at a 64-byte stride), each lane then reads its own 64-byte row from the wave's private staging area;
+//     the DMA permutes the four 16-byte pieces of row r by (r >> 3) & 3 so that those ds_read_b128 are conflict free;
+//   * the next group's DMA is issued as soon as the rows are in registers.
+// Bound by the LDS gather rate (64 random 4-byte reads per vector), roughly at par with the HBM rate of the codes.
+constexpr int PQS_WAVES = 16;
+constexpr int PQS_LUT_BYTES = 64 * 256 * 4;
+constexpr int PQS_STAGE = 4096 + 256;   // 64 code rows + 64 x 4 descriptor bytes
+constexpr int PQS_LDS = PQS_LUT_BYTES + PQS_WAVES * PQS_STAGE;
+
+__device__ __forceinline__ void pq_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);   // wave-uniform by construction; pin it to an SGPR
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void pq_dma4(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+}
+
+__global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* __restrict__ lut, const uint8_t* __restrict__ codes,
+                                                                  size_t n, const uint8_t* __restrict__ desc /* [n][4] or null */,
+                                                                  const float* __restrict__ scales, int64_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_lut = reinterpret_cast<float*>(smem);
+    for (int e = threadIdx.x; e < 64 * 256; e += blockDim.x) s_lut[e] = lut[e];
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (desc)
+        for (int j = 0; j < 4; j++) sc[j] = scales[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* stage = smem + PQS_LUT_BYTES + wave * PQS_STAGE;
+    const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
+    // DMA instruction j covers rows 16j .. 16j+15 of the group: lane -> row 16j + lane/4, LDS slot lane & 3 <- piece slot ^ f(row)
+    uint32_t voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = 16 * j + (lane >> 2);
+        voff[j] = (uint32_t)(r * 64 + (((lane & 3) ^ ((r >> 3) & 3)) * 16));
+    }
+    const size_t ngroups = (n + 63) / 64;
+    const size_t stride = (size_t)gridDim.x * PQS_WAVES;
+    size_t grp = (size_t)blockIdx.x * PQS_WAVES + wave;
+    // every VMEM operation of the loop but the result store is an LDS-DMA issued here (descriptor bytes included), so
+    // the waits can be counted by hand: the 4 (+1) DMAs of a group are older than the previous group's store
+    auto issue = [&](size_t gi) {
+        const uint8_t* base = codes + gi * 4096;   // the allocations carry slack for the last, partial group
+#pragma unroll
+        for (int j = 0; j < 4; j++) pq_dma16(base, voff[j], stage_lds + j * 1024);
+        if (desc) pq_dma4(desc + gi * 256, (uint32_t)(lane * 4), stage_lds + 4096);
+    };
+    if (grp < ngroups) issue(grp);
+    const int rsw = (lane >> 3) & 3;
+    bool first = true;
+    for (; grp < ngroups; grp += stride) {
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // the one younger operation is the previous result store
+        first = false;
+        uint4 w4[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) w4[p] = *reinterpret_cast<const uint4*>(stage + lane * 64 + ((p ^ rsw) * 16));
+        const uint32_t dw = desc ? *reinterpret_cast<const uint32_t*>(stage + 4096 + lane * 4) : 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rows are in registers: the staging area may be refilled
+        if (grp + stride < ngroups) issue(grp + stride);
+        const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
+                                w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
+        float s = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 16; a++)
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) s = add_rn(s, s_lut[(a * 4 + bb) * 256 + ((w[a] >> (8 * bb)) & 0xff)]);
+        const size_t v = grp * 64 + lane;
+        if (v < n) {
+            int64_t r = scale_dot_result(s);
+            if (desc) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) r += scale_dot_result(sc[j] * (float)((dw >> (8 * j)) & 0xffu));
+            }
+            out[v] = r;
+        }
+    }
+}
+
 // out[p] += descriptor_product(scales, ids[p])   (exact re-score path, query_disk_index.rs:169-170)
 __global__ void add_descriptor_kernel(const uint32_t* __restrict__ ids, size_t n, const uint8_t* __restrict__ desc,
                                       int n_desc, size_t n_codes, const float* __restrict__ scales,
@@ -189,6 +277,22 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
                   const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, const float* scales, int64_t* out,
                   int n_cu, hipStream_t stream) {
     if (n == 0) return 0;
+    const bool desc_ok = !(desc && scales) || n_desc == 4;
+    static const bool old_scan = getenv("MSE_PQ_OLDSCAN") != nullptr;   // developer knob
+    if (!ids && n_chunks == 64 && n_centroids == 256 && desc_ok && n == n_codes && !old_scan) {
+        static bool attr = false;
+        if (!attr) {
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_scan64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            PQS_LDS));
+            attr = true;
+        }
+        const size_t groups = (n + 63) / 64;
+        const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, (size_t)n_cu);
+        hipLaunchKernelGGL(pq_scan64_kernel, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
+                           (desc && scales) ? desc : nullptr, scales, out);
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const size_t lds = (size_t)n_chunks * n_centroids * 4;
     if (lds > 160 * 1024) return fail("PQ table does not fit LDS");
     if (lds > 64 * 1024) {

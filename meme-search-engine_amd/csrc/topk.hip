@@ -113,6 +113,7 @@ __device__ __forceinline__ bool match_above(const Composite& c, const Composite&
 }
 
 constexpr int SEL_THREADS = 1024;
+constexpr int SEL_LIST_CAP = 4096;
 
 template <typename T>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_t in_estride) {
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
     __shared__ uint32_t s_sel_lo[TOPK_KMAX];
     __shared__ uint64_t s_prefix_hi;
     __shared__ uint32_t s_prefix_lo;
-    __shared__ uint32_t s_need, s_count, s_valid;
+    __shared__ uint32_t s_need, s_count, s_valid, s_flag, s_list_n;
+    __shared__ uint32_t s_list[SEL_LIST_CAP];
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -167,31 +169,37 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
         return true;
     };
 
-    // count valid candidates
-    {
-        uint32_t local = 0;
+    // MSB-first radix select on the composite.  The first pass also counts the valid candidates.  As soon as the
+    // chosen bucket holds at most SEL_LIST_CAP candidates their positions are gathered into an LDS list and the
+    // remaining passes walk that list instead of all M candidates; a pass whose bucket holds exactly the number still
+    // needed ends the search (the lower digits of the threshold stay zero).  Both shortcuts are functions of the
+    // multiset of composites only, so the result is as deterministic as before.
+    bool list_mode = false;
+    for (int pos = 11; pos >= 0; pos--) {
+        if (K32 && pos >= 4 && pos < 8) continue;  // low half of `hi` is zero for 32-bit keys
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const Composite prefix{s_prefix_hi, s_prefix_lo};
         Composite c;
-        for (size_t i = tid; i < M; i += SEL_THREADS) local += load(i, c) ? 1u : 0u;
-        if (local) atomicAdd(&s_valid, local);
-    }
-    __syncthreads();
-    const uint32_t n_valid = s_valid;
-    const uint32_t k_eff = n_valid < (uint32_t)a.k ? n_valid : (uint32_t)a.k;
-    const bool take_all = n_valid <= (uint32_t)a.k;
-    if (tid == 0) s_need = k_eff;
-    __syncthreads();
-
-    if (!take_all) {
-        for (int pos = 11; pos >= 0; pos--) {
-            if (K32 && pos >= 4 && pos < 8) continue;  // low half of `hi` is zero for 32-bit keys
-            if (tid < 256) s_hist[tid] = 0;
-            __syncthreads();
-            const Composite prefix{s_prefix_hi, s_prefix_lo};
-            Composite c;
+        if (list_mode) {
+            const uint32_t ln = s_list_n;
+            for (uint32_t j = tid; j < ln; j += SEL_THREADS)
+                if (load(s_list[j], c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
+        } else {
             for (size_t i = tid; i < M; i += SEL_THREADS)
                 if (load(i, c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
-            __syncthreads();
-            if (tid == 0) {
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_flag = 0;
+            if (pos == 11) {
+                uint32_t total = 0;
+                for (int b = 0; b < 256; b++) total += s_hist[b];
+                s_valid = total;
+                s_need = total < (uint32_t)a.k ? total : (uint32_t)a.k;
+                if (total <= (uint32_t)a.k) s_flag = 2;   // take everything
+            }
+            if (s_flag == 0) {
                 uint32_t need = s_need, cum = 0;
                 int b = 255;
                 for (; b > 0; b--) {
@@ -201,10 +209,28 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
                 s_need = need - cum;
                 if (pos >= 4) s_prefix_hi |= (uint64_t)b << (8 * (pos - 4));
                 else s_prefix_lo |= (uint32_t)b << (8 * pos);
+                if (s_hist[b] == need - cum) s_flag = 1;                                   // bucket taken whole: done
+                else if (!list_mode && pos > 0 && s_hist[b] <= (uint32_t)SEL_LIST_CAP) s_flag = 3;   // gather the bucket
             }
+        }
+        __syncthreads();
+        const uint32_t flag = s_flag;
+        if (flag == 1 || flag == 2) break;
+        if (flag == 3) {
+            if (tid == 0) s_list_n = 0;
             __syncthreads();
+            const Composite np{s_prefix_hi, s_prefix_lo};
+            for (size_t i = tid; i < M; i += SEL_THREADS)
+                if (load(i, c) && match_above(c, np, pos - 1)) {
+                    const uint32_t slot = atomicAdd(&s_list_n, 1u);
+                    if (slot < (uint32_t)SEL_LIST_CAP) s_list[slot] = (uint32_t)i;
+                }
+            __syncthreads();
+            list_mode = true;
         }
     }
+    __syncthreads();
+    const bool take_all = s_valid <= (uint32_t)a.k;
     const Composite thr{take_all ? 0ull : s_prefix_hi, take_all ? 0u : s_prefix_lo};
     {
         Composite c;
