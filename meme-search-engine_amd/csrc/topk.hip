@@ -126,6 +126,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
     __shared__ uint64_t s_prefix_hi;
     __shared__ uint32_t s_prefix_lo;
     __shared__ uint32_t s_need, s_count, s_valid, s_flag, s_list_n;
+    __shared__ unsigned long long s_or_hi, s_and_hi;   // OR / AND of all valid score keys: digits on which they agree need no pass
+    __shared__ int s_next_pos;
     __shared__ uint32_t s_list[SEL_LIST_CAP];
 
     const int q = blockIdx.x;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
 
     if (use_par)
         for (size_t i = tid; i < a.n_par; i += SEL_THREADS) s_parents[i] = a.parents[(size_t)q * a.par_stride + i];
-    if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_count = 0; s_valid = 0; }
+    if (tid == 0) { s_prefix_hi = 0; s_prefix_lo = 0; s_count = 0; s_valid = 0; s_or_hi = 0ull; s_and_hi = ~0ull; }
     __syncthreads();
 
     auto load = [&](size_t c, Composite& out) -> bool {
@@ -185,6 +187,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
             const uint32_t ln = s_list_n;
             for (uint32_t j = tid; j < ln; j += SEL_THREADS)
                 if (load(s_list[j], c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
+        } else if (pos == 11) {
+            unsigned long long o = 0ull, n = ~0ull;
+            for (size_t i = tid; i < M; i += SEL_THREADS)
+                if (load(i, c)) { atomicAdd(&s_hist[digit_of(c, pos)], 1u); o |= c.hi; n &= c.hi; }
+            if (o | ~n) { atomicOr(&s_or_hi, o); atomicAnd(&s_and_hi, n); }
         } else {
             for (size_t i = tid; i < M; i += SEL_THREADS)
                 if (load(i, c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
         __syncthreads();
         if (tid == 0) {
             s_flag = 0;
+            s_next_pos = pos - 1;
             if (pos == 11) {
                 uint32_t total = 0;
                 for (int b = 0; b < 256; b++) total += s_hist[b];
@@ -209,12 +217,24 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
                 s_need = need - cum;
                 if (pos >= 4) s_prefix_hi |= (uint64_t)b << (8 * (pos - 4));
                 else s_prefix_lo |= (uint32_t)b << (8 * pos);
+                if (pos == 11) {
+                    // score digits on which every valid candidate agrees (i64 scores below 2^33 share their top bytes)
+                    // are copied into the threshold without a pass
+                    const unsigned long long diff = s_or_hi ^ s_and_hi;
+                    int np = 10;
+                    while (np >= 4 && ((diff >> (8 * (np - 4))) & 0xffull) == 0ull) {
+                        s_prefix_hi |= ((s_or_hi >> (8 * (np - 4))) & 0xffull) << (8 * (np - 4));
+                        np--;
+                    }
+                    s_next_pos = np;
+                }
                 if (s_hist[b] == need - cum) s_flag = 1;                                   // bucket taken whole: done
                 else if (!list_mode && pos > 0 && s_hist[b] <= (uint32_t)SEL_LIST_CAP) s_flag = 3;   // gather the bucket
             }
         }
         __syncthreads();
         const uint32_t flag = s_flag;
+        const int next_pos = s_next_pos;
         if (flag == 1 || flag == 2) break;
         if (flag == 3) {
             if (tid == 0) s_list_n = 0;
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
             __syncthreads();
             list_mode = true;
         }
+        pos = next_pos + 1;   // the loop's pos-- lands on next_pos
     }
     __syncthreads();
     const bool take_all = s_valid <= (uint32_t)a.k;
