@@ -62,6 +62,29 @@ def cpu_baseline(n_rows, k):
     }
 
 
+def pq_bench(args):
+    """BASELINE configs[4] shape: full ADC scan of 64-byte OPQ codes (+4 descriptor bytes) for ONE query, top-200 by
+    approximate score (the re-rank candidates), all arrays resident in HBM.  Reported end to end per query (table build,
+    scan, exact top-r selection); the scan kernel alone streams the codes at the rate in profiles/r01_pq_scan_stats.txt."""
+    import numpy as np
+    n = int(args.pq_rows)
+    rng = np.random.default_rng(0)
+    cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+    T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    gc = mse.Codes(rng.integers(0, 256, size=(n, 64), dtype=np.uint8), rng.integers(0, 256, size=(n, 4), dtype=np.uint8))
+    scales = np.array([0.5, 0, -0.25, 0], np.float32) / np.float32(512)
+    q = (rng.standard_normal(D) / np.sqrt(D)).astype(np.float32)
+    pq.scan_topk(gc, q, 200, 10, None, scales)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        pq.scan_topk(gc, q, 200, 10, None, scales)
+    dt = (time.perf_counter() - t0) / 10
+    return {"metric": "OPQ/PQ 64x8-bit ADC scan + top-200, one query", "ms_per_query": dt * 1e3, "vectors": n,
+            "codes_GBps_end_to_end": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
+            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), table 64 x 256 f32 in LDS, r = 200"}}
+
+
 def siglip_bench(args, world, rank):
     """BASELINE configs[1]: SigLIP-SO400M/14-384 image tower, batch 256 random 384x384 images, bf16, one
     replica per GPU.  Random-init weights of the named architecture (no checkpoint offline); images already
@@ -125,6 +148,8 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-siglip", action="store_true", help="skip the SigLIP image-tower leg")
+    ap.add_argument("--no-pq", action="store_true", help="skip the OPQ/PQ scan leg")
+    ap.add_argument("--pq-rows", type=float, default=2e7)
     ap.add_argument("--siglip-batch", type=int, default=256)
     ap.add_argument("--siglip-steps", type=int, default=3)
     args = ap.parse_args()
@@ -225,6 +250,9 @@ def main():
     siglip_line = None
     if not args.no_siglip:
         siglip_line = siglip_bench(args, world, rank)
+    pq_line = None
+    if rank == 0 and world == 1 and not args.no_pq:
+        pq_line = pq_bench(args)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -268,6 +296,8 @@ def main():
         }
         if siglip_line:
             line["siglip"] = siglip_line
+        if pq_line:
+            line["pq_scan"] = pq_line
         if note:
             line["note"] = note
         if world == 1 and not args.no_cpu_baseline:
