@@ -67,6 +67,7 @@ def pq_bench(args):
     approximate score (the re-rank candidates), all arrays resident in HBM.  Reported end to end per query (table build,
     scan, exact top-r selection); the scan kernel alone streams the codes at the rate in profiles/r01_pq_scan_stats.txt."""
     import numpy as np
+    import mse
     n = int(args.pq_rows)
     rng = np.random.default_rng(0)
     cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
