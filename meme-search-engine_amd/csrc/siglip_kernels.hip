@@ -746,16 +746,25 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PP_STAGE = 4096;
 constexpr int PP_STORES = 16;
-constexpr int LDSPP_BYTES = 2 * P8_BUF + 8 * PP_STAGE;   // 160 KiB
+constexpr int LDSPP_BYTES = 2 * P8_BUF + 8 * PP_STAGE;   // 160 KiB (NT = 2); the 128-column variant needs 2 * 48 KiB + 32 KiB
 
-template <int EPI, bool VSWAP, int ABL = 0>   // ABL (developer): 1 = no global stores, 2 = no epilogue at all
+// NT = 16-column fragments per n-quadrant of a wave: 2 -> 256-column tiles (wave tile 128 x 64); 1 -> 128-column tiles
+// (wave tile 128 x 32, C units of 64 rows) for the last 128 columns of N = 1152 / 3456, which the 256 x 128 kernel of
+// the first generation handled at half the efficiency.
+template <int EPI, bool VSWAP, int ABL = 0, int NT = 2>   // ABL (developer): 1 = no global stores, 2 = no epilogue at all
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int wr = wave >> 2, wc = wave & 3;
-    const int n_blocks = a.N / 256, m_blocks = a.M / 256;
+    constexpr int BNW = 128 * NT;                  // tile width in columns
+    constexpr int CU_BYTES = 8192 * NT;            // one C unit: 4 waves x 16 NT rows x 128 B
+    constexpr int OFF_CQ0 = P8_UNIT, OFF_CQ1 = P8_UNIT + CU_BYTES, OFF_RQ1 = P8_UNIT + 2 * CU_BYTES;
+    constexpr int BUF = 2 * P8_UNIT + 2 * CU_BYTES;   // one K tile: [Rq0 | Cq0 | Cq1 | Rq1]
+    constexpr int NWAIT = 4 + 2 * NT;              // DMAs of the four younger units (2 per R unit, NT per C unit)
+    constexpr int NSTORES = 8 * NT;                // global stores per wave and tile
+    const int n_blocks = a.N / BNW, m_blocks = a.M / 256;
     const int ntiles = n_blocks * m_blocks;
     const int G = (int)gridDim.x;
     const uint32_t kbytes = (uint32_t)a.K * 2;
@@ -769,31 +778,42 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         const int band = b / (8 * n_blocks), r = b - band * 8 * n_blocks;
         const int rows = min(8, m_blocks - band * 8);
         m0 = (size_t)(band * 8 + r % rows) * 256;
-        n0 = (size_t)(r / rows) * 256;
+        n0 = (size_t)(r / rows) * BNW;
     };
     // DMA source offsets of this lane inside a tile (row offset + swizzled 16-byte piece); the tile bases are wave-uniform
-    uint32_t roff[2], coff[2];
+    uint32_t roff[2], coff[NT];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int u = wave * 16 + j * 8 + (lane >> 3);
         const int piece = (lane & 7) ^ ((u >> 1) & 7);
         roff[j] = (uint32_t)((u >> 6) * 128 + (u & 63)) * kbytes + piece * 16;
-        coff[j] = (uint32_t)((u >> 5) * 64 + (u & 31)) * kbytes + piece * 16;
     }
-    const uint32_t rq1 = 64 * kbytes, cq1 = 32 * kbytes;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {   // C unit row u: n-quarter u / (16 NT), row u % (16 NT) of its quadrant
+        const int u = wave * 8 * NT + j * 8 + (lane >> 3);
+        const int piece = (lane & 7) ^ ((u >> 1) & 7);
+        coff[j] = (uint32_t)((u / (16 * NT)) * 32 * NT + (u % (16 * NT))) * kbytes + piece * 16;
+    }
+    const uint32_t rq1 = 64 * kbytes, cq1 = 16 * NT * kbytes;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int unit, int kt, int ring, const char* xb, const char* wb) {
-        const uint32_t dst = lds0 + (ring & 1) * P8_BUF + unit * P8_UNIT + wave * 2048;
         const bool is_r = unit == U_RQ0 || unit == U_RQ1;
+        const uint32_t uoff = unit == U_RQ0 ? 0u : (unit == U_CQ0 ? (uint32_t)OFF_CQ0 : (unit == U_CQ1 ? (uint32_t)OFF_CQ1 : (uint32_t)OFF_RQ1));
+        const uint32_t dst = lds0 + (ring & 1) * BUF + uoff + wave * (is_r ? 2048 : 1024 * NT);
         const uint32_t qoff = (unit == U_RQ1 ? rq1 : (unit == U_CQ1 ? cq1 : 0u)) + (uint32_t)kt * 128u;
         const char* sb = (is_r ? xb : wb) + qoff;   // wave-uniform
+        if (is_r) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) dma16_s(sb, is_r ? roff[j] : coff[j], dst + j * 1024);
+            for (int j = 0; j < 2; j++) dma16_s(sb, roff[j], dst + j * 1024);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; j++) dma16_s(sb, coff[j], dst + j * 1024);
+        }
     };
     const int foff0 = i * 128 + ((g ^ (i >> 1)) & 7) * 16;
     const int foff1 = i * 128 + (((4 + g) ^ (i >> 1)) & 7) * 16;
-    const int r_off = wr * 64 * 128, c_off = wc * 32 * 128;
-    char* const et = smem + 2 * P8_BUF + wave * PP_STAGE;
+    const int r_off = wr * 64 * 128, c_off = wc * 16 * NT * 128;
+    char* const et = smem + 2 * BUF + wave * PP_STAGE;
 
     int v = blockIdx.x;
     if (v >= ntiles) return;
@@ -815,11 +835,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     // prologue of the first tile only
     issue(U_RQ0, 0, 0, xb, wb); issue(U_CQ0, 0, 0, xb, wb); issue(U_CQ1, 0, 0, xb, wb); issue(U_RQ1, 0, 0, xb, wb);
     issue(U_RQ0, 1, 1, xb, wb); issue(U_CQ0, 1, 1, xb, wb);
-    vm_wait<8>();
+    vm_wait<NWAIT>();
     __builtin_amdgcn_s_barrier();
 
-    float4v acc[4][8];
-    bf16x8 rf[4][2], cf0[2][2], cf1[2][2];
+    float4v acc[2 * NT][8];
+    bf16x8 rf[4][2], cf0[NT][2], cf1[NT][2];
     auto read_r = [&](const char* unit_base) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -827,9 +847,9 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             rf[t][1] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + r_off + t * 2048 + foff1));
         }
     };
-    auto read_c = [&](const char* unit_base, bf16x8 (&cf)[2][2]) {
+    auto read_c = [&](const char* unit_base, bf16x8 (&cf)[NT][2]) {
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < NT; t++) {
             cf[t][0] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + c_off + t * 2048 + foff0));
             cf[t][1] = as_bf8(*reinterpret_cast<const u32x4*>(unit_base + c_off + t * 2048 + foff1));
         }
@@ -841,7 +861,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                            \
-            _Pragma("unroll") for (int ct = 0; ct < 2; ct++)                                                        \
+            _Pragma("unroll") for (int ct = 0; ct < NT; ct++)                                                       \
                 _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                  \
                     if constexpr (VSWAP)                                                                            \
                         acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[rt][ks], CF[ct][ks],  \
@@ -864,8 +884,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         else issued = false;                                                                                        \
         if (DO_WAIT) {                                                                                              \
             if (!issued) vm_wait<0>();                                                                              \
-            else if (after_epilogue) vm_wait<8 + PP_STORES>();                                                      \
-            else vm_wait<8>();                                                                                      \
+            else if (after_epilogue) vm_wait<NWAIT + NSTORES>();                                                    \
+            else vm_wait<NWAIT>();                                                                                  \
         }                                                                                                           \
     } while (0)
 
@@ -874,9 +894,9 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         // accumulators start at the bias: the loads sit at the tile start, where the wave is about to wait for the
         // K tile 0 units anyway, and the epilogue needs no global load at all
         {
-            const int wn0b = (int)n0 + wc * 64;
+            const int wn0b = (int)n0 + wc * 32 * NT;
 #pragma unroll
-            for (int ct = 0; ct < 4; ct++) {
+            for (int ct = 0; ct < 2 * NT; ct++) {
                 float4v b4;
                 if constexpr (VSWAP) {
                     const float bs = a.bias[wn0b + ct * 16 + i];
@@ -894,21 +914,21 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         if (wr == 1) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; t++, ring++) {
             const bool after_epilogue = iter > 0 && (t == 0 || (ABL == 3 && t <= 2));   // ABL 3: timing experiment only (racy)
-            const char* buf = smem + (ring & 1) * P8_BUF;
+            const char* buf = smem + (ring & 1) * BUF;
             // phase 0
-            read_c(buf + U_CQ0 * P8_UNIT, cf0);
+            read_c(buf + OFF_CQ0, cf0);
             __builtin_amdgcn_sched_barrier(0);
-            read_r(buf + U_RQ0 * P8_UNIT);
+            read_r(buf);
             PP_STAGE_UNIT(U_CQ1, 1, true);
             PP_MFMA(cf0, 0, 0);
             // phase 1
-            read_c(buf + U_CQ1 * P8_UNIT, cf1);
+            read_c(buf + OFF_CQ1, cf1);
             PP_STAGE_UNIT(U_RQ1, 1, true);
-            PP_MFMA(cf1, 2, 0);
+            PP_MFMA(cf1, NT, 0);
             // phase 2
-            read_r(buf + U_RQ1 * P8_UNIT);
+            read_r(buf + OFF_RQ1);
             PP_STAGE_UNIT(U_RQ0, 2, false);
-            PP_MFMA(cf1, 2, 4);
+            PP_MFMA(cf1, NT, 4);
             // phase 3
             PP_STAGE_UNIT(U_CQ0, 2, true);
             PP_MFMA(cf0, 0, 4);
@@ -917,18 +937,19 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         if (wr == 0) __builtin_amdgcn_s_barrier();
         // ---- epilogue: exactly PP_STORES global stores per wave, all unconditional --------------------------------
         const size_t wm0 = m0 + (size_t)wr * 128;
-        const int wn0 = (int)n0 + wc * 64;
+        const int wn0 = (int)n0 + wc * 32 * NT;
         if constexpr (ABL == 2) {
             float sacc = 0.0f;
 #pragma unroll
             for (int rt = 0; rt < 8; rt++)
 #pragma unroll
-                for (int ct = 0; ct < 4; ct++) sacc += acc[ct][rt][0] + acc[ct][rt][1] + acc[ct][rt][2] + acc[ct][rt][3];
+                for (int ct = 0; ct < 2 * NT; ct++) sacc += acc[ct][rt][0] + acc[ct][rt][1] + acc[ct][rt][2] + acc[ct][rt][3];
             if (sacc == 12345.678f) a.out_bf16[0] = 1;
         } else if constexpr (!VSWAP) {
-            // staging rounds of 32 rows x 64 columns bf16 (128-byte rows, 16-byte pieces XOR-swizzled by row & 7)
+            // staging rounds of 32 rows x 32 NT columns bf16 (64 NT-byte rows, 16-byte pieces XOR-swizzled by the row)
+            constexpr int CH = 4 * NT, RB = 16 * CH, RPI = 64 / CH;   // pieces per row, row bytes, rows per read instruction
             const GeluC gc = gelu_coef(a.gelu_tanh);
-            const int rsub = lane >> 3, chunk = lane & 7;
+            const int rsub = lane / CH, chunk = lane % CH;
             // QKV scatter geometry (8-column pieces stay inside one head: 8 | dh)
             int which = 0, head = 0, e = 0, bi0 = 0, tok0 = 0;
             if constexpr (EPI == EPI_QKV) {
@@ -946,17 +967,17 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ct++) {
+                    for (int ct = 0; ct < 2 * NT; ct++) {
                         const float4v& c = acc[ct][rd * 2 + rr];
                         float2v lo = {c[0], c[1]}, hi = {c[2], c[3]};
                         if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc); hi = gelu2(hi, gc); }
-                        const int row = rr * 16 + i, pc = (ct * 2 + (g >> 1)) ^ (row & 7);
-                        *reinterpret_cast<uint2*>(et + row * 128 + pc * 16 + (g & 1) * 8) = uint2{pack2(lo), pack2(hi)};
+                        const int row = rr * 16 + i, pc = (ct * 2 + (g >> 1)) ^ (row & (CH - 1));
+                        *reinterpret_cast<uint2*>(et + row * RB + pc * 16 + (g & 1) * 8) = uint2{pack2(lo), pack2(hi)};
                     }
 #pragma unroll
-                for (int it = 0; it < 4; it++) {
-                    const int row = it * 8 + rsub;
-                    const u32x4 val = *reinterpret_cast<const u32x4*>(et + row * 128 + ((chunk ^ (row & 7)) * 16));
+                for (int it = 0; it < 32 / RPI; it++) {
+                    const int row = it * RPI + rsub;
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(et + row * RB + ((chunk ^ (row & (CH - 1))) * 16));
                     const int mrow = rd * 32 + row;
                     if constexpr (EPI == EPI_QKV) {
                         int tok = tok0 + mrow, bi = bi0;
@@ -981,7 +1002,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             if (tok >= a.tokens) { tok -= a.tokens; bi++; }
             if (tok >= a.tokens) { tok -= a.tokens; bi++; }
 #pragma unroll
-            for (int ct = 0; ct < 4; ct++) {
+            for (int ct = 0; ct < 2 * NT; ct++) {
 #pragma unroll
                 for (int rt = 0; rt < 8; rt++) {
                     const float4v& c = acc[ct][rt];
@@ -1320,6 +1341,7 @@ constexpr int AT6_VT = 80 * 128;               // 10240
 constexpr int AT6_STAGE = AT6_KT + AT6_VT;     // 24 KiB
 constexpr int AT6_NS = 3;
 
+template <int ABL>   // 0 shipped; timing ablations: 1 no softmax arithmetic, 2 no MFMA, 3 no K/V fragment reads
 __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                           int dh, int dh_pad, int dv_pad, float scale_log2e,
@@ -1393,7 +1415,8 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
             for (int ks = 0; ks < 3; ks++)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
-                    const bf16x8 kf = as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
+                    const bf16x8 kf = ABL == 3 ? qf[0][ks] : as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
+                    if (ABL == 2) { s[0][h2][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kf[0]) << 16); continue; }
                     s[0][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][h2], 0, 0, 0);
                     s[1][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][h2], 0, 0, 0);
                 }
@@ -1409,6 +1432,7 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
             float mnew[2];
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
+                if (ABL == 1) { mnew[qt] = m_run[qt]; continue; }
                 float mx = max3f(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
                 mx = max3f(mx, s[qt][0][3], s[qt][1][0]);
                 mx = max3f(mx, s[qt][1][1], s[qt][1][2]);
@@ -1435,7 +1459,8 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) p[h2 * 4 + r] = __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
+                    for (int r = 0; r < 4; r++)
+                        p[h2 * 4 + r] = ABL == 1 ? s[qt][h2][r] : __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
                 pf[qt] = as_bf8(u32x4{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])});
             }
 #pragma unroll
@@ -1444,9 +1469,12 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
                 const char* vrow = vst + (t * 16 + i) * 128 + (g & 1) * 8;
                 const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + (g >> 1)) ^ vsw) * 16));
                 const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + 2 + (g >> 1)) ^ vsw) * 16));
-                const bf16x8 vf = as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
+                const bf16x8 vf = ABL == 3 ? pf[0] : as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++) o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
+                for (int qt = 0; qt < 2; qt++) {
+                    if (ABL == 2) { o[qt][t][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vf[0]) << 16) + __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, pf[qt][0]) << 16); continue; }
+                    o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
+                }
             }
         }
     }
@@ -1672,8 +1700,33 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         a.n_off = n256;
         a.w = a_in.w + (size_t)n256 * a_in.K;
         a.bias = a_in.bias + n256;
-        const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
-        hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), GS * STAGE_BYTES, st, a);
+        static const bool narrow_off = getenv("MSE_GEMM_NONARROW") != nullptr || getenv("MSE_GEMM_NOPERSIST") != nullptr ||
+                                       getenv("MSE_GEMM_128") != nullptr || getenv("MSE_GEMM_OLD256") != nullptr;
+        bool done = false;
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV) {
+            // 128-column form of the persistent ping-pong kernel (for QKV the remainder lies in the V columns)
+            const bool v_range = EPI == EPI_QKV && n256 >= 2 * a.heads * a.dh;
+            const bool qkv_ok = EPI != EPI_QKV || (v_range && a.tokens % 8 == 0 && a.tokens >= 64 && a.n_pad % 8 == 0 && a.dh % 8 == 0 &&
+                                                   a.dh >= 64 && a.m_valid % 8 == 0);
+            if (!narrow_off && a.N == 128 && a.K >= 256 && qkv_ok) {
+                constexpr bool VS = EPI == EPI_QKV;
+                constexpr int lds = 2 * (2 * P8_UNIT + 2 * 8192) + 8 * PP_STAGE;
+                static bool nattr = false;
+                if (!nattr) {
+                    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI, VS, 0, 1>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                    nattr = true;
+                }
+                a.stagger = 0;
+                const unsigned tiles = (unsigned)(a.M / 256);
+                hipLaunchKernelGGL((gemm8pp_kernel<EPI, VS, 0, 1>), dim3(std::min(tiles, (unsigned)mse::device_cu_count())), dim3(512), lds, st, a);
+                done = true;
+            }
+        }
+        if (!done) {
+            const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+            hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), GS * STAGE_BYTES, st, a);
+        }
         MSE_HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -1791,14 +1844,16 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
     static const bool tile32 = getenv("MSE_ATT_TILE32") != nullptr;   // developer knob: the 32-key-stage kernel
     if (!tile32 && abl == 0) {
         const int qblocks = (tokens + 255) / 256;
-        static bool attr_done = false;
-        if (!attr_done) {
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            AT6_NS * AT6_STAGE));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(attention64_kernel, dim3((unsigned)(B * heads * qblocks)), dim3(512), AT6_NS * AT6_STAGE, st, q, k, vt, heads,
-                           tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        static const int abl64 = getenv("MSE_ATT64_ABL") ? atoi(getenv("MSE_ATT64_ABL")) : 0;   // developer timing ablations
+#define MSE_ATT64(X)                                                                                                        \
+    {                                                                                                                       \
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<X>),                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));                   \
+        hipLaunchKernelGGL(attention64_kernel<X>, dim3((unsigned)(B * heads * qblocks)), dim3(512), AT6_NS * AT6_STAGE, st, \
+                           q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);             \
+    }
+        if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else MSE_ATT64(0)
+#undef MSE_ATT64
         MSE_HIP_TRY(hipGetLastError());
         return 0;
     }
