@@ -186,6 +186,20 @@ int mse_select_shard(const float* centroids, size_t n_shards, size_t d, const fl
  * mean of all rows; last maximum on ties. */
 int mse_medioid(const mse_base* b, uint32_t* id_out);
 
+/* ---- Index packing (dump_processor; quantize_batch is mse_pq_quantize_batch above) ----
+ * ScoreModel::score_batch (src/score_model.rs:13-32): out[b] = down_proj . silu(up_proj . x_b + bias) * d_emb / d_hidden.
+ * up_proj [d_hidden][d_emb], bias [d_hidden], down_proj [out_channels][d_hidden], row-major f32 (the safetensors layout). */
+typedef struct mse_score_model mse_score_model;
+mse_score_model* mse_score_model_load(const float* up_proj, const float* bias, const float* down_proj, size_t d_emb,
+                                      size_t d_hidden, size_t out_channels);
+void mse_score_model_free(mse_score_model* m);
+size_t mse_score_model_output_channels(const mse_score_model* m);
+int mse_score_model_score_batch(mse_score_model* m, const float* input, size_t batch, float* out /* [batch][out_channels] */);
+/* Descriptor bytes (src/dump_processor.rs:483-491): out[i][j] = position of scores[i][j] in the ascending cdfs[j]
+ * as `binary_search_by(|x| x.partial_cmp(score))` reports it (Ok(p) or Err(p) -> p), one byte; cdf_len <= 255
+ * (meme-rater/compute_cdf.py: 255 quantiles, 255 = above the last). */
+int mse_descriptor_buckets(const float* cdfs, size_t n_desc, size_t cdf_len, const float* scores, size_t n, uint8_t* out);
+
 /* ---- SigLIP ViT image tower: the in-process seam of clip_server.py, `fast_image_fns[batch](images NCHW
  * fp16 on device) -> [batch, 1152]` (clip_server.py:31,66-82,105-112), plus the normalisation and fp16
  * serialisation of do_inference / run_inference (clip_server.py:115,166).  Graph: aitemplate/model.py:13-123;

@@ -84,6 +84,11 @@ SIGNATURES = {
     "mse_dedup_visited": (C.c_int, [vp, u32p, sz, C.c_float, u8p]),
     "mse_select_shard": (C.c_int, [f32p, sz, sz, f32p, C.POINTER(sz)]),
     "mse_medioid": (C.c_int, [vp, u32p]),
+    "mse_score_model_load": (vp, [f32p, f32p, f32p, sz, sz, sz]),
+    "mse_score_model_free": (None, [vp]),
+    "mse_score_model_output_channels": (sz, [vp]),
+    "mse_score_model_score_batch": (C.c_int, [vp, f32p, sz, f32p]),
+    "mse_descriptor_buckets": (C.c_int, [f32p, sz, sz, f32p, sz, u8p]),
     "mse_siglip_create": (vp, [vp]),
     "mse_siglip_destroy": (None, [vp]),
     "mse_siglip_n_weights": (C.c_int, [vp]),

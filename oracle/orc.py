@@ -73,6 +73,8 @@ def lib():
             "orc_disk_greedy_search": (sz, [u16p, sz, sz, u32p, u32p, sz, u8p, u8p, sz, sz, u8p, sz, C.c_uint32, u16p, f32p,
                                             f32p, C.c_int, sz, C.c_void_p, u32p, i64p, sz, C.POINTER(sz), C.POINTER(sz)]),
             "orc_dedup_keep": (None, [u16p, sz, sz, C.c_float, u8p]),
+            "orc_score_batch": (None, [f32p, f32p, f32p, sz, sz, sz, f32p, sz, f32p]),
+            "orc_descriptor_bucket": (C.c_uint8, [f32p, sz, C.c_float]),
             "orc_centroid_f16": (None, [u16p, sz, sz, u16p]),
             "orc_medioid": (C.c_uint32, [u16p, sz, sz]),
             "orc_index_ip": (C.c_float, [u16p, f32p, sz, C.c_int]),
@@ -329,6 +331,24 @@ def dedup_keep(vecs, threshold=0.95):
     keep = np.zeros(vecs.shape[0], np.uint8)
     lib().orc_dedup_keep(_p(vecs, C.c_uint16), vecs.shape[0], vecs.shape[1], threshold, _p(keep, C.c_uint8))
     return keep
+
+
+def score_batch(up, bias, down, x):
+    up, bias, down = _c(up, np.float32), _c(bias, np.float32), _c(down, np.float32)
+    x = _c(x, np.float32).reshape(-1, up.shape[1])
+    out = np.empty((x.shape[0], down.shape[0]), np.float32)
+    lib().orc_score_batch(_p(up, C.c_float), _p(bias, C.c_float), _p(down, C.c_float), up.shape[1], up.shape[0], down.shape[0],
+                          _p(x, C.c_float), x.shape[0], _p(out, C.c_float))
+    return out
+
+
+def descriptor_buckets(cdfs, scores):
+    cdfs, scores = _c(cdfs, np.float32), _c(scores, np.float32)
+    out = np.empty(scores.shape, np.uint8)
+    for i in range(scores.shape[0]):
+        for j in range(scores.shape[1]):
+            out[i, j] = lib().orc_descriptor_bucket(_p(cdfs[j], C.c_float), cdfs.shape[1], float(scores[i, j]))
+    return out
 
 
 def centroid_f16(vecs):

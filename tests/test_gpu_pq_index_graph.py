@@ -272,3 +272,24 @@ def test_dedup_visited_matches_oracle(gpu, mse, orc):
     assert mse.dedup_visited(searcher, np.empty(0, np.uint32)).size == 0
     with pytest.raises(mse.MseError):
         mse.dedup_visited(searcher, np.array([n], np.uint32))
+
+
+def test_index_packing_pieces(gpu, mse, orc):
+    """score_model.rs:13-32 and dump_processor.rs:483-491 on the device against the oracle."""
+    rng = np.random.default_rng(14)
+    d, hdim, oc = D, 128, 3
+    up = (rng.standard_normal((hdim, d)) / np.sqrt(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(hdim)).astype(np.float32)
+    down = (rng.standard_normal((oc, hdim)) / np.sqrt(hdim)).astype(np.float32)
+    x = clustered_rows(orc, 300)
+    sm = mse.ScoreModel(up, b, down)
+    got = sm.score_batch(x)
+    want = orc.score_batch(up, b, down, x)
+    assert got.shape == (300, oc) and np.allclose(got, want, rtol=1e-5, atol=1e-5)
+    cdfs = np.sort(rng.standard_normal((4, 255)).astype(np.float32), axis=1)
+    cdfs[2, 10:14] = cdfs[2, 10]                                         # a run of equal quantiles
+    scores = np.concatenate([rng.standard_normal((1000, 4)).astype(np.float32), cdfs[:, :40].T,
+                             np.full((1, 4), 1e9, np.float32), np.full((1, 4), -1e9, np.float32)])
+    assert np.array_equal(mse.descriptor_buckets(cdfs, scores), orc.descriptor_buckets(cdfs, scores))
+    with pytest.raises(mse.MseError):
+        mse.descriptor_buckets(np.zeros((4, 300), np.float32), scores)

@@ -442,3 +442,29 @@ def test_dedup_keep_rule(orc):
     assert sims[1, 0] > 0.95 and sims[2, 1] > 0.95 and sims[2, 0] < 0.95
     # near_a is dropped (dup of a); near2 is similar only to the DROPPED near_a, so it is kept; last row duplicates a
     assert orc.dedup_keep(rows).tolist() == [1, 0, 1, 1, 0]
+
+
+def test_descriptor_bucket_is_rust_binary_search(orc):
+    # dump_processor.rs:485-488 against a literal model of `binary_search_by`: equal element -> its index, else insertion point
+    cdf = np.array([0.0, 0.1, 0.1, 0.1, 0.5, 0.9], np.float32)
+    got = orc.descriptor_buckets(cdf[None, :], np.array([[-1.0], [0.0], [0.05], [0.3], [0.5], [0.95]], np.float32))[:, 0]
+    assert got.tolist() == [0, 0, 1, 4, 4, 6]
+    b = int(orc.descriptor_buckets(cdf[None, :], np.array([[0.1]], np.float32))[0, 0])
+    assert cdf[b] == np.float32(0.1)                      # some index of the run of equal elements
+    rng = np.random.default_rng(3)
+    cdf = np.sort(rng.standard_normal(255).astype(np.float32))
+    sc = rng.standard_normal((500, 1)).astype(np.float32)
+    assert np.array_equal(orc.descriptor_buckets(cdf[None, :], sc)[:, 0], np.searchsorted(cdf, sc[:, 0], side="left").astype(np.uint8))
+    assert int(orc.descriptor_buckets(cdf[None, :], np.array([[1e9]], np.float32))[0, 0]) == 255   # above the last quantile
+
+
+def test_score_model_formula(orc):
+    rng = np.random.default_rng(4)
+    d, hdim, oc = 1152, 96, 3
+    up = (rng.standard_normal((hdim, d)) / np.sqrt(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(hdim)).astype(np.float32)
+    down = (rng.standard_normal((oc, hdim)) / np.sqrt(hdim)).astype(np.float32)
+    x = rng.standard_normal((5, d)).astype(np.float32)
+    h = (up.astype(np.float64) @ x.T.astype(np.float64)) + b[:, None]
+    want = ((down.astype(np.float64) @ (h / (1 + np.exp(-h)))) * (d / hdim)).T        # score_model.rs:21-29
+    assert np.allclose(orc.score_batch(up, b, down, x), want, rtol=2e-5, atol=2e-5)
