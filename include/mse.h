@@ -175,6 +175,21 @@ int mse_disk_greedy_search(mse_searcher* s, mse_pq* pq, const mse_codes* c, cons
                            size_t max_deg, const uint8_t* has_url, uint32_t start, const uint16_t* query, const float* lut,
                            const float* scales, int disable_pq, size_t beamwidth, mse_nb* buf, uint32_t* visited_ids,
                            int64_t* visited_scores, size_t visited_cap, size_t* n_visited, size_t* cmps, size_t* pq_cmps);
+/* The same search, GPU-resident and batched over queries: one workgroup per query keeps the
+ * NeighbourBuffer, the pre-buffer and the query's distance table in LDS and the visited sets as bit maps in HBM; no
+ * host round trip during a search.  The adjacency lives on the device (mse_graph).  Per query q the outputs equal
+ * those of mse_disk_greedy_search: buf_ids/buf_scores [nq][search_list] (first buf_len[q] valid, best first),
+ * visited_* [nq][visited_cap] in fetch order, n_visited/cmps/pq_cmps [nq].  starts [nq]; queries [nq][d] f16; luts
+ * [nq][64*256]; scales [nq][n_descriptors] or NULL.  Limits: 64 x 256 codec, search_list <= 1024, beamwidth <= 8,
+ * max_deg <= 64. */
+typedef struct mse_graph mse_graph;
+mse_graph* mse_graph_from_host(const uint32_t* adj, const uint32_t* deg, size_t n, size_t max_deg, const uint8_t* has_url);
+void mse_graph_free(mse_graph* g);
+int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+                          const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
+                          size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
+                          uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
+                          uint32_t* cmps, uint32_t* pq_cmps);
 /* Result de-duplication of the visited list (src/query_disk_index.rs:482-527): S = V V^T over the visited rows
  * (ids into the searcher's base, visit order), greedy keep-first filter with S[i][j] > threshold (0.95, :99) against
  * already kept rows.  keep[i] = 1 for survivors. */

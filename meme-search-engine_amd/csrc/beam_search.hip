@@ -1,0 +1,346 @@
+// GPU-resident form of the disk-index beam search (src/query_disk_index.rs:144-212), batched over queries:
+// one workgroup per query, everything the reference keeps in `Scratch` lives on the device --
+//   NeighbourBuffer (diskann/src/lib.rs:74-155)      three sorted arrays in LDS (capacity <= 1024)
+//   neighbour_pre_buffer, the beam                    LDS
+//   visited / visited_adjacent (HashSet<u32>)         one bit per node in HBM, per query
+//   QueryLUT (64 x 256 f32)                           LDS, 64 KiB
+//   record vectors, PQ codes, descriptors, adjacency  HBM (mse_base, mse_codes, mse_graph)
+// and no host round trip happens during a search.  Semantics are the reference's, replayed in its order, including
+// the quirks mse_disk_greedy_search documents (entry point inserted with score 0; the pre-buffer is cleared per beam
+// iteration, so later nodes of a beam re-insert the earlier nodes' fresh neighbours).  Exact scores use the
+// reference's fast_dot order (exact_dot.h), ADC sums are sequential fp32 adds in chunk order: every output is
+// bit-identical to the oracle's, query by query.
+//
+// Work split inside a workgroup (4 waves): the list manipulation is sequential by nature and is done by wave 0 (inserts
+// shift the sorted arrays 64 entries at a time); scoring the pre-buffer (64 LDS lookups or one exact dot per entry)
+// is spread over all 256 lanes.
+#include "../../include/mse.h"
+#include "exact_dot.h"
+#include "runtime.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+
+using namespace mse;
+
+struct mse_graph {
+    uint32_t* adj = nullptr;   // device [n][max_deg]
+    uint32_t* deg = nullptr;   // device [n]
+    uint8_t* has_url = nullptr;  // device [n] or null (= all)
+    size_t n = 0, max_deg = 0;
+};
+
+namespace {
+
+constexpr int BS_THREADS = 256;
+constexpr int BS_LMAX = 1024;
+constexpr int BS_BEAM_MAX = 8;
+constexpr int BS_DEG_MAX = 64;
+constexpr int BS_PRE_MAX = BS_BEAM_MAX * BS_DEG_MAX;
+constexpr int BS_DESC_MAX = 8;
+
+struct BeamArgs {
+    const uint16_t* base; size_t n; int d;
+    const uint8_t* codes; const uint8_t* desc; int n_desc;
+    const uint32_t* adj; const uint32_t* deg; int max_deg; const uint8_t* has_url;
+    const uint16_t* queries; const float* luts; const float* scales; const uint32_t* starts;
+    int beam, L, disable_pq;
+    uint32_t* bm_adj; uint32_t* bm_vis; size_t bm_words;
+    uint32_t* out_ids; long long* out_scores; uint32_t* out_len;
+    uint32_t* vis_ids; long long* vis_scores; size_t vis_cap; uint32_t* n_visited;
+    uint32_t* cmps; uint32_t* pq_cmps; uint32_t* err;
+};
+
+__global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_lut = reinterpret_cast<float*>(smem);
+    uint16_t* s_q = reinterpret_cast<uint16_t*>(smem + 65536);
+    char* p = smem + 65536 + ((a.d * 2 + 15) & ~15);
+    long long* nb_sc = reinterpret_cast<long long*>(p); p += BS_LMAX * 8;
+    long long* pre_sc = reinterpret_cast<long long*>(p); p += BS_PRE_MAX * 8;
+    uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += BS_LMAX * 4;
+    uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += BS_LMAX * 4;
+    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p);
+    __shared__ int s_len, s_next, s_npts, s_npre;
+    __shared__ uint32_t s_pts[BS_BEAM_MAX];
+    __shared__ int s_seg[BS_BEAM_MAX];
+    __shared__ long long s_ptsc[BS_BEAM_MAX];
+    __shared__ float s_scales[BS_DESC_MAX];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t qi = blockIdx.x;
+    const int cap = a.L;
+    uint32_t* bm_adj = a.bm_adj + qi * a.bm_words;
+    uint32_t* bm_vis = a.bm_vis + qi * a.bm_words;
+    const bool use_bias = a.scales && a.desc && a.n_desc > 0;
+
+    for (int e = tid; e < 64 * 256 / 4; e += BS_THREADS)
+        reinterpret_cast<float4*>(s_lut)[e] = reinterpret_cast<const float4*>(a.luts + qi * 16384)[e];
+    for (int e = tid; e < a.d / 8; e += BS_THREADS)
+        reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(a.queries + qi * a.d)[e];
+    if (tid < BS_DESC_MAX) s_scales[tid] = (use_bias && tid < a.n_desc) ? a.scales[qi * a.n_desc + tid] : 0.0f;
+    if (tid == 0) {
+        const uint32_t start = a.starts[qi];
+        nb_id[0] = start; nb_sc[0] = 0; nb_vis[0] = 0;   // :153 -- the entry point enters with score 0
+        s_len = 1; s_next = 0;
+        atomicOr(&bm_adj[start >> 5], 1u << (start & 31));   // :154
+    }
+    __syncthreads();
+
+    auto bias = [&](uint32_t id) -> long long {   // descriptor_product (:135-142)
+        long long r = 0;
+        if (use_bias)
+            for (int j = 0; j < a.n_desc; j++) r += scale_dot_result(s_scales[j] * (float)a.desc[(size_t)id * a.n_desc + j]);
+        return r;
+    };
+
+    uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
+    for (;;) {
+        // ---- next_several_unvisited (:83-97 over NeighbourBuffer::next_unvisited, lib.rs:93-107) ----
+        if (tid == 0) {
+            int n = 0, nu = s_next;
+            const int len = s_len;
+            while (n < a.beam && nu >= 0) {
+                const int cur = nu;
+                nb_vis[cur] = 1;
+                int c = cur;
+                while (c < len && nb_vis[c]) c++;
+                nu = c == len ? -1 : c;
+                s_pts[n++] = nb_id[cur];
+            }
+            s_next = nu;
+            s_npts = n;
+        }
+        __syncthreads();
+        const int npts = s_npts;
+        if (npts == 0) break;
+
+        // ---- fetched nodes: exact score + bias (:168-170), one lane quad per node ----
+        if (wave == 0) {
+            const int qd = lane >> 2;
+            const uint32_t pt = s_pts[qd < npts ? qd : npts - 1];
+            const float f = quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d);
+            if (qd < npts && (lane & 3) == 0) s_ptsc[qd] = scale_dot_result(f) + bias(pt);
+        }
+        __syncthreads();
+
+        // ---- visited list and fresh neighbours, node by node in fetch order (:171-188) ----
+        if (wave == 0) {
+            int npre = 0;
+            for (int j = 0; j < npts; j++) {
+                const uint32_t pt = s_pts[j];
+                if (lane == 0) {
+                    cmps++;
+                    const uint32_t old = atomicOr(&bm_vis[pt >> 5], 1u << (pt & 31));
+                    if (!(old & (1u << (pt & 31))) && (!a.has_url || a.has_url[pt])) {
+                        if (n_vis < a.vis_cap) {
+                            a.vis_ids[qi * a.vis_cap + n_vis] = pt;
+                            a.vis_scores[qi * a.vis_cap + n_vis] = s_ptsc[j];
+                        }
+                        n_vis++;
+                    }
+                }
+                int dg = (int)a.deg[pt];
+                if (dg > a.max_deg) dg = a.max_deg;
+                uint32_t nb = lane < dg ? a.adj[(size_t)pt * a.max_deg + lane] : 0xffffffffu;
+                bool cand = lane < dg;
+                if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
+                // an id listed twice in one adjacency list: the first occurrence is the one HashSet::insert accepts
+                for (int l = 0; l < dg; l++) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
+                    if (l < lane && o == nb) cand = false;
+                }
+                bool fresh = false;
+                if (cand) {
+                    const uint32_t old = atomicOr(&bm_adj[nb >> 5], 1u << (nb & 31));
+                    fresh = !(old & (1u << (nb & 31)));
+                }
+                const unsigned long long m = __ballot(fresh);
+                if (fresh) pre_id[npre + __popcll(m & ((1ull << lane) - 1ull))] = nb;
+                npre += __popcll(m);
+                if (lane == 0) s_seg[j] = npre;
+            }
+            if (lane == 0) s_npre = npre;
+        }
+        __syncthreads();
+
+        // ---- scores of the pre-buffer (:189-203): ADC + bias, or exact + bias with disable_pq ----
+        const int npre = s_npre;
+        if (!a.disable_pq) {
+            for (int e = tid; e < npre; e += BS_THREADS) {
+                const uint32_t id = pre_id[e];
+                const uint4* cp = reinterpret_cast<const uint4*>(a.codes + (size_t)id * 64);
+                float s = 0.0f;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    const uint4 w4 = cp[c4];
+                    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+#pragma unroll
+                        for (int bb = 0; bb < 4; bb++)
+                            s = add_rn(s, s_lut[(c4 * 16 + x * 4 + bb) * 256 + ((w[x] >> (8 * bb)) & 0xff)]);
+                }
+                pre_sc[e] = scale_dot_result(s) + bias(id);
+            }
+        } else {
+            for (int e0 = 0; e0 < npre; e0 += BS_THREADS / 4) {
+                const int e = e0 + (tid >> 2);
+                const uint32_t id = pre_id[e < npre ? e : npre - 1];
+                const float f = quad_fast_dot_f32(a.base + (size_t)id * a.d, s_q, a.d);
+                if (e < npre && (tid & 3) == 0) pre_sc[e] = scale_dot_result(f) + bias(id);
+            }
+        }
+        __syncthreads();
+
+        // ---- NeighbourBuffer::insert (lib.rs:117-147) for every (node, pre-buffer entry) pair in the reference's order ----
+        if (wave == 0) {
+            int len = s_len, nu = s_next;
+            for (int j = 0; j < npts; j++) {
+                const int upto = s_seg[j];
+                for (int ii = 0; ii < upto; ii++) {
+                    const uint32_t id = pre_id[ii];
+                    const long long sc = pre_sc[ii];
+                    if (!a.disable_pq) pq_cmps++;
+                    if (cap == 0) continue;
+                    if (len == cap && nb_sc[len - 1] > sc) continue;
+                    int loc = 0;
+                    if (len > 0) {   // binary_search_by over the descending scores (lib.rs:122-125)
+                        int size = len, base = 0;
+                        while (size > 1) {
+                            const int half = size / 2, mid = base + half;
+                            base = (sc > nb_sc[mid]) ? base : mid;
+                            size -= half;
+                        }
+                        const long long c = nb_sc[base];
+                        loc = (sc == c) ? base : base + (sc < c ? 1 : 0);
+                    }
+                    if (loc < len && nb_id[loc] == id) continue;
+                    const int newlen = len < cap ? len + 1 : cap;
+                    for (int top = newlen - 1; top > loc; top -= 64) {   // shift [loc, newlen-1) up by one, 64 entries at a time
+                        const int idx = top - lane;
+                        const bool act = idx > loc;
+                        uint32_t mi = 0, mv = 0;
+                        long long ms = 0;
+                        if (act) { mi = nb_id[idx - 1]; ms = nb_sc[idx - 1]; mv = nb_vis[idx - 1]; }
+                        if (act) { nb_id[idx] = mi; nb_sc[idx] = ms; nb_vis[idx] = mv; }
+                    }
+                    if (lane == 0) { nb_id[loc] = id; nb_sc[loc] = sc; nb_vis[loc] = 0; }
+                    len = newlen;
+                    if (nu < 0 || loc < nu) nu = loc;
+                }
+            }
+            if (lane == 0) { s_len = len; s_next = nu; }
+        }
+        __syncthreads();
+    }
+
+    const int len = s_len;
+    for (int e = tid; e < len; e += BS_THREADS) {
+        a.out_ids[qi * a.L + e] = nb_id[e];
+        a.out_scores[qi * a.L + e] = nb_sc[e];
+    }
+    if (tid == 0) {
+        a.out_len[qi] = (uint32_t)len;
+        a.n_visited[qi] = n_vis;
+        a.cmps[qi] = cmps;
+        a.pq_cmps[qi] = pq_cmps;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+mse_graph* mse_graph_from_host(const uint32_t* adj, const uint32_t* deg, size_t n, size_t max_deg, const uint8_t* has_url) {
+    if (!adj || !deg || n == 0 || max_deg == 0) { fail("graph_from_host: bad argument"); return nullptr; }
+    mse_graph* g = new (std::nothrow) mse_graph();
+    if (!g) { fail("out of host memory"); return nullptr; }
+    g->n = n; g->max_deg = max_deg;
+    bool ok = hipMalloc((void**)&g->adj, n * max_deg * 4) == hipSuccess && hipMalloc((void**)&g->deg, n * 4) == hipSuccess;
+    ok = ok && hipMemcpy(g->adj, adj, n * max_deg * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(g->deg, deg, n * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && has_url) ok = hipMalloc((void**)&g->has_url, n) == hipSuccess && hipMemcpy(g->has_url, has_url, n, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { mse_graph_free(g); fail("graph_from_host: device allocation/copy failed"); return nullptr; }
+    return g;
+}
+
+void mse_graph_free(mse_graph* g) {
+    if (!g) return;
+    if (g->adj) (void)hipFree(g->adj);
+    if (g->deg) (void)hipFree(g->deg);
+    if (g->has_url) (void)hipFree(g->has_url);
+    delete g;
+}
+
+int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+                          const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
+                          size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
+                          uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
+                          uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!s || !s->base || !pq || !c || !g || !starts || !queries || !luts || !buf_ids || !buf_scores || !buf_len || !n_visited || !cmps ||
+        !pq_cmps)
+        return fail("disk_search_batch: null argument");
+    if (nq == 0) return 0;
+    const mse_base* b = s->base;
+    if (c->n != b->n || g->n != b->n) return fail("disk_search_batch: vectors, codes and graph differ in length");
+    if (pq->n_chunks != 64 || pq->n_centroids != 256 || c->code_size != 64) return fail("disk_search_batch: needs the 64 x 256 codec");
+    if (beamwidth == 0 || beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
+    if (search_list == 0 || search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
+    if (g->max_deg > BS_DEG_MAX) return fail("disk_search_batch: at most 64 neighbours per node");
+    if (c->n_desc > BS_DESC_MAX) return fail("disk_search_batch: at most 8 descriptors");
+    if (b->d % 32 || b->d > 4096) return fail("disk_search_batch: vector width must be a multiple of 32");
+    if (visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
+    for (size_t q = 0; q < nq; q++)
+        if (starts[q] >= b->n) return fail("disk_search_batch: start node out of range");
+    hipStream_t st = s->stream;
+    const size_t d = b->d, words = (b->n + 31) / 32;
+    const bool bias = scales && c->n_desc && c->desc;
+    DevBuf dq, dl, dsc, dst, bm, oi, os, ol, vi, vs, cnt;
+    if (dq.ensure(nq * d * 2) || dl.ensure(nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
+        bm.ensure(nq * words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
+        vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
+        return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
+    if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 8, st));
+    MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 12 + 16, st));
+    BeamArgs a{};
+    a.base = b->dev; a.n = b->n; a.d = (int)d;
+    a.codes = c->codes; a.desc = bias ? c->desc : nullptr; a.n_desc = (int)c->n_desc;
+    a.adj = g->adj; a.deg = g->deg; a.max_deg = (int)g->max_deg; a.has_url = g->has_url;
+    a.queries = dq.as<uint16_t>(); a.luts = dl.as<float>(); a.scales = bias ? dsc.as<float>() : nullptr; a.starts = dst.as<uint32_t>();
+    a.beam = (int)beamwidth; a.L = (int)search_list; a.disable_pq = disable_pq;
+    a.bm_adj = bm.as<uint32_t>(); a.bm_vis = bm.as<uint32_t>() + nq * words; a.bm_words = words;
+    a.out_ids = oi.as<uint32_t>(); a.out_scores = os.as<long long>(); a.out_len = ol.as<uint32_t>();
+    a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
+    a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
+    a.err = cnt.as<uint32_t>() + 3 * nq;
+    const size_t lds = 65536 + ((d * 2 + 15) & ~(size_t)15) + BS_LMAX * 16 + BS_PRE_MAX * 12;
+    static bool attr = false;
+    if (!attr) {
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(beam_search_kernel, dim3((unsigned)nq), dim3(BS_THREADS), lds, st, a);
+    MSE_HIP_TRY(hipGetLastError());
+    uint32_t err = 0;
+    MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(buf_len, ol.p, nq * 4, hipMemcpyDeviceToHost, st));
+    if (visited_cap) {
+        MSE_HIP_TRY(hipMemcpyAsync(visited_ids, vi.p, nq * visited_cap * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipMemcpyAsync(visited_scores, vs.p, nq * visited_cap * 8, hipMemcpyDeviceToHost, st));
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(n_visited, a.n_visited, nq * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(cmps, a.cmps, nq * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(pq_cmps, a.pq_cmps, nq * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    if (err) return fail("disk_search_batch: a graph edge points outside the index");
+    return 0;
+}
+
+}  // extern "C"

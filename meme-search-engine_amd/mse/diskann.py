@@ -130,6 +130,57 @@ def disk_greedy_search(searcher: Searcher, quantizer, codes, graph: IndexGraph, 
     return DiskSearchResult(buf, vids[:k].copy(), vsc[:k].copy(), int(cm.value), int(pc.value))
 
 
+class DeviceGraph:
+    """Adjacency (and the has-url flags of the records) resident in HBM for disk_search_batch."""
+
+    def __init__(self, graph: IndexGraph, has_url=None):
+        hu = None if has_url is None else np.ascontiguousarray(has_url, np.uint8)
+        self._h = check_ptr(ffi.lib().mse_graph_from_host(_p(graph.adj, C.c_uint32), _p(graph.deg, C.c_uint32), graph.adj.shape[0],
+                                                          graph.adj.shape[1], _p(hu, C.c_uint8) if hu is not None else None),
+                            "mse_graph_from_host")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ffi.lib().mse_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph, starts, queries, luts, descriptor_scales=None,
+                      disable_pq=False, beamwidth=1, search_list=1000, visited_cap=4096):
+    """query_disk_index::greedy_search for a batch of queries, entirely on the device (one workgroup per query).
+    Returns a list of DiskSearchResult-like tuples (buffer ids, buffer scores, visited ids, visited scores, cmps, pq_cmps)."""
+    q = _bits(queries)
+    q = q.reshape(-1, q.shape[-1])
+    nq = q.shape[0]
+    tables = np.ascontiguousarray(np.stack([getattr(t, "table", t) for t in luts]) if not isinstance(luts, np.ndarray) else luts,
+                                  np.float32).reshape(nq, -1)
+    st = np.ascontiguousarray(starts, np.uint32).reshape(nq)
+    sc = None
+    if descriptor_scales is not None:
+        sc = np.ascontiguousarray(descriptor_scales, np.float32)
+        if sc.ndim == 1:
+            sc = np.ascontiguousarray(np.broadcast_to(sc, (nq, sc.size)))
+    bi, bs, bl = np.empty((nq, search_list), np.uint32), np.empty((nq, search_list), np.int64), np.empty(nq, np.uint32)
+    vi, vs = np.empty((nq, visited_cap), np.uint32), np.empty((nq, visited_cap), np.int64)
+    nv, cm, pc = np.empty(nq, np.uint32), np.empty(nq, np.uint32), np.empty(nq, np.uint32)
+    check(ffi.lib().mse_disk_search_batch(
+        searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_uint16), _p(tables, C.c_float),
+        _p(sc, C.c_float) if sc is not None else None, nq, int(bool(disable_pq)), int(beamwidth), int(search_list),
+        _p(bi, C.c_uint32), _p(bs, C.c_int64), _p(bl, C.c_uint32), _p(vi, C.c_uint32), _p(vs, C.c_int64), visited_cap,
+        _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32)), "disk_search_batch")
+    out = []
+    for i in range(nq):
+        k = min(int(nv[i]), visited_cap)
+        out.append((bi[i, :bl[i]].copy(), bs[i, :bl[i]].copy(), vi[i, :k].copy(), vs[i, :k].copy(), int(cm[i]), int(pc[i])))
+    return out
+
+
 def greedy_search(searcher: Searcher, start, base_vectors_only, query, graph: IndexGraph, l,
                   query_breakpoint=0xFFFFFFFF):
     """lib.rs:183-211.  Returns (NeighbourBuffer, distances); results are buffer.ids, best first."""

@@ -81,6 +81,10 @@ SIGNATURES = {
     "mse_greedy_search": (C.c_int, [vp, u32p, u32p, sz, C.c_uint32, u16p, C.c_int, C.c_uint32, vp, C.POINTER(sz)]),
     "mse_disk_greedy_search": (C.c_int, [vp, vp, vp, u32p, u32p, sz, u8p, C.c_uint32, u16p, f32p, f32p, C.c_int, sz, vp,
                                          u32p, i64p, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "mse_graph_from_host": (vp, [u32p, u32p, sz, sz, u8p]),
+    "mse_graph_free": (None, [vp]),
+    "mse_disk_search_batch": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
+                                        u32p, u32p, u32p]),
     "mse_dedup_visited": (C.c_int, [vp, u32p, sz, C.c_float, u8p]),
     "mse_select_shard": (C.c_int, [f32p, sz, sz, f32p, C.POINTER(sz)]),
     "mse_medioid": (C.c_int, [vp, u32p]),

@@ -293,3 +293,43 @@ def test_index_packing_pieces(gpu, mse, orc):
     assert np.array_equal(mse.descriptor_buckets(cdfs, scores), orc.descriptor_buckets(cdfs, scores))
     with pytest.raises(mse.MseError):
         mse.descriptor_buckets(np.zeros((4, 300), np.float32), scores)
+
+
+@pytest.mark.parametrize("beamwidth,disable_pq,use_scales", [(1, False, True), (4, False, True), (3, True, True), (8, False, False)])
+def test_device_resident_beam_search_matches_oracle(gpu, mse, orc, beamwidth, disable_pq, use_scales):
+    """The batched, GPU-resident search (one workgroup per query) returns, query by query, exactly what the oracle's
+    restatement of query_disk_index::greedy_search returns: buffer, visited list in fetch order, both counters."""
+    rng = np.random.default_rng(15)
+    n, deg, L = 3000, 14, 64
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:2000], iters=2)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    scales = (np.array([0.5, 0, -0.25, 1.0], np.float32) / np.float32(512)) if use_scales else None
+    has_url = (rng.random(n) > 0.1).astype(np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    adj[5, 3] = adj[5, 1]                                              # an id listed twice in one adjacency list
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs), has_url)
+    nq = 9
+    qs = clustered_rows(orc, nq, n_centres=32, seed=200)
+    qh = orc.f16_bits(qs)
+    luts = np.stack([opq.preprocess_query(q) for q in qs])
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    starts[0] = 5
+    got = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qh, luts, scales, disable_pq, beamwidth, search_list=L,
+                                visited_cap=n)
+    for i in range(nq):
+        obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, desc, int(starts[i]), qh[i], luts[i], scales,
+                                                              disable_pq, beamwidth, L, has_url)
+        bi, bs, vi, vs, cm, pc = got[i]
+        assert (cm, pc) == (ocm, opc), i
+        assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores), i
+        assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc), i
+    with pytest.raises(mse.MseError):
+        mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qh, luts, scales, disable_pq, 9, search_list=L)
+    with pytest.raises(mse.MseError):
+        mse.disk_search_batch(searcher, gpq, gcodes, dgraph, np.full(nq, n, np.uint32), qh, luts, scales, disable_pq, 2, search_list=L)
