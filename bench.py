@@ -86,6 +86,67 @@ def pq_bench(args):
             "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), table 64 x 256 f32 in LDS, r = 200"}}
 
 
+def graph_bench(args):
+    """The production caller of the scoring kernels (src/query_disk_index.rs:144-212): beam search over a graph index,
+    here GPU-resident and batched (one workgroup per query).  Synthetic clustered index; the graph is a navigable
+    stand-in built with the brute-force scan (20 nearest neighbours, 8 nearest cluster hubs, 4 random edges) because
+    the Vamana build is out of scope; recall@10 is measured against the exact brute-force top-10 of the same index."""
+    import numpy as np
+    import mse
+    n, nq, R, K = int(args.graph_rows), 1024, 32, 10
+    rng = np.random.default_rng(0)
+    centres = rng.standard_normal((max(64, n // 50), D)).astype(np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+
+    def rows(m, seed):
+        g = np.random.default_rng(seed)
+        asg = g.integers(0, len(centres), m)
+        x = centres[asg] + g.standard_normal((m, D)).astype(np.float32) * np.float32(0.3 / np.sqrt(D))
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return x.astype(np.float16), asg
+
+    base, assign = rows(n, 1)
+    qh, _ = rows(nq, 2)
+    vl = mse.VectorList.from_f16s(base.view(np.uint16), D)
+    searcher = mse.Searcher(vl)
+    adj = np.empty((n, R), np.uint32)
+    for s0 in range(0, n, 128):
+        _, ids = searcher.bruteforce_topk(base[s0:s0 + 128].view(np.uint16), 21)
+        adj[s0:s0 + 128, :20] = ids[:, 1:21]
+    hubs = np.unique(assign, return_index=True)[1].astype(np.uint32)
+    hub_searcher = mse.Searcher(mse.VectorList.from_f16s(np.ascontiguousarray(base[hubs]).view(np.uint16), D))
+    for s0 in range(0, n, 128):
+        _, ids = hub_searcher.bruteforce_topk(base[s0:s0 + 128].view(np.uint16), 8)
+        adj[s0:s0 + 128, 20:28] = hubs[ids]
+    adj[:, 28:] = rng.integers(0, n, size=(n, 4))
+    for s0 in range(0, len(hubs), 128):
+        _, ids = hub_searcher.bruteforce_topk(np.ascontiguousarray(base[hubs[s0:s0 + 128]]).view(np.uint16), 13)
+        adj[hubs[s0:s0 + 128], 16:28] = hubs[ids[:, 1:13]]
+    deg = np.full(n, R, np.uint32)
+    # the codec only has to exist for the exact-neighbour mode (disable_pq): an untrained one is enough
+    cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+    pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)
+    codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, deg))
+    starts = np.full(nq, mse.medioid(vl), np.uint32)
+    luts = np.zeros((nq, 64 * 256), np.float32)
+    _, truth = searcher.bruteforce_topk(qh.view(np.uint16), K)
+    out = []
+    for L in (64, 200):
+        mse.disk_search_batch(searcher, pq, codes, dgraph, starts[:8], qh[:8].view(np.uint16), luts[:8], None, True, 4, L, 1024)
+        t0 = time.perf_counter()
+        res = mse.disk_search_batch(searcher, pq, codes, dgraph, starts, qh.view(np.uint16), luts, None, True, 4, L, 1024)
+        dt = time.perf_counter() - t0
+        hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist()))
+                   for i, (_, _, vi, vs, _, _) in enumerate(res))
+        out.append({"search_list": L, "beamwidth": 4, "queries_per_s": nq / dt, "recall_at_10": hits / (K * nq),
+                    "node_fetches_per_query": float(np.mean([r[4] for r in res]))})
+    return {"metric": "GPU-resident beam search (query_disk_index::greedy_search), batch of 1024 queries",
+            "config": {"workload": f"{n} x {D} fp16 clustered rows, degree-32 stand-in graph, exact neighbour scoring "
+                                   "(disable_pq: the vectors are in HBM), host arrays in / out"},
+            "results": out}
+
+
 def siglip_bench(args, world, rank):
     """BASELINE configs[1]: SigLIP-SO400M/14-384 image tower, batch 256 random 384x384 images, bf16, one
     replica per GPU.  Random-init weights of the named architecture (no checkpoint offline); images already
@@ -151,6 +212,8 @@ def main():
     ap.add_argument("--no-siglip", action="store_true", help="skip the SigLIP image-tower leg")
     ap.add_argument("--no-pq", action="store_true", help="skip the OPQ/PQ scan leg")
     ap.add_argument("--pq-rows", type=float, default=2e7)
+    ap.add_argument("--no-graph", action="store_true", help="skip the GPU-resident beam-search leg")
+    ap.add_argument("--graph-rows", type=float, default=2e5)
     ap.add_argument("--siglip-batch", type=int, default=256)
     ap.add_argument("--siglip-steps", type=int, default=3)
     args = ap.parse_args()
@@ -251,9 +314,17 @@ def main():
     siglip_line = None
     if not args.no_siglip:
         siglip_line = siglip_bench(args, world, rank)
-    pq_line = None
-    if rank == 0 and world == 1 and not args.no_pq:
-        pq_line = pq_bench(args)
+    pq_line = graph_line = None
+    if rank == 0 and world == 1 and not args.no_pq:      # single-process side legs: a failure is reported, not fatal
+        try:
+            pq_line = pq_bench(args)
+        except Exception as e:  # noqa: BLE001
+            pq_line = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_graph:
+        try:
+            graph_line = graph_bench(args)
+        except Exception as e:  # noqa: BLE001
+            graph_line = {"error": repr(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -301,6 +372,8 @@ def main():
             line["siglip"] = siglip_line
         if pq_line:
             line["pq_scan"] = pq_line
+        if graph_line:
+            line["graph_search"] = graph_line
         if note:
             line["note"] = note
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,92 @@
+"""Batched GPU-resident beam search: QPS and recall@10 on a synthetic clustered index with a kNN + random-edge graph.
+usage: beam_bench.py [n_rows] [n_queries]"""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "meme-search-engine_amd"))
+import torch  # noqa: F401
+import mse
+
+D = 1152
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 200_000
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+R, K = 32, 10
+rng = np.random.default_rng(0)
+t0 = time.time()
+centres = rng.standard_normal((4096, D)).astype(np.float32)
+centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+
+
+def rows(m, seed, with_assign=False):
+    g = np.random.default_rng(seed)
+    asg = g.integers(0, len(centres), m)
+    x = centres[asg] + g.standard_normal((m, D)).astype(np.float32) * np.float32(0.3 / np.sqrt(D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return (x, asg) if with_assign else x
+
+
+x, assign = rows(n, 1, True)
+base = x.astype(np.float16)
+xq = rows(nq, 2)
+qh = xq.astype(np.float16)
+print(f"data {time.time()-t0:.1f}s", flush=True)
+vl = mse.VectorList.from_f16s(base.view(np.uint16), D)
+searcher = mse.Searcher(vl)
+# A navigable stand-in for a Vamana graph (the graph BUILD is not part of this round): 20 nearest neighbours, 8 nearest
+# "hub" nodes (one representative per cluster; hubs link to their 12 nearest hubs) and 4 random long edges, all found
+# with the brute-force scan on the device.
+t0 = time.time()
+adj = np.empty((n, R), np.uint32)
+for s in range(0, n, 128):
+    _, ids = searcher.bruteforce_topk(base[s:s + 128].view(np.uint16), 21)
+    adj[s:s + 128, :20] = ids[:, 1:21]                    # drop self (best match)
+_, first = np.unique(assign, return_index=True)
+hubs = first.astype(np.uint32)
+hub_searcher = mse.Searcher(mse.VectorList.from_f16s(np.ascontiguousarray(base[hubs]).view(np.uint16), D))
+for s in range(0, n, 128):
+    _, ids = hub_searcher.bruteforce_topk(base[s:s + 128].view(np.uint16), 8)
+    adj[s:s + 128, 20:28] = hubs[ids]
+adj[:, 28:] = rng.integers(0, n, size=(n, 4))
+for s in range(0, len(hubs), 128):
+    _, ids = hub_searcher.bruteforce_topk(np.ascontiguousarray(base[hubs[s:s + 128]]).view(np.uint16), 13)
+    adj[hubs[s:s + 128], 16:28] = hubs[ids[:, 1:13]]          # hubs keep 16 of their own neighbours and link to 12 other hubs
+deg = np.full(n, R, np.uint32)
+print(f"knn graph {time.time()-t0:.1f}s", flush=True)
+# OPQ-shaped codec trained on a sample (random rotation + per-subspace max-IP k-means), codes by the device
+t0 = time.time()
+samp = x[rng.choice(n, 20000, replace=False)]
+T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
+ts = samp @ T.T
+cents = np.zeros((256, D), np.float32)
+for i in range(64):
+    sub = ts[:, i * 18:(i + 1) * 18]
+    c = sub[rng.choice(len(sub), 256, replace=False)].copy()
+    for _ in range(3):
+        a = np.argmax(sub @ c.T, axis=1)
+        for j in range(256):
+            m = sub[a == j]
+            if len(m):
+                c[j] = m.mean(axis=0)
+    cents[:, i * 18:(i + 1) * 18] = c
+pq = mse.ProductQuantizer(cents, T, 18, D)
+codes = np.concatenate([pq.quantize_batch(base[s:s + 8192].astype(np.float32)) for s in range(0, n, 8192)])
+gcodes = mse.Codes(codes, None)
+print(f"codec + codes {time.time()-t0:.1f}s", flush=True)
+dgraph = mse.DeviceGraph(mse.IndexGraph(adj, deg))
+start = mse.medioid(vl)
+luts = np.stack([pq.preprocess_query(q).table for q in qh.astype(np.float32)])
+_, truth = searcher.bruteforce_topk(qh.view(np.uint16), K)
+starts = np.full(nq, start, np.uint32)
+for L, beam, nopq in ((64, 4, False), (128, 4, False), (200, 4, False), (64, 4, True), (200, 4, True)):
+    mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts[:8], qh[:8].view(np.uint16), luts[:8], None, nopq, beam, L, 2048)
+    t0 = time.perf_counter()
+    res = mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qh.view(np.uint16), luts, None, nopq, beam, L, 2048)
+    dt = time.perf_counter() - t0
+    hits = 0
+    cm = 0
+    for i, (bi, bs, vi, vs, c, p) in enumerate(res):
+        top = vi[np.argsort(-vs, kind="stable")[:K]]          # the server sorts the visited list by exact score (:529)
+        hits += len(set(top.tolist()) & set(truth[i].tolist()))
+        cm += c
+    print(f"n={n} L={L} beam={beam} exact_neighbours={nopq}: {nq/dt:8.0f} q/s ({dt*1e3:.1f} ms for {nq} queries, host arrays in/out), recall@10 {hits/(K*nq):.3f}, "
+          f"{cm/nq:.0f} node fetches/query", flush=True)
