@@ -1429,23 +1429,29 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
                         for (int r = 0; r < 4; r++)
                             if (kt + h2 * 16 + 4 * g + r >= tokens) s[qt][h2][r] = -1e30f;
             }
-            float mnew[2];
+            // Running maximum with a lazy, wave-voted update: a lane looks only at ITS eight keys; as long as no lane of the
+            // wave sees a score more than 2^8 above the running maximum nothing is exchanged between lanes and
+            // p = exp2(s - m_run) <= 256.  Only when some lane votes is the true row maximum formed across the four
+            // lane groups (two cross-lane exchanges) and O rescaled -- on the first tile and rarely afterwards.
+            float lmx[2];
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
-                if (ABL == 1) { mnew[qt] = m_run[qt]; continue; }
+                if (ABL == 1) { lmx[qt] = m_run[qt]; continue; }
                 float mx = max3f(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
                 mx = max3f(mx, s[qt][0][3], s[qt][1][0]);
                 mx = max3f(mx, s[qt][1][1], s[qt][1][2]);
                 mx = max3f(mx, s[qt][1][3], mx);
-                mx = max3f(mx, __shfl_xor(mx, 16), mx);
-                mx = max3f(mx, __shfl_xor(mx, 32), mx);
-                mnew[qt] = max3f(m_run[qt], mx * scale_log2e, m_run[qt]);
+                lmx[qt] = mx * scale_log2e;
             }
-            if (__any((mnew[0] - m_run[0] > 8.0f) || (mnew[1] - m_run[1] > 8.0f))) {   // see attention_kernel
+            if (__any((lmx[0] - m_run[0] > 8.0f) || (lmx[1] - m_run[1] > 8.0f))) {
 #pragma unroll
                 for (int qt = 0; qt < 2; qt++) {
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew[qt]);
-                    m_run[qt] = mnew[qt];
+                    float mx = lmx[qt];
+                    mx = max3f(mx, __shfl_xor(mx, 16), mx);
+                    mx = max3f(mx, __shfl_xor(mx, 32), mx);
+                    const float mnew = max3f(m_run[qt], mx, m_run[qt]);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew);
+                    m_run[qt] = mnew;
 #pragma unroll
                     for (int t = 0; t < 5; t++)
 #pragma unroll
