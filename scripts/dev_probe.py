@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "meme-search-engine_amd"))
-from oracle import orc  # noqa: E402
+from oracle import orc  # noqa: E402  (developer probe: compares against the checker, never shipped)
 
 L = C.CDLL(os.path.join(ROOT, "meme-search-engine_amd", "lib", "libmse_hip.so"))
 vp, sz = C.c_void_p, C.c_size_t

@@ -13,17 +13,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     depth = int(sys.argv[3]) if len(sys.argv) > 3 else 27
     cfg = dict(siglip.SO400M_384, depth=depth)
-    eng = siglip.SiglipImageEngine(cfg, max_batch=batch)
-    rng = np.random.default_rng(0)
-    shapes = {}
-    # cheap random weights straight on the host (fan-in scaled), enough for timing
-    for name in eng.weight_names():
-        pass
-    from oracle import siglip_ref as ref   # weight generator only (bench helper; not part of the timed path)
-    sd = ref.synthetic_weights(dict(ref.CONFIG, depth=depth))
-    for name in eng.weight_names():
-        eng.set_weight(name, sd[name])
-    ffi.check(ffi.lib().mse_siglip_finalize(eng._h))
+    eng = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=batch)
     img = torch.empty((batch, 3, 384, 384), dtype=torch.float16, device="cuda").uniform_(-1, 1)
     torch.cuda.synchronize()
     eng.encode_image_device(img.data_ptr(), batch)
