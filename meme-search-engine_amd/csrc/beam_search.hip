@@ -95,6 +95,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     };
 
     uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
+    bool ties = false;                           // wave 0: two different ids have met on one score (see the insert loop)
     for (;;) {
         // ---- next_several_unvisited (:83-97 over NeighbourBuffer::next_unvisited, lib.rs:93-107) ----
         if (tid == 0) {
@@ -198,14 +199,40 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
             int len = s_len, nu = s_next;
             for (int j = 0; j < npts; j++) {
                 const int upto = s_seg[j];
+                const int fresh_from = j ? s_seg[j - 1] : 0;   // entries below this index were already offered by an earlier node
                 for (int ii = 0; ii < upto; ii++) {
                     const uint32_t id = pre_id[ii];
                     const long long sc = pre_sc[ii];
                     if (!a.disable_pq) pq_cmps++;
                     if (cap == 0) continue;
+                    // Re-offering an entry (the pre-buffer quirk) changes nothing while all scores in the list are distinct:
+                    // it is either still there (the search lands on it: same id, skipped), or it was rejected / pushed out by
+                    // strictly better entries and is rejected again.  Only once two different ids have tied on a score can a
+                    // re-offer land next to its copy and duplicate it, so from then on every offer is replayed in full.
+                    if (ii < fresh_from && !ties) continue;
                     if (len == cap && nb_sc[len - 1] > sc) continue;
                     int loc = 0;
-                    if (len > 0) {   // binary_search_by over the descending scores (lib.rs:122-125)
+                    // Position by counting with all 64 lanes: the list is sorted, so with no equal score the insertion point is
+                    // the number of larger entries, and with exactly one equal score binary_search_by can only land on it.
+                    // Only when several entries tie with the new score does the landing slot depend on the probe sequence,
+                    // and then the reference's loop is replayed below.
+                    int n_gt = 0, n_eq = 0, eq_pos = -1;
+                    for (int b0 = 0; b0 < len; b0 += 64) {
+                        const int idx = b0 + lane;
+                        const long long v = idx < len ? nb_sc[idx] : 0;
+                        n_gt += __popcll(__ballot(idx < len && v > sc));
+                        const unsigned long long me = __ballot(idx < len && v == sc);
+                        if (me) {
+                            if (eq_pos < 0) eq_pos = b0 + __ffsll((long long)me) - 1;
+                            n_eq += __popcll(me);
+                        }
+                    }
+                    if (n_eq >= 2 || (n_eq == 1 && nb_id[eq_pos] != id)) ties = true;
+                    if (n_eq == 0) {
+                        loc = n_gt;
+                    } else if (n_eq == 1) {
+                        loc = eq_pos;
+                    } else if (len > 0) {   // binary_search_by over the descending scores (lib.rs:122-125)
                         int size = len, base = 0;
                         while (size > 1) {
                             const int half = size / 2, mid = base + half;
