@@ -190,6 +190,51 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
                           size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
                           uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
                           uint32_t* cmps, uint32_t* pq_cmps);
+/* ---- Vamana graph build on the device (diskann/src/lib.rs:183-389, driven by
+ * src/generate_index_shard.rs:85-133) ----
+ * The graph being built is an mse_graph with max_deg = r (lists of at most r ids, stride r) that stays in HBM
+ * between the passes; vectors are the searcher's base rows (base vectors first, then the query vectors of the
+ * OOD-DiskANN variant, ids >= query_breakpoint).  The reference leaves two things to chance, and both are
+ * arguments here: the insertion order (rng.shuffle, lib.rs:291-292,333-334) and the random initial graph. */
+typedef struct mse_build_config {   /* IndexBuildConfig, lib.rs:42-52; defaults generate_index_shard.rs:22-33,85-94 */
+    uint64_t r, l, maxc;            /* degree bound (<= 64), search list (<= 1024), candidate cap (<= 1024) */
+    int64_t alpha, query_alpha;     /* relaxation factors times 2^16 */
+    uint32_t saturate_graph, query_breakpoint;
+    uint64_t max_add_per_stitch_iter;
+} mse_build_config;
+mse_graph* mse_graph_new(size_t n, size_t max_deg);                        /* IndexGraph::empty (lib.rs:22-31) */
+int mse_graph_to_host(const mse_graph* g, uint32_t* adj, uint32_t* deg);   /* [n][max_deg], [n] */
+size_t mse_graph_len(const mse_graph* g);
+size_t mse_graph_max_degree(const mse_graph* g);
+/* random_fill_graph (lib.rs:376-389): every list topped up to r distinct uniformly drawn ids (a node may draw
+ * itself).  The reference draws from clock-seeded fastrand forks; here draw k of node i is
+ * mulhi(philox4x32-10(ctr = (k,0,i,0), key = (seed, 0xF111))[0], n), so a seed names one graph. */
+int mse_graph_random_fill(mse_graph* g, uint32_t seed, size_t r);
+/* build_graph (lib.rs:287-324) over order[0..n_order): for each point greedy_search from the medioid (:183-211),
+ * merge_existing_neighbours (:215-221), robust_prune (:227-285), then the back edges (:311-322).  The reference
+ * feeds the points to rayon workers under per-list locks, so its result depends on thread timing; here the points
+ * are taken `batch` at a time: the searches and prunes of a batch see the graph as it was before the batch, then the
+ * batch's lists are replaced, then the back edges are applied in (position in batch, position in list) order.
+ * batch = 1 is exactly the single-threaded loop the reference keeps in comments (:294,297).  One workgroup per point
+ * (search list, candidates, prune state in LDS, visited set as a bit map in HBM), one workgroup per touched list
+ * for the back edges; every score is the reference's fast_dot, bit for bit. */
+int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t n_order, size_t batch, uint32_t medioid,
+                    const mse_build_config* cfg);
+/* robust_stitch (lib.rs:326-374): query nodes are removed from the base nodes' lists; each base node that pointed
+ * at a query receives up to max_add_per_stitch_iter of that query's out-neighbours, best first.  queries_order
+ * [n - query_breakpoint] = the shuffled query ids, applied one after another. */
+int mse_robust_stitch(mse_searcher* s, mse_graph* g, const uint32_t* queries_order, const mse_build_config* cfg);
+/* robust_prune alone (lib.rs:227-285) on a caller-supplied candidate list (scratch.visited_list); neigh has room for
+ * cfg->r ids, *n_neigh receives the count.  n_cand is unbounded (the best maxc are kept, :233-234). */
+int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* cand_scores, size_t n_cand, uint32_t p,
+                     const mse_build_config* cfg, uint32_t* neigh, size_t* n_neigh);
+/* diskann::greedy_search (lib.rs:183-211) GPU-resident and batched over queries (the in-RAM scorer, A21): one
+ * workgroup per query, outputs as mse_greedy_search leaves them in `buf`: buf_ids/buf_scores [nq][search_list]
+ * (first buf_len[q] valid, best first), n_distances [nq] = GreedySearchCounters.distances. */
+int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* starts, const uint16_t* queries, size_t nq,
+                           size_t search_list, int base_vectors_only, uint32_t query_breakpoint, uint32_t* buf_ids,
+                           int64_t* buf_scores, uint32_t* buf_len, uint32_t* n_distances);
+
 /* Result de-duplication of the visited list (src/query_disk_index.rs:482-527): S = V V^T over the visited rows
  * (ids into the searcher's base, visit order), greedy keep-first filter with S[i][j] > threshold (0.95, :99) against
  * already kept rows.  keep[i] = 1 for survivors. */

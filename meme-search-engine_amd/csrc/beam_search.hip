@@ -23,13 +23,6 @@
 
 using namespace mse;
 
-struct mse_graph {
-    uint32_t* adj = nullptr;   // device [n][max_deg]
-    uint32_t* deg = nullptr;   // device [n]
-    uint8_t* has_url = nullptr;  // device [n] or null (= all)
-    size_t n = 0, max_deg = 0;
-};
-
 namespace {
 
 constexpr int BS_THREADS = 256;

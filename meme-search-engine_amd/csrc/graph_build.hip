@@ -1,0 +1,836 @@
+// Vamana graph build on the device (diskann/src/lib.rs:183-389, driven by src/generate_index_shard.rs:85-133) and the
+// batched GPU-resident form of the in-RAM greedy search (lib.rs:183-211).
+//
+// Everything the reference keeps in `Scratch` (lib.rs:157-175) lives on the device, one workgroup per point:
+//   NeighbourBuffer (lib.rs:74-155)          three sorted arrays in LDS (capacity <= 1024)
+//   visited (HashSet<u32>)                   one bit per node in HBM, per workgroup slot
+//   neighbour_pre_buffer                     LDS (<= 64 ids)
+//   visited_list = robust_prune candidates   HBM while it grows (it can reach tens of thousands of entries), then its
+//                                            best maxc entries sorted in LDS (bitonic, 2048-entry window)
+//   robust_prune_scratch_buffer              LDS list of the candidates still alive, rebuilt per p_star
+// Every score is fast_dot_noprefetch's value (exact_dot.h), every comparison is on the i64 fixed-point scores, and the
+// sequential parts (list inserts, the p_star loop, the back edges of one list) are replayed in the reference's order, so
+// the built graph is bit-identical to the oracle's for the same insertion order and batch size (include/mse.h says what
+// a batch is; batch = 1 is the reference's single-threaded loop).
+//
+// Work split: list manipulation is sequential and done by wave 0 (64-entry shifts); scoring is spread over all 256
+// lanes, one quad of lanes per row (64 rows per pass) -- the same quad dot the scan kernels use, so a row costs 2304 B
+// of HBM/L2 traffic and 36 dependent FMAs per lane.  Back edges: one workgroup per touched list, the sources of one list
+// applied in order, lists touched by a batch processed concurrently.
+#include "../../include/mse.h"
+#include "exact_dot.h"
+#include "runtime.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+
+using namespace mse;
+
+namespace {
+
+constexpr int GB_THREADS = 256;
+constexpr int GB_LMAX = 1024;   // search list
+constexpr int GB_RMAX = 64;     // degree bound
+constexpr int GB_CMAX = 1024;   // maxc
+constexpr int GB_WIN = 2048;    // sort window
+constexpr long long GB_MIN = (long long)0x8000000000000000ull;   // i64::MIN marks a discarded candidate (lib.rs:269)
+
+__device__ __forceinline__ bool cand_before(long long sa, uint32_t pa, long long sb, uint32_t pb) {
+    return sa > sb || (sa == sb && pa < pb);
+}
+
+// Bitonic sort of N (power of two, <= GB_WIN) candidates, best first: score descending, earlier position first among
+// equal scores (sort_unstable_by_key(-score), lib.rs:233, restated as a stable sort -- see the oracle's note).
+__device__ void wg_sort(long long* sc, uint32_t* id, uint32_t* pos, int N) {
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < N / 2; t += GB_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+                const bool up = (i & k) == 0;
+                const long long si = sc[i], sl = sc[l];
+                const uint32_t pi = pos[i], pl = pos[l];
+                if ((si != sl || pi != pl) && cand_before(sl, pl, si, pi) == up) {
+                    sc[i] = sl; sc[l] = si;
+                    pos[i] = pl; pos[l] = pi;
+                    const uint32_t ii = id[i];
+                    id[i] = id[l]; id[l] = ii;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// The best min(total, GB_CMAX) of the candidate list (vi, vs)[0..total) in HBM, sorted into c_*[0..): the first window
+// is sorted whole, every further 1024 entries are sorted in behind the best 1024 so far.  Returns how many are valid.
+__device__ int wg_best_candidates(const uint32_t* vi, const long long* vs, int total, long long* c_sc, uint32_t* c_id, uint32_t* c_pos) {
+    const int tid = threadIdx.x;
+    const int first = total < GB_WIN ? total : GB_WIN;
+    int N = 2;
+    while (N < first) N <<= 1;
+    for (int e = tid; e < N; e += GB_THREADS) {
+        const bool in = e < first;
+        c_sc[e] = in ? vs[e] : GB_MIN;
+        c_id[e] = in ? vi[e] : 0xffffffffu;
+        c_pos[e] = in ? (uint32_t)e : 0xffffffffu;
+    }
+    __syncthreads();
+    wg_sort(c_sc, c_id, c_pos, N);
+    for (int off = GB_WIN; off < total; off += GB_WIN / 2) {
+        for (int e = tid; e < GB_WIN / 2; e += GB_THREADS) {
+            const int src = off + e;
+            const bool in = src < total;
+            c_sc[GB_WIN / 2 + e] = in ? vs[src] : GB_MIN;
+            c_id[GB_WIN / 2 + e] = in ? vi[src] : 0xffffffffu;
+            c_pos[GB_WIN / 2 + e] = in ? (uint32_t)src : 0xffffffffu;
+        }
+        __syncthreads();
+        wg_sort(c_sc, c_id, c_pos, GB_WIN);
+    }
+    return total < GB_CMAX ? total : GB_CMAX;
+}
+
+struct PruneParams {
+    const uint16_t* base; int d;
+    uint32_t qb; long long alpha, qalpha; int r, saturate;
+};
+
+// robust_prune (lib.rs:227-285) after its sort/truncate: candidates c_*[0..nc) best first.  Called by the whole
+// workgroup; returns the new list's length, ids in s_neigh.  s_live: room for nc u16; s_cnt: one LDS int.
+__device__ int wg_robust_prune(const PruneParams& pp, uint32_t p, int nc, long long* c_sc, const uint32_t* c_id, uint16_t* s_star,
+                               uint16_t* s_live, uint32_t* s_neigh, int* s_cnt) {
+    const int tid = threadIdx.x, d = pp.d;
+    int nn = 0, ci = 0;
+    __syncthreads();
+    while (nn < pp.r && ci < nc) {
+        const uint32_t p_star = c_id[ci];
+        const long long p_star_score = c_sc[ci];
+        ci++;
+        if (p_star == p || p_star_score == GB_MIN) continue;   // :241 (uniform: every lane reads the same LDS words)
+        if (tid == 0) { s_neigh[nn] = p_star; *s_cnt = 0; }
+        nn++;
+        __syncthreads();
+        // :250-255 -- note the range starts one past the candidate behind p_star (candidate_index was already advanced)
+        for (int i = ci + 1 + tid; i < nc; i += GB_THREADS)
+            if (c_sc[i] != GB_MIN) s_live[atomicAdd(s_cnt, 1)] = (uint16_t)i;
+        for (int e = tid; e < d / 8; e += GB_THREADS)
+            reinterpret_cast<uint4*>(s_star)[e] = reinterpret_cast<const uint4*>(pp.base + (size_t)p_star * d)[e];
+        __syncthreads();
+        const int nlive = *s_cnt;
+        for (int e0 = 0; e0 < nlive; e0 += GB_THREADS / 4) {   // :257-271, one lane quad per surviving candidate
+            const int e = e0 + (tid >> 2);
+            const int i = s_live[e < nlive ? e : nlive - 1];
+            const uint32_t p_prime = c_id[i];
+            const float f = quad_fast_dot_f32(pp.base + (size_t)p_prime * d, s_star, d);
+            if (e < nlive && (tid & 3) == 0) {
+                const long long a = p_prime >= pp.qb ? pp.qalpha : pp.alpha;
+                const long long scaled = (long long)((unsigned long long)a * (unsigned long long)scale_dot_result(f)) >> 16;
+                if (scaled >= c_sc[i]) c_sc[i] = GB_MIN;
+            }
+        }
+        __syncthreads();
+    }
+    if (pp.saturate || p >= pp.qb) {   // :275-284
+        if (tid < 64) {
+            uint32_t mine = tid < nn ? s_neigh[tid] : 0u;
+            for (int i = 0; i < nc && nn < pp.r; i++) {
+                const uint32_t id = c_id[i];
+                if (__ballot(tid < nn && mine == id)) continue;
+                if (tid == nn) mine = id;
+                nn++;
+            }
+            if (tid < nn) s_neigh[tid] = mine;
+            if (tid == 0) *s_cnt = nn;
+        }
+        __syncthreads();
+        nn = *s_cnt;
+    }
+    __syncthreads();
+    return nn;
+}
+
+struct GraphArgs {
+    const uint16_t* base; uint32_t n; int d;
+    const uint32_t* adj; const uint32_t* deg; int r;
+    const uint32_t* points;      // build: the batch's points; search: the start node per query
+    const uint16_t* queries;     // search only
+    uint32_t medioid, qb; int base_only;
+    int L, maxc, saturate; long long alpha, qalpha;
+    uint32_t* bitmap; size_t bm_words;
+    uint32_t* vl_ids; long long* vl_sc; uint32_t vl_cap;
+    uint32_t* out_ids; long long* out_sc; uint32_t* out_len; uint32_t* out_dist;
+    uint32_t* err;   // bit 0: an edge points outside the graph; bit 1: visited list overflow
+};
+
+__host__ __device__ inline size_t graph_lds_bytes(int d) {
+    return 2 * (size_t)((d * 2 + 15) & ~15) + GB_WIN * 16 + 64 * 12 + 64 * 4 + GB_CMAX * 2;
+}
+
+// BUILD: greedy_search from the medioid for point p (query = its own vector), merge_existing_neighbours, robust_prune;
+// the new list goes to the staging rows.  !BUILD: greedy_search for an outside query; the buffer is the output.
+template <bool BUILD>
+__global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dq = (a.d * 2 + 15) & ~15;
+    uint16_t* s_q = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* s_star = reinterpret_cast<uint16_t*>(smem + dq);
+    char* p0 = smem + 2 * dq;
+    long long* c_sc = reinterpret_cast<long long*>(p0); p0 += GB_WIN * 8;
+    uint32_t* c_id = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
+    uint32_t* c_pos = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
+    long long* pre_sc = reinterpret_cast<long long*>(p0); p0 += 64 * 8;
+    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
+    uint32_t* s_neigh = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
+    uint16_t* s_live = reinterpret_cast<uint16_t*>(p0);
+    // the search list lives in the upper half of the sort window (dead once the search is over)
+    long long* nb_sc = c_sc + GB_WIN / 2;
+    uint32_t* nb_id = c_id + GB_WIN / 2;
+    uint32_t* nb_vis = c_pos + GB_WIN / 2;
+    __shared__ int s_len, s_next, s_npre, s_cnt, s_pt;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t bi = blockIdx.x;
+    const int cap = a.L, d = a.d;
+    const uint32_t p = BUILD ? a.points[bi] : 0u;
+    const uint32_t start = BUILD ? a.medioid : a.points[bi];
+    const bool base_only = BUILD ? p >= a.qb : a.base_only != 0;
+    uint32_t* bm = a.bitmap + bi * a.bm_words;
+    uint32_t* vl_i = a.vl_ids + bi * (size_t)a.vl_cap;
+    long long* vl_s = a.vl_sc + bi * (size_t)a.vl_cap;
+
+    {
+        const uint16_t* qsrc = BUILD ? a.base + (size_t)p * d : a.queries + bi * d;
+        for (int e = tid; e < d / 8; e += GB_THREADS) reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(qsrc)[e];
+    }
+    __syncthreads();
+    if (wave == 0) {   // :188-189
+        const float f = quad_fast_dot_f32(a.base + (size_t)start * d, s_q, d);
+        if (lane == 0) {
+            nb_id[0] = start; nb_sc[0] = scale_dot_result(f); nb_vis[0] = 0;
+            s_len = 1; s_next = 0;
+            atomicOr(&bm[start >> 5], 1u << (start & 31));
+        }
+    }
+    __syncthreads();
+
+    uint32_t n_vl = 0;   // wave 0: visited_list.len() == counters.distances
+    for (;;) {
+        if (tid == 0) {   // NeighbourBuffer::next_unvisited (lib.rs:93-107)
+            const int cur = s_next;
+            if (cur >= 0) {
+                const int len = s_len;
+                nb_vis[cur] = 1;
+                int c = cur;
+                while (c < len && nb_vis[c]) c++;
+                s_next = c == len ? -1 : c;
+                s_pt = (int)nb_id[cur];
+            } else {
+                s_pt = -1;
+            }
+        }
+        __syncthreads();
+        if (s_pt < 0) break;
+        const uint32_t pt = (uint32_t)s_pt;
+
+        if (wave == 0) {   // :194-200
+            int dg = (int)a.deg[pt];
+            if (dg > a.r) dg = a.r;
+            const uint32_t nb = lane < dg ? a.adj[(size_t)pt * a.r + lane] : 0xffffffffu;
+            bool cand = lane < dg;
+            if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
+            for (int l = 0; l < dg; l++) {   // an id listed twice: HashSet::insert accepts the first occurrence only
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
+                if (l < lane && o == nb) cand = false;
+            }
+            // a query node met while base_vectors_only is dropped whether or not it was seen before, so its bit is not needed
+            if (cand && base_only && nb >= a.qb) cand = false;
+            bool fresh = false;
+            if (cand) {
+                const uint32_t old = atomicOr(&bm[nb >> 5], 1u << (nb & 31));
+                fresh = !(old & (1u << (nb & 31)));
+            }
+            const unsigned long long m = __ballot(fresh);
+            if (fresh) pre_id[__popcll(m & ((1ull << lane) - 1ull))] = nb;
+            if (lane == 0) s_npre = __popcll(m);
+        }
+        __syncthreads();
+        const int npre = s_npre;
+        if (npre > 0) {   // :201-204, one lane quad per neighbour
+            const int e = tid >> 2;
+            const uint32_t id = pre_id[e < npre ? e : npre - 1];
+            const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_q, d);
+            if (e < npre && (tid & 3) == 0) pre_sc[e] = scale_dot_result(f);
+        }
+        __syncthreads();
+
+        if (wave == 0 && npre > 0) {
+            if (BUILD) {   // :206
+                if (n_vl + (uint32_t)npre <= a.vl_cap) {
+                    if (lane < npre) { vl_i[n_vl + lane] = pre_id[lane]; vl_s[n_vl + lane] = pre_sc[lane]; }
+                } else if (lane == 0) {
+                    atomicOr(a.err, 2u);
+                }
+            }
+            n_vl += (uint32_t)npre;
+            int len = s_len, nu = s_next;
+            for (int ii = 0; ii < npre; ii++) {   // NeighbourBuffer::insert (lib.rs:117-147), in order
+                const uint32_t id = pre_id[ii];
+                const long long sc = pre_sc[ii];
+                if (len == cap && nb_sc[len - 1] > sc) continue;
+                // position by counting with 64 lanes; only a run of equal scores makes binary_search_by's probe sequence matter
+                int n_gt = 0, n_eq = 0, eq_pos = -1;
+                for (int b0 = 0; b0 < len; b0 += 64) {
+                    const int idx = b0 + lane;
+                    const long long v = idx < len ? nb_sc[idx] : 0;
+                    n_gt += __popcll(__ballot(idx < len && v > sc));
+                    const unsigned long long me = __ballot(idx < len && v == sc);
+                    if (me) {
+                        if (eq_pos < 0) eq_pos = b0 + __ffsll((long long)me) - 1;
+                        n_eq += __popcll(me);
+                    }
+                }
+                int loc = 0;
+                if (n_eq == 0) {
+                    loc = n_gt;
+                } else if (n_eq == 1) {
+                    loc = eq_pos;
+                } else {
+                    int size = len, bs = 0;
+                    while (size > 1) {
+                        const int half = size / 2, mid = bs + half;
+                        bs = (sc > nb_sc[mid]) ? bs : mid;
+                        size -= half;
+                    }
+                    const long long c = nb_sc[bs];
+                    loc = (sc == c) ? bs : bs + (sc < c ? 1 : 0);
+                }
+                if (loc < len && nb_id[loc] == id) continue;
+                const int newlen = len < cap ? len + 1 : cap;
+                for (int top = newlen - 1; top > loc; top -= 64) {
+                    const int idx = top - lane;
+                    const bool act = idx > loc;
+                    uint32_t mi = 0, mv = 0;
+                    long long ms = 0;
+                    if (act) { mi = nb_id[idx - 1]; ms = nb_sc[idx - 1]; mv = nb_vis[idx - 1]; }
+                    if (act) { nb_id[idx] = mi; nb_sc[idx] = ms; nb_vis[idx] = mv; }
+                }
+                if (lane == 0) { nb_id[loc] = id; nb_sc[loc] = sc; nb_vis[loc] = 0; }
+                len = newlen;
+                if (nu < 0 || loc < nu) nu = loc;
+            }
+            if (lane == 0) { s_len = len; s_next = nu; }
+        }
+        __syncthreads();
+    }
+
+    if (!BUILD) {
+        const int len = s_len;
+        for (int e = tid; e < len; e += GB_THREADS) {
+            a.out_ids[bi * a.L + e] = nb_id[e];
+            a.out_sc[bi * a.L + e] = nb_sc[e];
+        }
+        if (tid == 0) { a.out_len[bi] = (uint32_t)len; a.out_dist[bi] = n_vl; }
+        return;
+    }
+
+    // ---- merge_existing_neighbours (lib.rs:215-221): the point's current list, scored against the point ----
+    if (tid == 0) s_cnt = (int)n_vl;
+    __syncthreads();
+    n_vl = (uint32_t)s_cnt;
+    int dg = (int)a.deg[p];
+    if (dg > a.r) dg = a.r;
+    if (dg > 0) {
+        const int e = tid >> 2;
+        uint32_t id = a.adj[(size_t)p * a.r + (e < dg ? e : dg - 1)];
+        if (id >= a.n) { id = 0; atomicOr(a.err, 1u); }
+        const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_q, d);
+        if (e < dg && (tid & 3) == 0) {
+            if (n_vl + (uint32_t)e < a.vl_cap) { vl_i[n_vl + e] = id; vl_s[n_vl + e] = scale_dot_result(f); }
+            else atomicOr(a.err, 2u);
+        }
+    }
+    __syncthreads();
+    uint32_t total = n_vl + (uint32_t)dg;
+    if (total > a.vl_cap) total = a.vl_cap;   // err bit 1 is set; the host repeats the batch with more room
+
+    // ---- robust_prune (lib.rs:227-285) ----
+    int nc = wg_best_candidates(vl_i, vl_s, (int)total, c_sc, c_id, c_pos);
+    if (nc > a.maxc) nc = a.maxc;
+    PruneParams pp{a.base, d, a.qb, a.alpha, a.qalpha, a.r, a.saturate};
+    const int nn = wg_robust_prune(pp, p, nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
+    if (tid < nn) a.out_ids[bi * a.r + tid] = s_neigh[tid];
+    if (tid == 0) a.out_len[bi] = (uint32_t)nn;
+}
+
+// robust_prune alone on a caller-supplied candidate list (one workgroup)
+__global__ __launch_bounds__(GB_THREADS) void prune_only_kernel(PruneParams pp, const uint32_t* ci, const long long* cs, int total, int maxc,
+                                                                uint32_t p, uint32_t* out_ids, uint32_t* out_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dq = (pp.d * 2 + 15) & ~15;
+    uint16_t* s_star = reinterpret_cast<uint16_t*>(smem + dq);
+    char* p0 = smem + 2 * dq;
+    long long* c_sc = reinterpret_cast<long long*>(p0); p0 += GB_WIN * 8;
+    uint32_t* c_id = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
+    uint32_t* c_pos = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
+    p0 += 64 * 12;
+    uint32_t* s_neigh = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
+    uint16_t* s_live = reinterpret_cast<uint16_t*>(p0);
+    __shared__ int s_cnt;
+    int nc = wg_best_candidates(ci, cs, total, c_sc, c_id, c_pos);
+    if (nc > maxc) nc = maxc;
+    const int nn = wg_robust_prune(pp, p, nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
+    if ((int)threadIdx.x < nn) out_ids[threadIdx.x] = s_neigh[threadIdx.x];
+    if (threadIdx.x == 0) *out_len = (uint32_t)nn;
+}
+
+__global__ void apply_lists_kernel(uint32_t* adj, uint32_t* deg, int r, const uint32_t* points, const uint32_t* staged, const uint32_t* staged_len,
+                                   int nb) {
+    const int k = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), e = threadIdx.x & 63;
+    if (k >= nb) return;
+    const uint32_t p = points[k], len = staged_len[k];
+    if ((uint32_t)e < len) adj[(size_t)p * r + e] = staged[(size_t)k * r + e];
+    if (e == 0) deg[p] = len;
+}
+
+struct BackArgs {
+    const uint16_t* base; int d;
+    uint32_t* adj; uint32_t* deg; int r;
+    const uint32_t* targets; const uint32_t* src_off; const uint32_t* srcs;
+    uint32_t qb; int maxc, saturate; long long alpha, qalpha;
+};
+
+// Back edges (lib.rs:311-322): workgroup b owns list targets[b] and applies its sources in order.
+__global__ __launch_bounds__(GB_THREADS) void backedge_kernel(BackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = a.d, dq = (d * 2 + 15) & ~15;
+    uint16_t* s_t = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* s_star = reinterpret_cast<uint16_t*>(smem + dq);
+    __shared__ long long c_sc[128];
+    __shared__ uint32_t c_id[128], c_pos[128], s_neigh[64], cur[64];
+    __shared__ uint16_t s_live[128];
+    __shared__ int s_cnt, s_len;
+    const int tid = threadIdx.x;
+    const uint32_t t = a.targets[blockIdx.x];
+    for (int e = tid; e < d / 8; e += GB_THREADS) reinterpret_cast<uint4*>(s_t)[e] = reinterpret_cast<const uint4*>(a.base + (size_t)t * d)[e];
+    if (tid == 0) s_len = (int)min(a.deg[t], (uint32_t)a.r);
+    __syncthreads();
+    if (tid < s_len) cur[tid] = a.adj[(size_t)t * a.r + tid];
+    __syncthreads();
+    PruneParams pp{a.base, d, a.qb, a.alpha, a.qalpha, a.r, a.saturate};
+    int N = 2;
+    while (N < a.r + 1) N <<= 1;
+    for (uint32_t si = a.src_off[blockIdx.x]; si < a.src_off[blockIdx.x + 1]; si++) {
+        const uint32_t p = a.srcs[si];
+        const int len = s_len;
+        if (len == a.r) {   // :314-318 -- the full list plus the newcomer, scored against the list's owner
+            {
+                const int e = tid >> 2;
+                const uint32_t id = cur[e < len ? e : len - 1];
+                const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_t, d);
+                if (e < len && (tid & 3) == 0) { c_sc[e] = scale_dot_result(f); c_id[e] = id; c_pos[e] = (uint32_t)e; }
+            }
+            if (tid < 64) {
+                const float f = quad_fast_dot_f32(a.base + (size_t)p * d, s_t, d);
+                if (tid == 0) { c_sc[len] = scale_dot_result(f); c_id[len] = p; c_pos[len] = (uint32_t)len; }
+            }
+            for (int e = len + 1 + tid; e < N; e += GB_THREADS) { c_sc[e] = GB_MIN; c_id[e] = 0xffffffffu; c_pos[e] = 0xffffffffu; }
+            __syncthreads();
+            wg_sort(c_sc, c_id, c_pos, N);
+            int nc = len + 1;
+            if (nc > a.maxc) nc = a.maxc;
+            const int nn = wg_robust_prune(pp, t, nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
+            if (tid < nn) cur[tid] = s_neigh[tid];
+            if (tid == 0) s_len = nn;
+        } else if (tid == 0) {   // :319-321
+            bool have = false;
+            for (int e = 0; e < len; e++) have |= cur[e] == p;
+            if (!have && len < a.r) { cur[len] = p; s_len = len + 1; }
+        }
+        __syncthreads();
+    }
+    if (tid < s_len) a.adj[(size_t)t * a.r + tid] = cur[tid];
+    if (tid == 0) a.deg[t] = (uint32_t)s_len;
+}
+
+struct StitchArgs {
+    const uint16_t* base; int d;
+    uint32_t* adj; uint32_t* deg; int r;
+    const uint32_t* targets; const uint32_t* src_off; const uint32_t* srcs;
+    int max_add;
+};
+
+// robust_stitch's second half (lib.rs:348-373): workgroup b owns base node targets[b]; for each query that it pointed
+// at, in order, the query's out-neighbours are scored against the base node and the best new ones appended.
+__global__ __launch_bounds__(GB_THREADS) void stitch_kernel(StitchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = a.d;
+    uint16_t* s_t = reinterpret_cast<uint16_t*>(smem);
+    __shared__ long long c_sc[64];
+    __shared__ uint32_t c_id[64], c_pos[64];
+    const int tid = threadIdx.x;
+    const uint32_t b = a.targets[blockIdx.x];
+    for (int e = tid; e < d / 8; e += GB_THREADS) reinterpret_cast<uint4*>(s_t)[e] = reinterpret_cast<const uint4*>(a.base + (size_t)b * d)[e];
+    int len = (int)min(a.deg[b], (uint32_t)a.r);   // tracked by wave 0
+    uint32_t mine = (tid < 64 && tid < len) ? a.adj[(size_t)b * a.r + tid] : 0u;
+    __syncthreads();
+    for (uint32_t si = a.src_off[blockIdx.x]; si < a.src_off[blockIdx.x + 1]; si++) {
+        const uint32_t q = a.srcs[si];
+        const int qn = (int)min(a.deg[q], (uint32_t)a.r);
+        if (qn == 0) continue;
+        int N = 2;
+        while (N < qn) N <<= 1;
+        {
+            const int e = tid >> 2;
+            const uint32_t id = a.adj[(size_t)q * a.r + (e < qn ? e : qn - 1)];
+            const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_t, d);
+            if ((tid & 3) == 0 && e < N) {
+                const bool in = e < qn;
+                c_sc[e] = in ? scale_dot_result(f) : GB_MIN; c_id[e] = in ? id : 0xffffffffu; c_pos[e] = in ? (uint32_t)e : 0xffffffffu;
+            }
+        }
+        __syncthreads();
+        wg_sort(c_sc, c_id, c_pos, N);   // :359
+        if (tid < 64) {   // :361-371
+            int added = 0;
+            for (int i = 0; i < qn; i++) {
+                if (added >= a.max_add || len >= a.r) break;
+                const uint32_t id = c_id[i];
+                if (__ballot(tid < len && mine == id)) continue;
+                if (tid == len) mine = id;
+                len++;
+                added++;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        if (tid < len) a.adj[(size_t)b * a.r + tid] = mine;
+        if (tid == 0) a.deg[b] = (uint32_t)len;
+    }
+}
+
+__device__ __forceinline__ uint32_t philox_first(uint32_t c0, uint32_t c2, uint32_t k0, uint32_t k1) {
+    uint32_t c1 = 0, c3 = 0;
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+__global__ void random_fill_kernel(uint32_t* adj, uint32_t* deg, uint32_t n, int stride, int r, uint32_t seed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* l = adj + (size_t)i * stride;
+    uint32_t len = deg[i];
+    for (uint32_t k = 0; len < (uint32_t)r && k < (1u << 20); k++) {
+        const uint32_t next = (uint32_t)(((uint64_t)philox_first(k, i, seed, 0xF111u) * (uint64_t)n) >> 32);
+        bool have = false;
+        for (uint32_t e = 0; e < len; e++) have |= l[e] == next;
+        if (!have) l[len++] = next;
+    }
+    deg[i] = len;
+}
+
+__global__ void check_graph_kernel(const uint32_t* adj, const uint32_t* deg, uint32_t n, int stride, uint32_t* err) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * stride) return;
+    const uint32_t node = (uint32_t)(i / stride), e = (uint32_t)(i % stride);
+    if (e == 0 && deg[node] > (uint32_t)stride) atomicOr(err, 1u);
+    if (e < deg[node] && adj[i] >= n) atomicOr(err, 1u);
+}
+
+int check_config(const mse_searcher* s, const mse_graph* g, const mse_build_config* cfg, const char* who) {
+    if (!s || !s->base || !g || !cfg) return fail(std::string(who) + ": null argument");
+    const mse_base* b = s->base;
+    if (g->n != b->n) return fail(std::string(who) + ": graph and vectors differ in length");
+    if (b->n >= 0xffffffffull) return fail(std::string(who) + ": too many vectors");   // lib.rs:288
+    if (cfg->r == 0 || cfg->r > GB_RMAX || cfg->r != g->max_deg) return fail(std::string(who) + ": r must be 1..64 and equal the graph's stride");
+    if (cfg->l == 0 || cfg->l > GB_LMAX) return fail(std::string(who) + ": l must be 1..1024");
+    if (cfg->maxc == 0 || cfg->maxc > GB_CMAX) return fail(std::string(who) + ": maxc must be 1..1024");
+    if (b->d % 32 || b->d > 4096) return fail(std::string(who) + ": vector width must be a multiple of 32");
+    return 0;
+}
+
+int check_graph(const mse_graph* g, hipStream_t st, const char* who) {
+    DevBuf e;
+    if (e.ensure(4)) return -1;
+    MSE_HIP_TRY(hipMemsetAsync(e.p, 0, 4, st));
+    const size_t total = g->n * g->max_deg;
+    hipLaunchKernelGGL(check_graph_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g->adj, g->deg, (uint32_t)g->n, (int)g->max_deg, e.as<uint32_t>());
+    MSE_HIP_TRY(hipGetLastError());
+    uint32_t err = 0;
+    MSE_HIP_TRY(hipMemcpyAsync(&err, e.p, 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    if (err) return fail(std::string(who) + ": the graph has an edge outside 0..n or a list longer than its stride");
+    return 0;
+}
+
+template <typename K> int set_lds(K kernel) {
+    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+mse_graph* mse_graph_new(size_t n, size_t max_deg) {
+    if (n == 0 || max_deg == 0) { fail("graph_new: bad argument"); return nullptr; }
+    mse_graph* g = new (std::nothrow) mse_graph();
+    if (!g) { fail("out of host memory"); return nullptr; }
+    g->n = n; g->max_deg = max_deg;
+    bool ok = hipMalloc((void**)&g->adj, n * max_deg * 4) == hipSuccess && hipMalloc((void**)&g->deg, n * 4) == hipSuccess;
+    ok = ok && hipMemset(g->adj, 0, n * max_deg * 4) == hipSuccess && hipMemset(g->deg, 0, n * 4) == hipSuccess;
+    if (!ok) { mse_graph_free(g); fail("graph_new: device allocation failed"); return nullptr; }
+    return g;
+}
+
+int mse_graph_to_host(const mse_graph* g, uint32_t* adj, uint32_t* deg) {
+    if (!g || !adj || !deg) return fail("graph_to_host: null argument");
+    MSE_HIP_TRY(hipDeviceSynchronize());
+    MSE_HIP_TRY(hipMemcpy(adj, g->adj, g->n * g->max_deg * 4, hipMemcpyDeviceToHost));
+    MSE_HIP_TRY(hipMemcpy(deg, g->deg, g->n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+size_t mse_graph_len(const mse_graph* g) { return g ? g->n : 0; }
+size_t mse_graph_max_degree(const mse_graph* g) { return g ? g->max_deg : 0; }
+
+int mse_graph_random_fill(mse_graph* g, uint32_t seed, size_t r) {
+    if (!g) return fail("graph_random_fill: null argument");
+    if (r == 0 || r > g->max_deg) return fail("graph_random_fill: r must be 1..max_deg");
+    if (g->n >= 0xffffffffull) return fail("graph_random_fill: too many nodes");
+    hipLaunchKernelGGL(random_fill_kernel, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, 0, g->adj, g->deg, (uint32_t)g->n, (int)g->max_deg, (int)r, seed);
+    MSE_HIP_TRY(hipGetLastError());
+    MSE_HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t n_order, size_t batch, uint32_t medioid,
+                    const mse_build_config* cfg) {
+    if (check_config(s, g, cfg, "build_graph")) return -1;
+    if (n_order && !order) return fail("build_graph: null argument");
+    const mse_base* b = s->base;
+    if (medioid >= b->n) return fail("build_graph: medioid out of range");
+    for (size_t i = 0; i < n_order; i++)
+        if (order[i] >= b->n) return fail("build_graph: point out of range");
+    if (n_order == 0) return 0;
+    if (batch == 0) batch = 1;
+    if (batch > n_order) batch = n_order;
+    if (batch > 65536) batch = 65536;
+    hipStream_t st = s->stream;
+    if (check_graph(g, st, "build_graph")) return -1;
+    const int r = (int)cfg->r, d = (int)b->d;
+    const size_t words = (b->n + 31) / 32;
+    size_t vl_cap = std::max<size_t>(4096, 2 * cfg->l * cfg->r) + cfg->r;
+    DevBuf d_order, bm, vli, vls, stg, stg_len, err, d_tg, d_off, d_src;
+    if (d_order.ensure(n_order * 4) || bm.ensure(batch * words * 4) || vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8) ||
+        stg.ensure(batch * r * 4) || stg_len.ensure(batch * 4) || err.ensure(4) || d_tg.ensure(batch * r * 4 + 4) ||
+        d_off.ensure(batch * r * 4 + 8) || d_src.ensure(batch * r * 4 + 4))
+        return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(d_order.p, order, n_order * 4, hipMemcpyHostToDevice, st));
+    if (set_lds(graph_search_kernel<true>)) return -1;
+    const size_t lds = graph_lds_bytes(d);
+    std::vector<uint32_t> h_stg(batch * r), h_len(batch), targets, offs, srcs;
+    std::vector<uint64_t> edges;
+    GraphArgs a{};
+    a.base = b->dev; a.n = (uint32_t)b->n; a.d = d;
+    a.adj = g->adj; a.deg = g->deg; a.r = r;
+    a.medioid = medioid; a.qb = cfg->query_breakpoint;
+    a.L = (int)cfg->l; a.maxc = (int)cfg->maxc; a.saturate = (int)cfg->saturate_graph; a.alpha = cfg->alpha; a.qalpha = cfg->query_alpha;
+    a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
+    a.out_ids = stg.as<uint32_t>(); a.out_len = stg_len.as<uint32_t>();
+    a.err = err.as<uint32_t>();
+    BackArgs ba{};
+    ba.base = b->dev; ba.d = d; ba.adj = g->adj; ba.deg = g->deg; ba.r = r;
+    ba.qb = cfg->query_breakpoint; ba.maxc = (int)cfg->maxc; ba.saturate = (int)cfg->saturate_graph; ba.alpha = cfg->alpha; ba.qalpha = cfg->query_alpha;
+    const size_t back_lds = 2 * (size_t)((d * 2 + 15) & ~15);
+    for (size_t b0 = 0; b0 < n_order; b0 += batch) {
+        const size_t nb = std::min(batch, n_order - b0);
+        a.points = d_order.as<uint32_t>() + b0;
+        for (;;) {
+            a.vl_ids = vli.as<uint32_t>(); a.vl_sc = vls.as<long long>(); a.vl_cap = (uint32_t)vl_cap;
+            MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nb * words * 4, st));
+            MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));
+            hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GB_THREADS), lds, st, a);
+            MSE_HIP_TRY(hipGetLastError());
+            uint32_t e = 0;
+            MSE_HIP_TRY(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
+            MSE_HIP_TRY(hipMemcpyAsync(h_stg.data(), stg.p, nb * r * 4, hipMemcpyDeviceToHost, st));
+            MSE_HIP_TRY(hipMemcpyAsync(h_len.data(), stg_len.p, nb * 4, hipMemcpyDeviceToHost, st));
+            MSE_HIP_TRY(hipStreamSynchronize(st));
+            if (e & 1u) return fail("build_graph: a graph edge points outside the index");
+            if (!(e & 2u)) break;
+            vl_cap *= 2;   // a search visited more nodes than there was room for: repeat the batch (the graph is untouched so far)
+            if (vl_cap > b->n + cfg->r) vl_cap = b->n + cfg->r;
+            if (vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8)) return -1;
+        }
+        hipLaunchKernelGGL(apply_lists_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, g->adj, g->deg, r, a.points, stg.as<uint32_t>(),
+                           stg_len.as<uint32_t>(), (int)nb);
+        MSE_HIP_TRY(hipGetLastError());
+        // back edges grouped by the list they touch, each group in (position in batch, position in list) order
+        edges.clear();
+        for (size_t k = 0; k < nb; k++)
+            for (uint32_t j = 0; j < h_len[k]; j++) edges.push_back(((uint64_t)h_stg[k * r + j] << 32) | (uint64_t)(k * r + j));
+        if (edges.empty()) continue;
+        std::sort(edges.begin(), edges.end());
+        targets.clear(); offs.clear(); srcs.clear();
+        for (size_t i = 0; i < edges.size(); i++) {
+            const uint32_t t = (uint32_t)(edges[i] >> 32);
+            if (targets.empty() || targets.back() != t) { targets.push_back(t); offs.push_back((uint32_t)i); }
+            srcs.push_back(order[b0 + (size_t)(uint32_t)edges[i] / r]);
+        }
+        offs.push_back((uint32_t)edges.size());
+        MSE_HIP_TRY(hipMemcpyAsync(d_tg.p, targets.data(), targets.size() * 4, hipMemcpyHostToDevice, st));
+        MSE_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, st));
+        MSE_HIP_TRY(hipMemcpyAsync(d_src.p, srcs.data(), srcs.size() * 4, hipMemcpyHostToDevice, st));
+        ba.targets = d_tg.as<uint32_t>(); ba.src_off = d_off.as<uint32_t>(); ba.srcs = d_src.as<uint32_t>();
+        hipLaunchKernelGGL(backedge_kernel, dim3((unsigned)targets.size()), dim3(GB_THREADS), back_lds, st, ba);
+        MSE_HIP_TRY(hipGetLastError());
+        MSE_HIP_TRY(hipStreamSynchronize(st));   // the host vectors above are reused by the next batch
+    }
+    return 0;
+}
+
+int mse_robust_stitch(mse_searcher* s, mse_graph* g, const uint32_t* queries_order, const mse_build_config* cfg) {
+    if (check_config(s, g, cfg, "robust_stitch")) return -1;
+    const mse_base* b = s->base;
+    const size_t n = b->n, r = cfg->r;
+    const uint32_t qb = cfg->query_breakpoint;
+    if (qb >= n) return 0;   // no query nodes: generate_index_shard.rs:129
+    if (!queries_order) return fail("robust_stitch: null argument");
+    hipStream_t st = s->stream;
+    if (check_graph(g, st, "robust_stitch")) return -1;
+    const size_t nq = n - qb;
+    std::vector<uint32_t> rank(nq, 0xffffffffu);
+    for (size_t k = 0; k < nq; k++) {
+        if (queries_order[k] < qb || queries_order[k] >= n || rank[queries_order[k] - qb] != 0xffffffffu)
+            return fail("robust_stitch: queries_order must list every query node once");
+        rank[queries_order[k] - qb] = (uint32_t)k;
+    }
+    // lib.rs:336-346 is list surgery without arithmetic: done on the host copy of the base nodes' lists
+    std::vector<uint32_t> adj((size_t)qb * r), deg(qb);
+    MSE_HIP_TRY(hipMemcpyAsync(adj.data(), g->adj, (size_t)qb * r * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(deg.data(), g->deg, (size_t)qb * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    struct Job { uint32_t base, qrank, occ, query; };
+    std::vector<Job> jobs;
+    for (uint32_t i = 0; i < qb; i++) {
+        uint32_t* l = adj.data() + (size_t)i * r;
+        uint32_t w = 0, occ = 0;
+        for (uint32_t e = 0; e < deg[i]; e++) {
+            if (l[e] >= qb) jobs.push_back(Job{i, rank[l[e] - qb], occ++, l[e]});
+            else l[w++] = l[e];
+        }
+        deg[i] = w;
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(g->adj, adj.data(), (size_t)qb * r * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(g->deg, deg.data(), (size_t)qb * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    if (jobs.empty()) return 0;
+    // a base node meets its queries in queries_order; a query listed twice by one node is applied twice in a row (:353)
+    std::sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) {
+        if (x.base != y.base) return x.base < y.base;
+        if (x.qrank != y.qrank) return x.qrank < y.qrank;
+        return x.occ < y.occ;
+    });
+    std::vector<uint32_t> targets, offs, srcs;
+    for (size_t i = 0; i < jobs.size(); i++) {
+        if (targets.empty() || targets.back() != jobs[i].base) { targets.push_back(jobs[i].base); offs.push_back((uint32_t)i); }
+        srcs.push_back(jobs[i].query);
+    }
+    offs.push_back((uint32_t)jobs.size());
+    DevBuf d_tg, d_off, d_src;
+    if (d_tg.ensure(targets.size() * 4) || d_off.ensure(offs.size() * 4) || d_src.ensure(srcs.size() * 4)) return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(d_tg.p, targets.data(), targets.size() * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(d_src.p, srcs.data(), srcs.size() * 4, hipMemcpyHostToDevice, st));
+    StitchArgs sa{};
+    sa.base = b->dev; sa.d = (int)b->d; sa.adj = g->adj; sa.deg = g->deg; sa.r = (int)r;
+    sa.targets = d_tg.as<uint32_t>(); sa.src_off = d_off.as<uint32_t>(); sa.srcs = d_src.as<uint32_t>();
+    sa.max_add = (int)std::min<uint64_t>(cfg->max_add_per_stitch_iter, 1u << 20);
+    hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)targets.size()), dim3(GB_THREADS), (size_t)((b->d * 2 + 15) & ~(size_t)15), st, sa);
+    MSE_HIP_TRY(hipGetLastError());
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* cand_scores, size_t n_cand, uint32_t p,
+                     const mse_build_config* cfg, uint32_t* neigh, size_t* n_neigh) {
+    if (!s || !s->base || !cfg || !neigh || !n_neigh || (n_cand && (!cand_ids || !cand_scores))) return fail("robust_prune: null argument");
+    const mse_base* b = s->base;
+    if (cfg->r == 0 || cfg->r > GB_RMAX) return fail("robust_prune: r must be 1..64");
+    if (cfg->maxc == 0 || cfg->maxc > GB_CMAX) return fail("robust_prune: maxc must be 1..1024");
+    if (b->d % 32 || b->d > 4096) return fail("robust_prune: vector width must be a multiple of 32");
+    if (n_cand > 0x7fffffffull) return fail("robust_prune: too many candidates");
+    for (size_t i = 0; i < n_cand; i++)
+        if (cand_ids[i] >= b->n) return fail("robust_prune: candidate out of range");
+    hipStream_t st = s->stream;
+    DevBuf ci, cs, out;
+    if (ci.ensure(n_cand * 4 + 16) || cs.ensure(n_cand * 8 + 16) || out.ensure((GB_RMAX + 1) * 4)) return -1;
+    if (n_cand) {
+        MSE_HIP_TRY(hipMemcpyAsync(ci.p, cand_ids, n_cand * 4, hipMemcpyHostToDevice, st));
+        MSE_HIP_TRY(hipMemcpyAsync(cs.p, cand_scores, n_cand * 8, hipMemcpyHostToDevice, st));
+    }
+    if (set_lds(prune_only_kernel)) return -1;
+    PruneParams pp{b->dev, (int)b->d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, (int)cfg->r, (int)cfg->saturate_graph};
+    hipLaunchKernelGGL(prune_only_kernel, dim3(1), dim3(GB_THREADS), graph_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(),
+                       (int)n_cand, (int)cfg->maxc, p, out.as<uint32_t>(), out.as<uint32_t>() + GB_RMAX);
+    MSE_HIP_TRY(hipGetLastError());
+    uint32_t h[GB_RMAX + 1];
+    MSE_HIP_TRY(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    *n_neigh = h[GB_RMAX];
+    for (uint32_t i = 0; i < h[GB_RMAX]; i++) neigh[i] = h[i];
+    return 0;
+}
+
+int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* starts, const uint16_t* queries, size_t nq,
+                           size_t search_list, int base_vectors_only, uint32_t query_breakpoint, uint32_t* buf_ids,
+                           int64_t* buf_scores, uint32_t* buf_len, uint32_t* n_distances) {
+    if (!s || !s->base || !g || !starts || !queries || !buf_ids || !buf_scores || !buf_len || !n_distances)
+        return fail("graph_search_batch: null argument");
+    if (nq == 0) return 0;
+    const mse_base* b = s->base;
+    if (g->n != b->n) return fail("graph_search_batch: graph and vectors differ in length");
+    if (search_list == 0 || search_list > GB_LMAX) return fail("graph_search_batch: search_list must be 1..1024");
+    if (g->max_deg > GB_RMAX) return fail("graph_search_batch: at most 64 neighbours per node");
+    if (b->d % 32 || b->d > 4096) return fail("graph_search_batch: vector width must be a multiple of 32");
+    for (size_t q = 0; q < nq; q++)
+        if (starts[q] >= b->n) return fail("graph_search_batch: start node out of range");
+    hipStream_t st = s->stream;
+    const size_t d = b->d, words = (b->n + 31) / 32;
+    DevBuf dq, dst, bm, oi, os, cnt;
+    if (dq.ensure(nq * d * 2) || dst.ensure(nq * 4) || bm.ensure(nq * words * 4) || oi.ensure(nq * search_list * 4) ||
+        os.ensure(nq * search_list * 8) || cnt.ensure(nq * 8 + 16))
+        return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
+    MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 4, st));
+    MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 8 + 16, st));
+    if (set_lds(graph_search_kernel<false>)) return -1;
+    GraphArgs a{};
+    a.base = b->dev; a.n = (uint32_t)b->n; a.d = (int)d;
+    a.adj = g->adj; a.deg = g->deg; a.r = (int)g->max_deg;
+    a.points = dst.as<uint32_t>(); a.queries = dq.as<uint16_t>();
+    a.qb = query_breakpoint; a.base_only = base_vectors_only;
+    a.L = (int)search_list;
+    a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
+    a.out_ids = oi.as<uint32_t>(); a.out_sc = os.as<long long>(); a.out_len = cnt.as<uint32_t>(); a.out_dist = cnt.as<uint32_t>() + nq;
+    a.err = cnt.as<uint32_t>() + 2 * nq;
+    hipLaunchKernelGGL(graph_search_kernel<false>, dim3((unsigned)nq), dim3(GB_THREADS), graph_lds_bytes((int)d), st, a);
+    MSE_HIP_TRY(hipGetLastError());
+    uint32_t err = 0;
+    MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(buf_len, a.out_len, nq * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(n_distances, a.out_dist, nq * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    if (err & 1u) return fail("graph_search_batch: a graph edge points outside the index");
+    return 0;
+}
+
+}  // extern "C"

@@ -85,3 +85,10 @@ struct mse_codes {
     uint8_t* desc = nullptr;     // device [n][n_desc] or null
     size_t n = 0, code_size = 0, n_desc = 0;
 };
+
+struct mse_graph {
+    uint32_t* adj = nullptr;   // device [n][max_deg]
+    uint32_t* deg = nullptr;   // device [n]
+    uint8_t* has_url = nullptr;  // device [n] or null (= all)
+    size_t n = 0, max_deg = 0;
+};

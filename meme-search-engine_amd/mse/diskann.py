@@ -191,3 +191,78 @@ def greedy_search(searcher: Searcher, start, base_vectors_only, query, graph: In
                                       graph.adj.shape[1], int(start), _p(q, C.c_uint16), int(bool(base_vectors_only)),
                                       int(query_breakpoint), buf._h, C.byref(nd)), "greedy_search")
     return buf, int(nd.value)
+
+
+# ---- Vamana graph build on the device (diskann/src/lib.rs:213-389; src/generate_index_shard.rs:85-133) -------------
+
+def IndexBuildConfig(r=64, l=192, maxc=750, alpha=65536, query_alpha=65536, saturate_graph=False, query_breakpoint=0xFFFFFFFF,
+                     max_add_per_stitch_iter=16):
+    """IndexBuildConfig (lib.rs:42-52) with generate_index_shard's defaults (:22-33,85-94)."""
+    return ffi.BuildConfig(r, l, maxc, alpha, query_alpha, int(bool(saturate_graph)), query_breakpoint, max_add_per_stitch_iter)
+
+
+class BuildGraph:
+    """The graph under construction, resident in HBM (IndexGraph::empty + the build passes)."""
+
+    def __init__(self, n, r, graph: IndexGraph = None):
+        if graph is not None:
+            assert graph.adj.shape == (n, r)
+            self._h = check_ptr(ffi.lib().mse_graph_from_host(_p(graph.adj, C.c_uint32), _p(graph.deg, C.c_uint32), n, r, None),
+                                "mse_graph_from_host")
+        else:
+            self._h = check_ptr(ffi.lib().mse_graph_new(n, r), "mse_graph_new")
+        self.n, self.r = n, r
+
+    def random_fill(self, seed, r=None):
+        """random_fill_graph (lib.rs:376-389) from a counter-based generator (a seed names one graph)."""
+        check(ffi.lib().mse_graph_random_fill(self._h, int(seed), self.r if r is None else r), "graph_random_fill")
+
+    def build(self, searcher: Searcher, order, medioid, config, batch=1024):
+        """build_graph (lib.rs:287-324); `order` = the shuffled point ids (sigmas); batch = 1 is the sequential form."""
+        o = np.ascontiguousarray(order, np.uint32)
+        check(ffi.lib().mse_build_graph(searcher._h, self._h, _p(o, C.c_uint32), o.size, int(batch), int(medioid), C.byref(config)),
+              "build_graph")
+
+    def robust_stitch(self, searcher: Searcher, queries_order, config):
+        """robust_stitch (lib.rs:326-374)."""
+        o = np.ascontiguousarray(queries_order, np.uint32)
+        check(ffi.lib().mse_robust_stitch(searcher._h, self._h, _p(o, C.c_uint32), C.byref(config)), "robust_stitch")
+
+    def to_host(self) -> IndexGraph:
+        adj, deg = np.empty((self.n, self.r), np.uint32), np.empty(self.n, np.uint32)
+        check(ffi.lib().mse_graph_to_host(self._h, _p(adj, C.c_uint32), _p(deg, C.c_uint32)), "graph_to_host")
+        return IndexGraph(adj, deg)
+
+    def search_batch(self, searcher: Searcher, starts, queries, l, base_vectors_only=False, query_breakpoint=0xFFFFFFFF):
+        """diskann::greedy_search (lib.rs:183-211) for a batch of queries on the device: list of (ids, scores, distances)."""
+        q = _bits(queries)
+        q = q.reshape(-1, q.shape[-1])
+        nq = q.shape[0]
+        st = np.ascontiguousarray(np.broadcast_to(np.asarray(starts, np.uint32), (nq,)))
+        bi, bs = np.empty((nq, l), np.uint32), np.empty((nq, l), np.int64)
+        bl, nd = np.empty(nq, np.uint32), np.empty(nq, np.uint32)
+        check(ffi.lib().mse_graph_search_batch(searcher._h, self._h, _p(st, C.c_uint32), _p(q, C.c_uint16), nq, int(l),
+                                               int(bool(base_vectors_only)), int(query_breakpoint), _p(bi, C.c_uint32),
+                                               _p(bs, C.c_int64), _p(bl, C.c_uint32), _p(nd, C.c_uint32)), "graph_search_batch")
+        return [(bi[i, :bl[i]].copy(), bs[i, :bl[i]].copy(), int(nd[i])) for i in range(nq)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            ffi.lib().mse_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def robust_prune(searcher: Searcher, cand_ids, cand_scores, p, config):
+    """robust_prune (lib.rs:227-285) on a candidate list; returns the new neighbour list."""
+    ci, cs = np.ascontiguousarray(cand_ids, np.uint32), np.ascontiguousarray(cand_scores, np.int64)
+    out = np.empty(int(config.r), np.uint32)
+    nn = C.c_size_t()
+    check(ffi.lib().mse_robust_prune(searcher._h, _p(ci, C.c_uint32), _p(cs, C.c_int64), ci.size, int(p), C.byref(config),
+                                     _p(out, C.c_uint32), C.byref(nn)), "robust_prune")
+    return out[:nn.value].copy()

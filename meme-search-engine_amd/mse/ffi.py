@@ -17,6 +17,13 @@ class MseError(RuntimeError):
 
 _lib = None
 
+
+class BuildConfig(C.Structure):
+    """mse_build_config == IndexBuildConfig (diskann/src/lib.rs:42-52)."""
+    _fields_ = [("r", C.c_uint64), ("l", C.c_uint64), ("maxc", C.c_uint64), ("alpha", C.c_int64), ("query_alpha", C.c_int64),
+                ("saturate_graph", C.c_uint32), ("query_breakpoint", C.c_uint32), ("max_add_per_stitch_iter", C.c_uint64)]
+
+
 u8p, u16p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)
 f32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int64)
 sz, vp = C.c_size_t, C.c_void_p
@@ -85,6 +92,15 @@ SIGNATURES = {
     "mse_graph_free": (None, [vp]),
     "mse_disk_search_batch": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
                                         u32p, u32p, u32p]),
+    "mse_graph_new": (vp, [sz, sz]),
+    "mse_graph_to_host": (C.c_int, [vp, u32p, u32p]),
+    "mse_graph_len": (sz, [vp]),
+    "mse_graph_max_degree": (sz, [vp]),
+    "mse_graph_random_fill": (C.c_int, [vp, C.c_uint32, sz]),
+    "mse_build_graph": (C.c_int, [vp, vp, u32p, sz, sz, C.c_uint32, vp]),
+    "mse_robust_stitch": (C.c_int, [vp, vp, u32p, vp]),
+    "mse_robust_prune": (C.c_int, [vp, u32p, i64p, sz, C.c_uint32, vp, u32p, C.POINTER(sz)]),
+    "mse_graph_search_batch": (C.c_int, [vp, vp, u32p, u16p, sz, sz, C.c_int, C.c_uint32, u32p, i64p, u32p, u32p]),
     "mse_dedup_visited": (C.c_int, [vp, u32p, sz, C.c_float, u8p]),
     "mse_select_shard": (C.c_int, [f32p, sz, sz, f32p, C.POINTER(sz)]),
     "mse_medioid": (C.c_int, [vp, u32p]),

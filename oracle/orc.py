@@ -21,6 +21,17 @@ def build(force=False):
     return _SO
 
 
+class BuildConfig(C.Structure):
+    """IndexBuildConfig (diskann/src/lib.rs:42-52); defaults of generate_index_shard.rs:22-33,85-94."""
+    _fields_ = [("r", C.c_uint64), ("l", C.c_uint64), ("maxc", C.c_uint64), ("alpha", C.c_int64), ("query_alpha", C.c_int64),
+                ("saturate_graph", C.c_uint32), ("query_breakpoint", C.c_uint32), ("max_add_per_stitch_iter", C.c_uint64)]
+
+    @classmethod
+    def make(cls, r=64, l=192, maxc=750, alpha=65536, query_alpha=65536, saturate_graph=False, query_breakpoint=0xFFFFFFFF,
+             max_add_per_stitch_iter=16):
+        return cls(r, l, maxc, alpha, query_alpha, int(saturate_graph), query_breakpoint, max_add_per_stitch_iter)
+
+
 _lib = None
 
 
@@ -82,6 +93,12 @@ def lib():
             "orc_total_embedding": (None, [u16p, f32p, sz, sz, f32p]),
             "orc_gen_row_ints": (None, [C.c_uint32, C.c_uint64, sz, i32p]),
             "orc_gen_rows_f16": (None, [C.c_uint32, C.c_uint64, sz, sz, u16p]),
+            "orc_greedy_search_visited": (sz, [u16p, sz, sz, u32p, u32p, sz, C.c_uint32, u16p, C.c_int, C.c_uint32, C.c_void_p,
+                                               u32p, i64p, sz]),
+            "orc_robust_prune": (sz, [u16p, sz, u32p, i64p, sz, C.c_uint32, C.POINTER(BuildConfig), u32p]),
+            "orc_build_graph": (None, [u16p, sz, sz, u32p, u32p, u32p, sz, sz, C.c_uint32, C.POINTER(BuildConfig)]),
+            "orc_robust_stitch": (None, [u16p, sz, sz, u32p, u32p, u32p, C.POINTER(BuildConfig)]),
+            "orc_random_fill_graph": (None, [C.c_uint32, sz, sz, u32p, u32p]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -389,3 +406,49 @@ def gen_row_ints(seed, row, d=1152):
     out = np.empty(d, np.int32)
     lib().orc_gen_row_ints(seed, row, d, _p(out, C.c_int32))
     return out
+
+
+# ---- Vamana graph build (diskann/src/lib.rs:213-389) -----------------------------------
+
+def greedy_search_visited(vecs, adj, deg, start, query, cap, base_vectors_only=False, query_breakpoint=0xFFFFFFFF):
+    """lib.rs:183-211 keeping scratch.visited_list: (buffer, visited ids, visited scores)."""
+    vecs, adj, deg, query = _c(vecs, np.uint16), _c(adj, np.uint32), _c(deg, np.uint32), _c(query, np.uint16)
+    nb = NeighbourBuffer(cap)
+    n, d = vecs.shape
+    vi, vs = np.empty(n, np.uint32), np.empty(n, np.int64)
+    nv = lib().orc_greedy_search_visited(_p(vecs, C.c_uint16), n, d, _p(adj, C.c_uint32), _p(deg, C.c_uint32), adj.shape[1],
+                                         start, _p(query, C.c_uint16), int(base_vectors_only), query_breakpoint, nb._h,
+                                         _p(vi, C.c_uint32), _p(vs, C.c_int64), n)
+    return nb, vi[:nv].copy(), vs[:nv].copy()
+
+
+def robust_prune(vecs, cand_ids, cand_scores, p, cfg):
+    vecs, ci, cs = _c(vecs, np.uint16), _c(cand_ids, np.uint32), _c(cand_scores, np.int64)
+    out = np.empty(int(cfg.r), np.uint32)
+    nn = lib().orc_robust_prune(_p(vecs, C.c_uint16), vecs.shape[1], _p(ci, C.c_uint32), _p(cs, C.c_int64), ci.size, p,
+                                C.byref(cfg), _p(out, C.c_uint32))
+    return out[:nn].copy()
+
+
+def build_graph(vecs, adj, deg, order, medioid, cfg, batch=1):
+    """In place on adj [n][r] / deg [n]."""
+    vecs, order = _c(vecs, np.uint16), _c(order, np.uint32)
+    assert adj.dtype == np.uint32 and deg.dtype == np.uint32 and adj.flags.c_contiguous and adj.shape[1] == cfg.r
+    n, d = vecs.shape
+    lib().orc_build_graph(_p(vecs, C.c_uint16), n, d, _p(adj, C.c_uint32), _p(deg, C.c_uint32), _p(order, C.c_uint32),
+                          order.size, batch, medioid, C.byref(cfg))
+
+
+def robust_stitch(vecs, adj, deg, queries_order, cfg):
+    vecs, qo = _c(vecs, np.uint16), _c(queries_order, np.uint32)
+    assert adj.dtype == np.uint32 and deg.dtype == np.uint32 and adj.flags.c_contiguous and adj.shape[1] == cfg.r
+    n, d = vecs.shape
+    assert qo.size == n - cfg.query_breakpoint
+    lib().orc_robust_stitch(_p(vecs, C.c_uint16), n, d, _p(adj, C.c_uint32), _p(deg, C.c_uint32), _p(qo, C.c_uint32), C.byref(cfg))
+
+
+def random_fill_graph(seed, n, r, adj=None, deg=None):
+    if adj is None:
+        adj, deg = np.zeros((n, r), np.uint32), np.zeros(n, np.uint32)
+    lib().orc_random_fill_graph(seed, n, r, _p(adj, C.c_uint32), _p(deg, C.c_uint32))
+    return adj, deg

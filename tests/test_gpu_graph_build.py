@@ -1,0 +1,166 @@
+"""Parity of the device Vamana build (diskann/src/lib.rs:183-389) with the CPU oracle: bit-exact graphs."""
+import numpy as np
+import pytest
+
+from conftest import SEED_BASE, SEED_QUERY
+from test_gpu_pq_index_graph import clustered_rows
+
+pytestmark = pytest.mark.gpu
+D = 1152
+
+
+def rows(orc, n, clustered=True, seed=0):
+    if not clustered:
+        return orc.gen_rows_f16(SEED_BASE, 0, n)
+    return orc.f16_bits(clustered_rows(orc, n, n_centres=max(8, n // 60), noise=0.5, seed=seed))
+
+
+def cfg_pair(orc, mse, **kw):
+    return orc.BuildConfig.make(**kw), mse.IndexBuildConfig(**kw)
+
+
+def test_random_fill_matches_oracle(gpu, mse, orc):
+    n, r = 5000, 64
+    g = mse.BuildGraph(n, r)
+    g.random_fill(0xABC)
+    h = g.to_host()
+    adj, deg = orc.random_fill_graph(0xABC, n, r)
+    assert np.array_equal(h.deg, deg) and np.array_equal(h.adj, adj)
+    assert (deg == r).all() and all(len(set(row)) == r for row in adj[:200])
+    # a partly filled list is topped up, not rebuilt
+    adj2, deg2 = np.zeros((n, r), np.uint32), np.zeros(n, np.uint32)
+    adj2[:, 0] = 7
+    deg2[:] = 1
+    g2 = mse.BuildGraph(n, r, mse.IndexGraph(adj2, deg2))
+    g2.random_fill(5)
+    h2 = g2.to_host()
+    a3, d3 = orc.random_fill_graph(5, n, r, adj2.copy(), deg2.copy())
+    assert (h2.deg == r).all() and np.array_equal(h2.adj, a3) and (h2.adj[:, 0] == 7).all()
+
+
+@pytest.mark.parametrize("base_only", [False, True])
+def test_graph_search_batch_matches_oracle(gpu, mse, orc, base_only):
+    n, r, L, nq = 4000, 24, 75, 40
+    vecs = rows(orc, n)
+    adj, deg = orc.random_fill_graph(11, n, r)
+    adj[5, 3] = adj[5, 1]   # an id listed twice in one list
+    deg[17] = 5             # a short list
+    qb = 3600 if base_only else 0xFFFFFFFF
+    queries = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    queries[:8] = vecs[100:108]
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    g = mse.BuildGraph(n, r, mse.IndexGraph(adj, deg))
+    starts = np.arange(nq, dtype=np.uint32) * 7
+    got = g.search_batch(s, starts, queries, L, base_vectors_only=base_only, query_breakpoint=qb)
+    for i in range(nq):
+        nb, dist = orc.greedy_search(vecs, adj, deg, int(starts[i]), queries[i], L, base_vectors_only=base_only, query_breakpoint=qb)
+        assert np.array_equal(got[i][0], nb.ids) and np.array_equal(got[i][1], nb.scores), i
+        assert got[i][2] == dist
+        if base_only:
+            assert (got[i][0][got[i][0] != starts[i]] < qb).all()
+
+
+@pytest.mark.parametrize("n_cand,alpha,saturate,p_is_query", [(300, 65536, False, False), (5000, 78643, False, False),
+                                                               (2500, 65536, True, False), (900, 70000, False, True), (0, 65536, False, False)])
+def test_robust_prune_matches_oracle(gpu, mse, orc, n_cand, alpha, saturate, p_is_query):
+    n = 3000
+    vecs = rows(orc, n, seed=3)
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    rng = np.random.default_rng(n_cand + alpha)
+    p = 2900 if p_is_query else 77
+    kw = dict(r=64, l=192, maxc=750, alpha=alpha, query_alpha=90000, saturate_graph=saturate, query_breakpoint=2800)
+    oc, mc = cfg_pair(orc, mse, **kw)
+    ids = rng.integers(0, n, n_cand).astype(np.uint32)   # duplicates and p itself occur, as in a real visited list
+    if n_cand:
+        ids[5] = p
+        ids[40] = ids[41]
+    scores = orc.score_rows(vecs, ids, vecs[p]) if n_cand else np.empty(0, np.int64)
+    want = orc.robust_prune(vecs, ids, scores, p, oc)
+    got = mse.robust_prune(s, ids, scores, p, mc)
+    assert np.array_equal(got, want)
+    if n_cand:
+        assert 0 < len(want) <= 64
+
+
+def build_both(orc, mse, vecs, r, order, med, passes, batch, seed=21, stitch_order=None):
+    n = len(vecs)
+    adj, deg = orc.random_fill_graph(seed, n, r)
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    g = mse.BuildGraph(n, r)
+    g.random_fill(seed)
+    for kw in passes:
+        oc, mc = cfg_pair(orc, mse, **kw)
+        orc.build_graph(vecs, adj, deg, order, med, oc, batch)
+        g.build(s, order, med, mc, batch)
+    if stitch_order is not None:
+        orc.robust_stitch(vecs, adj, deg, stitch_order, oc)
+        g.robust_stitch(s, stitch_order, mc)
+    return adj, deg, g, s
+
+
+def test_build_graph_sequential_matches_oracle(gpu, mse, orc):
+    """batch = 1: the reference's single-threaded loop (lib.rs:294,297), graph equal edge for edge."""
+    n, r = 700, 16
+    vecs = rows(orc, n, seed=5)
+    order = np.random.default_rng(1).permutation(n).astype(np.uint32)
+    med = int(orc.medioid(vecs))
+    adj, deg, g, _ = build_both(orc, mse, vecs, r, order, med, [dict(r=r, l=40, maxc=90)], 1)
+    h = g.to_host()
+    assert np.array_equal(h.deg, deg)
+    for i in range(n):
+        assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), i
+    assert deg.max() <= r and deg.min() > 0
+
+
+def test_build_graph_batched_two_passes_matches_oracle(gpu, mse, orc):
+    """Batched form, two passes (alpha 1.0 then 1.2, generate_index_shard.rs:113-127): equal to the oracle's batched form."""
+    n, r = 5000, 32
+    vecs = rows(orc, n, seed=6)
+    order = np.random.default_rng(2).permutation(n).astype(np.uint32)
+    med = int(orc.medioid(vecs))
+    passes = [dict(r=r, l=64, maxc=300), dict(r=r, l=64, maxc=300, alpha=78643)]
+    adj, deg, g, s = build_both(orc, mse, vecs, r, order, med, passes, 128)
+    h = g.to_host()
+    assert np.array_equal(h.deg, deg)
+    for i in range(n):
+        assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), i
+    # the graph is navigable: recall@1 of self-queries (the reference's harness, diskann/src/main.rs:117-136)
+    qi = np.arange(0, n, 25)
+    res = g.search_batch(s, med, vecs[qi], 64)
+    assert np.mean([res[k][0][0] == qi[k] for k in range(len(qi))]) > 0.85
+
+
+def test_build_graph_with_queries_and_stitch_matches_oracle(gpu, mse, orc):
+    """OOD-DiskANN variant: query nodes behind query_breakpoint, saturated lists for them, then robust_stitch."""
+    nb_, nq_, r = 1800, 200, 16
+    n = nb_ + nq_
+    vecs = np.concatenate([rows(orc, nb_, seed=8), orc.gen_rows_f16(SEED_QUERY, 0, nq_)])
+    order = np.random.default_rng(3).permutation(n).astype(np.uint32)
+    qorder = (nb_ + np.random.default_rng(4).permutation(nq_)).astype(np.uint32)
+    med = int(orc.medioid(vecs[:nb_]))
+    kw = dict(r=r, l=48, maxc=120, query_alpha=70000, query_breakpoint=nb_, max_add_per_stitch_iter=3)
+    adj, deg, g, _ = build_both(orc, mse, vecs, r, order, med, [kw], 64, stitch_order=qorder)
+    h = g.to_host()
+    assert np.array_equal(h.deg, deg)
+    for i in range(n):
+        assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), i
+    assert deg.max() <= r
+
+
+def test_build_graph_rejects_bad_arguments(gpu, mse, orc):
+    n, r = 300, 8
+    vecs = rows(orc, n, clustered=False)
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    g = mse.BuildGraph(n, r)
+    g.random_fill(1)
+    with pytest.raises(mse.MseError):
+        g.build(s, np.arange(n, dtype=np.uint32), 0, mse.IndexBuildConfig(r=16, l=32, maxc=50))      # r != stride
+    with pytest.raises(mse.MseError):
+        g.build(s, np.array([n], np.uint32), 0, mse.IndexBuildConfig(r=r, l=32, maxc=50))            # point out of range
+    with pytest.raises(mse.MseError):
+        g.build(s, np.arange(n, dtype=np.uint32), 0, mse.IndexBuildConfig(r=r, l=4096, maxc=50))     # list too long
+    bad = np.zeros((n, r), np.uint32)
+    bad[3, 0] = n + 5
+    g2 = mse.BuildGraph(n, r, mse.IndexGraph(bad, np.full(n, r, np.uint32)))
+    with pytest.raises(mse.MseError):
+        g2.build(s, np.arange(n, dtype=np.uint32), 0, mse.IndexBuildConfig(r=r, l=32, maxc=50))

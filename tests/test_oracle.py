@@ -468,3 +468,166 @@ def test_score_model_formula(orc):
     h = (up.astype(np.float64) @ x.T.astype(np.float64)) + b[:, None]
     want = ((down.astype(np.float64) @ (h / (1 + np.exp(-h)))) * (d / hdim)).T        # score_model.rs:21-29
     assert np.allclose(orc.score_batch(up, b, down, x), want, rtol=2e-5, atol=2e-5)
+
+
+# ---- Vamana build (diskann/src/lib.rs:183-389): literal Python restatement vs the C oracle ------------------------
+
+I64_MIN = -(1 << 63)
+
+
+def py_greedy_search(orc, vecs, lists, start, query, cap, base_only, qb):
+    """lib.rs:183-211 with sets and lists; returns (buffer ids, visited_list)."""
+    state, insert, next_unvisited = python_nb(cap)
+    visited, visited_list = {start}, []
+    insert(start, orc.fast_dot(query, vecs[start]))
+    while True:
+        pt = next_unvisited()
+        if pt is None:
+            break
+        pre = []
+        for nb in lists[pt]:
+            fresh = nb not in visited
+            visited.add(nb)
+            if fresh and not (base_only and nb >= qb):
+                pre.append(nb)
+        for nb in pre:
+            s = orc.fast_dot(query, vecs[nb])
+            insert(nb, s)
+            visited_list.append((nb, s))
+    return state["ids"], visited_list
+
+
+def py_robust_prune(orc, vecs, cands, p, cfg):
+    """lib.rs:227-285, statement by statement (the sort is made stable: see the oracle's note on :233)."""
+    cands = sorted(cands, key=lambda c: -c[1])[:cfg["maxc"]]
+    cands = [list(c) for c in cands]
+    neigh, ci = [], 0
+    while len(neigh) < cfg["r"] and ci < len(cands):
+        p_star, p_star_score = cands[ci]
+        ci += 1
+        if p_star == p or p_star_score == I64_MIN:
+            continue
+        neigh.append(p_star)
+        scratch = [(i, cands[i][0]) for i in range(ci + 1, len(cands)) if cands[i][1] != I64_MIN]
+        for i, p_prime in scratch:
+            s = orc.fast_dot(vecs[p_prime], vecs[p_star])
+            a = cfg["query_alpha"] if p_prime >= cfg["qb"] else cfg["alpha"]
+            if (a * s) >> 16 >= cands[i][1]:
+                cands[i][1] = I64_MIN
+    if cfg["saturate"] or p >= cfg["qb"]:
+        for cid, _ in cands:
+            if len(neigh) == cfg["r"]:
+                break
+            if cid not in neigh:
+                neigh.append(cid)
+    return neigh
+
+
+def py_build_graph(orc, vecs, lists, order, medioid, cfg):
+    """lib.rs:287-324, the single-threaded form kept in its comments (:294,297)."""
+    for sigma in order:
+        is_query = sigma >= cfg["qb"]
+        _, vl = py_greedy_search(orc, vecs, lists, medioid, vecs[sigma], cfg["l"], is_query, cfg["qb"])
+        vl += [(n, orc.fast_dot(vecs[sigma], vecs[n])) for n in lists[sigma]]
+        lists[sigma] = py_robust_prune(orc, vecs, vl, sigma, cfg)
+        for nb in list(lists[sigma]):
+            nn = lists[nb]
+            if len(nn) == cfg["r"]:
+                c = [(x, orc.fast_dot(vecs[nb], vecs[x])) for x in nn] + [(sigma, orc.fast_dot(vecs[nb], vecs[sigma]))]
+                lists[nb] = py_robust_prune(orc, vecs, c, nb, cfg)
+            elif sigma not in nn and len(nn) < cfg["r"]:
+                nn.append(sigma)
+
+
+def py_robust_stitch(orc, vecs, lists, queries_order, cfg):
+    """lib.rs:326-374, queries taken one after another."""
+    qb, n = cfg["qb"], len(lists)
+    in_edges = [[] for _ in range(n - qb)]
+    for b in range(qb):
+        keep = []
+        for e in lists[b]:
+            if e >= qb:
+                in_edges[e - qb].append(b)
+            else:
+                keep.append(e)
+        lists[b] = keep
+    for q in queries_order:
+        for b in in_edges[q - qb]:
+            cands = sorted([(x, orc.fast_dot(vecs[b], vecs[x])) for x in lists[q]], key=lambda c: -c[1])
+            added = 0
+            for x, _ in cands:
+                if added >= cfg["max_add"] or len(lists[b]) >= cfg["r"]:
+                    break
+                if x in lists[b]:
+                    continue
+                lists[b].append(x)
+                added += 1
+
+
+def _as_lists(adj, deg):
+    return [[int(x) for x in adj[i, :deg[i]]] for i in range(len(deg))]
+
+
+@pytest.mark.parametrize("qb_frac,saturate,alpha", [(None, False, 65536), (0.85, False, 78643), (None, True, 65536)])
+def test_build_graph_against_literal_restatement(orc, qb_frac, saturate, alpha):
+    rng = np.random.default_rng(77)
+    n, d, r = 260, 64, 6
+    centres = rng.standard_normal((12, d))
+    x = centres[rng.integers(0, 12, n)] + 0.6 * rng.standard_normal((n, d))
+    vecs = orc.f16_bits((x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32))
+    qb = int(n * qb_frac) if qb_frac else 0xFFFFFFFF
+    adj, deg = orc.random_fill_graph(9, n, r)
+    deg[3] = 2                 # a list that is not full: the push branch of the back-edge step
+    adj[8, 1] = adj[8, 0]      # an id listed twice
+    order = rng.permutation(n).astype(np.uint32)
+    med = int(orc.medioid(vecs))
+    cfg = dict(r=r, l=14, maxc=20, alpha=alpha, query_alpha=90000, saturate=saturate, qb=qb, max_add=2)
+    oc = orc.BuildConfig.make(r=r, l=14, maxc=20, alpha=alpha, query_alpha=90000, saturate_graph=saturate, query_breakpoint=qb,
+                              max_add_per_stitch_iter=2)
+    lists = _as_lists(adj, deg)
+    # one search + prune first, on the untouched graph
+    nb, vi, vs = orc.greedy_search_visited(vecs, adj, deg, med, vecs[5], 14, False, qb)
+    ids, vl = py_greedy_search(orc, vecs, lists, med, vecs[5], 14, False, qb)
+    assert list(nb.ids) == ids and list(zip(vi.tolist(), vs.tolist())) == vl
+    assert orc.robust_prune(vecs, vi, vs, 5, oc).tolist() == py_robust_prune(orc, vecs, vl, 5, cfg)
+    # the whole pass
+    py_build_graph(orc, vecs, lists, [int(v) for v in order], med, cfg)
+    orc.build_graph(vecs, adj, deg, order, med, oc, 1)
+    assert _as_lists(adj, deg) == lists
+    assert deg.max() <= r
+    if qb_frac:
+        qorder = (qb + rng.permutation(n - qb)).astype(np.uint32)
+        py_robust_stitch(orc, vecs, lists, [int(v) for v in qorder], cfg)
+        orc.robust_stitch(vecs, adj, deg, qorder, oc)
+        assert _as_lists(adj, deg) == lists
+
+
+def test_robust_prune_known_answers(orc):
+    """Hand-derivable cases: the candidate behind p_star escapes the test against it (lib.rs:240,250); p itself and
+    discarded candidates are skipped; alpha relaxes the discard rule."""
+    d = 64
+    e = np.zeros((6, d), np.float32)
+    e[0, 0] = 1.0                                   # p
+    e[1, 0], e[1, 1] = 0.9, 0.1                     # closest to p
+    e[2, 0], e[2, 1] = 0.8, 0.2                     # right behind it: never compared with candidate 1
+    e[3, 0], e[3, 1] = 0.7, 0.3                     # dot with row 1 = 0.66 < 0.7: kept at alpha 1, discarded at alpha 1.2
+    e[4, 0], e[4, 2] = 0.1, 0.9                     # dot with row 1 = 0.09 < 0.1: kept at alpha 1; 0.108 >= 0.1 at alpha 1.2
+    e[5, 0], e[5, 1] = 0.6, 0.8                     # dot with row 1 = 0.62 >= 0.6: discarded
+    vecs = orc.f16_bits(e)
+    ids = np.array([1, 2, 3, 4, 5, 0], np.uint32)
+    scores = orc.score_rows(vecs, ids, vecs[0])
+    cfg = orc.BuildConfig.make(r=4, l=8, maxc=10)
+    assert orc.robust_prune(vecs, ids, scores, 0, cfg).tolist() == [1, 2, 3, 4]
+    cfg12 = orc.BuildConfig.make(r=4, l=8, maxc=10, alpha=78643)
+    assert orc.robust_prune(vecs, ids, scores, 0, cfg12).tolist() == [1, 2]        # 2 survives only as the escapee
+    sat = orc.BuildConfig.make(r=4, l=8, maxc=10, alpha=78643, saturate_graph=True)
+    assert orc.robust_prune(vecs, ids, scores, 0, sat).tolist() == [1, 2, 0, 3]   # saturation refills in score order, p included
+    small = orc.BuildConfig.make(r=4, l=8, maxc=2)
+    assert orc.robust_prune(vecs, ids, scores, 0, small).tolist() == [1]           # maxc keeps (p, 1); p is skipped
+
+
+def test_random_fill_graph_properties(orc):
+    adj, deg = orc.random_fill_graph(4, 500, 12)
+    assert (deg == 12).all() and adj.max() < 500 and all(len(set(r)) == 12 for r in adj)
+    adj2, _ = orc.random_fill_graph(5, 500, 12)
+    assert not np.array_equal(adj, adj2)
