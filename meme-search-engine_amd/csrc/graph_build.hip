@@ -92,6 +92,7 @@ __device__ int wg_best_candidates(const uint32_t* vi, const long long* vs, int t
 struct PruneParams {
     const uint16_t* base; int d;
     uint32_t qb; long long alpha, qalpha; int r, saturate;
+    uint32_t n; uint32_t* err;
 };
 
 // robust_prune (lib.rs:227-285) after its sort/truncate: candidates c_*[0..nc) best first.  Called by the whole
@@ -112,6 +113,7 @@ __device__ int wg_robust_prune(const PruneParams& pp, uint32_t p, int nc, long l
         // :250-255 -- note the range starts one past the candidate behind p_star (candidate_index was already advanced)
         for (int i = ci + 1 + tid; i < nc; i += GB_THREADS)
             if (c_sc[i] != GB_MIN) s_live[atomicAdd(s_cnt, 1)] = (uint16_t)i;
+        if (p_star >= pp.n) { if (tid == 0) atomicOr(pp.err, 16u); break; }
         for (int e = tid; e < d / 8; e += GB_THREADS)
             reinterpret_cast<uint4*>(s_star)[e] = reinterpret_cast<const uint4*>(pp.base + (size_t)p_star * d)[e];
         __syncthreads();
@@ -119,7 +121,8 @@ __device__ int wg_robust_prune(const PruneParams& pp, uint32_t p, int nc, long l
         for (int e0 = 0; e0 < nlive; e0 += GB_THREADS / 4) {   // :257-271, one lane quad per surviving candidate
             const int e = e0 + (tid >> 2);
             const int i = s_live[e < nlive ? e : nlive - 1];
-            const uint32_t p_prime = c_id[i];
+            uint32_t p_prime = c_id[i];
+            if (p_prime >= pp.n) { atomicOr(pp.err, 32u); p_prime = 0; }
             const float f = quad_fast_dot_f32(pp.base + (size_t)p_prime * d, s_star, d);
             if (e < nlive && (tid & 3) == 0) {
                 const long long a = p_prime >= pp.qb ? pp.qalpha : pp.alpha;
@@ -161,30 +164,25 @@ struct GraphArgs {
     uint32_t* err;   // bit 0: an edge points outside the graph; bit 1: visited list overflow
 };
 
-__host__ __device__ inline size_t graph_lds_bytes(int d) {
-    return 2 * (size_t)((d * 2 + 15) & ~15) + GB_WIN * 16 + 64 * 12 + 64 * 4 + GB_CMAX * 2;
-}
+// LDS of the search kernel: the query row, the search list (sized by L, so the usual L = 192 leaves room for eight
+// workgroups per CU) and the pre-buffer; of the prune kernel: the p_star row, the sort window, the prune state.
+inline size_t search_lds_bytes(int d, int L) { return (size_t)((d * 2 + 15) & ~15) + (size_t)L * 16 + 64 * 12; }
+inline size_t prune_lds_bytes(int d) { return (size_t)((d * 2 + 15) & ~15) + GB_WIN * 16 + 64 * 4 + GB_CMAX * 2; }
 
-// BUILD: greedy_search from the medioid for point p (query = its own vector), merge_existing_neighbours, robust_prune;
-// the new list goes to the staging rows.  !BUILD: greedy_search for an outside query; the buffer is the output.
+// greedy_search (lib.rs:183-211), one workgroup per query.  BUILD: the query is point p's own vector, the start is the
+// medioid, the visited list is kept in HBM and merge_existing_neighbours (:215-221) is appended to it -- the candidate
+// list robust_prune starts from; out_dist = its length.  !BUILD: an outside query; the buffer is the output.
 template <bool BUILD>
 __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dq = (a.d * 2 + 15) & ~15;
     uint16_t* s_q = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* s_star = reinterpret_cast<uint16_t*>(smem + dq);
-    char* p0 = smem + 2 * dq;
-    long long* c_sc = reinterpret_cast<long long*>(p0); p0 += GB_WIN * 8;
-    uint32_t* c_id = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
-    uint32_t* c_pos = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
+    char* p0 = smem + dq;
+    long long* nb_sc = reinterpret_cast<long long*>(p0); p0 += (size_t)a.L * 8;
     long long* pre_sc = reinterpret_cast<long long*>(p0); p0 += 64 * 8;
-    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
-    uint32_t* s_neigh = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
-    uint16_t* s_live = reinterpret_cast<uint16_t*>(p0);
-    // the search list lives in the upper half of the sort window (dead once the search is over)
-    long long* nb_sc = c_sc + GB_WIN / 2;
-    uint32_t* nb_id = c_id + GB_WIN / 2;
-    uint32_t* nb_vis = c_pos + GB_WIN / 2;
+    uint32_t* nb_id = reinterpret_cast<uint32_t*>(p0); p0 += (size_t)a.L * 4;
+    uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p0); p0 += (size_t)a.L * 4;
+    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p0);
     __shared__ int s_len, s_next, s_npre, s_cnt, s_pt;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,38 +346,34 @@ __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
             else atomicOr(a.err, 2u);
         }
     }
-    __syncthreads();
-    uint32_t total = n_vl + (uint32_t)dg;
-    if (total > a.vl_cap) total = a.vl_cap;   // err bit 1 is set; the host repeats the batch with more room
-
-    // ---- robust_prune (lib.rs:227-285) ----
-    int nc = wg_best_candidates(vl_i, vl_s, (int)total, c_sc, c_id, c_pos);
-    if (nc > a.maxc) nc = a.maxc;
-    PruneParams pp{a.base, d, a.qb, a.alpha, a.qalpha, a.r, a.saturate};
-    const int nn = wg_robust_prune(pp, p, nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
-    if (tid < nn) a.out_ids[bi * a.r + tid] = s_neigh[tid];
-    if (tid == 0) a.out_len[bi] = (uint32_t)nn;
+    if (tid == 0) {
+        uint32_t total = n_vl + (uint32_t)dg;
+        if (total > a.vl_cap) total = a.vl_cap;   // err bit 1 is set; the host repeats the batch with more room
+        a.out_dist[bi] = total;
+    }
 }
 
-// robust_prune alone on a caller-supplied candidate list (one workgroup)
-__global__ __launch_bounds__(GB_THREADS) void prune_only_kernel(PruneParams pp, const uint32_t* ci, const long long* cs, int total, int maxc,
-                                                                uint32_t p, uint32_t* out_ids, uint32_t* out_len) {
+// robust_prune (lib.rs:227-285), one workgroup per point: candidate list b is (ci, cs)[b * stride ..][0..counts[b]),
+// the point is points[b]; the new list goes to staging row b.
+__global__ __launch_bounds__(GB_THREADS) void prune_kernel(PruneParams pp, const uint32_t* ci, const long long* cs, size_t stride,
+                                                           const uint32_t* counts, const uint32_t* points, int maxc, uint32_t* out_ids,
+                                                           uint32_t* out_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dq = (pp.d * 2 + 15) & ~15;
-    uint16_t* s_star = reinterpret_cast<uint16_t*>(smem + dq);
-    char* p0 = smem + 2 * dq;
+    uint16_t* s_star = reinterpret_cast<uint16_t*>(smem);
+    char* p0 = smem + dq;
     long long* c_sc = reinterpret_cast<long long*>(p0); p0 += GB_WIN * 8;
     uint32_t* c_id = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
     uint32_t* c_pos = reinterpret_cast<uint32_t*>(p0); p0 += GB_WIN * 4;
-    p0 += 64 * 12;
     uint32_t* s_neigh = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
     uint16_t* s_live = reinterpret_cast<uint16_t*>(p0);
     __shared__ int s_cnt;
-    int nc = wg_best_candidates(ci, cs, total, c_sc, c_id, c_pos);
+    const size_t b = blockIdx.x;
+    int nc = wg_best_candidates(ci + b * stride, cs + b * stride, (int)counts[b], c_sc, c_id, c_pos);
     if (nc > maxc) nc = maxc;
-    const int nn = wg_robust_prune(pp, p, nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
-    if ((int)threadIdx.x < nn) out_ids[threadIdx.x] = s_neigh[threadIdx.x];
-    if (threadIdx.x == 0) *out_len = (uint32_t)nn;
+    const int nn = wg_robust_prune(pp, points[b], nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
+    if ((int)threadIdx.x < nn) out_ids[b * pp.r + threadIdx.x] = s_neigh[threadIdx.x];
+    if (threadIdx.x == 0) out_len[b] = (uint32_t)nn;
 }
 
 __global__ void apply_lists_kernel(uint32_t* adj, uint32_t* deg, int r, const uint32_t* points, const uint32_t* staged, const uint32_t* staged_len,
@@ -396,6 +390,7 @@ struct BackArgs {
     uint32_t* adj; uint32_t* deg; int r;
     const uint32_t* targets; const uint32_t* src_off; const uint32_t* srcs;
     uint32_t qb; int maxc, saturate; long long alpha, qalpha;
+    uint32_t n; uint32_t* err;
 };
 
 // Back edges (lib.rs:311-322): workgroup b owns list targets[b] and applies its sources in order.
@@ -415,21 +410,24 @@ __global__ __launch_bounds__(GB_THREADS) void backedge_kernel(BackArgs a) {
     __syncthreads();
     if (tid < s_len) cur[tid] = a.adj[(size_t)t * a.r + tid];
     __syncthreads();
-    PruneParams pp{a.base, d, a.qb, a.alpha, a.qalpha, a.r, a.saturate};
+    PruneParams pp{a.base, d, a.qb, a.alpha, a.qalpha, a.r, a.saturate, a.n, a.err};
     int N = 2;
     while (N < a.r + 1) N <<= 1;
     for (uint32_t si = a.src_off[blockIdx.x]; si < a.src_off[blockIdx.x + 1]; si++) {
         const uint32_t p = a.srcs[si];
         const int len = s_len;
+        __syncthreads();   // everyone has the length before thread 0 may change it below
         if (len == a.r) {   // :314-318 -- the full list plus the newcomer, scored against the list's owner
             {
                 const int e = tid >> 2;
-                const uint32_t id = cur[e < len ? e : len - 1];
+                uint32_t id = cur[e < len ? e : len - 1];
+                if (id >= pp.n) { atomicOr(pp.err, 64u); id = 0; }
                 const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_t, d);
                 if (e < len && (tid & 3) == 0) { c_sc[e] = scale_dot_result(f); c_id[e] = id; c_pos[e] = (uint32_t)e; }
             }
             if (tid < 64) {
-                const float f = quad_fast_dot_f32(a.base + (size_t)p * d, s_t, d);
+                if (p >= pp.n) atomicOr(pp.err, 128u);
+                const float f = quad_fast_dot_f32(a.base + (size_t)(p >= pp.n ? 0 : p) * d, s_t, d);
                 if (tid == 0) { c_sc[len] = scale_dot_result(f); c_id[len] = p; c_pos[len] = (uint32_t)len; }
             }
             for (int e = len + 1 + tid; e < N; e += GB_THREADS) { c_sc[e] = GB_MIN; c_id[e] = 0xffffffffu; c_pos[e] = 0xffffffffu; }
@@ -625,14 +623,15 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     const int r = (int)cfg->r, d = (int)b->d;
     const size_t words = (b->n + 31) / 32;
     size_t vl_cap = std::max<size_t>(4096, 2 * cfg->l * cfg->r) + cfg->r;
-    DevBuf d_order, bm, vli, vls, stg, stg_len, err, d_tg, d_off, d_src;
-    if (d_order.ensure(n_order * 4) || bm.ensure(batch * words * 4) || vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8) ||
+    DevBuf d_order, bm, vli, vls, stg, stg_len, err, d_tg, d_off, d_src, cnts;
+    if (cnts.ensure(batch * 4) || d_order.ensure(n_order * 4) || bm.ensure(batch * words * 4) || vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8) ||
         stg.ensure(batch * r * 4) || stg_len.ensure(batch * 4) || err.ensure(4) || d_tg.ensure(batch * r * 4 + 4) ||
         d_off.ensure(batch * r * 4 + 8) || d_src.ensure(batch * r * 4 + 4))
         return -1;
     MSE_HIP_TRY(hipMemcpyAsync(d_order.p, order, n_order * 4, hipMemcpyHostToDevice, st));
-    if (set_lds(graph_search_kernel<true>)) return -1;
-    const size_t lds = graph_lds_bytes(d);
+    if (set_lds(graph_search_kernel<true>) || set_lds(prune_kernel)) return -1;
+    const size_t lds = search_lds_bytes(d, (int)cfg->l);
+    const PruneParams pp{b->dev, d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, r, (int)cfg->saturate_graph, (uint32_t)b->n, err.as<uint32_t>()};
     std::vector<uint32_t> h_stg(batch * r), h_len(batch), targets, offs, srcs;
     std::vector<uint64_t> edges;
     GraphArgs a{};
@@ -641,10 +640,11 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     a.medioid = medioid; a.qb = cfg->query_breakpoint;
     a.L = (int)cfg->l; a.maxc = (int)cfg->maxc; a.saturate = (int)cfg->saturate_graph; a.alpha = cfg->alpha; a.qalpha = cfg->query_alpha;
     a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
-    a.out_ids = stg.as<uint32_t>(); a.out_len = stg_len.as<uint32_t>();
+    a.out_dist = cnts.as<uint32_t>();
     a.err = err.as<uint32_t>();
     BackArgs ba{};
     ba.base = b->dev; ba.d = d; ba.adj = g->adj; ba.deg = g->deg; ba.r = r;
+    ba.n = (uint32_t)b->n; ba.err = err.as<uint32_t>();
     ba.qb = cfg->query_breakpoint; ba.maxc = (int)cfg->maxc; ba.saturate = (int)cfg->saturate_graph; ba.alpha = cfg->alpha; ba.qalpha = cfg->query_alpha;
     const size_t back_lds = 2 * (size_t)((d * 2 + 15) & ~15);
     for (size_t b0 = 0; b0 < n_order; b0 += batch) {
@@ -655,6 +655,9 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
             MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nb * words * 4, st));
             MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));
             hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GB_THREADS), lds, st, a);
+            MSE_HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(prune_kernel, dim3((unsigned)nb), dim3(GB_THREADS), prune_lds_bytes(d), st, pp, a.vl_ids, a.vl_sc, vl_cap,
+                               cnts.as<uint32_t>(), a.points, (int)cfg->maxc, stg.as<uint32_t>(), stg_len.as<uint32_t>());
             MSE_HIP_TRY(hipGetLastError());
             uint32_t e = 0;
             MSE_HIP_TRY(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
@@ -689,7 +692,10 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
         ba.targets = d_tg.as<uint32_t>(); ba.src_off = d_off.as<uint32_t>(); ba.srcs = d_src.as<uint32_t>();
         hipLaunchKernelGGL(backedge_kernel, dim3((unsigned)targets.size()), dim3(GB_THREADS), back_lds, st, ba);
         MSE_HIP_TRY(hipGetLastError());
+        uint32_t e2 = 0;
+        MSE_HIP_TRY(hipMemcpyAsync(&e2, err.p, 4, hipMemcpyDeviceToHost, st));
         MSE_HIP_TRY(hipStreamSynchronize(st));   // the host vectors above are reused by the next batch
+        if (e2) return fail("build_graph: internal error " + std::to_string(e2) + " (a candidate id outside the index)");
     }
     return 0;
 }
@@ -769,15 +775,19 @@ int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* c
         if (cand_ids[i] >= b->n) return fail("robust_prune: candidate out of range");
     hipStream_t st = s->stream;
     DevBuf ci, cs, out;
-    if (ci.ensure(n_cand * 4 + 16) || cs.ensure(n_cand * 8 + 16) || out.ensure((GB_RMAX + 1) * 4)) return -1;
+    if (ci.ensure(n_cand * 4 + 16) || cs.ensure(n_cand * 8 + 16) || out.ensure((GB_RMAX + 4) * 4)) return -1;
     if (n_cand) {
         MSE_HIP_TRY(hipMemcpyAsync(ci.p, cand_ids, n_cand * 4, hipMemcpyHostToDevice, st));
         MSE_HIP_TRY(hipMemcpyAsync(cs.p, cand_scores, n_cand * 8, hipMemcpyHostToDevice, st));
     }
-    if (set_lds(prune_only_kernel)) return -1;
-    PruneParams pp{b->dev, (int)b->d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, (int)cfg->r, (int)cfg->saturate_graph};
-    hipLaunchKernelGGL(prune_only_kernel, dim3(1), dim3(GB_THREADS), graph_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(),
-                       (int)n_cand, (int)cfg->maxc, p, out.as<uint32_t>(), out.as<uint32_t>() + GB_RMAX);
+    if (set_lds(prune_kernel)) return -1;
+    const uint32_t hdr[3] = {(uint32_t)n_cand, p, 0u};   // counts[0], points[0], error word
+    MSE_HIP_TRY(hipMemcpyAsync(out.as<uint32_t>() + GB_RMAX + 1, hdr, 12, hipMemcpyHostToDevice, st));
+    PruneParams pp{b->dev, (int)b->d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, (int)cfg->r, (int)cfg->saturate_graph, (uint32_t)b->n,
+                   out.as<uint32_t>() + GB_RMAX + 3};
+    hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(GB_THREADS), prune_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(), (size_t)0,
+                       out.as<uint32_t>() + GB_RMAX + 1, out.as<uint32_t>() + GB_RMAX + 2, (int)cfg->maxc, out.as<uint32_t>(),
+                       out.as<uint32_t>() + GB_RMAX);
     MSE_HIP_TRY(hipGetLastError());
     uint32_t h[GB_RMAX + 1];
     MSE_HIP_TRY(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -820,7 +830,7 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
     a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
     a.out_ids = oi.as<uint32_t>(); a.out_sc = os.as<long long>(); a.out_len = cnt.as<uint32_t>(); a.out_dist = cnt.as<uint32_t>() + nq;
     a.err = cnt.as<uint32_t>() + 2 * nq;
-    hipLaunchKernelGGL(graph_search_kernel<false>, dim3((unsigned)nq), dim3(GB_THREADS), graph_lds_bytes((int)d), st, a);
+    hipLaunchKernelGGL(graph_search_kernel<false>, dim3((unsigned)nq), dim3(GB_THREADS), search_lds_bytes((int)d, (int)search_list), st, a);
     MSE_HIP_TRY(hipGetLastError());
     uint32_t err = 0;
     MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
