@@ -633,7 +633,7 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     const size_t lds = search_lds_bytes(d, (int)cfg->l);
     const PruneParams pp{b->dev, d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, r, (int)cfg->saturate_graph, (uint32_t)b->n, err.as<uint32_t>()};
     std::vector<uint32_t> h_stg(batch * r), h_len(batch), targets, offs, srcs;
-    std::vector<uint64_t> edges;
+    std::vector<uint32_t> slot(b->n, 0xffffffffu), first_seen, counts, fill;
     GraphArgs a{};
     a.base = b->dev; a.n = (uint32_t)b->n; a.d = d;
     a.adj = g->adj; a.deg = g->deg; a.r = r;
@@ -673,19 +673,34 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
         hipLaunchKernelGGL(apply_lists_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, g->adj, g->deg, r, a.points, stg.as<uint32_t>(),
                            stg_len.as<uint32_t>(), (int)nb);
         MSE_HIP_TRY(hipGetLastError());
-        // back edges grouped by the list they touch, each group in (position in batch, position in list) order
-        edges.clear();
+        // back edges grouped by the list they touch, each group in (position in batch, position in list) order: a
+        // counting sort over the touched lists; lists with many newcomers go first (one workgroup works through them alone)
+        first_seen.clear(); counts.clear();
         for (size_t k = 0; k < nb; k++)
-            for (uint32_t j = 0; j < h_len[k]; j++) edges.push_back(((uint64_t)h_stg[k * r + j] << 32) | (uint64_t)(k * r + j));
-        if (edges.empty()) continue;
-        std::sort(edges.begin(), edges.end());
-        targets.clear(); offs.clear(); srcs.clear();
-        for (size_t i = 0; i < edges.size(); i++) {
-            const uint32_t t = (uint32_t)(edges[i] >> 32);
-            if (targets.empty() || targets.back() != t) { targets.push_back(t); offs.push_back((uint32_t)i); }
-            srcs.push_back(order[b0 + (size_t)(uint32_t)edges[i] / r]);
-        }
-        offs.push_back((uint32_t)edges.size());
+            for (uint32_t j = 0; j < h_len[k]; j++) {
+                const uint32_t t = h_stg[k * r + j];
+                if (slot[t] == 0xffffffffu) { slot[t] = (uint32_t)first_seen.size(); first_seen.push_back(t); counts.push_back(0); }
+                counts[slot[t]]++;
+            }
+        if (first_seen.empty()) continue;
+        targets.clear(); offs.clear();
+        uint32_t run = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (size_t i = 0; i < first_seen.size(); i++)
+                if ((counts[i] >= 4) == (pass == 0)) {
+                    slot[first_seen[i]] = (uint32_t)targets.size();
+                    targets.push_back(first_seen[i]); offs.push_back(run);
+                    run += counts[i];
+                }
+        offs.push_back(run);
+        srcs.resize(run);
+        fill.assign(targets.size(), 0);
+        for (size_t k = 0; k < nb; k++)
+            for (uint32_t j = 0; j < h_len[k]; j++) {
+                const uint32_t ti = slot[h_stg[k * r + j]];
+                srcs[offs[ti] + fill[ti]++] = order[b0 + k];
+            }
+        for (uint32_t t : targets) slot[t] = 0xffffffffu;
         MSE_HIP_TRY(hipMemcpyAsync(d_tg.p, targets.data(), targets.size() * 4, hipMemcpyHostToDevice, st));
         MSE_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, st));
         MSE_HIP_TRY(hipMemcpyAsync(d_src.p, srcs.data(), srcs.size() * 4, hipMemcpyHostToDevice, st));
