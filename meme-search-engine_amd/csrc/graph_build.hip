@@ -29,6 +29,7 @@ using namespace mse;
 namespace {
 
 constexpr int GB_THREADS = 256;
+constexpr int GS_THREADS = 128;   // search kernel: two waves per query, so that eight queries share a CU at its register budget
 constexpr int GB_LMAX = 1024;   // search list
 constexpr int GB_RMAX = 64;     // degree bound
 constexpr int GB_CMAX = 1024;   // maxc
@@ -166,14 +167,14 @@ struct GraphArgs {
 
 // LDS of the search kernel: the query row, the search list (sized by L, so the usual L = 192 leaves room for eight
 // workgroups per CU) and the pre-buffer; of the prune kernel: the p_star row, the sort window, the prune state.
-inline size_t search_lds_bytes(int d, int L) { return (size_t)((d * 2 + 15) & ~15) + (size_t)L * 16 + 64 * 12; }
+inline size_t search_lds_bytes(int d, int L) { return (size_t)((d * 2 + 15) & ~15) + (size_t)L * 16 + 64 * 16; }
 inline size_t prune_lds_bytes(int d) { return (size_t)((d * 2 + 15) & ~15) + GB_WIN * 16 + 64 * 4 + GB_CMAX * 2; }
 
 // greedy_search (lib.rs:183-211), one workgroup per query.  BUILD: the query is point p's own vector, the start is the
 // medioid, the visited list is kept in HBM and merge_existing_neighbours (:215-221) is appended to it -- the candidate
 // list robust_prune starts from; out_dist = its length.  !BUILD: an outside query; the buffer is the output.
 template <bool BUILD>
-__global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
+__global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dq = (a.d * 2 + 15) & ~15;
     uint16_t* s_q = reinterpret_cast<uint16_t*>(smem);
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
     long long* pre_sc = reinterpret_cast<long long*>(p0); p0 += 64 * 8;
     uint32_t* nb_id = reinterpret_cast<uint32_t*>(p0); p0 += (size_t)a.L * 4;
     uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p0); p0 += (size_t)a.L * 4;
-    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p0);
+    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
+    int* s_rank = reinterpret_cast<int*>(p0);
     __shared__ int s_len, s_next, s_npre, s_cnt, s_pt;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -197,22 +199,12 @@ __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
 
     {
         const uint16_t* qsrc = BUILD ? a.base + (size_t)p * d : a.queries + bi * d;
-        for (int e = tid; e < d / 8; e += GB_THREADS) reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(qsrc)[e];
+        for (int e = tid; e < d / 8; e += GS_THREADS) reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(qsrc)[e];
     }
     __syncthreads();
-    if (wave == 0) {   // :188-189
-        const float f = quad_fast_dot_f32(a.base + (size_t)start * d, s_q, d);
+    // NeighbourBuffer::next_unvisited (lib.rs:93-107) by lane 0 of wave 0; s_pt = the node to expand or -1
+    auto pop = [&]() {
         if (lane == 0) {
-            nb_id[0] = start; nb_sc[0] = scale_dot_result(f); nb_vis[0] = 0;
-            s_len = 1; s_next = 0;
-            atomicOr(&bm[start >> 5], 1u << (start & 31));
-        }
-    }
-    __syncthreads();
-
-    uint32_t n_vl = 0;   // wave 0: visited_list.len() == counters.distances
-    for (;;) {
-        if (tid == 0) {   // NeighbourBuffer::next_unvisited (lib.rs:93-107)
             const int cur = s_next;
             if (cur >= 0) {
                 const int len = s_len;
@@ -225,35 +217,55 @@ __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
                 s_pt = -1;
             }
         }
-        __syncthreads();
-        if (s_pt < 0) break;
-        const uint32_t pt = (uint32_t)s_pt;
+    };
+    if (wave == 0) {   // :188-189
+        const float f = quad_fast_dot_f32(a.base + (size_t)start * d, s_q, d);
+        if (lane == 0) {
+            nb_id[0] = start; nb_sc[0] = scale_dot_result(f); nb_vis[0] = 0;
+            s_len = 1; s_next = 0;
+            atomicOr(&bm[start >> 5], 1u << (start & 31));
+        }
+        pop();
+    }
 
+    // One step = expand one node.  Wave 0 owns the list: it takes the node, reads its neighbours and filters them
+    // through the visited bits; after the first barrier all four waves score the survivors; after the second, wave 0
+    // inserts them and takes the next node while the other waves already wait at the next step's first barrier.
+    uint32_t n_vl = 0;   // wave 0: visited_list.len() == counters.distances
+    for (;;) {
         if (wave == 0) {   // :194-200
-            int dg = (int)a.deg[pt];
-            if (dg > a.r) dg = a.r;
-            const uint32_t nb = lane < dg ? a.adj[(size_t)pt * a.r + lane] : 0xffffffffu;
-            bool cand = lane < dg;
-            if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
-            for (int l = 0; l < dg; l++) {   // an id listed twice: HashSet::insert accepts the first occurrence only
-                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
-                if (l < lane && o == nb) cand = false;
+            const int pti = s_pt;
+            if (pti < 0) {
+                if (lane == 0) s_npre = -1;
+            } else {
+                const uint32_t pt = (uint32_t)pti;
+                const uint32_t raw = lane < a.r ? a.adj[(size_t)pt * a.r + lane] : 0xffffffffu;   // row and length in one round trip
+                int dg = (int)a.deg[pt];
+                if (dg > a.r) dg = a.r;
+                const uint32_t nb = lane < dg ? raw : 0xffffffffu;
+                bool cand = lane < dg;
+                if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
+                for (int l = 0; l < dg; l++) {   // an id listed twice: HashSet::insert accepts the first occurrence only
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
+                    if (l < lane && o == nb) cand = false;
+                }
+                // a query node met while base_vectors_only is dropped whether or not it was seen before, so its bit is not needed
+                if (cand && base_only && nb >= a.qb) cand = false;
+                bool fresh = false;
+                if (cand) {
+                    const uint32_t old = atomicOr(&bm[nb >> 5], 1u << (nb & 31));
+                    fresh = !(old & (1u << (nb & 31)));
+                }
+                const unsigned long long m = __ballot(fresh);
+                        if (fresh) pre_id[__popcll(m & ((1ull << lane) - 1ull))] = nb;
+                if (lane == 0) s_npre = __popcll(m);
             }
-            // a query node met while base_vectors_only is dropped whether or not it was seen before, so its bit is not needed
-            if (cand && base_only && nb >= a.qb) cand = false;
-            bool fresh = false;
-            if (cand) {
-                const uint32_t old = atomicOr(&bm[nb >> 5], 1u << (nb & 31));
-                fresh = !(old & (1u << (nb & 31)));
-            }
-            const unsigned long long m = __ballot(fresh);
-            if (fresh) pre_id[__popcll(m & ((1ull << lane) - 1ull))] = nb;
-            if (lane == 0) s_npre = __popcll(m);
         }
         __syncthreads();
         const int npre = s_npre;
-        if (npre > 0) {   // :201-204, one lane quad per neighbour
-            const int e = tid >> 2;
+        if (npre < 0) break;
+        for (int e0 = 0; e0 < npre; e0 += GS_THREADS / 4) {   // :201-204, one lane quad per neighbour
+            const int e = e0 + (tid >> 2);
             const uint32_t id = pre_id[e < npre ? e : npre - 1];
             const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_q, d);
             if (e < npre && (tid & 3) == 0) pre_sc[e] = scale_dot_result(f);
@@ -270,59 +282,104 @@ __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
             }
             n_vl += (uint32_t)npre;
             int len = s_len, nu = s_next;
-            for (int ii = 0; ii < npre; ii++) {   // NeighbourBuffer::insert (lib.rs:117-147), in order
-                const uint32_t id = pre_id[ii];
-                const long long sc = pre_sc[ii];
-                if (len == cap && nb_sc[len - 1] > sc) continue;
-                // position by counting with 64 lanes; only a run of equal scores makes binary_search_by's probe sequence matter
-                int n_gt = 0, n_eq = 0, eq_pos = -1;
-                for (int b0 = 0; b0 < len; b0 += 64) {
-                    const int idx = b0 + lane;
-                    const long long v = idx < len ? nb_sc[idx] : 0;
-                    n_gt += __popcll(__ballot(idx < len && v > sc));
-                    const unsigned long long me = __ballot(idx < len && v == sc);
-                    if (me) {
-                        if (eq_pos < 0) eq_pos = b0 + __ffsll((long long)me) - 1;
-                        n_eq += __popcll(me);
+            // All newcomers at once.  While no two scores involved are equal, the order of the inserts does not matter:
+            // the list ends up as the best `cap` of old and new entries, and next_unvisited as the smaller of its old value
+            // and the slot the best newcomer took on arrival (every other insert lands at or behind that slot).  So each lane
+            // places one newcomer by two counts -- old entries above it (binary search) and newcomers above it -- and the old
+            // entries move up by the number of newcomers that go before them.  A tie anywhere, and the reference's loop is replayed.
+            const bool valid = lane < npre;
+            const long long my_sc = valid ? pre_sc[lane] : GB_MIN;
+            const uint32_t my_id = valid ? pre_id[lane] : 0u;
+            int lo = 0, hi = valid ? len : 0;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (nb_sc[mid] > my_sc) lo = mid + 1; else hi = mid;
+            }
+            bool tie = valid && lo < len && nb_sc[lo] == my_sc;
+            int r_new = 0;
+            for (int k = 0; k < npre; k++) {
+                const long long sk = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(my_sc >> 32), k) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)my_sc, k));
+                r_new += sk > my_sc;
+                tie |= valid && k != lane && sk == my_sc;
+            }
+            if (!__ballot(tie)) {
+                if (valid) s_rank[r_new] = lo;   // old entries above the newcomer of rank r_new; ascending in the rank
+                for (int c = (len - 1) / 64; c >= 0; c--) {   // highest entries first: nothing unread is overwritten
+                    const int i = c * 64 + lane;
+                    const bool act = i < len;
+                    long long osc = 0;
+                    uint32_t oid = 0, ovis = 0;
+                    if (act) { osc = nb_sc[i]; oid = nb_id[i]; ovis = nb_vis[i]; }
+                    int a0 = 0, b0 = npre;
+                    while (a0 < b0) {
+                        const int mid = (a0 + b0) >> 1;
+                        if (s_rank[mid] <= i) a0 = mid + 1; else b0 = mid;
                     }
+                    const int np = i + a0;
+                    if (act && a0 > 0 && np < cap) { nb_sc[np] = osc; nb_id[np] = oid; nb_vis[np] = ovis; }
                 }
-                int loc = 0;
-                if (n_eq == 0) {
-                    loc = n_gt;
-                } else if (n_eq == 1) {
-                    loc = eq_pos;
-                } else {
-                    int size = len, bs = 0;
-                    while (size > 1) {
-                        const int half = size / 2, mid = bs + half;
-                        bs = (sc > nb_sc[mid]) ? bs : mid;
-                        size -= half;
+                const int pos = lo + r_new;
+                if (valid && pos < cap) { nb_sc[pos] = my_sc; nb_id[pos] = my_id; nb_vis[pos] = 0; }
+                const int first = s_rank[0];
+                if (first < cap && (nu < 0 || first < nu)) nu = first;
+                len = len + npre < cap ? len + npre : cap;
+            } else {
+                for (int ii = 0; ii < npre; ii++) {   // NeighbourBuffer::insert (lib.rs:117-147), in order
+                    const uint32_t id = pre_id[ii];
+                    const long long sc = pre_sc[ii];
+                    if (len == cap && nb_sc[len - 1] > sc) continue;
+                    // position by counting with 64 lanes; only a run of equal scores makes binary_search_by's probe sequence matter
+                    int n_gt = 0, n_eq = 0, eq_pos = -1;
+                    for (int b0 = 0; b0 < len; b0 += 64) {
+                        const int idx = b0 + lane;
+                        const long long v = idx < len ? nb_sc[idx] : 0;
+                        n_gt += __popcll(__ballot(idx < len && v > sc));
+                        const unsigned long long me = __ballot(idx < len && v == sc);
+                        if (me) {
+                            if (eq_pos < 0) eq_pos = b0 + __ffsll((long long)me) - 1;
+                            n_eq += __popcll(me);
+                        }
                     }
-                    const long long c = nb_sc[bs];
-                    loc = (sc == c) ? bs : bs + (sc < c ? 1 : 0);
+                    int loc = 0;
+                    if (n_eq == 0) {
+                        loc = n_gt;
+                    } else if (n_eq == 1) {
+                        loc = eq_pos;
+                    } else {
+                        int size = len, bs = 0;
+                        while (size > 1) {
+                            const int half = size / 2, mid = bs + half;
+                            bs = (sc > nb_sc[mid]) ? bs : mid;
+                            size -= half;
+                        }
+                        const long long c = nb_sc[bs];
+                        loc = (sc == c) ? bs : bs + (sc < c ? 1 : 0);
+                    }
+                    if (loc < len && nb_id[loc] == id) continue;
+                    const int newlen = len < cap ? len + 1 : cap;
+                    for (int top = newlen - 1; top > loc; top -= 64) {
+                        const int idx = top - lane;
+                        const bool act = idx > loc;
+                        uint32_t mi = 0, mv = 0;
+                        long long ms = 0;
+                        if (act) { mi = nb_id[idx - 1]; ms = nb_sc[idx - 1]; mv = nb_vis[idx - 1]; }
+                        if (act) { nb_id[idx] = mi; nb_sc[idx] = ms; nb_vis[idx] = mv; }
+                    }
+                    if (lane == 0) { nb_id[loc] = id; nb_sc[loc] = sc; nb_vis[loc] = 0; }
+                    len = newlen;
+                    if (nu < 0 || loc < nu) nu = loc;
                 }
-                if (loc < len && nb_id[loc] == id) continue;
-                const int newlen = len < cap ? len + 1 : cap;
-                for (int top = newlen - 1; top > loc; top -= 64) {
-                    const int idx = top - lane;
-                    const bool act = idx > loc;
-                    uint32_t mi = 0, mv = 0;
-                    long long ms = 0;
-                    if (act) { mi = nb_id[idx - 1]; ms = nb_sc[idx - 1]; mv = nb_vis[idx - 1]; }
-                    if (act) { nb_id[idx] = mi; nb_sc[idx] = ms; nb_vis[idx] = mv; }
-                }
-                if (lane == 0) { nb_id[loc] = id; nb_sc[loc] = sc; nb_vis[loc] = 0; }
-                len = newlen;
-                if (nu < 0 || loc < nu) nu = loc;
             }
             if (lane == 0) { s_len = len; s_next = nu; }
         }
-        __syncthreads();
+        if (wave == 0) pop();
     }
+    __syncthreads();
 
     if (!BUILD) {
         const int len = s_len;
-        for (int e = tid; e < len; e += GB_THREADS) {
+        for (int e = tid; e < len; e += GS_THREADS) {
             a.out_ids[bi * a.L + e] = nb_id[e];
             a.out_sc[bi * a.L + e] = nb_sc[e];
         }
@@ -336,8 +393,8 @@ __global__ __launch_bounds__(GB_THREADS) void graph_search_kernel(GraphArgs a) {
     n_vl = (uint32_t)s_cnt;
     int dg = (int)a.deg[p];
     if (dg > a.r) dg = a.r;
-    if (dg > 0) {
-        const int e = tid >> 2;
+    for (int e0 = 0; e0 < dg; e0 += GS_THREADS / 4) {
+        const int e = e0 + (tid >> 2);
         uint32_t id = a.adj[(size_t)p * a.r + (e < dg ? e : dg - 1)];
         if (id >= a.n) { id = 0; atomicOr(a.err, 1u); }
         const float f = quad_fast_dot_f32(a.base + (size_t)id * d, s_q, d);
@@ -654,7 +711,7 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
             a.vl_ids = vli.as<uint32_t>(); a.vl_sc = vls.as<long long>(); a.vl_cap = (uint32_t)vl_cap;
             MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nb * words * 4, st));
             MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));
-            hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GB_THREADS), lds, st, a);
+            hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GS_THREADS), lds, st, a);
             MSE_HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(prune_kernel, dim3((unsigned)nb), dim3(GB_THREADS), prune_lds_bytes(d), st, pp, a.vl_ids, a.vl_sc, vl_cap,
                                cnts.as<uint32_t>(), a.points, (int)cfg->maxc, stg.as<uint32_t>(), stg_len.as<uint32_t>());
@@ -845,7 +902,7 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
     a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
     a.out_ids = oi.as<uint32_t>(); a.out_sc = os.as<long long>(); a.out_len = cnt.as<uint32_t>(); a.out_dist = cnt.as<uint32_t>() + nq;
     a.err = cnt.as<uint32_t>() + 2 * nq;
-    hipLaunchKernelGGL(graph_search_kernel<false>, dim3((unsigned)nq), dim3(GB_THREADS), search_lds_bytes((int)d, (int)search_list), st, a);
+    hipLaunchKernelGGL(graph_search_kernel<false>, dim3((unsigned)nq), dim3(GS_THREADS), search_lds_bytes((int)d, (int)search_list), st, a);
     MSE_HIP_TRY(hipGetLastError());
     uint32_t err = 0;
     MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
