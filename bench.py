@@ -86,49 +86,56 @@ def pq_bench(args):
             "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), table 64 x 256 f32 in LDS, r = 200"}}
 
 
+def graph_rows(n, seed, centres):
+    import numpy as np
+    g = np.random.default_rng(seed)
+    asg = g.integers(0, len(centres), n)
+    x = centres[asg] + g.standard_normal((n, D)).astype(np.float32) * np.float32(0.3 / np.sqrt(D))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float16)
+
+
+def graph_centres(n):
+    import numpy as np
+    c = np.random.default_rng(0).standard_normal((max(64, n // 50), D)).astype(np.float32)
+    return c / np.linalg.norm(c, axis=1, keepdims=True)
+
+
 def graph_bench(args):
-    """The production caller of the scoring kernels (src/query_disk_index.rs:144-212): beam search over a graph index,
-    here GPU-resident and batched (one workgroup per query).  Synthetic clustered index; the graph is a navigable
-    stand-in built with the brute-force scan (20 nearest neighbours, 8 nearest cluster hubs, 4 random edges) because
-    the Vamana build is out of scope; recall@10 is measured against the exact brute-force top-10 of the same index."""
+    """The graph side of the index.  Build: the Vamana passes of generate_index_shard
+    (diskann/src/lib.rs:287-324: random fill, first pass alpha 1.0, second pass alpha 1.2; R = 64, L = 192, C = 750) on
+    the device over a synthetic clustered set.  Search, on the graph just built: query_disk_index::greedy_search
+    (src/query_disk_index.rs:144-212) GPU-resident and batched, neighbours scored exactly (the vectors are in HBM), and
+    diskann::greedy_search (lib.rs:183-211) batched the same way; recall@10 against the exact brute-force top-10."""
     import numpy as np
     import mse
-    n, nq, R, K = int(args.graph_rows), 1024, 32, 10
-    rng = np.random.default_rng(0)
-    centres = rng.standard_normal((max(64, n // 50), D)).astype(np.float32)
-    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
-
-    def rows(m, seed):
-        g = np.random.default_rng(seed)
-        asg = g.integers(0, len(centres), m)
-        x = centres[asg] + g.standard_normal((m, D)).astype(np.float32) * np.float32(0.3 / np.sqrt(D))
-        x /= np.linalg.norm(x, axis=1, keepdims=True)
-        return x.astype(np.float16), asg
-
-    base, assign = rows(n, 1)
-    qh, _ = rows(nq, 2)
+    n, nq, R, K = int(args.graph_rows), 1024, 64, 10
+    centres = graph_centres(n)
+    base = graph_rows(n, 1, centres)
+    qh = graph_rows(nq, 2, centres)
     vl = mse.VectorList.from_f16s(base.view(np.uint16), D)
     searcher = mse.Searcher(vl)
-    adj = np.empty((n, R), np.uint32)
-    for s0 in range(0, n, 128):
-        _, ids = searcher.bruteforce_topk(base[s0:s0 + 128].view(np.uint16), 21)
-        adj[s0:s0 + 128, :20] = ids[:, 1:21]
-    hubs = np.unique(assign, return_index=True)[1].astype(np.uint32)
-    hub_searcher = mse.Searcher(mse.VectorList.from_f16s(np.ascontiguousarray(base[hubs]).view(np.uint16), D))
-    for s0 in range(0, n, 128):
-        _, ids = hub_searcher.bruteforce_topk(base[s0:s0 + 128].view(np.uint16), 8)
-        adj[s0:s0 + 128, 20:28] = hubs[ids]
-    adj[:, 28:] = rng.integers(0, n, size=(n, 4))
-    for s0 in range(0, len(hubs), 128):
-        _, ids = hub_searcher.bruteforce_topk(np.ascontiguousarray(base[hubs[s0:s0 + 128]]).view(np.uint16), 13)
-        adj[hubs[s0:s0 + 128], 16:28] = hubs[ids[:, 1:13]]
-    deg = np.full(n, R, np.uint32)
+    med = mse.medioid(vl)
+    g = mse.BuildGraph(n, R)
+    g.random_fill(1)
+    order = np.random.default_rng(3).permutation(n).astype(np.uint32)
+    batch = 2048
+    g.build(searcher, order[:batch], med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)   # warm-up: one batch
+    t0 = time.perf_counter()
+    g.build(searcher, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
+    t1 = time.perf_counter()
+    g.build(searcher, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750, alpha=78643), batch)
+    t2 = time.perf_counter()
+    host = g.to_host()
+    build = {"metric": "Vamana build (diskann::build_graph), points/s", "first_pass_points_per_s": n / (t1 - t0),
+             "second_pass_points_per_s": n / (t2 - t1), "batch": batch, "r": R, "l": 192, "maxc": 750,
+             "mean_degree": float(host.deg.mean())}
     # the codec only has to exist for the exact-neighbour mode (disable_pq): an untrained one is enough
-    cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+    cents = (np.random.default_rng(4).standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
     pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)
     codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
-    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, deg))
-    starts = np.full(nq, mse.medioid(vl), np.uint32)
+    dgraph = mse.DeviceGraph(host)
+    starts = np.full(nq, med, np.uint32)
     luts = np.zeros((nq, 64 * 256), np.float32)
     _, truth = searcher.bruteforce_topk(qh.view(np.uint16), K)
     out = []
@@ -139,12 +146,35 @@ def graph_bench(args):
         dt = time.perf_counter() - t0
         hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist()))
                    for i, (_, _, vi, vs, _, _) in enumerate(res))
+        g.search_batch(searcher, med, qh[:8].view(np.uint16), L)
+        t0 = time.perf_counter()
+        ram = g.search_batch(searcher, med, qh.view(np.uint16), L)
+        dr = time.perf_counter() - t0
+        rhits = sum(len(set(ids[:K].tolist()) & set(truth[i].tolist())) for i, (ids, _, _) in enumerate(ram))
         out.append({"search_list": L, "beamwidth": 4, "queries_per_s": nq / dt, "recall_at_10": hits / (K * nq),
-                    "node_fetches_per_query": float(np.mean([r[4] for r in res]))})
+                    "node_fetches_per_query": float(np.mean([r[4] for r in res])),
+                    "in_ram_greedy_search_queries_per_s": nq / dr, "in_ram_recall_at_10": rhits / (K * nq)})
     return {"metric": "GPU-resident beam search (query_disk_index::greedy_search), batch of 1024 queries",
-            "config": {"workload": f"{n} x {D} fp16 clustered rows, degree-32 stand-in graph, exact neighbour scoring "
-                                   "(disable_pq: the vectors are in HBM), host arrays in / out"},
-            "results": out}
+            "config": {"workload": f"{n} x {D} fp16 clustered rows, Vamana graph built on the device (R 64, L 192, two passes), "
+                                   "exact neighbour scoring (disable_pq: the vectors are in HBM), host arrays in / out"},
+            "build": build, "results": out}
+
+
+def cpu_graph_build(n, points=192):
+    """CPU side of the build line: the oracle's build_graph (batch form) on a bounded sample of the same workload --
+    `points` insertions into the same random initial graph over the same rows, one thread."""
+    import numpy as np
+    from oracle import orc
+    centres = graph_centres(n)
+    base = graph_rows(n, 1, centres).view(np.uint16)
+    adj, deg = orc.random_fill_graph(1, n, 64)
+    order = np.random.default_rng(3).permutation(n).astype(np.uint32)[:points]
+    med = int(orc.medioid(base[:20000]))   # any fixed start node serves the timing; the full medioid is a scan of its own
+    t0 = time.perf_counter()
+    orc.build_graph(base, adj, deg, order, med, orc.BuildConfig.make(r=64, l=192, maxc=750), points)
+    dt = time.perf_counter() - t0
+    return {"value": points / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"{points} insertions (one batch) into the random initial graph over the same {n} rows"}
 
 
 def siglip_bench(args, world, rank):
@@ -378,6 +408,8 @@ def main():
             line["note"] = note
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_total, k)
+            if graph_line:
+                line["cpu_baseline"]["graph_build"] = cpu_graph_build(int(args.graph_rows))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

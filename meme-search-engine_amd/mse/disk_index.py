@@ -1,0 +1,134 @@
+"""The on-disk index of query-disk-index (src/query_disk_index.rs:658-709, written by src/dump_processor.rs:306-313,
+463-569) as far as its formats are pinned by the reference's own sources:
+
+  index.msgpack                rmp-serde `to_vec_named` of IndexHeader (src/common.rs:166-174): a msgpack MAP with keys
+                               shards [[centroid f32 x d, medioid u32], ...], count, dead_count, record_pad_size,
+                               quantizer {centroids, transform, n_dims_per_code, n_dims} (diskann/src/vector.rs:308-314)
+                               and descriptor_cdfs [[f32, ...], ...]
+  index.pq-codes.bin           count x (n_dims / n_dims_per_code) bytes, row major (query_disk_index.rs:101-104,678)
+  index.descriptor-codes.bin   count x len(descriptor_cdfs) bytes (:133-142,679)
+  index.bin                    count x record_pad_size bytes; record = [u16 LE length][payload][zero padding]
+                               (:73-81; dump_processor.rs:505-521)
+
+The payload of an index.bin record is `bitcode::encode(PackedIndexEntry)` (bitcode 0.6.7).  bitcode's wire format is
+not described anywhere in the reference tree and the crate's source is not available here, so this module does NOT
+guess at it: `records()` hands out the payload bytes and a caller-supplied `decode_entry` turns them into
+(vector f16 bits, vertices, ...).  Everything else -- header, codec, codes, descriptors -- loads straight into the
+device objects of the search path.
+"""
+import os
+
+import msgpack
+import numpy as np
+
+from .vector import ProductQuantizer, Codes
+
+RECORD_PAD_SIZE = 4096   # dump_processor.rs:135
+
+
+class IndexHeader:
+    """src/common.rs:166-174."""
+
+    def __init__(self, shards, count, dead_count, record_pad_size, quantizer, descriptor_cdfs):
+        self.shards = shards                      # list of (centroid float32 [d], medioid)
+        self.count = int(count)
+        self.dead_count = int(dead_count)
+        self.record_pad_size = int(record_pad_size)
+        self.quantizer = quantizer                # dict: centroids, transform (float32 arrays), n_dims_per_code, n_dims
+        self.descriptor_cdfs = descriptor_cdfs    # list of float32 arrays
+
+    @property
+    def pq_code_size(self):                       # query_disk_index.rs:678
+        return self.quantizer["n_dims"] // self.quantizer["n_dims_per_code"]
+
+    @property
+    def n_descriptors(self):                      # :679
+        return len(self.descriptor_cdfs)
+
+    def product_quantizer(self) -> ProductQuantizer:
+        q = self.quantizer
+        d = q["n_dims"]
+        return ProductQuantizer(q["centroids"].reshape(-1, d), q["transform"].reshape(d, d), q["n_dims_per_code"], d)
+
+    def shard_centroids(self):
+        return np.stack([c for c, _ in self.shards]).astype(np.float32)
+
+
+def read_index_header(path) -> IndexHeader:
+    with open(path, "rb") as f:
+        m = msgpack.unpackb(f.read(), raw=False, strict_map_key=False)
+    need = {"shards", "count", "dead_count", "record_pad_size", "quantizer", "descriptor_cdfs"}
+    if not isinstance(m, dict) or not need <= set(m):
+        raise ValueError("index.msgpack is not an IndexHeader map")
+    q = m["quantizer"]
+    quant = {"centroids": np.asarray(q["centroids"], np.float32), "transform": np.asarray(q["transform"], np.float32),
+             "n_dims_per_code": int(q["n_dims_per_code"]), "n_dims": int(q["n_dims"])}
+    d = quant["n_dims"]
+    if quant["transform"].size != d * d or quant["centroids"].size % d or d % quant["n_dims_per_code"]:
+        raise ValueError("index.msgpack: quantizer arrays do not match n_dims")   # the asserts of vector.rs:334-337
+    shards = [(np.asarray(c, np.float32), int(med)) for c, med in m["shards"]]
+    return IndexHeader(shards, m["count"], m["dead_count"], m["record_pad_size"], quant,
+                       [np.asarray(c, np.float32) for c in m["descriptor_cdfs"]])
+
+
+def write_index_header(path, header: IndexHeader):
+    """`rmp_serde::to_vec_named(&header)` (dump_processor.rs:559-568): field order of the struct, f32 as float32."""
+    q = header.quantizer
+    m = {"shards": [[[float(x) for x in c], int(med)] for c, med in header.shards],
+         "count": header.count, "dead_count": header.dead_count, "record_pad_size": header.record_pad_size,
+         "quantizer": {"centroids": [float(x) for x in np.asarray(q["centroids"]).reshape(-1)],
+                       "transform": [float(x) for x in np.asarray(q["transform"]).reshape(-1)],
+                       "n_dims_per_code": int(q["n_dims_per_code"]), "n_dims": int(q["n_dims"])},
+         "descriptor_cdfs": [[float(x) for x in c] for c in header.descriptor_cdfs]}
+    with open(path, "wb") as f:
+        f.write(msgpack.packb(m, use_single_float=True))
+
+
+class DiskIndex:
+    """An index directory opened the way initialize_index / initialize_memory_maps do (query_disk_index.rs:658-709)."""
+
+    def __init__(self, path, decode_entry=None):
+        self.path = path
+        self.header = read_index_header(os.path.join(path, "index.msgpack"))
+        h = self.header
+        self.pq_codes = np.memmap(os.path.join(path, "index.pq-codes.bin"), dtype=np.uint8, mode="r")
+        self.descriptors = np.memmap(os.path.join(path, "index.descriptor-codes.bin"), dtype=np.uint8, mode="r")
+        if self.pq_codes.size != h.count * h.pq_code_size:
+            raise ValueError("index.pq-codes.bin does not hold count x pq_code_size bytes")
+        if self.descriptors.size != h.count * h.n_descriptors:
+            raise ValueError("index.descriptor-codes.bin does not hold count x n_descriptors bytes")
+        self.pq_codes = self.pq_codes.reshape(h.count, h.pq_code_size)
+        self.descriptors = self.descriptors.reshape(h.count, max(h.n_descriptors, 1)) if h.n_descriptors else None
+        self.decode_entry = decode_entry
+        self._data = os.path.join(path, "index.bin")
+
+    def device_codes(self) -> Codes:
+        """PQ codes + descriptor bytes resident in HBM (the reference keeps them in locked mmaps, :686-707)."""
+        return Codes(np.ascontiguousarray(self.pq_codes), None if self.descriptors is None else np.ascontiguousarray(self.descriptors))
+
+    def record_payload(self, idx) -> bytes:
+        """read_node (:73-81) up to the bitcode call: the payload bytes of record `idx`."""
+        pad = self.header.record_pad_size
+        with open(self._data, "rb") as f:
+            f.seek(idx * pad)
+            buf = f.read(pad)
+        if len(buf) != pad:
+            raise ValueError("index.bin ends inside record %d" % idx)
+        n = int.from_bytes(buf[:2], "little")
+        if n + 2 > pad:
+            raise ValueError("record %d: length prefix exceeds the record" % idx)
+        return buf[2:2 + n]
+
+    def read_node(self, idx):
+        if self.decode_entry is None:
+            raise NotImplementedError("index.bin payloads are bitcode-encoded PackedIndexEntry; pass decode_entry= (see module docstring)")
+        return self.decode_entry(self.record_payload(idx))
+
+
+def write_records(path, payloads, record_pad_size=RECORD_PAD_SIZE):
+    """dump_processor.rs:505-521: [u16 LE length][payload] zero-padded to the record size (used by tests and tools)."""
+    with open(path, "wb") as f:
+        for p in payloads:
+            if len(p) > record_pad_size - 2:
+                raise ValueError("payload does not fit a record")   # the reference drops such entries (:512)
+            f.write(len(p).to_bytes(2, "little") + p + bytes(record_pad_size - 2 - len(p)))
