@@ -103,7 +103,7 @@ def graph_centres(n):
 
 def graph_bench(args):
     """The graph side of the index.  Build: the Vamana passes of generate_index_shard
-    (diskann/src/lib.rs:287-324: random fill, first pass alpha 1.0, second pass alpha 1.2; R = 64, L = 192, C = 750) on
+    (diskann/src/lib.rs:287-324: random fill, two passes at the default relaxation factors 65536; R = 64, L = 192, C = 750) on
     the device over a synthetic clustered set.  Search, on the graph just built: query_disk_index::greedy_search
     (src/query_disk_index.rs:144-212) GPU-resident and batched, neighbours scored exactly (the vectors are in HBM), and
     diskann::greedy_search (lib.rs:183-211) batched the same way; recall@10 against the exact brute-force top-10."""
@@ -124,7 +124,7 @@ def graph_bench(args):
     t0 = time.perf_counter()
     g.build(searcher, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
     t1 = time.perf_counter()
-    g.build(searcher, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750, alpha=78643), batch)
+    g.build(searcher, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)   # -B defaults to 65536 as well
     t2 = time.perf_counter()
     host = g.to_host()
     build = {"metric": "Vamana build (diskann::build_graph), points/s", "first_pass_points_per_s": n / (t1 - t0),

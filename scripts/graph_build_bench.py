@@ -50,11 +50,11 @@ def main():
     t1 = time.time() - t0
     print(f"n={n} L={L} R={R} batch={batch}: random fill {t_fill*1e3:.1f} ms; first pass {t1:.2f} s = {n/t1:.0f} points/s", flush=True)
     if second:
-        cfg2 = mse.IndexBuildConfig(r=R, l=L, maxc=750, alpha=78643)
+        cfg2 = mse.IndexBuildConfig(r=R, l=L, maxc=750, alpha=int(os.environ.get("ALPHA2", "65536")))
         t0 = time.time()
         g.build(s, order, med, cfg2, batch)
         t2 = time.time() - t0
-        print(f"second pass (alpha 1.2) {t2:.2f} s = {n/t2:.0f} points/s", flush=True)
+        print(f"second pass (alpha_2 {cfg2.alpha}) {t2:.2f} s = {n/t2:.0f} points/s", flush=True)
     h = g.to_host()
     print(f"degree: mean {h.deg.mean():.1f} min {h.deg.min()} max {h.deg.max()}")
     nq = 1000
