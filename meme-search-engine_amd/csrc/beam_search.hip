@@ -46,15 +46,17 @@ struct BeamArgs {
 
 __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lut_bytes = a.disable_pq ? 0 : 65536;   // the distance table is only needed when neighbours are scored by ADC
     float* s_lut = reinterpret_cast<float*>(smem);
-    uint16_t* s_q = reinterpret_cast<uint16_t*>(smem + 65536);
-    char* p = smem + 65536 + ((a.d * 2 + 15) & ~15);
+    uint16_t* s_q = reinterpret_cast<uint16_t*>(smem + lut_bytes);
+    char* p = smem + lut_bytes + ((a.d * 2 + 15) & ~15);
     long long* nb_sc = reinterpret_cast<long long*>(p); p += BS_LMAX * 8;
     long long* pre_sc = reinterpret_cast<long long*>(p); p += BS_PRE_MAX * 8;
     uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += BS_LMAX * 4;
     uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += BS_LMAX * 4;
-    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p);
-    __shared__ int s_len, s_next, s_npts, s_npre;
+    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += BS_PRE_MAX * 4;
+    int* s_rank = reinterpret_cast<int*>(p);
+    __shared__ int s_len, s_next, s_npts, s_npre, s_ties;
     __shared__ uint32_t s_pts[BS_BEAM_MAX];
     __shared__ int s_seg[BS_BEAM_MAX];
     __shared__ long long s_ptsc[BS_BEAM_MAX];
@@ -67,8 +69,9 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     uint32_t* bm_vis = a.bm_vis + qi * a.bm_words;
     const bool use_bias = a.scales && a.desc && a.n_desc > 0;
 
-    for (int e = tid; e < 64 * 256 / 4; e += BS_THREADS)
-        reinterpret_cast<float4*>(s_lut)[e] = reinterpret_cast<const float4*>(a.luts + qi * 16384)[e];
+    if (!a.disable_pq)
+        for (int e = tid; e < 64 * 256 / 4; e += BS_THREADS)
+            reinterpret_cast<float4*>(s_lut)[e] = reinterpret_cast<const float4*>(a.luts + qi * 16384)[e];
     for (int e = tid; e < a.d / 8; e += BS_THREADS)
         reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(a.queries + qi * a.d)[e];
     if (tid < BS_DESC_MAX) s_scales[tid] = (use_bias && tid < a.n_desc) ? a.scales[qi * a.n_desc + tid] : 0.0f;
@@ -187,8 +190,86 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
         }
         __syncthreads();
 
+        // ---- all newcomers of this beam iteration at once ----
+        // While no two different ids share a score (`ties` is still false and nothing offered now equals anything), the
+        // order of the inserts does not matter and re-offers change nothing: the list ends up as the best `cap` of old and
+        // new entries, and next_unvisited as the smaller of its old value and the slot the best newcomer takes on arrival
+        // (every other insert lands at or behind that slot).  Each thread places up to two newcomers by two counts -- old
+        // entries above it (binary search) and newcomers above it -- and moves up to four old entries up by the number of
+        // newcomers that go before them.  Any equality, and the reference's sequence is replayed below instead.
+        bool merged = false;
+        if (cap > 0 && npre > 0) {
+            const int len = s_len;
+            int lo_[2], rn_[2];
+            long long sc_[2];
+            bool tie = false;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int e = tid + h * BS_THREADS;
+                lo_[h] = 0; rn_[h] = 0; sc_[h] = 0;
+                if (e < npre) {
+                    const long long sc = pre_sc[e];
+                    int lo = 0, hi = len;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (nb_sc[mid] > sc) lo = mid + 1; else hi = mid;
+                    }
+                    tie |= lo < len && nb_sc[lo] == sc;
+                    int rn = 0;
+                    for (int k = 0; k < npre; k++) {
+                        const long long sk = pre_sc[k];
+                        rn += sk > sc;
+                        tie |= k != e && sk == sc;
+                    }
+                    lo_[h] = lo; rn_[h] = rn; sc_[h] = sc;
+                }
+            }
+            if (tid == 0) s_ties = ties ? 1 : 0;   // `ties` lives in wave 0; every wave needs the verdict
+            const int any_tie = __syncthreads_or(tie ? 1 : 0);
+            if (!any_tie && !s_ties) {
+                merged = true;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (tid + h * BS_THREADS < npre) s_rank[rn_[h]] = lo_[h];
+                __syncthreads();
+                long long osc[4];
+                uint32_t oid[4], ovis[4];
+                int onp[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int i = tid + c * BS_THREADS;
+                    onp[c] = -1;
+                    if (i < len) {
+                        osc[c] = nb_sc[i]; oid[c] = nb_id[i]; ovis[c] = nb_vis[i];
+                        int a0 = 0, b0 = npre;
+                        while (a0 < b0) {
+                            const int mid = (a0 + b0) >> 1;
+                            if (s_rank[mid] <= i) a0 = mid + 1; else b0 = mid;
+                        }
+                        if (a0 > 0 && i + a0 < cap) onp[c] = i + a0;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (onp[c] >= 0) { nb_sc[onp[c]] = osc[c]; nb_id[onp[c]] = oid[c]; nb_vis[onp[c]] = ovis[c]; }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int e = tid + h * BS_THREADS, pos = lo_[h] + rn_[h];
+                    if (e < npre && pos < cap) { nb_sc[pos] = sc_[h]; nb_id[pos] = pre_id[e]; nb_vis[pos] = 0; }
+                }
+                if (tid == 0) {
+                    const int first = s_rank[0], nu = s_next;
+                    if (first < cap && (nu < 0 || first < nu)) s_next = first;
+                    s_len = len + npre < cap ? len + npre : cap;
+                    if (!a.disable_pq)
+                        for (int j = 0; j < npts; j++) pq_cmps += (uint32_t)s_seg[j];   // every offer counts, re-offers included (:205)
+                }
+            }
+        }
+
         // ---- NeighbourBuffer::insert (lib.rs:117-147) for every (node, pre-buffer entry) pair in the reference's order ----
-        if (wave == 0) {
+        if (wave == 0 && !merged) {
             int len = s_len, nu = s_next;
             for (int j = 0; j < npts; j++) {
                 const int upto = s_seg[j];
@@ -298,7 +379,7 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
                           size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
                           uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
                           uint32_t* cmps, uint32_t* pq_cmps) {
-    if (!s || !s->base || !pq || !c || !g || !starts || !queries || !luts || !buf_ids || !buf_scores || !buf_len || !n_visited || !cmps ||
+    if (!s || !s->base || !pq || !c || !g || !starts || !queries || (!luts && !disable_pq) || !buf_ids || !buf_scores || !buf_len || !n_visited || !cmps ||
         !pq_cmps)
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
@@ -317,12 +398,12 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
     const size_t d = b->d, words = (b->n + 31) / 32;
     const bool bias = scales && c->n_desc && c->desc;
     DevBuf dq, dl, dsc, dst, bm, oi, os, ol, vi, vs, cnt;
-    if (dq.ensure(nq * d * 2) || dl.ensure(nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
+    if (dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
         bm.ensure(nq * words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
         vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
         return -1;
     MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
-    MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
+    if (!disable_pq) MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
     if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 8, st));
@@ -338,7 +419,7 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
     a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
     a.err = cnt.as<uint32_t>() + 3 * nq;
-    const size_t lds = 65536 + ((d * 2 + 15) & ~(size_t)15) + BS_LMAX * 16 + BS_PRE_MAX * 12;
+    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + BS_LMAX * 16 + BS_PRE_MAX * 16;
     static bool attr = false;
     if (!attr) {
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
