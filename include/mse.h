@@ -235,6 +235,14 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
                            size_t search_list, int base_vectors_only, uint32_t query_breakpoint, uint32_t* buf_ids,
                            int64_t* buf_scores, uint32_t* buf_len, uint32_t* n_distances);
 
+/* The same with the caller's two preparation steps (src/query_disk_index.rs:475-477) done on the device: queries arrive
+ * as f32 [nq][d]; their f16 copies (RNE, half::f16::from_f32) score the fetched nodes and preprocess_query
+ * (vector.rs:367-384) makes the distance tables in HBM, so 64 KiB per query stay off PCIe. */
+int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+                              const float* queries_f32, const float* scales, size_t nq, int disable_pq, size_t beamwidth,
+                              size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
+                              uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
+                              uint32_t* cmps, uint32_t* pq_cmps);
 /* Result de-duplication of the visited list (src/query_disk_index.rs:482-527): S = V V^T over the visited rows
  * (ids into the searcher's base, visit order), greedy keep-first filter with S[i][j] > threshold (0.95, :99) against
  * already kept rows.  keep[i] = 1 for survivors. */

@@ -374,13 +374,13 @@ void mse_graph_free(mse_graph* g) {
     delete g;
 }
 
-int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
-                          const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
-                          size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
-                          uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
-                          uint32_t* cmps, uint32_t* pq_cmps) {
-    if (!s || !s->base || !pq || !c || !g || !starts || !queries || (!luts && !disable_pq) || !buf_ids || !buf_scores || !buf_len || !n_visited || !cmps ||
-        !pq_cmps)
+static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+                                  const uint16_t* queries, const float* queries_f32, const float* luts, const float* scales, size_t nq,
+                                  int disable_pq, size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores,
+                                  uint32_t* buf_len, uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap,
+                                  uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!s || !s->base || !pq || !c || !g || !starts || (!queries && !queries_f32) || (!luts && !queries_f32 && !disable_pq) || !buf_ids ||
+        !buf_scores || !buf_len || !n_visited || !cmps || !pq_cmps)
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
@@ -397,13 +397,25 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
     hipStream_t st = s->stream;
     const size_t d = b->d, words = (b->n + 31) / 32;
     const bool bias = scales && c->n_desc && c->desc;
-    DevBuf dq, dl, dsc, dst, bm, oi, os, ol, vi, vs, cnt;
-    if (dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
+    DevBuf dq, dl, dsc, dst, bm, oi, os, ol, vi, vs, cnt, qf, qt;
+    if ((queries_f32 && (qf.ensure(nq * d * 4) || qt.ensure(nq * d * 4))) || dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
         bm.ensure(nq * words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
         vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
         return -1;
-    MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
-    if (!disable_pq) MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
+    if (queries_f32) {
+        // the caller's side of query_disk_index.rs:475-477 on the device: f16 copy of the query (RNE) for the exact scores,
+        // preprocess_query (vector.rs:367-384) for the distance tables -- 64 KiB per query that never cross PCIe
+        if (pq->d != d) return fail("disk_search_batch: codec and vectors differ in width");
+        MSE_HIP_TRY(hipMemcpyAsync(qf.p, queries_f32, nq * d * 4, hipMemcpyHostToDevice, st));
+        if (launch_f32_to_f16(qf.as<float>(), nq * d, dq.as<uint16_t>(), st)) return -1;
+        if (!disable_pq) {
+            if (launch_pq_transform(pq->transform, (int)d, qf.as<float>(), nq, qt.as<float>(), st)) return -1;
+            if (launch_pq_lut_batch(pq->centroids, (int)pq->n_centroids, (int)d, (int)pq->dpc, qt.as<float>(), nq, dl.as<float>(), st)) return -1;
+        }
+    } else {
+        MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
+        if (!disable_pq) MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
+    }
     if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 8, st));
@@ -442,6 +454,25 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
     MSE_HIP_TRY(hipStreamSynchronize(st));
     if (err) return fail("disk_search_batch: a graph edge points outside the index");
     return 0;
+}
+
+int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+                          const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
+                          size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
+                          uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
+                          uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!queries) return fail("disk_search_batch: null argument");
+    return disk_search_batch_impl(s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
+                                  buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
+}
+
+int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+                              const float* queries_f32, const float* scales, size_t nq, int disable_pq, size_t beamwidth,
+                              size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len, uint32_t* visited_ids,
+                              int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!queries_f32) return fail("disk_search_batch_f32: null argument");
+    return disk_search_batch_impl(s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, nq, disable_pq, beamwidth, search_list,
+                                  buf_ids, buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
 }
 
 }  // extern "C"

@@ -76,6 +76,8 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,
                           const float* scales, int64_t* out, hipStream_t stream);
 int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stream);
+int launch_pq_lut_batch(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t nq, float* lut,
+                        hipStream_t stream);
 int rank_max_targets();
 int launch_rank(const int64_t* scores, size_t n, const uint32_t* targets, int m, unsigned long long* counts, int n_cu,
                 hipStream_t stream);

@@ -44,6 +44,8 @@ __global__ void pq_lut_kernel(const float* __restrict__ centroids, int n_centroi
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_chunks = d / dpc;
     if (idx >= n_chunks * n_centroids) return;
+    t += (size_t)blockIdx.y * d;                               // one table per query (blockIdx.y)
+    lut += (size_t)blockIdx.y * n_chunks * n_centroids;
     const int i = idx / n_centroids, j = idx % n_centroids;
     double s = 0.0;
     for (int u = 0; u < dpc; u++) s += (double)t[i * dpc + u] * (double)centroids[(size_t)j * d + i * dpc + u];
@@ -258,10 +260,17 @@ int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* 
 }
 int launch_pq_lut(const float* centroids, int n_centroids, int d, int dpc, const float* t, float* lut,
                   hipStream_t stream) {
+    return launch_pq_lut_batch(centroids, n_centroids, d, dpc, t, 1, lut, stream);
+}
+int launch_pq_lut_batch(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t nq, float* lut,
+                        hipStream_t stream) {
     const int total = (d / dpc) * n_centroids;
-    hipLaunchKernelGGL(pq_lut_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, centroids, n_centroids, d, dpc, t,
-                       lut);
-    MSE_HIP_TRY(hipGetLastError());
+    for (size_t q0 = 0; q0 < nq; q0 += 65535) {
+        const size_t m = nq - q0 < 65535 ? nq - q0 : 65535;
+        hipLaunchKernelGGL(pq_lut_kernel, dim3((total + 255) / 256, (unsigned)m), dim3(256), 0, stream, centroids, n_centroids, d, dpc,
+                           t + q0 * d, lut + q0 * total);
+        MSE_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t n,

@@ -151,15 +151,24 @@ class DeviceGraph:
             pass
 
 
-def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph, starts, queries, luts, descriptor_scales=None,
+def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph, starts, queries, luts=None, descriptor_scales=None,
                       disable_pq=False, beamwidth=1, search_list=1000, visited_cap=4096):
     """query_disk_index::greedy_search for a batch of queries, entirely on the device (one workgroup per query).
-    Returns a list of DiskSearchResult-like tuples (buffer ids, buffer scores, visited ids, visited scores, cmps, pq_cmps)."""
-    q = _bits(queries)
-    q = q.reshape(-1, q.shape[-1])
+    queries: f16 rows with `luts` (QueryLUTs / [nq][64*256] f32; not needed with disable_pq), or f32 rows with luts=None --
+    then the f16 copies and the tables are made on the device (query_disk_index.rs:475-477).
+    Returns a list of (buffer ids, buffer scores, visited ids, visited scores, cmps, pq_cmps)."""
+    qa = np.asarray(queries)
+    from_f32 = qa.dtype == np.float32 and luts is None
+    if from_f32:
+        q = np.ascontiguousarray(qa.reshape(-1, qa.shape[-1]), np.float32)
+    else:
+        q = _bits(queries)
+        q = q.reshape(-1, q.shape[-1])
     nq = q.shape[0]
-    tables = np.ascontiguousarray(np.stack([getattr(t, "table", t) for t in luts]) if not isinstance(luts, np.ndarray) else luts,
-                                  np.float32).reshape(nq, -1)
+    tables = None
+    if not from_f32 and luts is not None:
+        tables = np.ascontiguousarray(np.stack([getattr(t, "table", t) for t in luts]) if not isinstance(luts, np.ndarray) else luts,
+                                      np.float32).reshape(nq, -1)
     st = np.ascontiguousarray(starts, np.uint32).reshape(nq)
     sc = None
     if descriptor_scales is not None:
@@ -169,11 +178,15 @@ def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph,
     bi, bs, bl = np.empty((nq, search_list), np.uint32), np.empty((nq, search_list), np.int64), np.empty(nq, np.uint32)
     vi, vs = np.empty((nq, visited_cap), np.uint32), np.empty((nq, visited_cap), np.int64)
     nv, cm, pc = np.empty(nq, np.uint32), np.empty(nq, np.uint32), np.empty(nq, np.uint32)
-    check(ffi.lib().mse_disk_search_batch(
-        searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_uint16), _p(tables, C.c_float),
-        _p(sc, C.c_float) if sc is not None else None, nq, int(bool(disable_pq)), int(beamwidth), int(search_list),
-        _p(bi, C.c_uint32), _p(bs, C.c_int64), _p(bl, C.c_uint32), _p(vi, C.c_uint32), _p(vs, C.c_int64), visited_cap,
-        _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32)), "disk_search_batch")
+    tail = (nq, int(bool(disable_pq)), int(beamwidth), int(search_list), _p(bi, C.c_uint32), _p(bs, C.c_int64), _p(bl, C.c_uint32),
+            _p(vi, C.c_uint32), _p(vs, C.c_int64), visited_cap, _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32))
+    scp = _p(sc, C.c_float) if sc is not None else None
+    if from_f32:
+        check(ffi.lib().mse_disk_search_batch_f32(searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_float),
+                                                  scp, *tail), "disk_search_batch_f32")
+    else:
+        check(ffi.lib().mse_disk_search_batch(searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_uint16),
+                                              _p(tables, C.c_float) if tables is not None else None, scp, *tail), "disk_search_batch")
     out = []
     for i in range(nq):
         k = min(int(nv[i]), visited_cap)

@@ -92,6 +92,8 @@ SIGNATURES = {
     "mse_graph_free": (None, [vp]),
     "mse_disk_search_batch": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
                                         u32p, u32p, u32p]),
+    "mse_disk_search_batch_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
+                                            u32p, u32p, u32p]),
     "mse_graph_new": (vp, [sz, sz]),
     "mse_graph_to_host": (C.c_int, [vp, u32p, u32p]),
     "mse_graph_len": (sz, [vp]),

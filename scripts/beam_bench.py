@@ -90,3 +90,12 @@ for L, beam, nopq in ((64, 4, False), (128, 4, False), (200, 4, False), (64, 4, 
         cm += c
     print(f"n={n} L={L} beam={beam} exact_neighbours={nopq}: {nq/dt:8.0f} q/s ({dt*1e3:.1f} ms for {nq} queries, host arrays in/out), recall@10 {hits/(K*nq):.3f}, "
           f"{cm/nq:.0f} node fetches/query", flush=True)
+# f32 queries in, f16 copies and distance tables made on the device (no 64 KiB table per query over PCIe)
+qf = qh.astype(np.float32)
+for L, beam in ((64, 4), (128, 4), (200, 4)):
+    mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts[:8], qf[:8], None, None, False, beam, L, 2048)
+    t0 = time.perf_counter()
+    res = mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qf, None, None, False, beam, L, 2048)
+    dt = time.perf_counter() - t0
+    hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist())) for i, (_, _, vi, vs, _, _) in enumerate(res))
+    print(f"n={n} L={L} beam={beam} ADC, f32 queries (tables made on the device): {nq/dt:8.0f} q/s ({dt*1e3:.1f} ms), recall@10 {hits/(K*nq):.3f}", flush=True)

@@ -333,3 +333,32 @@ def test_device_resident_beam_search_matches_oracle(gpu, mse, orc, beamwidth, di
         mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qh, luts, scales, disable_pq, 9, search_list=L)
     with pytest.raises(mse.MseError):
         mse.disk_search_batch(searcher, gpq, gcodes, dgraph, np.full(nq, n, np.uint32), qh, luts, scales, disable_pq, 2, search_list=L)
+
+
+@pytest.mark.parametrize("disable_pq", [False, True])
+def test_device_resident_beam_search_from_f32_queries(gpu, mse, orc, disable_pq):
+    """f32 queries in: the f16 copies (RNE) and the distance tables are made on the device (query_disk_index.rs:475-477);
+    the result equals the call that is handed f16 queries and tables made one by one."""
+    rng = np.random.default_rng(16)
+    n, deg, L, nq = 2500, 12, 48, 11
+    x = clustered_rows(orc, n, n_centres=24)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:1500], iters=2)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    adj, degs = knn_graph(x, deg, rng)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    gcodes = mse.Codes(codes, None)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    qs = (clustered_rows(orc, nq, n_centres=24, seed=300) * np.float32(1.7)).astype(np.float32)   # queries need not be unit norm
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    luts = np.stack([gpq.preprocess_query(q).table for q in qs])
+    want = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, orc.f16_bits(qs), luts, None, disable_pq, 3, search_list=L, visited_cap=n)
+    got = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qs, None, None, disable_pq, 3, search_list=L, visited_cap=n)
+    for w, g_ in zip(want, got):
+        assert all(np.array_equal(a, b) for a, b in zip(w[:4], g_[:4])) and w[4:] == g_[4:]
+    # and against the oracle for one query
+    obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, None, int(starts[0]), orc.f16_bits(qs[0]),
+                                                          opq.preprocess_query(qs[0]), None, disable_pq, 3, L, None)
+    if disable_pq:   # the tables differ in the last bit between host libm-free orders only in ADC mode; exact mode must agree outright
+        assert np.array_equal(got[0][0], obuf.ids) and np.array_equal(got[0][2], ovids)
