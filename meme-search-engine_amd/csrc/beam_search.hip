@@ -397,7 +397,8 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     hipStream_t st = s->stream;
     const size_t d = b->d, words = (b->n + 31) / 32;
     const bool bias = scales && c->n_desc && c->desc;
-    DevBuf dq, dl, dsc, dst, bm, oi, os, ol, vi, vs, cnt, qf, qt;
+    DevBuf &dq = s->pool[0], &dl = s->pool[1], &dsc = s->pool[2], &dst = s->pool[3], &bm = s->pool[4], &oi = s->pool[5], &os = s->pool[6],
+           &ol = s->pool[7], &vi = s->pool[8], &vs = s->pool[9], &cnt = s->pool[10], &qf = s->pool[11], &qt = s->pool[12];
     if ((queries_f32 && (qf.ensure(nq * d * 4) || qt.ensure(nq * d * 4))) || dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
         bm.ensure(nq * words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
         vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
@@ -443,16 +444,22 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(buf_len, ol.p, nq * 4, hipMemcpyDeviceToHost, st));
-    if (visited_cap) {
-        MSE_HIP_TRY(hipMemcpyAsync(visited_ids, vi.p, nq * visited_cap * 4, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipMemcpyAsync(visited_scores, vs.p, nq * visited_cap * 8, hipMemcpyDeviceToHost, st));
-    }
     MSE_HIP_TRY(hipMemcpyAsync(n_visited, a.n_visited, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(cmps, a.cmps, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(pq_cmps, a.pq_cmps, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipStreamSynchronize(st));
     if (err) return fail("disk_search_batch: a graph edge points outside the index");
+    if (visited_cap) {   // only the columns any query filled travel back (entries past n_visited[q] are unspecified)
+        size_t widest = 0;
+        for (size_t q = 0; q < nq; q++) widest = n_visited[q] > widest ? n_visited[q] : widest;
+        if (widest > visited_cap) widest = visited_cap;
+        if (widest) {
+            MSE_HIP_TRY(hipMemcpy2DAsync(visited_ids, visited_cap * 4, vi.p, visited_cap * 4, widest * 4, nq, hipMemcpyDeviceToHost, st));
+            MSE_HIP_TRY(hipMemcpy2DAsync(visited_scores, visited_cap * 8, vs.p, visited_cap * 8, widest * 8, nq, hipMemcpyDeviceToHost, st));
+            MSE_HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
     return 0;
 }
 

@@ -884,7 +884,7 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
         if (starts[q] >= b->n) return fail("graph_search_batch: start node out of range");
     hipStream_t st = s->stream;
     const size_t d = b->d, words = (b->n + 31) / 32;
-    DevBuf dq, dst, bm, oi, os, cnt;
+    DevBuf &dq = s->pool[0], &dst = s->pool[3], &bm = s->pool[4], &oi = s->pool[5], &os = s->pool[6], &cnt = s->pool[10];
     if (dq.ensure(nq * d * 2) || dst.ensure(nq * 4) || bm.ensure(nq * words * 4) || oi.ensure(nq * search_list * 4) ||
         os.ensure(nq * search_list * 8) || cnt.ensure(nq * 8 + 16))
         return -1;

@@ -64,6 +64,7 @@ struct mse_searcher {
     mse::DevBuf gmax;         // MFMA group maxima [n_groups][nq_pad]
     mse::DevBuf cand_ids, cand_scores, gkeys, eps, margin;
     mse::DevBuf misc, qpacked;
+    mse::DevBuf pool[16];     // scratch of the batched graph searches (kept between calls: no hipMalloc on the query path)
     uint32_t last_widened = 0, last_max_groups = 0;
     // optional HIP-event timing of the dominant (scan) kernel, for bench.py's roofline line
     bool timing = false;
