@@ -50,11 +50,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     float* s_lut = reinterpret_cast<float*>(smem);
     uint16_t* s_q = reinterpret_cast<uint16_t*>(smem + lut_bytes);
     char* p = smem + lut_bytes + ((a.d * 2 + 15) & ~15);
-    long long* nb_sc = reinterpret_cast<long long*>(p); p += BS_LMAX * 8;
-    long long* pre_sc = reinterpret_cast<long long*>(p); p += BS_PRE_MAX * 8;
-    uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += BS_LMAX * 4;
-    uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += BS_LMAX * 4;
-    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += BS_PRE_MAX * 4;
+    // the list is sized by this call's search_list and the pre-buffer by its beam width, so that the usual settings
+    // (L = 200, beam 4) leave room for two workgroups per CU next to their 64 KiB tables, eight without tables
+    const size_t l_cap = (size_t)a.L, p_cap = (size_t)a.beam * BS_DEG_MAX;
+    long long* nb_sc = reinterpret_cast<long long*>(p); p += l_cap * 8;
+    long long* pre_sc = reinterpret_cast<long long*>(p); p += p_cap * 8;
+    uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
+    uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
+    uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += p_cap * 4;
     int* s_rank = reinterpret_cast<int*>(p);
     __shared__ int s_len, s_next, s_npts, s_npre, s_ties;
     __shared__ uint32_t s_pts[BS_BEAM_MAX];
@@ -432,7 +435,7 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
     a.err = cnt.as<uint32_t>() + 3 * nq;
-    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + BS_LMAX * 16 + BS_PRE_MAX * 16;
+    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + beamwidth * BS_DEG_MAX * 16;
     static bool attr = false;
     if (!attr) {
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
