@@ -1,0 +1,80 @@
+"""Graph index at BASELINE config 3's size (1e7 x 1152): build the Vamana graph on the device, then queries/s and
+recall@10 of the GPU-resident searches against the exact brute-force top-10 of the same index.
+usage: graph_scale_bench.py [n_rows] [passes] [batch]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "meme-search-engine_amd"))
+import torch  # noqa: F401,E402
+import mse  # noqa: E402
+from mse import ffi  # noqa: E402
+
+D = 1152
+
+
+def clustered(n, centres, noise, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    out = torch.empty(n, D, device="cuda", dtype=torch.float16)
+    for i in range(0, n, 1 << 18):
+        m = min(1 << 18, n - i)
+        x = centres[torch.randint(0, len(centres), (m,), device="cuda", generator=g)] + torch.randn(m, D, device="cuda", generator=g) * (noise / D ** 0.5)
+        out[i:i + m] = (x / x.norm(dim=1, keepdim=True)).half()
+    return out
+
+
+def main():
+    n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+    passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+    nq, K, R, L = 1024, 10, 64, 192
+    ffi.check(ffi.lib().mse_set_device(0))
+    g0 = torch.Generator(device="cuda").manual_seed(0)
+    centres = torch.randn(max(64, n // 50), D, device="cuda", generator=g0)
+    centres /= centres.norm(dim=1, keepdim=True)
+    rows = clustered(n, centres, 0.3, 1)
+    queries = clustered(nq, centres, 0.3, 2)
+    del centres
+    torch.cuda.synchronize()
+    vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows)
+    s = mse.Searcher(vecs)
+    t0 = time.time()
+    med = mse.medioid(vecs)
+    print(f"n={n}: medioid {time.time()-t0:.1f} s", flush=True)
+    g = mse.BuildGraph(n, R)
+    g.random_fill(1)
+    rng = np.random.default_rng(3)
+    for p in range(passes):
+        order = rng.permutation(n).astype(np.uint32)
+        t0 = time.time()
+        g.build(s, order, med, mse.IndexBuildConfig(r=R, l=L, maxc=750), batch)
+        dt = time.time() - t0
+        print(f"pass {p + 1}: {dt:.1f} s = {n/dt:.0f} points/s (R {R}, L {L}, C 750, batch {batch})", flush=True)
+    qh = queries.cpu().numpy().view(np.uint16)
+    t0 = time.time()
+    _, truth = s.bruteforce_topk(qh, K)
+    print(f"brute-force truth for {nq} queries: {time.time()-t0:.2f} s", flush=True)
+    cents = (np.random.default_rng(4).standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+    pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)     # unused in exact-neighbour mode
+    codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
+    starts = np.full(nq, med, np.uint32)
+    for Ls in (32, 64, 100, 200):
+        mse.disk_search_batch(s, pq, codes, g, starts[:8], qh[:8], None, None, True, 4, Ls, 1024)
+        t0 = time.perf_counter()
+        res = mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024)
+        dt = time.perf_counter() - t0
+        hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist())) for i, (_, _, vi, vs, _, _) in enumerate(res))
+        g.search_batch(s, med, qh[:8], Ls)
+        t0 = time.perf_counter()
+        ram = g.search_batch(s, med, qh, Ls)
+        dr = time.perf_counter() - t0
+        rh = sum(len(set(ids[:K].tolist()) & set(truth[i].tolist())) for i, (ids, _, _) in enumerate(ram))
+        print(f"L={Ls}: beam search (beam 4, exact neighbours) {nq/dt:8.0f} q/s recall@10 {hits/(K*nq):.3f} "
+              f"({np.mean([r[4] for r in res]):.0f} node fetches/query); in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
