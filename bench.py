@@ -140,19 +140,20 @@ def graph_bench(args):
     _, truth = searcher.bruteforce_topk(qh.view(np.uint16), K)
     out = []
     for L in (64, 200):
-        mse.disk_search_batch(searcher, pq, codes, dgraph, starts[:8], qh[:8].view(np.uint16), luts[:8], None, True, 4, L, 1024)
+        # timed: the C-ABI call with host arrays in and out (one warm call first: scratch is allocated on first use)
+        mse.disk_search_batch(searcher, pq, codes, dgraph, starts, qh.view(np.uint16), None, None, True, 4, L, 1024, as_arrays=True)
         t0 = time.perf_counter()
-        res = mse.disk_search_batch(searcher, pq, codes, dgraph, starts, qh.view(np.uint16), luts, None, True, 4, L, 1024)
+        res = mse.disk_search_batch(searcher, pq, codes, dgraph, starts, qh.view(np.uint16), None, None, True, 4, L, 1024, as_arrays=True)
         dt = time.perf_counter() - t0
-        hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist()))
-                   for i, (_, _, vi, vs, _, _) in enumerate(res))
-        g.search_batch(searcher, med, qh[:8].view(np.uint16), L)
+        top = mse.topk_of_visited(res, K)
+        hits = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq))
+        g.search_batch(searcher, med, qh.view(np.uint16), L, as_arrays=True)
         t0 = time.perf_counter()
-        ram = g.search_batch(searcher, med, qh.view(np.uint16), L)
+        rid, _, _, _ = g.search_batch(searcher, med, qh.view(np.uint16), L, as_arrays=True)
         dr = time.perf_counter() - t0
-        rhits = sum(len(set(ids[:K].tolist()) & set(truth[i].tolist())) for i, (ids, _, _) in enumerate(ram))
+        rhits = sum(len(set(rid[i, :K].tolist()) & set(truth[i].tolist())) for i in range(nq))
         out.append({"search_list": L, "beamwidth": 4, "queries_per_s": nq / dt, "recall_at_10": hits / (K * nq),
-                    "node_fetches_per_query": float(np.mean([r[4] for r in res])),
+                    "node_fetches_per_query": float(res["cmps"].mean()),
                     "in_ram_greedy_search_queries_per_s": nq / dr, "in_ram_recall_at_10": rhits / (K * nq)})
     return {"metric": "GPU-resident beam search (query_disk_index::greedy_search), batch of 1024 queries",
             "config": {"workload": f"{n} x {D} fp16 clustered rows, Vamana graph built on the device (R 64, L 192, two passes), "

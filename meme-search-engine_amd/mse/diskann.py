@@ -152,8 +152,10 @@ class DeviceGraph:
 
 
 def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph, starts, queries, luts=None, descriptor_scales=None,
-                      disable_pq=False, beamwidth=1, search_list=1000, visited_cap=4096):
+                      disable_pq=False, beamwidth=1, search_list=1000, visited_cap=4096, as_arrays=False):
     """query_disk_index::greedy_search for a batch of queries, entirely on the device (one workgroup per query).
+    as_arrays=True returns the padded output arrays themselves (dict: buf_ids, buf_scores, buf_len, visited_ids,
+    visited_scores, n_visited, cmps, pq_cmps) instead of one tuple per query.
     queries: f16 rows with `luts` (QueryLUTs / [nq][64*256] f32; not needed with disable_pq), or f32 rows with luts=None --
     then the f16 copies and the tables are made on the device (query_disk_index.rs:475-477).
     Returns a list of (buffer ids, buffer scores, visited ids, visited scores, cmps, pq_cmps)."""
@@ -187,11 +189,27 @@ def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph,
     else:
         check(ffi.lib().mse_disk_search_batch(searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_uint16),
                                               _p(tables, C.c_float) if tables is not None else None, scp, *tail), "disk_search_batch")
+    if as_arrays:
+        return {"buf_ids": bi, "buf_scores": bs, "buf_len": bl, "visited_ids": vi, "visited_scores": vs, "n_visited": nv, "cmps": cm,
+                "pq_cmps": pc}
     out = []
     for i in range(nq):
         k = min(int(nv[i]), visited_cap)
         out.append((bi[i, :bl[i]].copy(), bs[i, :bl[i]].copy(), vi[i, :k].copy(), vs[i, :k].copy(), int(cm[i]), int(pc[i])))
     return out
+
+
+def topk_of_visited(res, k):
+    """The server's last step (query_disk_index.rs:529-540) for a whole batch: ids of the k best visited records per query by
+    exact score (stable), from disk_search_batch(..., as_arrays=True).  Rows with fewer than k records are padded with ID_NONE."""
+    vi, vs, nv = res["visited_ids"], res["visited_scores"], res["n_visited"]
+    w = int(min(vi.shape[1], max(int(nv.max()), 1)))
+    sc = vs[:, :w].copy()
+    sc[np.arange(w)[None, :] >= np.minimum(nv, vi.shape[1])[:, None]] = np.iinfo(np.int64).min
+    order = np.argsort(-sc.astype(np.float64), axis=1, kind="stable")[:, :k]
+    ids = np.take_along_axis(vi[:, :w], order, axis=1).astype(np.int64)
+    ids[np.take_along_axis(sc, order, axis=1) == np.iinfo(np.int64).min] = 0xFFFFFFFF
+    return ids
 
 
 def greedy_search(searcher: Searcher, start, base_vectors_only, query, graph: IndexGraph, l,
@@ -246,8 +264,9 @@ class BuildGraph:
         check(ffi.lib().mse_graph_to_host(self._h, _p(adj, C.c_uint32), _p(deg, C.c_uint32)), "graph_to_host")
         return IndexGraph(adj, deg)
 
-    def search_batch(self, searcher: Searcher, starts, queries, l, base_vectors_only=False, query_breakpoint=0xFFFFFFFF):
-        """diskann::greedy_search (lib.rs:183-211) for a batch of queries on the device: list of (ids, scores, distances)."""
+    def search_batch(self, searcher: Searcher, starts, queries, l, base_vectors_only=False, query_breakpoint=0xFFFFFFFF, as_arrays=False):
+        """diskann::greedy_search (lib.rs:183-211) for a batch of queries on the device: list of (ids, scores, distances), or with
+        as_arrays=True the padded arrays (ids [nq][l], scores [nq][l], len [nq], distances [nq])."""
         q = _bits(queries)
         q = q.reshape(-1, q.shape[-1])
         nq = q.shape[0]
@@ -257,6 +276,8 @@ class BuildGraph:
         check(ffi.lib().mse_graph_search_batch(searcher._h, self._h, _p(st, C.c_uint32), _p(q, C.c_uint16), nq, int(l),
                                                int(bool(base_vectors_only)), int(query_breakpoint), _p(bi, C.c_uint32),
                                                _p(bs, C.c_int64), _p(bl, C.c_uint32), _p(nd, C.c_uint32)), "graph_search_batch")
+        if as_arrays:
+            return bi, bs, bl, nd
         return [(bi[i, :bl[i]].copy(), bs[i, :bl[i]].copy(), int(nd[i])) for i in range(nq)]
 
     def close(self):

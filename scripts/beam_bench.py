@@ -78,24 +78,21 @@ luts = np.stack([pq.preprocess_query(q).table for q in qh.astype(np.float32)])
 _, truth = searcher.bruteforce_topk(qh.view(np.uint16), K)
 starts = np.full(nq, start, np.uint32)
 for L, beam, nopq in ((64, 4, False), (128, 4, False), (200, 4, False), (64, 4, True), (200, 4, True)):
-    mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts[:8], qh[:8].view(np.uint16), luts[:8], None, nopq, beam, L, 2048)
+    mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qh.view(np.uint16), luts, None, nopq, beam, L, 2048, as_arrays=True)   # warm
     t0 = time.perf_counter()
-    res = mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qh.view(np.uint16), luts, None, nopq, beam, L, 2048)
+    res = mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qh.view(np.uint16), luts, None, nopq, beam, L, 2048, as_arrays=True)
     dt = time.perf_counter() - t0
-    hits = 0
-    cm = 0
-    for i, (bi, bs, vi, vs, c, p) in enumerate(res):
-        top = vi[np.argsort(-vs, kind="stable")[:K]]          # the server sorts the visited list by exact score (:529)
-        hits += len(set(top.tolist()) & set(truth[i].tolist()))
-        cm += c
+    top = mse.topk_of_visited(res, K)          # the server sorts the visited list by exact score (:529)
+    hits = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq))
     print(f"n={n} L={L} beam={beam} exact_neighbours={nopq}: {nq/dt:8.0f} q/s ({dt*1e3:.1f} ms for {nq} queries, host arrays in/out), recall@10 {hits/(K*nq):.3f}, "
-          f"{cm/nq:.0f} node fetches/query", flush=True)
+          f"{res['cmps'].mean():.0f} node fetches/query", flush=True)
 # f32 queries in, f16 copies and distance tables made on the device (no 64 KiB table per query over PCIe)
 qf = qh.astype(np.float32)
 for L, beam in ((64, 4), (128, 4), (200, 4)):
-    mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts[:8], qf[:8], None, None, False, beam, L, 2048)
+    mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qf, None, None, False, beam, L, 2048, as_arrays=True)
     t0 = time.perf_counter()
-    res = mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qf, None, None, False, beam, L, 2048)
+    res = mse.disk_search_batch(searcher, pq, gcodes, dgraph, starts, qf, None, None, False, beam, L, 2048, as_arrays=True)
     dt = time.perf_counter() - t0
-    hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist())) for i, (_, _, vi, vs, _, _) in enumerate(res))
+    top = mse.topk_of_visited(res, K)
+    hits = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq))
     print(f"n={n} L={L} beam={beam} ADC, f32 queries (tables made on the device): {nq/dt:8.0f} q/s ({dt*1e3:.1f} ms), recall@10 {hits/(K*nq):.3f}", flush=True)

@@ -62,18 +62,19 @@ def main():
     codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
     starts = np.full(nq, med, np.uint32)
     for Ls in (32, 64, 100, 200):
-        mse.disk_search_batch(s, pq, codes, g, starts[:8], qh[:8], None, None, True, 4, Ls, 1024)
+        mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)   # warm: scratch is allocated on first use
         t0 = time.perf_counter()
-        res = mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024)
+        res = mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)
         dt = time.perf_counter() - t0
-        hits = sum(len(set(vi[np.argsort(-vs, kind="stable")[:K]].tolist()) & set(truth[i].tolist())) for i, (_, _, vi, vs, _, _) in enumerate(res))
-        g.search_batch(s, med, qh[:8], Ls)
+        top = mse.topk_of_visited(res, K)
+        hits = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq))
+        g.search_batch(s, med, qh, Ls, as_arrays=True)
         t0 = time.perf_counter()
-        ram = g.search_batch(s, med, qh, Ls)
+        rid, _, _, _ = g.search_batch(s, med, qh, Ls, as_arrays=True)
         dr = time.perf_counter() - t0
-        rh = sum(len(set(ids[:K].tolist()) & set(truth[i].tolist())) for i, (ids, _, _) in enumerate(ram))
+        rh = sum(len(set(rid[i, :K].tolist()) & set(truth[i].tolist())) for i in range(nq))
         print(f"L={Ls}: beam search (beam 4, exact neighbours) {nq/dt:8.0f} q/s recall@10 {hits/(K*nq):.3f} "
-              f"({np.mean([r[4] for r in res]):.0f} node fetches/query); in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f}", flush=True)
+              f"({res['cmps'].mean():.0f} node fetches/query); in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f}", flush=True)
 
 
 if __name__ == "__main__":
