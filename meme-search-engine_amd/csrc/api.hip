@@ -96,7 +96,7 @@ int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_o
     return 0;
 }
 
-static int ensure_norm(const mse_base* b, hipStream_t st) {
+int ensure_base_norm(const mse_base* b, hipStream_t st) {
     std::lock_guard<std::mutex> g(b->norm_mu);
     if (b->norm_ready) return 0;
     if (!b->norm_bits_dev) MSE_HIP_TRY(hipMalloc((void**)&b->norm_bits_dev, 4));
@@ -130,7 +130,7 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
     const int d = (int)b->d;
     const int tile = mfma_query_tile();
     const int nq_pad = tile;
-    if (ensure_norm(b, st)) return -1;
+    if (ensure_base_norm(b, st)) return -1;
     // padded query tile
     if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;
     MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, (size_t)nq_pad * d * 2, st));

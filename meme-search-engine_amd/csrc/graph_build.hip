@@ -21,6 +21,9 @@
 #include "exact_dot.h"
 #include "runtime.h"
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -506,6 +509,219 @@ __global__ __launch_bounds__(GB_THREADS) void backedge_kernel(BackArgs a) {
     if (tid == 0) a.deg[t] = (uint32_t)s_len;
 }
 
+// ---- back edges with the candidate products taken from the matrix cores --------------------------------------------
+// robust_prune over a full list and one newcomer asks for up to 65*64/2 products between candidates, but only to
+// decide `(alpha * s) >> 16 >= score` (lib.rs:266-268).  The 65 x 65 Gram matrix of the candidate rows costs 540
+// v_mfma_f32_16x16x32_f16 per list; its entries are not fast_dot's bit pattern, so a decision is taken from them only
+// when it holds for every value within the error bound of the MFMA sum (the scan kernel's certificate, DESIGN 3.1:
+// |mfma - fast_dot| <= 2.8e-4 * |x| |y|); a comparison inside the bound is settled by the exact dot.  The scores
+// against the list's owner, which fix the candidate order and are the right-hand sides, are always exact.  The
+// result is therefore the reference's, bit for bit; only the cost changes.
+// One WAVE per list (four independent waves per workgroup, no block barriers): exact scores by 16 lane quads per pass;
+// the Gram tiles accumulate from fragments read straight from global memory (lane = row i, k-slot g, 16 bytes);
+// the matrix, the sorted candidates and the prune state live in the wave's 18 KiB of LDS and in registers.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int GR_NB = 5;                  // 16-row blocks: up to 80 >= 65 candidates
+constexpr int GR_C = GB_RMAX + 1;         // 65 candidates at most
+constexpr int GR_GS = 66;                 // row stride of the matrix in LDS
+constexpr int GR_WAVE_LDS = GR_C * GR_GS * 4 + 72 * 8 + 72 * 4 + 72 * 4;
+
+struct GramArgs {
+    BackArgs b;
+    int n_targets;
+    long long eps_fix;   // ceil(2^32 * bound on |mfma - fast_dot|) + 1
+};
+
+__device__ __forceinline__ long long shfl_i64(long long v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long readlane_i64(long long v, int src) {   // src uniform
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(256) void backedge_gram_kernel(GramArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const BackArgs& a = ga.b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ti = blockIdx.x * 4 + wave;
+    if (ti >= ga.n_targets) return;   // the waves of a workgroup never meet at a barrier
+    char* wl = smem + wave * GR_WAVE_LDS;
+    float* G = reinterpret_cast<float*>(wl);
+    long long* s_sc = reinterpret_cast<long long*>(wl + GR_C * GR_GS * 4);
+    uint32_t* s_id = reinterpret_cast<uint32_t*>(wl + GR_C * GR_GS * 4 + 72 * 8);
+    uint32_t* s_pos = s_id + 72;
+    const int d = a.d, r = a.r, T = d / 32;
+    const uint32_t t = a.targets[ti];
+    const uint16_t* trow = a.base + (size_t)t * d;
+    int len = (int)min(a.deg[t], (uint32_t)r);
+    uint32_t cur = lane < len ? a.adj[(size_t)t * r + lane] : 0u;   // lane l holds list entry l
+    const int i16 = lane & 15, g4 = lane >> 4;
+
+    for (uint32_t si = a.src_off[ti]; si < a.src_off[ti + 1]; si++) {
+        const uint32_t p = a.srcs[si];
+        if (len != r) {   // lib.rs:319-321
+            if (!__ballot(lane < len && cur == p) && len < r) {
+                if (lane == len) cur = p;
+                len++;
+            }
+            continue;
+        }
+        const int nc0 = r + 1;   // candidate c < r is list entry c, candidate r is the newcomer
+        // ---- exact scores against the owner (merge_existing_neighbours, lib.rs:215-221) ----
+        long long my_sc = GB_MIN, p_sc = 0;
+        for (int c0 = 0; c0 < nc0; c0 += 16) {
+            int c = c0 + (lane >> 2);
+            if (c > r) c = r;
+            uint32_t idc = (uint32_t)__shfl((int)cur, c < r ? c : 0);
+            if (c == r) idc = p;
+            if (idc >= a.n) { atomicOr(a.err, 64u); idc = 0; }
+            const long long s = scale_dot_result(quad_fast_dot_f32(a.base + (size_t)idc * d, trow, d));
+            const long long got = shfl_i64(s, ((lane - c0) & 15) * 4);
+            if (lane >= c0 && lane < c0 + 16 && lane < r) my_sc = got;
+            if (r >= c0 && r < c0 + 16) p_sc = shfl_i64(s, (r - c0) * 4);
+        }
+        // ---- Gram matrix of the candidate rows on the matrix cores ----
+        {
+            const uint4* rp[GR_NB];
+#pragma unroll
+            for (int b = 0; b < GR_NB; b++) {
+                int c = 16 * b + i16;
+                if (c > r) c = r;
+                uint32_t idc = (uint32_t)__shfl((int)cur, c < r ? c : 0);
+                if (c == r) idc = p;
+                if (idc >= a.n) idc = 0;
+                rp[b] = reinterpret_cast<const uint4*>(a.base + (size_t)idc * d) + g4;
+            }
+            const int nb = (nc0 + 15) / 16;
+            float4v acc[15];
+#pragma unroll
+            for (int x = 0; x < 15; x++) acc[x] = (float4v){0.0f, 0.0f, 0.0f, 0.0f};
+            uint4 fa[GR_NB], fb[GR_NB];
+#pragma unroll
+            for (int b = 0; b < GR_NB; b++) fa[b] = b < nb ? rp[b][0] : make_uint4(0, 0, 0, 0);
+            for (int ks = 0; ks < T; ks += 2) {
+                const int k1 = ks + 1 < T ? ks + 1 : T - 1, k2 = ks + 2 < T ? ks + 2 : T - 1;   // clamped look-ahead: always inside the row
+#pragma unroll
+                for (int b = 0; b < GR_NB; b++) fb[b] = b < nb ? rp[b][k1 * 4] : make_uint4(0, 0, 0, 0);
+                {
+                    int x = 0;
+#pragma unroll
+                    for (int I = 0; I < GR_NB; I++)
+#pragma unroll
+                        for (int J = I; J < GR_NB; J++, x++)
+                            if (J < nb)
+                                acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa[I]), __builtin_bit_cast(half8, fa[J]), acc[x], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < GR_NB; b++) fa[b] = b < nb ? rp[b][k2 * 4] : make_uint4(0, 0, 0, 0);
+                if (ks + 1 < T) {
+                    int x = 0;
+#pragma unroll
+                    for (int I = 0; I < GR_NB; I++)
+#pragma unroll
+                        for (int J = I; J < GR_NB; J++, x++)
+                            if (J < nb)
+                                acc[x] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fb[I]), __builtin_bit_cast(half8, fb[J]), acc[x], 0, 0, 0);
+                }
+            }
+            // tile (I, J): this lane holds rows 16 I + 4 g + v, column 16 J + i; both triangles are written
+            int x = 0;
+#pragma unroll
+            for (int I = 0; I < GR_NB; I++)
+#pragma unroll
+                for (int J = I; J < GR_NB; J++, x++)
+                    if (J < nb) {
+                        const int col = 16 * J + i16;
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const int row = 16 * I + 4 * g4 + v;
+                            if (row < nc0 && col < nc0) { G[row * GR_GS + col] = acc[x][v]; G[col * GR_GS + row] = acc[x][v]; }
+                        }
+                    }
+        }
+        // ---- candidate order: score descending, earlier position first (lib.rs:233), by counting ----
+        {
+            int rank = 0, rank_p = 0;
+            for (int m = 0; m < r; m++) {
+                const long long sm = readlane_i64(my_sc, m);
+                rank += (sm > my_sc || (sm == my_sc && m < lane)) ? 1 : 0;
+                rank_p += sm >= p_sc ? 1 : 0;          // the newcomer is the last position: ties go before it
+            }
+            rank += p_sc > my_sc ? 1 : 0;
+            if (lane < r) { s_sc[rank] = my_sc; s_id[rank] = cur; s_pos[rank] = (uint32_t)lane; }
+            if (lane == 0) { s_sc[rank_p] = p_sc; s_id[rank_p] = p; s_pos[rank_p] = (uint32_t)r; }
+        }
+        int nc = nc0 < a.maxc ? nc0 : a.maxc;
+        // sorted entry i = lane in registers; entry 64 (only when nc0 == 65) is kept by every lane
+        long long e_sc = lane < nc ? s_sc[lane] : GB_MIN;
+        const uint32_t e_id = lane < nc ? s_id[lane] : 0u, e_pos = lane < nc ? s_pos[lane] : 0u;
+        const bool has64 = nc > 64;
+        long long x_sc = has64 ? s_sc[64] : GB_MIN;
+        const uint32_t x_id = has64 ? s_id[64] : 0u, x_pos = has64 ? s_pos[64] : 0u;
+        // ---- robust_prune's loop (lib.rs:236-272) ----
+        uint32_t mine = 0u;   // lane l: new list entry l
+        int nn = 0, ci = 0;
+        while (nn < r && ci < nc) {
+            const uint32_t p_star = ci < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)e_id, ci) : x_id;
+            const uint32_t pos_star = ci < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)e_pos, ci) : x_pos;
+            const long long ps = ci < 64 ? readlane_i64(e_sc, ci) : x_sc;
+            ci++;
+            if (p_star == t || ps == GB_MIN) continue;
+            if (lane == nn) mine = p_star;
+            nn++;
+            // candidates ci + 1 .. nc - 1 that are still alive (the one right behind p_star escapes, as in the reference)
+            const float* grow = G + pos_star * GR_GS;
+            bool border = false, border64 = false;
+            if (lane >= ci + 1 && lane < nc && lane < 64 && e_sc != GB_MIN) {
+                const long long al = e_id >= a.qb ? a.qalpha : a.alpha;
+                const long long scaled = (long long)((unsigned long long)al * (unsigned long long)scale_dot_result(grow[e_pos])) >> 16;
+                const long long m = ((al * ga.eps_fix) >> 16) + 2;
+                if (scaled - m >= e_sc) e_sc = GB_MIN;
+                else if (scaled + m >= e_sc) border = true;
+            }
+            if (has64 && 64 >= ci + 1 && x_sc != GB_MIN) {   // uniform
+                const long long al = x_id >= a.qb ? a.qalpha : a.alpha;
+                const long long scaled = (long long)((unsigned long long)al * (unsigned long long)scale_dot_result(grow[x_pos])) >> 16;
+                const long long m = ((al * ga.eps_fix) >> 16) + 2;
+                if (scaled - m >= x_sc) x_sc = GB_MIN;
+                else if (scaled + m >= x_sc) border64 = true;
+            }
+            unsigned long long bm = __ballot(border);
+            while (bm || border64) {   // comparisons inside the error bound: the exact dot decides (rare)
+                const int j = bm ? __ffsll((long long)bm) - 1 : 64;
+                const uint32_t idj = j < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)e_id, j) : x_id;
+                const long long s = scale_dot_result(quad_fast_dot_f32(a.base + (size_t)idj * d, a.base + (size_t)p_star * d, d));
+                const long long al = idj >= a.qb ? a.qalpha : a.alpha;
+                const bool drop = ((long long)((unsigned long long)al * (unsigned long long)s) >> 16) >= (j < 64 ? readlane_i64(e_sc, j) : x_sc);
+                if (j < 64) {
+                    if (drop && lane == j) e_sc = GB_MIN;
+                    bm &= bm - 1;
+                } else {
+                    if (drop) x_sc = GB_MIN;
+                    border64 = false;
+                }
+            }
+        }
+        if (a.saturate || t >= a.qb) {   // lib.rs:275-284
+            for (int i = 0; i < nc && nn < r; i++) {
+                const uint32_t id = i < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)e_id, i) : x_id;
+                if (__ballot(lane < nn && mine == id)) continue;
+                if (lane == nn) mine = id;
+                nn++;
+            }
+        }
+        cur = lane < nn ? mine : 0u;
+        len = nn;
+    }
+    if (lane < len) a.adj[(size_t)t * r + lane] = cur;
+    if (lane == 0) a.deg[t] = (uint32_t)len;
+}
+
 struct StitchArgs {
     const uint16_t* base; int d;
     uint32_t* adj; uint32_t* deg; int r;
@@ -704,6 +920,22 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     ba.n = (uint32_t)b->n; ba.err = err.as<uint32_t>();
     ba.qb = cfg->query_breakpoint; ba.maxc = (int)cfg->maxc; ba.saturate = (int)cfg->saturate_graph; ba.alpha = cfg->alpha; ba.qalpha = cfg->query_alpha;
     const size_t back_lds = 2 * (size_t)((d * 2 + 15) & ~15);
+    // back edges: candidate products from the matrix cores when the error bound can be stated (finite norms, sane factors)
+    bool use_gram = !getenv("MSE_BUILD_EXACT_BACKEDGE") && d % 64 == 0 && cfg->alpha > 0 && cfg->alpha <= (1 << 20) && cfg->query_alpha > 0 &&
+                    cfg->query_alpha <= (1 << 20);
+    long long eps_fix = 0;
+    if (use_gram) {
+        if (ensure_base_norm(b, st)) return -1;
+        uint32_t bits = 0;
+        MSE_HIP_TRY(hipMemcpy(&bits, b->norm_bits_dev, 4, hipMemcpyDeviceToHost));
+        float mx;
+        memcpy(&mx, &bits, 4);
+        const char* sc = getenv("MSE_GRAM_EPS_SCALE");   // test hook: widen (or zero) the band in which the exact dot decides
+        const double bound = 2.8e-4 * (double)mx * (double)mx * (sc ? atof(sc) : 1.0);
+        if (!(bound == bound) || bound > 1e6) use_gram = false;
+        else eps_fix = (long long)ceil(bound * 4294967296.0) + 1;
+        if (use_gram && set_lds(backedge_gram_kernel)) return -1;
+    }
     for (size_t b0 = 0; b0 < n_order; b0 += batch) {
         const size_t nb = std::min(batch, n_order - b0);
         a.points = d_order.as<uint32_t>() + b0;
@@ -762,7 +994,12 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
         MSE_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, st));
         MSE_HIP_TRY(hipMemcpyAsync(d_src.p, srcs.data(), srcs.size() * 4, hipMemcpyHostToDevice, st));
         ba.targets = d_tg.as<uint32_t>(); ba.src_off = d_off.as<uint32_t>(); ba.srcs = d_src.as<uint32_t>();
-        hipLaunchKernelGGL(backedge_kernel, dim3((unsigned)targets.size()), dim3(GB_THREADS), back_lds, st, ba);
+        if (use_gram) {
+            GramArgs ga{ba, (int)targets.size(), eps_fix};
+            hipLaunchKernelGGL(backedge_gram_kernel, dim3((unsigned)((targets.size() + 3) / 4)), dim3(256), 4 * GR_WAVE_LDS, st, ga);
+        } else {
+            hipLaunchKernelGGL(backedge_kernel, dim3((unsigned)targets.size()), dim3(GB_THREADS), back_lds, st, ba);
+        }
         MSE_HIP_TRY(hipGetLastError());
         uint32_t e2 = 0;
         MSE_HIP_TRY(hipMemcpyAsync(&e2, err.p, 4, hipMemcpyDeviceToHost, st));

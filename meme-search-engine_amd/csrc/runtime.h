@@ -87,6 +87,11 @@ struct mse_codes {
     size_t n = 0, code_size = 0, n_desc = 0;
 };
 
+namespace mse {
+// largest row norm of the base (x 1.0001), computed once and kept on the device as float bits (b->norm_bits_dev)
+int ensure_base_norm(const mse_base* b, hipStream_t st);
+}  // namespace mse
+
 struct mse_graph {
     uint32_t* adj = nullptr;   // device [n][max_deg]
     uint32_t* deg = nullptr;   // device [n]

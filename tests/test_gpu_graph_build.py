@@ -147,6 +147,24 @@ def test_build_graph_with_queries_and_stitch_matches_oracle(gpu, mse, orc):
     assert deg.max() <= r
 
 
+@pytest.mark.parametrize("env", [{"MSE_GRAM_EPS_SCALE": "3000"}, {"MSE_BUILD_EXACT_BACKEDGE": "1"}])
+def test_back_edge_paths_agree(gpu, mse, orc, env, monkeypatch):
+    """The back-edge prune takes candidate products from MFMA tiles and settles comparisons inside the error bound with the
+    exact dot.  Widening the bound 3000-fold sends nearly every comparison down the exact path; the all-exact kernel is the
+    third route.  All three must give the oracle's graph (the default route is what the other tests run)."""
+    n, r = 3000, 64
+    vecs = rows(orc, n, seed=9)
+    order = np.random.default_rng(5).permutation(n).astype(np.uint32)
+    med = int(orc.medioid(vecs))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    adj, deg, g, _ = build_both(orc, mse, vecs, r, order, med, [dict(r=r, l=96, maxc=400)], 256)
+    h = g.to_host()
+    assert np.array_equal(h.deg, deg)
+    for i in range(n):
+        assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), i
+
+
 def test_build_graph_rejects_bad_arguments(gpu, mse, orc):
     n, r = 300, 8
     vecs = rows(orc, n, clustered=False)
