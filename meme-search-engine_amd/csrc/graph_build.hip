@@ -691,20 +691,27 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(GramArgs ga) {
                 if (scaled - m >= x_sc) x_sc = GB_MIN;
                 else if (scaled + m >= x_sc) border64 = true;
             }
+            // comparisons inside the error bound: the exact dot decides, sixteen candidates per pass (one lane quad each)
             unsigned long long bm = __ballot(border);
-            while (bm || border64) {   // comparisons inside the error bound: the exact dot decides (rare)
-                const int j = bm ? __ffsll((long long)bm) - 1 : 64;
-                const uint32_t idj = j < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)e_id, j) : x_id;
+            while (bm) {
+                const int cnt = __popcll(bm), take = cnt < 16 ? cnt : 16;
+                unsigned long long mm = bm;
+                for (int z = (lane >> 2) < take ? (lane >> 2) : 0; z > 0; z--) mm &= mm - 1;
+                const int j = __ffsll((long long)mm) - 1;   // this quad's candidate (quads past `take` repeat the first)
+                const uint32_t idj = (uint32_t)__shfl((int)e_id, j);
                 const long long s = scale_dot_result(quad_fast_dot_f32(a.base + (size_t)idj * d, a.base + (size_t)p_star * d, d));
                 const long long al = idj >= a.qb ? a.qalpha : a.alpha;
-                const bool drop = ((long long)((unsigned long long)al * (unsigned long long)s) >> 16) >= (j < 64 ? readlane_i64(e_sc, j) : x_sc);
-                if (j < 64) {
-                    if (drop && lane == j) e_sc = GB_MIN;
+                const int drop = ((long long)((unsigned long long)al * (unsigned long long)s) >> 16) >= shfl_i64(e_sc, j) ? 1 : 0;
+                for (int q = 0; q < take; q++) {
+                    const int jq = __builtin_amdgcn_readlane(j, q * 4), dq = __builtin_amdgcn_readlane(drop, q * 4);
+                    if (dq && lane == jq) e_sc = GB_MIN;
                     bm &= bm - 1;
-                } else {
-                    if (drop) x_sc = GB_MIN;
-                    border64 = false;
                 }
+            }
+            if (border64) {
+                const long long s = scale_dot_result(quad_fast_dot_f32(a.base + (size_t)x_id * d, a.base + (size_t)p_star * d, d));
+                const long long al = x_id >= a.qb ? a.qalpha : a.alpha;
+                if (((long long)((unsigned long long)al * (unsigned long long)s) >> 16) >= x_sc) x_sc = GB_MIN;
             }
         }
         if (a.saturate || t >= a.qb) {   // lib.rs:275-284
