@@ -43,6 +43,19 @@ __device__ __forceinline__ bool cand_before(long long sa, uint32_t pa, long long
     return sa > sb || (sa == sb && pa < pb);
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long long shfl_i64(long long v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long readlane_i64(long long v, int src) {   // src uniform
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // Bitonic sort of N (power of two, <= GB_WIN) candidates, best first: score descending, earlier position first among
 // equal scores (sort_unstable_by_key(-score), lib.rs:233, restated as a stable sort -- see the oracle's note).
 __device__ void wg_sort(long long* sc, uint32_t* id, uint32_t* pos, int N) {
@@ -97,6 +110,7 @@ struct PruneParams {
     const uint16_t* base; int d;
     uint32_t qb; long long alpha, qalpha; int r, saturate;
     uint32_t n; uint32_t* err;
+    long long eps_fix;   // > 0: candidate products may be taken from the matrix cores (see wg_robust_prune_mfma); 0: exact dots only
 };
 
 // robust_prune (lib.rs:227-285) after its sort/truncate: candidates c_*[0..nc) best first.  Called by the whole
@@ -413,6 +427,116 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
     }
 }
 
+// robust_prune's loop, candidate-major, with the products from the matrix cores.
+// The reference walks p_star by p_star and discards later candidates (lib.rs:236-272).  Whether candidate i is still alive
+// when the walk reaches it depends only on the selected candidates before it: it is dead iff some selected s at index
+// <= i - 2 (the candidate right behind a p_star is never tested against it, :240,250) has (alpha * dot(s, i)) >> 16 >= score_i.
+// So the walk can go candidate by candidate, sixteen at a time: the four waves take the products of the sixteen candidates
+// with the (at most 64) rows selected so far, one 16 x 16 MFMA tile per wave, plus the tile of the sixteen among themselves;
+// wave 0 then settles the sixteen in order.  A product decides only if the comparison holds for every value within the MFMA
+// error bound (eps_fix, the scan's certificate); inside the bound the exact quad dot decides.  Candidate rows are read once
+// instead of once per p_star they survive.  Same result as wg_robust_prune, bit for bit.
+// P: [64][16] floats, Q: [16][16] floats, s_selidx: [64] ints (LDS).  d / 32 must be a multiple of 6.
+__device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, const long long* c_sc, const uint32_t* c_id, float* P, float* Q,
+                                    int* s_selidx, uint32_t* s_neigh, int* s_cnt) {
+    constexpr int PD = 6;   // k-steps in flight
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int d = pp.d, T = d / 32, r = pp.r;
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nc; b0 += 16) {
+        const int nn0 = *s_cnt;
+        if (nn0 >= r) break;
+        const int ntile = (nn0 + 15) / 16, intra_wave = ntile < 4 ? ntile : 0;
+        const bool do_sel = wave < ntile, do_intra = wave == intra_wave;
+        if (do_sel || do_intra) {
+            const int cb = b0 + i16 < nc ? b0 + i16 : nc - 1;
+            const uint4* rb = reinterpret_cast<const uint4*>(pp.base + (size_t)c_id[cb] * d) + g4;
+            int sa = 16 * wave + i16;
+            if (sa > nn0 - 1) sa = nn0 - 1;
+            const uint4* ra = do_sel ? reinterpret_cast<const uint4*>(pp.base + (size_t)s_neigh[sa] * d) + g4 : rb;
+            float4v acc_s = {0.0f, 0.0f, 0.0f, 0.0f}, acc_i = {0.0f, 0.0f, 0.0f, 0.0f};
+            uint4 fa[PD], fb[PD];
+#pragma unroll
+            for (int u = 0; u < PD; u++) { fa[u] = ra[u * 4]; fb[u] = rb[u * 4]; }
+            for (int k0 = 0; k0 < T; k0 += PD) {
+#pragma unroll
+                for (int u = 0; u < PD; u++) {
+                    const half8 A = __builtin_bit_cast(half8, fa[u]), B = __builtin_bit_cast(half8, fb[u]);
+                    const int kn = k0 + PD + u < T ? k0 + PD + u : T - 1;   // clamped: always inside the row
+                    fa[u] = ra[kn * 4];
+                    fb[u] = rb[kn * 4];
+                    if (do_sel) acc_s = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc_s, 0, 0, 0);
+                    if (do_intra) acc_i = __builtin_amdgcn_mfma_f32_16x16x32_f16(B, B, acc_i, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                if (do_sel) P[(16 * wave + 4 * g4 + v) * 16 + i16] = acc_s[v];
+                if (do_intra) Q[(4 * g4 + v) * 16 + i16] = acc_i[v];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int nn = nn0;
+            for (int j = 0; j < 16 && b0 + j < nc && nn < r; j++) {
+                const int i = b0 + j;
+                const long long sc = c_sc[i];
+                const uint32_t id = c_id[i];
+                if (sc == GB_MIN) continue;
+                const long long al = id >= pp.qb ? pp.qalpha : pp.alpha;
+                const long long m = ((al * pp.eps_fix) >> 16) + 2;
+                bool kill = false, border = false;
+                if (lane < nn) {
+                    const int si = s_selidx[lane];
+                    if (si <= i - 2) {
+                        const float g = lane < nn0 ? P[lane * 16 + j] : Q[(si - b0) * 16 + j];
+                        const long long scaled = (long long)((unsigned long long)al * (unsigned long long)scale_dot_result(g)) >> 16;
+                        if (scaled - m >= sc) kill = true;
+                        else if (scaled + m >= sc) border = true;
+                    }
+                }
+                bool dead = __ballot(kill) != 0ull;
+                unsigned long long bm = dead ? 0ull : __ballot(border);
+                while (bm && !dead) {   // inside the error bound: exact dots, sixteen selected rows per pass
+                    const int cnt = __popcll(bm), take = cnt < 16 ? cnt : 16;
+                    unsigned long long mm = bm;
+                    for (int z = (lane >> 2) < take ? (lane >> 2) : 0; z > 0; z--) mm &= mm - 1;
+                    const int sl = __ffsll((long long)mm) - 1;
+                    const long long s = scale_dot_result(quad_fast_dot_f32(pp.base + (size_t)id * d, pp.base + (size_t)s_neigh[sl] * d, d));
+                    const bool hit = (lane >> 2) < take && ((long long)((unsigned long long)al * (unsigned long long)s) >> 16) >= sc;
+                    dead = __ballot(hit) != 0ull;
+                    for (int q = 0; q < take; q++) bm &= bm - 1;
+                }
+                if (dead || id == p) continue;
+                if (lane == 0) { s_neigh[nn] = id; s_selidx[nn] = i; }
+                nn++;
+            }
+            if (lane == 0) *s_cnt = nn;
+        }
+        __syncthreads();
+    }
+    int nn = *s_cnt;
+    if (pp.saturate || p >= pp.qb) {   // lib.rs:275-284
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t mine = tid < nn ? s_neigh[tid] : 0u;
+            for (int i = 0; i < nc && nn < r; i++) {
+                const uint32_t id = c_id[i];
+                if (__ballot(tid < nn && mine == id)) continue;
+                if (tid == nn) mine = id;
+                nn++;
+            }
+            if (tid < nn) s_neigh[tid] = mine;
+            if (tid == 0) *s_cnt = nn;
+        }
+        __syncthreads();
+        nn = *s_cnt;
+    }
+    __syncthreads();
+    return nn;
+}
+
 // robust_prune (lib.rs:227-285), one workgroup per point: candidate list b is (ci, cs)[b * stride ..][0..counts[b]),
 // the point is points[b]; the new list goes to staging row b.
 __global__ __launch_bounds__(GB_THREADS) void prune_kernel(PruneParams pp, const uint32_t* ci, const long long* cs, size_t stride,
@@ -431,7 +555,13 @@ __global__ __launch_bounds__(GB_THREADS) void prune_kernel(PruneParams pp, const
     const size_t b = blockIdx.x;
     int nc = wg_best_candidates(ci + b * stride, cs + b * stride, (int)counts[b], c_sc, c_id, c_pos);
     if (nc > maxc) nc = maxc;
-    const int nn = wg_robust_prune(pp, points[b], nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
+    int nn;
+    if (pp.eps_fix > 0) {   // the upper half of the sort window is free once the candidates are sorted: tiles and selected indices
+        float* P = reinterpret_cast<float*>(c_sc + GB_WIN / 2);
+        nn = wg_robust_prune_mfma(pp, points[b], nc, c_sc, c_id, P, P + 64 * 16, reinterpret_cast<int*>(P + 64 * 16 + 16 * 16), s_neigh, &s_cnt);
+    } else {
+        nn = wg_robust_prune(pp, points[b], nc, c_sc, c_id, s_star, s_live, s_neigh, &s_cnt);
+    }
     if ((int)threadIdx.x < nn) out_ids[b * pp.r + threadIdx.x] = s_neigh[threadIdx.x];
     if (threadIdx.x == 0) out_len[b] = (uint32_t)nn;
 }
@@ -520,8 +650,6 @@ __global__ __launch_bounds__(GB_THREADS) void backedge_kernel(BackArgs a) {
 // One WAVE per list (four independent waves per workgroup, no block barriers): exact scores by 16 lane quads per pass;
 // the Gram tiles accumulate from fragments read straight from global memory (lane = row i, k-slot g, 16 bytes);
 // the matrix, the sorted candidates and the prune state live in the wave's 18 KiB of LDS and in registers.
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int GR_NB = 5;                  // 16-row blocks: up to 80 >= 65 candidates
 constexpr int GR_C = GB_RMAX + 1;         // 65 candidates at most
@@ -533,16 +661,6 @@ struct GramArgs {
     int n_targets;
     long long eps_fix;   // ceil(2^32 * bound on |mfma - fast_dot|) + 1
 };
-
-__device__ __forceinline__ long long shfl_i64(long long v, int src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)((unsigned long long)v >> 32), src);
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ long long readlane_i64(long long v, int src) {   // src uniform
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), src);
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
 
 __global__ __launch_bounds__(256) void backedge_gram_kernel(GramArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -845,6 +963,23 @@ int check_graph(const mse_graph* g, hipStream_t st, const char* who) {
     return 0;
 }
 
+// Bound, in the fixed-point scale, on |MFMA f16 sum - fast_dot| for two base rows: 2.8e-4 * (largest row norm)^2, the
+// allowance the scan's certificate uses.  *eps_fix = 0 when no bound can be stated (the exact kernels run).
+int mfma_bound(const mse_base* b, const mse_build_config* cfg, hipStream_t st, long long* eps_fix) {
+    *eps_fix = 0;
+    if (b->d % 64 || cfg->alpha <= 0 || cfg->alpha > (1 << 20) || cfg->query_alpha <= 0 || cfg->query_alpha > (1 << 20)) return 0;
+    if (ensure_base_norm(b, st)) return -1;
+    uint32_t bits = 0;
+    MSE_HIP_TRY(hipMemcpy(&bits, b->norm_bits_dev, 4, hipMemcpyDeviceToHost));
+    float mx;
+    memcpy(&mx, &bits, 4);
+    const char* sc = getenv("MSE_GRAM_EPS_SCALE");   // test hook: widen (or zero) the band in which the exact dot decides
+    const double bound = 2.8e-4 * (double)mx * (double)mx * (sc ? atof(sc) : 1.0);
+    if (!(bound == bound) || bound > 1e6) return 0;
+    *eps_fix = (long long)ceil(bound * 4294967296.0) + 1;
+    return 0;
+}
+
 template <typename K> int set_lds(K kernel) {
     MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     return 0;
@@ -911,7 +1046,7 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     MSE_HIP_TRY(hipMemcpyAsync(d_order.p, order, n_order * 4, hipMemcpyHostToDevice, st));
     if (set_lds(graph_search_kernel<true>) || set_lds(prune_kernel)) return -1;
     const size_t lds = search_lds_bytes(d, (int)cfg->l);
-    const PruneParams pp{b->dev, d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, r, (int)cfg->saturate_graph, (uint32_t)b->n, err.as<uint32_t>()};
+    PruneParams pp{b->dev, d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, r, (int)cfg->saturate_graph, (uint32_t)b->n, err.as<uint32_t>(), 0};
     std::vector<uint32_t> h_stg(batch * r), h_len(batch), targets, offs, srcs;
     std::vector<uint32_t> slot(b->n, 0xffffffffu), first_seen, counts, fill;
     GraphArgs a{};
@@ -927,22 +1062,12 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     ba.n = (uint32_t)b->n; ba.err = err.as<uint32_t>();
     ba.qb = cfg->query_breakpoint; ba.maxc = (int)cfg->maxc; ba.saturate = (int)cfg->saturate_graph; ba.alpha = cfg->alpha; ba.qalpha = cfg->query_alpha;
     const size_t back_lds = 2 * (size_t)((d * 2 + 15) & ~15);
-    // back edges: candidate products from the matrix cores when the error bound can be stated (finite norms, sane factors)
-    bool use_gram = !getenv("MSE_BUILD_EXACT_BACKEDGE") && d % 64 == 0 && cfg->alpha > 0 && cfg->alpha <= (1 << 20) && cfg->query_alpha > 0 &&
-                    cfg->query_alpha <= (1 << 20);
+    // candidate products from the matrix cores wherever the error bound can be stated (finite norms, sane factors)
     long long eps_fix = 0;
-    if (use_gram) {
-        if (ensure_base_norm(b, st)) return -1;
-        uint32_t bits = 0;
-        MSE_HIP_TRY(hipMemcpy(&bits, b->norm_bits_dev, 4, hipMemcpyDeviceToHost));
-        float mx;
-        memcpy(&mx, &bits, 4);
-        const char* sc = getenv("MSE_GRAM_EPS_SCALE");   // test hook: widen (or zero) the band in which the exact dot decides
-        const double bound = 2.8e-4 * (double)mx * (double)mx * (sc ? atof(sc) : 1.0);
-        if (!(bound == bound) || bound > 1e6) use_gram = false;
-        else eps_fix = (long long)ceil(bound * 4294967296.0) + 1;
-        if (use_gram && set_lds(backedge_gram_kernel)) return -1;
-    }
+    if (mfma_bound(b, cfg, st, &eps_fix)) return -1;
+    const bool use_gram = eps_fix > 0 && !getenv("MSE_BUILD_EXACT_BACKEDGE");
+    if (use_gram && set_lds(backedge_gram_kernel)) return -1;
+    if (eps_fix > 0 && d % 192 == 0 && !getenv("MSE_BUILD_EXACT_PRUNE")) pp.eps_fix = eps_fix;
     for (size_t b0 = 0; b0 < n_order; b0 += batch) {
         const size_t nb = std::min(batch, n_order - b0);
         a.points = d_order.as<uint32_t>() + b0;
@@ -1100,7 +1225,8 @@ int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* c
     const uint32_t hdr[3] = {(uint32_t)n_cand, p, 0u};   // counts[0], points[0], error word
     MSE_HIP_TRY(hipMemcpyAsync(out.as<uint32_t>() + GB_RMAX + 1, hdr, 12, hipMemcpyHostToDevice, st));
     PruneParams pp{b->dev, (int)b->d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, (int)cfg->r, (int)cfg->saturate_graph, (uint32_t)b->n,
-                   out.as<uint32_t>() + GB_RMAX + 3};
+                   out.as<uint32_t>() + GB_RMAX + 3, 0};
+    if (b->d % 192 == 0 && !getenv("MSE_BUILD_EXACT_PRUNE") && mfma_bound(b, cfg, st, &pp.eps_fix)) return -1;
     hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(GB_THREADS), prune_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(), (size_t)0,
                        out.as<uint32_t>() + GB_RMAX + 1, out.as<uint32_t>() + GB_RMAX + 2, (int)cfg->maxc, out.as<uint32_t>(),
                        out.as<uint32_t>() + GB_RMAX);
