@@ -77,10 +77,81 @@ __device__ void wg_sort(long long* sc, uint32_t* id, uint32_t* pos, int N) {
         }
 }
 
-// The best min(total, GB_CMAX) of the candidate list (vi, vs)[0..total) in HBM, sorted into c_*[0..): the first window
-// is sorted whole, every further 1024 entries are sorted in behind the best 1024 so far.  Returns how many are valid.
-__device__ int wg_best_candidates(const uint32_t* vi, const long long* vs, int total, long long* c_sc, uint32_t* c_id, uint32_t* c_pos) {
+// The best min(total, want) (want <= GB_CMAX) of the candidate list (vi, vs)[0..total) in HBM, sorted into c_*[0..).  Returns
+// how many are valid (at least min(total, want)).
+// A list that fits the 2048-entry window is sorted whole.  A longer one (a search at L = 192 leaves about 7000) is first
+// cut down by value: 4096 equal buckets between the smallest and the largest score, a histogram, and the bucket that holds
+// the want-th best score -- every entry in that bucket or above is gathered (position kept) and the survivors are sorted
+// once.  The cut only removes entries that cannot be among the best `want`, so the result equals a full stable sort.
+// If ties crowd more than a window's worth of entries into the cut, the list is fed through the window 1024 at a time.
+__device__ int wg_best_candidates(const uint32_t* vi, const long long* vs, int total, long long* c_sc, uint32_t* c_id, uint32_t* c_pos,
+                                  int want = GB_CMAX) {
     const int tid = threadIdx.x;
+    __shared__ long long s_mn, s_mx;
+    __shared__ int s_thr, s_count;
+    __shared__ uint32_t s_part[GB_THREADS];
+    if (total > GB_WIN) {
+        long long mn = 0x7fffffffffffffffll, mx = GB_MIN;
+        for (int e = tid; e < total; e += GB_THREADS) {
+            const long long v = vs[e];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+        for (int o = 32; o >= 1; o >>= 1) {
+            const long long a = shfl_i64(mn, (threadIdx.x & 63) ^ o), b = shfl_i64(mx, (threadIdx.x & 63) ^ o);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if (tid == 0) { s_mn = 0x7fffffffffffffffll; s_mx = GB_MIN; s_count = 0; }
+        uint32_t* hist = reinterpret_cast<uint32_t*>(c_sc);   // 4096 bins = the window's score array
+        for (int e = tid; e < 4096; e += GB_THREADS) hist[e] = 0u;
+        __syncthreads();
+        if ((tid & 63) == 0) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+        __syncthreads();
+        mn = s_mn;
+        const unsigned long long range = (unsigned long long)s_mx - (unsigned long long)mn;
+        int sh = 0;
+        while ((range >> sh) >= (1ull << 40)) sh++;
+        const unsigned long long den = (range >> sh) + 1ull;
+        auto bucket = [&](long long v) -> int { return (int)(((((unsigned long long)v - (unsigned long long)mn) >> sh) * 4096ull) / den); };
+        for (int e = tid; e < total; e += GB_THREADS) atomicAdd(&hist[bucket(vs[e])], 1u);
+        __syncthreads();
+        // bucket of the want-th best: the largest b with (entries in buckets >= b) >= want
+        uint32_t mine = 0;
+        for (int x = 0; x < 16; x++) mine += hist[tid * 16 + x];
+        s_part[tid] = mine;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t above = 0;
+            int t = GB_THREADS - 1;
+            while (t > 0 && above + s_part[t] < (uint32_t)want) { above += s_part[t]; t--; }
+            int b = t * 16 + 15;
+            while (b > t * 16 && above + hist[b] < (uint32_t)want) { above += hist[b]; b--; }
+            s_thr = b;
+            uint32_t cnt = above;           // entries in buckets > b so far; add bucket b itself
+            s_part[0] = cnt + hist[b];
+        }
+        __syncthreads();
+        const int thr = s_thr;
+        const int kept = (int)s_part[0];
+        __syncthreads();
+        if (kept <= GB_WIN) {
+            for (int e = tid; e < total; e += GB_THREADS) {
+                const long long v = vs[e];
+                if (bucket(v) >= thr) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    c_sc[slot] = v; c_id[slot] = vi[e]; c_pos[slot] = (uint32_t)e;
+                }
+            }
+            __syncthreads();
+            int N = 2;
+            while (N < kept) N <<= 1;
+            for (int e = kept + tid; e < N; e += GB_THREADS) { c_sc[e] = GB_MIN; c_id[e] = 0xffffffffu; c_pos[e] = 0xffffffffu; }
+            __syncthreads();
+            wg_sort(c_sc, c_id, c_pos, N);
+            return kept < GB_CMAX ? kept : GB_CMAX;
+        }
+    }
     const int first = total < GB_WIN ? total : GB_WIN;
     int N = 2;
     while (N < first) N <<= 1;
@@ -442,11 +513,26 @@ __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, c
     constexpr int PD = 6;   // k-steps in flight
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g4 = lane >> 4;
     const int d = pp.d, T = d / 32, r = pp.r;
+    __shared__ unsigned long long s_border[16];   // per candidate of the block: selected rows whose comparison needs the exact dot
+    __shared__ int s_kill[16];                    // per candidate: some selected row discards it for certain
     if (tid == 0) *s_cnt = 0;
+    uint32_t sink = 0;
+    // candidate rows are first touched two blocks before their tiles are computed, so that the fragments come from L2
+    auto touch = [&](int b0) {
+        const int lines = (d * 2 + 127) / 128;
+        for (int e = tid; e < 16 * lines; e += GB_THREADS) {
+            const int c = b0 + e / lines;
+            if (c < nc) sink ^= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pp.base + (size_t)c_id[c] * d) + (size_t)(e % lines) * 128);
+        }
+    };
     __syncthreads();
+    touch(0);
+    touch(16);
     for (int b0 = 0; b0 < nc; b0 += 16) {
         const int nn0 = *s_cnt;
         if (nn0 >= r) break;
+        touch(b0 + 32);
+        if (tid < 16) { s_border[tid] = 0ull; s_kill[tid] = 0; }
         const int ntile = (nn0 + 15) / 16, intra_wave = ntile < 4 ? ntile : 0;
         const bool do_sel = wave < ntile, do_intra = wave == intra_wave;
         if (do_sel || do_intra) {
@@ -477,7 +563,28 @@ __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, c
             }
         }
         __syncthreads();
-        if (wave == 0) {
+        // every (selected row, candidate of the block) pair at once: thread = (candidate j, four selected rows)
+        {
+            const int j = tid >> 4, i = b0 + j;
+            if (i < nc) {
+                const long long sc = c_sc[i];
+                const uint32_t id = c_id[i];
+                const long long al = id >= pp.qb ? pp.qalpha : pp.alpha;
+                const long long m = ((al * pp.eps_fix) >> 16) + 2;
+                unsigned long long bord = 0ull;
+                int kill = 0;
+                for (int l = tid & 15; l < nn0; l += 16)
+                    if (s_selidx[l] <= i - 2) {
+                        const long long scaled = (long long)((unsigned long long)al * (unsigned long long)scale_dot_result(P[l * 16 + j])) >> 16;
+                        if (scaled - m >= sc) kill = 1;
+                        else if (scaled + m >= sc) bord |= 1ull << l;
+                    }
+                if (kill) atomicOr(&s_kill[j], 1);
+                if (bord) atomicOr(&s_border[j], bord);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {   // the sixteen in order; only rows selected inside this block still have to be looked at one by one
             int nn = nn0;
             for (int j = 0; j < 16 && b0 + j < nc && nn < r; j++) {
                 const int i = b0 + j;
@@ -486,18 +593,17 @@ __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, c
                 if (sc == GB_MIN) continue;
                 const long long al = id >= pp.qb ? pp.qalpha : pp.alpha;
                 const long long m = ((al * pp.eps_fix) >> 16) + 2;
-                bool kill = false, border = false;
-                if (lane < nn) {
+                bool kill = s_kill[j] != 0, border = false;
+                if (!kill && lane >= nn0 && lane < nn) {
                     const int si = s_selidx[lane];
                     if (si <= i - 2) {
-                        const float g = lane < nn0 ? P[lane * 16 + j] : Q[(si - b0) * 16 + j];
-                        const long long scaled = (long long)((unsigned long long)al * (unsigned long long)scale_dot_result(g)) >> 16;
+                        const long long scaled = (long long)((unsigned long long)al * (unsigned long long)scale_dot_result(Q[(si - b0) * 16 + j])) >> 16;
                         if (scaled - m >= sc) kill = true;
                         else if (scaled + m >= sc) border = true;
                     }
                 }
                 bool dead = __ballot(kill) != 0ull;
-                unsigned long long bm = dead ? 0ull : __ballot(border);
+                unsigned long long bm = dead ? 0ull : (__ballot(border) | s_border[j]);
                 while (bm && !dead) {   // inside the error bound: exact dots, sixteen selected rows per pass
                     const int cnt = __popcll(bm), take = cnt < 16 ? cnt : 16;
                     unsigned long long mm = bm;
@@ -516,6 +622,7 @@ __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, c
         }
         __syncthreads();
     }
+    if (sink == 0x9e3779b9u && pp.n == 0xffffffffu) atomicOr(pp.err, 256u);   // keeps the touches alive; never true
     int nn = *s_cnt;
     if (pp.saturate || p >= pp.qb) {   // lib.rs:275-284
         __syncthreads();
@@ -553,7 +660,7 @@ __global__ __launch_bounds__(GB_THREADS) void prune_kernel(PruneParams pp, const
     uint16_t* s_live = reinterpret_cast<uint16_t*>(p0);
     __shared__ int s_cnt;
     const size_t b = blockIdx.x;
-    int nc = wg_best_candidates(ci + b * stride, cs + b * stride, (int)counts[b], c_sc, c_id, c_pos);
+    int nc = wg_best_candidates(ci + b * stride, cs + b * stride, (int)counts[b], c_sc, c_id, c_pos, maxc);
     if (nc > maxc) nc = maxc;
     int nn;
     if (pp.eps_fix > 0) {   // the upper half of the sort window is free once the candidates are sorted: tiles and selected indices
@@ -1067,7 +1174,9 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     if (mfma_bound(b, cfg, st, &eps_fix)) return -1;
     const bool use_gram = eps_fix > 0 && !getenv("MSE_BUILD_EXACT_BACKEDGE");
     if (use_gram && set_lds(backedge_gram_kernel)) return -1;
-    if (eps_fix > 0 && d % 192 == 0 && !getenv("MSE_BUILD_EXACT_PRUNE")) pp.eps_fix = eps_fix;
+    // the candidate-major MFMA walk of the prune is exact too, but re-reads the selected rows per block of sixteen and is not
+    // faster than the p_star walk yet: opt-in
+    if (eps_fix > 0 && d % 192 == 0 && getenv("MSE_BUILD_MFMA_PRUNE")) pp.eps_fix = eps_fix;
     for (size_t b0 = 0; b0 < n_order; b0 += batch) {
         const size_t nb = std::min(batch, n_order - b0);
         a.points = d_order.as<uint32_t>() + b0;
@@ -1226,7 +1335,7 @@ int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* c
     MSE_HIP_TRY(hipMemcpyAsync(out.as<uint32_t>() + GB_RMAX + 1, hdr, 12, hipMemcpyHostToDevice, st));
     PruneParams pp{b->dev, (int)b->d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, (int)cfg->r, (int)cfg->saturate_graph, (uint32_t)b->n,
                    out.as<uint32_t>() + GB_RMAX + 3, 0};
-    if (b->d % 192 == 0 && !getenv("MSE_BUILD_EXACT_PRUNE") && mfma_bound(b, cfg, st, &pp.eps_fix)) return -1;
+    if (b->d % 192 == 0 && getenv("MSE_BUILD_MFMA_PRUNE") && mfma_bound(b, cfg, st, &pp.eps_fix)) return -1;
     hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(GB_THREADS), prune_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(), (size_t)0,
                        out.as<uint32_t>() + GB_RMAX + 1, out.as<uint32_t>() + GB_RMAX + 2, (int)cfg->maxc, out.as<uint32_t>(),
                        out.as<uint32_t>() + GB_RMAX);

@@ -82,6 +82,23 @@ def test_robust_prune_matches_oracle(gpu, mse, orc, n_cand, alpha, saturate, p_i
         assert 0 < len(want) <= 64
 
 
+def test_robust_prune_mfma_route_long_list(gpu, mse, orc, monkeypatch):
+    """The candidate-major MFMA walk behind a 6000-entry list (value cut + one sort), default bound and widened bound."""
+    n = 3000
+    vecs = rows(orc, n, seed=4)
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    rng = np.random.default_rng(8)
+    ids = rng.integers(0, n, 6000).astype(np.uint32)
+    scores = orc.score_rows(vecs, ids, vecs[11])
+    kw = dict(r=64, l=192, maxc=750, alpha=65536, query_alpha=65536, query_breakpoint=0xFFFFFFFF)
+    oc, mc = cfg_pair(orc, mse, **kw)
+    want = orc.robust_prune(vecs, ids, scores, 11, oc)
+    monkeypatch.setenv("MSE_BUILD_MFMA_PRUNE", "1")
+    assert np.array_equal(mse.robust_prune(s, ids, scores, 11, mc), want)
+    monkeypatch.setenv("MSE_GRAM_EPS_SCALE", "3000")
+    assert np.array_equal(mse.robust_prune(s, ids, scores, 11, mc), want)
+
+
 def build_both(orc, mse, vecs, r, order, med, passes, batch, seed=21, stitch_order=None):
     n = len(vecs)
     adj, deg = orc.random_fill_graph(seed, n, r)
@@ -147,11 +164,13 @@ def test_build_graph_with_queries_and_stitch_matches_oracle(gpu, mse, orc):
     assert deg.max() <= r
 
 
-@pytest.mark.parametrize("env", [{"MSE_GRAM_EPS_SCALE": "3000"}, {"MSE_BUILD_EXACT_BACKEDGE": "1"}])
-def test_back_edge_paths_agree(gpu, mse, orc, env, monkeypatch):
+@pytest.mark.parametrize("env", [{"MSE_GRAM_EPS_SCALE": "3000"}, {"MSE_BUILD_EXACT_BACKEDGE": "1"}, {"MSE_BUILD_MFMA_PRUNE": "1"},
+                                 {"MSE_BUILD_MFMA_PRUNE": "1", "MSE_GRAM_EPS_SCALE": "3000"}])
+def test_mfma_and_exact_routes_agree(gpu, mse, orc, env, monkeypatch):
     """The back-edge prune takes candidate products from MFMA tiles and settles comparisons inside the error bound with the
     exact dot.  Widening the bound 3000-fold sends nearly every comparison down the exact path; the all-exact kernel is the
-    third route.  All three must give the oracle's graph (the default route is what the other tests run)."""
+    third route; the main prune has an MFMA (candidate-major) route as well, off by default.  Every route must give the
+    oracle's graph (the default routes are what the other tests run)."""
     n, r = 3000, 64
     vecs = rows(orc, n, seed=9)
     order = np.random.default_rng(5).permutation(n).astype(np.uint32)
