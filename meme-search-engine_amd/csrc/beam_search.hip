@@ -29,7 +29,6 @@ constexpr int BS_THREADS = 256;
 constexpr int BS_LMAX = 1024;
 constexpr int BS_BEAM_MAX = 8;
 constexpr int BS_DEG_MAX = 64;
-constexpr int BS_PRE_MAX = BS_BEAM_MAX * BS_DEG_MAX;
 constexpr int BS_DESC_MAX = 8;
 
 struct BeamArgs {

@@ -745,7 +745,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 // be complete at phase p's wait; with the issue order above that leaves four younger units (8 DMAs) in flight.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PP_STAGE = 4096;
-constexpr int PP_STORES = 16;
 constexpr int LDSPP_BYTES = 2 * P8_BUF + 8 * PP_STAGE;   // 160 KiB (NT = 2); the 128-column variant needs 2 * 48 KiB + 32 KiB
 
 // NT = 16-column fragments per n-quadrant of a wave: 2 -> 256-column tiles (wave tile 128 x 64); 1 -> 128-column tiles

@@ -184,6 +184,38 @@ def test_mfma_and_exact_routes_agree(gpu, mse, orc, env, monkeypatch):
         assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), i
 
 
+def test_build_properties_at_scale(gpu, mse, orc):
+    """1e5 points at the reference's defaults (R 64, L 192, C 750) -- too many for the oracle in a test, so size-independent
+    properties instead: the build is a function of (order, initial graph) -- two runs give the same graph, and a different
+    batch size a different but equally valid one; lists hold at most R ids, all inside the index; every point finds itself."""
+    n, r = 100_000, 64
+    host = rows(orc, n, seed=13)
+    vecs = mse.VectorList.from_f16s(host, D)
+    s = mse.Searcher(vecs)
+    med = mse.medioid(vecs)
+    order = np.random.default_rng(11).permutation(n).astype(np.uint32)
+    cfg = mse.IndexBuildConfig(r=r, l=96, maxc=400)
+
+    def run(batch):
+        g = mse.BuildGraph(n, r)
+        g.random_fill(3)
+        g.build(s, order, med, cfg, batch)
+        return g, g.to_host()
+
+    g1, h1 = run(2048)
+    _, h2 = run(2048)
+    assert np.array_equal(h1.deg, h2.deg) and np.array_equal(h1.adj, h2.adj)
+    _, h3 = run(1024)
+    assert not np.array_equal(h1.adj, h3.adj)
+    for h in (h1, h3):
+        assert h.deg.max() <= r and h.deg.min() >= 1
+        mask = np.arange(r)[None, :] < h.deg[:, None]
+        assert (h.adj[mask] < n).all()
+    qi = np.arange(0, n, 200)
+    ids, _, _, _ = g1.search_batch(s, med, host[qi], 96, as_arrays=True)
+    assert (ids[:, 0] == qi).mean() > 0.97
+
+
 def test_build_graph_rejects_bad_arguments(gpu, mse, orc):
     n, r = 300, 8
     vecs = rows(orc, n, clustered=False)
