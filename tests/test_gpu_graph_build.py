@@ -184,6 +184,30 @@ def test_mfma_and_exact_routes_agree(gpu, mse, orc, env, monkeypatch):
         assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), i
 
 
+@pytest.mark.parametrize("d,r,n,batch", [(128, 8, 600, 32), (64, 64, 300, 16), (256, 5, 40, 64)])
+def test_build_graph_other_shapes(gpu, mse, orc, d, r, n, batch):
+    """Widths other than 1152, degree bounds that are not multiples of 16, a batch larger than the point count, maxc below
+    the list length of the back-edge prune: the generic paths, against the oracle."""
+    rng = np.random.default_rng(d + r)
+    centres = rng.standard_normal((6, d))
+    x = centres[rng.integers(0, 6, n)] + 0.7 * rng.standard_normal((n, d))
+    vecs = orc.f16_bits((x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32))
+    order = rng.permutation(n).astype(np.uint32)
+    med = int(orc.medioid(vecs))
+    adj, deg = orc.random_fill_graph(2, n, r)
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, d))
+    g = mse.BuildGraph(n, r)
+    g.random_fill(2)
+    for maxc in (40, max(2, r // 2)):
+        kw = dict(r=r, l=24, maxc=maxc, alpha=70000)
+        orc.build_graph(vecs, adj, deg, order, med, orc.BuildConfig.make(**kw), batch)
+        g.build(s, order, med, mse.IndexBuildConfig(**kw), batch)
+        h = g.to_host()
+        assert np.array_equal(h.deg, deg)
+        for i in range(n):
+            assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), (maxc, i)
+
+
 def test_build_properties_at_scale(gpu, mse, orc):
     """1e5 points at the reference's defaults (R 64, L 192, C 750) -- too many for the oracle in a test, so size-independent
     properties instead: the build is a function of (order, initial graph) -- two runs give the same graph, and a different
