@@ -1,4 +1,5 @@
 // C ABI (include/mse.h): runtime, base vectors, searcher, brute-force search, flat index.
+#include <cstdlib>
 #include "../../include/mse.h"
 #include "runtime.h"
 #include <algorithm>
@@ -94,6 +95,11 @@ int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_o
     }
     *sel_out = cur_sel;
     return 0;
+}
+
+size_t visited_budget_bytes() {
+    const char* e = getenv("MSE_VISITED_BUDGET_KB");
+    return e ? (size_t)atoll(e) * 1024 : (size_t)4 << 30;
 }
 
 int ensure_base_norm(const mse_base* b, hipStream_t st) {

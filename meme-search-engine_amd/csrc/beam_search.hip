@@ -386,6 +386,23 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
+    {   // two visited sets of n / 8 bytes per query in flight: long batches go through in pieces of at most ~4 GiB of them
+        const size_t per_query = ((b->n + 31) / 32) * 8, piece = std::max<size_t>(1, visited_budget_bytes() / per_query);
+        if (nq > piece) {
+            for (size_t q0 = 0; q0 < nq; q0 += piece) {
+                const size_t m = std::min(piece, nq - q0);
+                if (disk_search_batch_impl(s, pq, c, g, starts + q0, queries ? queries + q0 * b->d : nullptr,
+                                           queries_f32 ? queries_f32 + q0 * b->d : nullptr, luts ? luts + q0 * 16384 : nullptr,
+                                           scales ? scales + q0 * c->n_desc : nullptr, m, disable_pq, beamwidth, search_list,
+                                           buf_ids + q0 * search_list, buf_scores + q0 * search_list, buf_len + q0,
+                                           visited_ids ? visited_ids + q0 * visited_cap : nullptr,
+                                           visited_scores ? visited_scores + q0 * visited_cap : nullptr, visited_cap, n_visited + q0, cmps + q0,
+                                           pq_cmps + q0))
+                    return -1;
+            }
+            return 0;
+        }
+    }
     if (c->n != b->n || g->n != b->n) return fail("disk_search_batch: vectors, codes and graph differ in length");
     if (pq->n_chunks != 64 || pq->n_centroids != 256 || c->code_size != 64) return fail("disk_search_batch: needs the 64 x 256 codec");
     if (beamwidth == 0 || beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");

@@ -1355,6 +1355,18 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
         return fail("graph_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
+    {   // the visited sets take n / 8 bytes per query in flight: long batches go through in pieces of at most ~4 GiB of them
+        const size_t per_query = ((b->n + 31) / 32) * 4, piece = std::max<size_t>(1, visited_budget_bytes() / per_query);
+        if (nq > piece) {
+            for (size_t q0 = 0; q0 < nq; q0 += piece) {
+                const size_t m = std::min(piece, nq - q0);
+                if (mse_graph_search_batch(s, g, starts + q0, queries + q0 * b->d, m, search_list, base_vectors_only, query_breakpoint,
+                                           buf_ids + q0 * search_list, buf_scores + q0 * search_list, buf_len + q0, n_distances + q0))
+                    return -1;
+            }
+            return 0;
+        }
+    }
     if (g->n != b->n) return fail("graph_search_batch: graph and vectors differ in length");
     if (search_list == 0 || search_list > GB_LMAX) return fail("graph_search_batch: search_list must be 1..1024");
     if (g->max_deg > GB_RMAX) return fail("graph_search_batch: at most 64 neighbours per node");

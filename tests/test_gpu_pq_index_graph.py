@@ -362,3 +362,30 @@ def test_device_resident_beam_search_from_f32_queries(gpu, mse, orc, disable_pq)
                                                           opq.preprocess_query(qs[0]), None, disable_pq, 3, L, None)
     if disable_pq:   # the tables differ in the last bit between host libm-free orders only in ADC mode; exact mode must agree outright
         assert np.array_equal(got[0][0], obuf.ids) and np.array_equal(got[0][2], ovids)
+
+
+def test_long_batches_go_through_in_pieces(gpu, mse, orc, monkeypatch):
+    """A batch whose visited sets would not fit the budget is cut into pieces; the result does not depend on the cut."""
+    rng = np.random.default_rng(17)
+    n, deg, L, nq = 2000, 10, 32, 37
+    x = clustered_rows(orc, n, n_centres=16)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    cents, T, _, _ = make_pq(orc)
+    gpq = mse.ProductQuantizer(cents, T, 18, D)
+    gcodes = mse.Codes(rng.integers(0, 256, size=(n, 64), dtype=np.uint8), None)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    qs = orc.f16_bits(clustered_rows(orc, nq, n_centres=16, seed=400))
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    luts = np.stack([gpq.preprocess_query(orc.f16_to_f32(q)).table for q in qs])
+    whole = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qs, luts, None, False, 2, search_list=L, visited_cap=256)
+    bg = mse.BuildGraph(n, deg, mse.IndexGraph(adj, degs))
+    whole_ram = bg.search_batch(searcher, starts, qs, L)
+    monkeypatch.setenv("MSE_VISITED_BUDGET_KB", "3")     # 250 B (in-RAM) / 500 B (disk variant) per query -> pieces of 12 / 6
+    cut = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qs, luts, None, False, 2, search_list=L, visited_cap=256)
+    cut_ram = bg.search_batch(searcher, starts, qs, L)
+    for a, b in zip(whole, cut):
+        assert all(np.array_equal(u, v) for u, v in zip(a[:4], b[:4])) and a[4:] == b[4:]
+    for a, b in zip(whole_ram, cut_ram):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
