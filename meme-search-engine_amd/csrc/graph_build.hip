@@ -510,9 +510,17 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
 // P: [64][16] floats, Q: [16][16] floats, s_selidx: [64] ints (LDS).  d / 32 must be a multiple of 6.
 __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, const long long* c_sc, const uint32_t* c_id, float* P, float* Q,
                                     int* s_selidx, uint32_t* s_neigh, int* s_cnt) {
-    constexpr int PD = 6;   // k-steps in flight
+    constexpr int PD = 6;    // k-steps of the candidate rows in flight
+    constexpr int TK = 36;   // k-steps per row: this route is built for d = 1152 (the caller checks)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g4 = lane >> 4;
-    const int d = pp.d, T = d / 32, r = pp.r;
+    const int d = pp.d, r = pp.r;
+    // The selected rows are the A operand of every tile, so they stay in registers: wave w keeps rows 16 w .. 16 w + 15 of the
+    // selected set as 36 fragments (144 VGPRs) and fetches a row once, when it is selected.  Only the sixteen candidate rows
+    // of a block stream through (B operand): a candidate row is read once per prune instead of once per surviving p_star.
+    half8 afrag[TK];
+#pragma unroll
+    for (int ks = 0; ks < TK; ks++) afrag[ks] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    int have = 0;
     __shared__ unsigned long long s_border[16];   // per candidate of the block: selected rows whose comparison needs the exact dot
     __shared__ int s_kill[16];                    // per candidate: some selected row discards it for certain
     if (tid == 0) *s_cnt = 0;
@@ -534,27 +542,30 @@ __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, c
         touch(b0 + 32);
         if (tid < 16) { s_border[tid] = 0ull; s_kill[tid] = 0; }
         const int ntile = (nn0 + 15) / 16, intra_wave = ntile < 4 ? ntile : 0;
-        const bool do_sel = wave < ntile, do_intra = wave == intra_wave;
+        int avail = nn0 - 16 * wave;
+        avail = avail < 0 ? 0 : (avail > 16 ? 16 : avail);
+        if (avail > have) {   // rows selected since this wave last looked
+            if (i16 >= have && i16 < avail) {
+                const uint4* ra = reinterpret_cast<const uint4*>(pp.base + (size_t)s_neigh[16 * wave + i16] * d) + g4;
+#pragma unroll
+                for (int ks = 0; ks < TK; ks++) afrag[ks] = __builtin_bit_cast(half8, ra[ks * 4]);
+            }
+            have = avail;
+        }
+        const bool do_sel = avail > 0, do_intra = wave == intra_wave;
         if (do_sel || do_intra) {
             const int cb = b0 + i16 < nc ? b0 + i16 : nc - 1;
             const uint4* rb = reinterpret_cast<const uint4*>(pp.base + (size_t)c_id[cb] * d) + g4;
-            int sa = 16 * wave + i16;
-            if (sa > nn0 - 1) sa = nn0 - 1;
-            const uint4* ra = do_sel ? reinterpret_cast<const uint4*>(pp.base + (size_t)s_neigh[sa] * d) + g4 : rb;
             float4v acc_s = {0.0f, 0.0f, 0.0f, 0.0f}, acc_i = {0.0f, 0.0f, 0.0f, 0.0f};
-            uint4 fa[PD], fb[PD];
+            uint4 fb[PD];
 #pragma unroll
-            for (int u = 0; u < PD; u++) { fa[u] = ra[u * 4]; fb[u] = rb[u * 4]; }
-            for (int k0 = 0; k0 < T; k0 += PD) {
+            for (int u = 0; u < PD; u++) fb[u] = rb[u * 4];
 #pragma unroll
-                for (int u = 0; u < PD; u++) {
-                    const half8 A = __builtin_bit_cast(half8, fa[u]), B = __builtin_bit_cast(half8, fb[u]);
-                    const int kn = k0 + PD + u < T ? k0 + PD + u : T - 1;   // clamped: always inside the row
-                    fa[u] = ra[kn * 4];
-                    fb[u] = rb[kn * 4];
-                    if (do_sel) acc_s = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc_s, 0, 0, 0);
-                    if (do_intra) acc_i = __builtin_amdgcn_mfma_f32_16x16x32_f16(B, B, acc_i, 0, 0, 0);
-                }
+            for (int ks = 0; ks < TK; ks++) {
+                const half8 B = __builtin_bit_cast(half8, fb[ks % PD]);
+                fb[ks % PD] = rb[(ks + PD < TK ? ks + PD : TK - 1) * 4];   // clamped: always inside the row
+                if (do_sel) acc_s = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[ks], B, acc_s, 0, 0, 0);
+                if (do_intra) acc_i = __builtin_amdgcn_mfma_f32_16x16x32_f16(B, B, acc_i, 0, 0, 0);
             }
 #pragma unroll
             for (int v = 0; v < 4; v++) {
@@ -646,7 +657,8 @@ __device__ int wg_robust_prune_mfma(const PruneParams& pp, uint32_t p, int nc, c
 
 // robust_prune (lib.rs:227-285), one workgroup per point: candidate list b is (ci, cs)[b * stride ..][0..counts[b]),
 // the point is points[b]; the new list goes to staging row b.
-__global__ __launch_bounds__(GB_THREADS) void prune_kernel(PruneParams pp, const uint32_t* ci, const long long* cs, size_t stride,
+template <bool MFMA>
+__global__ __launch_bounds__(GB_THREADS, 2) void prune_kernel(PruneParams pp, const uint32_t* ci, const long long* cs, size_t stride,
                                                            const uint32_t* counts, const uint32_t* points, int maxc, uint32_t* out_ids,
                                                            uint32_t* out_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -663,7 +675,7 @@ __global__ __launch_bounds__(GB_THREADS) void prune_kernel(PruneParams pp, const
     int nc = wg_best_candidates(ci + b * stride, cs + b * stride, (int)counts[b], c_sc, c_id, c_pos, maxc);
     if (nc > maxc) nc = maxc;
     int nn;
-    if (pp.eps_fix > 0) {   // the upper half of the sort window is free once the candidates are sorted: tiles and selected indices
+    if constexpr (MFMA) {   // the upper half of the sort window is free once the candidates are sorted: tiles and selected indices
         float* P = reinterpret_cast<float*>(c_sc + GB_WIN / 2);
         nn = wg_robust_prune_mfma(pp, points[b], nc, c_sc, c_id, P, P + 64 * 16, reinterpret_cast<int*>(P + 64 * 16 + 16 * 16), s_neigh, &s_cnt);
     } else {
@@ -1151,7 +1163,7 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
         d_off.ensure(batch * r * 4 + 8) || d_src.ensure(batch * r * 4 + 4))
         return -1;
     MSE_HIP_TRY(hipMemcpyAsync(d_order.p, order, n_order * 4, hipMemcpyHostToDevice, st));
-    if (set_lds(graph_search_kernel<true>) || set_lds(prune_kernel)) return -1;
+    if (set_lds(graph_search_kernel<true>) || set_lds(prune_kernel<false>) || set_lds(prune_kernel<true>)) return -1;
     const size_t lds = search_lds_bytes(d, (int)cfg->l);
     PruneParams pp{b->dev, d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, r, (int)cfg->saturate_graph, (uint32_t)b->n, err.as<uint32_t>(), 0};
     std::vector<uint32_t> h_stg(batch * r), h_len(batch), targets, offs, srcs;
@@ -1174,9 +1186,8 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     if (mfma_bound(b, cfg, st, &eps_fix)) return -1;
     const bool use_gram = eps_fix > 0 && !getenv("MSE_BUILD_EXACT_BACKEDGE");
     if (use_gram && set_lds(backedge_gram_kernel)) return -1;
-    // the candidate-major MFMA walk of the prune is exact too, but re-reads the selected rows per block of sixteen and is not
-    // faster than the p_star walk yet: opt-in
-    if (eps_fix > 0 && d % 192 == 0 && getenv("MSE_BUILD_MFMA_PRUNE")) pp.eps_fix = eps_fix;
+    // the candidate-major MFMA walk of the prune keeps the selected rows in registers as 36 fragments: built for d = 1152
+    if (eps_fix > 0 && d == 1152 && !getenv("MSE_BUILD_EXACT_PRUNE")) pp.eps_fix = eps_fix;
     for (size_t b0 = 0; b0 < n_order; b0 += batch) {
         const size_t nb = std::min(batch, n_order - b0);
         a.points = d_order.as<uint32_t>() + b0;
@@ -1186,8 +1197,12 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
             MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));
             hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GS_THREADS), lds, st, a);
             MSE_HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(prune_kernel, dim3((unsigned)nb), dim3(GB_THREADS), prune_lds_bytes(d), st, pp, a.vl_ids, a.vl_sc, vl_cap,
-                               cnts.as<uint32_t>(), a.points, (int)cfg->maxc, stg.as<uint32_t>(), stg_len.as<uint32_t>());
+            if (pp.eps_fix > 0)
+                hipLaunchKernelGGL(prune_kernel<true>, dim3((unsigned)nb), dim3(GB_THREADS), prune_lds_bytes(d), st, pp, a.vl_ids, a.vl_sc, vl_cap,
+                                   cnts.as<uint32_t>(), a.points, (int)cfg->maxc, stg.as<uint32_t>(), stg_len.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(prune_kernel<false>, dim3((unsigned)nb), dim3(GB_THREADS), prune_lds_bytes(d), st, pp, a.vl_ids, a.vl_sc, vl_cap,
+                                   cnts.as<uint32_t>(), a.points, (int)cfg->maxc, stg.as<uint32_t>(), stg_len.as<uint32_t>());
             MSE_HIP_TRY(hipGetLastError());
             uint32_t e = 0;
             MSE_HIP_TRY(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
@@ -1330,15 +1345,20 @@ int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* c
         MSE_HIP_TRY(hipMemcpyAsync(ci.p, cand_ids, n_cand * 4, hipMemcpyHostToDevice, st));
         MSE_HIP_TRY(hipMemcpyAsync(cs.p, cand_scores, n_cand * 8, hipMemcpyHostToDevice, st));
     }
-    if (set_lds(prune_kernel)) return -1;
+    if (set_lds(prune_kernel<false>) || set_lds(prune_kernel<true>)) return -1;
     const uint32_t hdr[3] = {(uint32_t)n_cand, p, 0u};   // counts[0], points[0], error word
     MSE_HIP_TRY(hipMemcpyAsync(out.as<uint32_t>() + GB_RMAX + 1, hdr, 12, hipMemcpyHostToDevice, st));
     PruneParams pp{b->dev, (int)b->d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, (int)cfg->r, (int)cfg->saturate_graph, (uint32_t)b->n,
                    out.as<uint32_t>() + GB_RMAX + 3, 0};
-    if (b->d % 192 == 0 && getenv("MSE_BUILD_MFMA_PRUNE") && mfma_bound(b, cfg, st, &pp.eps_fix)) return -1;
-    hipLaunchKernelGGL(prune_kernel, dim3(1), dim3(GB_THREADS), prune_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(), (size_t)0,
-                       out.as<uint32_t>() + GB_RMAX + 1, out.as<uint32_t>() + GB_RMAX + 2, (int)cfg->maxc, out.as<uint32_t>(),
-                       out.as<uint32_t>() + GB_RMAX);
+    if (b->d == 1152 && !getenv("MSE_BUILD_EXACT_PRUNE") && mfma_bound(b, cfg, st, &pp.eps_fix)) return -1;
+    if (pp.eps_fix > 0)
+        hipLaunchKernelGGL(prune_kernel<true>, dim3(1), dim3(GB_THREADS), prune_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(),
+                           (size_t)0, out.as<uint32_t>() + GB_RMAX + 1, out.as<uint32_t>() + GB_RMAX + 2, (int)cfg->maxc, out.as<uint32_t>(),
+                           out.as<uint32_t>() + GB_RMAX);
+    else
+        hipLaunchKernelGGL(prune_kernel<false>, dim3(1), dim3(GB_THREADS), prune_lds_bytes((int)b->d), st, pp, ci.as<uint32_t>(), cs.as<long long>(),
+                           (size_t)0, out.as<uint32_t>() + GB_RMAX + 1, out.as<uint32_t>() + GB_RMAX + 2, (int)cfg->maxc, out.as<uint32_t>(),
+                           out.as<uint32_t>() + GB_RMAX);
     MSE_HIP_TRY(hipGetLastError());
     uint32_t h[GB_RMAX + 1];
     MSE_HIP_TRY(hipMemcpyAsync(h, out.p, sizeof(h), hipMemcpyDeviceToHost, st));

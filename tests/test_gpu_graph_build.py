@@ -93,9 +93,10 @@ def test_robust_prune_mfma_route_long_list(gpu, mse, orc, monkeypatch):
     kw = dict(r=64, l=192, maxc=750, alpha=65536, query_alpha=65536, query_breakpoint=0xFFFFFFFF)
     oc, mc = cfg_pair(orc, mse, **kw)
     want = orc.robust_prune(vecs, ids, scores, 11, oc)
-    monkeypatch.setenv("MSE_BUILD_MFMA_PRUNE", "1")
     assert np.array_equal(mse.robust_prune(s, ids, scores, 11, mc), want)
     monkeypatch.setenv("MSE_GRAM_EPS_SCALE", "3000")
+    assert np.array_equal(mse.robust_prune(s, ids, scores, 11, mc), want)
+    monkeypatch.setenv("MSE_BUILD_EXACT_PRUNE", "1")
     assert np.array_equal(mse.robust_prune(s, ids, scores, 11, mc), want)
 
 
@@ -164,13 +165,13 @@ def test_build_graph_with_queries_and_stitch_matches_oracle(gpu, mse, orc):
     assert deg.max() <= r
 
 
-@pytest.mark.parametrize("env", [{"MSE_GRAM_EPS_SCALE": "3000"}, {"MSE_BUILD_EXACT_BACKEDGE": "1"}, {"MSE_BUILD_MFMA_PRUNE": "1"},
-                                 {"MSE_BUILD_MFMA_PRUNE": "1", "MSE_GRAM_EPS_SCALE": "3000"}])
+@pytest.mark.parametrize("env", [{"MSE_GRAM_EPS_SCALE": "3000"}, {"MSE_BUILD_EXACT_BACKEDGE": "1"}, {"MSE_BUILD_EXACT_PRUNE": "1"},
+                                 {"MSE_BUILD_EXACT_PRUNE": "1", "MSE_BUILD_EXACT_BACKEDGE": "1"}])
 def test_mfma_and_exact_routes_agree(gpu, mse, orc, env, monkeypatch):
-    """The back-edge prune takes candidate products from MFMA tiles and settles comparisons inside the error bound with the
-    exact dot.  Widening the bound 3000-fold sends nearly every comparison down the exact path; the all-exact kernel is the
-    third route; the main prune has an MFMA (candidate-major) route as well, off by default.  Every route must give the
-    oracle's graph (the default routes are what the other tests run)."""
+    """Both prunes (of an inserted point's candidates, of a full list plus a newcomer) take candidate products from MFMA tiles
+    and settle comparisons inside the error bound with the exact dot.  Widening the bound 3000-fold sends nearly every
+    comparison down the exact path; the all-exact kernels are further routes.  Every route must give the oracle's graph
+    (the default routes are what the other tests run)."""
     n, r = 3000, 64
     vecs = rows(orc, n, seed=9)
     order = np.random.default_rng(5).permutation(n).astype(np.uint32)
