@@ -39,6 +39,13 @@ def main():
     queries = clustered(nq, centres, 0.3, 2)
     del centres
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    print(f"rows resident; device memory free {free/1e9:.1f} of {total/1e9:.1f} GB", flush=True)
+    need = n * R * 4 + n * 4 + batch * ((n + 31) // 32) * 4 + batch * 25000 * 12 + (2 << 30)
+    if need > free:
+        print(f"not enough device memory for the graph and the visited sets ({need/1e9:.1f} GB needed): stopping here", flush=True)
+        return
     vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows)
     s = mse.Searcher(vecs)
     t0 = time.time()
@@ -50,18 +57,33 @@ def main():
     for p in range(passes):
         order = rng.permutation(n).astype(np.uint32)
         t0 = time.time()
-        g.build(s, order, med, mse.IndexBuildConfig(r=R, l=L, maxc=750), batch)
+        seg = max(batch, (n // 20 + batch - 1) // batch * batch)      # progress lines; a multiple of the batch, so the result is the same
+        for o0 in range(0, n, seg):
+            g.build(s, order[o0:o0 + seg], med, mse.IndexBuildConfig(r=R, l=L, maxc=750), batch)
+            if n >= 5_000_000:
+                done = min(n, o0 + seg)
+                print(f"  {done} points in {time.time()-t0:.0f} s", flush=True)
         dt = time.time() - t0
         print(f"pass {p + 1}: {dt:.1f} s = {n/dt:.0f} points/s (R {R}, L {L}, C 750, batch {batch})", flush=True)
     qh = queries.cpu().numpy().view(np.uint16)
     t0 = time.time()
     _, truth = s.bruteforce_topk(qh, K)
     print(f"brute-force truth for {nq} queries: {time.time()-t0:.2f} s", flush=True)
-    cents = (np.random.default_rng(4).standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
-    pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)     # unused in exact-neighbour mode
-    codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
+    disk = n <= 20_000_000      # the disk variant wants a codes array (64 B per row) even when neighbours are scored exactly
+    if disk:
+        cents = (np.random.default_rng(4).standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+        pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)     # unused in exact-neighbour mode
+        codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
     starts = np.full(nq, med, np.uint32)
     for Ls in (32, 64, 100, 200):
+        if not disk:
+            g.search_batch(s, med, qh, Ls, as_arrays=True)
+            t0 = time.perf_counter()
+            rid, _, _, nd = g.search_batch(s, med, qh, Ls, as_arrays=True)
+            dr = time.perf_counter() - t0
+            rh = sum(len(set(rid[i, :K].tolist()) & set(truth[i].tolist())) for i in range(nq))
+            print(f"L={Ls}: in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f} ({nd.mean():.0f} distances/query)", flush=True)
+            continue
         mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)   # warm: scratch is allocated on first use
         t0 = time.perf_counter()
         res = mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)
