@@ -5,18 +5,22 @@
 //   NeighbourBuffer (lib.rs:74-155)          three sorted arrays in LDS (capacity <= 1024)
 //   visited (HashSet<u32>)                   one bit per node in HBM, per workgroup slot
 //   neighbour_pre_buffer                     LDS (<= 64 ids)
-//   visited_list = robust_prune candidates   HBM while it grows (it can reach tens of thousands of entries), then its
-//                                            best maxc entries sorted in LDS (bitonic, 2048-entry window)
-//   robust_prune_scratch_buffer              LDS list of the candidates still alive, rebuilt per p_star
-// Every score is fast_dot_noprefetch's value (exact_dot.h), every comparison is on the i64 fixed-point scores, and the
-// sequential parts (list inserts, the p_star loop, the back edges of one list) are replayed in the reference's order, so
-// the built graph is bit-identical to the oracle's for the same insertion order and batch size (include/mse.h says what
-// a batch is; batch = 1 is the reference's single-threaded loop).
+//   visited_list = robust_prune candidates   HBM while it grows (thousands of entries), then its best maxc entries, found by
+//                                            a value cut and sorted once in LDS (bitonic, 2048-entry window)
+//   robust_prune_scratch_buffer              LDS list of the candidates still alive (exact p_star walk), or per-block masks
+//                                            (candidate-major walk on the matrix cores)
+// Every score that leaves a kernel or orders a list is fast_dot_noprefetch's value (exact_dot.h), every comparison is on
+// the i64 fixed-point scores, and the sequential parts (list inserts, the prune walk, the back edges of one list) give the
+// reference's result, so the built graph is bit-identical to the oracle's for the same insertion order and batch size
+// (include/mse.h says what a batch is; batch = 1 is the reference's single-threaded loop).  Where a product between two
+// candidates is only needed to decide `(alpha * s) >> 16 >= score` (both prunes), it may come from MFMA tiles: the decision
+// is taken only if it holds across the MFMA error bound, otherwise the exact dot decides (wg_robust_prune_mfma,
+// backedge_gram_kernel; the all-exact routes wg_robust_prune / backedge_kernel remain for other widths and for testing).
 //
-// Work split: list manipulation is sequential and done by wave 0 (64-entry shifts); scoring is spread over all 256
-// lanes, one quad of lanes per row (64 rows per pass) -- the same quad dot the scan kernels use, so a row costs 2304 B
-// of HBM/L2 traffic and 36 dependent FMAs per lane.  Back edges: one workgroup per touched list, the sources of one list
-// applied in order, lists touched by a batch processed concurrently.
+// Kernels per batch: graph_search_kernel (one 128-lane workgroup per point: search + merge_existing_neighbours),
+// prune_kernel (one workgroup per point), apply_lists_kernel, then the back edges grouped per touched list on the host
+// (counting sort) and applied by backedge_gram_kernel (one wave per list).  Exact scoring is one quad of lanes per row,
+// the row fetched six 16-byte pieces per lane ahead: a row costs 2304 B of HBM/L2 traffic.
 #include "../../include/mse.h"
 #include "exact_dot.h"
 #include "runtime.h"
