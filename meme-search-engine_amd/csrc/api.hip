@@ -105,8 +105,8 @@ size_t visited_budget_bytes() {
 int ensure_base_norm(const mse_base* b, hipStream_t st) {
     std::lock_guard<std::mutex> g(b->norm_mu);
     if (b->norm_ready) return 0;
-    if (!b->norm_bits_dev) MSE_HIP_TRY(hipMalloc((void**)&b->norm_bits_dev, 4));
-    MSE_HIP_TRY(hipMemsetAsync(b->norm_bits_dev, 0, 4, st));
+    if (!b->norm_bits_dev) MSE_HIP_TRY(hipMalloc((void**)&b->norm_bits_dev, 12));   // [max norm, max subnormal mass of a row, max |x_i|]
+    MSE_HIP_TRY(hipMemsetAsync(b->norm_bits_dev, 0, 12, st));
     if (launch_row_norm_max(b->dev, b->n, (int)b->d, b->norm_bits_dev, st)) return -1;
     MSE_HIP_TRY(hipStreamSynchronize(st));
     b->norm_ready = true;

@@ -77,19 +77,22 @@ __global__ __launch_bounds__(256) void generate_rows_kernel(uint16_t* __restrict
     }
 }
 
-// 4 lanes per row like the scan; fp32 sum of squares, slight upward bias is applied by the caller
+// 4 lanes per row like the scan; fp32 sum of squares, slight upward bias is applied by the caller.  out_bits[0] = the
+// largest row norm (float bits, buffer zeroed first).  out_bits[1], [2] = the allowance for a matrix core that flushes f16
+// subnormal inputs: the largest per-row sum of |x_i| over subnormal x_i and the largest |x_i| of the base -- flushing
+// changes dot(x, y) by at most S_sub(x) * max|y| + S_sub(y) * max|x|.
 __global__ __launch_bounds__(256) void row_norm_max_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
                                                            uint32_t* __restrict__ out_bits) {
     const int lane = threadIdx.x & 63;
     const int part = lane & 3;
-    float best = 0.0f;
+    float best = 0.0f, best_sub = 0.0f, best_abs = 0.0f;
     const size_t quad0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const size_t nquads = ((size_t)gridDim.x * blockDim.x) >> 2;
     const size_t n_round = (n_rows + 15) / 16 * 16;
     for (size_t row = quad0; row < n_round; row += nquads) {
         const size_t rr = row < n_rows ? row : n_rows - 1;
         const uint4* xp = reinterpret_cast<const uint4*>(base + rr * (size_t)d) + part;
-        float s = 0.0f;
+        float s = 0.0f, sub = 0.0f;
         for (int t = 0; t < d / 32; t++) {
             const uint4 x = xp[t * 4];
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
@@ -99,31 +102,56 @@ __global__ __launch_bounds__(256) void row_norm_max_kernel(const uint16_t* __res
                 const float hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[i] >> 16));
                 s = fmaf(lo, lo, s);
                 s = fmaf(hi, hi, s);
+                const float alo = fabsf(lo), ahi = fabsf(hi);
+                if (alo < 6.103515625e-5f) sub += alo;          // below 2^-14: an f16 subnormal
+                if (ahi < 6.103515625e-5f) sub += ahi;
+                if (alo == alo) best_abs = fmaxf(best_abs, alo);
+                if (ahi == ahi) best_abs = fmaxf(best_abs, ahi);
             }
         }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
+        sub += __shfl_xor(sub, 1);
+        sub += __shfl_xor(sub, 2);
         if (!(s == s)) s = __builtin_inff();  // NaN rows: force "no certificate"
         best = fmaxf(best, s);
+        best_sub = fmaxf(best_sub, sub);
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
-    if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(best) * 1.0001f));
+    for (int o = 32; o >= 1; o >>= 1) {
+        best = fmaxf(best, __shfl_xor(best, o));
+        best_sub = fmaxf(best_sub, __shfl_xor(best_sub, o));
+        best_abs = fmaxf(best_abs, __shfl_xor(best_abs, o));
+    }
+    if (lane == 0) {
+        atomicMax(out_bits, __float_as_uint(sqrtf(best) * 1.0001f));
+        atomicMax(out_bits + 1, __float_as_uint(best_sub * 1.0001f));
+        atomicMax(out_bits + 2, __float_as_uint(best_abs));
+    }
 }
 
 __global__ void query_eps_kernel(const uint16_t* __restrict__ queries, int nq, int d,
                                  const uint32_t* __restrict__ max_norm_bits, float factor, float* __restrict__ eps) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;  // 64 threads
-    float s = 0.0f;
+    float s = 0.0f, sub = 0.0f, mabs = 0.0f;
     for (int i = lane; i < d; i += 64) {
         const float v = (float)__builtin_bit_cast(_Float16, queries[(size_t)q * d + i]);
         s = fmaf(v, v, s);
+        const float av = fabsf(v);
+        if (av < 6.103515625e-5f) sub += av;
+        if (av == av) mabs = fmaxf(mabs, av);
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        sub += __shfl_xor(sub, o);
+        mabs = fmaxf(mabs, __shfl_xor(mabs, o));
+    }
     if (lane == 0) {
         float e = factor * sqrtf(s) * 1.0001f * __uint_as_float(*max_norm_bits);
+        // should the matrix core flush f16 subnormal inputs: the products it would drop (see row_norm_max_kernel)
+        e += 1.0001f * (__uint_as_float(max_norm_bits[1]) * mabs + sub * __uint_as_float(max_norm_bits[2]));
         if (!(e == e)) e = __builtin_inff();
         eps[q] = e;
     }

@@ -1092,12 +1092,13 @@ int mfma_bound(const mse_base* b, const mse_build_config* cfg, hipStream_t st, l
     *eps_fix = 0;
     if (b->d % 64 || cfg->alpha <= 0 || cfg->alpha > (1 << 20) || cfg->query_alpha <= 0 || cfg->query_alpha > (1 << 20)) return 0;
     if (ensure_base_norm(b, st)) return -1;
-    uint32_t bits = 0;
-    MSE_HIP_TRY(hipMemcpy(&bits, b->norm_bits_dev, 4, hipMemcpyDeviceToHost));
-    float mx;
-    memcpy(&mx, &bits, 4);
+    uint32_t bits[3] = {0, 0, 0};
+    MSE_HIP_TRY(hipMemcpy(bits, b->norm_bits_dev, 12, hipMemcpyDeviceToHost));
+    float mx, sub, ab;
+    memcpy(&mx, &bits[0], 4); memcpy(&sub, &bits[1], 4); memcpy(&ab, &bits[2], 4);
     const char* sc = getenv("MSE_GRAM_EPS_SCALE");   // test hook: widen (or zero) the band in which the exact dot decides
-    const double bound = 2.8e-4 * (double)mx * (double)mx * (sc ? atof(sc) : 1.0);
+    // accumulation error of the MFMA sum + the products a matrix core that flushes f16 subnormal inputs would drop
+    const double bound = (2.8e-4 * (double)mx * (double)mx + 2.0002 * (double)sub * (double)ab) * (sc ? atof(sc) : 1.0);
     if (!(bound == bound) || bound > 1e6) return 0;
     *eps_fix = (long long)ceil(bound * 4294967296.0) + 1;
     return 0;

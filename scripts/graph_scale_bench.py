@@ -1,6 +1,8 @@
 """Graph index at BASELINE config 3's size (1e7 x 1152): build the Vamana graph on the device, then queries/s and
 recall@10 of the GPU-resident searches against the exact brute-force top-10 of the same index.
-usage: graph_scale_bench.py [n_rows] [passes] [batch]"""
+usage: graph_scale_bench.py [n_rows] [passes] [batch] [entries]
+entries > 0: each query starts from the best of `entries` sampled rows (a stand-in for the reference's shard selection,
+src/query_disk_index.rs:447-450: the medioid of the shard whose centroid is closest) instead of the one global medioid."""
 import os
 import sys
 import time
@@ -30,10 +32,22 @@ def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
     passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+    n_entries = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    hier = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # > 0: cluster centres are themselves drawn around `hier` super-centres
     nq, K, R, L = 1024, 10, 64, 192
     ffi.check(ffi.lib().mse_set_device(0))
     g0 = torch.Generator(device="cuda").manual_seed(0)
-    centres = torch.randn(max(64, n // 50), D, device="cuda", generator=g0)
+    nc_ = max(64, n // 50)
+    if hier:
+        sup = torch.randn(hier, D, device="cuda", generator=g0)
+        sup /= sup.norm(dim=1, keepdim=True)
+        centres = torch.empty(nc_, D, device="cuda")
+        for i in range(0, nc_, 1 << 18):
+            m = min(1 << 18, nc_ - i)
+            centres[i:i + m] = sup[torch.randint(0, hier, (m,), device="cuda", generator=g0)] + torch.randn(m, D, device="cuda", generator=g0) * (0.7 / D ** 0.5)
+        print(f"hierarchical centres: {nc_} centres around {hier} super-centres (noise 0.7)", flush=True)
+    else:
+        centres = torch.randn(nc_, D, device="cuda", generator=g0)
     centres /= centres.norm(dim=1, keepdim=True)
     rows = clustered(n, centres, 0.3, 1)
     queries = clustered(nq, centres, 0.3, 2)
@@ -74,29 +88,45 @@ def main():
         cents = (np.random.default_rng(4).standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
         pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)     # unused in exact-neighbour mode
         codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
-    starts = np.full(nq, med, np.uint32)
-    for Ls in (32, 64, 100, 200):
-        if not disk:
-            g.search_batch(s, med, qh, Ls, as_arrays=True)
+    med_starts = np.full(nq, med, np.uint32)
+    starts = None
+    if n_entries:
+        eid = np.sort(np.random.default_rng(9).choice(n, n_entries, replace=False)).astype(np.int64)
+        erows = rows[torch.from_numpy(eid).cuda()].contiguous()
+        es = mse.Searcher(mse.VectorList.wrap_device(erows.data_ptr(), n_entries, D, keepalive=erows))
+        t0 = time.perf_counter()
+        _, best = es.bruteforce_topk(qh, 1)
+        starts = eid[best[:, 0].astype(np.int64)].astype(np.uint32)
+        print(f"entry points: best of {n_entries} sampled rows per query ({(time.perf_counter()-t0)*1e3:.1f} ms for {nq} queries)", flush=True)
+
+    def sweep(starts, label):
+        print(f"-- start: {label}", flush=True)
+        for Ls in (32, 64, 100, 200):
+            if not disk:
+                g.search_batch(s, starts, qh, Ls, as_arrays=True)
+                t0 = time.perf_counter()
+                rid, _, _, nd = g.search_batch(s, starts, qh, Ls, as_arrays=True)
+                dr = time.perf_counter() - t0
+                rh = sum(len(set(rid[i, :K].tolist()) & set(truth[i].tolist())) for i in range(nq))
+                print(f"L={Ls}: in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f} ({nd.mean():.0f} distances/query)", flush=True)
+                continue
+            mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)   # warm: scratch is allocated on first use
             t0 = time.perf_counter()
-            rid, _, _, nd = g.search_batch(s, med, qh, Ls, as_arrays=True)
+            res = mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)
+            dt = time.perf_counter() - t0
+            top = mse.topk_of_visited(res, K)
+            hits = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq))
+            g.search_batch(s, starts, qh, Ls, as_arrays=True)
+            t0 = time.perf_counter()
+            rid, _, _, _ = g.search_batch(s, starts, qh, Ls, as_arrays=True)
             dr = time.perf_counter() - t0
             rh = sum(len(set(rid[i, :K].tolist()) & set(truth[i].tolist())) for i in range(nq))
-            print(f"L={Ls}: in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f} ({nd.mean():.0f} distances/query)", flush=True)
-            continue
-        mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)   # warm: scratch is allocated on first use
-        t0 = time.perf_counter()
-        res = mse.disk_search_batch(s, pq, codes, g, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)
-        dt = time.perf_counter() - t0
-        top = mse.topk_of_visited(res, K)
-        hits = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq))
-        g.search_batch(s, med, qh, Ls, as_arrays=True)
-        t0 = time.perf_counter()
-        rid, _, _, _ = g.search_batch(s, med, qh, Ls, as_arrays=True)
-        dr = time.perf_counter() - t0
-        rh = sum(len(set(rid[i, :K].tolist()) & set(truth[i].tolist())) for i in range(nq))
-        print(f"L={Ls}: beam search (beam 4, exact neighbours) {nq/dt:8.0f} q/s recall@10 {hits/(K*nq):.3f} "
-              f"({res['cmps'].mean():.0f} node fetches/query); in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f}", flush=True)
+            print(f"L={Ls}: beam search (beam 4, exact neighbours) {nq/dt:8.0f} q/s recall@10 {hits/(K*nq):.3f} "
+                  f"({res['cmps'].mean():.0f} node fetches/query); in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f}", flush=True)
+
+    sweep(med_starts, "the medioid")
+    if starts is not None:
+        sweep(starts, f"best of {n_entries} sampled rows")
 
 
 if __name__ == "__main__":

@@ -100,6 +100,26 @@ def test_robust_prune_mfma_route_long_list(gpu, mse, orc, monkeypatch):
     assert np.array_equal(mse.robust_prune(s, ids, scores, 11, mc), want)
 
 
+def test_certificate_covers_subnormal_components(gpu, mse, orc):
+    """A decision that hinges on 1151 products of a normal value with an f16 SUBNORMAL one (6e-5 < 2^-14).  If the matrix
+    cores flushed subnormal inputs, their sum would miss 3.45e-3 here -- more than the stated error bound -- and the MFMA route
+    would keep a candidate the reference discards.  The exact walk is the referee."""
+    s_row = np.full(D, 0.05, np.float32); s_row[0] = 0.9          # the first p_star
+    dummy = np.zeros(D, np.float32); dummy[0] = 0.5               # sits right behind it (never tested against it)
+    c_row = np.full(D, 6e-5, np.float32); c_row[0] = 0.02         # dot with s_row: 0.018 + 1151 * 0.05 * 6e-5 = 0.02145 >= 0.02
+    p_row = np.zeros(D, np.float32); p_row[0] = 1.0
+    filler = np.zeros((60, D), np.float32); filler[:, 1] = 1.0    # keeps the base from being tiny
+    vecs = orc.f16_bits(np.stack([p_row, s_row, dummy, c_row, *filler]))
+    assert (orc.f16_to_f32(vecs[3][1:]) > 0).all() and (orc.f16_to_f32(vecs[3][1:]) < 2.0 ** -14).all()   # really subnormal
+    s = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    ids = np.array([1, 2, 3], np.uint32)
+    scores = orc.score_rows(vecs, ids, vecs[0])
+    oc, mc = cfg_pair(orc, mse, r=8, l=16, maxc=16)
+    want = orc.robust_prune(vecs, ids, scores, 0, oc)
+    assert want.tolist() == [1, 2]                                 # the reference discards candidate 3
+    assert mse.robust_prune(s, ids, scores, 0, mc).tolist() == [1, 2]
+
+
 def build_both(orc, mse, vecs, r, order, med, passes, batch, seed=21, stitch_order=None):
     n = len(vecs)
     adj, deg = orc.random_fill_graph(seed, n, r)
