@@ -68,17 +68,19 @@ def main():
     g = mse.BuildGraph(n, R)
     g.random_fill(1)
     rng = np.random.default_rng(3)
-    for p in range(passes):
+    alphas = [int(x) for x in os.environ.get("ALPHAS", "65536").split(",")]   # relaxation factor (x 2^16) per pass
+
+    def build_pass(p):
         order = rng.permutation(n).astype(np.uint32)
         t0 = time.time()
         seg = max(batch, (n // 20 + batch - 1) // batch * batch)      # progress lines; a multiple of the batch, so the result is the same
         for o0 in range(0, n, seg):
-            g.build(s, order[o0:o0 + seg], med, mse.IndexBuildConfig(r=R, l=L, maxc=750), batch)
+            g.build(s, order[o0:o0 + seg], med, mse.IndexBuildConfig(r=R, l=L, maxc=750, alpha=alphas[min(p, len(alphas) - 1)]), batch)
             if n >= 5_000_000:
-                done = min(n, o0 + seg)
-                print(f"  {done} points in {time.time()-t0:.0f} s", flush=True)
+                print(f"  {min(n, o0 + seg)} points in {time.time()-t0:.0f} s", flush=True)
         dt = time.time() - t0
-        print(f"pass {p + 1}: {dt:.1f} s = {n/dt:.0f} points/s (R {R}, L {L}, C 750, batch {batch})", flush=True)
+        print(f"pass {p + 1}: {dt:.1f} s = {n/dt:.0f} points/s (R {R}, L {L}, C 750, batch {batch}, alpha {alphas[min(p, len(alphas) - 1)]})", flush=True)
+
     qh = queries.cpu().numpy().view(np.uint16)
     t0 = time.time()
     _, truth = s.bruteforce_topk(qh, K)
@@ -101,7 +103,7 @@ def main():
 
     def sweep(starts, label):
         print(f"-- start: {label}", flush=True)
-        for Ls in (32, 64, 100, 200):
+        for Ls in ((64, 100, 200, 400) if n >= 50_000_000 else (32, 64, 100, 200)):
             if not disk:
                 g.search_batch(s, starts, qh, Ls, as_arrays=True)
                 t0 = time.perf_counter()
@@ -124,9 +126,11 @@ def main():
             print(f"L={Ls}: beam search (beam 4, exact neighbours) {nq/dt:8.0f} q/s recall@10 {hits/(K*nq):.3f} "
                   f"({res['cmps'].mean():.0f} node fetches/query); in-RAM greedy search {nq/dr:8.0f} q/s recall@10 {rh/(K*nq):.3f}", flush=True)
 
-    sweep(med_starts, "the medioid")
-    if starts is not None:
-        sweep(starts, f"best of {n_entries} sampled rows")
+    for p in range(passes):
+        build_pass(p)
+        sweep(med_starts, f"the medioid, after pass {p + 1}")
+        if starts is not None:
+            sweep(starts, f"best of {n_entries} sampled rows, after pass {p + 1}")
 
 
 if __name__ == "__main__":
