@@ -85,7 +85,7 @@ def main():
     t0 = time.time()
     _, truth = s.bruteforce_topk(qh, K)
     print(f"brute-force truth for {nq} queries: {time.time()-t0:.2f} s", flush=True)
-    disk = n <= 20_000_000      # the disk variant wants a codes array (64 B per row) even when neighbours are scored exactly
+    disk = n <= 20_000_000 or os.environ.get("DISK_VARIANT") == "1"   # the disk variant wants a codes array (64 B per row) even when neighbours are scored exactly
     if disk:
         cents = (np.random.default_rng(4).standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
         pq = mse.ProductQuantizer(cents, np.eye(D, dtype=np.float32), 18, D)     # unused in exact-neighbour mode
@@ -103,7 +103,7 @@ def main():
 
     def sweep(starts, label):
         print(f"-- start: {label}", flush=True)
-        for Ls in ((64, 100, 200, 400) if n >= 50_000_000 else (32, 64, 100, 200)):
+        for Ls in ((100, 200, 400, 800) if n >= 50_000_000 else (32, 64, 100, 200)):
             if not disk:
                 g.search_batch(s, starts, qh, Ls, as_arrays=True)
                 t0 = time.perf_counter()
