@@ -216,8 +216,11 @@ int mse_graph_random_fill(mse_graph* g, uint32_t seed, size_t r);
  * are taken `batch` at a time: the searches and prunes of a batch see the graph as it was before the batch, then the
  * batch's lists are replaced, then the back edges are applied in (position in batch, position in list) order.
  * batch = 1 is exactly the single-threaded loop the reference keeps in comments (:294,297).  One workgroup per point
- * (search list, candidates, prune state in LDS, visited set as a bit map in HBM), one workgroup per touched list
- * for the back edges; every score is the reference's fast_dot, bit for bit. */
+ * (search list, candidates, prune state in LDS, visited set as a bit map in HBM), one wave per touched list for the
+ * back edges.  Every score that orders a list or is compared against is the reference's fast_dot, bit for bit; the
+ * candidate-candidate products of the two prunes, which only feed `(alpha * s) >> 16 >= score`, may come from the
+ * matrix cores, and then decide only when the comparison holds across their error bound (the exact dot settles the
+ * rest), so the graph is the same as with exact products throughout. */
 int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t n_order, size_t batch, uint32_t medioid,
                     const mse_build_config* cfg);
 /* robust_stitch (lib.rs:326-374): query nodes are removed from the base nodes' lists; each base node that pointed
