@@ -171,3 +171,14 @@ def test_shard_ranges_and_merge(mse, orc):
         valid = ids[q] != 0xFFFFFFFF
         order = np.lexsort((ids[q][valid], -scores[q][valid]))[:10]
         assert np.array_equal(i_np[q], ids[q][valid][order])
+
+
+def test_topk_of_visited_sorts_by_exact_score(mse):
+    """The server's last step (src/query_disk_index.rs:529-540) over the padded arrays of a batched search."""
+    res = {"visited_ids": np.array([[5, 6, 7, 9], [1, 2, 0, 0], [4, 0, 0, 0]], np.uint32),
+           "visited_scores": np.array([[10, 30, 30, 99], [5, -7, 0, 0], [np.iinfo(np.int64).max, 0, 0, 0]], np.int64),
+           "n_visited": np.array([3, 2, 1], np.uint32)}
+    top = mse.topk_of_visited(res, 3)
+    assert top[0].tolist() == [6, 7, 5]                       # equal scores keep visit order; the fourth column is past n_visited
+    assert top[1].tolist() == [1, 2, mse.ID_NONE]
+    assert top[2].tolist() == [4, mse.ID_NONE, mse.ID_NONE]
