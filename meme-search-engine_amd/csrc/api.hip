@@ -99,7 +99,15 @@ int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_o
 
 size_t visited_budget_bytes() {
     const char* e = getenv("MSE_VISITED_BUDGET_KB");
-    return e ? (size_t)atoll(e) * 1024 : (size_t)4 << 30;
+    if (e) return (size_t)atoll(e) * 1024;
+    // half of what is free right now, between 256 MiB and 64 GiB (an index that fills the HBM leaves little; a small one leaves
+    // room for every query of a batch at once)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)4 << 30;
+    size_t b = free_b / 2;
+    if (b < ((size_t)256 << 20)) b = (size_t)256 << 20;
+    if (b > ((size_t)64 << 30)) b = (size_t)64 << 30;
+    return b;
 }
 
 int ensure_base_norm(const mse_base* b, hipStream_t st) {

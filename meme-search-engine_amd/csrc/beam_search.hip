@@ -387,7 +387,7 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     if (nq == 0) return 0;
     const mse_base* b = s->base;
     {   // two visited sets of n / 8 bytes per query in flight: long batches go through in pieces of at most ~4 GiB of them
-        const size_t per_query = ((b->n + 31) / 32) * 8, piece = std::max<size_t>(1, visited_budget_bytes() / per_query);
+        const size_t per_query = ((b->n + 31) / 32) * 8, piece = std::max<size_t>(1, std::max(s->pool[4].cap, visited_budget_bytes()) / per_query);   // pool[4]: the bitmaps already held
         if (nq > piece) {
             for (size_t q0 = 0; q0 < nq; q0 += piece) {
                 const size_t m = std::min(piece, nq - q0);

@@ -90,7 +90,8 @@ struct mse_codes {
 namespace mse {
 // largest row norm of the base (x 1.0001), computed once and kept on the device as float bits (b->norm_bits_dev)
 int ensure_base_norm(const mse_base* b, hipStream_t st);
-// device memory the batched graph searches may spend on visited sets per launch (4 GiB; MSE_VISITED_BUDGET_KB overrides, for tests)
+// device memory the batched graph searches may spend on visited sets per launch: half of the free HBM, 256 MiB .. 64 GiB
+// (MSE_VISITED_BUDGET_KB overrides, for tests)
 size_t visited_budget_bytes();
 }  // namespace mse
 
