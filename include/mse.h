@@ -181,7 +181,7 @@ int mse_disk_greedy_search(mse_searcher* s, mse_pq* pq, const mse_codes* c, cons
  * those of mse_disk_greedy_search: buf_ids/buf_scores [nq][search_list] (first buf_len[q] valid, best first),
  * visited_* [nq][visited_cap] in fetch order, n_visited/cmps/pq_cmps [nq].  starts [nq]; queries [nq][d] f16; luts
  * [nq][64*256]; scales [nq][n_descriptors] or NULL.  Limits: 64 x 256 codec, search_list <= 1024, beamwidth <= 8,
- * max_deg <= 64. */
+ * max_deg <= 128 (merged indexes carry up to SHARD_SPILL x R neighbours per node, src/dump_processor.rs:282-291). */
 typedef struct mse_graph mse_graph;
 mse_graph* mse_graph_from_host(const uint32_t* adj, const uint32_t* deg, size_t n, size_t max_deg, const uint8_t* has_url);
 void mse_graph_free(mse_graph* g);

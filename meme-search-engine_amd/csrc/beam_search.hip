@@ -28,7 +28,7 @@ namespace {
 constexpr int BS_THREADS = 256;
 constexpr int BS_LMAX = 1024;
 constexpr int BS_BEAM_MAX = 8;
-constexpr int BS_DEG_MAX = 64;
+constexpr int BS_DEG_MAX = 128;   // merged indexes: up to SHARD_SPILL x R neighbours per node
 constexpr int BS_DESC_MAX = 8;
 
 struct BeamArgs {
@@ -36,7 +36,7 @@ struct BeamArgs {
     const uint8_t* codes; const uint8_t* desc; int n_desc;
     const uint32_t* adj; const uint32_t* deg; int max_deg; const uint8_t* has_url;
     const uint16_t* queries; const float* luts; const float* scales; const uint32_t* starts;
-    int beam, L, disable_pq;
+    int beam, L, disable_pq, p_cap;   // p_cap: pre-buffer entries = beam x max_deg rounded up to 64
     uint32_t* bm_adj; uint32_t* bm_vis; size_t bm_words;
     uint32_t* out_ids; long long* out_scores; uint32_t* out_len;
     uint32_t* vis_ids; long long* vis_scores; size_t vis_cap; uint32_t* n_visited;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     char* p = smem + lut_bytes + ((a.d * 2 + 15) & ~15);
     // the list is sized by this call's search_list and the pre-buffer by its beam width, so that the usual settings
     // (L = 200, beam 4) leave room for two workgroups per CU next to their 64 KiB tables, eight without tables
-    const size_t l_cap = (size_t)a.L, p_cap = (size_t)a.beam * BS_DEG_MAX;
+    const size_t l_cap = (size_t)a.L, p_cap = (size_t)a.p_cap;
     long long* nb_sc = reinterpret_cast<long long*>(p); p += l_cap * 8;
     long long* pre_sc = reinterpret_cast<long long*>(p); p += p_cap * 8;
     uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
@@ -139,24 +139,29 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
                         n_vis++;
                     }
                 }
-                int dg = (int)a.deg[pt];
-                if (dg > a.max_deg) dg = a.max_deg;
-                uint32_t nb = lane < dg ? a.adj[(size_t)pt * a.max_deg + lane] : 0xffffffffu;
-                bool cand = lane < dg;
-                if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
-                // an id listed twice in one adjacency list: the first occurrence is the one HashSet::insert accepts
-                for (int l = 0; l < dg; l++) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
-                    if (l < lane && o == nb) cand = false;
+                int dg_all = (int)a.deg[pt];
+                if (dg_all > a.max_deg) dg_all = a.max_deg;
+                // 64 neighbours per round (merged indexes carry up to 2 R per node, dump_processor.rs:282-291); an id repeated in a
+                // later round finds its bit already set by the earlier one
+                for (int h0 = 0; h0 < dg_all; h0 += 64) {
+                    const int dg = dg_all - h0 < 64 ? dg_all - h0 : 64;
+                    uint32_t nb = lane < dg ? a.adj[(size_t)pt * a.max_deg + h0 + lane] : 0xffffffffu;
+                    bool cand = lane < dg;
+                    if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
+                    // an id listed twice in one adjacency list: the first occurrence is the one HashSet::insert accepts
+                    for (int l = 0; l < dg; l++) {
+                        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
+                        if (l < lane && o == nb) cand = false;
+                    }
+                    bool fresh = false;
+                    if (cand) {
+                        const uint32_t old = atomicOr(&bm_adj[nb >> 5], 1u << (nb & 31));
+                        fresh = !(old & (1u << (nb & 31)));
+                    }
+                    const unsigned long long m = __ballot(fresh);
+                    if (fresh) pre_id[npre + __popcll(m & ((1ull << lane) - 1ull))] = nb;
+                    npre += __popcll(m);
                 }
-                bool fresh = false;
-                if (cand) {
-                    const uint32_t old = atomicOr(&bm_adj[nb >> 5], 1u << (nb & 31));
-                    fresh = !(old & (1u << (nb & 31)));
-                }
-                const unsigned long long m = __ballot(fresh);
-                if (fresh) pre_id[npre + __popcll(m & ((1ull << lane) - 1ull))] = nb;
-                npre += __popcll(m);
                 if (lane == 0) s_seg[j] = npre;
             }
             if (lane == 0) s_npre = npre;
@@ -196,17 +201,17 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
         // While no two different ids share a score (`ties` is still false and nothing offered now equals anything), the
         // order of the inserts does not matter and re-offers change nothing: the list ends up as the best `cap` of old and
         // new entries, and next_unvisited as the smaller of its old value and the slot the best newcomer takes on arrival
-        // (every other insert lands at or behind that slot).  Each thread places up to two newcomers by two counts -- old
+        // (every other insert lands at or behind that slot).  Each thread places up to four newcomers by two counts -- old
         // entries above it (binary search) and newcomers above it -- and moves up to four old entries up by the number of
         // newcomers that go before them.  Any equality, and the reference's sequence is replayed below instead.
         bool merged = false;
         if (cap > 0 && npre > 0) {
             const int len = s_len;
-            int lo_[2], rn_[2];
-            long long sc_[2];
+            int lo_[4], rn_[4];
+            long long sc_[4];
             bool tie = false;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 4; h++) {
                 const int e = tid + h * BS_THREADS;
                 lo_[h] = 0; rn_[h] = 0; sc_[h] = 0;
                 if (e < npre) {
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
             if (!any_tie && !s_ties) {
                 merged = true;
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+                for (int h = 0; h < 4; h++)
                     if (tid + h * BS_THREADS < npre) s_rank[rn_[h]] = lo_[h];
                 __syncthreads();
                 long long osc[4];
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
                 for (int c = 0; c < 4; c++)
                     if (onp[c] >= 0) { nb_sc[onp[c]] = osc[c]; nb_id[onp[c]] = oid[c]; nb_vis[onp[c]] = ovis[c]; }
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < 4; h++) {
                     const int e = tid + h * BS_THREADS, pos = lo_[h] + rn_[h];
                     if (e < npre && pos < cap) { nb_sc[pos] = sc_[h]; nb_id[pos] = pre_id[e]; nb_vis[pos] = 0; }
                 }
@@ -407,7 +412,7 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     if (pq->n_chunks != 64 || pq->n_centroids != 256 || c->code_size != 64) return fail("disk_search_batch: needs the 64 x 256 codec");
     if (beamwidth == 0 || beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
     if (search_list == 0 || search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
-    if (g->max_deg > BS_DEG_MAX) return fail("disk_search_batch: at most 64 neighbours per node");
+    if (g->max_deg > BS_DEG_MAX) return fail("disk_search_batch: at most 128 neighbours per node");
     if (c->n_desc > BS_DESC_MAX) return fail("disk_search_batch: at most 8 descriptors");
     if (b->d % 32 || b->d > 4096) return fail("disk_search_batch: vector width must be a multiple of 32");
     if (visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
@@ -440,18 +445,19 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 8, st));
     MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 12 + 16, st));
+    const size_t p_cap = beamwidth * ((g->max_deg + 63) / 64 * 64);
     BeamArgs a{};
     a.base = b->dev; a.n = b->n; a.d = (int)d;
     a.codes = c->codes; a.desc = bias ? c->desc : nullptr; a.n_desc = (int)c->n_desc;
     a.adj = g->adj; a.deg = g->deg; a.max_deg = (int)g->max_deg; a.has_url = g->has_url;
     a.queries = dq.as<uint16_t>(); a.luts = dl.as<float>(); a.scales = bias ? dsc.as<float>() : nullptr; a.starts = dst.as<uint32_t>();
-    a.beam = (int)beamwidth; a.L = (int)search_list; a.disable_pq = disable_pq;
+    a.beam = (int)beamwidth; a.L = (int)search_list; a.disable_pq = disable_pq; a.p_cap = (int)p_cap;
     a.bm_adj = bm.as<uint32_t>(); a.bm_vis = bm.as<uint32_t>() + nq * words; a.bm_words = words;
     a.out_ids = oi.as<uint32_t>(); a.out_scores = os.as<long long>(); a.out_len = ol.as<uint32_t>();
     a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
     a.err = cnt.as<uint32_t>() + 3 * nq;
-    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + beamwidth * BS_DEG_MAX * 16;
+    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16;
     static bool attr = false;
     if (!attr) {
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));

@@ -389,3 +389,36 @@ def test_long_batches_go_through_in_pieces(gpu, mse, orc, monkeypatch):
         assert all(np.array_equal(u, v) for u, v in zip(a[:4], b[:4])) and a[4:] == b[4:]
     for a, b in zip(whole_ram, cut_ram):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+@pytest.mark.parametrize("beamwidth,disable_pq", [(4, False), (8, True)])
+def test_device_resident_beam_search_wide_lists(gpu, mse, orc, beamwidth, disable_pq):
+    """Merged indexes carry the union of a point's lists from its shards -- up to 2 R = 128 neighbours (dump_processor.rs:282-291).
+    Lists of up to 100 ids, with an id repeated across the two 64-neighbour rounds, beam 8 x 100 newcomers per iteration."""
+    rng = np.random.default_rng(23)
+    n, deg, L, nq = 2500, 100, 80, 7
+    x = clustered_rows(orc, n, n_centres=10)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:1500], iters=1)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    adj, degs = knn_graph(x, deg, rng, long_edges=10)
+    degs[:] = rng.integers(60, deg + 1, size=n)
+    adj[9, 70] = adj[9, 3]                                             # repeated across the two rounds
+    adj[9, 71] = adj[9, 70]                                            # and inside the second round
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    gcodes = mse.Codes(codes, None)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    qs = clustered_rows(orc, nq, n_centres=10, seed=500)
+    qh = orc.f16_bits(qs)
+    luts = np.stack([opq.preprocess_query(q) for q in qs])
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    starts[0] = 9
+    got = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qh, luts, None, disable_pq, beamwidth, search_list=L, visited_cap=n)
+    for i in range(nq):
+        obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, None, int(starts[i]), qh[i], luts[i], None,
+                                                              disable_pq, beamwidth, L, None)
+        bi, bs, vi, vs, cm, pc = got[i]
+        assert (cm, pc) == (ocm, opc), i
+        assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores), i
+        assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc), i
