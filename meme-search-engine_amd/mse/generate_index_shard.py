@@ -133,3 +133,47 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+
+
+# ---- merging the shard graphs (src/dump_processor.rs:219-296) ------------------------------------------------------------
+
+SHARD_SPILL = 2   # dump_processor.rs:136: every record is written to its two closest shards
+
+
+def merge_shards(shards_dir, shard_ids=None, spill=SHARD_SPILL):
+    """What dump-processor does with the outputs of generate-index-shard before it packs index.bin: for every original id, the
+    union of its neighbour lists from the (at most `spill`) shards that hold it, within-shard ids mapped back to original ids,
+    first occurrence kept (`!out_vertices.contains`, :286-289).  The reference fills a record's shard slots in directory-listing
+    order (:225,248-254), which the OS decides; here shards are taken in ascending id.
+    -> (adj uint32 [n][spill * max list], deg uint32 [n], shards_of int32 [n][spill] (-1 = none),
+        shard_specs [(centroid float32 [d], medioid as ORIGINAL id)] in ascending shard id (IndexHeader.shards, :261))."""
+    if shard_ids is None:
+        shard_ids = sorted(int(f.split(".")[0]) for f in os.listdir(shards_dir) if f.endswith(".shard-header.msgpack"))
+    headers, lists = {}, {}
+    n = 0
+    for sid in shard_ids:
+        h, ls = read_shard_output(shards_dir, sid)
+        headers[sid], lists[sid] = h, ls
+        n = max(n, int(h["max"]) + 1)
+    width = spill * max((max((len(l) for l in ls), default=0) for ls in lists.values()), default=0)
+    adj = np.zeros((n, max(width, 1)), np.uint32)
+    deg = np.zeros(n, np.uint32)
+    shards_of = np.full((n, spill), -1, np.int32)
+    filled = np.zeros(n, np.int32)
+    specs = []
+    for sid in shard_ids:
+        h = headers[sid]
+        mapping = np.asarray(h["mapping"], np.uint32)
+        specs.append((np.asarray(h["centroid"], np.float32), int(mapping[h["medioid"]])))
+        for local, gid in enumerate(mapping):
+            if filled[gid] >= spill:
+                raise ValueError("shard processing inconsistency")          # :257-259: a record sits in more shards than the spill
+            shards_of[gid, filled[gid]] = sid
+            filled[gid] += 1
+            row, k = adj[gid], int(deg[gid])
+            for g in mapping[lists[sid][local]]:
+                if g not in row[:k]:
+                    row[k] = g
+                    k += 1
+            deg[gid] = k
+    return adj, deg, shards_of, specs

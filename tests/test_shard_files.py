@@ -143,3 +143,62 @@ def test_index_directory_records_and_code_files(tmp_path):
     np.arange(5, dtype=np.uint8).tofile(str(tmp_path / "index.pq-codes.bin"))
     with pytest.raises(ValueError):
         di.DiskIndex(str(tmp_path))
+
+
+def test_merge_shards_by_hand(tmp_path):
+    """Two shards sharing records 10 and 30 (spill 2): lists are mapped back to original ids and united in shard order,
+    first occurrence kept (src/dump_processor.rs:264-293)."""
+    from mse import generate_index_shard as gis
+    from mse.diskann import IndexGraph
+    # shard 0 holds originals [10, 20, 30]; shard 1 holds [30, 40, 10]
+    g0 = IndexGraph(np.array([[1, 2], [0, 0], [0, 1]], np.uint32), np.array([2, 1, 2], np.uint32))
+    g1 = IndexGraph(np.array([[1, 2], [0, 0], [1, 0]], np.uint32), np.array([2, 1, 2], np.uint32))
+    gis.write_shard_output(str(tmp_path), {"id": 0, "centroid": [1.0, 0.0]}, 1, np.array([10, 20, 30], np.uint32), g0, 3)
+    gis.write_shard_output(str(tmp_path), {"id": 1, "centroid": [0.0, 1.0]}, 2, np.array([30, 40, 10], np.uint32), g1, 3)
+    adj, deg, shards_of, specs = gis.merge_shards(str(tmp_path))
+    lists = {i: adj[i, :deg[i]].tolist() for i in (10, 20, 30, 40)}
+    assert lists == {10: [20, 30, 40], 20: [10], 30: [10, 20, 40], 40: [30]}        # 10: [20, 30] from shard 0, then 40 (30 is a repeat)
+    assert shards_of[10].tolist() == [0, 1] and shards_of[20].tolist() == [0, -1] and shards_of[5].tolist() == [-1, -1]
+    assert [m for _, m in specs] == [20, 10] and specs[1][0].tolist() == [0.0, 1.0]   # medioids as original ids
+    gis.write_shard_output(str(tmp_path), {"id": 2, "centroid": [0.0, 0.0]}, 0, np.array([10], np.uint32), IndexGraph(np.zeros((1, 2), np.uint32), np.zeros(1, np.uint32)), 1)
+    with pytest.raises(ValueError):
+        gis.merge_shards(str(tmp_path))                                               # record 10 in three shards
+
+
+@pytest.mark.gpu
+def test_sharded_pipeline_end_to_end(gpu, mse, orc, tmp_path):
+    """The reference's large-index recipe in small: records spilled to their two closest shards (dump_processor.rs:438-455), one
+    graph per shard (generate-index-shard), lists merged (:264-293), a query enters at the medioid of the shard whose centroid it is
+    closest to (query_disk_index.rs:447-450) and is searched over the merged graph on the device."""
+    from mse import generate_index_shard as gis
+    from test_gpu_graph_build import rows
+    n, S, R, K = 6000, 3, 24, 10
+    vecs = rows(orc, n, seed=31)
+    x = orc.f16_to_f32(vecs)
+    cents = x[[10, 2000, 4000]].copy()
+    for _ in range(3):                                                   # a few k-means steps for the shard centroids (kmeans.py)
+        a = np.argmax(x @ cents.T, axis=1)
+        cents = np.stack([x[a == s].mean(axis=0) for s in range(S)])
+    two = np.argsort(-(x @ cents.T), axis=1)[:, :gis.SHARD_SPILL]
+    sh_in, sh_out = tmp_path / "in", tmp_path / "out"
+    sh_in.mkdir(); sh_out.mkdir()
+    for s in range(S):
+        ids = np.flatnonzero((two == s).any(axis=1)).astype(np.uint32)
+        gis.write_shard_input(str(sh_in / f"{s}.shard.msgpack"), s, cents[s], ids, vecs[ids])
+        gis.generate_index_shard(str(sh_in / f"{s}.shard.msgpack"), str(sh_out), l=64, r=R, maxc=200, seed=s, batch=256, log=lambda *_: None)
+    adj, deg, shards_of, specs = gis.merge_shards(str(sh_out))
+    assert (shards_of >= 0).all() and deg.max() <= 2 * R and deg.min() >= 1
+    searcher = mse.Searcher(mse.VectorList.from_f16s(vecs, D))
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, deg))
+    nq = 64
+    q = rows(orc, nq, seed=32)
+    qf = orc.f16_to_f32(q)
+    centroids = np.stack([c for c, _ in specs])
+    starts = np.array([specs[mse.select_shard(centroids, qf[i])][1] for i in range(nq)], np.uint32)
+    pq = mse.ProductQuantizer(np.zeros((256, D), np.float32), np.eye(D, dtype=np.float32), 18, D)
+    codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
+    res = mse.disk_search_batch(searcher, pq, codes, dgraph, starts, q, None, None, True, 4, search_list=64, visited_cap=1024, as_arrays=True)
+    top = mse.topk_of_visited(res, K)
+    _, truth = searcher.bruteforce_topk(q, K)
+    recall = np.mean([len(set(top[i].tolist()) & set(truth[i].tolist())) / K for i in range(nq)])
+    assert recall > 0.9
