@@ -386,7 +386,11 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
                                   int disable_pq, size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores,
                                   uint32_t* buf_len, uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap,
                                   uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
-    if (!s || !s->base || !pq || !c || !g || !starts || (!queries && !queries_f32) || (!luts && !queries_f32 && !disable_pq) || !buf_ids ||
+    // with disable_pq and no descriptor bias neither the codec nor the codes are touched: both may be NULL then
+    static const mse_codes no_codes{};
+    if (!c && disable_pq && !scales) c = &no_codes;
+    const bool codec_needed = !disable_pq;
+    if (!s || !s->base || (!pq && codec_needed) || !c || !g || !starts || (!queries && !queries_f32) || (!luts && !queries_f32 && !disable_pq) || !buf_ids ||
         !buf_scores || !buf_len || !n_visited || !cmps || !pq_cmps)
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
@@ -408,8 +412,8 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
             return 0;
         }
     }
-    if (c->n != b->n || g->n != b->n) return fail("disk_search_batch: vectors, codes and graph differ in length");
-    if (pq->n_chunks != 64 || pq->n_centroids != 256 || c->code_size != 64) return fail("disk_search_batch: needs the 64 x 256 codec");
+    if ((c != &no_codes && c->n != b->n) || g->n != b->n) return fail("disk_search_batch: vectors, codes and graph differ in length");
+    if (codec_needed && (pq->n_chunks != 64 || pq->n_centroids != 256 || c->code_size != 64)) return fail("disk_search_batch: needs the 64 x 256 codec");
     if (beamwidth == 0 || beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
     if (search_list == 0 || search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
     if (g->max_deg > BS_DEG_MAX) return fail("disk_search_batch: at most 128 neighbours per node");
@@ -430,7 +434,7 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     if (queries_f32) {
         // the caller's side of query_disk_index.rs:475-477 on the device: f16 copy of the query (RNE) for the exact scores,
         // preprocess_query (vector.rs:367-384) for the distance tables -- 64 KiB per query that never cross PCIe
-        if (pq->d != d) return fail("disk_search_batch: codec and vectors differ in width");
+        if (pq && pq->d != d) return fail("disk_search_batch: codec and vectors differ in width");
         MSE_HIP_TRY(hipMemcpyAsync(qf.p, queries_f32, nq * d * 4, hipMemcpyHostToDevice, st));
         if (launch_f32_to_f16(qf.as<float>(), nq * d, dq.as<uint16_t>(), st)) return -1;
         if (!disable_pq) {

@@ -184,10 +184,12 @@ def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph,
             _p(vi, C.c_uint32), _p(vs, C.c_int64), visited_cap, _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32))
     scp = _p(sc, C.c_float) if sc is not None else None
     if from_f32:
-        check(ffi.lib().mse_disk_search_batch_f32(searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_float),
+        check(ffi.lib().mse_disk_search_batch_f32(searcher._h, quantizer._h if quantizer is not None else None,
+                                                  codes._h if codes is not None else None, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_float),
                                                   scp, *tail), "disk_search_batch_f32")
     else:
-        check(ffi.lib().mse_disk_search_batch(searcher._h, quantizer._h, codes._h, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_uint16),
+        check(ffi.lib().mse_disk_search_batch(searcher._h, quantizer._h if quantizer is not None else None,
+                                              codes._h if codes is not None else None, dgraph._h, _p(st, C.c_uint32), _p(q, C.c_uint16),
                                               _p(tables, C.c_float) if tables is not None else None, scp, *tail), "disk_search_batch")
     if as_arrays:
         return {"buf_ids": bi, "buf_scores": bs, "buf_len": bl, "visited_ids": vi, "visited_scores": vs, "n_visited": nv, "cmps": cm,

@@ -44,8 +44,8 @@ def main():
     two = torch.empty(n, 2, dtype=torch.int64, device="cuda")
     for i in range(0, n, 1 << 20):
         two[i:i + (1 << 20)] = (rows[i:i + (1 << 20)].float() @ cent.T).topk(2, dim=1).indices
-    merged = torch.full((n, 2 * R), NONE, dtype=torch.int64, device="cuda")   # first R columns: first shard seen, next R: second
-    seen = torch.zeros(n, dtype=torch.int64, device="cuda")
+    merged = np.full((n, 2 * R), NONE, np.uint32)      # host: first R columns = the record's first shard, next R = its second
+    seen = torch.zeros(n, dtype=torch.int8, device="cuda")
     specs = []
     t_build = 0.0
     for s in range(S):
@@ -67,19 +67,21 @@ def main():
         glob = ids[adj]                                                        # within-shard ids -> original ids
         glob[torch.arange(R, device="cuda")[None, :] >= deg[:, None]] = NONE
         col = seen[ids]                                                        # 0: first shard of the record, 1: second
+        ids_h, glob_h, col_h = ids.cpu().numpy(), glob.cpu().numpy().astype(np.uint32), col.cpu().numpy()
         for c in (0, 1):
-            pick = col == c
-            merged[ids[pick], c * R:(c + 1) * R] = glob[pick]
+            pick = col_h == c
+            merged[ids_h[pick], c * R:(c + 1) * R] = glob_h[pick]
         seen[ids] += 1
         specs.append(int(ids[med]))
         print(f"shard {s}: {m} records, built in {time.time()-t0:.1f} s", flush=True)
         del sub, vl, sr, adj, deg, glob
+        torch.cuda.empty_cache()
     print(f"{S} shards, {t_build:.1f} s of graph building in total ({n/t_build:.0f} records/s, each record in two shards)", flush=True)
     # union per record, first occurrence kept (read_out_vertices): drop an entry equal to an earlier one of its row
     out = np.empty((n, 2 * R), np.uint32)
     degs = np.empty(n, np.uint32)
     for i in range(0, n, 1 << 16):
-        blk = merged[i:i + (1 << 16)]
+        blk = torch.from_numpy(merged[i:i + (1 << 16)].astype(np.int64)).cuda()
         dup = (blk[:, :, None] == blk[:, None, :]) & (torch.arange(2 * R, device="cuda")[None, :, None] > torch.arange(2 * R, device="cuda")[None, None, :])
         keep = (blk != NONE) & ~dup.any(dim=2)
         order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)      # kept entries first, original order
@@ -87,6 +89,12 @@ def main():
         out[i:i + (1 << 16)] = blk.cpu().numpy().astype(np.uint32)
         degs[i:i + (1 << 16)] = keep.sum(dim=1).cpu().numpy()
     del merged
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    print(f"device memory free {free/1e9:.1f} GB before the merged graph ({out.nbytes/1e9:.1f} GB) is uploaded", flush=True)
+    if out.nbytes + (6 << 30) > free:
+        print("not enough device memory for the merged graph: stopping here", flush=True)
+        return
     print(f"merged lists: mean {degs.mean():.1f} max {degs.max()} neighbours", flush=True)
     vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows)
     s = mse.Searcher(vecs)
@@ -96,9 +104,8 @@ def main():
     cents = cent.cpu().numpy().astype(np.float32)
     qf = queries.float().cpu().numpy()
     starts = np.array([specs[mse.select_shard(cents, qf[i])] for i in range(nq)], np.uint32)
-    pq = mse.ProductQuantizer(np.zeros((256, D), np.float32), np.eye(D, dtype=np.float32), 18, D)     # unused in exact-neighbour mode
-    codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
-    for Ls in (32, 64, 100, 200):
+    pq = codes = None      # neighbours are scored exactly: neither the codec nor the codes are touched
+    for Ls in ((64, 100, 200, 400) if n >= 50_000_000 else (32, 64, 100, 200)):
         mse.disk_search_batch(s, pq, codes, dgraph, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)
         t0 = time.perf_counter()
         res = mse.disk_search_batch(s, pq, codes, dgraph, starts, qh, None, None, True, 4, Ls, 1024, as_arrays=True)
