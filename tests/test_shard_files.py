@@ -195,9 +195,10 @@ def test_sharded_pipeline_end_to_end(gpu, mse, orc, tmp_path):
     qf = orc.f16_to_f32(q)
     centroids = np.stack([c for c, _ in specs])
     starts = np.array([specs[mse.select_shard(centroids, qf[i])][1] for i in range(nq)], np.uint32)
-    pq = mse.ProductQuantizer(np.zeros((256, D), np.float32), np.eye(D, dtype=np.float32), 18, D)
-    codes = mse.Codes(np.zeros((n, 64), np.uint8), None)
-    res = mse.disk_search_batch(searcher, pq, codes, dgraph, starts, q, None, None, True, 4, search_list=64, visited_cap=1024, as_arrays=True)
+    # neighbours scored exactly: neither codec nor codes are needed (and asking for ADC without them is an error)
+    res = mse.disk_search_batch(searcher, None, None, dgraph, starts, q, None, None, True, 4, search_list=64, visited_cap=1024, as_arrays=True)
+    with pytest.raises(mse.MseError):
+        mse.disk_search_batch(searcher, None, None, dgraph, starts, qf, None, None, False, 4, search_list=64, visited_cap=1024)
     top = mse.topk_of_visited(res, K)
     _, truth = searcher.bruteforce_topk(q, K)
     recall = np.mean([len(set(top[i].tolist()) & set(truth[i].tolist())) / K for i in range(nq)])
