@@ -443,6 +443,9 @@ def main():
             line["graph_search"] = graph_line
         if note:
             line["note"] = note
+        # not measured by this command (the build takes 20 minutes): the same 1e8-row index served through the graph path
+        line["see_also"] = "profiles/r01_graph_scale.txt: 1e8 x 1152 on one GPU, sharded Vamana index, 66 k queries/s at recall@10 0.993"
+
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_total, k)
             if graph_line:
