@@ -149,31 +149,44 @@ def merge_shards(shards_dir, shard_ids=None, spill=SHARD_SPILL):
         shard_specs [(centroid float32 [d], medioid as ORIGINAL id)] in ascending shard id (IndexHeader.shards, :261))."""
     if shard_ids is None:
         shard_ids = sorted(int(f.split(".")[0]) for f in os.listdir(shards_dir) if f.endswith(".shard-header.msgpack"))
-    headers, lists = {}, {}
-    n = 0
+    none = np.uint32(0xFFFFFFFF)
+    loaded, n, widest = [], 0, 0
     for sid in shard_ids:
         h, ls = read_shard_output(shards_dir, sid)
-        headers[sid], lists[sid] = h, ls
+        loaded.append((sid, h, ls))
         n = max(n, int(h["max"]) + 1)
-    width = spill * max((max((len(l) for l in ls), default=0) for ls in lists.values()), default=0)
-    adj = np.zeros((n, max(width, 1)), np.uint32)
-    deg = np.zeros(n, np.uint32)
+        widest = max(widest, max((len(l) for l in ls), default=0))
+    width = max(spill * widest, 1)
+    slots = np.full((n, width), none, np.uint32)      # slot block c of a record = its list in the c-th shard that holds it
     shards_of = np.full((n, spill), -1, np.int32)
-    filled = np.zeros(n, np.int32)
+    filled = np.zeros(n, np.int64)
     specs = []
-    for sid in shard_ids:
-        h = headers[sid]
+    for sid, h, ls in loaded:
         mapping = np.asarray(h["mapping"], np.uint32)
         specs.append((np.asarray(h["centroid"], np.float32), int(mapping[h["medioid"]])))
-        for local, gid in enumerate(mapping):
-            if filled[gid] >= spill:
-                raise ValueError("shard processing inconsistency")          # :257-259: a record sits in more shards than the spill
-            shards_of[gid, filled[gid]] = sid
-            filled[gid] += 1
-            row, k = adj[gid], int(deg[gid])
-            for g in mapping[lists[sid][local]]:
-                if g not in row[:k]:
-                    row[k] = g
-                    k += 1
-            deg[gid] = k
+        if len(np.unique(mapping)) != len(mapping) or (filled[mapping] >= spill).any():
+            raise ValueError("shard processing inconsistency")              # :257-259: a record sits in more shards than the spill
+        lens = np.fromiter((len(l) for l in ls), np.int64, len(ls))
+        local = np.full((len(ls), widest), 0, np.int64)
+        mask = np.arange(widest)[None, :] < lens[:, None]
+        if mask.any():
+            local[mask] = np.concatenate(ls).astype(np.int64)
+        glob = np.where(mask, mapping[local], none)                         # within-shard ids -> original ids
+        c = filled[mapping]
+        for k in range(spill):
+            pick = c == k
+            slots[mapping[pick], k * widest:(k + 1) * widest] = glob[pick]
+            shards_of[mapping[pick], k] = sid
+        filled[mapping] += 1
+    # first occurrence kept, order kept (`!out_vertices.contains`), a few thousand records at a time
+    adj = np.zeros((n, width), np.uint32)
+    deg = np.zeros(n, np.uint32)
+    later = np.arange(width)[:, None] > np.arange(width)[None, :]
+    for i in range(0, n, 4096):
+        blk = slots[i:i + 4096]
+        dup = ((blk[:, :, None] == blk[:, None, :]) & later[None]).any(axis=2)
+        keep = (blk != none) & ~dup
+        order = np.argsort(~keep, axis=1, kind="stable")
+        adj[i:i + 4096] = np.where(np.take_along_axis(keep, order, axis=1), np.take_along_axis(blk, order, axis=1), 0)
+        deg[i:i + 4096] = keep.sum(axis=1)
     return adj, deg, shards_of, specs
