@@ -16,8 +16,11 @@
 // is spread over all 256 lanes.
 #include "../../include/mse.h"
 #include "exact_dot.h"
+#include "visited_set.h"
 #include "runtime.h"
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -37,7 +40,7 @@ struct BeamArgs {
     const uint32_t* adj; const uint32_t* deg; int max_deg; const uint8_t* has_url;
     const uint16_t* queries; const float* luts; const float* scales; const uint32_t* starts;
     int beam, L, disable_pq, p_cap;   // p_cap: pre-buffer entries = beam x max_deg rounded up to 64
-    uint32_t* bm_adj; uint32_t* bm_vis; size_t bm_words;
+    uint32_t* bm_adj; uint32_t* bm_vis; size_t bm_words; int hash_bits;   // visited sets (visited_set.h): bm_words u32 per set
     uint32_t* out_ids; long long* out_scores; uint32_t* out_len;
     uint32_t* vis_ids; long long* vis_scores; size_t vis_cap; uint32_t* n_visited;
     uint32_t* cmps; uint32_t* pq_cmps; uint32_t* err;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
     uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += p_cap * 4;
     int* s_rank = reinterpret_cast<int*>(p);
-    __shared__ int s_len, s_next, s_npts, s_npre, s_ties;
+    __shared__ int s_len, s_next, s_npts, s_npre, s_ties, s_abort;
     __shared__ uint32_t s_pts[BS_BEAM_MAX];
     __shared__ int s_seg[BS_BEAM_MAX];
     __shared__ long long s_ptsc[BS_BEAM_MAX];
@@ -80,8 +83,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     if (tid == 0) {
         const uint32_t start = a.starts[qi];
         nb_id[0] = start; nb_sc[0] = 0; nb_vis[0] = 0;   // :153 -- the entry point enters with score 0
-        s_len = 1; s_next = 0;
-        atomicOr(&bm_adj[start >> 5], 1u << (start & 31));   // :154
+        s_len = 1; s_next = 0; s_abort = 0;
+        (void)visited_insert(bm_adj, a.hash_bits, start);   // :154
     }
     __syncthreads();
 
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
     };
 
     uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
+    uint32_t n_adj = 1;                          // wave 0: ids inserted into visited_adjacent so far
     bool ties = false;                           // wave 0: two different ids have met on one score (see the insert loop)
     for (;;) {
         // ---- next_several_unvisited (:83-97 over NeighbourBuffer::next_unvisited, lib.rs:93-107) ----
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
         }
         __syncthreads();
         const int npts = s_npts;
-        if (npts == 0) break;
+        if (npts == 0 || s_abort) break;
 
         // ---- fetched nodes: exact score + bias (:168-170), one lane quad per node ----
         if (wave == 0) {
@@ -130,8 +134,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
                 const uint32_t pt = s_pts[j];
                 if (lane == 0) {
                     cmps++;
-                    const uint32_t old = atomicOr(&bm_vis[pt >> 5], 1u << (pt & 31));
-                    if (!(old & (1u << (pt & 31))) && (!a.has_url || a.has_url[pt])) {
+                    if (visited_insert(bm_vis, a.hash_bits, pt) && (!a.has_url || a.has_url[pt])) {
                         if (n_vis < a.vis_cap) {
                             a.vis_ids[qi * a.vis_cap + n_vis] = pt;
                             a.vis_scores[qi * a.vis_cap + n_vis] = s_ptsc[j];
@@ -154,10 +157,7 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
                         if (l < lane && o == nb) cand = false;
                     }
                     bool fresh = false;
-                    if (cand) {
-                        const uint32_t old = atomicOr(&bm_adj[nb >> 5], 1u << (nb & 31));
-                        fresh = !(old & (1u << (nb & 31)));
-                    }
+                    if (cand) fresh = visited_insert(bm_adj, a.hash_bits, nb);
                     const unsigned long long m = __ballot(fresh);
                     if (fresh) pre_id[npre + __popcll(m & ((1ull << lane) - 1ull))] = nb;
                     npre += __popcll(m);
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
                 if (lane == 0) s_seg[j] = npre;
             }
             if (lane == 0) s_npre = npre;
+            n_adj += (uint32_t)npre;
+            if (a.hash_bits && n_adj > (1u << (a.hash_bits - 1)) && lane == 0) {   // table half full: give up, the host repeats with bit maps
+                atomicOr(a.err, 4u);
+                s_abort = 1;
+            }
         }
         __syncthreads();
 
@@ -381,7 +386,7 @@ void mse_graph_free(mse_graph* g) {
     delete g;
 }
 
-static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
+static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
                                   const uint16_t* queries, const float* queries_f32, const float* luts, const float* scales, size_t nq,
                                   int disable_pq, size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores,
                                   uint32_t* buf_len, uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap,
@@ -395,12 +400,18 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
-    {   // two visited sets of n / 8 bytes per query in flight: long batches go through in pieces of at most ~4 GiB of them
-        const size_t per_query = ((b->n + 31) / 32) * 8, piece = std::max<size_t>(1, std::max(s->pool[4].cap, visited_budget_bytes()) / per_query);   // pool[4]: the bitmaps already held
+    // visited sets: bit maps, or hash tables once the index is so large that the tables are the smaller ones (visited_set.h)
+    const size_t words = (b->n + 31) / 32;
+    const int table_bits = visited_table_bits(std::min<size_t>(b->n, search_list * 192 + 4096));
+    const char* vm = getenv("MSE_VISITED_MODE");   // test hook: "hash" / "bitmap"
+    const bool use_hash = visited_mode >= 0 ? visited_mode == 1 : (vm ? !strcmp(vm, "hash") : words > ((size_t)1 << table_bits));
+    const size_t set_words = use_hash ? (size_t)1 << table_bits : words;
+    {   // two visited sets per query in flight: long batches go through in pieces of at most ~4 GiB of them
+        const size_t per_query = set_words * 8, piece = std::max<size_t>(1, std::max(s->pool[4].cap, visited_budget_bytes()) / per_query);   // pool[4]: the bitmaps already held
         if (nq > piece) {
             for (size_t q0 = 0; q0 < nq; q0 += piece) {
                 const size_t m = std::min(piece, nq - q0);
-                if (disk_search_batch_impl(s, pq, c, g, starts + q0, queries ? queries + q0 * b->d : nullptr,
+                if (disk_search_batch_impl(visited_mode, s, pq, c, g, starts + q0, queries ? queries + q0 * b->d : nullptr,
                                            queries_f32 ? queries_f32 + q0 * b->d : nullptr, luts ? luts + q0 * 16384 : nullptr,
                                            scales ? scales + q0 * c->n_desc : nullptr, m, disable_pq, beamwidth, search_list,
                                            buf_ids + q0 * search_list, buf_scores + q0 * search_list, buf_len + q0,
@@ -423,12 +434,12 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     for (size_t q = 0; q < nq; q++)
         if (starts[q] >= b->n) return fail("disk_search_batch: start node out of range");
     hipStream_t st = s->stream;
-    const size_t d = b->d, words = (b->n + 31) / 32;
+    const size_t d = b->d;
     const bool bias = scales && c->n_desc && c->desc;
     DevBuf &dq = s->pool[0], &dl = s->pool[1], &dsc = s->pool[2], &dst = s->pool[3], &bm = s->pool[4], &oi = s->pool[5], &os = s->pool[6],
            &ol = s->pool[7], &vi = s->pool[8], &vs = s->pool[9], &cnt = s->pool[10], &qf = s->pool[11], &qt = s->pool[12];
     if ((queries_f32 && (qf.ensure(nq * d * 4) || qt.ensure(nq * d * 4))) || dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
-        bm.ensure(nq * words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
+        bm.ensure(nq * set_words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
         vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
         return -1;
     if (queries_f32) {
@@ -447,7 +458,7 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     }
     if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
-    MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 8, st));
+    MSE_HIP_TRY(hipMemsetAsync(bm.p, use_hash ? 0xff : 0, nq * set_words * 8, st));
     MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 12 + 16, st));
     const size_t p_cap = beamwidth * ((g->max_deg + 63) / 64 * 64);
     BeamArgs a{};
@@ -456,7 +467,7 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     a.adj = g->adj; a.deg = g->deg; a.max_deg = (int)g->max_deg; a.has_url = g->has_url;
     a.queries = dq.as<uint16_t>(); a.luts = dl.as<float>(); a.scales = bias ? dsc.as<float>() : nullptr; a.starts = dst.as<uint32_t>();
     a.beam = (int)beamwidth; a.L = (int)search_list; a.disable_pq = disable_pq; a.p_cap = (int)p_cap;
-    a.bm_adj = bm.as<uint32_t>(); a.bm_vis = bm.as<uint32_t>() + nq * words; a.bm_words = words;
+    a.bm_adj = bm.as<uint32_t>(); a.bm_vis = bm.as<uint32_t>() + nq * set_words; a.bm_words = set_words; a.hash_bits = use_hash ? table_bits : 0;
     a.out_ids = oi.as<uint32_t>(); a.out_scores = os.as<long long>(); a.out_len = ol.as<uint32_t>();
     a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
@@ -478,7 +489,10 @@ static int disk_search_batch_impl(mse_searcher* s, mse_pq* pq, const mse_codes* 
     MSE_HIP_TRY(hipMemcpyAsync(pq_cmps, a.pq_cmps, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipStreamSynchronize(st));
-    if (err) return fail("disk_search_batch: a graph edge points outside the index");
+    if (err & 1u) return fail("disk_search_batch: a graph edge points outside the index");
+    if (err & 4u)   // a search outgrew its table: the bit maps have room for everything
+        return disk_search_batch_impl(0, s, pq, c, g, starts, queries, queries_f32, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
+                                      buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
     if (visited_cap) {   // only the columns any query filled travel back (entries past n_visited[q] are unspecified)
         size_t widest = 0;
         for (size_t q = 0; q < nq; q++) widest = n_visited[q] > widest ? n_visited[q] : widest;
@@ -498,7 +512,7 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
                           uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
                           uint32_t* cmps, uint32_t* pq_cmps) {
     if (!queries) return fail("disk_search_batch: null argument");
-    return disk_search_batch_impl(s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
+    return disk_search_batch_impl(-1, s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
                                   buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
 }
 
@@ -507,7 +521,7 @@ int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
                               size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len, uint32_t* visited_ids,
                               int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
     if (!queries_f32) return fail("disk_search_batch_f32: null argument");
-    return disk_search_batch_impl(s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, nq, disable_pq, beamwidth, search_list,
+    return disk_search_batch_impl(-1, s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, nq, disable_pq, beamwidth, search_list,
                                   buf_ids, buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
 }
 

@@ -23,6 +23,7 @@
 // the row fetched six 16-byte pieces per lane ahead: a row costs 2304 B of HBM/L2 traffic.
 #include "../../include/mse.h"
 #include "exact_dot.h"
+#include "visited_set.h"
 #include "runtime.h"
 #include <algorithm>
 #include <cmath>
@@ -251,7 +252,7 @@ struct GraphArgs {
     const uint16_t* queries;     // search only
     uint32_t medioid, qb; int base_only;
     int L, maxc, saturate; long long alpha, qalpha;
-    uint32_t* bitmap; size_t bm_words;
+    uint32_t* bitmap; size_t bm_words; int hash_bits;   // visited set per workgroup slot (visited_set.h): bm_words u32 each
     uint32_t* vl_ids; long long* vl_sc; uint32_t vl_cap;
     uint32_t* out_ids; long long* out_sc; uint32_t* out_len; uint32_t* out_dist;
     uint32_t* err;   // bit 0: an edge points outside the graph; bit 1: visited list overflow
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
     uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p0); p0 += (size_t)a.L * 4;
     uint32_t* pre_id = reinterpret_cast<uint32_t*>(p0); p0 += 64 * 4;
     int* s_rank = reinterpret_cast<int*>(p0);
-    __shared__ int s_len, s_next, s_npre, s_cnt, s_pt;
+    __shared__ int s_len, s_next, s_npre, s_cnt, s_pt, s_abort;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t bi = blockIdx.x;
@@ -314,8 +315,8 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
         const float f = quad_fast_dot_f32(a.base + (size_t)start * d, s_q, d);
         if (lane == 0) {
             nb_id[0] = start; nb_sc[0] = scale_dot_result(f); nb_vis[0] = 0;
-            s_len = 1; s_next = 0;
-            atomicOr(&bm[start >> 5], 1u << (start & 31));
+            s_len = 1; s_next = 0; s_abort = 0;
+            (void)visited_insert(bm, a.hash_bits, start);
         }
         pop();
     }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
     uint32_t n_vl = 0;   // wave 0: visited_list.len() == counters.distances
     for (;;) {
         if (wave == 0) {   // :194-200
-            const int pti = s_pt;
+            const int pti = s_abort ? -1 : s_pt;
             if (pti < 0) {
                 if (lane == 0) s_npre = -1;
             } else {
@@ -344,10 +345,7 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
                 // a query node met while base_vectors_only is dropped whether or not it was seen before, so its bit is not needed
                 if (cand && base_only && nb >= a.qb) cand = false;
                 bool fresh = false;
-                if (cand) {
-                    const uint32_t old = atomicOr(&bm[nb >> 5], 1u << (nb & 31));
-                    fresh = !(old & (1u << (nb & 31)));
-                }
+                if (cand) fresh = visited_insert(bm, a.hash_bits, nb);
                 const unsigned long long m = __ballot(fresh);
                         if (fresh) pre_id[__popcll(m & ((1ull << lane) - 1ull))] = nb;
                 if (lane == 0) s_npre = __popcll(m);
@@ -373,6 +371,10 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
                 }
             }
             n_vl += (uint32_t)npre;
+            if (a.hash_bits && n_vl >= (1u << (a.hash_bits - 1)) && lane == 0) {   // table half full: the host repeats with bit maps
+                atomicOr(a.err, 4u);
+                s_abort = 1;
+            }
             int len = s_len, nu = s_next;
             // All newcomers at once.  While no two scores involved are equal, the order of the inserts does not matter:
             // the list ends up as the best `cap` of old and new entries, and next_unvisited as the smaller of its old value
@@ -1161,9 +1163,14 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     if (check_graph(g, st, "build_graph")) return -1;
     const int r = (int)cfg->r, d = (int)b->d;
     const size_t words = (b->n + 31) / 32;
+    const char* vm = getenv("MSE_VISITED_MODE");   // test hook: "hash" / "bitmap"
     size_t vl_cap = std::max<size_t>(4096, 2 * cfg->l * cfg->r) + cfg->r;
     DevBuf d_order, bm, vli, vls, stg, stg_len, err, d_tg, d_off, d_src, cnts;
-    if (cnts.ensure(batch * 4) || d_order.ensure(n_order * 4) || bm.ensure(batch * words * 4) || vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8) ||
+    // visited sets: bit maps, or hash tables once the index is so large that the tables are the smaller ones (visited_set.h)
+    int table_bits = visited_table_bits(std::min<size_t>(b->n, vl_cap));
+    bool use_hash = vm ? !strcmp(vm, "hash") : words > ((size_t)1 << table_bits);
+    size_t set_words = use_hash ? (size_t)1 << table_bits : words;
+    if (cnts.ensure(batch * 4) || d_order.ensure(n_order * 4) || bm.ensure(batch * set_words * 4) || vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8) ||
         stg.ensure(batch * r * 4) || stg_len.ensure(batch * 4) || err.ensure(4) || d_tg.ensure(batch * r * 4 + 4) ||
         d_off.ensure(batch * r * 4 + 8) || d_src.ensure(batch * r * 4 + 4))
         return -1;
@@ -1178,7 +1185,6 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     a.adj = g->adj; a.deg = g->deg; a.r = r;
     a.medioid = medioid; a.qb = cfg->query_breakpoint;
     a.L = (int)cfg->l; a.maxc = (int)cfg->maxc; a.saturate = (int)cfg->saturate_graph; a.alpha = cfg->alpha; a.qalpha = cfg->query_alpha;
-    a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
     a.out_dist = cnts.as<uint32_t>();
     a.err = err.as<uint32_t>();
     BackArgs ba{};
@@ -1198,7 +1204,8 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
         a.points = d_order.as<uint32_t>() + b0;
         for (;;) {
             a.vl_ids = vli.as<uint32_t>(); a.vl_sc = vls.as<long long>(); a.vl_cap = (uint32_t)vl_cap;
-            MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nb * words * 4, st));
+            a.bitmap = bm.as<uint32_t>(); a.bm_words = set_words; a.hash_bits = use_hash ? table_bits : 0;
+            MSE_HIP_TRY(hipMemsetAsync(bm.p, use_hash ? 0xff : 0, nb * set_words * 4, st));
             MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));
             hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GS_THREADS), lds, st, a);
             MSE_HIP_TRY(hipGetLastError());
@@ -1215,10 +1222,19 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
             MSE_HIP_TRY(hipMemcpyAsync(h_len.data(), stg_len.p, nb * 4, hipMemcpyDeviceToHost, st));
             MSE_HIP_TRY(hipStreamSynchronize(st));
             if (e & 1u) return fail("build_graph: a graph edge points outside the index");
-            if (!(e & 2u)) break;
-            vl_cap *= 2;   // a search visited more nodes than there was room for: repeat the batch (the graph is untouched so far)
-            if (vl_cap > b->n + cfg->r) vl_cap = b->n + cfg->r;
-            if (vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8)) return -1;
+            if (!(e & 6u)) break;
+            // a search visited more nodes than there was room for (list or table): repeat the batch with more (the graph is untouched so far)
+            if (e & 2u) {
+                vl_cap *= 2;
+                if (vl_cap > b->n + cfg->r) vl_cap = b->n + cfg->r;
+                if (vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8)) return -1;
+            }
+            if (use_hash) {
+                table_bits = std::max(table_bits + ((e & 4u) ? 1 : 0), visited_table_bits(std::min<size_t>(b->n, vl_cap)));
+                if (words <= ((size_t)1 << table_bits)) use_hash = false;
+                set_words = use_hash ? (size_t)1 << table_bits : words;
+                if (bm.ensure(batch * set_words * 4)) return -1;
+            }
         }
         hipLaunchKernelGGL(apply_lists_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, g->adj, g->deg, r, a.points, stg.as<uint32_t>(),
                            stg_len.as<uint32_t>(), (int)nb);
@@ -1373,19 +1389,24 @@ int mse_robust_prune(mse_searcher* s, const uint32_t* cand_ids, const int64_t* c
     return 0;
 }
 
-int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* starts, const uint16_t* queries, size_t nq,
-                           size_t search_list, int base_vectors_only, uint32_t query_breakpoint, uint32_t* buf_ids,
-                           int64_t* buf_scores, uint32_t* buf_len, uint32_t* n_distances) {
+static int graph_search_batch_impl(int visited_mode, mse_searcher* s, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
+                                   size_t nq, size_t search_list, int base_vectors_only, uint32_t query_breakpoint, uint32_t* buf_ids,
+                                   int64_t* buf_scores, uint32_t* buf_len, uint32_t* n_distances) {
     if (!s || !s->base || !g || !starts || !queries || !buf_ids || !buf_scores || !buf_len || !n_distances)
         return fail("graph_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
-    {   // the visited sets take n / 8 bytes per query in flight: long batches go through in pieces of at most ~4 GiB of them
-        const size_t per_query = ((b->n + 31) / 32) * 4, piece = std::max<size_t>(1, std::max(s->pool[4].cap, visited_budget_bytes()) / per_query);   // pool[4]: the bitmaps already held
+    const size_t words = (b->n + 31) / 32;
+    const int table_bits = visited_table_bits(std::min<size_t>(b->n, search_list * 192 + 4096));
+    const char* vm = getenv("MSE_VISITED_MODE");   // test hook: "hash" / "bitmap"
+    const bool use_hash = visited_mode >= 0 ? visited_mode == 1 : (vm ? !strcmp(vm, "hash") : words > ((size_t)1 << table_bits));
+    const size_t set_words = use_hash ? (size_t)1 << table_bits : words;
+    {   // one visited set per query in flight: long batches go through in pieces that fit the budget
+        const size_t per_query = set_words * 4, piece = std::max<size_t>(1, std::max(s->pool[4].cap, visited_budget_bytes()) / per_query);   // pool[4]: the bitmaps already held
         if (nq > piece) {
             for (size_t q0 = 0; q0 < nq; q0 += piece) {
                 const size_t m = std::min(piece, nq - q0);
-                if (mse_graph_search_batch(s, g, starts + q0, queries + q0 * b->d, m, search_list, base_vectors_only, query_breakpoint,
+                if (graph_search_batch_impl(visited_mode, s, g, starts + q0, queries + q0 * b->d, m, search_list, base_vectors_only, query_breakpoint,
                                            buf_ids + q0 * search_list, buf_scores + q0 * search_list, buf_len + q0, n_distances + q0))
                     return -1;
             }
@@ -1399,14 +1420,14 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
     for (size_t q = 0; q < nq; q++)
         if (starts[q] >= b->n) return fail("graph_search_batch: start node out of range");
     hipStream_t st = s->stream;
-    const size_t d = b->d, words = (b->n + 31) / 32;
+    const size_t d = b->d;
     DevBuf &dq = s->pool[0], &dst = s->pool[3], &bm = s->pool[4], &oi = s->pool[5], &os = s->pool[6], &cnt = s->pool[10];
-    if (dq.ensure(nq * d * 2) || dst.ensure(nq * 4) || bm.ensure(nq * words * 4) || oi.ensure(nq * search_list * 4) ||
+    if (dq.ensure(nq * d * 2) || dst.ensure(nq * 4) || bm.ensure(nq * set_words * 4) || oi.ensure(nq * search_list * 4) ||
         os.ensure(nq * search_list * 8) || cnt.ensure(nq * 8 + 16))
         return -1;
     MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
     MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
-    MSE_HIP_TRY(hipMemsetAsync(bm.p, 0, nq * words * 4, st));
+    MSE_HIP_TRY(hipMemsetAsync(bm.p, use_hash ? 0xff : 0, nq * set_words * 4, st));
     MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 8 + 16, st));
     if (set_lds(graph_search_kernel<false>)) return -1;
     GraphArgs a{};
@@ -1415,7 +1436,7 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
     a.points = dst.as<uint32_t>(); a.queries = dq.as<uint16_t>();
     a.qb = query_breakpoint; a.base_only = base_vectors_only;
     a.L = (int)search_list;
-    a.bitmap = bm.as<uint32_t>(); a.bm_words = words;
+    a.bitmap = bm.as<uint32_t>(); a.bm_words = set_words; a.hash_bits = use_hash ? table_bits : 0;
     a.out_ids = oi.as<uint32_t>(); a.out_sc = os.as<long long>(); a.out_len = cnt.as<uint32_t>(); a.out_dist = cnt.as<uint32_t>() + nq;
     a.err = cnt.as<uint32_t>() + 2 * nq;
     hipLaunchKernelGGL(graph_search_kernel<false>, dim3((unsigned)nq), dim3(GS_THREADS), search_lds_bytes((int)d, (int)search_list), st, a);
@@ -1428,7 +1449,17 @@ int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* 
     MSE_HIP_TRY(hipMemcpyAsync(&err, a.err, 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipStreamSynchronize(st));
     if (err & 1u) return fail("graph_search_batch: a graph edge points outside the index");
+    if (err & 4u)   // a search outgrew its table: the bit maps have room for everything
+        return graph_search_batch_impl(0, s, g, starts, queries, nq, search_list, base_vectors_only, query_breakpoint, buf_ids, buf_scores, buf_len,
+                                       n_distances);
     return 0;
+}
+
+int mse_graph_search_batch(mse_searcher* s, const mse_graph* g, const uint32_t* starts, const uint16_t* queries, size_t nq,
+                           size_t search_list, int base_vectors_only, uint32_t query_breakpoint, uint32_t* buf_ids,
+                           int64_t* buf_scores, uint32_t* buf_len, uint32_t* n_distances) {
+    return graph_search_batch_impl(-1, s, g, starts, queries, nq, search_list, base_vectors_only, query_breakpoint, buf_ids, buf_scores, buf_len,
+                                   n_distances);
 }
 
 }  // extern "C"

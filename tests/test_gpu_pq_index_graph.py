@@ -422,3 +422,31 @@ def test_device_resident_beam_search_wide_lists(gpu, mse, orc, beamwidth, disabl
         assert (cm, pc) == (ocm, opc), i
         assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores), i
         assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc), i
+
+
+@pytest.mark.parametrize("bits", [None, "12"])
+def test_visited_sets_as_hash_tables(gpu, mse, orc, bits, monkeypatch):
+    """Large indexes keep their visited sets in open-addressing tables instead of one bit per node (visited_set.h).  Forced here
+    on a small index: same results; with a 4096-slot table the searches outgrow it and the call falls back to bit maps."""
+    rng = np.random.default_rng(29)
+    n, deg, L, nq = 6000, 40, 100, 12
+    x = clustered_rows(orc, n, n_centres=12)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng, long_edges=6)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    bg = mse.BuildGraph(n, deg, mse.IndexGraph(adj, degs))
+    qs = orc.f16_bits(clustered_rows(orc, nq, n_centres=12, seed=600))
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    want = mse.disk_search_batch(searcher, None, None, dgraph, starts, qs, None, None, True, 4, search_list=L, visited_cap=n)
+    want_ram = bg.search_batch(searcher, starts, qs, L)
+    monkeypatch.setenv("MSE_VISITED_MODE", "hash")
+    if bits:
+        monkeypatch.setenv("MSE_VISITED_TABLE_BITS", bits)
+    got = mse.disk_search_batch(searcher, None, None, dgraph, starts, qs, None, None, True, 4, search_list=L, visited_cap=n)
+    got_ram = bg.search_batch(searcher, starts, qs, L)
+    for a, b in zip(want, got):
+        assert all(np.array_equal(u, v) for u, v in zip(a[:4], b[:4])) and a[4:] == b[4:]
+    for a, b in zip(want_ram, got_ram):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert max(r[4] for r in want) * 20 > 2048 or bits is None      # the small table really is outgrown (fetches x ~20 fresh ids)
