@@ -203,3 +203,38 @@ def test_sharded_pipeline_end_to_end(gpu, mse, orc, tmp_path):
     _, truth = searcher.bruteforce_topk(q, K)
     recall = np.mean([len(set(top[i].tolist()) & set(truth[i].tolist())) / K for i in range(nq)])
     assert recall > 0.9
+
+
+def test_merge_shards_random_against_per_record_loop(tmp_path):
+    """The vectorised merge against read_out_vertices written out record by record (dump_processor.rs:264-293): random shards with
+    spill 2, ragged lists, repeated ids inside a list and across the two shards of a record."""
+    from mse import generate_index_shard as gis
+    from mse.diskann import IndexGraph
+    rng = np.random.default_rng(41)
+    n, S, R = 400, 5, 7
+    member = np.stack([rng.permutation(S)[:2] for _ in range(n)])            # the two shards of every record
+    member[rng.random(n) < 0.2, 1] = -1                                       # some records sit in one shard only
+    shard_data = {}
+    for s in range(S):
+        ids = np.flatnonzero((member == s).any(axis=1)).astype(np.uint32)
+        m = len(ids)
+        adj = rng.integers(0, m, size=(m, R)).astype(np.uint32)               # repeats inside a list happen
+        deg = rng.integers(0, R + 1, size=m).astype(np.uint32)
+        gis.write_shard_output(str(tmp_path), {"id": s, "centroid": [float(s)]}, int(rng.integers(0, m)), ids, IndexGraph(adj, deg), m)
+        shard_data[s] = (ids, adj, deg)
+    adj, deg, shards_of, specs = gis.merge_shards(str(tmp_path))
+    for gid in range(n):
+        want, want_sh = [], []
+        for s in range(S):                                                    # shard slots in ascending shard id
+            ids, a, d = shard_data[s]
+            pos = np.flatnonzero(ids == gid)
+            if len(pos) == 0:
+                continue
+            want_sh.append(s)
+            for w in a[pos[0], :d[pos[0]]]:
+                g = int(ids[w])
+                if g not in want:
+                    want.append(g)
+        assert adj[gid, :deg[gid]].tolist() == want, gid
+        assert [x for x in shards_of[gid].tolist() if x >= 0] == want_sh
+    assert len(specs) == S
