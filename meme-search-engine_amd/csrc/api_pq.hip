@@ -83,8 +83,12 @@ int mse_index_add(mse_index* idx, const float* x, size_t n) {
         ncap = std::max<size_t>(ncap, 1024);
         uint16_t* np = nullptr;
         MSE_HIP_TRY(hipMalloc((void**)&np, ncap * d * 2));
-        if (idx->n) MSE_HIP_TRY(hipMemcpyAsync(np, idx->codes, idx->n * d * 2, hipMemcpyDeviceToDevice, st));
-        MSE_HIP_TRY(hipStreamSynchronize(st));
+        hipError_t ce = idx->n ? hipMemcpyAsync(np, idx->codes, idx->n * d * 2, hipMemcpyDeviceToDevice, st) : hipSuccess;
+        if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+        if (ce != hipSuccess) {   // the old block stays in place; the new one must not leak
+            (void)hipFree(np);
+            return fail(std::string("mse_index_add: growing the index failed: ") + hipGetErrorString(ce));
+        }
         if (idx->codes) (void)hipFree(idx->codes);
         idx->codes = np;
         idx->cap = ncap;

@@ -18,17 +18,24 @@ __device__ __forceinline__ bool visited_insert(uint32_t* set, int bits, uint32_t
     }
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t h = (id * 2654435761u) >> (32 - bits);
-    for (;;) {
+    // The callers keep a table at most half full between steps and a step adds <= 1024 ids to a table of >= 4096 slots, so a free
+    // slot always exists; the probe count is bounded all the same so that a mis-sized table can never spin the GPU (a full table
+    // reports "already present": the search stops growing instead of hanging, and the half-full check raises err bit 4).
+    for (uint32_t probes = 0; probes <= mask; probes++) {
         const uint32_t old = atomicCAS(&set[h], 0xffffffffu, id);
         if (old == 0xffffffffu) return true;
         if (old == id) return false;
         h = (h + 1) & mask;
     }
+    return false;
 }
 
 // slots (u32 words) of one set, and the table size for a search that inserts at most `max_inserts` ids
 inline int visited_table_bits(size_t max_inserts) {
-    if (const char* e = getenv("MSE_VISITED_TABLE_BITS")) return atoi(e);   // test hook (>= 12: one step inserts at most 1024 ids)
+    if (const char* e = getenv("MSE_VISITED_TABLE_BITS")) {   // test hook; honoured only inside [12, 26] (one step inserts <= 1024 ids)
+        const int v = atoi(e);
+        if (v >= 12 && v <= 26) return v;
+    }
     int bits = 14;
     while (((size_t)1 << bits) < 2 * max_inserts && bits < 26) bits++;
     return bits;

@@ -201,16 +201,34 @@ def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph,
     return out
 
 
-def topk_of_visited(res, k):
-    """The server's last step (query_disk_index.rs:529-540) for a whole batch: ids of the k best visited records per query by
-    exact score (stable), from disk_search_batch(..., as_arrays=True).  Rows with fewer than k records are padded with ID_NONE."""
+def topk_of_visited(res, k, keep=None):
+    """Batch form of the server's last step (query_disk_index.rs:529-540): the reference sorts the WHOLE visited list by exact
+    score after the dedup filter (:482-527) and returns all of it; this helper cuts that sorted list to its first k ids per query
+    (stable order), from disk_search_batch(..., as_arrays=True).  `keep` ([nq, visited_cap] bool, e.g. from dedup_visited per
+    query) drops filtered records first; without it no dedup is applied.  Always returns [nq, k]: rows with fewer than k
+    records are padded with ID_NONE.  Raises if a search visited more records than visited_cap held (the reference keeps all)."""
     vi, vs, nv = res["visited_ids"], res["visited_scores"], res["n_visited"]
-    w = int(min(vi.shape[1], max(int(nv.max()), 1)))
+    cap = vi.shape[1]
+    if int(nv.max(initial=0)) > cap:
+        raise ValueError(f"a search visited {int(nv.max())} records but visited_cap is {cap}: raise visited_cap (the reference keeps every visited record)")
+    nq = vi.shape[0]
+    w = int(min(cap, max(int(nv.max(initial=0)), 1)))
+    lowest = np.iinfo(np.int64).min
     sc = vs[:, :w].copy()
-    sc[np.arange(w)[None, :] >= np.minimum(nv, vi.shape[1])[:, None]] = np.iinfo(np.int64).min
-    order = np.argsort(-sc.astype(np.float64), axis=1, kind="stable")[:, :k]
-    ids = np.take_along_axis(vi[:, :w], order, axis=1).astype(np.int64)
-    ids[np.take_along_axis(sc, order, axis=1) == np.iinfo(np.int64).min] = 0xFFFFFFFF
+    dead = np.arange(w)[None, :] >= nv[:, None]
+    if keep is not None:
+        dead |= ~np.asarray(keep, bool)[:, :w]
+    sc[dead] = lowest
+    # two stable passes: order by score descending without the precision loss of a float cast
+    order = np.argsort(-(sc >> 1), axis=1, kind="stable")          # coarse (halved scores cannot overflow when negated)
+    fine = np.take_along_axis(sc, order, axis=1)
+    fix = np.lexsort((np.arange(w)[None, :].repeat(nq, 0), -(fine & 1), -(fine >> 1)), axis=1)
+    order = np.take_along_axis(order, fix, axis=1)
+    ids = np.full((nq, k), 0xFFFFFFFF, np.int64)
+    m = min(k, w)
+    top = order[:, :m]
+    ids[:, :m] = np.take_along_axis(vi[:, :w], top, axis=1)
+    ids[:, :m][np.take_along_axis(dead, top, axis=1)] = 0xFFFFFFFF
     return ids
 
 

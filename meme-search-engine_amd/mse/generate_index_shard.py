@@ -164,22 +164,32 @@ def merge_shards(shards_dir, shard_ids=None, spill=SHARD_SPILL):
     for sid, h, ls in loaded:
         mapping = np.asarray(h["mapping"], np.uint32)
         specs.append((np.asarray(h["centroid"], np.float32), int(mapping[h["medioid"]])))
-        if len(np.unique(mapping)) != len(mapping) or (filled[mapping] >= spill).any():
-            raise ValueError("shard processing inconsistency")              # :257-259: a record sits in more shards than the spill
+        # :245-259: every occurrence of an id takes the record's next empty slot -- also when one shard's mapping repeats the id
+        # (occurrence r of an id inside this shard goes to slot filled + r); no empty slot left = "shard processing inconsistency"
+        by_id = np.argsort(mapping, kind="stable")
+        sorted_ids = mapping[by_id]
+        first = np.r_[True, sorted_ids[1:] != sorted_ids[:-1]] if len(mapping) else np.zeros(0, bool)
+        run_start = np.maximum.accumulate(np.where(first, np.arange(len(mapping)), 0)) if len(mapping) else np.zeros(0, np.int64)
+        occ = np.empty(len(mapping), np.int64)
+        occ[by_id] = np.arange(len(mapping)) - run_start
+        if ((filled[mapping] + occ) >= spill).any():
+            raise ValueError("shard processing inconsistency")
         lens = np.fromiter((len(l) for l in ls), np.int64, len(ls))
         local = np.full((len(ls), widest), 0, np.int64)
         mask = np.arange(widest)[None, :] < lens[:, None]
         if mask.any():
             local[mask] = np.concatenate(ls).astype(np.int64)
         glob = np.where(mask, mapping[local], none)                         # within-shard ids -> original ids
-        c = filled[mapping]
+        c = filled[mapping] + occ
         for k in range(spill):
             pick = c == k
             slots[mapping[pick], k * widest:(k + 1) * widest] = glob[pick]
             shards_of[mapping[pick], k] = sid
-        filled[mapping] += 1
+        np.add.at(filled, mapping, 1)
     # first occurrence kept, order kept (`!out_vertices.contains`), a few thousand records at a time
-    adj = np.zeros((n, width), np.uint32)
+    # The slot array is compacted in place and returned as the adjacency array, so the peak is ONE dense n x width u32 array
+    # (the reference streams per record, :264-293; at 1e8 records and R = 64 this array is 51 GB -- merge in id ranges via
+    # `shard_ids` subsets and np.memmap outputs beyond that).
     deg = np.zeros(n, np.uint32)
     later = np.arange(width)[:, None] > np.arange(width)[None, :]
     for i in range(0, n, 4096):
@@ -187,6 +197,6 @@ def merge_shards(shards_dir, shard_ids=None, spill=SHARD_SPILL):
         dup = ((blk[:, :, None] == blk[:, None, :]) & later[None]).any(axis=2)
         keep = (blk != none) & ~dup
         order = np.argsort(~keep, axis=1, kind="stable")
-        adj[i:i + 4096] = np.where(np.take_along_axis(keep, order, axis=1), np.take_along_axis(blk, order, axis=1), 0)
+        slots[i:i + 4096] = np.where(np.take_along_axis(keep, order, axis=1), np.take_along_axis(blk, order, axis=1), 0)
         deg[i:i + 4096] = keep.sum(axis=1)
-    return adj, deg, shards_of, specs
+    return slots, deg, shards_of, specs

@@ -238,3 +238,24 @@ def test_merge_shards_random_against_per_record_loop(tmp_path):
         assert adj[gid, :deg[gid]].tolist() == want, gid
         assert [x for x in shards_of[gid].tolist() if x >= 0] == want_sh
     assert len(specs) == S
+
+
+def test_merge_shards_repeated_id_takes_next_slot(tmp_path):
+    """dump_processor.rs:245-259: each occurrence of an id in a shard's mapping takes the record's next empty slot, also when the
+    SAME shard lists the id twice; a third occurrence (spill = 2) is the "shard processing inconsistency" error."""
+    from mse import generate_index_shard as gis
+    from mse.diskann import IndexGraph
+    ids = np.array([0, 1, 1, 2], np.uint32)                      # id 1 twice in shard 0
+    adj = np.array([[1, 0], [0, 3], [3, 0], [1, 2]], np.uint32)  # within-shard ids
+    deg = np.array([1, 2, 1, 2], np.uint32)
+    gis.write_shard_output(str(tmp_path), {"id": 0, "centroid": [0.0]}, 0, ids, IndexGraph(adj, deg), 4)
+    m_adj, m_deg, shards_of, _ = gis.merge_shards(str(tmp_path))
+    # record 1: slot 0 = list of occurrence 0 -> [ids[0], ids[3]] = [0, 2]; slot 1 = occurrence 1 -> [ids[3]] = [2] (already there)
+    assert m_adj[1, :m_deg[1]].tolist() == [0, 2] and shards_of[1].tolist() == [0, 0]
+    assert m_adj[0, :m_deg[0]].tolist() == [1] and shards_of[0].tolist() == [0, -1]
+    ids3 = np.array([1, 1, 1], np.uint32)
+    (tmp_path / "x").mkdir()
+    gis.write_shard_output(str(tmp_path / "x"), {"id": 0, "centroid": [0.0]}, 0, ids3,
+                           IndexGraph(np.zeros((3, 1), np.uint32), np.ones(3, np.uint32)), 3)
+    with pytest.raises(ValueError, match="inconsistency"):
+        gis.merge_shards(str(tmp_path / "x"))
