@@ -4,8 +4,11 @@
 
 A "step" = one batch of Q queries scored against the whole index (all shards), top-k returned.
   N = 1 : the whole index lives in one MI355X's HBM (1e8 x 1152 fp16 = 230.4 GB of 288 GB).
-  N > 1 : rows are partitioned contiguously over the ranks (strong scaling, fixed total index);
-          each rank scans its shard, ONE all-gather of the [Q, k] records over RCCL, k-way merge.
+  N > 1 : rows are partitioned contiguously over the GPUs (strong scaling, fixed total index); each shard is scanned
+          on its GPU, the per-shard [Q, k] records meet in ONE exchange and are merged k-way -- all behind the C ABI
+          (csrc/shard_group.hip).  Launched by torchrun (one process per GPU) the exchange is one ncclAllGather through
+          librccl; launched bare (`python bench.py --gpus N`) this process drives all N devices with a host thread per
+          shard and the records are written into the root device's buffer over peer mappings.
 Inputs (index rows and query batches) are synthetic, generated on the device, and resident in HBM
 before the timed region.  One JSON line on stdout (rank 0).
 """
@@ -214,7 +217,7 @@ def cpu_graph_build(n, points=192):
             "sample": f"{points} insertions (one batch) into the random initial graph over the same {n} rows"}
 
 
-def siglip_bench(args, world, rank):
+def siglip_bench(args, world, rank, dist=None):
     """BASELINE configs[1]: SigLIP-SO400M/14-384 image tower, batch 256 random 384x384 images, bf16, one
     replica per GPU.  Random-init weights of the named architecture (no checkpoint offline); images already
     resident in HBM as fp16 NCHW (what clip_server's preprocessing thread hands to the model).  One step = one
@@ -228,7 +231,6 @@ def siglip_bench(args, world, rank):
     torch.cuda.synchronize()
     eng.encode_image_device(img.data_ptr(), batch)            # warm-up (encode_image synchronises its stream)
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -236,10 +238,10 @@ def siglip_bench(args, world, rank):
         eng.encode_image_device(img.data_ptr(), batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)       # the control-plane group is gloo (CPU tensors)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        dt = float(t.item())
     eng.close()
     # text tower (clip_server.py:98): batch of 256 token rows, random-init weights; small next to the image tower
     import numpy as np
@@ -276,6 +278,8 @@ def main():
     ap.add_argument("--queries", type=int, default=128, help="queries per step (one scan pass per 128)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--logical-shards", action="store_true",
+                    help="developer dry run of the in-process --gpus N path on fewer devices (shard g on device g mod count)")
     ap.add_argument("--no-siglip", action="store_true", help="skip the SigLIP image-tower leg")
     ap.add_argument("--no-pq", action="store_true", help="skip the OPQ/PQ scan leg")
     ap.add_argument("--pq-rows", type=float, default=2e7)
@@ -293,101 +297,133 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # Two launch shapes for N > 1, both ending in the same C-ABI merge (csrc/shard_group.hip):
+    #   torchrun (WORLD_SIZE = N): one process per GPU, ONE ncclAllGather of the packed records per step (mse_comm_*);
+    #   bare `python bench.py --gpus N`: this one process drives all N devices, a host thread per shard, records written into
+    #   the root device's buffer over peer mappings (mse_shard_group_*).
+    in_process = world == 1 and args.gpus > 1
+    n_gpus = args.gpus if in_process else world
+    if world > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = ffi.lib().mse_device_count()
+    if in_process and n_dev < args.gpus and not args.logical_shards:
+        raise SystemExit(f"--gpus {args.gpus} but only {ffi.lib().mse_device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     ffi.check(ffi.lib().mse_set_device(local_rank), "mse_set_device")
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # control plane only (barrier, the 128-byte RCCL id, max of the timings); the data path's collective is RCCL, called
+        # from C++ on the searcher's stream
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def sync_all():
+        if in_process:
+            for dv in range(min(n_gpus, n_dev)):
+                torch.cuda.synchronize(dv)
+        else:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     n_total = int(args.rows)
     nq, k = args.queries, args.k
-    lo, hi = shard.shard_range(n_total, rank, world)
+    tile = 256 if nq > 128 else 128
+    lo, hi = shard.shard_range(n_total, rank, n_gpus) if not in_process else shard.shard_range(n_total, 0, n_gpus)
     free_b, total_b = ffi.sz(), ffi.sz()
     ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
-    need = (hi - lo) * D * 2 + ((hi - lo) // 32 + 1) * 128 * 4 + (8 << 30)
+    need = (hi - lo) * D * 2 + ((hi - lo) // 32 + 1) * tile * 4 + (8 << 30)
     note = ""
     if need > free_b.value:
-        if world == 1 and n_total > 10_000_000:
+        if n_gpus == 1 and n_total > 10_000_000:
             note = f"1e8 rows need {need / 1e9:.0f} GB > {free_b.value / 1e9:.0f} GB free; fell back to 1e7 rows (configs[2])"
             n_total = 10_000_000
             lo, hi = 0, n_total
         else:
             raise SystemExit(f"shard does not fit: need {need / 1e9:.0f} GB, free {free_b.value / 1e9:.0f} GB")
 
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        vecs = mse.VectorList.generate(SEED_BASE, lo, hi - lo, D)       # shard rows made on the device
-        n_batches = 4
-        qsets = mse.VectorList.generate(SEED_QUERY, 0, nq * n_batches, D)  # query batches, resident in HBM
-        searcher = mse.Searcher(vecs)
-        searcher.set_stream(stream.cuda_stream)
-        out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-        out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
-        if world > 1:
-            gs = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
-            gi = torch.empty((world, nq, k), dtype=torch.int32, device="cuda")
-            fin_s = torch.empty_like(out_s)
-            fin_i = torch.empty_like(out_i)
+    n_batches = 4
+    qsets = mse.VectorList.generate(SEED_QUERY, 0, nq * n_batches, D)  # query batches, resident in HBM (root device)
+    out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    comm = group = None
+    exchange = None
+    if in_process:
+        group = mse.ShardGroup(n_gpus, D, devices=[g % n_dev for g in range(n_gpus)])
+        group.generate(SEED_BASE, 0, n_total)                         # every shard's rows made on its own device
+        searcher = group.searcher(0)
+        peers = sum(group.peer_mapped(g) for g in range(n_gpus))
+        exchange = {"kind": "one process, a host thread per shard; per-shard [Q,k] records written into the root device's buffer",
+                    "shards": n_gpus, "devices": [group.device(g) for g in range(n_gpus)],
+                    "peer_mapped_shards": peers, "ranks": n_gpus}
 
         def step(i):
             qptr = qsets.device_ptr + (i % n_batches) * nq * D * 2
-            searcher.bruteforce_topk_dev(qptr, nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=lo)
-            if world > 1:
-                dist.all_gather_into_tensor(gs, out_s)
-                dist.all_gather_into_tensor(gi, out_i)
-                searcher.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), world, nq, k, fin_s.data_ptr(), fin_i.data_ptr())
-
-        for i in range(args.warmup):
-            step(i)
-        searcher.scan_timing(2)
-        torch.cuda.synchronize()
+            group.bruteforce_topk_dev(qptr, nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA)
+    else:
+        vecs = mse.VectorList.generate(SEED_BASE, lo, hi - lo, D)       # shard rows made on the device
+        searcher = mse.Searcher(vecs)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        scan_ms, scan_launches = searcher.scan_timing(0)
-        stats = searcher.last_stats()
+            ids = [mse.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = mse.Comm(ids[0], rank, world)
+            exchange = {"kind": "one process per GPU; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record blocks per step",
+                        "ranks": comm.size, "bytes_per_rank_per_step": int(ffi.lib().mse_topk_block_bytes(nq, k))}
+            if comm.size != world:
+                raise SystemExit(f"RCCL reports {comm.size} ranks, expected {world}")
 
-        # correctness spot check outside the timed region: the batched (MFMA) answer of the last step
-        # must equal the exact-order kernel's answer for the same queries (two independent kernels)
-        last = (args.warmup + args.steps - 1) % n_batches
-        qptr = qsets.device_ptr + last * nq * D * 2
-        chk_s = torch.empty((8, k), dtype=torch.int64, device="cuda")
-        chk_i = torch.empty((8, k), dtype=torch.int32, device="cuda")
-        searcher.bruteforce_topk_dev(qptr, min(8, nq), k, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT, id_offset=lo)
-        torch.cuda.synchronize()
-        m = min(8, nq)
-        if world == 1:
-            verified = bool(torch.equal(chk_s[:m], out_s[:m]) and torch.equal(chk_i[:m], out_i[:m]))
-        else:
-            verified = None  # shard-local exact check is covered by tests; merged result differs by construction
+        def step(i):
+            qptr = qsets.device_ptr + (i % n_batches) * nq * D * 2
+            if comm is None:
+                searcher.bruteforce_topk_dev(qptr, nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=lo)
+            else:
+                comm.search_dev(searcher, qptr, nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=lo)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    for i in range(args.warmup):
+        step(i)
+    searcher.scan_timing(2)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_launches = searcher.scan_timing(0)
+    stats = searcher.last_stats()
+
+    # correctness spot check outside the timed region: the batched (MFMA) answer of the last step must equal the
+    # exact-order kernel's answer for the same queries (two independent kernels), over the whole (sharded) index
+    last = (args.warmup + args.steps - 1) % n_batches
+    qptr = qsets.device_ptr + last * nq * D * 2
+    m = min(8, nq)
+    chk_s = torch.empty((m, k), dtype=torch.int64, device="cuda")
+    chk_i = torch.empty((m, k), dtype=torch.int32, device="cuda")
+    if in_process:
+        group.bruteforce_topk_dev(qptr, m, k, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT)
+    elif comm is not None:
+        comm.search_dev(searcher, qptr, m, k, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT, id_offset=lo)
+    else:
+        searcher.bruteforce_topk_dev(qptr, m, k, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT, id_offset=lo)
+    sync_all()
+    verified = bool(torch.equal(chk_s, out_s[:m]) and torch.equal(chk_i, out_i[:m]))
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
 
     # ---- second half of BASELINE.json's metric: SigLIP image embeds/s/GPU (replicas, no collective) ----
     siglip_line = None
     if not args.no_siglip:
-        siglip_line = siglip_bench(args, world, rank)
+        siglip_line = siglip_bench(args, world, rank, dist)
     pq_line = graph_line = None
-    if rank == 0 and world == 1 and not args.no_pq:      # single-process side legs: a failure is reported, not fatal
+    if rank == 0 and n_gpus == 1 and not args.no_pq:      # single-process side legs: a failure is reported, not fatal
         try:
             pq_line = pq_bench(args)
         except Exception as e:  # noqa: BLE001
             pq_line = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_graph:
+    if rank == 0 and n_gpus == 1 and not args.no_graph:
         try:
             graph_line = graph_bench(args)
         except Exception as e:  # noqa: BLE001
@@ -412,7 +448,7 @@ def main():
             "metric": "queries/sec over 1e8x1152 index @ recall@10>=0.95 (exact brute force: recall 1.0)",
             "value": qps,
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -422,9 +458,10 @@ def main():
             "dtype": "f16 in, f32 accumulate, i64 fixed-point scores",
             "data": "synthetic (device-generated unit-norm rows, seeds 0x5EED0001/2)",
             "config": {"workload": f"brute-force top-{k} over {n_total} x {D} fp16 rows, {nq} queries/step, "
-                                   f"row-sharded over {world} GPU(s)" + (" + RCCL all-gather of [Q,k] records" if world > 1 else ""),
+                                   f"row-sharded over {n_gpus} GPU(s)" + (" + RCCL all-gather of [Q,k] records" if world > 1 else
+                                                                          " + peer-mapped gather of [Q,k] records" if in_process else ""),
                        "rows_total": n_total, "rows_per_gpu": hi - lo, "queries_per_step": nq, "k": k,
-                       "parallelism": f"row-shard x{world}"},
+                       "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
@@ -446,12 +483,16 @@ def main():
         # not measured by this command (the build takes 20 minutes): the same 1e8-row index served through the graph path
         line["see_also"] = "profiles/r01_graph_scale.txt: 1e8 x 1152 on one GPU, sharded Vamana index, 66 k queries/s at recall@10 0.993"
 
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_total, k)
             if graph_line:
                 line["cpu_baseline"]["graph_build"] = cpu_graph_build(int(args.graph_rows))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if group is not None:
+        group.close()
+    if comm is not None:
+        comm.close()
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -50,16 +50,23 @@ int64_t mse_scale_dot_f64(double x);             /* scale_dot_result_f64 */
 /* ---- base vectors: diskann::vector::VectorList (vector.rs:118-186) kept resident in HBM - */
 typedef struct mse_base mse_base;
 mse_base* mse_base_from_host(const uint16_t* data, size_t n_rows, size_t d);      /* copies */
-mse_base* mse_base_wrap_device(const void* data_dev, size_t n_rows, size_t d);    /* borrows */
+mse_base* mse_base_wrap_device(const void* data_dev, size_t n_rows, size_t d);    /* borrows; see mse_base_rows_changed */
 mse_base* mse_base_generate(uint32_t seed, uint64_t first_row, size_t n_rows, size_t d); /* synthetic rows made on the device */
 void mse_base_free(mse_base* b);
 size_t mse_base_len(const mse_base* b);
 size_t mse_base_dim(const mse_base* b);
 const void* mse_base_device_ptr(const mse_base* b);
 int mse_base_read_rows(const mse_base* b, size_t first_row, size_t n_rows, uint16_t* out); /* D2H, for spot checks */
+/* A base caches its largest row norm (the bound behind the MFMA scan's exactness certificate and the
+ * graph build's).  Borrowed memory must stay unchanged while searches run; after rewriting rows of a
+ * wrapped base call this (with no search in flight) so the bound is measured again on next use. */
+int mse_base_rows_changed(mse_base* b);
 
 /* fast_dot_noprefetch(x, y) / fast_dot(x, y, _) -- diskann/src/vector.rs:255-306,192-252.
  * Host slices in, one i64 out, computed on the device in the reference's summation order. */
+/* NB: one call = two uploads, one launch, one download (tens of microseconds): it pins the arithmetic of
+ * the interface for parity tests and documents it; production scoring goes through mse_score_rows_f16 /
+ * the searches, which keep rows resident and batch the work. */
 int mse_fast_dot_f16(const uint16_t* x, const uint16_t* y, size_t n, int64_t* out);
 
 /* ---- searcher: per-thread scratch + stream (reference: `Scratch`, lib.rs:157-175 and
@@ -99,12 +106,59 @@ int mse_score_rows_f16(mse_searcher* s, const uint32_t* ids, size_t n_ids, const
  * rank's [nq][k]); out_* are device [nq][k].  Asynchronous on the searcher's stream. */
 int mse_merge_topk_dev(mse_searcher* s, const void* gathered_scores_dev, const void* gathered_ids_dev,
                        size_t n_shards, size_t nq, size_t k, void* out_scores_dev, void* out_ids_dev);
+/* Same merge for PACKED per-shard blocks: block g = [nq*k] i64 scores then [nq*k] u32 ids, blocks
+ * mse_topk_block_bytes(nq, k) apart (what mse_comm_search_dev gathers and mse_shard_group fills). */
+size_t mse_topk_block_bytes(size_t nq, size_t k);
+int mse_merge_topk_packed_dev(mse_searcher* s, const void* gathered_blocks_dev, size_t n_shards, size_t nq, size_t k,
+                              void* out_scores_dev, void* out_ids_dev);
 /* HIP-event timing of the scan kernel (the HBM-bound kernel) on the searcher's stream: returns the
  * totals accumulated so far, then sets the mode: enable 0 = off, 1 = on, 2 = on and reset totals. */
 int mse_searcher_scan_timing(mse_searcher* s, int enable, double* total_ms, uint64_t* launches);
 /* statistics of the last MFMA-mode call: number of queries whose certificate needed a wider
  * candidate set, and the widest group count used. */
 int mse_searcher_last_stats(const mse_searcher* s, uint32_t* n_widened, uint32_t* max_groups);
+
+/* ---- row-sharded index over the GPUs of one node.  The reference has no multi-GPU
+ * code; its query server is a thread per core, each with its own Scratch over shared read-only maps
+ * (src/query_disk_index.rs:711-736).  Same shape here with a thread per shard: rows partitioned
+ * contiguously (shard g of G holds rows [g*n/G ..), remainder on the first shards), every shard scores
+ * the same query batch and returns global ids, the per-shard [nq][k] records meet in ONE buffer on the
+ * root device (shard 0's; written over a peer mapping, i.e. xGMI, when the devices allow it) and are
+ * merged by (score desc, id asc).  Results equal those of one searcher over all rows.
+ * devices[g] = HIP ordinal of shard g (NULL: g mod device count); ordinals may repeat (logical shards). */
+typedef struct mse_shard_group mse_shard_group;
+mse_shard_group* mse_shard_group_new(const int* devices, size_t n_shards, size_t d);
+void mse_shard_group_free(mse_shard_group* g);
+size_t mse_shard_group_n_shards(const mse_shard_group* g);
+size_t mse_shard_group_len(const mse_shard_group* g);                       /* rows over all shards */
+int mse_shard_group_device(const mse_shard_group* g, size_t shard);
+int mse_shard_group_peer_mapped(const mse_shard_group* g, size_t shard);    /* 1: writes the gather buffer directly */
+mse_searcher* mse_shard_group_searcher(mse_shard_group* g, size_t shard);   /* for scan timing / certificate stats; owned by the group */
+/* fill: synthetic rows first_row .. first_row+total_rows made on each shard's device | one host array split
+ * over the shards (copied) | one shard borrowed from device memory on that shard's device */
+int mse_shard_group_generate(mse_shard_group* g, uint32_t seed, uint64_t first_row, size_t total_rows);
+int mse_shard_group_load_host(mse_shard_group* g, const uint16_t* rows, size_t total_rows);
+int mse_shard_group_set_shard_device(mse_shard_group* g, size_t shard, const void* rows_dev, size_t n_rows, uint64_t first_row);
+/* brute-force top-k over all shards: same contract as mse_bruteforce_topk_f16 (ids are global). */
+int mse_shard_group_search(mse_shard_group* g, const uint16_t* queries, size_t nq, size_t k, int mode, int64_t* scores,
+                           uint32_t* ids);
+/* queries / outputs on the ROOT device (queries complete before the call); returns when the result is complete. */
+int mse_shard_group_search_dev(mse_shard_group* g, const void* queries_dev, size_t nq, size_t k, int mode, void* scores_dev,
+                               void* ids_dev);
+
+/* One process per GPU instead (the launch shape of torchrun): ONE ncclAllGather of the packed per-shard
+ * records over RCCL/xGMI on the searcher's stream, then the same merge on every rank.  RCCL is loaded on
+ * first use (librccl.so); the 128-byte id made by rank 0 reaches the other ranks through the host's own
+ * rendezvous (any byte transport).  Every rank must call mse_comm_search_dev with the same nq and k. */
+typedef struct { char internal[128]; } mse_comm_id;     /* == ncclUniqueId */
+typedef struct mse_comm mse_comm;
+int mse_comm_unique_id(mse_comm_id* out);
+mse_comm* mse_comm_init(const mse_comm_id* id, int rank, int world);  /* collective; on the thread's current device */
+void mse_comm_free(mse_comm* c);
+int mse_comm_rank(const mse_comm* c);
+int mse_comm_size(const mse_comm* c);                   /* rank count as RCCL reports it */
+int mse_comm_search_dev(mse_comm* c, mse_searcher* s, const void* queries_dev, size_t nq, size_t k, int mode,
+                        uint64_t id_offset, void* scores_dev, void* ids_dev);
 
 /* ---- flat in-memory index: FAISS IndexScalarQuantizer(QT_fp16, INNER_PRODUCT) as used by
  * src/main.rs:822 (new), :858,:892 (add), :900 (search), :1015,:1053 (ntotal) -------------- */

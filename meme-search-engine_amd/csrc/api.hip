@@ -300,6 +300,12 @@ void mse_base_free(mse_base* b) {
     if (b->norm_bits_dev) (void)hipFree(b->norm_bits_dev);
     delete b;
 }
+int mse_base_rows_changed(mse_base* b) {
+    if (!b) return fail("null base");
+    std::lock_guard<std::mutex> g(b->norm_mu);
+    b->norm_ready = false;
+    return 0;
+}
 size_t mse_base_len(const mse_base* b) { return b ? b->n : 0; }
 size_t mse_base_dim(const mse_base* b) { return b ? b->d : 0; }
 const void* mse_base_device_ptr(const mse_base* b) { return b ? b->dev : nullptr; }

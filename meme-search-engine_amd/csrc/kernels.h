@@ -43,6 +43,7 @@ struct SelectArgs {
     const void* list_keys;
     size_t list_stride, n_list;
     size_t list_chunk = 0, list_chunk_stride = 0;  // if list_chunk != 0: candidate c lives at (c / chunk) * chunk_stride + c % chunk
+    size_t list_id_chunk_stride = 0;               // chunk stride of list_ids when it differs from that of list_keys (0 = the same)
     int k;                   // number to select (<= TOPK_KMAX)
     uint32_t* out_ids;       // [nq][out_stride], best first, padded with ID_NONE
     void* out_keys;          // optional: raw keys (same type as `in`) of the selected, [nq][out_stride]

@@ -1,0 +1,425 @@
+// Row-sharded brute-force search over the GPUs of one node; C ABI in include/mse.h.
+//
+// The reference has no multi-GPU code; what it has is a thread per core, each with its own scratch over shared read-only
+// maps (src/query_disk_index.rs:711-736).  Scoring is row-independent, so the same shape carries over: base rows are partitioned
+// contiguously, every shard scores the same query batch and returns GLOBAL ids (local id + the shard's first row), the
+// per-shard [nq][k] records meet in one buffer, and a k-way merge by (score desc, id asc) gives the result of the whole index.
+//
+// Two ways for the records to meet, both behind this file, neither touching torch:
+//   mse_shard_group   ONE process drives every shard: a persistent host thread per shard (hipSetDevice once, own mse_base,
+//                     mse_searcher and stream).  Shards may share a device ("logical shards"; how the 8-way layout is tested on a
+//                     one-GPU box).  The gather buffer [G] x {[nq][k] i64, [nq][k] u32} lives on the root device; a shard on
+//                     another device writes its block straight into it through a peer mapping (hipDeviceEnablePeerAccess:
+//                     the finalize kernel's few KB of stores cross xGMI), or, without peer access, by one hipMemcpyPeerAsync.
+//   mse_comm          one process per GPU (torchrun's shape): ONE ncclAllGather of the packed 12-byte-per-record block on the
+//                     searcher's stream through librccl.so (dlopen'ed here; the unique id travels through the host's own
+//                     rendezvous), then the same merge on every rank.
+// The merge is the radix select of topk.hip over the G*k candidates of a query (unique composite key, so deterministic).
+#include "../../include/mse.h"
+#include "runtime.h"
+#include <dlfcn.h>
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+using namespace mse;
+
+namespace {
+
+// packed per-shard block: [nq*k] i64 scores, then [nq*k] u32 ids, padded to 16 bytes
+inline size_t block_bytes(size_t nq, size_t k) { return (nq * k * 12 + 15) & ~(size_t)15; }
+
+// merge G packed blocks (device memory of the searcher's device) -> out [nq][k]; asynchronous on the searcher's stream
+int merge_packed(mse_searcher* s, const char* gathered, size_t n_shards, size_t nq, size_t k, void* out_scores_dev,
+                 void* out_ids_dev) {
+    if (k > (size_t)TOPK_KMAX) return fail("k too large");
+    if (s->misc.ensure(nq * k * 4) || s->sel_keys.ensure(nq * k * 8)) return -1;
+    const size_t B = block_bytes(nq, k);
+    SelectArgs a{};
+    a.kind = KEY_I64;
+    a.list_keys = gathered;
+    a.list_ids = reinterpret_cast<const uint32_t*>(gathered + nq * k * 8);
+    a.list_stride = k;                  // query q starts k records into each shard's block
+    a.list_chunk = k;
+    a.list_chunk_stride = B / 8;        // next shard, in i64 elements
+    a.list_id_chunk_stride = B / 4;     // next shard, in u32 elements
+    a.n_list = n_shards * k;
+    a.k = (int)k; a.out_ids = s->misc.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = k; a.nq = (int)nq;
+    if (launch_select(a, s->stream)) return -1;
+    return launch_finalize(s->misc.as<uint32_t>(), s->sel_keys.as<int64_t>(), k, (int)k, (int)nq, 0,
+                           reinterpret_cast<int64_t*>(out_scores_dev), reinterpret_cast<uint32_t*>(out_ids_dev), k, nullptr, 0,
+                           0, 0, nullptr, nullptr, s->stream);
+}
+
+struct Shard {
+    int device = 0;
+    size_t first_row = 0;       // global id of local row 0
+    mse_base* base = nullptr;
+    mse_searcher* searcher = nullptr;
+    DevBuf q_local, block;      // on this shard's device (used when it cannot reach the root's memory directly)
+    bool peer = false;          // may read/write root-device memory from kernels
+    std::string err;
+    int rc = 0;
+};
+
+}  // namespace
+
+struct mse_shard_group {
+    size_t d = 0;
+    int root_device = 0;
+    std::vector<Shard> shards;
+    mse_searcher* root = nullptr;       // scratch searcher on the root device: merge + its stream
+    DevBuf gathered, q_root, out_s, out_i;
+    // persistent workers: run(fn) executes fn(shard index) on every shard's thread and waits
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(size_t)> job;
+    uint64_t job_seq = 0;
+    size_t pending = 0;
+    bool stop = false;
+    std::mutex call_mu;                 // one search at a time per group (a second group = a second set of scratch)
+
+    void worker(size_t g) {
+        (void)hipSetDevice(shards[g].device);
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<int(size_t)> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return stop || job_seq != seen; });
+                if (stop) return;
+                seen = job_seq;
+                fn = job;
+            }
+            set_error("");
+            const int rc = fn(g);
+            shards[g].rc = rc;
+            shards[g].err = rc ? std::string(mse_last_error()) : std::string();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    int run(std::function<int(size_t)> fn) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = std::move(fn);
+            pending = shards.size();
+            job_seq++;
+        }
+        cv_job.notify_all();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        for (size_t g = 0; g < shards.size(); g++)
+            if (shards[g].rc) return fail("shard " + std::to_string(g) + ": " + shards[g].err);
+        return 0;
+    }
+};
+
+// contiguous split, remainder spread over the first shards (the same rule as the host mirror's shard_range)
+static void shard_range(size_t n, size_t g, size_t G, size_t* lo, size_t* hi) {
+    const size_t base = n / G, rem = n % G;
+    *lo = g * base + std::min(g, rem);
+    *hi = *lo + base + (g < rem ? 1 : 0);
+}
+
+extern "C" {
+
+size_t mse_topk_block_bytes(size_t nq, size_t k) { return block_bytes(nq, k); }
+int mse_merge_topk_packed_dev(mse_searcher* s, const void* gathered_blocks_dev, size_t n_shards, size_t nq, size_t k,
+                              void* out_scores_dev, void* out_ids_dev) {
+    if (!s) return fail("null searcher");
+    if (nq == 0 || k == 0 || n_shards == 0) return 0;
+    return merge_packed(s, reinterpret_cast<const char*>(gathered_blocks_dev), n_shards, nq, k, out_scores_dev, out_ids_dev);
+}
+
+mse_shard_group* mse_shard_group_new(const int* devices, size_t n_shards, size_t d) {
+    if (n_shards == 0 || n_shards > 1024) { fail("shard group: 1..1024 shards"); return nullptr; }
+    if (d == 0 || d % 64 != 0 || d > (size_t)D_MAX) { fail("vector width must be a positive multiple of 64"); return nullptr; }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { fail("shard group: no HIP device"); return nullptr; }
+    for (size_t g = 0; g < n_shards; g++)
+        if (devices && (devices[g] < 0 || devices[g] >= n_dev)) { fail("shard group: device ordinal out of range"); return nullptr; }
+    mse_shard_group* G = new (std::nothrow) mse_shard_group();
+    if (!G) { fail("out of host memory"); return nullptr; }
+    G->d = d;
+    G->shards.resize(n_shards);
+    for (size_t g = 0; g < n_shards; g++) G->shards[g].device = devices ? devices[g] : (int)(g % (size_t)n_dev);
+    G->root_device = G->shards[0].device;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(G->root_device);
+    G->root = scratch_searcher_new();
+    (void)hipSetDevice(prev);
+    if (!G->root) { delete G; return nullptr; }
+    for (size_t g = 0; g < n_shards; g++) G->threads.emplace_back([G, g] { G->worker(g); });
+    // peer mappings towards the root, once per distinct device
+    const int rc = G->run([G](size_t g) -> int {
+        Shard& sh = G->shards[g];
+        if (sh.device == G->root_device) { sh.peer = true; return 0; }
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, sh.device, G->root_device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(G->root_device, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) sh.peer = true;
+            (void)hipGetLastError();
+        }
+        return 0;
+    });
+    if (rc) { mse_shard_group_free(G); return nullptr; }
+    return G;
+}
+
+void mse_shard_group_free(mse_shard_group* G) {
+    if (!G) return;
+    if (!G->threads.empty()) {
+        (void)G->run([G](size_t g) -> int {   // handles are released on the thread (and device) that made them
+            Shard& sh = G->shards[g];
+            if (sh.searcher) mse_searcher_free(sh.searcher);
+            if (sh.base) mse_base_free(sh.base);
+            sh.searcher = nullptr; sh.base = nullptr;
+            sh.q_local.release(); sh.block.release();
+            return 0;
+        });
+        {
+            std::lock_guard<std::mutex> lk(G->mu);
+            G->stop = true;
+        }
+        G->cv_job.notify_all();
+        for (auto& t : G->threads) t.join();
+    }
+    if (G->root) mse_searcher_free(G->root);
+    delete G;
+}
+
+size_t mse_shard_group_n_shards(const mse_shard_group* G) { return G ? G->shards.size() : 0; }
+size_t mse_shard_group_len(const mse_shard_group* G) {
+    size_t n = 0;
+    if (G) for (const Shard& s : G->shards) n += s.base ? s.base->n : 0;
+    return n;
+}
+int mse_shard_group_device(const mse_shard_group* G, size_t shard) {
+    return (G && shard < G->shards.size()) ? G->shards[shard].device : -1;
+}
+mse_searcher* mse_shard_group_searcher(mse_shard_group* G, size_t shard) {
+    return (G && shard < G->shards.size()) ? G->shards[shard].searcher : nullptr;
+}
+int mse_shard_group_peer_mapped(const mse_shard_group* G, size_t shard) {
+    return (G && shard < G->shards.size()) ? (G->shards[shard].peer ? 1 : 0) : 0;
+}
+
+static int install(Shard& sh, mse_base* b, size_t first_row) {
+    if (!b) return -1;
+    mse_searcher* s = mse_searcher_new(b);
+    if (!s) { mse_base_free(b); return -1; }
+    if (sh.searcher) mse_searcher_free(sh.searcher);
+    if (sh.base) mse_base_free(sh.base);
+    sh.base = b; sh.searcher = s; sh.first_row = first_row;
+    return 0;
+}
+
+int mse_shard_group_generate(mse_shard_group* G, uint32_t seed, uint64_t first_row, size_t total_rows) {
+    if (!G) return fail("null shard group");
+    if (first_row + total_rows > 0xFFFFFFFEull) return fail("row ids are u32: too many rows");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    return G->run([=](size_t g) -> int {
+        size_t lo, hi;
+        shard_range(total_rows, g, G->shards.size(), &lo, &hi);
+        return install(G->shards[g], mse_base_generate(seed, first_row + lo, hi - lo, G->d), first_row + lo);
+    });
+}
+
+int mse_shard_group_load_host(mse_shard_group* G, const uint16_t* rows, size_t total_rows) {
+    if (!G) return fail("null shard group");
+    if (total_rows > 0xFFFFFFFEull) return fail("row ids are u32: too many rows");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    return G->run([=](size_t g) -> int {
+        size_t lo, hi;
+        shard_range(total_rows, g, G->shards.size(), &lo, &hi);
+        return install(G->shards[g], mse_base_from_host(rows + lo * G->d, hi - lo, G->d), lo);
+    });
+}
+
+int mse_shard_group_set_shard_device(mse_shard_group* G, size_t shard, const void* rows_dev, size_t n_rows, uint64_t first_row) {
+    if (!G) return fail("null shard group");
+    if (shard >= G->shards.size()) return fail("shard index out of range");
+    if (first_row + n_rows > 0xFFFFFFFEull) return fail("row ids are u32: too many rows");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    return G->run([=](size_t g) -> int {
+        if (g != shard) return 0;
+        return install(G->shards[g], mse_base_wrap_device(rows_dev, n_rows, G->d), (size_t)first_row);
+    });
+}
+
+// queries_dev: [nq][d] f16 on the ROOT device (device of shard 0), complete before the call; outputs [nq][k] on the root device.
+// Returns when the merged result is complete.
+int mse_shard_group_search_dev(mse_shard_group* G, const void* queries_dev, size_t nq, size_t k, int mode,
+                               void* scores_dev, void* ids_dev) {
+    if (!G) return fail("null shard group");
+    if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    for (const Shard& s : G->shards) if (!s.searcher) return fail("shard group: a shard holds no rows yet");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    const size_t n_shards = G->shards.size();
+    const size_t B = block_bytes(nq, k), qbytes = nq * G->d * 2;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    MSE_HIP_TRY(hipSetDevice(G->root_device));
+    int rc = G->gathered.ensure(B * n_shards);
+    if (!rc) {
+        char* const gathered = G->gathered.as<char>();
+        rc = G->run([=](size_t g) -> int {
+            Shard& sh = G->shards[g];
+            hipStream_t st = sh.searcher->stream;
+            const void* q = queries_dev;
+            char* blk = gathered + g * B;
+            if (!sh.peer) {   // no mapping of the root's memory: stage the queries here, copy the block back
+                if (sh.q_local.ensure(qbytes) || sh.block.ensure(B)) return -1;
+                MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
+                q = sh.q_local.p;
+                blk = sh.block.as<char>();
+            }
+            if (mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8)) return -1;
+            if (!sh.peer) MSE_HIP_TRY(hipMemcpyPeerAsync(gathered + g * B, G->root_device, blk, sh.device, B, st));
+            MSE_HIP_TRY(hipStreamSynchronize(st));
+            return 0;
+        });
+        if (!rc) rc = merge_packed(G->root, gathered, n_shards, nq, k, scores_dev, ids_dev);
+        if (!rc && hipStreamSynchronize(G->root->stream) != hipSuccess) rc = fail("shard group: merge failed");
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+int mse_shard_group_search(mse_shard_group* G, const uint16_t* queries, size_t nq, size_t k, int mode, int64_t* scores,
+                           uint32_t* ids) {
+    if (!G) return fail("null shard group");
+    if (nq == 0 || k == 0) return 0;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    MSE_HIP_TRY(hipSetDevice(G->root_device));
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> call(G->call_mu);   // q_root / out_* are group scratch
+        rc = G->q_root.ensure(nq * G->d * 2) || G->out_s.ensure(nq * k * 8) || G->out_i.ensure(nq * k * 4);
+        if (!rc && hipMemcpy(G->q_root.p, queries, nq * G->d * 2, hipMemcpyHostToDevice) != hipSuccess) rc = fail("query upload failed");
+    }
+    if (!rc) rc = mse_shard_group_search_dev(G, G->q_root.p, nq, k, mode, G->out_s.p, G->out_i.p);
+    if (!rc && (hipMemcpy(scores, G->out_s.p, nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(ids, G->out_i.p, nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail("result download failed");
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---- one process per GPU: RCCL -------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, mse_comm_id, int) = nullptr;   // ncclUniqueId is a 128-byte struct passed by value
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy the process already holds (the torch wheel bundles one) is reused; otherwise ROCm's
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!r.lib) for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!r.lib) { r.why = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.why.empty()) r.why = std::string("librccl.so lacks ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+
+int rccl_ready() {
+    Rccl& r = rccl();
+    if (!r.why.empty()) return fail(r.why);
+    return 0;
+}
+int rccl_fail(const char* what, int code) {
+    Rccl& r = rccl();
+    return fail(std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+}
+
+}  // namespace
+
+struct mse_comm {
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf local, gathered;
+};
+
+extern "C" {
+
+int mse_comm_unique_id(mse_comm_id* out) {
+    if (!out) return fail("null id");
+    if (rccl_ready()) return -1;
+    const int rc = rccl().GetUniqueId(out);
+    return rc ? rccl_fail("ncclGetUniqueId", rc) : 0;
+}
+
+mse_comm* mse_comm_init(const mse_comm_id* id, int rank, int world) {
+    if (!id || world <= 0 || rank < 0 || rank >= world) { fail("mse_comm_init: bad rank / world"); return nullptr; }
+    if (rccl_ready()) return nullptr;
+    mse_comm* c = new (std::nothrow) mse_comm();
+    if (!c) { fail("out of host memory"); return nullptr; }
+    c->rank = rank; c->world = world;
+    const int rc = rccl().CommInitRank(&c->comm, world, *id, rank);
+    if (rc) { rccl_fail("ncclCommInitRank", rc); delete c; return nullptr; }
+    return c;
+}
+
+void mse_comm_free(mse_comm* c) {
+    if (!c) return;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+int mse_comm_rank(const mse_comm* c) { return c ? c->rank : -1; }
+int mse_comm_size(const mse_comm* c) {
+    if (!c) return 0;
+    int n = 0;
+    if (rccl().CommCount(c->comm, &n)) return 0;   // what RCCL itself reports, not what the caller claimed
+    return n;
+}
+
+// local search over this rank's shard + ONE all-gather of the packed records + merge; outputs [nq][k] on this rank's device,
+// identical on every rank.  Asynchronous on the searcher's stream after the local search (which synchronises internally).
+int mse_comm_search_dev(mse_comm* c, mse_searcher* s, const void* queries_dev, size_t nq, size_t k, int mode,
+                        uint64_t id_offset, void* scores_dev, void* ids_dev) {
+    if (!c || !s) return fail("null communicator / searcher");
+    if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    const size_t B = block_bytes(nq, k);
+    if (c->local.ensure(B) || c->gathered.ensure(B * (size_t)c->world)) return -1;
+    char* blk = c->local.as<char>();
+    if (mse_bruteforce_topk_f16_dev(s, queries_dev, nq, k, mode, id_offset, blk, blk + nq * k * 8)) return -1;
+    const int rc = rccl().AllGather(blk, c->gathered.p, B, /*ncclInt8*/ 0, c->comm, s->stream);
+    if (rc) return rccl_fail("ncclAllGather", rc);
+    return merge_packed(s, c->gathered.as<char>(), (size_t)c->world, nq, k, scores_dev, ids_dev);
+}
+
+}  // extern "C"

@@ -152,8 +152,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
         uint32_t id;
         K key;
         if (use_list) {
-            const size_t ci = a.list_chunk ? (c / a.list_chunk) * a.list_chunk_stride + (c % a.list_chunk) : c;
-            id = list_ids[ci];
+            size_t ci = c, ii = c;
+            if (a.list_chunk) {
+                const size_t ch = c / a.list_chunk, r = c % a.list_chunk;
+                ci = ch * a.list_chunk_stride + r;
+                ii = a.list_id_chunk_stride ? ch * a.list_id_chunk_stride + r : ci;
+            }
+            id = list_ids[ii];
             if (id == ID_NONE) return false;
             key = key_of(list_keys[ci]);
         } else if (use_par) {

@@ -12,3 +12,4 @@ from .diskann import (NeighbourBuffer, IndexGraph, greedy_search, disk_greedy_se
 from .index import ScalarQuantizerIndex  # noqa: F401
 from .common import decode_fp16_buffer, chunk_fp16_buffer, get_total_embedding  # noqa: F401
 from .index_pack import ScoreModel, descriptor_buckets  # noqa: F401
+from .shard import ShardGroup, Comm, shard_range  # noqa: F401

@@ -57,6 +57,27 @@ SIGNATURES = {
     "mse_bruteforce_ranks_f16": (C.c_int, [vp, u16p, u32p, sz, u32p]),
     "mse_score_rows_f16": (C.c_int, [vp, u32p, sz, u16p, i64p]),
     "mse_merge_topk_dev": (C.c_int, [vp, vp, vp, sz, sz, sz, vp, vp]),
+    "mse_topk_block_bytes": (sz, [sz, sz]),
+    "mse_merge_topk_packed_dev": (C.c_int, [vp, vp, sz, sz, sz, vp, vp]),
+    "mse_base_rows_changed": (C.c_int, [vp]),
+    "mse_shard_group_new": (vp, [C.POINTER(C.c_int), sz, sz]),
+    "mse_shard_group_free": (None, [vp]),
+    "mse_shard_group_n_shards": (sz, [vp]),
+    "mse_shard_group_len": (sz, [vp]),
+    "mse_shard_group_device": (C.c_int, [vp, sz]),
+    "mse_shard_group_peer_mapped": (C.c_int, [vp, sz]),
+    "mse_shard_group_searcher": (vp, [vp, sz]),
+    "mse_shard_group_generate": (C.c_int, [vp, C.c_uint32, C.c_uint64, sz]),
+    "mse_shard_group_load_host": (C.c_int, [vp, u16p, sz]),
+    "mse_shard_group_set_shard_device": (C.c_int, [vp, sz, vp, sz, C.c_uint64]),
+    "mse_shard_group_search": (C.c_int, [vp, u16p, sz, sz, C.c_int, i64p, u32p]),
+    "mse_shard_group_search_dev": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, vp]),
+    "mse_comm_unique_id": (C.c_int, [vp]),
+    "mse_comm_init": (vp, [vp, C.c_int, C.c_int]),
+    "mse_comm_free": (None, [vp]),
+    "mse_comm_rank": (C.c_int, [vp]),
+    "mse_comm_size": (C.c_int, [vp]),
+    "mse_comm_search_dev": (C.c_int, [vp, vp, vp, sz, sz, C.c_int, C.c_uint64, vp, vp]),
     "mse_searcher_scan_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mse_searcher_last_stats": (C.c_int, [vp, u32p, u32p]),
     "mse_index_new": (vp, [C.c_int]),

@@ -6,10 +6,137 @@ returns ids offset to global ids, and ONE all-gather of the per-shard top-k reco
 ([nq, k] i64 scores + u32 ids, a few KiB) over RCCL/xGMI followed by a k-way merge gives the
 global result.  No other collective exists on this path.
 
-torch.distributed is plumbing here (process group + all_gather); the merge of the gathered
-records runs in the HIP selection kernel when the tensors are on the device.
+The exchange lives behind the C ABI (csrc/shard_group.hip), no torch involved:
+  ShardGroup  one process, a host thread per shard, records written into the root device's gather
+              buffer over peer mappings (mse_shard_group_*); shards may share a device.
+  Comm        one process per GPU: one ncclAllGather of the packed records through librccl.so on the
+              searcher's stream + merge (mse_comm_*); the 128-byte id reaches the ranks through
+              whatever rendezvous the host has (bench.py: a gloo broadcast).
+merge_topk_numpy / merge_topk_torch / all_gather_topk are the host-side restatement of the merge
+rule, used by the CPU (gloo) tests of the plumbing.
 """
+import ctypes as C
+
 import numpy as np
+
+from . import ffi
+from .ffi import check, check_ptr
+from .vector import MODE_AUTO, Searcher, _bits, _p
+
+
+class _BorrowedSearcher(Searcher):
+    """A shard's searcher, owned by its ShardGroup (timing / certificate statistics only)."""
+
+    def __init__(self, handle):   # noqa: D401 -- no mse_searcher_new: the group made it
+        self.vecs = None
+        self._h = handle
+
+    def close(self):
+        self._h = None
+
+
+class ShardGroup:
+    """Row-sharded index driven by one process: mse_shard_group (include/mse.h)."""
+
+    def __init__(self, n_shards, d=1152, devices=None):
+        dev = None
+        if devices is not None:
+            if len(devices) != n_shards:
+                raise ValueError("one device ordinal per shard")
+            dev = (C.c_int * n_shards)(*[int(x) for x in devices])
+        self.d = d
+        self._h = check_ptr(ffi.lib().mse_shard_group_new(dev, n_shards, d), "mse_shard_group_new")
+
+    @property
+    def n_shards(self):
+        return int(ffi.lib().mse_shard_group_n_shards(self._h))
+
+    def __len__(self):
+        return int(ffi.lib().mse_shard_group_len(self._h))
+
+    def device(self, shard):
+        return int(ffi.lib().mse_shard_group_device(self._h, shard))
+
+    def peer_mapped(self, shard):
+        return bool(ffi.lib().mse_shard_group_peer_mapped(self._h, shard))
+
+    def searcher(self, shard):
+        return _BorrowedSearcher(check_ptr(ffi.lib().mse_shard_group_searcher(self._h, shard), "mse_shard_group_searcher"))
+
+    def generate(self, seed, first_row, total_rows):
+        check(ffi.lib().mse_shard_group_generate(self._h, seed, first_row, total_rows), "mse_shard_group_generate")
+
+    def load_host(self, f16s):
+        a = _bits(f16s).reshape(-1, self.d)
+        check(ffi.lib().mse_shard_group_load_host(self._h, _p(a, C.c_uint16), a.shape[0]), "mse_shard_group_load_host")
+
+    def set_shard_device(self, shard, rows_dev, n_rows, first_row):
+        check(ffi.lib().mse_shard_group_set_shard_device(self._h, shard, rows_dev, n_rows, first_row), "mse_shard_group_set_shard_device")
+
+    def bruteforce_topk(self, queries, k, mode=MODE_AUTO):
+        """Same contract as Searcher.bruteforce_topk over the whole (sharded) index; ids are global."""
+        q = _bits(queries).reshape(-1, self.d)
+        nq = q.shape[0]
+        scores = np.empty((nq, k), np.int64)
+        ids = np.empty((nq, k), np.uint32)
+        check(ffi.lib().mse_shard_group_search(self._h, _p(q, C.c_uint16), nq, k, mode, _p(scores, C.c_int64), _p(ids, C.c_uint32)),
+              "mse_shard_group_search")
+        return scores, ids
+
+    def bruteforce_topk_dev(self, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO):
+        check(ffi.lib().mse_shard_group_search_dev(self._h, queries_dev, nq, k, mode, scores_dev, ids_dev), "mse_shard_group_search_dev")
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_shard_group_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """One rank of the one-process-per-GPU layout: mse_comm (RCCL all-gather of packed top-k records + merge)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(ffi.lib().mse_comm_unique_id(buf), "mse_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world):
+        if len(unique_id) != Comm.ID_BYTES:
+            raise ValueError("the communicator id is 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), Comm.ID_BYTES)
+        self._h = check_ptr(ffi.lib().mse_comm_init(buf, rank, world), "mse_comm_init")
+
+    @property
+    def rank(self):
+        return int(ffi.lib().mse_comm_rank(self._h))
+
+    @property
+    def size(self):
+        return int(ffi.lib().mse_comm_size(self._h))
+
+    def search_dev(self, searcher, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO, id_offset=0):
+        check(ffi.lib().mse_comm_search_dev(self._h, searcher._h, queries_dev, nq, k, mode, id_offset, scores_dev, ids_dev),
+              "mse_comm_search_dev")
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_range(n_rows, rank, world):

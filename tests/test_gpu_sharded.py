@@ -1,0 +1,200 @@
+"""The row-sharded search (BASELINE configs[3]) through its C-ABI entry points, against the ORACLE:
+mse_shard_group (one process, a host thread per shard; logical shards share the one device of the test box),
+mse_comm (RCCL all-gather; world of one here: the collective call path and the packed-block merge),
+the threading contract of the ABI (include/mse.h: shared read-only base, one searcher per thread, thread-local errors)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import SEED_BASE, SEED_QUERY
+
+pytestmark = pytest.mark.gpu
+D = 1152
+
+
+@pytest.mark.parametrize("n,G,nq,k", [(40_003, 8, 24, 10), (20_000, 3, 140, 10), (5, 8, 3, 4), (4096, 2, 9, 70)])
+def test_shard_group_logical_shards_match_oracle(gpu, mse, orc, n, G, nq, k):
+    base = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    want_s, want_i = orc.bruteforce_topk(base, q, k)
+    grp = mse.ShardGroup(G, D, devices=[0] * G)
+    assert grp.n_shards == G and all(grp.device(g) == 0 and grp.peer_mapped(g) for g in range(G))
+    grp.generate(SEED_BASE, 0, n)                      # every shard makes its own rows [lo, hi) on the device
+    assert len(grp) == n
+    for mode in (mse.MODE_MFMA, mse.MODE_EXACT):
+        s, i = grp.bruteforce_topk(q, k, mode)
+        assert np.array_equal(i, want_i) and np.array_equal(s, want_s), mode
+    grp.load_host(base)                                # the same rows handed over as one host array
+    s, i = grp.bruteforce_topk(q, k)
+    assert np.array_equal(i, want_i) and np.array_equal(s, want_s)
+    grp.close()
+
+
+def test_shard_group_ties_across_shards_break_by_lower_global_id(gpu, mse, orc):
+    # the same row in every shard: equal scores in different shards must come back in ascending global id
+    row = orc.gen_rows_f16(SEED_BASE, 7, 1)
+    base = np.repeat(row, 64, axis=0)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, 2)
+    grp = mse.ShardGroup(4, D, devices=[0] * 4)
+    grp.load_host(base)
+    s, i = grp.bruteforce_topk(q, 10, mse.MODE_MFMA)
+    assert i.tolist() == [list(range(10))] * 2
+    ws, wi = orc.bruteforce_topk(base, q, 10)
+    assert np.array_equal(s, ws) and np.array_equal(i, wi)
+    grp.close()
+
+
+def test_shard_group_errors(gpu, mse):
+    with pytest.raises(mse.MseError):
+        mse.ShardGroup(2, D, devices=[0, 99])
+    with pytest.raises(mse.MseError):
+        mse.ShardGroup(2, 100)
+    grp = mse.ShardGroup(2, D, devices=[0, 0])
+    with pytest.raises(mse.MseError, match="holds no rows"):
+        grp.bruteforce_topk(np.zeros((1, D), np.uint16), 3)
+    grp.close()
+
+
+def test_rccl_comm_world_of_one(gpu, mse, orc):
+    """mse_comm on the one GPU of the test box: ncclGetUniqueId / ncclCommInitRank / ncclAllGather really run (RCCL reports
+    its own rank count), and the packed-block merge returns the oracle's answer.  More ranks need more GPUs (bench.py --gpus N)."""
+    import torch
+    n, nq, k = 30_000, 20, 10
+    base = orc.gen_rows_f16(SEED_BASE, 1000, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    ws, wi = orc.bruteforce_topk(base, q, k)
+    comm = mse.Comm(mse.Comm.unique_id(), 0, 1)
+    assert comm.size == 1 and comm.rank == 0
+    sr = mse.Searcher(mse.VectorList.generate(SEED_BASE, 1000, n))
+    qd = torch.from_numpy(q.view(np.int16)).cuda()
+    out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    comm.search_dev(sr, qd.data_ptr(), nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=5000)
+    torch.cuda.synchronize()
+    assert np.array_equal(out_s.cpu().numpy(), ws)
+    assert np.array_equal(out_i.cpu().numpy().view(np.uint32), wi + np.uint32(5000))
+    comm.close()
+
+
+def test_packed_merge_of_eight_blocks_matches_host_merge(gpu, mse, orc):
+    """What eight ranks' all-gather would deliver: eight packed blocks, merged on the device, against the numpy merge."""
+    import ctypes as C
+    import torch
+    from mse import ffi, shard
+    G, nq, k = 8, 33, 10
+    rng = np.random.default_rng(5)
+    B = int(ffi.lib().mse_topk_block_bytes(nq, k))
+    assert B % 16 == 0 and B >= nq * k * 12
+    blocks = np.zeros((G, B), np.uint8)
+    sc = rng.integers(-2 ** 40, 2 ** 40, size=(G, nq, k)).astype(np.int64)
+    sc[:, :, ::3] = 12345                                  # plenty of equal scores across shards
+    ids = rng.permutation(G * nq * k).astype(np.uint32).reshape(G, nq, k)
+    ids[3, :, 5:] = 0xFFFFFFFF                             # a shard with fewer than k rows
+    for g in range(G):
+        blocks[g, :nq * k * 8] = sc[g].view(np.uint8).reshape(-1)
+        blocks[g, nq * k * 8:nq * k * 12] = ids[g].view(np.uint8).reshape(-1)
+    want_s, want_i = shard.merge_topk_numpy(sc.transpose(1, 0, 2).reshape(nq, G * k), ids.transpose(1, 0, 2).reshape(nq, G * k), k)
+    sr = mse.Searcher(mse.VectorList.generate(SEED_BASE, 0, 64))
+    bd = torch.from_numpy(blocks).cuda()
+    out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ffi.check(ffi.lib().mse_merge_topk_packed_dev(sr._h, bd.data_ptr(), G, nq, k, out_s.data_ptr(), out_i.data_ptr()))
+    ffi.check(ffi.lib().mse_device_synchronize())
+    assert np.array_equal(out_s.cpu().numpy(), want_s)
+    assert np.array_equal(out_i.cpu().numpy().view(np.uint32), want_i)
+
+
+def test_concurrent_searchers_share_one_base(gpu, mse, orc):
+    """include/mse.h threading contract (the reference: a thread per core, each with its own Scratch over shared Arc maps,
+    src/query_disk_index.rs:714-731): two threads, two searchers, ONE base, different queries, at the same time."""
+    n, nq, k = 60_000, 40, 10
+    vl = mse.VectorList.generate(SEED_BASE, 0, n)
+    base = orc.gen_rows_f16(SEED_BASE, 0, n)
+    qs = [orc.gen_rows_f16(SEED_QUERY, 100 * t, nq) for t in range(2)]
+    want = [orc.bruteforce_topk(base, q, k) for q in qs]
+    got, errs = [None, None], []
+    start = threading.Barrier(2)
+
+    def work(t):
+        try:
+            s = mse.Searcher(vl)
+            start.wait()
+            for rep in range(6):
+                mode = mse.MODE_MFMA if (rep + t) % 2 else mse.MODE_EXACT
+                r = s.bruteforce_topk(qs[t][:8] if mode == mse.MODE_EXACT else qs[t], k, mode)
+                m = 8 if mode == mse.MODE_EXACT else nq
+                if not (np.array_equal(r[0], want[t][0][:m]) and np.array_equal(r[1], want[t][1][:m])):
+                    errs.append((t, rep, mode))
+            got[t] = s.bruteforce_topk(qs[t], k, mse.MODE_MFMA)
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for t in range(2):
+        assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1])
+
+
+def test_last_error_is_thread_local(gpu, mse):
+    from mse import ffi
+    L = ffi.lib()
+    seen = {}
+
+    def bad():
+        assert L.mse_base_wrap_device(None, 10, 100) is None      # width not a multiple of 64 -> error on THIS thread
+        seen["bad"] = ffi.last_error()
+
+    t = threading.Thread(target=bad)
+    assert L.mse_scale_dot_f32(1.0) == 2 ** 32
+    before = ffi.last_error()
+    t.start()
+    t.join()
+    assert "multiple of 64" in seen["bad"]
+    assert ffi.last_error() == before                                # the failing thread's message did not leak here
+
+
+def test_config4_full_size_1e8_eight_shards(gpu, mse, orc):
+    """BASELINE configs[3]: the 1e8 x 1152 index sharded 8 ways (12.5 M rows = 28.8 GB per shard), here as eight logical shards
+    on the one device (230 GB resident), through mse_shard_group.  The oracle cannot scan 1e8 rows in a test, so:
+    size-independent properties, with every returned score re-derived by the oracle from regenerated rows."""
+    from mse import ffi
+    free_b, total_b = ffi.sz(), ffi.sz()
+    ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
+    n, G, nq, k = 100_000_000, 8, 136, 10
+    if free_b.value < n * D * 2 + (24 << 30):
+        pytest.skip(f"needs {n * D * 2 / 1e9:.0f} GB of free HBM, {free_b.value / 1e9:.0f} GB free")
+    grp = mse.ShardGroup(G, D, devices=[0] * G)
+    grp.generate(SEED_BASE, 0, n)
+    assert len(grp) == n
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    # planted winners: copies of rows at shard seams and deep inside shards (global ids carry the shard offset)
+    planted = [0, 12_499_999, 12_500_000, 99_999_999, 87_654_321, 50_000_000]
+    for j, r in enumerate(planted):
+        q[j] = orc.gen_rows_f16(SEED_BASE, r, 1)[0]
+    sm, im = grp.bruteforce_topk(q, k, mse.MODE_MFMA)
+    se, ie = grp.bruteforce_topk(q[:8], k, mse.MODE_EXACT)
+    assert np.array_equal(im[:8], ie) and np.array_equal(sm[:8], se)            # two independent kernels agree, merged
+    assert [int(im[j, 0]) for j in range(len(planted))] == planted              # a row is its own best match
+    assert np.all(sm[:, :-1] >= sm[:, 1:])                                      # sorted
+    assert np.all(im < n) and all(len(set(r)) == k for r in im.tolist())        # valid, distinct global ids
+    assert len({int(x) // 12_500_000 for x in im.reshape(-1)}) == G             # winners come from every shard
+    for qi in (0, 5, 77, 135):                                                  # returned scores are the oracle's
+        for j in (0, 3, 9):
+            row = orc.gen_rows_f16(SEED_BASE, int(im[qi, j]), 1)[0]
+            assert orc.fast_dot(q[qi], row) == int(sm[qi, j])
+    rng = np.random.default_rng(3)                                              # the k-th score bounds sampled outsiders
+    sample = rng.integers(0, n, 400)
+    rows = np.stack([orc.gen_rows_f16(SEED_BASE, int(r), 1)[0] for r in sample])
+    for qi in (5, 77):
+        sc = orc.score_all(rows, q[qi])
+        assert np.all(sc[~np.isin(sample, im[qi])] <= sm[qi, -1])
+    sm2, im2 = grp.bruteforce_topk(q, k, mse.MODE_MFMA)                          # idempotence
+    assert np.array_equal(sm, sm2) and np.array_equal(im, im2)
+    assert all(grp.searcher(g).last_stats()["widened_queries"] == 0 for g in range(G))
+    grp.close()
