@@ -142,8 +142,7 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
     const mse_base* b = s->base;
     hipStream_t st = s->stream;
     const int d = (int)b->d;
-    const int tile = mfma_query_tile();
-    const int nq_pad = tile;
+    const int nq_pad = nq_pass > 128 ? 256 : 128;   // one pass over the rows serves up to 256 queries
     if (ensure_base_norm(b, st)) return -1;
     // padded query tile
     if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;

@@ -8,9 +8,11 @@
 // candidate groups can belong to the exact top-k; otherwise the caller widens the candidate set.
 //
 // Kernel: C[row, query] = sum_k X[row,k] * Q[query,k] with v_mfma_f32_16x16x32_f16, 8 waves per workgroup,
-// one workgroup per CU (128 KiB of LDS), persistent grid-stride over 256-row tiles.
-//   - a wave owns 32 base rows (two 16-row MFMA tiles, A operand) x 128 queries (eight 16-query column
-//     tiles, B operand; each B fragment read from LDS feeds two MFMAs).
+// one workgroup per CU (128 / 160 KiB of LDS), persistent grid-stride over 256-row tiles.  BN = queries per
+// pass over the rows: 128, or 256 (round 2: the same HBM stream serves twice the queries; the matrix cores go
+// from ~35 % to ~70 % busy, which is what the HBM-bound 128-query pass left idle).
+//   - a wave owns 32 base rows (two 16-row MFMA tiles, A operand) x BN queries (BN/16 16-query column
+//     tiles, B operand; each B fragment read from LDS feeds two MFMAs; 64 or 128 accumulator registers).
 //   - base rows are streamed HBM -> LDS by the DMA path (global_load_lds, no VGPR staging).  Each wave DMAs
 //     exactly the 32 rows x 128 B it will consume into its OWN ring of S stages (4 KiB each), so the
 //     streamed operand needs no barrier: an LDS-DMA is ordered for a ds_read only by the issuing wave's
@@ -19,9 +21,9 @@
 //     lane-linear, so the bank-conflict swizzle is applied to the SOURCE address: LDS slot (row, s) holds
 //     global 16-byte piece s ^ f(row), f(row) = (row >> 1) & 7, and the A-fragment ds_read_b128 applies the
 //     same involution (measured SQ_LDS_BANK_CONFLICT = 0).
-//   - queries are re-tiled once per search into K-block-major, identically swizzled 16 KiB tiles
-//     (pack_queries_kernel); a tile is DMA'd linearly into a double buffer (2 instructions per wave), one
-//     barrier per 64-element K block.  The tile is shared by 256 rows, so L2->LDS query traffic is half the
+//   - queries are re-tiled once per search into K-block-major, identically swizzled BN x 128 B tiles
+//     (pack_queries_kernel); a tile is DMA'd linearly into a double buffer (BN/64 instructions per wave), one
+//     barrier per 64-element K block.  The tile is shared by 256 rows, so L2->LDS query traffic is BN/256 of the
 //     HBM traffic (it competes with the HBM stream for the CU's outstanding-miss slots).
 //   - epilogue per 32-row group: max over the rows of each query column -> group_max[group][q]
 //     (the level-0 array of the selection tournament).  4 bytes written per 32*2304 bytes read.
@@ -34,6 +36,19 @@
 // 4.4-4.7 TB/s at 4 waves, 5.0-5.2 TB/s at 8 waves per workgroup; non-temporal loads on partial lines: -25 %;
 // this DMA variant: 5.3-5.6 TB/s.  Ordinary (compiler-scheduled) loads are sunk next to their first use by
 // hipcc, which leaves them no flight time; hence hand-issued DMA + counted waits.
+//
+// Round 2, the 256-query pass (1e7 x 1152, random rows, scan kernel alone; scripts/scan_ablate.py, MSE_SCAN_ABL):
+//   128 queries 3.95-4.1 ms (HBM-bound, 5.6-5.8 TB/s) | 256 queries 5.65-5.75 ms = 4.0 TB/s, 1.04 PFLOP/s: +40 % queries/s.
+//   Ablations of the 256-query kernel: MFMAs only 3.6 ms | X DMA only 3.9 | query-tile DMA only 0.83 | everything but the
+//   MFMAs 4.1 | everything but the X DMA 4.5.  The parts do not hide behind each other the way the instruction counts
+//   suggest, and re-timing them does not help: DMA pieces in one burst 5.90, one piece between MFMA groups (kept) 5.72,
+//   bursts of the two waves of a SIMD half an iteration apart 6.30, a two-group ping-pong kernel (one wave per SIMD on the
+//   matrix core while the other issues pieces, two barriers per K block) 6.06, nt loads for the rows: no change.  In-kernel
+//   s_memtime stamps put the clock at 1.64 GHz under this load (2176 of 3400 cycles per K block are matrix-core cycles),
+//   and the same kernel on all-zero rows -- same traffic, no operand toggling -- runs in 4.7 ms (MFMAs only: 3.0 ms):
+//   the pass is bound by the chip's power budget (DVFS), not by a schedule.  LDS-DMA issue is not the limit either
+//   (scripts/microbench/dma_rate.hip: 137 GB/s per CU from L2 with >= 4 waves, 7.5 ns per 1 KiB piece).  What would lower
+//   the energy per row: wave tiles of 64 rows x 128 queries (a third fewer B-fragment LDS reads), not tried.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -45,17 +60,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128;           // queries per pass
 constexpr int KB = 64;            // contraction elements per K block
-constexpr int QT_SLOTS = BN * 8;  // 16-byte slots per query tile (16 KiB)
-constexpr int QT_BYTES = QT_SLOTS * 16;
 constexpr int W = 8;              // waves per workgroup
 constexpr int TILE_ROWS = 32 * W;
-constexpr int QI = QT_SLOTS / (W * 64);  // DMA instructions per wave per query tile (2)
 
-// packed[kb][q][slot ^ ((q>>1)&7)] = 16-byte slot `slot` of K block kb of query q
-__global__ void pack_queries_kernel(const uint16_t* __restrict__ queries, int d, uint4* __restrict__ packed) {
+// packed[kb][q][slot ^ ((q>>1)&7)] = 16-byte slot `slot` of K block kb of query q   (bn queries per tile)
+__global__ void pack_queries_kernel(const uint16_t* __restrict__ queries, int d, int bn, uint4* __restrict__ packed) {
     const int nkb = d / KB;
+    const int QT_SLOTS = bn * 8;
     const int total = nkb * QT_SLOTS;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int kb = idx / QT_SLOTS;
@@ -82,10 +94,17 @@ __device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
 
 // S = stages in each wave's ring of X K-blocks (S-1 blocks in flight beyond the one being consumed);
 // nkb must be a multiple of S so that stage indices are compile-time constants.
-template <int S>
+// NCT = 16-query column tiles per pass (8: 128 queries, 16: 256 queries)
+// ABL (developer ablations, MSE_SCAN_ABL; results are then meaningless, only the timing is of interest):
+// bit 0 no MFMAs, bit 1 no query-tile DMA, bit 2 no X DMA, bit 3 no B-fragment LDS reads
+template <int S, int NCT, int ABL = 0>
 __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
                                                            const uint4* __restrict__ packed_ro,
                                                            float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
+    constexpr int BN = NCT * 16;
+    constexpr int QT_BYTES = BN * 128;       // one query tile: BN x 64 f16
+    constexpr int QI = BN / 64;              // DMA instructions per wave per query tile
+    constexpr bool ILV = S >= 2 && !(ABL & 16);   // DMA pieces interleaved with the MFMA groups (ABL bit 4: burst, as in round 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];  // ALL LDS in one object (5.x trap (a))
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -94,7 +113,7 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
     const size_t row_bytes = (size_t)d * 2;
     const int swz = (i >> 1) & 7;
     const size_t n_groups = (n_rows + 31) / 32;
-    char* const qbase = smem;                                     // [2][16 KiB] query tiles
+    char* const qbase = smem;                                     // [2][BN x 128 B] query tiles
     char* const xbase = smem + 2 * QT_BYTES + wave * (S * 4096);  // this wave's ring: S stages x 4 KiB
     const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)(wave * QI * 64 + lane) * 16;
 
@@ -112,12 +131,14 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
     };
     auto dma_x = [&](const char* (&rp)[4], int kblock, int stage) {
         char* dst = xbase + stage * 4096;
+        if (ABL & 4) return;
 #pragma unroll
         for (int u = 0; u < 4; u++) dma16(rp[u] + (size_t)kblock * 128, dst + u * 1024);
     };
     auto dma_q = [&](int kblock, int qb) {
         const char* src = packed + (size_t)kblock * QT_BYTES;
         char* dst = qbase + qb * QT_BYTES + wave * (QI * 1024);
+        if (ABL & 2) return;
 #pragma unroll
         for (int u = 0; u < QI; u++) dma16(src + u * 1024, dst + u * 1024);
     };
@@ -135,11 +156,11 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
 
     int buf = 0;
     while (true) {
-        float4v acc[2][8];
+        float4v acc[2][NCT];
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-            for (int ct = 0; ct < 8; ct++)
+            for (int ct = 0; ct < NCT; ct++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[rt][ct][r] = 0.0f;
 
@@ -152,16 +173,32 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
 #pragma unroll
             for (int j = 0; j < S; j++) {
                 const int kb = kb0 + j;
-                // ---- issue, always in this order: next query tile (QI), then the X block S-1 steps ahead (4)
-                dma_q(kb + 1 == nkb ? 0 : kb + 1, buf ^ 1);
-                {
-                    const int kf = kb + S - 1;
-                    if (kf >= nkb) dma_x(rn, kf - nkb, (j + S - 1) % S);  // first blocks of the next tile
-                    else dma_x(rp, kf, (j + S - 1) % S);
+                // ---- DMA pieces of this iteration, always in this order: next query tile (QI), then the X block S-1 steps
+                // ahead (4).  ILV: one piece at a time BETWEEN the MFMA groups below -- a burst of QI + 4 pieces at the top
+                // costs each wave 100-185 cycles of issue per piece while both waves of the SIMD sit in the same phase and
+                // the matrix core idles (measured: 256-query pass 5.94 ms burst vs MFMA-only 3.63 / DMA-only 4.58 at 1e7 rows).
+                const int kq = kb + 1 == nkb ? 0 : kb + 1;
+                const int kf = kb + S - 1;
+                const bool x_next = kf >= nkb;                                 // first blocks of the next tile
+                const size_t xoff = (size_t)(kf >= nkb ? kf - nkb : kf) * 128;
+                char* const xdst = xbase + ((j + S - 1) % S) * 4096;
+                const char* const qsrc = packed + (size_t)kq * QT_BYTES;
+                char* const qdst = qbase + (buf ^ 1) * QT_BYTES + wave * (QI * 1024);
+                auto issue_piece = [&](int p) {
+                    if (p < QI) { if (!(ABL & 2)) dma16(qsrc + p * 1024, qdst + p * 1024); }
+                    else if (!(ABL & 4)) dma16((x_next ? rn[p - QI] : rp[p - QI]) + xoff, xdst + (p - QI) * 1024);
+                };
+                if (!ILV) {
+#pragma unroll
+                    for (int p = 0; p < QI + 4; p++) issue_piece(p);
+                    // the X block consumed now was issued S-1 iterations ago: everything issued after it may fly on.
+                    // (DMAs return in order; the epilogue's stores share the counter and only make a wait stricter.)
+                    vm_wait<(QI + 4) * (S - 1)>();
+                } else if (S == 2) {
+                    vm_wait<0>();   // the block consumed now was the last thing issued in the previous iteration
                 }
-                // the X block consumed now was issued S-1 iterations ago: everything issued after it may fly on.
-                // (DMAs return in order; the epilogue's stores share the counter and only make a wait stricter.)
-                vm_wait<(QI + 4) * (S - 1)>();
+                // ILV, S >= 3: the block consumed now was issued BEFORE the query pieces the previous iteration's closing
+                // wait already covered, so it has landed.
 
                 const u32x4* xs = reinterpret_cast<const u32x4*>(xbase + j * 4096) + i * 8;
                 const u32x4* qt = reinterpret_cast<const u32x4*>(qbase + buf * QT_BYTES) + i * 8;
@@ -172,23 +209,41 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
                 bq[0][1] = qt[1 * 128 + slot_a];
                 const half8 a00 = as_half8(xs[slot_a]), a10 = as_half8(xs[128 + slot_a]);  // row tile 0 / 1, k step 0
                 const half8 a01 = as_half8(xs[slot_b]), a11 = as_half8(xs[128 + slot_b]);  // k step 1
+                constexpr int NCP = NCT / 2;   // column-tile pairs per k step
 #pragma unroll
-                for (int t = 0; t < 8; t++) {  // t = ks*4 + column-tile pair
-                    const int ks = t >> 2, cp = t & 3;
-                    if (t + 1 < 8) {
-                        const int ks2 = (t + 1) >> 2, cp2 = (t + 1) & 3;
-                        bq[(t + 1) & 1][0] = qt[(cp2 * 2) * 128 + (ks2 ? slot_b : slot_a)];
-                        bq[(t + 1) & 1][1] = qt[(cp2 * 2 + 1) * 128 + (ks2 ? slot_b : slot_a)];
+                for (int t = 0; t < 2 * NCP; t++) {  // t = ks*NCP + column-tile pair
+                    const int ks = t / NCP, cp = t % NCP;
+                    if (t + 1 < 2 * NCP) {
+                        const int ks2 = (t + 1) / NCP, cp2 = (t + 1) % NCP;
+                        if (!(ABL & 8)) {
+                            bq[(t + 1) & 1][0] = qt[(cp2 * 2) * 128 + (ks2 ? slot_b : slot_a)];
+                            bq[(t + 1) & 1][1] = qt[(cp2 * 2 + 1) * 128 + (ks2 ? slot_b : slot_a)];
+                        } else {
+                            bq[(t + 1) & 1][0] = bq[t & 1][1];
+                            bq[(t + 1) & 1][1] = bq[t & 1][0];
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the reads for t+1 ahead of the MFMAs of t
+                    if (ILV) {
+                        // pieces spread evenly over the 2*NCP MFMA groups: piece p goes before group 1 + p*STEP
+                        constexpr int STEP = (2 * NCP) / (QI + 4);
+                        if (t >= 1 && (t - 1) % STEP == 0 && (t - 1) / STEP < QI + 4) {
+                            issue_piece((t - 1) / STEP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                     const half8 a0 = ks ? a01 : a00;
                     const half8 a1 = ks ? a11 : a10;
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const half8 b = as_half8(bq[t & 1][e]);
                         const int ct = cp * 2 + e;
-                        acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, acc[0][ct], 0, 0, 0);
-                        acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc[1][ct], 0, 0, 0);
+                        if (!(ABL & 1)) {
+                            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, acc[0][ct], 0, 0, 0);
+                            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc[1][ct], 0, 0, 0);
+                        } else {
+                            asm volatile("" ::"v"(b), "v"(a0), "v"(a1));
+                        }
                     }
                 }
                 // next query tile: this wave's share has landed once only the 4 X DMAs issued after it remain;
@@ -203,7 +258,7 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
         // epilogue: per query column, max over this wave's 32 rows (2 row tiles x 4 accumulator rows x 4 lane groups)
         const size_t group = tile * W + wave;
 #pragma unroll
-        for (int ct = 0; ct < 8; ct++) {
+        for (int ct = 0; ct < NCT; ct++) {
             float m = fmaxf(fmaxf(acc[0][ct][0], acc[0][ct][1]), fmaxf(acc[0][ct][2], acc[0][ct][3]));
             m = fmaxf(m, fmaxf(fmaxf(acc[1][ct][0], acc[1][ct][1]), fmaxf(acc[1][ct][2], acc[1][ct][3])));
             m = fmaxf(m, __shfl_xor(m, 16));
@@ -219,21 +274,21 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
     vm_wait<0>();  // nothing may still be writing this workgroup's LDS when it is released
 }
 
-template <int S>
+template <int S, int NCT, int ABL = 0>
 int launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
                    float* group_max, int nq_pad) {
     const size_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     if (grid > n_tiles) grid = n_tiles;
-    const size_t lds = 2 * QT_BYTES + (size_t)W * S * 4096;  // 128 KiB at S = 3
+    const size_t lds = 2 * (size_t)(NCT * 16 * 128) + (size_t)W * S * 4096;  // S = 3: 128 KiB at 128 queries, 160 KiB at 256
     int dev = 0;
     MSE_HIP_TRY(hipGetDevice(&dev));
     static bool attr_set[64] = {};
     if (dev < 64 && !attr_set[dev]) {
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_mfma_kernel<S>),
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_mfma_kernel<S, NCT, ABL>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((scan_mfma_kernel<S>), dim3((unsigned)grid), dim3(W * 64), lds, stream, base, n_rows, d, packed,
+    hipLaunchKernelGGL((scan_mfma_kernel<S, NCT, ABL>), dim3((unsigned)grid), dim3(W * 64), lds, stream, base, n_rows, d, packed,
                        group_max, nq_pad, n_tiles);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
@@ -241,9 +296,9 @@ int launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t
 
 }  // namespace
 
-int mfma_query_tile() { return BN; }
+int mfma_query_tile() { return 256; }   // largest pass; passes of <= 128 queries use the 128-query kernel
 
-size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * QT_BYTES; }
+size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * 256 * 128; }
 
 // packed_scratch: mfma_packed_bytes(d) bytes of device scratch owned by the caller (per searcher)
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
@@ -251,9 +306,9 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
                      hipEvent_t ev_end) {
     if (n_rows == 0) return 0;
     if (d % 64 != 0 || d <= 0 || d > D_MAX) return fail("vector width must be a positive multiple of 64");
-    if (nq_pad != BN) return fail("scan_mfma: query tile must be padded to 128");
+    if (nq_pad != 128 && nq_pad != 256) return fail("scan_mfma: query tile must be padded to 128 or 256");
     uint4* packed = reinterpret_cast<uint4*>(packed_scratch);
-    hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, packed);
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, nq_pad, packed);
     if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
     const int nkb = d / KB;
     // developer knob: ring depth (default 3 when the K-block count allows it)
@@ -262,9 +317,32 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     if (env_s >= 1 && env_s <= 3 && nkb % env_s == 0) S = env_s;
     const size_t grid = (size_t)n_cu;  // one 128-KiB workgroup per CU
     int rc;
-    if (S == 3) rc = launch_variant<3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else if (S == 2) rc = launch_variant<2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else rc = launch_variant<1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    if (nq_pad == 128 && S == 3 && getenv("MSE_SCAN_ABL") && atoi(getenv("MSE_SCAN_ABL")) == 16) {
+        rc = launch_variant<3, 8, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    } else if (nq_pad == 128) {
+        if (S == 3) rc = launch_variant<3, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else if (S == 2) rc = launch_variant<2, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else rc = launch_variant<1, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    } else if (const char* ea = (S == 3 ? getenv("MSE_SCAN_ABL") : nullptr)) {
+        switch (atoi(ea)) {
+            case 1: rc = launch_variant<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 2: rc = launch_variant<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 4: rc = launch_variant<3, 16, 4>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 6: rc = launch_variant<3, 16, 6>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 8: rc = launch_variant<3, 16, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 9: rc = launch_variant<3, 16, 9>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 11: rc = launch_variant<3, 16, 11>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 13: rc = launch_variant<3, 16, 13>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 14: rc = launch_variant<3, 16, 14>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 16: rc = launch_variant<3, 16, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 17: rc = launch_variant<3, 16, 17>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            default: rc = launch_variant<3, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+        }
+    } else {
+        if (S == 3) rc = launch_variant<3, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else if (S == 2) rc = launch_variant<2, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else rc = launch_variant<1, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    }
     if (rc) return rc;
     if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));
     return 0;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmse_hip.so")
+# MSE_HIP_LIB: developer override (A/B builds of the same library); the default is the in-tree build
+LIB_PATH = os.environ.get("MSE_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmse_hip.so")
 
 
 class MseError(RuntimeError):
