@@ -195,6 +195,11 @@ int mse_pq_adc_gather(mse_pq* pq, const mse_codes* c, const float* lut, const fl
  * f16 query, final top-k (BASELINE config 5).  base may be NULL: then scores are the ADC scores. */
 int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,
                      const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
+/* The same for nq queries ([nq][n_dims] f32) back to back on one stream with one upload and one download;
+ * scores / ids are [nq][k].  The scan keeps one maximum per 64 vectors instead of a score per vector; the r best
+ * vectors are then found inside the r best groups (exact, ties by lower id). */
+int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
+                           const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
 /* descriptor_product (src/query_disk_index.rs:135-142) for one id, host-side helper. */
 int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id);
 

@@ -73,15 +73,20 @@ int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_o
         lv.push_back(LevelRef{k64 ? KEY_U64 : KEY_U32, s->levels[li].p, n_out, 1, n_out, false, 0});
         li++;
     }
-    if (s->sel_a.ensure((size_t)nq * k * 4) || s->sel_b.ensure((size_t)nq * k * 4)) return -1;
+    if (s->sel_a.ensure((size_t)nq * k * 4) || s->sel_b.ensure((size_t)nq * k * 4) || s->thr.ensure((size_t)nq * 16)) return -1;
     uint32_t* cur_sel = s->sel_a.as<uint32_t>();
     uint32_t* nxt_sel = s->sel_b.as<uint32_t>();
+    // each level hands the score key of its k-th best entry down as a floor: every one of the k best parents has a child with
+    // exactly its key, so at least k children reach the floor and everything below it can be skipped unread by the radix passes
+    unsigned long long* kth_cur = s->thr.as<unsigned long long>();
+    unsigned long long* kth_nxt = kth_cur + nq;
     const int top = (int)lv.size() - 1;
     {
         SelectArgs a{};
         const LevelRef& L = lv[top];
         a.kind = L.kind; a.in = L.ptr; a.in_stride = L.q_stride; a.n_in = L.n;
         a.k = k; a.out_ids = cur_sel; a.out_keys = top == 0 ? keys_out : nullptr; a.out_stride = k; a.nq = nq;
+        a.kth_hi_out = kth_cur;
         if (launch_select_strided(a, L.e_stride, st)) return -1;
     }
     for (int l = top - 1; l >= 0; l--) {
@@ -90,9 +95,12 @@ int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_o
         a.kind = L.kind; a.in = L.ptr; a.in_stride = L.q_stride; a.n_in = L.n;
         a.parents = cur_sel; a.par_stride = k; a.n_par = k; a.fanout = TOPK_FANOUT;
         a.k = k; a.out_ids = nxt_sel; a.out_keys = l == 0 ? keys_out : nullptr; a.out_stride = k; a.nq = nq;
+        a.floor_hi = kth_cur; a.kth_hi_out = kth_nxt;
         if (launch_select_strided(a, L.e_stride, st)) return -1;
         std::swap(cur_sel, nxt_sel);
+        std::swap(kth_cur, kth_nxt);
     }
+    s->last_kth = kth_cur;
     *sel_out = cur_sel;
     return 0;
 }

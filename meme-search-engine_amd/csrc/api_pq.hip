@@ -153,10 +153,21 @@ mse_pq* mse_pq_load(const float* centroids, size_t n_centroids, const float* tra
     if (hipMalloc((void**)&pq->centroids, n_centroids * n_dims * 4) != hipSuccess ||
         hipMalloc((void**)&pq->transform, n_dims * n_dims * 4) != hipSuccess ||
         hipMemcpy(pq->centroids, centroids, n_centroids * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(pq->transform, transform, n_dims * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(pq->transform, transform, n_dims * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void**)&pq->transform_t, n_dims * n_dims * 4) != hipSuccess) {
         mse_pq_free(pq);
         fail("device allocation/copy failed for the quantiser");
         return nullptr;
+    }
+    {
+        std::vector<float> tt(n_dims * n_dims);
+        for (size_t i = 0; i < n_dims; i++)
+            for (size_t k = 0; k < n_dims; k++) tt[k * n_dims + i] = transform[i * n_dims + k];
+        if (hipMemcpy(pq->transform_t, tt.data(), n_dims * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            mse_pq_free(pq);
+            fail("device copy failed for the quantiser");
+            return nullptr;
+        }
     }
     return pq;
 }
@@ -164,6 +175,7 @@ void mse_pq_free(mse_pq* pq) {
     if (!pq) return;
     if (pq->centroids) (void)hipFree(pq->centroids);
     if (pq->transform) (void)hipFree(pq->transform);
+    if (pq->transform_t) (void)hipFree(pq->transform_t);
     delete pq;
 }
 
@@ -196,7 +208,7 @@ int mse_pq_quantize_batch(mse_pq* pq, const float* x, size_t n, uint8_t* codes) 
 // device LUT build into pq->c (needs pq->mu held); query_dev = fp32 [d] on device
 static int build_lut_locked(mse_pq* pq, const float* query_dev, hipStream_t st) {
     if (pq->b.ensure(pq->d * 4) || pq->c.ensure(pq->n_chunks * pq->n_centroids * 4)) return -1;
-    if (launch_pq_transform(pq->transform, (int)pq->d, query_dev, 1, pq->b.as<float>(), st)) return -1;
+    if (launch_pq_transform_vec(pq->transform_t, (int)pq->d, query_dev, pq->b.as<float>(), st)) return -1;
     return launch_pq_lut(pq->centroids, (int)pq->n_centroids, (int)pq->d, (int)pq->dpc, pq->b.as<float>(),
                          pq->c.as<float>(), st);
 }
@@ -272,73 +284,120 @@ int mse_pq_adc_gather(mse_pq* pq, const mse_codes* c, const float* lut, const fl
     return 0;
 }
 
-int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,
-                     const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
+// One query of the flat ADC scan, entirely on the searcher's stream (no host synchronisation):
+//   table(query) -> scan of all codes keeping one maximum per 64 vectors -> tournament over the maxima -> the r best groups'
+//   r x 64 vectors re-scored by the gather kernel (same arithmetic) -> exact top-r by ADC score (ties: lower id)
+//   -> with base vectors: exact fast_dot re-score of those r (+ descriptor bias) and top-k of that
+// t_dev: transformed query (fp32 [d]) scratch, lut_dev: table scratch (64 KiB), qf16_dev: f16 copy of the query (8 rows of scratch)
+static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* query_dev, float* t_dev, float* lut_dev,
+                           uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k, int64_t* out_scores_dev,
+                           uint32_t* out_ids_dev) {
+    hipStream_t st = s->stream;
+    const size_t d = pq->d;
+    if (launch_pq_transform_vec(pq->transform_t, (int)d, query_dev, t_dev, st)) return -1;
+    if (launch_pq_lut(pq->centroids, (int)pq->n_centroids, (int)d, (int)pq->dpc, t_dev, lut_dev, st)) return -1;
+    const uint8_t* desc = scales_dev ? c->desc : nullptr;
+    uint32_t* top_ids = nullptr;           // the r best by approximate score
+    const int64_t* top_scores = nullptr;
+    if (s->sel_keys.ensure(r * 8)) return -1;
+    if (pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc, (int)c->n_desc, scales_dev)) {
+        const size_t n_groups = (c->n + 63) / 64;
+        const size_t rg = std::min(r, n_groups);
+        if (s->scores.ensure(n_groups * 8) || s->gkeys.ensure(rg * 8) || s->cand_ids.ensure(rg * 64 * 4) ||
+            s->cand_scores.ensure(rg * 64 * 8) || s->out_ids.ensure(r * 4)) return -1;
+        if (launch_pq_scan_gmax(lut_dev, c->codes, c->n, desc, scales_dev, s->scores.as<int64_t>(), s->n_cu, st)) return -1;
+        uint32_t* gsel = nullptr;
+        LevelRef l0{KEY_I64, s->scores.p, n_groups, 1, n_groups, false, 0};
+        if (descend(s, l0, 1, (int)rg, &gsel, s->gkeys.p)) return -1;
+        if (launch_expand_groups(gsel, rg, rg, 64, c->n, s->cand_ids.as<uint32_t>(), rg * 64, 1, st)) return -1;
+        if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), rg * 64,
+                          desc, (int)c->n_desc, scales_dev, s->cand_scores.as<int64_t>(), s->n_cu, st)) return -1;
+        SelectArgs a{};
+        a.kind = KEY_I64; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p; a.list_stride = rg * 64;
+        a.n_list = rg * 64; a.k = (int)r; a.out_ids = s->out_ids.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = r; a.nq = 1;
+        if (rg == r) a.floor_hi = s->last_kth;   // r group maxima reach the r-th best group's key, so r vectors do
+        if (launch_select(a, st)) return -1;
+        top_ids = s->out_ids.as<uint32_t>();
+    } else {
+        // other codec shapes: every vector's score, then the tournament over them
+        if (s->scores.ensure(c->n * 8)) return -1;
+        if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, nullptr, c->n, desc, (int)c->n_desc,
+                          scales_dev, s->scores.as<int64_t>(), s->n_cu, st)) return -1;
+        LevelRef l0{KEY_I64, s->scores.p, c->n, 1, c->n, false, 0};
+        if (descend(s, l0, 1, (int)r, &top_ids, s->sel_keys.p)) return -1;
+    }
+    top_scores = s->sel_keys.as<int64_t>();
+    if (s->base) {
+        // exact re-score: f16(query) . base[id] (+ descriptor bias), query_disk_index.rs:168-170,477
+        const mse_base* b = s->base;
+        if (s->cand_scores.ensure(r * 8) || s->misc.ensure(k * 4) || s->gkeys.ensure(k * 8)) return -1;
+        if (launch_f32_to_f16(query_dev, d, qf16_dev, st)) return -1;
+        if (launch_score_rows(b->dev, b->n, (int)d, qf16_dev, false, top_ids, r, r, s->cand_scores.as<int64_t>(), nullptr, st))
+            return -1;
+        if (launch_add_descriptor(top_ids, r, desc, (int)c->n_desc, c->n, scales_dev, s->cand_scores.as<int64_t>(), st)) return -1;
+        SelectArgs a{};
+        a.kind = KEY_I64; a.list_ids = top_ids; a.list_keys = s->cand_scores.p; a.list_stride = r; a.n_list = r;
+        a.k = (int)k; a.out_ids = s->misc.as<uint32_t>(); a.out_keys = s->gkeys.p; a.out_stride = k; a.nq = 1;
+        if (launch_select(a, st)) return -1;
+        top_ids = s->misc.as<uint32_t>();
+        top_scores = s->gkeys.as<int64_t>();
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(out_ids_dev, top_ids, k * 4, hipMemcpyDeviceToDevice, st));
+    MSE_HIP_TRY(hipMemcpyAsync(out_scores_dev, top_scores, k * 8, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
+                           const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
     if (!pq || !c) return fail("null quantiser or codes");
     if (c->code_size != pq->n_chunks) return fail("code size does not match the quantiser");
-    if (k == 0) return 0;
+    if (k == 0 || nq == 0) return 0;
     if (r < k) r = k;
     if (r > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
-    for (size_t i = 0; i < k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
+    for (size_t i = 0; i < nq * k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
     if (c->n == 0) return 0;
     mse_searcher* s = s_or_null;
     mse_searcher* tmp = nullptr;
     if (!s) { tmp = scratch_searcher_new(); if (!tmp) return -1; s = tmp; }
     if (s->base && s->base->n != c->n) { if (tmp) mse_searcher_free(tmp); return fail("base and codes differ in length"); }
+    if (s->base && s->base->d != pq->d) { if (tmp) mse_searcher_free(tmp); return fail("base width differs from the quantiser"); }
     std::lock_guard<std::mutex> g(pq->mu);
     hipStream_t st = s->stream;
     const size_t d = pq->d;
     int rc = -1;
     do {
-        // query (fp32) + scales to the device; LUT built on the device
+        // all queries (+ scales) go up once; every query then runs back to back on the stream; one download at the end
+        const size_t sc_off = (nq * d * 4 + 255) & ~(size_t)255;
         const size_t sc_bytes = c->n_desc * 4;
-        if (pq->a.ensure(d * 4 + 256 + sc_bytes)) break;
-        if (hipMemcpyAsync(pq->a.p, query_f32, d * 4, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
+        if (pq->a.ensure(sc_off + sc_bytes + 256) || pq->b.ensure(d * 4) || pq->c.ensure(pq->n_chunks * pq->n_centroids * 4)) break;
+        if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(nq * k * 8)) break;
+        DevBuf out_ids_dev;
+        if (out_ids_dev.ensure(nq * k * 4)) break;
+        if (hipMemcpyAsync(pq->a.p, queries_f32, nq * d * 4, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
         float* scales_dev = nullptr;
         if (scales && c->n_desc) {
-            scales_dev = reinterpret_cast<float*>(pq->a.as<char>() + ((d * 4 + 255) & ~(size_t)255));
+            scales_dev = reinterpret_cast<float*>(pq->a.as<char>() + sc_off);
             if (hipMemcpyAsync(scales_dev, scales, sc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
         }
-        if (build_lut_locked(pq, pq->a.as<float>(), st)) break;
-        // full ADC scan
-        if (s->scores.ensure(c->n * 8)) break;
-        if (launch_pq_adc(pq->c.as<float>(), (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, nullptr, c->n,
-                          scales_dev ? c->desc : nullptr, (int)c->n_desc, scales_dev, s->scores.as<int64_t>(), s->n_cu, st))
-            break;
-        // top-r by approximate score
-        if (s->sel_keys.ensure(r * 8)) break;
-        uint32_t* sel = nullptr;
-        LevelRef l0{KEY_I64, s->scores.p, c->n, 1, c->n, false, 0};
-        if (descend(s, l0, 1, (int)r, &sel, s->sel_keys.p)) break;
-        const uint32_t* final_ids = sel;
-        const int64_t* final_scores = s->sel_keys.as<int64_t>();
-        if (s->base) {
-            // exact re-score: f16(query) . base[id] (+ descriptor bias), query_disk_index.rs:168-170,477
-            const mse_base* b = s->base;
-            if (b->d != d) { fail("base width differs from the quantiser"); break; }
-            if (s->q_stage.ensure(8 * d * 2) || s->cand_scores.ensure(r * 8) || s->misc.ensure(k * 4) ||
-                s->gkeys.ensure(k * 8)) break;
-            if (launch_f32_to_f16(pq->a.as<float>(), d, s->q_stage.as<uint16_t>(), st)) break;
-            if (launch_score_rows(b->dev, b->n, (int)d, s->q_stage.p, false, sel, r, r, s->cand_scores.as<int64_t>(),
-                                  nullptr, st)) break;
-            if (launch_add_descriptor(sel, r, scales_dev ? c->desc : nullptr, (int)c->n_desc, c->n, scales_dev,
-                                      s->cand_scores.as<int64_t>(), st)) break;
-            SelectArgs a{};
-            a.kind = KEY_I64; a.list_ids = sel; a.list_keys = s->cand_scores.p; a.list_stride = r; a.n_list = r;
-            a.k = (int)k; a.out_ids = s->misc.as<uint32_t>(); a.out_keys = s->gkeys.p; a.out_stride = k; a.nq = 1;
-            if (launch_select(a, st)) break;
-            final_ids = s->misc.as<uint32_t>();
-            final_scores = s->gkeys.as<int64_t>();
-        }
-        if (hipMemcpyAsync(ids, final_ids, k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(scores, final_scores, k * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        bool ok = true;
+        for (size_t q = 0; q < nq && ok; q++)
+            ok = scan_topk_async(pq, c, s, pq->a.as<float>() + q * d, pq->b.as<float>(), pq->c.as<float>(), s->q_stage.as<uint16_t>(),
+                                 scales_dev, r, k, s->out_scores.as<int64_t>() + q * k, out_ids_dev.as<uint32_t>() + q * k) == 0;
+        if (!ok) break;
+        if (hipMemcpyAsync(ids, out_ids_dev.p, nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(scores, s->out_scores.p, nq * k * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
-        for (size_t i = 0; i < k; i++)
+        for (size_t i = 0; i < nq * k; i++)
             if (ids[i] == MSE_ID_NONE) scores[i] = INT64_MIN;
         rc = 0;
     } while (0);
     if (tmp) mse_searcher_free(tmp);
     return rc;
+}
+
+int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,
+                     const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
+    return mse_pq_scan_topk_batch(pq, c, s_or_null, query_f32, 1, scales, r, k, scores, ids);
 }
 
 int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id) {

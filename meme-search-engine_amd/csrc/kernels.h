@@ -49,6 +49,12 @@ struct SelectArgs {
     void* out_keys;          // optional: raw keys (same type as `in`) of the selected, [nq][out_stride]
     size_t out_stride;
     int nq;
+    // optional, per query, in the composite's score domain (sortable u64; 32-bit keys sit in the top half):
+    // floor_hi: candidates whose score key is below it are skipped (the caller knows >= k candidates reach it -- e.g. the
+    // k-th best key of the parent level, since every one of the k best parents has a child with exactly its key);
+    // kth_hi_out: receives the score key of the k-th best candidate (0 when fewer than k candidates exist).
+    const unsigned long long* floor_hi = nullptr;
+    unsigned long long* kth_hi_out = nullptr;
 };
 int launch_select(const SelectArgs& a, hipStream_t stream);
 // same, with element (q, i) of `in` at in[q*in_stride + i*in_estride] (group-major level arrays)
@@ -67,6 +73,7 @@ int launch_finalize(const uint32_t* sel_ids, const int64_t* sel_scores, size_t s
 
 // ---- pq.hip ----------------------------------------------------------------------------------
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream);
+int launch_pq_transform_vec(const float* T_transposed, int d, const float* x, float* out, hipStream_t stream);   // n = 1, same arithmetic
 int launch_pq_lut(const float* centroids, int n_centroids, int d, int dpc, const float* t, float* lut,
                   hipStream_t stream);
 int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t n,
@@ -74,6 +81,9 @@ int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, 
 int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t* codes, size_t n_codes,
                   const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, const float* scales, int64_t* out,
                   int n_cu, hipStream_t stream);
+bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, int n_desc, const float* scales);
+int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
+                        int64_t* gmax, int n_cu, hipStream_t stream);
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,
                           const float* scales, int64_t* out, hipStream_t stream);
 int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stream);

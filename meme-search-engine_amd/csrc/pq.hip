@@ -36,6 +36,38 @@ __global__ __launch_bounds__(TT* TT) void pq_transform_kernel(const float* __res
     if (i0 + ti < (size_t)d && j0 + tj < n) out[(j0 + tj) * d + i0 + ti] = acc;
 }
 
+// The same product for ONE vector (the query path): thread i owns out[i] and runs the identical k-ascending chain of fused
+// multiply-adds, reading the TRANSPOSED matrix Tt[k][i] so that a wave's loads are contiguous (the tiled kernel above keeps
+// 16 of its 256 threads busy when n = 1).
+__global__ __launch_bounds__(64) void pq_transform_vec_kernel(const float* __restrict__ Tt, int d, const float* __restrict__ x,
+                                                              float* __restrict__ out) {
+    extern __shared__ float xs[];
+    for (int k = threadIdx.x; k < d; k += blockDim.x) xs[k] = x[k];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    const float* col = Tt + i;
+    float acc = 0.0f;
+    int k = 0;
+    // 64 loads in flight per thread: the chain is latency-bound (a miss costs ~0.5 us and only 18 waves are at work)
+    for (; k + 64 <= d; k += 64) {
+        float t[64];
+#pragma unroll
+        for (int u = 0; u < 64; u++) t[u] = col[(size_t)(k + u) * d];
+#pragma unroll
+        for (int u = 0; u < 64; u++) acc = fmaf(t[u], xs[k + u], acc);
+    }
+    for (; k + 8 <= d; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = col[(size_t)(k + u) * d];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = fmaf(t[u], xs[k + u], acc);
+    }
+    for (; k < d; k++) acc = fmaf(col[(size_t)k * d], xs[k], acc);
+    out[i] = acc;
+}
+
 // preprocess_query table (vector.rs:373-381): lut[i*C + j] = (f32) sum_u t[i*dpc+u] * c_j[i*dpc+u]
 // with the sum carried in f64 (simsimd's f32 dot returns f64; its lane order is CPU dependent, so
 // "parity unpinned"; products of two f32 are exact in f64, hence index-order f64 adds here).
@@ -138,6 +170,11 @@ __device__ __forceinline__ void pq_dma4(const void* sbase, uint32_t voff, uint32
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
 
+// GMAX: instead of one i64 per vector (8 B written per 68 B read, and read again by the selection), the wave keeps only
+// the maximum of its 64 scores: out[group] (0.125 B per vector).  The r best vectors lie inside the r best groups by
+// (maximum desc, group asc) -- a group ranked ahead of v's group holds a vector that precedes v, by score or, on a tie,
+// by its lower id -- so the caller re-scores those r x 64 vectors (pq_adc_kernel, same arithmetic) and selects among them.
+template <bool GMAX>
 __global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* __restrict__ lut, const uint8_t* __restrict__ codes,
                                                                   size_t n, const uint8_t* __restrict__ desc /* [n][4] or null */,
                                                                   const float* __restrict__ scales, int64_t* __restrict__ out) {
@@ -191,12 +228,20 @@ __global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* 
 #pragma unroll
             for (int bb = 0; bb < 4; bb++) s = add_rn(s, s_lut[(a * 4 + bb) * 256 + ((w[a] >> (8 * bb)) & 0xff)]);
         const size_t v = grp * 64 + lane;
-        if (v < n) {
-            int64_t r = scale_dot_result(s);
-            if (desc) {
+        int64_t r = scale_dot_result(s);
+        if (desc) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) r += scale_dot_result(sc[j] * (float)((dw >> (8 * j)) & 0xffu));
+            for (int j = 0; j < 4; j++) r += scale_dot_result(sc[j] * (float)((dw >> (8 * j)) & 0xffu));
+        }
+        if (GMAX) {
+            if (v >= n) r = INT64_MIN;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const int64_t other = __shfl_xor(r, o);
+                r = other > r ? other : r;
             }
+            if (lane == 0) out[grp] = r;      // one store per group either way: the counted waits above are unchanged
+        } else if (v < n) {
             out[v] = r;
         }
     }
@@ -258,6 +303,11 @@ int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* 
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
+int launch_pq_transform_vec(const float* Tt, int d, const float* x, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pq_transform_vec_kernel, dim3((d + 63) / 64), dim3(64), (size_t)d * 4, stream, Tt, d, x, out);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
 int launch_pq_lut(const float* centroids, int n_centroids, int d, int dpc, const float* t, float* lut,
                   hipStream_t stream) {
     return launch_pq_lut_batch(centroids, n_centroids, d, dpc, t, 1, lut, stream);
@@ -282,6 +332,27 @@ int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, 
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
+bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, int n_desc, const float* scales) {
+    return n_chunks == 64 && n_centroids == 256 && (!(desc && scales) || n_desc == 4);
+}
+// group maxima of a full scan: gmax[g] = max ADC score (+ descriptor bias) of vectors 64g .. 64g+63 (INT64_MIN past the end)
+int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
+                        int64_t* gmax, int n_cu, hipStream_t stream) {
+    if (n == 0) return 0;
+    static bool attr = false;
+    if (!attr) {
+        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_scan64_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, PQS_LDS));
+        attr = true;
+    }
+    const size_t groups = (n + 63) / 64;
+    const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, (size_t)n_cu);
+    hipLaunchKernelGGL(pq_scan64_kernel<true>, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
+                       (desc && scales) ? desc : nullptr, scales, gmax);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t* codes, size_t n_codes,
                   const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, const float* scales, int64_t* out,
                   int n_cu, hipStream_t stream) {
@@ -291,13 +362,13 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
     if (!ids && n_chunks == 64 && n_centroids == 256 && desc_ok && n == n_codes && !old_scan) {
         static bool attr = false;
         if (!attr) {
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_scan64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_scan64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             PQS_LDS));
             attr = true;
         }
         const size_t groups = (n + 63) / 64;
         const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, (size_t)n_cu);
-        hipLaunchKernelGGL(pq_scan64_kernel, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
+        hipLaunchKernelGGL(pq_scan64_kernel<false>, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
                            (desc && scales) ? desc : nullptr, scales, out);
         MSE_HIP_TRY(hipGetLastError());
         return 0;

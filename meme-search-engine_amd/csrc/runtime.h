@@ -64,6 +64,8 @@ struct mse_searcher {
     mse::DevBuf gmax;         // MFMA group maxima [n_groups][nq_pad]
     mse::DevBuf cand_ids, cand_scores, gkeys, eps, margin;
     mse::DevBuf misc, qpacked;
+    mse::DevBuf thr;          // [2][nq] u64: k-th best score key of each tournament level, the floor of the level below
+    const unsigned long long* last_kth = nullptr;   // after descend(): k-th best level-0 key per query (sortable), or null
     mse::DevBuf pool[16];     // scratch of the batched graph searches (kept between calls: no hipMalloc on the query path)
     uint32_t last_widened = 0, last_max_groups = 0;
     // optional HIP-event timing of the dominant (scan) kernel, for bench.py's roofline line
@@ -77,6 +79,7 @@ struct mse_pq {
     size_t n_centroids = 0, d = 0, dpc = 0, n_chunks = 0;
     float* centroids = nullptr;  // device [n_centroids][d]
     float* transform = nullptr;  // device [d][d]
+    float* transform_t = nullptr;  // device [d][d], transposed copy for the one-vector (query) path
     std::mutex mu;
     mse::DevBuf a, b, c;              // call scratch (guarded by mu)
 };

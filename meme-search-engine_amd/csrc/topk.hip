@@ -148,6 +148,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
     __syncthreads();
 
     const int fshift = (a.fanout > 0 && (a.fanout & (a.fanout - 1)) == 0) ? __ffs(a.fanout) - 1 : -1;
+    const uint64_t floor_hi = a.floor_hi ? a.floor_hi[q] : 0ull;
     auto load = [&](size_t c, Composite& out) -> bool {
         uint32_t id;
         K key;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
         }
         out.hi = K32 ? ((uint64_t)key << 32) : (uint64_t)key;
         out.lo = ~id;
-        return true;
+        return out.hi >= floor_hi;
     };
 
     // MSB-first radix select on the composite.  The first pass also counts the valid candidates.  As soon as the
@@ -206,22 +207,38 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
                 if (load(i, c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            s_flag = 0;
-            s_next_pos = pos - 1;
-            if (pos == 11) {
-                uint32_t total = 0;
-                for (int b = 0; b < 256; b++) total += s_hist[b];
-                s_valid = total;
-                s_need = total < (uint32_t)a.k ? total : (uint32_t)a.k;
-                if (total <= (uint32_t)a.k) s_flag = 2;   // take everything
+        if (tid < 64) {
+            // the bucket holding the need-th largest digit, found by wave 0: lane l owns buckets 4l .. 4l+3, a suffix sum over
+            // the lanes replaces the serial walk over 256 LDS counters (8 us per pass when one thread does it)
+            const uint32_t h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+            uint32_t suf = h0 + h1 + h2 + h3;            // becomes the inclusive suffix sum over lanes >= tid
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t other = __shfl_down(suf, o);
+                if (tid + o < 64) suf += other;
             }
-            if (s_flag == 0) {
-                uint32_t need = s_need, cum = 0;
-                int b = 255;
-                for (; b > 0; b--) {
-                    if (cum + s_hist[b] >= need) break;
-                    cum += s_hist[b];
+            const uint32_t total = __shfl(suf, 0);
+            const uint32_t above = suf - (h0 + h1 + h2 + h3);   // candidates in buckets of higher lanes
+            uint32_t need = s_need;
+            int flag = 0;
+            if (pos == 11) {
+                need = total < (uint32_t)a.k ? total : (uint32_t)a.k;
+                if (total <= (uint32_t)a.k) flag = 2;   // take everything
+            }
+            if (tid == 0) {
+                s_next_pos = pos - 1;
+                if (pos == 11) { s_valid = total; s_need = need; }
+                s_flag = flag;
+            }
+            // exactly one lane has above < need <= suf (lane 0 takes the walk's default, bucket 0, if none does)
+            const bool mine = flag == 0 && ((above < need && need <= suf) || (tid == 0 && need > suf));
+            if (mine) {
+                uint32_t cum = above;
+                int b = 4 * tid + 3;
+                const uint32_t hh[4] = {h0, h1, h2, h3};
+                for (; b > 4 * tid; b--) {
+                    if (cum + hh[b - 4 * tid] >= need) break;
+                    cum += hh[b - 4 * tid];
                 }
                 s_need = need - cum;
                 if (pos >= 4) s_prefix_hi |= (uint64_t)b << (8 * (pos - 4));
@@ -237,8 +254,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
                     }
                     s_next_pos = np;
                 }
-                if (s_hist[b] == need - cum) s_flag = 1;                                   // bucket taken whole: done
-                else if (!list_mode && pos > 0 && s_hist[b] <= (uint32_t)SEL_LIST_CAP) s_flag = 3;   // gather the bucket
+                if (hh[b - 4 * tid] == need - cum) s_flag = 1;                                   // bucket taken whole: done
+                else if (!list_mode && pos > 0 && hh[b - 4 * tid] <= (uint32_t)SEL_LIST_CAP) s_flag = 3;   // gather the bucket
             }
         }
         __syncthreads();
@@ -262,6 +279,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
     __syncthreads();
     const bool take_all = s_valid <= (uint32_t)a.k;
     const Composite thr{take_all ? 0ull : s_prefix_hi, take_all ? 0u : s_prefix_lo};
+    if (a.kth_hi_out && tid == 0) a.kth_hi_out[q] = take_all ? 0ull : s_prefix_hi;   // a lower bound of the k-th key when the search ended early
     {
         Composite c;
         for (size_t i = tid; i < M; i += SEL_THREADS)

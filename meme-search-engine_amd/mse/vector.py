@@ -265,6 +265,17 @@ class ProductQuantizer:
                                          _p(scores, C.c_int64), _p(ids, C.c_uint32)), "pq_scan_topk")
         return scores, ids
 
+    def scan_topk_batch(self, codes, queries_f32, r, k, searcher=None, scales=None):
+        """scan_topk for [nq, n_dims] queries in one call (one upload, the scans back to back, one download) -> ([nq,k], [nq,k])."""
+        q = np.ascontiguousarray(queries_f32, np.float32).reshape(-1, self.n_dims)
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32)
+        scores = np.empty((q.shape[0], k), np.int64)
+        ids = np.empty((q.shape[0], k), np.uint32)
+        check(ffi.lib().mse_pq_scan_topk_batch(self._h, codes._h, searcher._h if searcher is not None else None,
+                                               _p(q, C.c_float), q.shape[0], _p(sc, C.c_float) if sc is not None else None, r, k,
+                                               _p(scores, C.c_int64), _p(ids, C.c_uint32)), "pq_scan_topk_batch")
+        return scores, ids
+
     def close(self):
         if self._h:
             ffi.lib().mse_pq_free(self._h)

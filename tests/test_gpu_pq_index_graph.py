@@ -116,6 +116,38 @@ def test_pq_scan_rerank_recall(gpu, mse, orc):
     assert recall >= 0.9, recall
 
 
+@pytest.mark.parametrize("n,r,k", [(70, 200, 10), (4097, 64, 64), (12345, 200, 10), (64, 5, 5), (1, 3, 2)])
+def test_pq_scan_group_maxima_ragged_ties_and_batch(gpu, mse, orc, n, r, k):
+    """The flat scan keeps one maximum per 64 vectors and re-scores the best groups: ragged sizes (fewer groups than r, a partial
+    last group, fewer vectors than k), heavy score ties across groups (few distinct code rows) and the batched entry point,
+    all against the oracle's ADC scores ranked by (score desc, id asc)."""
+    rng = np.random.default_rng(n)
+    cents, T, _, _ = make_pq(orc)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    distinct = rng.integers(0, 256, size=(7, 64), dtype=np.uint8)
+    codes = distinct[rng.integers(0, 7, size=n)]                      # many vectors share a code row => equal ADC scores
+    desc = rng.integers(0, 3, size=(n, 4), dtype=np.uint8)
+    scales = np.array([0.25, 0, -0.125, 0.5], np.float32) / np.float32(512)
+    gcodes = mse.Codes(codes, desc)
+    qs = (rng.standard_normal((5, D)) / np.sqrt(D)).astype(np.float32)
+    bs, bi = gpq.scan_topk_batch(gcodes, qs, r, k, None, scales)
+    for j, qv in enumerate(qs):
+        approx = opq.adc_desc(opq.preprocess_query(qv), codes, desc, scales)
+        ws, wi = orc.topk_from_scores(approx, k)
+        m = min(k, n)
+        assert np.array_equal(bi[j, :m], wi[:m]) and np.array_equal(bs[j, :m], ws[:m]), j
+        assert np.all(bi[j, m:] == 0xFFFFFFFF) and np.all(bs[j, m:] == np.iinfo(np.int64).min)
+        s1, i1 = gpq.scan_topk(gcodes, qv, r, k, None, scales)
+        assert np.array_equal(s1, bs[j]) and np.array_equal(i1, bi[j])
+    # no descriptors at all
+    g2 = mse.Codes(codes, None)
+    s2, i2 = gpq.scan_topk_batch(g2, qs[:2], r, k)
+    for j in range(2):
+        ws, wi = orc.topk_from_scores(opq.asymmetric_dot_product(opq.preprocess_query(qs[j]), codes), k)
+        m = min(k, n)
+        assert np.array_equal(i2[j, :m], wi[:m]) and np.array_equal(s2[j, :m], ws[:m])
+
+
 @pytest.mark.parametrize("n,d", [(0, 128), (1, 128), (777, 128), (3000, 1152), (20000, 256)])
 def test_flat_index_matches_oracle(gpu, mse, orc, n, d):
     rng = np.random.default_rng(4)
@@ -360,8 +392,13 @@ def test_device_resident_beam_search_from_f32_queries(gpu, mse, orc, disable_pq)
     # and against the oracle for one query
     obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, None, int(starts[0]), orc.f16_bits(qs[0]),
                                                           opq.preprocess_query(qs[0]), None, disable_pq, 3, L, None)
-    if disable_pq:   # the tables differ in the last bit between host libm-free orders only in ADC mode; exact mode must agree outright
-        assert np.array_equal(got[0][0], obuf.ids) and np.array_equal(got[0][2], ovids)
+    # one table builder on the device (pq_transform_kernel + pq_lut_kernel, single or batched launch) and it is bit-equal to the
+    # oracle's (test_codec_matches_oracle), so ADC mode must agree with the oracle outright as well: buffer, visited list, counters
+    assert np.array_equal(np.asarray(luts[0]).reshape(-1), opq.preprocess_query(qs[0]).reshape(-1))
+    bi, bs, vi, vs, cm, pc = got[0]
+    assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores)
+    assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc)
+    assert (cm, pc) == (ocm, opc)
 
 
 def test_long_batches_go_through_in_pieces(gpu, mse, orc, monkeypatch):
