@@ -10,17 +10,21 @@
   index.bin                    count x record_pad_size bytes; record = [u16 LE length][payload][zero padding]
                                (:73-81; dump_processor.rs:505-521)
 
-The payload of an index.bin record is `bitcode::encode(PackedIndexEntry)` (bitcode 0.6.7).  bitcode's wire format is
-not described anywhere in the reference tree and the crate's source is not available here, so this module does NOT
-guess at it: `records()` hands out the payload bytes and a caller-supplied `decode_entry` turns them into
-(vector f16 bits, vertices, ...).  Everything else -- header, codec, codes, descriptors -- loads straight into the
-device objects of the search path.
+The payload of an index.bin record is `bitcode::encode(PackedIndexEntry)` (bitcode 0.6.7, src/common.rs:154-164).  bitcode's
+wire format is not described anywhere in the reference tree and the crate's source is not available here: mse/bitcode06.py
+restates it for this struct from knowledge of the crate (parity UNPINNED -- see that module), encoder and decoder written
+together, and is the default `decode_entry`; a caller who has the real crate's output can still plug in another decoder.
+`DiskIndex.to_device()` is the front door of the GPU-resident beam search: vectors, adjacency (+ the "has a URL" flags the
+search filters on, query_disk_index.rs:172), PQ codes and descriptor bytes go to HBM in one step; `write_index` is what
+dump-processor's packing loop writes (dump_processor.rs:463-569) so that the build side of this package produces a directory
+the read side (and, format permitting, the reference) opens.
 """
 import os
 
 import msgpack
 import numpy as np
 
+from . import bitcode06
 from .vector import ProductQuantizer, Codes
 
 RECORD_PAD_SIZE = 4096   # dump_processor.rs:135
@@ -87,7 +91,7 @@ def write_index_header(path, header: IndexHeader):
 class DiskIndex:
     """An index directory opened the way initialize_index / initialize_memory_maps do (query_disk_index.rs:658-709)."""
 
-    def __init__(self, path, decode_entry=None):
+    def __init__(self, path, decode_entry=bitcode06.decode_packed_index_entry):
         self.path = path
         self.header = read_index_header(os.path.join(path, "index.msgpack"))
         h = self.header
@@ -120,9 +124,53 @@ class DiskIndex:
         return buf[2:2 + n]
 
     def read_node(self, idx):
+        """read_node (:73-81): the PackedIndexEntry of record `idx` (a dict with the struct's field names)."""
         if self.decode_entry is None:
-            raise NotImplementedError("index.bin payloads are bitcode-encoded PackedIndexEntry; pass decode_entry= (see module docstring)")
+            raise NotImplementedError("no decode_entry: index.bin payloads are bitcode-encoded PackedIndexEntry (mse/bitcode06.py)")
         return self.decode_entry(self.record_payload(idx))
+
+    def entries(self):
+        """All records in id order, read sequentially (one pass over index.bin)."""
+        pad, h = self.header.record_pad_size, self.header
+        with open(self._data, "rb") as f:
+            for idx in range(h.count):
+                buf = f.read(pad)
+                if len(buf) != pad:
+                    raise ValueError("index.bin ends inside record %d" % idx)
+                n = int.from_bytes(buf[:2], "little")
+                if n + 2 > pad:
+                    raise ValueError("record %d: length prefix exceeds the record" % idx)
+                yield self.decode_entry(buf[2:2 + n])
+
+    def to_device(self):
+        """Everything the GPU-resident beam search needs, resident in HBM:
+        -> (VectorList of the fp16 vectors, DeviceGraph with the has-url flags, Codes, IndexGraph host copy, urls list).
+        Records whose URL is empty are graph-only nodes (dump_processor.rs:510-517): traversed, never returned (:172)."""
+        from .vector import VectorList
+        from .diskann import DeviceGraph, IndexGraph
+        h = self.header
+        d = h.quantizer["n_dims"]
+        vecs = np.zeros((h.count, d), np.uint16)
+        lists, urls = [], []
+        for i, e in enumerate(self.entries()):
+            if e["id"] != i:
+                raise ValueError("record %d carries id %d" % (i, e["id"]))          # ids are positions (dump_processor.rs:501)
+            if len(e["vector"]) != d:
+                raise ValueError("record %d: vector has %d components, the quantiser %d" % (i, len(e["vector"]), d))
+            vecs[i] = e["vector"]
+            lists.append(np.asarray(e["vertices"], np.uint32))
+            urls.append(e["url"])
+        width = max((len(l) for l in lists), default=0) or 1
+        adj = np.zeros((h.count, width), np.uint32)
+        deg = np.zeros(h.count, np.uint32)
+        for i, l in enumerate(lists):
+            adj[i, :len(l)] = l
+            deg[i] = len(l)
+        if h.count and int(adj.max()) >= h.count:
+            raise ValueError("a neighbour list points outside the index")
+        has_url = np.array([1 if u else 0 for u in urls], np.uint8)
+        graph = IndexGraph(adj, deg)
+        return VectorList.from_f16s(vecs, d), DeviceGraph(graph, has_url), self.device_codes(), graph, urls
 
 
 def write_records(path, payloads, record_pad_size=RECORD_PAD_SIZE):
@@ -132,3 +180,35 @@ def write_records(path, payloads, record_pad_size=RECORD_PAD_SIZE):
             if len(p) > record_pad_size - 2:
                 raise ValueError("payload does not fit a record")   # the reference drops such entries (:512)
             f.write(len(p).to_bytes(2, "little") + p + bytes(record_pad_size - 2 - len(p)))
+
+
+def write_index(out_dir, header: IndexHeader, entries, pq_codes, descriptor_codes, encode_entry=bitcode06.encode_packed_index_entry):
+    """The files dump-processor's packing loop leaves behind (dump_processor.rs:306-313,463-569): index.bin (one padded record
+    per entry; an entry whose payload does not fit loses its URL and is counted dead, :510-517), index.pq-codes.bin,
+    index.descriptor-codes.bin and index.msgpack (count / dead_count filled in here).  `entries` yields PackedIndexEntry dicts
+    in id order.  Returns the header as written."""
+    pad = header.record_pad_size
+    count = dead = 0
+    with open(os.path.join(out_dir, "index.bin"), "wb") as f:
+        for e in entries:
+            e = dict(e, id=count)
+            payload = encode_entry(e)
+            if len(payload) > pad - 2:
+                e["url"] = ""
+                payload = encode_entry(e)
+                dead += 1
+                if len(payload) > pad - 2:
+                    raise ValueError("record %d does not fit %d bytes even without its URL" % (count, pad))
+            f.write(len(payload).to_bytes(2, "little") + payload + bytes(pad - 2 - len(payload)))
+            count += 1
+    pq_codes = np.ascontiguousarray(pq_codes, np.uint8).reshape(count, -1)
+    if pq_codes.shape[1] != header.pq_code_size:
+        raise ValueError("pq_codes rows do not match the quantiser")
+    pq_codes.tofile(os.path.join(out_dir, "index.pq-codes.bin"))
+    dc = np.zeros((count, 0), np.uint8) if descriptor_codes is None else np.ascontiguousarray(descriptor_codes, np.uint8).reshape(count, -1)
+    if dc.shape[1] != header.n_descriptors:
+        raise ValueError("descriptor rows do not match descriptor_cdfs")
+    dc.tofile(os.path.join(out_dir, "index.descriptor-codes.bin"))
+    header.count, header.dead_count = count, header.dead_count + dead
+    write_index_header(os.path.join(out_dir, "index.msgpack"), header)
+    return header

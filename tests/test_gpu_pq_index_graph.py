@@ -487,3 +487,45 @@ def test_visited_sets_as_hash_tables(gpu, mse, orc, bits, monkeypatch):
     for a, b in zip(want_ram, got_ram):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
     assert max(r[4] for r in want) * 20 > 2048 or bits is None      # the small table really is outgrown (fetches x ~20 fresh ids)
+
+
+def test_index_directory_is_the_front_door_of_the_beam_search(gpu, mse, orc, tmp_path):
+    """an index directory written the way dump-processor packs it (index.bin records, code files, header),
+    opened with DiskIndex, moved to HBM with to_device(), searched with the GPU-resident beam search: equal to the oracle's
+    greedy_search over the arrays the directory was written from, including the records that lost their URL (graph-only nodes)."""
+    from mse import disk_index as di
+    rng = np.random.default_rng(23)
+    n, deg, L, nq = 1200, 10, 40, 6
+    x = clustered_rows(orc, n, n_centres=16)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:800], iters=2)
+    opq = orc.PQ(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 2), dtype=np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    urls = ["https://example.org/%d" % i if i % 7 else "" for i in range(n)]            # every seventh record is a dead node
+    hdr = di.IndexHeader([(x[:50].mean(axis=0).astype(np.float32), 3)], 0, 0, di.RECORD_PAD_SIZE,
+                         {"centroids": cents.reshape(-1), "transform": T.reshape(-1), "n_dims_per_code": 18, "n_dims": D},
+                         [np.linspace(0, 1, 5).astype(np.float32)] * 2)
+    ents = ({"vector": base[i], "vertices": adj[i, :degs[i]], "id": i, "timestamp": 1_700_000_000 + i, "dimensions": (100 + i, 50),
+             "scores": np.array([0.1, 0.2], np.float32), "url": urls[i], "shards": np.array([0], np.uint32)} for i in range(n))
+    di.write_index(str(tmp_path), hdr, ents, codes, desc)
+    idx = di.DiskIndex(str(tmp_path))
+    assert idx.header.count == n and idx.header.dead_count == 0       # empty URLs given by the caller are not "dead" by overflow
+    vl, dgraph, gcodes, graph, got_urls = idx.to_device()
+    assert got_urls == urls and np.array_equal(vl.rows(0, n), base)
+    assert np.array_equal(graph.deg, degs) and all(np.array_equal(graph.adj[i, :degs[i]], adj[i, :degs[i]]) for i in range(n))
+    gpq = idx.header.product_quantizer()
+    searcher = mse.Searcher(vl)
+    qs = clustered_rows(orc, nq, n_centres=16, seed=77)
+    starts = np.full(nq, 3, np.uint32)                                                   # the shard's medioid from the header
+    scales = np.array([0.5, -0.25], np.float32) / np.float32(512)
+    got = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qs, None, scales, False, 3, search_list=L, visited_cap=n)
+    has_url = np.array([1 if u else 0 for u in urls], np.uint8)
+    for i in range(nq):
+        obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, graph.adj, degs, codes, desc, 3, orc.f16_bits(qs[i]),
+                                                              opq.preprocess_query(qs[i]), scales, False, 3, L, has_url)
+        bi, bs, vi, vs, cm, pc = got[i]
+        assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores) and (cm, pc) == (ocm, opc)
+        assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc)
+        assert all(urls[int(v)] for v in vi)                                             # dead nodes are traversed, never returned
