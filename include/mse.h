@@ -361,6 +361,13 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
 /* Same from decoded RGB bytes [batch][H][W][3] (host): the ToTensor / Normalize(0.5, 0.5) / .half() / stack steps of the
  * preprocessing thread (clip_server.py:131-146) run on the device; x / 127.5 - 1 in fp32, fp16 round-to-nearest-even. */
 int mse_siglip_encode_rgb8(mse_siglip* m, const uint8_t* rgb_hwc, int batch, int normalize, float* out_f32, uint16_t* out_f16);
+/* Same from the request bytes themselves when they are what the reference's clients send (src/common.rs:31-54: 24-bit
+ * uncompressed BMP of exactly image_size): the host reads the 54-byte header, the device does BGR -> RGB, the bottom-up row
+ * flip and the normalisation.  Any other file (or size) is an error: decode it on the host and use mse_siglip_encode_rgb8.
+ * mse_bmp24_info is the header check alone (0 = plain 24-bit BMP; width / height / pixel_offset / bottom_up may be NULL). */
+int mse_bmp24_info(const uint8_t* data, size_t size, uint32_t* width, uint32_t* height, uint32_t* pixel_offset, int* bottom_up);
+int mse_siglip_encode_bmp(mse_siglip* m, const uint8_t* const* bmps, const size_t* sizes, int batch, int normalize, float* out_f32,
+                          uint16_t* out_f16);
 const void* mse_siglip_output_device(const mse_siglip* m, int which);  /* device result of the last call: 0 f32, 1 f16 */
 void* mse_siglip_stream(const mse_siglip* m);
 int mse_siglip_debug_residual(mse_siglip* m, float* out);             /* test hook: residual stream after the last block */

@@ -40,6 +40,8 @@ int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
                      int dh_pad, int dv_pad, uint16_t* out, int ldo, int tstride, hipStream_t st);
 // u8 [B][H][W][C] -> fp16 [B][C][H][W], x / 127.5 - 1
+int launch_bmp24_to_nchw_f16(const uint8_t* in, size_t img_stride, int row_stride, const uint8_t* flags, void* out, int B, int H, int W,
+                             hipStream_t st);
 int launch_rgb8_to_nchw_f16(const uint8_t* in, void* out, int B, int C, int H, int W, hipStream_t st);
 // must be applied once to a (zero-initialised) Vt buffer before launch_attention is used on it
 int launch_vt_ones_row(uint16_t* vt, size_t n_mats, int dh, int dv_pad, int n_pad, hipStream_t st);

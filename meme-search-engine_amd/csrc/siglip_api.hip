@@ -231,6 +231,58 @@ int mse_siglip_encode_rgb8(mse_siglip* m, const uint8_t* rgb_hwc, int batch, int
     return mse_siglip_encode_image(m, m->img_dev, 1, 1, batch, normalize, out_f32, out_f16);
 }
 
+// BITMAPFILEHEADER (14 bytes) + BITMAPINFOHEADER or one of its longer successors: what `image::codecs::bmp::BmpEncoder`
+// writes for Rgb8 (54-byte header, bottom-up rows) and what PIL writes.  Anything else (palettes, RLE, 32 bits, OS/2 headers)
+// is not "plain" and goes through the host decoder instead.
+int mse_bmp24_info(const uint8_t* data, size_t size, uint32_t* width, uint32_t* height, uint32_t* pixel_offset, int* bottom_up) {
+    auto u16 = [&](size_t o) { return (uint32_t)data[o] | ((uint32_t)data[o + 1] << 8); };
+    auto u32 = [&](size_t o) { return u16(o) | (u16(o + 2) << 16); };
+    if (!data || size < 54 || data[0] != 'B' || data[1] != 'M') return fail("not a BMP file");
+    const uint32_t off = u32(10), dib = u32(14);
+    if (dib < 40 || 14 + (size_t)dib > size) return fail("BMP: unsupported header");
+    const int32_t w = (int32_t)u32(18), h = (int32_t)u32(22);
+    if (u16(26) != 1 || u16(28) != 24 || u32(30) != 0) return fail("BMP: not uncompressed 24-bit");
+    if (w <= 0 || h == 0 || w > 65535 || h > 65535 || h < -65535) return fail("BMP: bad dimensions");
+    const uint32_t ah = (uint32_t)(h < 0 ? -h : h);
+    const size_t stride = ((size_t)w * 3 + 3) & ~(size_t)3;
+    if (off < 14 + dib || (size_t)off + stride * ah > size) return fail("BMP: pixel array exceeds the file");
+    if (width) *width = (uint32_t)w;
+    if (height) *height = ah;
+    if (pixel_offset) *pixel_offset = off;
+    if (bottom_up) *bottom_up = h > 0;
+    return 0;
+}
+
+// Request bytes in, features out: header check on the host (54 bytes), the pixel arrays go up as they are and the device does
+// BGR -> RGB, the row flip, ToTensor / Normalize / .half() (the whole of clip_server.py:131-146 for the client's own format).
+int mse_siglip_encode_bmp(mse_siglip* m, const uint8_t* const* bmps, const size_t* sizes, int batch, int normalize, float* out_f32,
+                          uint16_t* out_f16) {
+    if (!m || !bmps || !sizes) return fail("null engine or image list");
+    if (batch <= 0 || batch > m->max_batch) return fail("siglip: batch exceeds max_batch");
+    const mse_siglip_config& c = m->cfg;
+    if (c.in_chans != 3) return fail("siglip: BMP input needs a 3-channel model");
+    const int S = c.img_size;
+    const size_t row_stride = ((size_t)S * 3 + 3) & ~(size_t)3, img_stride = row_stride * S;
+    // staging: behind the fp16 image (2 bytes per element of a 4-byte-per-element allocation), flags after the pixels
+    uint8_t* u8 = reinterpret_cast<uint8_t*>(m->img_dev) + 2 * (size_t)m->max_batch * 3 * S * S;
+    const size_t room = 2 * (size_t)m->max_batch * 3 * S * S;
+    if ((size_t)batch * img_stride + batch > room) return fail("siglip: BMP staging does not fit");
+    std::vector<uint8_t> flags(batch);
+    for (int b = 0; b < batch; b++) {
+        uint32_t w = 0, h = 0, off = 0;
+        int bu = 0;
+        if (mse_bmp24_info(bmps[b], sizes[b], &w, &h, &off, &bu)) return -1;
+        if ((int)w != S || (int)h != S) return fail("BMP: image is not " + std::to_string(S) + " x " + std::to_string(S));
+        flags[b] = (uint8_t)bu;
+        MSE_HIP_TRY(hipMemcpyAsync(u8 + (size_t)b * img_stride, bmps[b] + off, img_stride, hipMemcpyHostToDevice, m->stream));
+    }
+    uint8_t* flags_dev = u8 + (size_t)batch * img_stride;
+    MSE_HIP_TRY(hipMemcpyAsync(flags_dev, flags.data(), batch, hipMemcpyHostToDevice, m->stream));
+    MSE_HIP_TRY(hipStreamSynchronize(m->stream));   // `flags` is a stack-owned source
+    if (launch_bmp24_to_nchw_f16(u8, img_stride, (int)row_stride, flags_dev, m->img_dev, batch, S, S, m->stream)) return -1;
+    return mse_siglip_encode_image(m, m->img_dev, 1, 1, batch, normalize, out_f32, out_f16);
+}
+
 int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on_device, int batch, int normalize,
                             float* out_f32, uint16_t* out_f16) {
     if (!m) return fail("null engine");

@@ -1512,6 +1512,20 @@ __global__ void rgb8_to_nchw_f16_kernel(const uint8_t* __restrict__ in, _Float16
     out[idx] = (_Float16)v;
 }
 
+// The same from the pixel array of a 24-bit BMP as the clients send it (src/common.rs:50-53: `BmpEncoder`, Rgb8): rows of
+// `row_stride` bytes (3W rounded up to 4), blue-green-red byte order, bottom row first unless the header's height was negative
+// (flags[b] bit 0 = bottom-up).  Identical arithmetic, so the result equals decode-with-PIL + rgb8_to_nchw_f16_kernel bit for bit.
+__global__ void bmp24_to_nchw_f16_kernel(const uint8_t* __restrict__ in, size_t img_stride, int row_stride,
+                                         const uint8_t* __restrict__ flags, _Float16* __restrict__ out, int H, int W, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H), c = (int)((idx / ((size_t)W * H)) % 3);
+    const size_t b = idx / ((size_t)W * H * 3);
+    const int row = (flags[b] & 1) ? H - 1 - y : y;
+    const float v = (float)in[b * img_stride + (size_t)row * row_stride + x * 3 + (2 - c)] / 127.5f - 1.0f;
+    out[idx] = (_Float16)v;
+}
+
 // Row `dh` of every Vt matrix = 1.0 (the attention kernel reads sum(p) out of the PV product)
 __global__ void vt_ones_row_kernel(uint16_t* __restrict__ vt, size_t n_mats, int dv_pad, int n_pad, int row) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1879,6 +1893,15 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
     return 0;
 }
 
+int launch_bmp24_to_nchw_f16(const uint8_t* in, size_t img_stride, int row_stride, const uint8_t* flags, void* out, int B, int H, int W,
+                             hipStream_t st) {
+    const size_t total = (size_t)B * 3 * H * W;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(bmp24_to_nchw_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, img_stride, row_stride,
+                       flags, reinterpret_cast<_Float16*>(out), H, W, total);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
 int launch_rgb8_to_nchw_f16(const uint8_t* in, void* out, int B, int C, int H, int W, hipStream_t st) {
     const size_t total = (size_t)B * C * H * W;
     if (total == 0) return 0;

@@ -12,8 +12,10 @@ Contract (reference clip_server.py) -- kept byte compatible:
   GET  /metrics Prometheus text: modelserver_total_items{model,modality},
                 modelserver_inftime{model,batch_size}, modelserver_batchcount{model}           (:86-88,189-191)
   request bodies up to 64 MiB                                                                  (:148)
-Thread structure mirrors the reference: aiohttp handler -> preprocessing thread -> inference thread, two
-bounded queues of 10 (:125,130).  Configuration = JSON file given as argv[1] with the reference's keys
+Stages as in the reference: aiohttp handler -> preprocessing thread -> model thread, two bounded queues of 10
+(:125,130); a request travels as a `Job` whose asyncio future the handler awaits.  Images that are what the reference's
+clients send -- 24-bit BMP of the model's size (src/common.rs:31-54) -- skip the host decoder: the request bytes go to the
+device as they are (SiglipImageEngine.encode_bmp); anything else is decoded with PIL on the preprocessing thread.  Configuration = JSON file given as argv[1] with the reference's keys
 (`device`, `model`, `model_path`, `model_name`, `max_batch_size`, `port`).
 
 The model call is the seam the reference fills with `fast_image_fns` / `model.encode_image`
@@ -21,7 +23,6 @@ The model call is the seam the reference fills with `fast_image_fns` / `model.en
 the contract is testable without a GPU (tests/test_clip_server.py uses a stand-in engine).
 """
 import asyncio
-import collections
 import io
 import json
 import queue
@@ -32,25 +33,18 @@ import traceback
 import msgpack
 import numpy as np
 
-InferenceParameters = collections.namedtuple("InferenceParameters", ["text", "images", "callback"])
-
-
 def preprocess_image(data: bytes, size):
     """open_clip's preprocess for ViT-SO400M-14-SigLIP-384 as the reference relies on it:
     decode, RGB, resize to (w, h) if needed (bicubic, squash), ToTensor, Normalize(mean=std=0.5), .half().
     Clients already send 384x384 24-bit BMP (src/common.rs:50-53), so the resize is normally the identity."""
-    from PIL import Image
-    im = Image.open(io.BytesIO(data)).convert("RGB")
-    if im.size != tuple(size):
-        im = im.resize(tuple(size), Image.BICUBIC)
-    a = np.asarray(im, dtype=np.float32)                     # [h, w, 3]
+    a = decode_image(data, size).astype(np.float32)          # [h, w, 3]
     a = a / np.float32(127.5) - np.float32(1.0)               # (x/255 - 0.5) / 0.5
     return np.ascontiguousarray(a.transpose(2, 0, 1)).astype(np.float16)
 
 
 def decode_image(data: bytes, size):
-    """The host half of preprocess_image: decode, RGB, resize if needed -> uint8 [h, w, 3].  The arithmetic half
-    (x/127.5 - 1, fp16, NCHW) then runs on the device (SiglipImageEngine.encode_rgb8)."""
+    """Host decoder for everything that is not the clients' own format: decode, RGB, resize if needed -> uint8 [h, w, 3].
+    The arithmetic half (x/127.5 - 1, fp16, NCHW) then runs on the device (SiglipImageEngine.encode_rgb8)."""
     from PIL import Image
     im = Image.open(io.BytesIO(data)).convert("RGB")
     if im.size != tuple(size):
@@ -58,7 +52,30 @@ def decode_image(data: bytes, size):
     return np.asarray(im, dtype=np.uint8)
 
 
+class Job:
+    """One POST on its way through the two worker threads.  The handler awaits `done`; whichever stage ends the job --
+    a failed check, a failed decode, the model -- resolves it from its own thread."""
+
+    __slots__ = ("text", "images", "done", "_loop", "stage")
+
+    def __init__(self, text, images, loop=None):
+        self.text, self.images = text, images
+        self._loop = loop
+        self.done = loop.create_future() if loop is not None else None
+        self.stage = None          # what the preprocessing step hands to the model: ("tokens" | "bmp" | "rgb8" | "nchw", payload)
+
+    def finish(self, ok, payload):
+        if self.done is not None:
+            self._loop.call_soon_threadsafe(self._resolve, ok, payload)
+
+    def _resolve(self, ok, payload):
+        if not self.done.done():
+            self.done.set_result((ok, payload))
+
+
 class ClipServer:
+    QUEUE_DEPTH = 10           # both hand-off queues of the reference hold 10 (clip_server.py:125,130)
+
     def __init__(self, config, image_engine, text_engine=None, tokenizer=None, registry=None):
         from prometheus_client import CollectorRegistry, Counter, Histogram
         self.config = config
@@ -75,130 +92,112 @@ class ClipServer:
         self.inference_time_hist = Histogram("modelserver_inftime", "Time running inference", ["model", "batch_size"],
                                              registry=self.registry)
         self.batch_count_ctr = Counter("modelserver_batchcount", "Inference batches run", ["model"], registry=self.registry)
-        self.iq = queue.Queue(10)
-        self.pq = queue.Queue(10)
+        self.prep_q = queue.Queue(self.QUEUE_DEPTH)     # handler -> preprocessing
+        self.model_q = queue.Queue(self.QUEUE_DEPTH)    # preprocessing -> model
         self._threads = []
         self._stop = object()
 
-    # ---- inference thread (clip_server.py:91-128) ----
-    def do_inference(self, params):
-        text, images, callback = params
-        try:
-            if text is not None:
-                if self.text_engine is None:
-                    raise RuntimeError("text tower not loaded")
-                self.items_ctr.labels(self.model_name, "text").inc(text.shape[0])
-                with self.inference_time_hist.labels(self.model_name + "-text", text.shape[0]).time():
-                    features = np.asarray(self.text_engine.encode_text(text), np.float32)
-                    features = features / np.linalg.norm(features, axis=-1, keepdims=True)
-            elif images is not None:
-                with self.inference_time_hist.labels(self.model_name + "-image", images.shape[0]).time():
-                    self.items_ctr.labels(self.model_name, "image").inc(images.shape[0])
-                    # the engine normalises on the device; result rows are unit norm like `features /= norm`
-                    if images.dtype == np.uint8:    # decoded bytes: normalisation / fp16 / NCHW happen on the device
-                        features = np.asarray(self.image_engine.encode_rgb8(images), np.float32)
-                    else:
-                        features = np.asarray(self.image_engine.encode_image(images), np.float32)
-            else:
-                raise AssertionError("images or text required")
-            self.batch_count_ctr.labels(self.model_name).inc()
-            callback(True, features)
-        except Exception as e:  # noqa: BLE001 - the reference reports every failure as a 500 string
-            traceback.print_exc()
-            callback(False, str(e))
+    def submit(self, job):
+        """What the POST handler does with a request: a full queue raises queue.Full out of the handler, as the reference's
+        put_nowait does (clip_server.py:161)."""
+        self.prep_q.put_nowait(job)
 
-    def infer_thread(self):
-        while True:
-            item = self.iq.get()
-            if item is self._stop:
-                return
-            self.do_inference(item)
+    # ---- preprocessing stage (the reference's preprocessing_thread, clip_server.py:131-146) ----
+    def prepare(self, job):
+        if job.text:
+            assert len(job.text) <= self.bs, f"max batch size is {self.bs}"
+            if self.tokenizer is None:
+                raise RuntimeError("tokenizer not available")
+            return "tokens", np.asarray(self.tokenizer(job.text))
+        if job.images:
+            assert len(job.images) <= self.bs, f"max batch size is {self.bs}"
+            eng = self.image_engine
+            if hasattr(eng, "encode_bmp"):
+                from .siglip import is_plain_bmp
+                if all(is_plain_bmp(im, self.image_size) for im in job.images):
+                    return "bmp", list(job.images)          # the clients' own format: no host decode at all
+            if hasattr(eng, "encode_rgb8"):
+                return "rgb8", np.stack([decode_image(im, self.image_size) for im in job.images])
+            return "nchw", np.stack([preprocess_image(im, self.image_size) for im in job.images])
+        raise AssertionError("images or text required")
 
-    # ---- preprocessing thread (clip_server.py:131-146) ----
-    def preprocessing_thread(self):
+    # ---- model stage (do_inference, clip_server.py:91-123) ----
+    def run_model(self, kind, payload):
+        n = len(payload)
+        if kind == "tokens":
+            if self.text_engine is None:
+                raise RuntimeError("text tower not loaded")
+            self.items_ctr.labels(self.model_name, "text").inc(n)
+            with self.inference_time_hist.labels(self.model_name + "-text", n).time():
+                f = np.asarray(self.text_engine.encode_text(payload), np.float32)
+                f = f / np.linalg.norm(f, axis=-1, keepdims=True)
+        else:
+            self.items_ctr.labels(self.model_name, "image").inc(n)
+            with self.inference_time_hist.labels(self.model_name + "-image", n).time():
+                # the engine normalises on the device; result rows are unit norm like `features /= norm`
+                call = {"bmp": "encode_bmp", "rgb8": "encode_rgb8", "nchw": "encode_image"}[kind]
+                f = np.asarray(getattr(self.image_engine, call)(payload), np.float32)
+        self.batch_count_ctr.labels(self.model_name).inc()
+        return f
+
+    def _stage_loop(self, inbox, work):
         while True:
-            item = self.pq.get()
-            if item is self._stop:
+            job = inbox.get()
+            if job is self._stop:
                 return
-            text, images, callback = item
             try:
-                if text:
-                    assert len(text) <= self.bs, f"max batch size is {self.bs}"
-                    if self.tokenizer is None:
-                        raise RuntimeError("tokenizer not available")
-                    text = np.asarray(self.tokenizer(text))
-                    images = None
-                elif images:
-                    assert len(images) <= self.bs, f"max batch size is {self.bs}"
-                    if hasattr(self.image_engine, "encode_rgb8"):
-                        images = np.stack([decode_image(im, self.image_size) for im in images])
-                    else:
-                        images = np.stack([preprocess_image(im, self.image_size) for im in images])
-                    text = None
-                else:
-                    assert False, "images or text required"
-                self.iq.put(InferenceParameters(text, images, callback))
-            except Exception as e:  # noqa: BLE001
+                work(job)
+            except Exception as e:  # noqa: BLE001 - every failure is reported to the client as a 500 string
                 traceback.print_exc()
-                callback(False, str(e))
+                job.finish(False, str(e))
+
+    def _prep_work(self, job):
+        job.stage = self.prepare(job)
+        self.model_q.put(job)
+
+    def _model_work(self, job):
+        job.finish(True, self.run_model(*job.stage))
 
     def start_threads(self):
-        for fn in (self.infer_thread, self.preprocessing_thread):
-            th = threading.Thread(target=fn, daemon=True)
+        for inbox, work in ((self.model_q, self._model_work), (self.prep_q, self._prep_work)):
+            th = threading.Thread(target=self._stage_loop, args=(inbox, work), daemon=True)
             th.start()
             self._threads.append(th)
 
     def stop_threads(self):
-        self.pq.put(self._stop)
-        self.iq.put(self._stop)
+        self.prep_q.put(self._stop)
+        self.model_q.put(self._stop)
 
     # ---- HTTP (clip_server.py:148-200) ----
     def make_app(self):
         from aiohttp import web
         from prometheus_client import generate_latest
-        app = web.Application(client_max_size=2 ** 26)
-        routes = web.RouteTableDef()
+        msgpack_type = "application/msgpack"
 
-        @routes.post("/")
-        async def run_inference(request):
-            loop = asyncio.get_event_loop()
-            data = msgpack.loads(await request.read())
-            event = asyncio.Event()
-            results = None
+        async def embed(request):
+            body = msgpack.loads(await request.read())
+            job = Job(body.get("text"), body.get("images"), asyncio.get_running_loop())
+            self.submit(job)
+            ok, payload = await job.done
+            if ok:
+                payload = [row.astype("float16").tobytes() for row in payload]
+            return web.Response(body=msgpack.dumps(payload), status=200 if ok else 500, content_type=msgpack_type)
 
-            def callback(*argv):
-                nonlocal results
-                results = argv
-                loop.call_soon_threadsafe(lambda: event.set())
+        async def describe(request):
+            info = {"model": self.config["model"], "batch": self.bs, "image_size": self.image_size, "embedding_size": self.embedding_size}
+            return web.Response(body=msgpack.dumps(info), status=200, content_type=msgpack_type)
 
-            self.pq.put_nowait(InferenceParameters(data.get("text"), data.get("images"), callback))
-            await event.wait()
-            body_data = results[1]
-            if results[0]:
-                status = 200
-                body_data = [x.astype("float16").tobytes() for x in body_data]
-            else:
-                status = 500
-            return web.Response(body=msgpack.dumps(body_data), status=status, content_type="application/msgpack")
-
-        @routes.get("/config")
-        async def config(request):
-            return web.Response(body=msgpack.dumps({
-                "model": self.config["model"],
-                "batch": self.bs,
-                "image_size": self.image_size,
-                "embedding_size": self.embedding_size,
-            }), status=200, content_type="application/msgpack")
-
-        @routes.get("/")
-        async def health(request):
+        async def alive(request):
             return web.Response(status=204)
 
-        @routes.get("/metrics")
         async def metrics(request):
             return web.Response(body=generate_latest(self.registry))
 
-        app.router.add_routes(routes)
+        app = web.Application(client_max_size=64 << 20)
+        app.router.add_post("/", embed)
+        app.router.add_get("/config", describe)
+        app.router.add_get("/", alive)
+        app.router.add_get("/metrics", metrics)
         return app
 
 

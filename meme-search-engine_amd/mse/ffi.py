@@ -142,6 +142,8 @@ SIGNATURES = {
     "mse_siglip_finalize": (C.c_int, [vp]),
     "mse_siglip_encode_image": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, u16p]),
     "mse_siglip_encode_rgb8": (C.c_int, [vp, u8p, C.c_int, C.c_int, f32p, u16p]),
+    "mse_bmp24_info": (C.c_int, [C.c_char_p, sz, u32p, u32p, u32p, C.POINTER(C.c_int)]),
+    "mse_siglip_encode_bmp": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_int, C.c_int, f32p, u16p]),
     "mse_siglip_output_device": (vp, [vp, C.c_int]),
     "mse_siglip_stream": (vp, [vp]),
     "mse_siglip_debug_residual": (C.c_int, [vp, f32p]),

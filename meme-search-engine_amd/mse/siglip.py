@@ -60,6 +60,14 @@ def _to_numpy_f32(t):
     return np.ascontiguousarray(t, np.float32)
 
 
+def is_plain_bmp(data, size):
+    """True if `data` is a 24-bit uncompressed BMP of (width, height) = size: the file the device path takes as it is."""
+    w, h = C.c_uint32(), C.c_uint32()
+    if ffi.lib().mse_bmp24_info(bytes(data), len(data), C.byref(w), C.byref(h), None, None) != 0:
+        return False
+    return (w.value, h.value) == tuple(size)
+
+
 class SiglipImageEngine:
     def __init__(self, config=None, max_batch=32, eps=1e-6, gelu="erf"):
         cfg = dict(SO400M_384 if config is None else config)
@@ -130,6 +138,23 @@ class SiglipImageEngine:
                                                of32.ctypes.data_as(ffi.f32p) if of32 is not None else None,
                                                of16.ctypes.data_as(ffi.u16p) if of16 is not None else None),
               "siglip_encode_rgb8")
+        return of32 if out == "f32" else of16
+
+    def encode_bmp(self, files, normalize=True, out="f32"):
+        """files: the request's image bytes, every one a 24-bit uncompressed BMP of the model's size (what the reference's clients
+        send, src/common.rs:31-54).  Header check on the host, everything else on the device; equal to decoding with PIL and
+        encode_rgb8 bit for bit.  Raises MseError for any other file: use `is_plain_bmp` first (or catch and decode on the host)."""
+        files = [bytes(f) for f in files]
+        b = len(files)
+        if b > self.max_batch:
+            raise MseError(f"max batch size is {self.max_batch}")
+        ptrs = (C.c_char_p * b)(*files)
+        sizes = (ffi.sz * b)(*[len(f) for f in files])
+        of32 = np.empty((b, self.embedding_size), np.float32) if out == "f32" else None
+        of16 = np.empty((b, self.embedding_size), np.uint16) if out == "f16" else None
+        check(ffi.lib().mse_siglip_encode_bmp(self._h, ptrs, sizes, b, int(normalize),
+                                              of32.ctypes.data_as(ffi.f32p) if of32 is not None else None,
+                                              of16.ctypes.data_as(ffi.u16p) if of16 is not None else None), "siglip_encode_bmp")
         return of32 if out == "f32" else of16
 
     def encode_image_device(self, dev_ptr, batch, dtype_f16=True, normalize=True):

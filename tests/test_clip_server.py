@@ -170,12 +170,83 @@ def test_preprocess_matches_reference_normalisation(mse):
 
 def test_queue_full_raises_like_put_nowait(mse):
     import queue
-    from mse.clip_server import ClipServer, InferenceParameters
-    srv = ClipServer(CONFIG, StandInEngine())
+    from mse.clip_server import ClipServer, Job
+    srv = ClipServer(CONFIG, StandInEngine())             # threads not started: nothing drains the queue
     for _ in range(10):
-        srv.pq.put_nowait(InferenceParameters(None, [b"x"], lambda *a: None))
+        srv.submit(Job(None, [b"x"]))
     with pytest.raises(queue.Full):                                                     # clip_server.py:161
-        srv.pq.put_nowait(InferenceParameters(None, [b"x"], lambda *a: None))
+        srv.submit(Job(None, [b"x"]))
+
+
+def rust_style_bmp(rgb):
+    """What `image::codecs::bmp::BmpEncoder` writes for Rgb8 (src/common.rs:50-53): 14 + 40 byte headers, 24 bits, rows bottom-up,
+    blue-green-red, padded to 4 bytes -- assembled by hand so the test does not depend on PIL's writer."""
+    import struct
+    h, w, _ = rgb.shape
+    stride = (3 * w + 3) & ~3
+    rows = np.zeros((h, stride), np.uint8)
+    rows[:, :3 * w] = rgb[::-1, :, ::-1].reshape(h, 3 * w)
+    pixels = rows.tobytes()
+    return (b"BM" + struct.pack("<IHHI", 54 + len(pixels), 0, 0, 54)
+            + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(pixels), 2835, 2835, 0, 0) + pixels)
+
+
+def test_bmp_header_check(mse):
+    from mse.siglip import is_plain_bmp
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, size=(384, 384, 3), dtype=np.uint8)
+    f = rust_style_bmp(rgb)
+    assert len(f) == 54 + 384 * 384 * 3 and is_plain_bmp(f, (384, 384)) and is_plain_bmp(bmp_bytes(1), (384, 384))
+    assert not is_plain_bmp(f, (385, 384)) and not is_plain_bmp(f[:1000], (384, 384)) and not is_plain_bmp(b"\x89PNG" + f[4:], (384, 384))
+    assert not is_plain_bmp(f[:28] + b"\x20\x00" + f[30:], (384, 384))      # 32 bits per pixel
+    assert not is_plain_bmp(f[:30] + b"\x01\x00\x00\x00" + f[34:], (384, 384))   # RLE8
+    assert is_plain_bmp(rust_style_bmp(rgb[:10, :7]), (7, 10))                 # padded rows (21 -> 24 bytes)
+
+
+@pytest.mark.gpu
+def test_bmp_bytes_through_the_device_path(gpu, mse):
+    """the request's BMP bytes go to the device as they are (header strip, BGR -> RGB, bottom-up flip, x/127.5 - 1,
+    fp16, NCHW in one kernel): features bit-equal to decode-with-PIL + encode_rgb8 and to the host preprocess + encode_image; a
+    top-down BMP (negative height) and PIL-written files too; a PNG in the batch sends the whole batch through the host decoder."""
+    import struct
+    from mse import siglip
+    from mse.clip_server import ClipServer, decode_image, preprocess_image
+    cfg = dict(siglip.SO400M_384, depth=1)
+    eng = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=4)
+    eng.image_size = (384, 384)
+    rng = np.random.default_rng(5)
+    rgbs = [rng.integers(0, 256, size=(384, 384, 3), dtype=np.uint8) for _ in range(3)]
+    files = [rust_style_bmp(rgbs[0]), bmp_bytes(11), rust_style_bmp(rgbs[2])]
+    top_down = bytearray(rust_style_bmp(rgbs[1]))                                    # same pixels stored top row first
+    top_down[22:26] = struct.pack("<i", -384)
+    top_down[54:] = rgbs[1][:, :, ::-1].tobytes()
+    files.append(bytes(top_down))
+    assert np.array_equal(decode_image(files[3], (384, 384)), rgbs[1])
+    via_bmp = eng.encode_bmp(files)
+    via_rgb8 = eng.encode_rgb8(np.stack([decode_image(f, (384, 384)) for f in files]))
+    via_host = eng.encode_image(np.stack([preprocess_image(f, (384, 384)) for f in files]))
+    assert np.array_equal(via_bmp, via_rgb8) and np.array_equal(via_bmp, via_host)
+    with pytest.raises(mse.MseError):
+        eng.encode_bmp([files[0][:5000]])
+    # through the server: which stage the preprocessing thread picks
+    srv = ClipServer(CONFIG, eng)
+    from mse.clip_server import Job
+    assert srv.prepare(Job(None, files[:2]))[0] == "bmp"
+    import io
+    from PIL import Image
+    png = io.BytesIO()
+    Image.fromarray(rgbs[0], "RGB").save(png, format="PNG")
+    kind, payload = srv.prepare(Job(None, [files[0], png.getvalue()]))
+    assert kind == "rgb8" and np.array_equal(payload[0], payload[1])
+
+    async def scenario(client):
+        r = await client.post("/", data=msgpack.dumps({"images": files}))
+        return r.status, msgpack.loads(await r.read())
+
+    status, rows = run_with_server(srv, scenario)
+    assert status == 200
+    got = np.stack([np.frombuffer(r, "<f2") for r in rows])
+    assert np.array_equal(got, via_bmp.astype(np.float16))
 
 
 @pytest.mark.gpu
