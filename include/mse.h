@@ -111,6 +111,9 @@ int mse_merge_topk_dev(mse_searcher* s, const void* gathered_scores_dev, const v
 size_t mse_topk_block_bytes(size_t nq, size_t k);
 int mse_merge_topk_packed_dev(mse_searcher* s, const void* gathered_blocks_dev, size_t n_shards, size_t nq, size_t k,
                               void* out_scores_dev, void* out_ids_dev);
+/* Test hook: raw output of the matrix-core scan, out[g][q] = max over rows 32g..32g+31 of the MFMA score of query q
+ * (nq <= 256, host arrays), so that tests can measure its distance from the exact-order scores. */
+int mse_debug_mfma_group_max(mse_searcher* s, const uint16_t* queries, size_t nq, float* out);
 /* HIP-event timing of the scan kernel (the HBM-bound kernel) on the searcher's stream: returns the
  * totals accumulated so far, then sets the mode: enable 0 = off, 1 = on, 2 = on and reset totals. */
 int mse_searcher_scan_timing(mse_searcher* s, int enable, double* total_ms, uint64_t* launches);

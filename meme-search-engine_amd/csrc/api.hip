@@ -430,6 +430,26 @@ int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t
     return fail("unknown mode");
 }
 
+// test hook: the raw output of the matrix-core scan, so that its deviation from the exact-order scores can be MEASURED
+// (tests/test_gpu_bruteforce.py) instead of assumed: out[g][q] = max over rows 32g .. 32g+31 of the MFMA score of query q
+int mse_debug_mfma_group_max(mse_searcher* s, const uint16_t* queries, size_t nq, float* out) {
+    if (!s || !s->base) return fail("null searcher");
+    const mse_base* b = s->base;
+    if (nq == 0 || nq > 256 || b->n == 0) return fail("mfma_group_max: 1..256 queries, non-empty base");
+    const int d = (int)b->d;
+    const int nq_pad = nq > 128 ? 256 : 128;
+    const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;
+    if (s->q_stage.ensure((size_t)nq_pad * d * 2) || s->gmax.ensure(n_groups * (size_t)nq_pad * 4) ||
+        s->qpacked.ensure(mfma_packed_bytes(d))) return -1;
+    MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, (size_t)nq_pad * d * 2, s->stream));
+    MSE_HIP_TRY(hipMemcpyAsync(s->q_stage.p, queries, nq * d * 2, hipMemcpyHostToDevice, s->stream));
+    if (launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>(), nq_pad, s->qpacked.p, s->gmax.as<float>(), s->n_cu, s->stream))
+        return -1;
+    MSE_HIP_TRY(hipMemcpy2DAsync(out, nq * 4, s->gmax.p, (size_t)nq_pad * 4, nq * 4, n_groups, hipMemcpyDeviceToHost, s->stream));
+    MSE_HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
 int mse_bruteforce_topk_f16(mse_searcher* s, const uint16_t* queries, size_t nq, size_t k, int mode, int64_t* scores,
                             uint32_t* ids) {
     if (!s) return fail("null searcher");

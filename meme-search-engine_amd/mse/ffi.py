@@ -79,6 +79,7 @@ SIGNATURES = {
     "mse_comm_rank": (C.c_int, [vp]),
     "mse_comm_size": (C.c_int, [vp]),
     "mse_comm_search_dev": (C.c_int, [vp, vp, vp, sz, sz, C.c_int, C.c_uint64, vp, vp]),
+    "mse_debug_mfma_group_max": (C.c_int, [vp, u16p, sz, f32p]),
     "mse_searcher_scan_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mse_searcher_last_stats": (C.c_int, [vp, u32p, u32p]),
     "mse_index_new": (vp, [C.c_int]),

@@ -224,3 +224,34 @@ def test_full_size_properties_1e7(gpu, mse, orc):
     sm2, im2 = s.bruteforce_topk(q, k, mse.MODE_MFMA)
     assert np.array_equal(sm, sm2) and np.array_equal(im, im2)
     assert s.last_stats()["widened_queries"] == 0
+
+
+def test_mfma_error_bound_is_measured_not_assumed(gpu, mse, orc):
+    """The exactness certificate of the batched scan rests on |MFMA score - exact-order score| <= eps * |q| * |x| with
+    eps = 2.8e-4 (api.hip mfma_pass / DESIGN 3.1).  Measure the left side: a 1e7-row base in which every row is repeated 32
+    times, so that the scan's per-32-row maximum IS the row's MFMA score, against the exact-order scores of the 312 500
+    distinct rows, for 128 and 256 queries (40 M and 80 M (row, query) pairs).  The bound must hold with a margin of 4."""
+    import ctypes as C
+    import torch
+    from mse import ffi
+    n_distinct = 312_500
+    rows = orc.gen_rows_f16(SEED_BASE, 0, n_distinct)
+    small = mse.Searcher(mse.VectorList.from_f16s(rows, D))
+    rep = torch.from_numpy(rows.view(np.int16)).cuda().repeat_interleave(32, dim=0).contiguous()     # 1e7 x 1152, 23 GB
+    torch.cuda.synchronize()
+    big = mse.Searcher(mse.VectorList.wrap_device(rep.data_ptr(), n_distinct * 32, D, keepalive=rep))
+    row_norm = np.linalg.norm(orc.f16_to_f32(rows).astype(np.float64), axis=1)
+    worst = 0.0
+    for nq in (128, 256):
+        q = orc.gen_rows_f16(SEED_QUERY, 1000, nq)
+        q[: nq // 2] = (orc.f16_to_f32(q[: nq // 2]) * np.float32(3.0)).astype(np.float16).view(np.uint16)   # queries need not be unit norm
+        got = np.empty((n_distinct, nq), np.float32)
+        ffi.check(ffi.lib().mse_debug_mfma_group_max(big._h, q.ctypes.data_as(ffi.u16p), nq, got.ctypes.data_as(ffi.f32p)))
+        q_norm = np.linalg.norm(orc.f16_to_f32(q).astype(np.float64), axis=1)
+        for j in range(nq):
+            exact = small.scores(q[j]).astype(np.float64) / 4294967296.0
+            ratio = np.abs(got[:, j].astype(np.float64) - exact) / (row_norm * q_norm[j])
+            worst = max(worst, float(ratio.max()))
+    print("max |mfma - exact| / (|q||x|) =", worst)
+    assert worst > 0                                  # the two orders do differ: the certificate is not vacuous
+    assert 2.8e-4 >= 4 * worst, worst

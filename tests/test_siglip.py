@@ -93,6 +93,9 @@ def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
     resid = eng.debug_residual(batch)
     cos_resid = cosine(resid.reshape(batch, -1), taps[f"block{depth - 1}"].numpy().reshape(batch, -1))
     assert np.all(cos_resid > 1 - 1e-3), cos_resid
+    # headroom of the fp16 residual stream: the largest magnitude after the last block against fp16's 65504
+    peak = float(np.abs(resid).max())
+    assert np.isfinite(resid).all() and peak < 65504 / 16, peak
     cos = cosine(got, want)
     assert np.all(cos > 1 - 1e-3), cos                                    # north_star tolerance
     assert np.all(np.abs(np.linalg.norm(got, axis=1) - 1) < 1e-3)
@@ -104,6 +107,30 @@ def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
     assert np.all(cosine(got1, want[:1]) > 1 - 1e-3)
     with pytest.raises(mse.MseError):
         eng.encode_image(np.zeros((5, 3, 384, 384), np.float32))           # > max_batch (clip_server.py:139)
+
+
+@pytest.mark.gpu
+def test_engine_with_massive_activation_channels(gpu, mse, ref):
+    """Trained ViTs carry a few residual channels hundreds of times larger than the rest ("massive activations"); the seeded
+    Gaussian weights of the other tests never do.  Plant them -- biases of +3000 / -800 / +12000 on three channels of the
+    first block's proj / fc2 outputs -- and require the same 1e-3 cosine against the fp32 restatement: the fp16 residual
+    stream (11-bit mantissa, range 65504) must carry them, and the fp32 LayerNorm statistics must see through them."""
+    from mse import siglip
+    cfg = dict(ref.CONFIG, depth=3)
+    sd = ref.synthetic_weights(cfg)
+    sd["trunk.blocks.0.attn.proj.bias"][100] = -800.0
+    sd["trunk.blocks.0.mlp.fc2.bias"][7] = 3000.0
+    sd["trunk.blocks.1.mlp.fc2.bias"][640] = 12000.0
+    img = ref.synthetic_images(2, cfg)
+    taps = {}
+    want = ref.encode_image(img, sd, cfg, normalize=True, taps=taps).numpy()
+    eng = siglip.SiglipImageEngine.from_state_dict({"visual." + k: v for k, v in sd.items()}, dict(siglip.SO400M_384, depth=3), max_batch=2)
+    got = eng.encode_image(img.numpy())
+    resid = eng.debug_residual(2)
+    want_resid = taps["block2"].numpy()
+    assert 11000 < float(np.abs(resid).max()) < 65504 and np.isfinite(resid).all()
+    assert abs(float(np.abs(resid).max()) - float(np.abs(want_resid).max())) < 16        # fp16 spacing at 12000 is 8
+    assert np.all(cosine(got, want) > 1 - 1e-3), cosine(got, want)
 
 
 @pytest.mark.gpu
