@@ -379,11 +379,31 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
             scales_dev = reinterpret_cast<float*>(pq->a.as<char>() + sc_off);
             if (hipMemcpyAsync(scales_dev, scales, sc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
         }
+        // Queries alternate between two streams (each with its own scratch): the chain of small kernels that follows a scan
+        // (tournament, re-score of the best groups, selects: ~0.2 ms, mostly single-workgroup launches) runs beside the NEXT
+        // query's scan, which leaves a few CUs free for it (pq.hip launch_pq_scan_gmax).
+        mse_searcher* lanes[2] = {s, nullptr};
+        DevBuf t2, lut2, qf2;
+        if (nq >= 4) {
+            lanes[1] = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
+            if (!lanes[1] || t2.ensure(d * 4) || lut2.ensure(pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) {
+                if (lanes[1]) mse_searcher_free(lanes[1]);
+                break;
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) { mse_searcher_free(lanes[1]); fail("H2D failed"); break; }   // uploads visible to both streams
+        }
         bool ok = true;
-        for (size_t q = 0; q < nq && ok; q++)
-            ok = scan_topk_async(pq, c, s, pq->a.as<float>() + q * d, pq->b.as<float>(), pq->c.as<float>(), s->q_stage.as<uint16_t>(),
+        for (size_t q = 0; q < nq && ok; q++) {
+            const int w = lanes[1] ? (int)(q & 1) : 0;
+            ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, w ? t2.as<float>() : pq->b.as<float>(),
+                                 w ? lut2.as<float>() : pq->c.as<float>(), w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>(),
                                  scales_dev, r, k, s->out_scores.as<int64_t>() + q * k, out_ids_dev.as<uint32_t>() + q * k) == 0;
-        if (!ok) break;
+        }
+        if (lanes[1]) {
+            if (hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
+            mse_searcher_free(lanes[1]);
+        }
+        if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
         if (hipMemcpyAsync(ids, out_ids_dev.p, nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(scores, s->out_scores.p, nq * k * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }

@@ -346,7 +346,10 @@ int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const 
         attr = true;
     }
     const size_t groups = (n + 63) / 64;
-    const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, (size_t)n_cu);
+    // one 133-KiB workgroup per CU, on all but a few CUs: the single-workgroup kernels of another query's tail (radix selects,
+    // ~50 KiB of LDS each) can then run beside a scan instead of queueing behind all of its workgroups (-1.6 % scan rate)
+    const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;
+    const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, cus);
     hipLaunchKernelGGL(pq_scan64_kernel<true>, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
                        (desc && scales) ? desc : nullptr, scales, gmax);
     MSE_HIP_TRY(hipGetLastError());

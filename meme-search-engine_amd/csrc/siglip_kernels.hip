@@ -1340,8 +1340,12 @@ constexpr int AT6_VT = 80 * 128;               // 10240
 constexpr int AT6_STAGE = AT6_KT + AT6_VT;     // 24 KiB
 constexpr int AT6_NS = 3;
 
-template <int ABL>   // 0 shipped; timing ablations: 1 no softmax arithmetic, 2 no MFMA, 3 no K/V fragment reads
-__global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+// QT = 16-query tiles per wave, NW = waves per workgroup: NW * QT * 16 = 256 queries share one K / Vt stream either way.
+// <2, 8> is the round-1 shape; <4, 4> (round 2) lets every K / Vt fragment read from LDS feed four MFMAs instead of two --
+// the eight waves of the old shape all re-read the same fragments and the kernel sat at 38 % MFMA-busy behind its LDS
+// traffic -- with two 4-wave workgroups per CU so that one's barrier wait overlaps the other's MFMAs.
+template <int ABL, int QT = 2, int NW = 8>   // ABL 0 shipped; timing ablations: 1 no softmax arithmetic, 2 no MFMA, 3 no K/V fragment reads
+__global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
                                                           int dh, int dh_pad, int dv_pad, float scale_log2e,
                                                           uint16_t* __restrict__ out, int ldo, int tstride) {
@@ -1349,14 +1353,16 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
+    constexpr int PW = 24 / NW;   // DMA pieces per wave per stage
+    static_assert(NW * QT == 16 && 24 % NW == 0, "256 queries per workgroup");
     const int qblocks = (tokens + 255) / 256;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const int q0 = qb * 256 + wave * 32;
+    const int q0 = qb * 256 + wave * (QT * 16);
     const char* kp = reinterpret_cast<const char*>(k) + (size_t)bh * n_pad * ATT_KROW;
     const char* vp = reinterpret_cast<const char*>(vt + (size_t)bh * dv_pad * n_pad);
-    bf16x8 qf[2][3];
+    bf16x8 qf[QT][3];
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         int qrow = q0 + qt * 16 + i;
         if (qrow >= n_pad) qrow = n_pad - 1;
         const uint16_t* qp = q + ((size_t)bh * n_pad + qrow) * dh_pad;
@@ -1370,8 +1376,8 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
         const char* kb = kp + (size_t)tile * AT6_KT;
         const char* vb = vp + (size_t)tile * 128;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int id = wave + 8 * j;
+        for (int j = 0; j < PW; j++) {
+            const int id = wave + NW * j;
             if (id < 14) {
                 dma16_s(kb, (uint32_t)(id * 1024 + lane * 16), st + id * 1024);
             } else {
@@ -1383,17 +1389,19 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
     const int nt = (n_pad + 63) / 64;
     for (int t0 = 0; t0 < AT6_NS - 1 && t0 < nt; t0++) issue(t0);
 
-    float4v o[2][5];
+    float4v o[QT][5];
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++)
+    for (int qt = 0; qt < QT; qt++)
 #pragma unroll
         for (int t = 0; t < 5; t++)
 #pragma unroll
             for (int r = 0; r < 4; r++) o[qt][t][r] = 0.0f;
-    float m_run[2] = {-1e30f, -1e30f};
+    float m_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) m_run[qt] = -1e30f;
     const int vsw = (i >> 1) & 7;   // read-side swizzle of the Vt rows this lane reads (rows t*16 + i)
     for (int tile = 0; tile < nt; tile++) {
-        vm_wait_n(min(AT6_NS - 2, nt - 1 - tile) * 3);
+        vm_wait_n(min(AT6_NS - 2, nt - 1 - tile) * PW);
         __builtin_amdgcn_s_barrier();
         if (tile + AT6_NS - 1 < nt) issue(tile + AT6_NS - 1);
         const char* kst = lds + (tile % AT6_NS) * AT6_STAGE;
@@ -1403,9 +1411,9 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
             const int kt = tile * 64 + hh * 32;
             if (kt >= n_pad) break;
             const char* kl = kst + hh * 32 * ATT_KROW;
-            float4v s[2][2];
+            float4v s[QT][2];
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++)
+            for (int qt = 0; qt < QT; qt++)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
@@ -1416,12 +1424,12 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
                 for (int h2 = 0; h2 < 2; h2++) {
                     const bf16x8 kf = ABL == 3 ? qf[0][ks] : as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
                     if (ABL == 2) { s[0][h2][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kf[0]) << 16); continue; }
-                    s[0][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][h2], 0, 0, 0);
-                    s[1][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][h2], 0, 0, 0);
+#pragma unroll
+                    for (int qt = 0; qt < QT; qt++) s[qt][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][h2], 0, 0, 0);
                 }
             if (kt + 32 > tokens) {
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++)
+                for (int qt = 0; qt < QT; qt++)
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
@@ -1432,19 +1440,21 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
             // wave sees a score more than 2^8 above the running maximum nothing is exchanged between lanes and
             // p = exp2(s - m_run) <= 256.  Only when some lane votes is the true row maximum formed across the four
             // lane groups (two cross-lane exchanges) and O rescaled -- on the first tile and rarely afterwards.
-            float lmx[2];
+            float lmx[QT];
+            bool vote = false;
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) {
+            for (int qt = 0; qt < QT; qt++) {
                 if (ABL == 1) { lmx[qt] = m_run[qt]; continue; }
                 float mx = max3f(s[qt][0][0], s[qt][0][1], s[qt][0][2]);
                 mx = max3f(mx, s[qt][0][3], s[qt][1][0]);
                 mx = max3f(mx, s[qt][1][1], s[qt][1][2]);
                 mx = max3f(mx, s[qt][1][3], mx);
                 lmx[qt] = mx * scale_log2e;
+                vote = vote || (lmx[qt] - m_run[qt] > 8.0f);
             }
-            if (__any((lmx[0] - m_run[0] > 8.0f) || (lmx[1] - m_run[1] > 8.0f))) {
+            if (__any(vote)) {
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++) {
+                for (int qt = 0; qt < QT; qt++) {
                     float mx = lmx[qt];
                     mx = max3f(mx, __shfl_xor(mx, 16), mx);
                     mx = max3f(mx, __shfl_xor(mx, 32), mx);
@@ -1457,9 +1467,9 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
                         for (int r = 0; r < 4; r++) o[qt][t][r] *= alpha;
                 }
             }
-            bf16x8 pf[2];
+            bf16x8 pf[QT];
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) {
+            for (int qt = 0; qt < QT; qt++) {
                 float p[8];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++)
@@ -1476,7 +1486,7 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
                 const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + 2 + (g >> 1)) ^ vsw) * 16));
                 const bf16x8 vf = ABL == 3 ? pf[0] : as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++) {
+                for (int qt = 0; qt < QT; qt++) {
                     if (ABL == 2) { o[qt][t][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vf[0]) << 16) + __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, pf[qt][0]) << 16); continue; }
                     o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt], o[qt][t], 0, 0, 0);
                 }
@@ -1485,7 +1495,7 @@ __global__ __launch_bounds__(512) void attention64_kernel(const uint16_t* __rest
     }
     const int b = bh / heads, hd = bh % heads;
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         const int tok = q0 + qt * 16 + i;
         const float lsum = __shfl(o[qt][4][0], 32 + i);   // row dh = 72 of O^T holds sum(p)
         if (tok < tokens) {
@@ -1871,7 +1881,13 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
         hipLaunchKernelGGL(attention64_kernel<X>, dim3((unsigned)(B * heads * qblocks)), dim3(512), AT6_NS * AT6_STAGE, st, \
                            q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);             \
     }
-        if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else MSE_ATT64(0)
+        static const int att_qt = getenv("MSE_ATT_QT") ? atoi(getenv("MSE_ATT_QT")) : 4;   // developer knob: 2 = the round-1 shape
+        if (abl64 == 0 && att_qt == 4) {
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<0, 4, 4>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
+            hipLaunchKernelGGL((attention64_kernel<0, 4, 4>), dim3((unsigned)(B * heads * qblocks)), dim3(256), AT6_NS * AT6_STAGE, st,
+                               q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        } else if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else MSE_ATT64(0)
 #undef MSE_ATT64
         MSE_HIP_TRY(hipGetLastError());
         return 0;
