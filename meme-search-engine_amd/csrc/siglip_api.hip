@@ -54,6 +54,7 @@ struct mse_siglip {
     float *bq = nullptr, *bkv = nullptr, *bpp = nullptr, *lnp_g = nullptr, *lnp_b = nullptr, *bp1 = nullptr, *bp2 = nullptr;
     float* qlat = nullptr;
     // activations
+    int dp = 0;              // emb_dim rounded up to whole 256-column GEMM tiles (ld of the residual-branch buffer)
     void* img_dev = nullptr;
     uint16_t *patches = nullptr, *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *kvb = nullptr;
     uint16_t* x = nullptr;   // residual stream [M][D], fp16
@@ -103,7 +104,8 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     // 8- and 16-token pieces never straddle two images (the transposed V scatter of the QKV epilogue needs that)
     m->m_pad = round_up((size_t)m->max_batch * m->n_pad, 256);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
-    const size_t D = m->D, MP = m->mlp_pad;
+    const size_t D = m->D, MP = m->mlp_pad, DP = round_up(D, 256);
+    m->dp = (int)DP;
     // parameters (names: clip_server.py:40-57)
     m->add_bf16("trunk.patch_embed.proj.weight", &m->wpe, D, m->kpe, D, m->kpe_pad);
     m->add_f32("trunk.patch_embed.proj.bias", &m->bpe, 1, D);
@@ -115,10 +117,12 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
         const std::string p = "trunk.blocks." + std::to_string(i) + ".";
         m->add_f32(p + "norm1.weight", &b.ln1_g, 1, D); m->add_f32(p + "norm1.bias", &b.ln1_b, 1, D);
         m->add_bf16(p + "attn.qkv.weight", &b.wqkv, 3 * D, D, 3 * D, D); m->add_f32(p + "attn.qkv.bias", &b.bqkv, 1, 3 * D);
-        m->add_bf16(p + "attn.proj.weight", &b.wproj, D, D, D, D); m->add_f32(p + "attn.proj.bias", &b.bproj, 1, D);
+        // proj and fc2 write the residual branch: their N = D output columns are padded to whole 256-column tiles (zero weight
+        // rows, ld DP) so that the persistent 256 x 256 kernel covers them without the half-efficiency 128-column remainder launch
+        m->add_bf16(p + "attn.proj.weight", &b.wproj, D, D, DP, D); m->add_f32(p + "attn.proj.bias", &b.bproj, 1, D, DP);
         m->add_f32(p + "norm2.weight", &b.ln2_g, 1, D); m->add_f32(p + "norm2.bias", &b.ln2_b, 1, D);
         m->add_bf16(p + "mlp.fc1.weight", &b.w1, m->mlp, D, MP, D); m->add_f32(p + "mlp.fc1.bias", &b.b1, 1, m->mlp, MP);
-        m->add_bf16(p + "mlp.fc2.weight", &b.w2, D, m->mlp, D, MP); m->add_f32(p + "mlp.fc2.bias", &b.b2, 1, D);
+        m->add_bf16(p + "mlp.fc2.weight", &b.w2, D, m->mlp, DP, MP); m->add_f32(p + "mlp.fc2.bias", &b.b2, 1, D, DP);
     }
     m->add_f32("trunk.norm.weight", &m->lnf_g, 1, D); m->add_f32("trunk.norm.bias", &m->lnf_b, 1, D);
     const std::string ap = "trunk.attn_pool.";
@@ -135,7 +139,7 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->patches = m->dalloc<uint16_t>(M * m->kpe_pad, true);
     m->x = m->dalloc<uint16_t>(M * D, true);   // residual stream, fp16
     m->h = m->dalloc<uint16_t>(M * D, true);
-    m->dlt = m->dalloc<uint16_t>(M * D, true);
+    m->dlt = m->dalloc<uint16_t>(M * DP, true);
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
     m->qb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * m->dh_pad, true);   // one image of slack (rows of the M padding)
     m->kb = m->dalloc<uint16_t>((BH + m->H) * m->n_pad * attention_k_stride(), true);   // 224-byte rows (attention DMA)
@@ -297,7 +301,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         MSE_HIP_TRY(hipMemcpyAsync(m->img_dev, images, img_elems * (dtype ? 2 : 4), hipMemcpyHostToDevice, st));
         img = m->img_dev;
     }
-    const int D = m->D, T = m->tokens, TS = m->n_pad;
+    const int D = m->D, T = m->tokens, TS = m->n_pad, DP = m->dp;
     const int M = batch * TS;   // rows incl. the (finite, never read as keys) padding rows of every image
     const int Mp = (int)round_up(M, 256);
     const int gelu_tanh = c.gelu_tanh;
@@ -311,7 +315,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
     for (int i = 0; i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
         const Block& b = m->blocks[i];
         // x += (fc2 output of the previous block), then LayerNorm
-        if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
+        if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, DP, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
         {
             GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
             g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
@@ -320,23 +324,23 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         }
         if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;
         {
-            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M;
-            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
+            g.out_bf16 = m->dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm (columns >= D are padding)
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
-        if (launch_layernorm(m->x, 1, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
+        if (launch_layernorm(m->x, 1, D, m->dlt, DP, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
         {
             GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
             g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
             if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
         }
         {
-            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M;
-            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
+            g.out_bf16 = m->dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
     }
-    if (launch_layernorm(m->x, 1, D, c.depth ? m->dlt : nullptr, D, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
+    if (launch_layernorm(m->x, 1, D, c.depth ? m->dlt : nullptr, DP, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
     // MAPHead (model.py:82-111)
     {
         GemmLaunch g; g.x = m->h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;

@@ -1552,18 +1552,33 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const uint16_t* __r
                                                              const float* __restrict__ qlat, int heads, int dh,
                                                              int tokens, int tstride, float scale, float* __restrict__ out,
                                                              int ldo) {
+    // Round 2: 16-byte loads throughout.  A head's slice of a k / v row is dh * 2 = 144 contiguous bytes = nine 16-byte pieces
+    // (dh % 8 == 0 is checked by the launcher).  Scores: one thread per token reads its nine pieces.  Values: thread
+    // (token group tg, piece c) accumulates eight features over tokens tg, tg + NTG, ...; the NTG partial sums of a feature meet
+    // in LDS.  (The first version read 2 bytes per load at a 4.6 KB stride and kept 72 of 256 threads busy in the value loop:
+    // 2.6 ms per batch of 256 against the 0.2 ms its 0.87 GB of kv traffic need.)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sc = sm;             // [tokens]
-    float* red = sm + tokens;   // [256]
+    float* sc = sm;                       // [tokens]
+    float* red = sm + tokens;             // [256]
+    float* part = red + 256;              // [NTG][dh] partial value sums
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int D = heads * dh;
     const int tid = threadIdx.x;
+    const int np = dh / 8;                // 16-byte pieces per head slice (9)
     const float* qh = qlat + hd * dh;
     float lmax = -1e30f;
     for (int t = tid; t < tokens; t += blockDim.x) {
-        const uint16_t* kr = kv + ((size_t)b * tstride + t) * ldkv + hd * dh;
+        const uint4* kr = reinterpret_cast<const uint4*>(kv + ((size_t)b * tstride + t) * ldkv + hd * dh);
         float s = 0.0f;
-        for (int e = 0; e < dh; e++) s = fmaf(qh[e], bf2f(kr[e]), s);
+        for (int c = 0; c < np; c++) {
+            const uint4 w = kr[c];
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s = fmaf(qh[c * 8 + 2 * j], __builtin_bit_cast(float, ww[j] << 16), s);
+                s = fmaf(qh[c * 8 + 2 * j + 1], __builtin_bit_cast(float, ww[j] & 0xffff0000u), s);
+            }
+        }
         s *= scale;
         sc[t] = s;
         lmax = fmaxf(lmax, s);
@@ -1589,11 +1604,29 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const uint16_t* __r
         __syncthreads();
     }
     const float inv = 1.0f / red[0];
-    // out[e] = sum_t p[t] * v[t][e]: thread e handles one output feature
+    // out[e] = sum_t p[t] * v[t][e]
+    const int ntg = blockDim.x / np;      // token groups (28 at dh = 72)
+    const int tg = tid / np, c = tid % np;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (tg < ntg) {
+        for (int t = tg; t < tokens; t += ntg) {
+            const uint4 w = *reinterpret_cast<const uint4*>(kv + ((size_t)b * tstride + t) * ldkv + D + hd * dh + c * 8);
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            const float p = sc[t];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[2 * j] = fmaf(p, __builtin_bit_cast(float, ww[j] << 16), acc[2 * j]);
+                acc[2 * j + 1] = fmaf(p, __builtin_bit_cast(float, ww[j] & 0xffff0000u), acc[2 * j + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) part[tg * dh + c * 8 + j] = acc[j];
+    }
+    __syncthreads();
     for (int e = tid; e < dh; e += blockDim.x) {
-        float acc = 0.0f;
-        for (int t = 0; t < tokens; t++) acc = fmaf(sc[t], bf2f(kv[((size_t)b * tstride + t) * ldkv + D + hd * dh + e]), acc);
-        out[(size_t)b * ldo + hd * dh + e] = acc * inv;
+        float a = 0.0f;
+        for (int g2 = 0; g2 < ntg; g2++) a += part[g2 * dh + e];
+        out[(size_t)b * ldo + hd * dh + e] = a * inv;
     }
 }
 
@@ -1881,7 +1914,7 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
         hipLaunchKernelGGL(attention64_kernel<X>, dim3((unsigned)(B * heads * qblocks)), dim3(512), AT6_NS * AT6_STAGE, st, \
                            q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);             \
     }
-        static const int att_qt = getenv("MSE_ATT_QT") ? atoi(getenv("MSE_ATT_QT")) : 4;   // developer knob: 2 = the round-1 shape
+        static const int att_qt = getenv("MSE_ATT_QT") ? atoi(getenv("MSE_ATT_QT")) : 2;   // developer knob: 4 = four query tiles per wave, 4 waves (measured: no faster -- the kernel is not bound by its fragment reads)
         if (abl64 == 0 && att_qt == 4) {
             MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<0, 4, 4>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
@@ -1937,7 +1970,8 @@ int launch_vt_ones_row(uint16_t* vt, size_t n_mats, int dh, int dv_pad, int n_pa
 
 int launch_pool_attention(const uint16_t* kv, int ldkv, const float* qlat, int B, int heads, int dh, int tokens, int tstride,
                           float* out, int ldo, hipStream_t st) {
-    const size_t lds = (size_t)(tokens + 256) * 4;
+    if (dh % 8 || dh > 256 || ldkv % 8) return fail("pool attention: head width must be a multiple of 8 (16-byte pieces)");
+    const size_t lds = (size_t)(tokens + 256 + (256 / (dh / 8)) * dh) * 4;
     hipLaunchKernelGGL(pool_attention_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, st, kv, ldkv, qlat, heads, dh, tokens,
                        tstride, 1.0f / sqrtf((float)dh), out, ldo);
     MSE_HIP_TRY(hipGetLastError());
