@@ -161,6 +161,10 @@ constexpr int PQS_LUT_BYTES = 64 * 256 * 4;
 constexpr int PQS_STAGE = 4096 + 256;   // 64 code rows + 64 x 4 descriptor bytes
 constexpr int PQS_LDS = PQS_LUT_BYTES + PQS_WAVES * PQS_STAGE;
 
+// (M0 is written and consumed inside one asm statement; this kernel issues all of its DMA through these two helpers and has no
+// other use of M0 -- see the note at dma16_s in siglip_kernels.hip)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void pq_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);   // wave-uniform by construction; pin it to an SGPR
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
@@ -169,6 +173,7 @@ __device__ __forceinline__ void pq_dma4(const void* sbase, uint32_t voff, uint32
     lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // GMAX: instead of one i64 per vector (8 B written per 68 B read, and read again by the selection), the wave keeps only
 // the maximum of its 64 scores: out[group] (0.125 B per vector).  The r best vectors lie inside the r best groups by

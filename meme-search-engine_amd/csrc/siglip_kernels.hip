@@ -49,9 +49,18 @@ __device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
 
 // LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane offset: keeps tile bases out of the
 // vector registers.  M0 = LDS byte address of the wave's 1 KiB destination; one wait state after the M0 write.
+// M0 discipline: the write of M0 and the instruction that consumes it sit in ONE asm statement, so nothing the compiler
+// schedules can come between them, and a kernel uses EITHER this helper OR the compiler-managed builtin (dma16 above) for all
+// of its DMA, never both: gemm8pp_kernel and the attention kernels use only this one, the first-generation GEMMs only the
+// builtin.  No other instruction of those kernels reads M0 (gfx950 LDS instructions do not, and their register arrays are
+// indexed with compile-time constants only: no s_movrel).  M0 is named as clobbered all the same; clang notes that it cannot
+// promise to honour a clobber of a reserved register, which is why the separation above is what the code relies on.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below bf16 resolution by four orders of magnitude): one
 // reciprocal, one exp2, eight fused multiply-adds instead of libm's ~30-instruction erff in the GEMM epilogue
