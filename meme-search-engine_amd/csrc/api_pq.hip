@@ -176,6 +176,9 @@ void mse_pq_free(mse_pq* pq) {
     if (pq->centroids) (void)hipFree(pq->centroids);
     if (pq->transform) (void)hipFree(pq->transform);
     if (pq->transform_t) (void)hipFree(pq->transform_t);
+    if (pq->pin) (void)hipHostFree(pq->pin);
+    if (pq->scratch) mse_searcher_free(pq->scratch);
+    if (pq->lane2) mse_searcher_free(pq->lane2);
     delete pq;
 }
 
@@ -356,62 +359,66 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
     if (r > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
     for (size_t i = 0; i < nq * k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
     if (c->n == 0) return 0;
-    mse_searcher* s = s_or_null;
-    mse_searcher* tmp = nullptr;
-    if (!s) { tmp = scratch_searcher_new(); if (!tmp) return -1; s = tmp; }
-    if (s->base && s->base->n != c->n) { if (tmp) mse_searcher_free(tmp); return fail("base and codes differ in length"); }
-    if (s->base && s->base->d != pq->d) { if (tmp) mse_searcher_free(tmp); return fail("base width differs from the quantiser"); }
     std::lock_guard<std::mutex> g(pq->mu);
+    mse_searcher* s = s_or_null;
+    if (!s) {
+        if (!pq->scratch && !(pq->scratch = scratch_searcher_new())) return -1;
+        s = pq->scratch;
+    }
+    if (s->base && s->base->n != c->n) return fail("base and codes differ in length");
+    if (s->base && s->base->d != pq->d) return fail("base width differs from the quantiser");
     hipStream_t st = s->stream;
     const size_t d = pq->d;
     int rc = -1;
     do {
-        // all queries (+ scales) go up once; every query then runs back to back on the stream; one download at the end
+        // all queries (+ scales) go up in ONE copy from pinned memory; every query then runs on the streams; ONE download at the end
         const size_t sc_off = (nq * d * 4 + 255) & ~(size_t)255;
-        const size_t sc_bytes = c->n_desc * 4;
-        if (pq->a.ensure(sc_off + sc_bytes + 256) || pq->b.ensure(d * 4) || pq->c.ensure(pq->n_chunks * pq->n_centroids * 4)) break;
-        if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(nq * k * 8)) break;
-        DevBuf out_ids_dev;
-        if (out_ids_dev.ensure(nq * k * 4)) break;
-        if (hipMemcpyAsync(pq->a.p, queries_f32, nq * d * 4, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
-        float* scales_dev = nullptr;
-        if (scales && c->n_desc) {
-            scales_dev = reinterpret_cast<float*>(pq->a.as<char>() + sc_off);
-            if (hipMemcpyAsync(scales_dev, scales, sc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
+        const size_t sc_bytes = (scales && c->n_desc) ? c->n_desc * 4 : 0;
+        const size_t in_bytes = sc_off + sc_bytes, out_bytes = nq * k * 12;
+        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(d * 4) || pq->c.ensure(pq->n_chunks * pq->n_centroids * 4)) break;
+        if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(out_bytes)) break;
+        if (pq->pin_cap < std::max(in_bytes, out_bytes)) {
+            if (pq->pin) (void)hipHostFree(pq->pin);
+            pq->pin = nullptr; pq->pin_cap = 0;
+            const size_t want = std::max<size_t>(std::max(in_bytes, out_bytes) * 2, 1 << 16);
+            if (hipHostMalloc(&pq->pin, want, hipHostMallocDefault) != hipSuccess) { fail("pinned staging allocation failed"); break; }
+            pq->pin_cap = want;
         }
+        memcpy(pq->pin, queries_f32, nq * d * 4);
+        if (sc_bytes) memcpy(static_cast<char*>(pq->pin) + sc_off, scales, sc_bytes);
+        if (hipMemcpyAsync(pq->a.p, pq->pin, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { fail("H2D failed"); break; }
+        float* scales_dev = sc_bytes ? reinterpret_cast<float*>(pq->a.as<char>() + sc_off) : nullptr;
+        int64_t* const out_scores_dev = s->out_scores.as<int64_t>();
+        uint32_t* const out_ids_dev = reinterpret_cast<uint32_t*>(s->out_scores.as<char>() + nq * k * 8);
         // Queries alternate between two streams (each with its own scratch): the chain of small kernels that follows a scan
         // (tournament, re-score of the best groups, selects: ~0.2 ms, mostly single-workgroup launches) runs beside the NEXT
         // query's scan, which leaves a few CUs free for it (pq.hip launch_pq_scan_gmax).
         mse_searcher* lanes[2] = {s, nullptr};
-        DevBuf t2, lut2, qf2;
+        DevBuf &t2 = pq->t2, &lut2 = pq->lut2, &qf2 = pq->qf2;
         if (nq >= 4) {
-            lanes[1] = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
-            if (!lanes[1] || t2.ensure(d * 4) || lut2.ensure(pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) {
-                if (lanes[1]) mse_searcher_free(lanes[1]);
-                break;
-            }
-            if (hipStreamSynchronize(st) != hipSuccess) { mse_searcher_free(lanes[1]); fail("H2D failed"); break; }   // uploads visible to both streams
+            if (pq->lane2 && pq->lane2->base != s->base) { mse_searcher_free(pq->lane2); pq->lane2 = nullptr; }
+            if (!pq->lane2) pq->lane2 = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
+            lanes[1] = pq->lane2;
+            if (!lanes[1] || t2.ensure(d * 4) || lut2.ensure(pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
+            if (hipStreamSynchronize(st) != hipSuccess) { fail("H2D failed"); break; }   // uploads visible to both streams
         }
         bool ok = true;
         for (size_t q = 0; q < nq && ok; q++) {
             const int w = lanes[1] ? (int)(q & 1) : 0;
             ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, w ? t2.as<float>() : pq->b.as<float>(),
                                  w ? lut2.as<float>() : pq->c.as<float>(), w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>(),
-                                 scales_dev, r, k, s->out_scores.as<int64_t>() + q * k, out_ids_dev.as<uint32_t>() + q * k) == 0;
+                                 scales_dev, r, k, out_scores_dev + q * k, out_ids_dev + q * k) == 0;
         }
-        if (lanes[1]) {
-            if (hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
-            mse_searcher_free(lanes[1]);
-        }
+        if (lanes[1] && hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
         if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
-        if (hipMemcpyAsync(ids, out_ids_dev.p, nq * k * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(scores, s->out_scores.p, nq * k * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (hipMemcpyAsync(pq->pin, s->out_scores.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
+        memcpy(scores, pq->pin, nq * k * 8);
+        memcpy(ids, static_cast<char*>(pq->pin) + nq * k * 8, nq * k * 4);
         for (size_t i = 0; i < nq * k; i++)
             if (ids[i] == MSE_ID_NONE) scores[i] = INT64_MIN;
         rc = 0;
     } while (0);
-    if (tmp) mse_searcher_free(tmp);
     return rc;
 }
 

@@ -82,6 +82,11 @@ struct mse_pq {
     float* transform_t = nullptr;  // device [d][d], transposed copy for the one-vector (query) path
     std::mutex mu;
     mse::DevBuf a, b, c;              // call scratch (guarded by mu)
+    mse_searcher* scratch = nullptr;  // stream + scratch for scan calls that bring no searcher (guarded by mu; made on first use)
+    mse_searcher* lane2 = nullptr;    // second stream of the batched scan; bound to the base of the call that made it
+    mse::DevBuf t2, lut2, qf2;        // its transformed query, table and f16 query
+    void* pin = nullptr;              // pinned host staging of the scan entry points (one upload + one download per call, both
+    size_t pin_cap = 0;               // truly asynchronous: a pageable source makes the runtime stage and block per copy)
 };
 
 struct mse_codes {

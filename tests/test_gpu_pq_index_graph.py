@@ -116,6 +116,37 @@ def test_pq_scan_rerank_recall(gpu, mse, orc):
     assert recall >= 0.9, recall
 
 
+def test_pq_scan_batch_with_exact_rescore_equals_one_by_one(gpu, mse, orc):
+    """mse_pq_scan_topk_batch alternates its queries between two streams with separate scratch (the tail of one query runs beside
+    the next query's scan): every query's answer -- ADC top-r, exact fp16 re-score with descriptor bias, top-k -- must equal the
+    one-query-per-call answer and the oracle pipeline, in both the re-scored and the ADC-only form, for odd and even batch sizes."""
+    n, r, k = 9000, 120, 10
+    x = clustered_rows(orc, n, n_centres=32)
+    cents, T = train_pq(orc, x[:3000], iters=2)
+    base = orc.f16_bits(x)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = np.random.default_rng(3).integers(0, 256, size=(n, 4), dtype=np.uint8)
+    scales = np.array([0.5, 0, -0.25, 0.125], np.float32) / np.float32(512)
+    gcodes = mse.Codes(codes, desc)
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    queries = clustered_rows(orc, 9, n_centres=32, seed=11)
+    for nq in (9, 4, 3):
+        bs, bi = gpq.scan_topk_batch(gcodes, queries[:nq], r, k, searcher, scales)
+        as_, ai = gpq.scan_topk_batch(gcodes, queries[:nq], r, k, None, scales)
+        for j in range(nq):
+            qv = queries[j]
+            s1, i1 = gpq.scan_topk(gcodes, qv, r, k, searcher, scales)
+            assert np.array_equal(bs[j], s1) and np.array_equal(bi[j], i1), (nq, j)
+            approx = opq.adc_desc(opq.preprocess_query(qv), codes, desc, scales)
+            _, cand = orc.topk_from_scores(approx, r)
+            exact = orc.score_rows(base, cand, orc.f16_bits(qv)) + np.array([orc.descriptor_product(scales, desc, int(c)) for c in cand])
+            order = np.lexsort((cand, -exact))[:k]
+            assert np.array_equal(bi[j], cand[order]) and np.array_equal(bs[j], exact[order]), (nq, j)
+            ws, wi = orc.topk_from_scores(approx, k)
+            assert np.array_equal(ai[j], wi) and np.array_equal(as_[j], ws), (nq, j)
+
+
 @pytest.mark.parametrize("n,r,k", [(70, 200, 10), (4097, 64, 64), (12345, 200, 10), (64, 5, 5), (1, 3, 2)])
 def test_pq_scan_group_maxima_ragged_ties_and_batch(gpu, mse, orc, n, r, k):
     """The flat scan keeps one maximum per 64 vectors and re-scores the best groups: ragged sizes (fewer groups than r, a partial
