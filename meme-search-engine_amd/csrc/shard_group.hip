@@ -18,6 +18,7 @@
 #include "../../include/mse.h"
 #include "runtime.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <algorithm>
 #include <condition_variable>
 #include <functional>
@@ -162,8 +163,12 @@ mse_shard_group* mse_shard_group_new(const int* devices, size_t n_shards, size_t
     if (!G->root) { delete G; return nullptr; }
     for (size_t g = 0; g < n_shards; g++) G->threads.emplace_back([G, g] { G->worker(g); });
     // peer mappings towards the root, once per distinct device
-    const int rc = G->run([G](size_t g) -> int {
+    // test hook: MSE_SHARD_NO_PEER=1 sends every shard down the staged path (queries copied in, block copied back) that devices
+    // without a peer mapping take
+    const bool no_peer = getenv("MSE_SHARD_NO_PEER") != nullptr;
+    const int rc = G->run([G, no_peer](size_t g) -> int {
         Shard& sh = G->shards[g];
+        if (no_peer) { sh.peer = false; return 0; }
         if (sh.device == G->root_device) { sh.peer = true; return 0; }
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, sh.device, G->root_device) == hipSuccess && can) {

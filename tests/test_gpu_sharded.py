@@ -45,6 +45,23 @@ def test_shard_group_ties_across_shards_break_by_lower_global_id(gpu, mse, orc):
     grp.close()
 
 
+def test_shard_group_without_peer_mappings(gpu, mse, orc, monkeypatch):
+    """Devices that cannot map each other's memory take the staged path (queries copied to the shard's device, its block of
+    records copied back by hipMemcpyPeerAsync): forced here on the one device, same answer."""
+    monkeypatch.setenv("MSE_SHARD_NO_PEER", "1")
+    n, G, nq, k = 30_001, 5, 150, 10
+    base = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    want_s, want_i = orc.bruteforce_topk(base, q, k)
+    grp = mse.ShardGroup(G, D, devices=[0] * G)
+    assert not any(grp.peer_mapped(g) for g in range(G))
+    grp.load_host(base)
+    for mode in (mse.MODE_MFMA, mse.MODE_EXACT):
+        s, i = grp.bruteforce_topk(q, k, mode)
+        assert np.array_equal(i, want_i) and np.array_equal(s, want_s), mode
+    grp.close()
+
+
 def test_shard_group_errors(gpu, mse):
     with pytest.raises(mse.MseError):
         mse.ShardGroup(2, D, devices=[0, 99])
@@ -198,3 +215,29 @@ def test_config4_full_size_1e8_eight_shards(gpu, mse, orc):
     assert np.array_equal(sm, sm2) and np.array_equal(im, im2)
     assert all(grp.searcher(g).last_stats()["widened_queries"] == 0 for g in range(G))
     grp.close()
+
+
+def test_borrowed_base_rows_changed(gpu, mse, orc):
+    """A wrapped (borrowed) base caches its largest row norm -- the bound behind the MFMA scan's certificate.  After the caller
+    rewrites rows (here: scaled up 40x, far outside the cached bound) mse_base_rows_changed makes the next search measure it
+    again, and the batched answer equals the oracle's on the new contents."""
+    import torch
+    from mse import ffi
+    n, nq, k = 20_000, 24, 10
+    rows = orc.gen_rows_f16(SEED_BASE, 0, n)
+    t = torch.from_numpy(rows.view(np.int16).copy()).cuda()
+    vl = mse.VectorList.wrap_device(t.data_ptr(), n, D, keepalive=t)
+    s = mse.Searcher(vl)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    ws, wi = orc.bruteforce_topk(rows, q, k)
+    got = s.bruteforce_topk(q, k, mse.MODE_MFMA)
+    assert np.array_equal(got[0], ws) and np.array_equal(got[1], wi)
+    big = (orc.f16_to_f32(rows) * np.float32(40.0)).astype(np.float16).view(np.uint16)
+    big[::7] = rows[::7]                                   # mixed magnitudes: near ties between small and large rows matter
+    t.copy_(torch.from_numpy(big.view(np.int16)).cuda())
+    torch.cuda.synchronize()
+    ffi.check(ffi.lib().mse_base_rows_changed(vl._h))
+    ws2, wi2 = orc.bruteforce_topk(big, q, k)
+    got2 = s.bruteforce_topk(q, k, mse.MODE_MFMA)
+    assert np.array_equal(got2[0], ws2) and np.array_equal(got2[1], wi2)
+    assert not np.array_equal(wi, wi2)
