@@ -49,7 +49,9 @@
 //   the pass is bound by the chip's power budget (DVFS), not by a schedule.  LDS-DMA issue is not the limit either
 //   (scripts/microbench/dma_rate.hip: 137 GB/s per CU from L2 with >= 4 waves, 7.5 ns per 1 KiB piece).  What would lower
 //   the energy per row: wave tiles of 64 rows x 128 queries (a third fewer B-fragment LDS reads), not tried.
-//   Also without effect: fragment reads issued by hand (asm ds_read_b128 + counted lgkmcnt waits instead of the
+//   Also without effect: v_mfma_f32_32x32x16_f16 over the same LDS images (half the MFMA instructions, one fragment read per
+//   MFMA of twice the size; conflict-free with the same swizzle): 5.97 vs 5.80 ms; a 2-stage row ring instead of 3 (MSE_SCAN_S=2):
+//   5.96 vs 5.95 ms at 256 queries, 4.25 vs 4.17 at 128 -- the pass is not limited by rows in flight; fragment reads issued by hand (asm ds_read_b128 + counted lgkmcnt waits instead of the
 //   `s_waitcnt lgkmcnt(0)` hipcc puts in front of every MFMA group): 5.95 vs 6.06 ms on the same box, within noise.
 //   Per K block (32 KiB of rows + 32 KiB of query tile through the CU's load path) the pass takes 2.1 us where the rows alone
 //   take 1.4 us and the MFMAs alone 1.3 us; at 128 queries (48 KiB per K block) it takes 1.45 us.

@@ -35,3 +35,9 @@ wall = (time.perf_counter() - t0) / 5
 ms, k = s.scan_timing(0)
 print(f"abl={os.environ.get('MSE_SCAN_ABL', '0')} S={os.environ.get('MSE_SCAN_S', '3')} rows={n} nq={nq}: scan {ms / k:.3f} ms "
       f"({n * 2304 / (ms / k) / 1e6:.0f} GB/s), step {wall * 1e3:.3f} ms")
+if os.environ.get("CHECK"):   # the variant's answers against the exact-order kernel (first 8 queries)
+    chk_s = torch.empty((8, 10), dtype=torch.int64, device="cuda")
+    chk_i = torch.empty((8, 10), dtype=torch.int32, device="cuda")
+    s.bruteforce_topk_dev(qs.device_ptr, 8, 10, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT)
+    torch.cuda.synchronize()
+    print("answers equal the exact-order kernel:", bool(torch.equal(chk_s, out_s[:8]) and torch.equal(chk_i, out_i[:8])), s.last_stats())
