@@ -1363,10 +1363,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     constexpr int PW = 24 / NW;   // DMA pieces per wave per stage
-    static_assert(NW * QT == 16 && 24 % NW == 0, "256 queries per workgroup");
-    const int qblocks = (tokens + 255) / 256;
+    constexpr int QPW = NW * QT * 16;   // queries per workgroup = per pass over this (image, head)'s K / Vt
+    static_assert(24 % NW == 0, "24 DMA pieces per stage");
+    const int qblocks = (tokens + QPW - 1) / QPW;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    const int q0 = qb * 256 + wave * (QT * 16);
+    const int q0 = qb * QPW + wave * (QT * 16);
     const char* kp = reinterpret_cast<const char*>(k) + (size_t)bh * n_pad * ATT_KROW;
     const char* vp = reinterpret_cast<const char*>(vt + (size_t)bh * dv_pad * n_pad);
     bf16x8 qf[QT][3];
@@ -1924,7 +1925,14 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
                            q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);             \
     }
         static const int att_qt = getenv("MSE_ATT_QT") ? atoi(getenv("MSE_ATT_QT")) : 2;   // developer knob: 4 = four query tiles per wave, 4 waves (measured: no faster -- the kernel is not bound by its fragment reads)
-        if (abl64 == 0 && att_qt == 4) {
+        if (abl64 == 0 && att_qt == 3) {
+            // 8 waves x 3 query tiles = 384 queries per workgroup: 729 tokens take TWO passes over K / Vt instead of three
+            const int qb3 = (tokens + 383) / 384;
+            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<0, 3, 8>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
+            hipLaunchKernelGGL((attention64_kernel<0, 3, 8>), dim3((unsigned)(B * heads * qb3)), dim3(512), AT6_NS * AT6_STAGE, st,
+                               q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        } else if (abl64 == 0 && att_qt == 4) {
             MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<0, 4, 4>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
             hipLaunchKernelGGL((attention64_kernel<0, 4, 4>), dim3((unsigned)(B * heads * qblocks)), dim3(256), AT6_NS * AT6_STAGE, st,

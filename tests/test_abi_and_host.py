@@ -182,3 +182,17 @@ def test_topk_of_visited_sorts_by_exact_score(mse):
     assert top[0].tolist() == [6, 7, 5]                       # equal scores keep visit order; the fourth column is past n_visited
     assert top[1].tolist() == [1, 2, mse.ID_NONE]
     assert top[2].tolist() == [4, mse.ID_NONE, mse.ID_NONE]
+
+
+def test_bench_launch_shapes_are_checked_before_any_device_work():
+    """bench.py --gpus N runs bare (one process over N devices) or under torchrun (WORLD_SIZE = N): the two ways of getting that
+    wrong are reported at once, with no device needed."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "HIP device(s) visible" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
