@@ -29,6 +29,20 @@ SEED_BASE, SEED_QUERY = 0x5EED0001, 0x5EED0002
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+class _stdout_to_stderr:
+    """librccl prints a version banner on fd 1 when a communicator comes up; stdout is reserved for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def cpu_baseline(n_rows, k):
     """The oracle (C restatement of the reference's AVX2 `fast_dot` loop, oracle/mse_oracle.c) on the host cores, both modes of
     SURVEY 8(d), on a bounded sample: 1e6 rows x 1152 fp16 = 2.3 GB (ten copies of a 1e5-row generated block: larger than any
@@ -418,13 +432,15 @@ def main():
     #   torchrun (WORLD_SIZE = N): one process per GPU, ONE ncclAllGather of the packed records per step (mse_comm_*);
     #   bare `python bench.py --gpus N`: this one process drives all N devices, a host thread per shard, records written into
     #   the root device's buffer over peer mappings (mse_shard_group_*).
+    n_dev = ffi.lib().mse_device_count()
     in_process = world == 1 and args.gpus > 1
     n_gpus = args.gpus if in_process else world
     if world > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    n_dev = ffi.lib().mse_device_count()
     if in_process and n_dev < args.gpus and not args.logical_shards:
-        raise SystemExit(f"--gpus {args.gpus} but only {ffi.lib().mse_device_count()} HIP device(s) visible")
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} HIP device(s) visible")
+    if args.logical_shards and n_dev > 0:
+        local_rank %= n_dev          # developer dry run of the torchrun shape on fewer devices (RCCL then refuses: fallback path)
     torch.cuda.set_device(local_rank)
     ffi.check(ffi.lib().mse_set_device(local_rank), "mse_set_device")
     dist = None
@@ -432,7 +448,9 @@ def main():
         import torch.distributed as dist
         # control plane only (barrier, the 128-byte RCCL id, max of the timings); the data path's collective is RCCL, called
         # from C++ on the searcher's stream
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with _stdout_to_stderr():      # gloo announces its connections on fd 1
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
 
     def sync_all():
         if in_process:
@@ -465,6 +483,7 @@ def main():
     out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
     out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
     comm = group = None
+    host_exchange = None
     exchange = None
     if in_process:
         group = mse.ShardGroup(n_gpus, D, devices=[g % n_dev for g in range(n_gpus)])
@@ -482,20 +501,61 @@ def main():
         vecs = mse.VectorList.generate(SEED_BASE, lo, hi - lo, D)       # shard rows made on the device
         searcher = mse.Searcher(vecs)
         if world > 1:
-            ids = [mse.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = mse.Comm(ids[0], rank, world)
-            exchange = {"kind": "one process per GPU; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record blocks per step",
-                        "ranks": comm.size, "bytes_per_rank_per_step": int(ffi.lib().mse_topk_block_bytes(nq, k))}
-            if comm.size != world:
-                raise SystemExit(f"RCCL reports {comm.size} ranks, expected {world}")
+            # the exchange of the product path: RCCL through the C ABI.  Every rank reports whether its communicator came up; if any
+            # did not (no usable bootstrap interface, ...) ALL ranks fall back to carrying the same packed blocks over the gloo
+            # control plane and merging them with the same device kernel -- slower, loudly labelled, but the line is still measured.
+            err = ""
+            with _stdout_to_stderr():
+                try:
+                    ids = [mse.Comm.unique_id() if rank == 0 else None]
+                except Exception as e:  # noqa: BLE001
+                    ids, err = [None], repr(e)
+                dist.broadcast_object_list(ids, src=0)
+                if ids[0] is not None:
+                    try:
+                        comm = mse.Comm(ids[0], rank, world)
+                        if comm.size != world:
+                            err = f"RCCL reports {comm.size} ranks, expected {world}"
+                    except Exception as e:  # noqa: BLE001
+                        err = repr(e)
+                elif not err:
+                    err = "rank 0 could not create the RCCL id"
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            if any(flags):
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                host_exchange = next(f for f in flags if f)
+                print(f"[bench] RCCL exchange unavailable ({host_exchange}); falling back to a gloo all-gather of the packed blocks", file=sys.stderr)
+                B_blk = int(ffi.lib().mse_topk_block_bytes(nq, k))
+                blk = torch.zeros(B_blk, dtype=torch.uint8, device="cuda")
+                gathered_dev = torch.empty(world * B_blk, dtype=torch.uint8, device="cuda")
+                gathered_host = [torch.empty(B_blk, dtype=torch.uint8) for _ in range(world)]
+                exchange = {"kind": "FALLBACK: gloo all-gather of the packed 12 B/record blocks through host memory + device merge "
+                                    f"(RCCL init failed: {host_exchange})", "ranks": world, "bytes_per_rank_per_step": B_blk}
+            else:
+                exchange = {"kind": "one process per GPU; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record blocks per step",
+                            "ranks": comm.size, "bytes_per_rank_per_step": int(ffi.lib().mse_topk_block_bytes(nq, k))}
 
         def step(i):
             qptr = qsets.device_ptr + (i % n_batches) * nq * D * 2
-            if comm is None:
+            if host_exchange is not None:
+                host_step(qptr, nq, mse.MODE_MFMA, out_s, out_i)
+            elif comm is None:
                 searcher.bruteforce_topk_dev(qptr, nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=lo)
             else:
                 comm.search_dev(searcher, qptr, nq, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=lo)
+
+        def host_step(qptr, n_q, mode, dst_s, dst_i):
+            # fallback exchange: local search into the packed block, gloo all-gather through host memory, packed merge on the device
+            bb = int(ffi.lib().mse_topk_block_bytes(n_q, k))
+            searcher.bruteforce_topk_dev(qptr, n_q, k, blk.data_ptr(), blk.data_ptr() + n_q * k * 8, mode, id_offset=lo)
+            torch.cuda.synchronize()
+            parts = [torch.empty(bb, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, blk[:bb].cpu())
+            gathered_dev[:world * bb].copy_(torch.cat(parts))
+            ffi.check(ffi.lib().mse_merge_topk_packed_dev(searcher._h, gathered_dev.data_ptr(), world, n_q, k, dst_s.data_ptr(), dst_i.data_ptr()))
 
     for i in range(args.warmup):
         step(i)
@@ -521,6 +581,8 @@ def main():
             qptr = qsets.device_ptr + (i % n_batches) * nq * D * 2
             if in_process:
                 group.bruteforce_topk_dev(qptr, 128, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA)
+            elif host_exchange is not None:
+                host_step(qptr, 128, mse.MODE_MFMA, out_s, out_i)
             elif comm is not None:
                 comm.search_dev(searcher, qptr, 128, k, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA, id_offset=lo)
             else:
@@ -542,6 +604,8 @@ def main():
     chk_i = torch.empty((m, k), dtype=torch.int32, device="cuda")
     if in_process:
         group.bruteforce_topk_dev(qptr, m, k, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT)
+    elif host_exchange is not None:
+        host_step(qptr, m, mse.MODE_EXACT, chk_s, chk_i)
     elif comm is not None:
         comm.search_dev(searcher, qptr, m, k, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT, id_offset=lo)
     else:

@@ -194,6 +194,10 @@ def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph,
     if as_arrays:
         return {"buf_ids": bi, "buf_scores": bs, "buf_len": bl, "visited_ids": vi, "visited_scores": vs, "n_visited": nv, "cmps": cm,
                 "pq_cmps": pc}
+    if int(nv.max(initial=0)) > visited_cap:
+        # the reference keeps every visited record (query_disk_index.rs:168-186); a silently shortened list would change results
+        raise MseError(f"a search visited {int(nv.max())} records but visited_cap is {visited_cap}: raise visited_cap "
+                       "(as_arrays=True returns the truncated arrays together with n_visited instead)")
     out = []
     for i in range(nq):
         k = min(int(nv[i]), visited_cap)
