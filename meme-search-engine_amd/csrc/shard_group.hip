@@ -161,7 +161,14 @@ mse_shard_group* mse_shard_group_new(const int* devices, size_t n_shards, size_t
     G->root = scratch_searcher_new();
     (void)hipSetDevice(prev);
     if (!G->root) { delete G; return nullptr; }
-    for (size_t g = 0; g < n_shards; g++) G->threads.emplace_back([G, g] { G->worker(g); });
+    try {
+        for (size_t g = 0; g < n_shards; g++) G->threads.emplace_back([G, g] { G->worker(g); });
+    } catch (...) {   // nothing may be thrown across the ABI: a thread that could not start is an error like any other
+        fail("shard group: could not start the worker threads");
+        G->shards.resize(G->threads.size());   // run() waits for exactly the workers that exist
+        mse_shard_group_free(G);
+        return nullptr;
+    }
     // peer mappings towards the root, once per distinct device
     // test hook: MSE_SHARD_NO_PEER=1 sends every shard down the staged path (queries copied in, block copied back) that devices
     // without a peer mapping take
@@ -270,8 +277,8 @@ int mse_shard_group_search_dev(mse_shard_group* G, const void* queries_dev, size
     if (!G) return fail("null shard group");
     if (nq == 0 || k == 0) return 0;
     if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
-    for (const Shard& s : G->shards) if (!s.searcher) return fail("shard group: a shard holds no rows yet");
     std::lock_guard<std::mutex> call(G->call_mu);
+    for (const Shard& s : G->shards) if (!s.searcher) return fail("shard group: a shard holds no rows yet");
     const size_t n_shards = G->shards.size();
     const size_t B = block_bytes(nq, k), qbytes = nq * G->d * 2;
     int prev = 0;
