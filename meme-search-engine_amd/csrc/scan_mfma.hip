@@ -49,6 +49,10 @@
 //   the pass is bound by the chip's power budget (DVFS), not by a schedule.  LDS-DMA issue is not the limit either
 //   (scripts/microbench/dma_rate.hip: 137 GB/s per CU from L2 with >= 4 waves, 7.5 ns per 1 KiB piece).  What would lower
 //   the energy per row: wave tiles of 64 rows x 128 queries (a third fewer B-fragment LDS reads), not tried.
+//   PMC counters (profiles/r02_pmc_scan_1e7.txt): 1.53 GHz and 62 % MFMA-busy at 256 queries, 1.84 GHz and 38 % at 128; both
+//   passes pull ~19 B per cycle per CU through the vector L1 (rows + query tiles), which suggested that path as the bound --
+//   but a 128-query kernel with 64 rows per wave (512-row tiles: a query tile fetched once per 512 rows, 17 % fewer L1 bytes
+//   per row, 2-stage ring) ran 4.33 vs 4.20 ms at 1e7 rows and 42.0 vs 41.0 ms at 1e8: not that either.
 //   Also without effect: v_mfma_f32_32x32x16_f16 over the same LDS images (half the MFMA instructions, one fragment read per
 //   MFMA of twice the size; conflict-free with the same swizzle): 5.97 vs 5.80 ms; a 2-stage row ring instead of 3 (MSE_SCAN_S=2):
 //   5.96 vs 5.95 ms at 256 queries, 4.25 vs 4.17 at 128 -- the pass is not limited by rows in flight; fragment reads issued by hand (asm ds_read_b128 + counted lgkmcnt waits instead of the
