@@ -299,13 +299,16 @@ __global__ __launch_bounds__(GW * 64) void gemm_kernel(GemmArgs a) {
 // instruction covers 16 rows), 4-stage ring of 32 KiB stages, one barrier per K step.
 // Swizzle for 64-byte rows: LDS slot (row, s) holds global 16-byte piece s ^ T[(row >> 2) & 3], T = {0,3,2,1},
 // which makes every ds_read_b128 service group hit 16 distinct 16-byte bank slots.
-constexpr int B2 = 256, BK2 = 32, GS2 = 4;
+constexpr int B2 = 256, BK2 = 32;
+[[maybe_unused]] constexpr int GS2 = 4;
 constexpr int T2_BYTES = B2 * BK2 * 2;        // 16 KiB per operand tile
-constexpr int STAGE2_BYTES = 2 * T2_BYTES;    // 32 KiB
+[[maybe_unused]] constexpr int STAGE2_BYTES = 2 * T2_BYTES;    // 32 KiB
 constexpr int LDS256_BYTES = 8 * 64 * 272;   // max(4 stages = 128 KiB, epilogue staging = 136 KiB)
 
 __device__ __forceinline__ int swz64(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }  // T = {0,3,2,1}
 
+// First 256 x 256 kernel (round 1, superseded by the ping-pong kernels below): built only with -DMSE_DEV_KERNELS, for A/B timing.
+#ifdef MSE_DEV_KERNELS
 // ABL: developer ablation (0 = shipped kernel, 1 = no MFMA, 2 = no DMA in the loop, 3 = no LDS fragment reads)
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
@@ -433,6 +436,8 @@ __global__ __launch_bounds__(GW * 64) void gemm256_kernel(GemmArgs a) {
                 store_quad<EPI>(a, m0 + wm * 64 + mt * 16 + i, (int)n0 + wn * 128 + nt * 16 + 4 * g, acc[nt][mt]);
     }
 }
+
+#endif  // MSE_DEV_KERNELS
 
 // ---------------------------------------------------------------------------------------------------------
 // 256 x 256 x 64 GEMM, two wave groups in ping-pong ("8 phases per two K tiles").
@@ -1154,9 +1159,9 @@ __global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, 
 // with 4 waves.  Waves 0-6 issue the 7 K pieces, waves 0-4 the 5 Vt pieces of each tile.
 constexpr int ATT_KROW = 224;
 constexpr int ATT_KTILE = 32 * ATT_KROW, ATT_VTILE = 80 * 64;
-constexpr int ATT_STAGE = ATT_KTILE + ATT_VTILE;   // 12 KiB
+[[maybe_unused]] constexpr int ATT_STAGE = ATT_KTILE + ATT_VTILE;   // 12 KiB
 constexpr int ATT_KSTRIDE = ATT_KROW / 2;           // k row stride in elements (global)
-constexpr int ATT_NS = 3;                           // ring stages: tiles t+1 .. t+3 are in flight while tile t is consumed
+[[maybe_unused]] constexpr int ATT_NS = 3;                           // ring stages: tiles t+1 .. t+3 are in flight while tile t is consumed
 
 __device__ __forceinline__ void vm_wait_n(int n) {   // n: wave-uniform, 0..9
     switch (n) {
@@ -1177,6 +1182,8 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {   // one ins
     return d;
 }
 
+// 32-key-stage attention (round 1, superseded by attention64_kernel below): built only with -DMSE_DEV_KERNELS.
+#ifdef MSE_DEV_KERNELS
 template <int NW, int ABL = 0>   // waves per workgroup (4 or 8); NW * 32 queries share the K / Vt stream.  ABL: timing ablations
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                         const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
@@ -1335,6 +1342,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
         }
     }
 }
+
+#endif  // MSE_DEV_KERNELS
 
 // ---------------------------------------------------------------------------------------------------------
 // Same attention with 64-key ring stages: one barrier and one counted wait per 64 keys, the two 32-key halves of a
@@ -1712,28 +1721,41 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
     if (dev < 64 && !attr_set[dev]) {
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, GS * STAGE_BYTES));
+#ifdef MSE_DEV_KERNELS
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+#endif
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
         attr_set[dev] = true;
     }
     static const bool force128 = getenv("MSE_GEMM_128") != nullptr;   // developer knobs: older kernels only
     static const bool old256 = getenv("MSE_GEMM_OLD256") != nullptr;
-    const int n256 = force128 ? 0 : (a_in.N / B2) * B2;
+    // the ping-pong kernels want K >= 128 and, for the QKV scatter, 8-token / 8-column pieces inside WG-uniform q/k/v tiles;
+    // anything else (no shipped configuration) runs the first-generation 256 x 128 kernel over all of N
+    const bool pp_ok = a_in.K >= 128 &&
+                       (EPI != EPI_QKV || (a_in.tokens % 8 == 0 && a_in.tokens >= 64 && a_in.n_pad % 8 == 0 && a_in.dh % 8 == 0 && a_in.dh >= 64 &&
+                                           (a_in.heads * a_in.dh) % 64 == 0 && (2 * a_in.heads * a_in.dh) % 256 == 0 && a_in.m_valid % 8 == 0));
+    bool use256 = !force128 && pp_ok;
+#ifdef MSE_DEV_KERNELS
+    if (old256 && !force128) use256 = true;
+#else
+    (void)old256;
+#endif
+    const int n256 = use256 ? (a_in.N / B2) * B2 : 0;
     if (n256 > 0) {
         GemmArgs a = a_in;
         a.N = n256;
         const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
-        // the ping-pong kernel's QKV scatter works on 8-token / 8-column pieces and WG-uniform q/k/v tiles
-        const bool qkv_ok = EPI != EPI_QKV || (a.tokens % 8 == 0 && a.tokens >= 64 && a.n_pad % 8 == 0 && a.dh % 8 == 0 && a.dh >= 64 &&
-                                               (a.heads * a.dh) % 64 == 0 && (2 * a.heads * a.dh) % 256 == 0 && a.m_valid % 8 == 0);
         static const bool nopersist = getenv("MSE_GEMM_NOPERSIST") != nullptr;
         constexpr bool store_only = EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV;
         const unsigned cus = (unsigned)mse::device_cu_count();
-        if (old256 || a.K < 128 || !qkv_ok) {
+#ifdef MSE_DEV_KERNELS
+        if (old256 || !pp_ok) {
             hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(GW * 64), LDS256_BYTES, st, a);
-        } else if constexpr (store_only) {
+        } else
+#endif
+        if constexpr (store_only) {
             // persistent ping-pong kernel; for QKV the q/k columns [0, 2D) and the (transposed) v columns are two launches
             static bool pattr[64] = {};
             if (dev < 64 && !pattr[dev]) {
@@ -1812,7 +1834,7 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
     a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid; a.n_off = 0;
     a.out_bf16 = g.out_bf16; a.ldo = g.ldo;
     const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
-    const size_t lds = LDS256_BYTES;
+    [[maybe_unused]] const size_t lds = LDS256_BYTES;
 #define MSE_ABL(X)                                                                                              \
     case X:                                                                                                     \
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_GELU, X>),             \
@@ -1820,7 +1842,9 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
         hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, X>), dim3(grid), dim3(GW * 64), lds, st, a);               \
         break;
     switch (abl) {
+#ifdef MSE_DEV_KERNELS
         MSE_ABL(0) MSE_ABL(1) MSE_ABL(2) MSE_ABL(3)
+#endif
 #define MSE_ABL8(X)                                                                                             \
     case 10 + X:                                                                                                \
         MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_GELU, X>),              \
@@ -1942,6 +1966,7 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
         MSE_HIP_TRY(hipGetLastError());
         return 0;
     }
+#ifdef MSE_DEV_KERNELS
     if (abl == 1 || abl == 2) {
         const int qblocks = (tokens + 255) / 256;
         if (abl == 1) hipLaunchKernelGGL((attention_kernel<8, 1>), dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
@@ -1957,6 +1982,10 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
     }
     MSE_HIP_TRY(hipGetLastError());
     return 0;
+#else
+    (void)nw;
+    return fail("attention: MSE_ATT_TILE32 / MSE_ATT_ABL need a build with -DMSE_DEV_KERNELS");
+#endif
 }
 
 int launch_bmp24_to_nchw_f16(const uint8_t* in, size_t img_stride, int row_stride, const uint8_t* flags, void* out, int B, int H, int W,
