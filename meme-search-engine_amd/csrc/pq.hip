@@ -36,6 +36,57 @@ __global__ __launch_bounds__(TT* TT) void pq_transform_kernel(const float* __res
     if (i0 + ti < (size_t)d && j0 + tj < n) out[(j0 + tj) * d + i0 + ti] = acc;
 }
 
+// Register-tiled form for batches (index packing transforms every record): a thread owns a 4 x 4 block of outputs, a workgroup
+// 64 (i) x 64 (j); operand tiles are stored k-major in LDS so that one ds_read_b128 delivers T[i..i+3][k] (or x[j..j+3][k]) and
+// 16 fused multiply-adds follow.  Every output still accumulates k = 0 .. d-1 in ascending order with one fmaf per term, so the
+// result is bit-identical to the kernel above (and to the oracle); 2 LDS values per 16 FMAs instead of 2 per FMA.
+constexpr int T4_B = 64, T4_K = 32;
+__global__ __launch_bounds__(256) void pq_transform_tiled_kernel(const float* __restrict__ T, int d, const float* __restrict__ x, size_t n,
+                                                                 float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float Ts[T4_K][T4_B + 4];
+    __shared__ __attribute__((aligned(16))) float Xs[T4_K][T4_B + 4];
+    const int tid = threadIdx.x;
+    const int ti = tid & 15, tj = tid >> 4;
+    const size_t i0 = (size_t)blockIdx.x * T4_B, j0 = (size_t)blockIdx.y * T4_B;
+    float acc[4][4];   // [b: vector j][a: output i]
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) acc[b][a] = 0.0f;
+    for (int k0 = 0; k0 < d; k0 += T4_K) {
+#pragma unroll
+        for (int r = 0; r < (T4_B * T4_K) / 256; r++) {
+            const int e = tid + 256 * r;
+            const int kk = e % T4_K, row = e / T4_K;           // consecutive threads walk k: 128-byte runs of one row
+            const bool kin = k0 + kk < d;
+            Ts[kk][row] = (kin && i0 + row < (size_t)d) ? T[(i0 + row) * d + k0 + kk] : 0.0f;
+            Xs[kk][row] = (kin && j0 + row < n) ? x[(j0 + row) * d + k0 + kk] : 0.0f;
+        }
+        __syncthreads();
+        const int kmax = d - k0 < T4_K ? d - k0 : T4_K;
+        for (int kk = 0; kk < kmax; kk++) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&Ts[kk][ti * 4]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Xs[kk][tj * 4]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) acc[b][a] = fmaf(av[a], bv[b], acc[b][a]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const size_t j = j0 + tj * 4 + b;
+        if (j >= n) continue;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const size_t i = i0 + ti * 4 + a;
+            if (i < (size_t)d) out[j * d + i] = acc[b][a];
+        }
+    }
+}
+
 // The same product for ONE vector (the query path): thread i owns out[i] and runs the identical k-ascending chain of fused
 // multiply-adds, reading the TRANSPOSED matrix Tt[k][i] so that a wave's loads are contiguous (the tiled kernel above keeps
 // 16 of its 256 threads busy when n = 1).
@@ -103,6 +154,50 @@ __global__ void pq_quantize_kernel(const float* __restrict__ centroids, int n_ce
         if (s > best) { best = s; code = c; }
     }
     codes[idx] = (uint8_t)code;
+}
+
+// The same arithmetic, organised for throughput (index packing encodes every record: src/dump_processor.rs:470,523).  The
+// kernel above gives one thread one (vector, sub-space) pair and lets it stream 256 x dpc centroid values from global memory:
+// 6.9 ms per 8192-row batch, 1 % of the fp32 rate.  Here a workgroup takes ONE sub-space and 256 x VPT vectors: the 256 x DPC
+// centroid block sits in LDS (18 KiB at DPC = 18), a thread keeps its VPT vectors' DPC transformed values in registers and
+// walks the centroids in ascending order -- every LDS value is a wave-wide broadcast and feeds VPT fused multiply-adds.  Each
+// dot is the same chain of DPC fmaf in ascending u, the comparison the same strict `>` in ascending c: bit-identical codes.
+template <int DPC, int VPT>
+__global__ __launch_bounds__(256) void pq_quantize_tiled_kernel(const float* __restrict__ centroids, int n_centroids, int d,
+                                                                const float* __restrict__ t, size_t n, uint8_t* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) float cs[];   // [n_centroids][DPC]
+    const int n_chunks = d / DPC;
+    const int chunk = blockIdx.y;
+    for (int e = threadIdx.x; e < n_centroids * DPC; e += blockDim.x)
+        cs[e] = centroids[(size_t)(e / DPC) * d + chunk * DPC + e % DPC];
+    __syncthreads();
+    const size_t v0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VPT;
+    float tv[VPT][DPC];
+#pragma unroll
+    for (int j = 0; j < VPT; j++) {
+        const size_t v = v0 + j < n ? v0 + j : (n ? n - 1 : 0);
+#pragma unroll
+        for (int u = 0; u < DPC; u++) tv[j][u] = t[v * d + chunk * DPC + u];
+    }
+    float best[VPT];
+    int code[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; j++) { best[j] = -__builtin_inff(); code[j] = 0; }
+    for (int c = 0; c < n_centroids; c++) {
+        float cv[DPC];
+#pragma unroll
+        for (int u = 0; u < DPC; u++) cv[u] = cs[c * DPC + u];
+#pragma unroll
+        for (int j = 0; j < VPT; j++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int u = 0; u < DPC; u++) s = fmaf(tv[j][u], cv[u], s);
+            if (s > best[j]) { best[j] = s; code[j] = c; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; j++)
+        if (v0 + j < n) codes[(v0 + j) * n_chunks + chunk] = (uint8_t)code[j];
 }
 
 // asymmetric_dot_product (vector.rs:387-405) with the table in LDS: per vector, s = 0; for chunk i
@@ -303,6 +398,13 @@ __global__ __launch_bounds__(256) void rank_kernel(const int64_t* __restrict__ s
 
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream) {
     if (n == 0) return 0;
+    static const bool old_t = getenv("MSE_PQ_OLDTRANSFORM") != nullptr;   // developer knob
+    if (n >= 32 && !old_t) {
+        dim3 grid4((d + T4_B - 1) / T4_B, (unsigned)((n + T4_B - 1) / T4_B));
+        hipLaunchKernelGGL(pq_transform_tiled_kernel, grid4, dim3(256), 0, stream, T, d, x, n, out);
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     dim3 grid((d + TT - 1) / TT, (unsigned)((n + TT - 1) / TT));
     hipLaunchKernelGGL(pq_transform_kernel, grid, dim3(TT * TT), 0, stream, T, d, x, n, out);
     MSE_HIP_TRY(hipGetLastError());
@@ -332,6 +434,16 @@ int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, 
                        uint8_t* codes, hipStream_t stream) {
     const size_t total = n * (size_t)(d / dpc);
     if (total == 0) return 0;
+    static const bool old_q = getenv("MSE_PQ_OLDQUANT") != nullptr;   // developer knob
+    if (dpc == 18 && n_centroids <= 256 && !old_q) {       // the reference's codec shape (aopq_train.py:9-13)
+        constexpr int VPT = 4;
+        const size_t per_block = 256 * VPT;
+        dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)(d / dpc));
+        hipLaunchKernelGGL((pq_quantize_tiled_kernel<18, VPT>), grid, dim3(256), (size_t)n_centroids * 18 * 4, stream, centroids,
+                           n_centroids, d, t, n, codes);
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(pq_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, centroids,
                        n_centroids, d, dpc, t, n, codes);
     MSE_HIP_TRY(hipGetLastError());
