@@ -29,19 +29,53 @@ __global__ void shard_keys_kernel(const float* __restrict__ centroids, int n_sha
     keys[s] = scale_dot_result_f64(acc);
 }
 
-// running mean of lib.rs:55-58, one thread per component; rows are read coalesced (consecutive components)
-__global__ void centroid_kernel(const uint16_t* __restrict__ base, size_t n, int d, uint16_t* __restrict__ mean) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= d) return;
-    const __half* b = reinterpret_cast<const __half*>(base);
+// running mean of lib.rs:55-58: c += (row - c) * (1 / (i + 1)) row after row, in f32 -- a sequential chain per component.
+// One thread per component carries the chain; what the first version got wrong was feeding it: every step waited for its own
+// 2-byte global load (384 ns per row, 38 s at 1e8 rows).  Here a workgroup of 1024 threads owns 128 components: all threads
+// fetch the next 64 rows' 256-byte slices (16 bytes each) into registers while 128 of them walk the current 64 rows out of LDS,
+// so the chain (three dependent f32 operations per row) is the only thing on the critical path.  Same operations in the same
+// order as before (and as the oracle): identical result.
+constexpr int CEN_COMP = 128, CEN_ROWS = 64;
+__global__ __launch_bounds__(1024) void centroid_kernel(const uint16_t* __restrict__ base, size_t n, int d, uint16_t* __restrict__ mean) {
+    __shared__ __attribute__((aligned(16))) float tile[2][CEN_ROWS][CEN_COMP];   // rows already widened to f32 (exact)
+    __shared__ float wt[2][CEN_ROWS];                                              // 1 / (i + 1), IEEE f32 division, per row
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * CEN_COMP;
+    const int lrow = tid >> 4, piece = tid & 15;                       // loader role: row of the chunk, 16-byte piece of the slice
+    const bool piece_ok = k0 + piece * 8 < d;                           // d is a multiple of 8 (checked by the caller)
+    auto fetch = [&](size_t chunk) -> uint4 {
+        const size_t r = chunk * CEN_ROWS + lrow;
+        if (r < n && piece_ok) return *reinterpret_cast<const uint4*>(base + r * d + k0 + piece * 8);
+        return uint4{0u, 0u, 0u, 0u};
+    };
+    const size_t n_chunks = (n + CEN_ROWS - 1) / CEN_ROWS;
+    uint4 next = fetch(0);
     float c = 0.0f;
-    for (size_t r = 0; r < n; r++) {
-        const float w = 1.0f / (float)(r + 1);
-        const float diff = __half2float(b[r * d + k]) - c;
-        const float step = diff * w;
-        c = c + step;
+    for (size_t chunk = 0; chunk < n_chunks; chunk++) {
+        const int buf = (int)(chunk & 1);
+        {
+            const uint32_t w4[4] = {next.x, next.y, next.z, next.w};
+            float* dst = &tile[buf][lrow][piece * 8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                dst[2 * j] = __half2float(__ushort_as_half((unsigned short)(w4[j] & 0xffffu)));
+                dst[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w4[j] >> 16)));
+            }
+            if (tid < CEN_ROWS) wt[buf][tid] = 1.0f / (float)(chunk * CEN_ROWS + tid + 1);
+        }
+        __syncthreads();                                                // also: everybody is done with tile[buf] of two chunks ago
+        if (chunk + 1 < n_chunks) next = fetch(chunk + 1);
+        if (tid < CEN_COMP) {
+            const size_t r0 = chunk * CEN_ROWS;
+            const int rows = (int)(n - r0 < (size_t)CEN_ROWS ? n - r0 : (size_t)CEN_ROWS);
+            for (int rr = 0; rr < rows; rr++) {
+                const float diff = tile[buf][rr][tid] - c;
+                const float step = diff * wt[buf][rr];
+                c = c + step;
+            }
+        }
     }
-    reinterpret_cast<__half*>(mean)[k] = __float2half_rn(c);
+    if (tid < CEN_COMP && k0 + tid < d) reinterpret_cast<__half*>(mean)[k0 + tid] = __float2half_rn(c);
 }
 
 // `dot` (vector.rs:49-52) in the order the oracle states for simsimd: exact products, f64 sum in index order
@@ -149,7 +183,8 @@ int mse_medioid(const mse_base* b, uint32_t* id_out) {
     if (d % 8) return fail("medioid: d must be a multiple of 8");
     DevBuf mean, keys;
     if (mean.ensure((size_t)d * 2) || keys.ensure(n * 8)) return -1;
-    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, nullptr, b->dev, n, d, mean.as<uint16_t>());
+    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)((d + CEN_COMP - 1) / CEN_COMP)), dim3(1024), 0, nullptr, b->dev, n, d,
+                       mean.as<uint16_t>());
     MSE_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(dot_f64_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)d * 4, nullptr, b->dev, n, d,
                        mean.as<uint16_t>(), keys.as<int64_t>());
