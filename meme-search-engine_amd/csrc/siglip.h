@@ -8,7 +8,7 @@
 namespace mse {
 namespace siglip {
 
-enum { GEMM_EPI_BF16 = 0, GEMM_EPI_GELU = 1, GEMM_EPI_RESID = 2, GEMM_EPI_PATCH = 3, GEMM_EPI_QKV = 4 };
+enum { GEMM_EPI_BF16 = 0, GEMM_EPI_GELU = 1, GEMM_EPI_RESID = 2, GEMM_EPI_PATCH = 3, GEMM_EPI_QKV = 4, GEMM_EPI_RESID_LN = 5 };
 
 struct GemmLaunch {
     const uint16_t* x = nullptr;   // [M][K] bf16
@@ -22,6 +22,14 @@ struct GemmLaunch {
     int heads = 0, dh = 0, dh_pad = 0, n_pad = 0, dv_pad = 0;
     int kdh_pad = 0;               // k row stride in elements (attention_k_stride()); 0 = dh_pad
     int gelu_tanh = 0;
+    // LayerNorm-fused launches (launch_gemm_fused)
+    const float* ln_stats = nullptr;   // consumers (QKV, GELU): (mean, 1/std) per row of x, which is then the FP16 residual stream
+    const float* csum = nullptr;       // consumers: sum_k w'[n][k]; `w` holds the fp16 gamma-folded weights, `bias` the beta-folded bias
+    uint16_t* xres = nullptr;          // RESID_LN: fp16 residual stream [M][ldr], x += acc + bias in place
+    float* part = nullptr;             // RESID_LN: [n_valid / 64][part_rows][2] statistics of the 64-column groups
+    size_t part_rows = 0;
+    int n_valid = 0;                   // RESID_LN: real output columns (the rest of N is tile padding)
+    void* sink = nullptr;              // RESID_LN: >= 2 KiB of scratch
 };
 
 int attention_k_stride();   // row stride (elements) launch_attention expects of the K buffer
@@ -30,6 +38,14 @@ int gemm_bn();
 int gemm_bk();
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
+// LayerNorm folded into the GEMMs on either side of it (siglip_kernels.hip, "Fused LayerNorm"): epi = GEMM_EPI_QKV / GEMM_EPI_GELU
+// (consumers) or GEMM_EPI_RESID_LN (producer); gemm_fused_ok says whether a geometry can run them
+bool gemm_fused_ok(int M, int D, int mlp_pad, int heads, int dh, int tokens_stride, int n_pad, int m_valid);
+int launch_gemm_fused(int epi, const GemmLaunch& g, hipStream_t st);
+int launch_ln_fold(const uint16_t* w, int n_rows, int K, const float* gamma, const float* beta, const float* bias, uint16_t* w16, float* csum,
+                   float* bias2, hipStream_t st);
+int launch_row_stats(const uint16_t* x_f16, int ldx, int width, size_t rows, float eps, float* stats, hipStream_t st);
+int launch_ln_finalize(const float* part, size_t part_rows, int groups, size_t rows, float eps, float* stats, hipStream_t st);
 // delta (optional, bf16 [rows][ldd]): x += delta is applied and written back before normalising
 // x: fp32 rows, or fp16 rows (x_is_f16: the towers' residual stream)
 int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,

@@ -7,6 +7,7 @@
 #include "runtime.h"
 #include "siglip.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -24,6 +25,9 @@ struct Block {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     uint16_t *wqkv, *wproj, *w1, *w2;
     float *bqkv, *bproj, *b1, *b2;
+    // LayerNorm folded into QKV / fc1 (built by mse_siglip_finalize): fp16 w * gamma, its row sums, bias + w . beta
+    uint16_t *wqkv16 = nullptr, *w116 = nullptr;
+    float *cqkv = nullptr, *c1 = nullptr, *bqkv2 = nullptr, *b12 = nullptr;
 };
 
 struct Slot {
@@ -62,6 +66,11 @@ struct mse_siglip {
     float* out_f32 = nullptr; uint16_t* out_f16 = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
     int last_batch = 0;
+    // fused LayerNorm path (siglip_kernels.hip "Fused LayerNorm"); MSE_SIGLIP_NOFUSE=1 keeps LN1 / LN2 as kernels of their own
+    bool fused = false;
+    float* ln_stats = nullptr;   // [m_pad] (mean, 1/std)
+    float* ln_part = nullptr;    // [D / 64][m_pad] (sum, M2)
+    void* sink = nullptr;
 
     template <typename T> T* dalloc(size_t n, bool zero = false) {
         void* p = nullptr;
@@ -124,6 +133,23 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
         m->add_bf16(p + "mlp.fc1.weight", &b.w1, m->mlp, D, MP, D); m->add_f32(p + "mlp.fc1.bias", &b.b1, 1, m->mlp, MP);
         m->add_bf16(p + "mlp.fc2.weight", &b.w2, D, m->mlp, DP, MP); m->add_f32(p + "mlp.fc2.bias", &b.b2, 1, D, DP);
     }
+    {
+        const char* e = getenv("MSE_SIGLIP_NOFUSE");
+        m->fused = !(e && atoi(e)) && gemm_fused_ok((int)m->m_pad, (int)D, (int)MP, m->H, m->dh, m->n_pad, m->n_pad, 8);
+    }
+    bool fused_alloc_ok = true;
+    if (m->fused) {
+        for (int i = 0; i < c->depth; i++) {
+            Block& b = m->blocks[i];
+            b.wqkv16 = m->dalloc<uint16_t>(3 * D * D); b.cqkv = m->dalloc<float>(3 * D); b.bqkv2 = m->dalloc<float>(3 * D);
+            b.w116 = m->dalloc<uint16_t>(MP * D); b.c1 = m->dalloc<float>(MP); b.b12 = m->dalloc<float>(MP);
+            fused_alloc_ok = fused_alloc_ok && b.wqkv16 && b.cqkv && b.bqkv2 && b.w116 && b.c1 && b.b12;
+        }
+        m->ln_stats = m->dalloc<float>(2 * m->m_pad, true);
+        m->ln_part = m->dalloc<float>(2 * (D / 64) * m->m_pad, true);
+        m->sink = m->dalloc<char>(4096, true);
+        fused_alloc_ok = fused_alloc_ok && m->ln_stats && m->ln_part && m->sink;
+    }
     m->add_f32("trunk.norm.weight", &m->lnf_g, 1, D); m->add_f32("trunk.norm.bias", &m->lnf_b, 1, D);
     const std::string ap = "trunk.attn_pool.";
     m->add_f32(ap + "latent", &m->latent, 1, D);
@@ -151,6 +177,7 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
     bool ok = m->img_dev && m->patches && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat &&
               m->pool_a && m->pool_o && m->pool_ln && m->pool_h && m->pool_f && m->out_f32 && m->out_f16;
+    ok = ok && fused_alloc_ok;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_destroy(m); fail("siglip: device allocation failed"); return nullptr; }
     (void)hipDeviceSynchronize();   // the zero fills above ran on the null stream; m->stream does not wait for it
@@ -217,6 +244,12 @@ int mse_siglip_finalize(mse_siglip* m) {
         if (!kv.second.loaded) return fail("siglip: weight '" + kv.first + "' was never set");
     // the pooling query does not depend on the input: q = Linear(latent)   (model.py:94-95)
     if (launch_small_linear(m->latent, m->D, m->wq, m->D, m->bq, m->D, m->D, 1, 0, nullptr, 0, m->qlat, m->D, m->stream)) return -1;
+    if (m->fused) {
+        for (Block& b : m->blocks) {
+            if (launch_ln_fold(b.wqkv, 3 * m->D, m->D, b.ln1_g, b.ln1_b, b.bqkv, b.wqkv16, b.cqkv, b.bqkv2, m->stream)) return -1;
+            if (launch_ln_fold(b.w1, m->mlp_pad, m->D, b.ln2_g, b.ln2_b, b.b1, b.w116, b.c1, b.b12, m->stream)) return -1;
+        }
+    }
     MSE_HIP_TRY(hipStreamSynchronize(m->stream));
     m->finalized = true;
     return 0;
@@ -312,7 +345,37 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         g.out_bf16 = m->x; g.ldo = D; g.ldr = D; g.pos = m->pos; g.tokens = TS;   // writes the fp16 residual stream
         if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
     }
-    for (int i = 0; i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
+    const bool fused = m->fused && gemm_fused_ok(Mp, D, m->mlp_pad, m->H, m->dh, TS, m->n_pad, M);
+    if (fused && launch_row_stats(m->x, D, D, (size_t)Mp, c.eps, m->ln_stats, st)) return -1;
+    for (int i = 0; fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44) with LN1 / LN2 folded into the GEMMs around them
+        const Block& b = m->blocks[i];
+        {
+            GemmLaunch g; g.x = m->x; g.w = b.wqkv16; g.bias = b.bqkv2; g.csum = b.cqkv; g.ln_stats = m->ln_stats;
+            g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
+            g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+            g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+            if (launch_gemm_fused(GEMM_EPI_QKV, g, st)) return -1;
+        }
+        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
+            g.xres = m->x; g.ldr = D; g.part = m->ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
+            if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, st)) return -1;   // x += attention branch, statistics for LN2
+        }
+        if (launch_ln_finalize(m->ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, m->ln_stats, st)) return -1;
+        {
+            GemmLaunch g; g.x = m->x; g.w = b.w116; g.bias = b.b12; g.csum = b.c1; g.ln_stats = m->ln_stats;
+            g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M; g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
+            if (launch_gemm_fused(GEMM_EPI_GELU, g, st)) return -1;
+        }
+        {
+            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
+            g.xres = m->x; g.ldr = D; g.part = m->ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
+            if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, st)) return -1;   // x += MLP branch, statistics for the next LN1
+        }
+        if (i + 1 < c.depth && launch_ln_finalize(m->ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, m->ln_stats, st)) return -1;
+    }
+    for (int i = 0; !fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
         const Block& b = m->blocks[i];
         // x += (fc2 output of the previous block), then LayerNorm
         if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, DP, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
@@ -340,7 +403,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
     }
-    if (launch_layernorm(m->x, 1, D, c.depth ? m->dlt : nullptr, DP, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
+    if (launch_layernorm(m->x, 1, D, (c.depth && !fused) ? m->dlt : nullptr, DP, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
     // MAPHead (model.py:82-111)
     {
         GemmLaunch g; g.x = m->h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
@@ -369,6 +432,19 @@ const void* mse_siglip_output_device(const mse_siglip* m, int which) { return m 
 void* mse_siglip_stream(const mse_siglip* m) { return m ? (void*)m->stream : nullptr; }
 
 // developer hook: average ms of the fc1-shaped GEMM (bias + GELU) over `iters` launches with ablation `abl`
+namespace {
+// developer data for the GEMM timing hook: bf16 values uniform in (-1, 1) from a counter hash (MSE_GEMM_RANDOM=1);
+// constant operands let the chip clock higher than real activations do
+__global__ void fill_random_bf16_kernel(uint16_t* p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        const float f = (float)(int32_t)h * (1.0f / 2147483648.0f);
+        p[i] = (uint16_t)(__float_as_uint(f) >> 16);
+    }
+}
+}  // namespace
+
 int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
     if (M % 256 || N % 256 || K % 64) return fail("debug gemm: M, N multiples of 256, K of 64");
     DevBuf x, w, bias, out;
@@ -376,6 +452,11 @@ int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
     MSE_HIP_TRY(hipMemset(x.p, 0x3c, (size_t)M * K * 2));   // bf16 0x3c3c ~ 0.0115
     MSE_HIP_TRY(hipMemset(w.p, 0x3c, (size_t)N * K * 2));
     MSE_HIP_TRY(hipMemset(bias.p, 0, (size_t)N * 4));
+    if (const char* e = getenv("MSE_GEMM_RANDOM"); e && atoi(e)) {
+        hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, nullptr, x.as<uint16_t>(), (size_t)M * K, 1u);
+        hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, nullptr, w.as<uint16_t>(), (size_t)N * K, 2u);
+        MSE_HIP_TRY(hipGetLastError());
+    }
     GemmLaunch g; g.x = x.as<uint16_t>(); g.w = w.as<uint16_t>(); g.bias = bias.as<float>(); g.M = M; g.N = N; g.K = K;
     g.m_valid = M; g.out_bf16 = out.as<uint16_t>(); g.ldo = N;
     hipEvent_t e0, e1;

@@ -130,9 +130,17 @@ struct GemmArgs {
     int kdh_pad;                           // k row stride in elements (112: the 224-byte rows the attention DMA wants)
     int gelu_tanh;
     int stagger;          // persistent kernel: 64-cycle sleep units per K tile and XCD index at start (0 = none)
+    // LayerNorm folded into the GEMMs around it (gemm8pp_kernel only; see "Fused LayerNorm" above that kernel)
+    const float2* ln_stats;   // LNF consumers: (mean, 1/std) of every row of x
+    const float* csum;        // LNF consumers: c[n] = sum_k w'[n][k] (pre-offset like bias)
+    uint16_t* xres;           // EPI_RESID_LN: fp16 residual stream [M][ldr], updated in place
+    float2* part;             // EPI_RESID_LN: [n_valid / 64][part_rows] (sum, M2) of every 64-column group of the new rows
+    size_t part_rows;
+    int n_valid;              // EPI_RESID_LN: real columns (multiple of 64); the rest of N is tile padding
+    char* sink;               // EPI_RESID_LN: >= 2 KiB that the waves of padding columns store to
 };
 
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4, EPI_RESID_LN = 5 };
 
 // One accumulator quad of the epilogue: row m, columns n..n+3 (n = column inside this launch; a.n_off is
 // added for the output address), acc = raw MFMA sums.
@@ -758,14 +766,29 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 // K tile after an epilogue allow PP_STORES more operations in flight.  Waits: the unit read in phase p+1 must
 // be complete at phase p's wait; with the issue order above that leaves four younger units (8 DMAs) in flight.
 // ---------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// one 16 x 16 x 32 MFMA on eight 16-bit values per lane and operand: bf16, or fp16 for the LayerNorm-fused consumers
+template <bool F16> __device__ __forceinline__ float4v mfma16(const bf16x8& a, const bf16x8& b, const float4v& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {   // v + (v of the lane CTRL names), all lanes valid
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 8 lanes 8r .. 8r+7 (every lane gets the total): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float sum8(float v) { return dpp_add<0x141>(dpp_add<0x4e>(dpp_add<0xb1>(v))); }
+
 constexpr int PP_STAGE = 4096;
 constexpr int LDSPP_BYTES = 2 * P8_BUF + 8 * PP_STAGE;   // 160 KiB (NT = 2); the 128-column variant needs 2 * 48 KiB + 32 KiB
 
 // NT = 16-column fragments per n-quadrant of a wave: 2 -> 256-column tiles (wave tile 128 x 64); 1 -> 128-column tiles
 // (wave tile 128 x 32, C units of 64 rows) for the last 128 columns of N = 1152 / 3456, which the 256 x 128 kernel of
 // the first generation handled at half the efficiency.
-template <int EPI, bool VSWAP, int ABL = 0, int NT = 2>   // ABL (developer): 1 = no global stores, 2 = no epilogue at all
+template <int EPI, bool VSWAP, int ABL = 0, int NT = 2, bool LNF = false>   // ABL (developer): 1 = no global stores, 2 = no epilogue at all
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
+    static_assert(EPI != EPI_RESID_LN || (!VSWAP && NT == 2 && !LNF), "the residual + statistics epilogue exists for plain 256-column tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -776,7 +799,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     constexpr int OFF_CQ0 = P8_UNIT, OFF_CQ1 = P8_UNIT + CU_BYTES, OFF_RQ1 = P8_UNIT + 2 * CU_BYTES;
     constexpr int BUF = 2 * P8_UNIT + 2 * CU_BYTES;   // one K tile: [Rq0 | Cq0 | Cq1 | Rq1]
     constexpr int NWAIT = 4 + 2 * NT;              // DMAs of the four younger units (2 per R unit, NT per C unit)
-    constexpr int NSTORES = 8 * NT;                // global stores per wave and tile
+    constexpr int NSTORES = EPI == EPI_RESID_LN ? 16 * NT : 8 * NT;   // global stores per wave and tile (RESID_LN: + one statistics store per piece)
     const int n_blocks = a.N / BNW, m_blocks = a.M / 256;
     const int ntiles = n_blocks * m_blocks;
     const int G = (int)gridDim.x;
@@ -877,11 +900,9 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             _Pragma("unroll") for (int ct = 0; ct < NT; ct++)                                                       \
                 _Pragma("unroll") for (int rt = 0; rt < 4; rt++) {                                                  \
                     if constexpr (VSWAP)                                                                            \
-                        acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[rt][ks], CF[ct][ks],  \
-                                                                                      acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
+                        acc[CT0 + ct][RT0 + rt] = mfma16<LNF>(rf[rt][ks], CF[ct][ks], acc[CT0 + ct][RT0 + rt]);    \
                     else                                                                                            \
-                        acc[CT0 + ct][RT0 + rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(CF[ct][ks], rf[rt][ks],  \
-                                                                                      acc[CT0 + ct][RT0 + rt], 0, 0, 0); \
+                        acc[CT0 + ct][RT0 + rt] = mfma16<LNF>(CF[ct][ks], rf[rt][ks], acc[CT0 + ct][RT0 + rt]);    \
                 }                                                                                                   \
         __builtin_amdgcn_s_setprio(0);                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -911,7 +932,9 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
 #pragma unroll
             for (int ct = 0; ct < 2 * NT; ct++) {
                 float4v b4;
-                if constexpr (VSWAP) {
+                if constexpr (LNF) {   // bias, mean and 1/std are applied by the epilogue
+                    b4 = float4v{0.f, 0.f, 0.f, 0.f};
+                } else if constexpr (VSWAP) {
                     const float bs = a.bias[wn0b + ct * 16 + i];
                     b4 = float4v{bs, bs, bs, bs};
                 } else {
@@ -975,14 +998,58 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                 bi0 = (int)(wm0 / a.tokens);
                 tok0 = (int)(wm0 - (size_t)bi0 * a.tokens);
             }
+            // LNF: out = rstd_m * acc + (b'_n - rstd_m * mean_m * c_n)
+            [[maybe_unused]] float4 cn[2 * NT], bn[2 * NT];
+            if constexpr (LNF) {
+#pragma unroll
+                for (int ct = 0; ct < 2 * NT; ct++) {
+                    cn[ct] = *reinterpret_cast<const float4*>(a.csum + wn0 + ct * 16 + 4 * g);
+                    bn[ct] = *reinterpret_cast<const float4*>(a.bias + wn0 + ct * 16 + 4 * g);
+                }
+            }
+            // RESID_LN: the fp16 residual rows this wave updates, and where the (sum, M2) of its 64-column groups go; waves
+            // that hold padding columns of the last tile do the same work on a sink so that every wave issues NSTORES stores
+            typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+            [[maybe_unused]] uint16_t* xbase = nullptr;
+            [[maybe_unused]] float2* pbase = nullptr;
+            [[maybe_unused]] size_t xrow = 0, prow = 0;
+            if constexpr (EPI == EPI_RESID_LN) {
+                const bool wvalid = wn0 < a.n_valid;   // wave-uniform (n_valid is a multiple of 64)
+                xbase = wvalid ? a.xres + wm0 * a.ldr + wn0 + chunk * 8 : reinterpret_cast<uint16_t*>(a.sink) + lane * 8;
+                xrow = wvalid ? (size_t)a.ldr : 0;
+                pbase = wvalid ? a.part + (size_t)(wn0 >> 6) * a.part_rows + wm0 : reinterpret_cast<float2*>(a.sink + 1024);
+                prow = wvalid ? 1 : 0;
+            }
 #pragma unroll
             for (int rd = 0; rd < 4; rd++) {
+                [[maybe_unused]] float rs[2], tm[2];   // the two 16-row blocks of this round (loaded per round: registers)
+                if constexpr (LNF) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; rr++) {
+                        const float2 st = a.ln_stats[wm0 + (rd * 2 + rr) * 16 + i];
+                        rs[rr] = st.y;
+                        tm[rr] = -st.x * st.y;
+                    }
+                }
+                [[maybe_unused]] half8v xin[32 / RPI];
+                if constexpr (EPI == EPI_RESID_LN) {
+#pragma unroll
+                    for (int it = 0; it < 32 / RPI; it++)
+                        xin[it] = *reinterpret_cast<const half8v*>(xbase + (size_t)(rd * 32 + it * RPI + rsub) * xrow);
+                }
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++)
 #pragma unroll
                     for (int ct = 0; ct < 2 * NT; ct++) {
                         const float4v& c = acc[ct][rd * 2 + rr];
                         float2v lo = {c[0], c[1]}, hi = {c[2], c[3]};
+                        if constexpr (LNF) {
+                            const float r = rs[rr], t = tm[rr];
+                            lo = __builtin_elementwise_fma((float2v){r, r}, lo,
+                                                           __builtin_elementwise_fma((float2v){t, t}, (float2v){cn[ct].x, cn[ct].y}, (float2v){bn[ct].x, bn[ct].y}));
+                            hi = __builtin_elementwise_fma((float2v){r, r}, hi,
+                                                           __builtin_elementwise_fma((float2v){t, t}, (float2v){cn[ct].z, cn[ct].w}, (float2v){bn[ct].z, bn[ct].w}));
+                        }
                         if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc); hi = gelu2(hi, gc); }
                         const int row = rr * 16 + i, pc = (ct * 2 + (g >> 1)) ^ (row & (CH - 1));
                         *reinterpret_cast<uint2*>(et + row * RB + pc * 16 + (g & 1) * 8) = uint2{pack2(lo), pack2(hi)};
@@ -1000,6 +1067,26 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                         *reinterpret_cast<u32x4*>(base + (((size_t)bi * a.heads + head) * a.n_pad + tok) * (which == 0 ? a.dh_pad : a.kdh_pad) + e) = val;
                     } else if constexpr (ABL == 1) {
                         if (val[0] == 0x12345678u) a.out_bf16[0] = 1;
+                    } else if constexpr (EPI == EPI_RESID_LN) {
+                        // x += delta (delta rounded to bf16 by the staging, the sum formed in fp32 exactly as layernorm_kernel
+                        // forms it), statistics of the unrounded sums of this row's 64 columns, x back as fp16
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            v[2 * j] = __uint_as_float(val[j] << 16) + (float)xin[it][2 * j];
+                            v[2 * j + 1] = __uint_as_float(val[j] & 0xffff0000u) + (float)xin[it][2 * j + 1];
+                        }
+                        const float sm = sum8(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+                        const float mp = sm * (1.0f / 64.0f);
+                        float q = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) q = fmaf(v[j] - mp, v[j] - mp, q);
+                        q = sum8(q);
+                        half8v o;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) o[j] = (_Float16)v[j];
+                        *reinterpret_cast<half8v*>(xbase + (size_t)mrow * xrow) = o;
+                        if (chunk == 0) pbase[(size_t)mrow * prow] = float2{sm, q};
                     } else {
                         *reinterpret_cast<u32x4*>(a.out_bf16 + (wm0 + mrow) * a.ldo + a.n_off + wn0 + chunk * 8) = val;
                     }
@@ -1014,11 +1101,26 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             int tok = tok0 + chunk * 8, bi = bi0;
             if (tok >= a.tokens) { tok -= a.tokens; bi++; }
             if (tok >= a.tokens) { tok -= a.tokens; bi++; }
-#pragma unroll
-            for (int ct = 0; ct < 2 * NT; ct++) {
+            // LNF: the per-token factors lie along the accumulator quad here (tokens rt*16 + 4g .. +3), the per-column ones per ct
+            [[maybe_unused]] float4v rs4[8], tm4[8];
+            if constexpr (LNF) {
 #pragma unroll
                 for (int rt = 0; rt < 8; rt++) {
-                    const float4v& c = acc[ct][rt];
+                    const float4* sp = reinterpret_cast<const float4*>(a.ln_stats + wm0 + rt * 16 + 4 * g);
+                    const float4 s01 = sp[0], s23 = sp[1];   // (mean, rstd) x 2 each
+                    rs4[rt] = float4v{s01.y, s01.w, s23.y, s23.w};
+                    tm4[rt] = float4v{-s01.x * s01.y, -s01.z * s01.w, -s23.x * s23.y, -s23.z * s23.w};
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2 * NT; ct++) {
+                [[maybe_unused]] float cnv = 0.f, bnv = 0.f;
+                if constexpr (LNF) { cnv = a.csum[wn0 + ct * 16 + i]; bnv = a.bias[wn0 + ct * 16 + i]; }
+#pragma unroll
+                for (int rt = 0; rt < 8; rt++) {
+                    float4v c = acc[ct][rt];
+                    if constexpr (LNF)
+                        c = __builtin_elementwise_fma(rs4[rt], c, __builtin_elementwise_fma(tm4[rt], float4v{cnv, cnv, cnv, cnv}, float4v{bnv, bnv, bnv, bnv}));
                     const int pc = (rt * 2 + (g >> 1)) ^ i;
                     *reinterpret_cast<uint2*>(et + i * 256 + pc * 16 + (g & 1) * 8) = uint2{pack2(c[0], c[1]), pack2(c[2], c[3])};
                 }
@@ -1114,6 +1216,92 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* __restrict__ x, int 
             if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * ldo + c) = float4{y0, y1, y2, y3};
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused LayerNorm (image tower): LN1 / LN2 never run as kernels of their own.
+//   producer  proj / fc2 (gemm8pp_kernel<EPI_RESID_LN>): x += branch output in place (fp16) and, per row and 64-column group of
+//             the wave tile, (sum, M2 = sum (v - group mean)^2) of the new values -> part[group][row]
+//   finalize  ln_stats_finalize_kernel: the groups of a row combined with the pairwise update of Chan, Golub & LeVeque
+//             (equal group sizes) -> (mean, 1/std)[row]; the first block's statistics come from row_stats_kernel
+//   consumer  QKV / fc1 (gemm8pp_kernel<.., LNF = true>): A operand = the fp16 residual rows themselves (fp16 MFMA), weights
+//             w'[n][k] = fp16(w[n][k] * gamma[k]) built once by fold_ln_weights_kernel, and the epilogue applies
+//             out = rstd_m * (acc - mean_m * c_n) + b'_n,  c_n = sum_k w'[n][k],  b'_n = b_n + sum_k w[n][k] * beta[k]
+// which is LayerNorm followed by the Linear, with the normalised activations never rounded to bf16 or written to HBM.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float2* __restrict__ part, size_t part_rows, int groups, size_t rows,
+                                                                float eps, float2* __restrict__ out) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int gi = 0; gi < groups; gi++) s += part[(size_t)gi * part_rows + row].x;
+    const float width = (float)(groups * 64);
+    const float mean = s / width;
+    float m2 = 0.0f;
+    for (int gi = 0; gi < groups; gi++) {
+        const float2 p = part[(size_t)gi * part_rows + row];
+        const float d = p.x * (1.0f / 64.0f) - mean;
+        m2 += p.y + 64.0f * d * d;
+    }
+    out[row] = float2{mean, rsqrtf(m2 / width + eps)};
+}
+
+// (mean, 1/std) of fp16 rows, one wave per row, two passes over registers like layernorm_kernel
+__global__ __launch_bounds__(256) void row_stats_kernel(const _Float16* __restrict__ x, int ldx, int width, size_t rows, float eps,
+                                                        float2* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    float4 v[8];
+    float s = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = lane * 4 + j * 256;
+        v[j] = float4{0.f, 0.f, 0.f, 0.f};
+        if (c < width) {
+            const half4v hv = *reinterpret_cast<const half4v*>(x + row * ldx + c);
+            v[j] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            s += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)width;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int c = lane * 4 + j * 256;
+        if (c < width) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) out[row] = float2{mean, rsqrtf(ss / (float)width + eps)};
+}
+
+// one workgroup per weight row n: w16[n][k] = fp16(bf16 w[n][k] * gamma[k]); csum[n] = sum_k w16[n][k]; bias2[n] = bias[n] + sum_k w[n][k] beta[k]
+__global__ __launch_bounds__(256) void fold_ln_weights_kernel(const uint16_t* __restrict__ w, int K, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias,
+                                                              uint16_t* __restrict__ w16, float* __restrict__ csum, float* __restrict__ bias2) {
+    __shared__ float red[2][256];
+    const size_t n = blockIdx.x;
+    float cs = 0.0f, bs = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float wf = bf2f(w[n * K + k]);
+        const _Float16 h = (_Float16)(wf * gamma[k]);
+        w16[n * K + k] = __builtin_bit_cast(uint16_t, h);
+        cs += (float)h;
+        bs = fmaf(wf, beta[k], bs);
+    }
+    red[0][threadIdx.x] = cs; red[1][threadIdx.x] = bs;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { csum[n] = red[0][0]; bias2[n] = bias[n] + red[1][0]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1901,6 +2089,90 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
         case EPI_QKV: return launch_gemm_t<EPI_QKV>(a, st);
     }
     return fail("gemm: unknown epilogue");
+}
+
+// The LayerNorm-fused GEMMs of the image tower (persistent ping-pong kernel only; the caller checks gemm_fused_ok first).
+bool gemm_fused_ok(int M, int D, int mlp_pad, int heads, int dh, int tokens_stride, int n_pad, int m_valid) {
+    return M % 256 == 0 && D % 64 == 0 && D >= 256 && mlp_pad % 256 == 0 && mlp_pad >= 256 && heads * dh == D && (2 * D) % 256 == 0 &&
+           ((3 * D) % 256 == 0 || (3 * D) % 256 == 128) && tokens_stride % 8 == 0 && tokens_stride >= 64 && n_pad % 8 == 0 && dh % 8 == 0 &&
+           dh >= 64 && m_valid % 8 == 0;
+}
+
+namespace {
+template <typename KernelT> int launch_pp(KernelT kernel, int lds, const GemmArgs& a, int bnw, hipStream_t st) {
+    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const unsigned tiles = (unsigned)((a.M / 256) * (a.N / bnw));
+    hipLaunchKernelGGL(kernel, dim3(std::min(tiles, (unsigned)mse::device_cu_count())), dim3(512), lds, st, a);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+int launch_gemm_fused(int epi, const GemmLaunch& g, hipStream_t st) {
+    if (g.M % 256 || g.K % 64 || g.K < 256 || g.N % 128) return fail("fused gemm: M % 256, K % 64, K >= 256, N % 128 required");
+    GemmArgs a{};
+    a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid; a.n_off = 0;
+    a.out_bf16 = g.out_bf16; a.ldo = g.ldo; a.ldr = g.ldr; a.tokens = g.tokens;
+    a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
+    a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh; a.kdh_pad = g.kdh_pad ? g.kdh_pad : g.dh_pad;
+    a.ln_stats = reinterpret_cast<const float2*>(g.ln_stats); a.csum = g.csum;
+    a.xres = g.xres; a.part = reinterpret_cast<float2*>(g.part); a.part_rows = g.part_rows; a.n_valid = g.n_valid;
+    a.sink = reinterpret_cast<char*>(g.sink);
+    constexpr int lds_narrow = 2 * (2 * P8_UNIT + 2 * 8192) + 8 * PP_STAGE;
+    switch (epi) {
+        case EPI_RESID_LN:
+            if (g.N % 256 || !g.xres || !g.part || !g.sink || g.n_valid % 64 || g.n_valid > g.N || g.part_rows < (size_t)g.M)
+                return fail("fused gemm: bad residual / statistics arguments");
+            return launch_pp(gemm8pp_kernel<EPI_RESID_LN, false>, LDSPP_BYTES, a, 256, st);
+        case EPI_GELU:
+            if (g.N % 256 || !g.ln_stats || !g.csum) return fail("fused gemm: fc1 needs N % 256 == 0 and row statistics");
+            return launch_pp(gemm8pp_kernel<EPI_GELU, false, 0, 2, true>, LDSPP_BYTES, a, 256, st);
+        case EPI_QKV: {
+            const int D = g.heads * g.dh;
+            if (g.N != 3 * D || (2 * D) % 256 || !g.ln_stats || !g.csum) return fail("fused gemm: QKV geometry");
+            GemmArgs aq = a;
+            aq.N = 2 * D;
+            if (launch_pp(gemm8pp_kernel<EPI_QKV, false, 0, 2, true>, LDSPP_BYTES, aq, 256, st)) return -1;
+            const int nv = (D / 256) * 256;
+            GemmArgs av = a;
+            av.N = nv; av.n_off = 2 * D; av.w = a.w + (size_t)av.n_off * a.K; av.bias = a.bias + av.n_off; av.csum = a.csum + av.n_off;
+            if (nv && launch_pp(gemm8pp_kernel<EPI_QKV, true, 0, 2, true>, LDSPP_BYTES, av, 256, st)) return -1;
+            if (D - nv == 128) {
+                GemmArgs at = a;
+                at.N = 128; at.n_off = 2 * D + nv; at.w = a.w + (size_t)at.n_off * a.K; at.bias = a.bias + at.n_off; at.csum = a.csum + at.n_off;
+                if (launch_pp(gemm8pp_kernel<EPI_QKV, true, 0, 1, true>, lds_narrow, at, 128, st)) return -1;
+            } else if (D != nv) {
+                return fail("fused gemm: V columns must be whole 256-column tiles plus at most one of 128");
+            }
+            return 0;
+        }
+    }
+    return fail("fused gemm: unknown epilogue");
+}
+
+int launch_ln_fold(const uint16_t* w, int n_rows, int K, const float* gamma, const float* beta, const float* bias, uint16_t* w16, float* csum,
+                   float* bias2, hipStream_t st) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(fold_ln_weights_kernel, dim3((unsigned)n_rows), dim3(256), 0, st, w, K, gamma, beta, bias, w16, csum, bias2);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_row_stats(const uint16_t* x_f16, int ldx, int width, size_t rows, float eps, float* stats, hipStream_t st) {
+    if (rows == 0) return 0;
+    if (width % 4 || width > 2048) return fail("row_stats: width must be a multiple of 4, at most 2048");
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const _Float16*>(x_f16), ldx,
+                       width, rows, eps, reinterpret_cast<float2*>(stats));
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_ln_finalize(const float* part, size_t part_rows, int groups, size_t rows, float eps, float* stats, hipStream_t st) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float2*>(part),
+                       part_rows, groups, rows, eps, reinterpret_cast<float2*>(stats));
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,
