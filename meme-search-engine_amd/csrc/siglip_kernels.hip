@@ -93,8 +93,8 @@ __device__ __forceinline__ GeluC gelu_coef(int tanh_flavour) {
     return tanh_flavour ? GeluC{L * 1.5957691216f, L * 0.0713548163f, 0.0f}
                         : GeluC{L * 1.59501574f, L * 7.40113143e-02f, L * -7.03036941e-04f};
 }
-__device__ __forceinline__ float2v gelu2(float2v x, const GeluC& k) {
-    float2v s = __builtin_elementwise_min(x * x, (float2v){50.0f, 50.0f});
+__device__ __forceinline__ float2v gelu2(float2v x, const GeluC& k, float clamp = 50.0f) {
+    float2v s = __builtin_elementwise_min(x * x, (float2v){clamp, clamp});
     float2v t = __builtin_elementwise_fma(s, (float2v){k.c, k.c}, (float2v){k.b, k.b});
     t = __builtin_elementwise_fma(t, s, (float2v){k.a, k.a});
     const float2v u = t * x;
@@ -875,6 +875,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
 
     float4v acc[2 * NT][8];
+    [[maybe_unused]] float rsk[8];   // LNF, non-swapped: 1/std of this lane's 8 accumulator rows
     bf16x8 rf[4][2], cf0[NT][2], cf1[NT][2];
     auto read_r = [&](const char* unit_base) {
 #pragma unroll
@@ -923,28 +924,100 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         }                                                                                                           \
     } while (0)
 
-    int ring = 0;   // running K tile count: LDS buffer = ring & 1
-    for (int iter = 0;; iter++) {
-        // accumulators start at the bias: the loads sit at the tile start, where the wave is about to wait for the
-        // K tile 0 units anyway, and the epilogue needs no global load at all
-        {
-            const int wn0b = (int)n0 + wc * 32 * NT;
+    // Per-tile vectors of the accumulator start value, fetched for the NEXT tile at the start of the epilogue, i.e. before the
+    // epilogue's global stores: loads and stores retire in order on one counter, so a load issued after the stores cannot
+    // return before all of them have drained, and the tile start would wait for that drain every time.
+    //   plain:  acc = bias_n
+    //   LNF:    acc = std_m * b'_n - mean_m * c_n, so that the epilogue is out = acc / std_m and needs nothing but 1/std
+    //           (non-swapped form: 1/std stays in registers across the main loop)
+    //   LNF keeps these in FEW registers: lane l holds (mean, rstd) of rows l and l + 64 of the wave's 128 and, non-swapped,
+    //   (c, b') of column l of the wave's 64; init_acc and the swapped epilogue pick what a lane needs with ds_bpermute.
+    constexpr int NCOLV = 2 * NT;
+    struct TileVec {
+        float4v col_b[NCOLV];   // plain: bias of the lane's column quads (non-swapped) / its column, broadcast (swapped)
+        float colc[NCOLV], colb[NCOLV];   // LNF swapped: c and b' of the lane's columns ct * 16 + i
+        float cb[2];            // LNF non-swapped: (c, b') of column `lane`
+        float2 ra, rb;          // LNF: (mean, rstd) of rows lane and lane + 64
+    };
+    auto bperm = [&](float v, int src_lane) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+    };
+    auto fetch_vec = [&](size_t m0v, size_t n0v, TileVec& tv) {
+        const int wn0b = (int)n0v + wc * 32 * NT;
+        if constexpr (!LNF) {
 #pragma unroll
-            for (int ct = 0; ct < 2 * NT; ct++) {
-                float4v b4;
-                if constexpr (LNF) {   // bias, mean and 1/std are applied by the epilogue
-                    b4 = float4v{0.f, 0.f, 0.f, 0.f};
-                } else if constexpr (VSWAP) {
+            for (int ct = 0; ct < NCOLV; ct++) {
+                if constexpr (VSWAP) {
                     const float bs = a.bias[wn0b + ct * 16 + i];
-                    b4 = float4v{bs, bs, bs, bs};
+                    tv.col_b[ct] = float4v{bs, bs, bs, bs};
                 } else {
                     const float4 bq = *reinterpret_cast<const float4*>(a.bias + wn0b + ct * 16 + 4 * g);
-                    b4 = float4v{bq.x, bq.y, bq.z, bq.w};
+                    tv.col_b[ct] = float4v{bq.x, bq.y, bq.z, bq.w};
                 }
+            }
+        } else {
+            const float2* lp = a.ln_stats + m0v + (size_t)wr * 128 + lane;
+            tv.ra = lp[0];
+            tv.rb = lp[64];
+            if constexpr (VSWAP) {
 #pragma unroll
-                for (int rt = 0; rt < 8; rt++) acc[ct][rt] = b4;
+                for (int ct = 0; ct < NCOLV; ct++) { tv.colc[ct] = a.csum[wn0b + ct * 16 + i]; tv.colb[ct] = a.bias[wn0b + ct * 16 + i]; }
+            } else {
+                static_assert(!LNF || VSWAP || NT == 2, "column-per-lane vectors assume 64 columns per wave");
+                tv.cb[0] = a.csum[wn0b + lane];
+                tv.cb[1] = a.bias[wn0b + lane];
             }
         }
+    };
+    auto init_acc = [&](const TileVec& tv) {
+        if constexpr (!LNF) {
+#pragma unroll
+            for (int ct = 0; ct < NCOLV; ct++)
+#pragma unroll
+                for (int rt = 0; rt < 8; rt++) acc[ct][rt] = tv.col_b[ct];
+        } else if constexpr (VSWAP) {
+#pragma unroll
+            for (int rt = 0; rt < 8; rt++) {
+                float4v mu, sd;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {   // token rt * 16 + 4g + j: half (rt >= 4) of lane (rt & 3) * 16 + 4g + j
+                    const int src = (rt & 3) * 16 + 4 * g + j;
+                    mu[j] = -bperm(rt < 4 ? tv.ra.x : tv.rb.x, src);
+                    sd[j] = 1.0f / bperm(rt < 4 ? tv.ra.y : tv.rb.y, src);
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCOLV; ct++) {
+                    const float bv = tv.colb[ct], cv = tv.colc[ct];
+                    acc[ct][rt] = __builtin_elementwise_fma(sd, float4v{bv, bv, bv, bv}, mu * cv);
+                }
+            }
+        } else {
+            float4v cq[NCOLV], bq[NCOLV];
+#pragma unroll
+            for (int ct = 0; ct < NCOLV; ct++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    cq[ct][j] = bperm(tv.cb[0], ct * 16 + 4 * g + j);
+                    bq[ct][j] = bperm(tv.cb[1], ct * 16 + 4 * g + j);
+                }
+#pragma unroll
+            for (int rt = 0; rt < 8; rt++) {   // row rt * 16 + i: half (rt >= 4) of lane (rt & 3) * 16 + i
+                const int src = (rt & 3) * 16 + i;
+                const float mean = bperm(rt < 4 ? tv.ra.x : tv.rb.x, src), rstd = bperm(rt < 4 ? tv.ra.y : tv.rb.y, src);
+                const float sd = 1.0f / rstd;
+                rsk[rt] = rstd;
+#pragma unroll
+                for (int ct = 0; ct < NCOLV; ct++)
+                    acc[ct][rt] = __builtin_elementwise_fma(bq[ct], float4v{sd, sd, sd, sd}, cq[ct] * (-mean));
+            }
+        }
+    };
+    TileVec tvec;
+    fetch_vec(m0, n0, tvec);
+    init_acc(tvec);
+
+    int ring = 0;   // running K tile count: LDS buffer = ring & 1
+    for (int iter = 0;; iter++) {
         // the second m-half runs one barrier behind the first inside a tile; the halves are re-aligned before the
         // epilogue so that both run it at the same time (two waves per SIMD hide each other's LDS round trips)
         if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -974,6 +1047,15 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         // ---- epilogue: exactly PP_STORES global stores per wave, all unconditional --------------------------------
         const size_t wm0 = m0 + (size_t)wr * 128;
         const int wn0 = (int)n0 + wc * 32 * NT;
+        // swapped LNF epilogue: 1/std of the lane's tokens, picked from the current tile's vectors before they are replaced
+        [[maybe_unused]] float4v rs4[8];
+        if constexpr (LNF && VSWAP) {
+#pragma unroll
+            for (int rt = 0; rt < 8; rt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) rs4[rt][j] = bperm(rt < 4 ? tvec.ra.y : tvec.rb.y, (rt & 3) * 16 + 4 * g + j);
+        }
+        if (has_next) fetch_vec(m0n, n0n, tvec);   // before the stores (see TileVec)
         if constexpr (ABL == 2) {
             float sacc = 0.0f;
 #pragma unroll
@@ -984,7 +1066,12 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
         } else if constexpr (!VSWAP) {
             // staging rounds of 32 rows x 32 NT columns bf16 (64 NT-byte rows, 16-byte pieces XOR-swizzled by the row)
             constexpr int CH = 4 * NT, RB = 16 * CH, RPI = 64 / CH;   // pieces per row, row bytes, rows per read instruction
-            const GeluC gc = gelu_coef(a.gelu_tanh);
+            // the GELU constants are re-made per tile on purpose (values laundered through empty asm): hoisted out of the tile loop
+            // their packed copies are six more register pairs alive across the main loop, which the LNF variant cannot afford
+            int gelu_flavour = a.gelu_tanh;
+            float gelu_clamp = 50.0f;
+            if constexpr (EPI == EPI_GELU) asm volatile("" : "+s"(gelu_flavour), "+v"(gelu_clamp));
+            const GeluC gc = gelu_coef(gelu_flavour);
             const int rsub = lane / CH, chunk = lane % CH;
             // QKV scatter geometry (8-column pieces stay inside one head: 8 | dh)
             int which = 0, head = 0, e = 0, bi0 = 0, tok0 = 0;
@@ -998,15 +1085,10 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                 bi0 = (int)(wm0 / a.tokens);
                 tok0 = (int)(wm0 - (size_t)bi0 * a.tokens);
             }
-            // LNF: out = rstd_m * acc + (b'_n - rstd_m * mean_m * c_n)
-            [[maybe_unused]] float4 cn[2 * NT], bn[2 * NT];
-            if constexpr (LNF) {
-#pragma unroll
-                for (int ct = 0; ct < 2 * NT; ct++) {
-                    cn[ct] = *reinterpret_cast<const float4*>(a.csum + wn0 + ct * 16 + 4 * g);
-                    bn[ct] = *reinterpret_cast<const float4*>(a.bias + wn0 + ct * 16 + 4 * g);
-                }
-            }
+            // LNF: out = rstd_m * acc   (acc started at std_m * b'_n - mean_m * c_n)
+
+            [[maybe_unused]] uint16_t* orow = nullptr;
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) orow = a.out_bf16 + (wm0 + rsub) * a.ldo + a.n_off + wn0 + chunk * 8;
             // RESID_LN: the fp16 residual rows this wave updates, and where the (sum, M2) of its 64-column groups go; waves
             // that hold padding columns of the last tile do the same work on a sink so that every wave issues NSTORES stores
             typedef _Float16 half8v __attribute__((ext_vector_type(8)));
@@ -1020,22 +1102,21 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                 pbase = wvalid ? a.part + (size_t)(wn0 >> 6) * a.part_rows + wm0 : reinterpret_cast<float2*>(a.sink + 1024);
                 prow = wvalid ? 1 : 0;
             }
+            // the residual pieces of round rd + 1 are requested while round rd is staged and reduced
+            [[maybe_unused]] half8v xnext[32 / RPI];
+            if constexpr (EPI == EPI_RESID_LN) {
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; it++) xnext[it] = *reinterpret_cast<const half8v*>(xbase + (size_t)(it * RPI + rsub) * xrow);
+            }
 #pragma unroll
             for (int rd = 0; rd < 4; rd++) {
-                [[maybe_unused]] float rs[2], tm[2];   // the two 16-row blocks of this round (loaded per round: registers)
-                if constexpr (LNF) {
-#pragma unroll
-                    for (int rr = 0; rr < 2; rr++) {
-                        const float2 st = a.ln_stats[wm0 + (rd * 2 + rr) * 16 + i];
-                        rs[rr] = st.y;
-                        tm[rr] = -st.x * st.y;
-                    }
-                }
                 [[maybe_unused]] half8v xin[32 / RPI];
                 if constexpr (EPI == EPI_RESID_LN) {
 #pragma unroll
-                    for (int it = 0; it < 32 / RPI; it++)
-                        xin[it] = *reinterpret_cast<const half8v*>(xbase + (size_t)(rd * 32 + it * RPI + rsub) * xrow);
+                    for (int it = 0; it < 32 / RPI; it++) {
+                        xin[it] = xnext[it];
+                        if (rd < 3) xnext[it] = *reinterpret_cast<const half8v*>(xbase + (size_t)((rd + 1) * 32 + it * RPI + rsub) * xrow);
+                    }
                 }
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++)
@@ -1044,13 +1125,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                         const float4v& c = acc[ct][rd * 2 + rr];
                         float2v lo = {c[0], c[1]}, hi = {c[2], c[3]};
                         if constexpr (LNF) {
-                            const float r = rs[rr], t = tm[rr];
-                            lo = __builtin_elementwise_fma((float2v){r, r}, lo,
-                                                           __builtin_elementwise_fma((float2v){t, t}, (float2v){cn[ct].x, cn[ct].y}, (float2v){bn[ct].x, bn[ct].y}));
-                            hi = __builtin_elementwise_fma((float2v){r, r}, hi,
-                                                           __builtin_elementwise_fma((float2v){t, t}, (float2v){cn[ct].z, cn[ct].w}, (float2v){bn[ct].z, bn[ct].w}));
+                            const float r = rsk[rd * 2 + rr];
+                            lo = lo * r;
+                            hi = hi * r;
                         }
-                        if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc); hi = gelu2(hi, gc); }
+                        if constexpr (EPI == EPI_GELU) { lo = gelu2(lo, gc, gelu_clamp); hi = gelu2(hi, gc, gelu_clamp); }
                         const int row = rr * 16 + i, pc = (ct * 2 + (g >> 1)) ^ (row & (CH - 1));
                         *reinterpret_cast<uint2*>(et + row * RB + pc * 16 + (g & 1) * 8) = uint2{pack2(lo), pack2(hi)};
                     }
@@ -1088,7 +1167,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
                         *reinterpret_cast<half8v*>(xbase + (size_t)mrow * xrow) = o;
                         if (chunk == 0) pbase[(size_t)mrow * prow] = float2{sm, q};
                     } else {
-                        *reinterpret_cast<u32x4*>(a.out_bf16 + (wm0 + mrow) * a.ldo + a.n_off + wn0 + chunk * 8) = val;
+                        // per-lane row pointer + a wave-uniform row offset: no per-(round, piece) 64-bit lane indices to keep alive
+                        *reinterpret_cast<u32x4*>(orow + (size_t)(rd * 32 + it * RPI) * a.ldo) = val;
                     }
                 }
             }
@@ -1102,25 +1182,12 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             if (tok >= a.tokens) { tok -= a.tokens; bi++; }
             if (tok >= a.tokens) { tok -= a.tokens; bi++; }
             // LNF: the per-token factors lie along the accumulator quad here (tokens rt*16 + 4g .. +3), the per-column ones per ct
-            [[maybe_unused]] float4v rs4[8], tm4[8];
-            if constexpr (LNF) {
-#pragma unroll
-                for (int rt = 0; rt < 8; rt++) {
-                    const float4* sp = reinterpret_cast<const float4*>(a.ln_stats + wm0 + rt * 16 + 4 * g);
-                    const float4 s01 = sp[0], s23 = sp[1];   // (mean, rstd) x 2 each
-                    rs4[rt] = float4v{s01.y, s01.w, s23.y, s23.w};
-                    tm4[rt] = float4v{-s01.x * s01.y, -s01.z * s01.w, -s23.x * s23.y, -s23.z * s23.w};
-                }
-            }
 #pragma unroll
             for (int ct = 0; ct < 2 * NT; ct++) {
-                [[maybe_unused]] float cnv = 0.f, bnv = 0.f;
-                if constexpr (LNF) { cnv = a.csum[wn0 + ct * 16 + i]; bnv = a.bias[wn0 + ct * 16 + i]; }
 #pragma unroll
                 for (int rt = 0; rt < 8; rt++) {
                     float4v c = acc[ct][rt];
-                    if constexpr (LNF)
-                        c = __builtin_elementwise_fma(rs4[rt], c, __builtin_elementwise_fma(tm4[rt], float4v{cnv, cnv, cnv, cnv}, float4v{bnv, bnv, bnv, bnv}));
+                    if constexpr (LNF) c = c * rs4[rt];
                     const int pc = (rt * 2 + (g >> 1)) ^ i;
                     *reinterpret_cast<uint2*>(et + i * 256 + pc * 16 + (g & 1) * 8) = uint2{pack2(c[0], c[1]), pack2(c[2], c[3])};
                 }
@@ -1144,6 +1211,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
             xbn = reinterpret_cast<const char*>(a.x) + m0n * kbytes;
             wbn = reinterpret_cast<const char*>(a.w) + n0n * kbytes;
         }
+        init_acc(tvec);   // fetched before this tile's stores; straight-line from there, so the wait is a counted one
     }
 #undef PP_MFMA
 #undef PP_STAGE_UNIT
