@@ -110,6 +110,36 @@ def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
 
 
 @pytest.mark.gpu
+def test_fused_layernorm_equals_separate_layernorm(gpu, mse, ref, monkeypatch):
+    """The image tower folds LN1 / LN2 and the residual adds into the GEMMs; MSE_SIGLIP_NOFUSE=1 runs them as
+    passes of their own.  Same weights, same images: the two engines must agree far inside the oracle tolerance, the residual
+    streams too, and planted LayerNorm gains / offsets (the seeded weights have gamma = 1, beta = 0) must be honoured."""
+    from mse import siglip
+    cfg = dict(ref.CONFIG, depth=3)
+    sd = ref.synthetic_weights(cfg)
+    g = torch.Generator().manual_seed(5)
+    for i in range(3):
+        for nm in ("norm1", "norm2"):
+            sd[f"trunk.blocks.{i}.{nm}.weight"] = 0.5 + torch.rand(1152, generator=g)
+            sd[f"trunk.blocks.{i}.{nm}.bias"] = 0.2 * torch.randn(1152, generator=g)
+    img = ref.synthetic_images(3, cfg)
+    want = ref.encode_image(img, sd, cfg, normalize=True).numpy()
+    named = {"visual." + k: v for k, v in sd.items()}
+    fused = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=4)
+    got_f = fused.encode_image(img.numpy())
+    res_f = fused.debug_residual(3)
+    monkeypatch.setenv("MSE_SIGLIP_NOFUSE", "1")
+    plain = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=4)
+    monkeypatch.delenv("MSE_SIGLIP_NOFUSE")
+    got_p = plain.encode_image(img.numpy())
+    res_p = plain.debug_residual(3)
+    assert np.all(cosine(got_f, want) > 1 - 1e-3) and np.all(cosine(got_p, want) > 1 - 1e-3)
+    assert np.all(cosine(got_f, got_p) > 1 - 1e-4), cosine(got_f, got_p)
+    assert np.all(cosine(res_f.reshape(3, -1), res_p.reshape(3, -1)) > 1 - 1e-4)
+    assert not np.array_equal(got_f, got_p)     # two different code paths really ran
+
+
+@pytest.mark.gpu
 def test_engine_with_massive_activation_channels(gpu, mse, ref):
     """Trained ViTs carry a few residual channels hundreds of times larger than the rest ("massive activations"); the seeded
     Gaussian weights of the other tests never do.  Plant them -- biases of +3000 / -800 / +12000 on three channels of the
