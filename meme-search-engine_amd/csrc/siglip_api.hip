@@ -62,7 +62,9 @@ struct mse_siglip {
     void* img_dev = nullptr;
     uint16_t *patches = nullptr, *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *kvb = nullptr;
     uint16_t* x = nullptr;   // residual stream [M][D], fp16
-    float *pool_a = nullptr, *pool_o = nullptr, *pool_ln = nullptr, *pool_h = nullptr, *pool_f = nullptr;
+    float *pool_a = nullptr, *pool_o = nullptr;
+    uint16_t *pool_a16 = nullptr, *pool_ln16 = nullptr, *pool_h16 = nullptr;   // bf16 operands of the MAP head's GEMMs, rows padded to 256
+    size_t pool_rows = 0;
     float* out_f32 = nullptr; uint16_t* out_f16 = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
     int last_batch = 0;
@@ -157,8 +159,8 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->add_bf16(ap + "kv.weight", &m->wkv, 2 * D, D, 2 * D, D); m->add_f32(ap + "kv.bias", &m->bkv, 1, 2 * D);
     m->add_bf16(ap + "proj.weight", &m->wpp, D, D, D, D); m->add_f32(ap + "proj.bias", &m->bpp, 1, D);
     m->add_f32(ap + "norm.weight", &m->lnp_g, 1, D); m->add_f32(ap + "norm.bias", &m->lnp_b, 1, D);
-    m->add_bf16(ap + "mlp.fc1.weight", &m->wp1, m->mlp, D, m->mlp, D); m->add_f32(ap + "mlp.fc1.bias", &m->bp1, 1, m->mlp);
-    m->add_bf16(ap + "mlp.fc2.weight", &m->wp2, D, m->mlp, D, m->mlp); m->add_f32(ap + "mlp.fc2.bias", &m->bp2, 1, D);
+    m->add_bf16(ap + "mlp.fc1.weight", &m->wp1, m->mlp, D, MP, D); m->add_f32(ap + "mlp.fc1.bias", &m->bp1, 1, m->mlp, MP);
+    m->add_bf16(ap + "mlp.fc2.weight", &m->wp2, D, m->mlp, D, MP); m->add_f32(ap + "mlp.fc2.bias", &m->bp2, 1, D);
     // activations
     const size_t B = m->max_batch, M = m->m_pad, BH = B * m->H;
     m->img_dev = m->dalloc<float>(B * c->in_chans * c->img_size * c->img_size);
@@ -172,11 +174,13 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->vtb = m->dalloc<uint16_t>((BH + m->H) * m->dv_pad * m->n_pad, true);
     m->kvb = m->dalloc<uint16_t>(M * 2 * D, true);
     m->qlat = m->dalloc<float>(D, true);
-    m->pool_a = m->dalloc<float>(B * D); m->pool_o = m->dalloc<float>(B * D); m->pool_ln = m->dalloc<float>(B * D);
-    m->pool_h = m->dalloc<float>(B * m->mlp); m->pool_f = m->dalloc<float>(B * D);
+    m->pool_rows = round_up(B, 256);
+    m->pool_a = m->dalloc<float>(B * D); m->pool_o = m->dalloc<float>(m->pool_rows * D, true);
+    m->pool_a16 = m->dalloc<uint16_t>(m->pool_rows * D, true); m->pool_ln16 = m->dalloc<uint16_t>(m->pool_rows * D, true);
+    m->pool_h16 = m->dalloc<uint16_t>(m->pool_rows * MP, true);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
     bool ok = m->img_dev && m->patches && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat &&
-              m->pool_a && m->pool_o && m->pool_ln && m->pool_h && m->pool_f && m->out_f32 && m->out_f16;
+              m->pool_a && m->pool_o && m->pool_a16 && m->pool_ln16 && m->pool_h16 && m->out_f32 && m->out_f16;
     ok = ok && fused_alloc_ok;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_destroy(m); fail("siglip: device allocation failed"); return nullptr; }
@@ -411,14 +415,25 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
     }
     if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, m->pool_a, D, st)) return -1;
-    if (launch_small_linear(m->pool_a, D, m->wpp, D, m->bpp, D, D, batch, 0, nullptr, 0, m->pool_o, D, st)) return -1;
-    if (launch_layernorm(m->pool_o, 0, D, nullptr, 0, m->lnp_g, m->lnp_b, c.eps, D, batch, nullptr, D, m->pool_ln, st)) return -1;
-    if (launch_small_linear(m->pool_ln, D, m->wp1, D, m->bp1, D, m->mlp, batch, gelu_tanh ? 2 : 1, nullptr, 0, m->pool_h, m->mlp,
-                            st)) return -1;
-    if (launch_small_linear(m->pool_h, m->mlp, m->wp2, m->mlp, m->bp2, m->mlp, D, batch, 0, m->pool_o, D, m->pool_f, D, st))
-        return -1;
+    // proj, LayerNorm, MLP with residual on the matrix cores: the batch is one (or a few) 256-row block of the same GEMM kernels
+    // (rows >= batch are zero padding; the fp32 accumulating epilogue builds pool_o = proj, then pool_o += fc2)
+    {
+        const int Bp = (int)round_up((size_t)batch, 256);
+        if (launch_f32_to_bf16_pad(m->pool_a, batch, D, D, m->pool_a16, Bp, D, st)) return -1;
+        MSE_HIP_TRY(hipMemsetAsync(m->pool_o, 0, (size_t)Bp * D * 4, st));
+        GemmLaunch g; g.x = m->pool_a16; g.w = m->wpp; g.bias = m->bpp; g.M = Bp; g.N = D; g.K = D; g.m_valid = batch;
+        g.resid = m->pool_o; g.ldr = D;
+        if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
+        if (launch_layernorm(m->pool_o, 0, D, nullptr, 0, m->lnp_g, m->lnp_b, c.eps, D, batch, m->pool_ln16, D, nullptr, st)) return -1;
+        GemmLaunch g1; g1.x = m->pool_ln16; g1.w = m->wp1; g1.bias = m->bp1; g1.M = Bp; g1.N = m->mlp_pad; g1.K = D; g1.m_valid = batch;
+        g1.out_bf16 = m->pool_h16; g1.ldo = m->mlp_pad; g1.gelu_tanh = gelu_tanh;
+        if (launch_gemm(GEMM_EPI_GELU, g1, st)) return -1;
+        GemmLaunch g2; g2.x = m->pool_h16; g2.w = m->wp2; g2.bias = m->bp2; g2.M = Bp; g2.N = D; g2.K = m->mlp_pad; g2.m_valid = batch;
+        g2.resid = m->pool_o; g2.ldr = D;
+        if (launch_gemm(GEMM_EPI_RESID, g2, st)) return -1;
+    }
     // features /= norm (clip_server.py:115); fp16 rows are what the server serialises (clip_server.py:166)
-    if (launch_l2norm(m->pool_f, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
+    if (launch_l2norm(m->pool_o, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
     if (out_f32) MSE_HIP_TRY(hipMemcpyAsync(out_f32, m->out_f32, (size_t)batch * D * 4, hipMemcpyDeviceToHost, st));
     if (out_f16) MSE_HIP_TRY(hipMemcpyAsync(out_f16, m->out_f16, (size_t)batch * D * 2, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipStreamSynchronize(st));
