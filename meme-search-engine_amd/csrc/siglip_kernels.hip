@@ -1394,6 +1394,29 @@ __global__ void patchify_kernel(const T* __restrict__ img, int B, int C, int H, 
     }
 }
 
+// Same layout, patch size a compile-time constant (divisions become multiplies) and 8 output elements = one 16-byte store per
+// thread: one workgroup per token row, thread c8 writes columns 8 c8 .. 8 c8 + 7.
+template <typename T, int P>
+__global__ __launch_bounds__(128) void patchify8_kernel(const T* __restrict__ img, int C, int H, int Wd, int k_pad, int tstride,
+                                                        uint16_t* __restrict__ out) {
+    const unsigned gw = (unsigned)Wd / P, tokens = gw * ((unsigned)H / P), kk = (unsigned)C * P * P;
+    const unsigned row = blockIdx.x, c8 = threadIdx.x;
+    if (c8 * 8 >= (unsigned)k_pad) return;
+    const unsigned b = row / (unsigned)tstride, t = row % (unsigned)tstride;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned col = c8 * 8 + j;
+        v[j] = 0.0f;
+        if (col < kk && t < tokens) {
+            const unsigned py = t / gw, px = t % gw;
+            const unsigned c = col / (P * P), r = col % (P * P), ky = r / P, kx = r % P;
+            v[j] = (float)img[(((size_t)b * C + c) * H + py * P + ky) * Wd + px * P + kx];
+        }
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)row * k_pad + c8 * 8) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Self attention, flash style, "swapped" products so that all softmax state is per lane:
 //   St[key][query] = K . Q^T   (A = K rows, B = Q rows)     -> lane (query = lane&15) holds 4 keys per 16-key tile
@@ -2260,6 +2283,17 @@ int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int 
 int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
                     hipStream_t st) {
     const size_t total = (size_t)B * tstride * k_pad;
+    if (P == 14 && k_pad % 8 == 0 && k_pad <= 1024 && (size_t)B * tstride < (1u << 31)) {   // the shipped geometry
+        const unsigned rows = (unsigned)((size_t)B * tstride);
+        if (is_f16)
+            hipLaunchKernelGGL((patchify8_kernel<_Float16, 14>), dim3(rows), dim3(128), 0, st, reinterpret_cast<const _Float16*>(img), C, H, W,
+                               k_pad, tstride, out);
+        else
+            hipLaunchKernelGGL((patchify8_kernel<float, 14>), dim3(rows), dim3(128), 0, st, reinterpret_cast<const float*>(img), C, H, W, k_pad,
+                               tstride, out);
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 65535 * 4);
     if (is_f16)
         hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const _Float16*>(img), B,
