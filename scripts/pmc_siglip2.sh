@@ -15,7 +15,7 @@ f=sys.argv[1]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k=r['Kernel_Name']
-    m=re.search(r'(gemm8pp_kernel<[^>]*>|attention64_kernel<\d>|layernorm_kernel)', k)
+    m=re.search(r'(gemm8pp_kernel<[^>]*>|attention64_kernel<[^>]*>|layernorm_kernel)', k)
     if not m:
         if 'layernorm_kernelIDF16' in k: name='layernorm_kernel<half>'
         else: continue
