@@ -47,6 +47,10 @@ struct mse_siglip {
     int max_batch = 0;
     size_t m_pad = 0;
     hipStream_t stream = nullptr;
+    static constexpr int MAX_SIDE = 3;
+    hipStream_t side[MAX_SIDE] = {};   // further streams of a forward pass (MSE_SIGLIP_STREAMS = 1 + how many are used; default 2)
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
+    int n_side = 0;
     std::vector<void*> allocs;
     std::map<std::string, Slot> slots;
     bool finalized = false;
@@ -115,6 +119,15 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     // 8- and 16-token pieces never straddle two images (the transposed V scatter of the QKV epilogue needs that)
     m->m_pad = round_up((size_t)m->max_batch * m->n_pad, 256);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
+    {
+        const char* e = getenv("MSE_SIGLIP_STREAMS");
+        m->n_side = std::min(std::max((e ? atoi(e) : 2) - 1, 0), (int)mse_siglip::MAX_SIDE);
+        bool ok = m->n_side == 0 || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < m->n_side; i++)
+            ok = hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { mse_siglip_destroy(m); fail("hipStreamCreate failed"); return nullptr; }
+    }
     const size_t D = m->D, MP = m->mlp_pad, DP = round_up(D, 256);
     m->dp = (int)DP;
     // parameters (names: clip_server.py:40-57)
@@ -194,6 +207,11 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
 
 void mse_siglip_destroy(mse_siglip* m) {
     if (!m) return;
+    for (int i = 0; i < mse_siglip::MAX_SIDE; i++) {
+        if (m->side[i]) { (void)hipStreamSynchronize(m->side[i]); (void)hipStreamDestroy(m->side[i]); }
+        if (m->ev_join[i]) (void)hipEventDestroy(m->ev_join[i]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stage) (void)hipFree(m->stage);
@@ -339,82 +357,117 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         img = m->img_dev;
     }
     const int D = m->D, T = m->tokens, TS = m->n_pad, DP = m->dp;
-    const int M = batch * TS;   // rows incl. the (finite, never read as keys) padding rows of every image
-    const int Mp = (int)round_up(M, 256);
     const int gelu_tanh = c.gelu_tanh;
-    // PatchEmbedder + PositionalEmbeddings (model.py:57-80,122)
-    if (launch_patchify(img, dtype, batch, c.in_chans, c.img_size, c.img_size, c.patch_size, m->kpe_pad, TS, m->patches, st)) return -1;
-    {
-        GemmLaunch g; g.x = m->patches; g.w = m->wpe; g.bias = m->bpe; g.M = Mp; g.N = D; g.K = m->kpe_pad; g.m_valid = M;
-        g.out_bf16 = m->x; g.ldo = D; g.ldr = D; g.pos = m->pos; g.tokens = TS;   // writes the fp16 residual stream
-        if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
-    }
-    const bool fused = m->fused && gemm_fused_ok(Mp, D, m->mlp_pad, m->H, m->dh, TS, m->n_pad, M);
-    if (fused && launch_row_stats(m->x, D, D, (size_t)Mp, c.eps, m->ln_stats, st)) return -1;
-    for (int i = 0; fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44) with LN1 / LN2 folded into the GEMMs around them
-        const Block& b = m->blocks[i];
+    const size_t img_stride = (size_t)c.in_chans * c.img_size * c.img_size * (dtype ? 2 : 4);
+    // The trunk (patch embedding .. MAP-head pooling) of images [b0, b0 + batch) on stream st: every activation buffer is indexed by
+    // image or by token row b * n_pad + t, so a sub-batch that starts at a multiple of 8 images (= 23 whole 256-row blocks) is just
+    // an offset into each of them.
+    auto trunk = [&](int b0, int batch, hipStream_t st) -> int {
+        const size_t r0 = (size_t)b0 * TS, bh0 = (size_t)b0 * m->H;
+        const void* v_img = reinterpret_cast<const char*>(img) + (size_t)b0 * img_stride;
+        uint16_t* v_patches = m->patches + r0 * m->kpe_pad;
+        uint16_t *v_x = m->x + r0 * D, *v_h = m->h + r0 * D, *v_dlt = m->dlt + r0 * DP, *v_mlp_h = m->mlp_h + r0 * m->mlp_pad;
+        uint16_t* v_kvb = m->kvb + r0 * 2 * D;
+        float* v_ln_stats = m->ln_stats ? m->ln_stats + 2 * r0 : nullptr;
+        float* v_ln_part = m->ln_part ? m->ln_part + 2 * r0 : nullptr;
+        uint16_t* v_qb = m->qb + bh0 * m->n_pad * m->dh_pad;
+        uint16_t* v_kb = m->kb + bh0 * m->n_pad * attention_k_stride();
+        uint16_t* v_vtb = m->vtb + bh0 * m->dv_pad * m->n_pad;
+        float* v_pool_a = m->pool_a + (size_t)b0 * D;
+        const int M = batch * TS;   // rows incl. the (finite, never read as keys) padding rows of every image
+        const int Mp = (int)round_up(M, 256);
+        // PatchEmbedder + PositionalEmbeddings (model.py:57-80,122)
+        if (launch_patchify(v_img, dtype, batch, c.in_chans, c.img_size, c.img_size, c.patch_size, m->kpe_pad, TS, v_patches, st)) return -1;
         {
-            GemmLaunch g; g.x = m->x; g.w = b.wqkv16; g.bias = b.bqkv2; g.csum = b.cqkv; g.ln_stats = m->ln_stats;
-            g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
-            g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
-            g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
-            if (launch_gemm_fused(GEMM_EPI_QKV, g, st)) return -1;
+            GemmLaunch g; g.x = v_patches; g.w = m->wpe; g.bias = m->bpe; g.M = Mp; g.N = D; g.K = m->kpe_pad; g.m_valid = M;
+            g.out_bf16 = v_x; g.ldo = D; g.ldr = D; g.pos = m->pos; g.tokens = TS;   // writes the fp16 residual stream
+            if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
         }
-        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
-            g.xres = m->x; g.ldr = D; g.part = m->ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
-            if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, st)) return -1;   // x += attention branch, statistics for LN2
+        const bool fused = m->fused && gemm_fused_ok(Mp, D, m->mlp_pad, m->H, m->dh, TS, m->n_pad, M);
+        if (fused && launch_row_stats(v_x, D, D, (size_t)Mp, c.eps, v_ln_stats, st)) return -1;
+        for (int i = 0; fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44) with LN1 / LN2 folded into the GEMMs around them
+            const Block& b = m->blocks[i];
+            {
+                GemmLaunch g; g.x = v_x; g.w = b.wqkv16; g.bias = b.bqkv2; g.csum = b.cqkv; g.ln_stats = v_ln_stats;
+                g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
+                g.q = v_qb; g.k = v_kb; g.vt = v_vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+                g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+                if (launch_gemm_fused(GEMM_EPI_QKV, g, st)) return -1;
+            }
+            if (launch_attention(v_qb, v_kb, v_vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, v_h, D, TS, st)) return -1;
+            {
+                GemmLaunch g; g.x = v_h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
+                g.xres = v_x; g.ldr = D; g.part = v_ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
+                if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, st)) return -1;   // x += attention branch, statistics for LN2
+            }
+            if (launch_ln_finalize(v_ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, v_ln_stats, st)) return -1;
+            {
+                GemmLaunch g; g.x = v_x; g.w = b.w116; g.bias = b.b12; g.csum = b.c1; g.ln_stats = v_ln_stats;
+                g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M; g.out_bf16 = v_mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
+                if (launch_gemm_fused(GEMM_EPI_GELU, g, st)) return -1;
+            }
+            {
+                GemmLaunch g; g.x = v_mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
+                g.xres = v_x; g.ldr = D; g.part = v_ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
+                if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, st)) return -1;   // x += MLP branch, statistics for the next LN1
+            }
+            if (i + 1 < c.depth && launch_ln_finalize(v_ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, v_ln_stats, st)) return -1;
         }
-        if (launch_ln_finalize(m->ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, m->ln_stats, st)) return -1;
-        {
-            GemmLaunch g; g.x = m->x; g.w = b.w116; g.bias = b.b12; g.csum = b.c1; g.ln_stats = m->ln_stats;
-            g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M; g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
-            if (launch_gemm_fused(GEMM_EPI_GELU, g, st)) return -1;
+        for (int i = 0; !fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
+            const Block& b = m->blocks[i];
+            // x += (fc2 output of the previous block), then LayerNorm
+            if (launch_layernorm(v_x, 1, D, i ? v_dlt : nullptr, DP, b.ln1_g, b.ln1_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;
+            {
+                GemmLaunch g; g.x = v_h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
+                g.q = v_qb; g.k = v_kb; g.vt = v_vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+                g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+                if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
+            }
+            if (launch_attention(v_qb, v_kb, v_vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, v_h, D, TS, st)) return -1;
+            {
+                GemmLaunch g; g.x = v_h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
+                g.out_bf16 = v_dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm (columns >= D are padding)
+                if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
+            }
+            if (launch_layernorm(v_x, 1, D, v_dlt, DP, b.ln2_g, b.ln2_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;   // x += attention branch
+            {
+                GemmLaunch g; g.x = v_h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
+                g.out_bf16 = v_mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
+                if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
+            }
+            {
+                GemmLaunch g; g.x = v_mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
+                g.out_bf16 = v_dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm
+                if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
+            }
         }
+        if (launch_layernorm(v_x, 1, D, (c.depth && !fused) ? v_dlt : nullptr, DP, m->lnf_g, m->lnf_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;  // model.py:50,55
+        // MAPHead (model.py:82-111)
         {
-            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
-            g.xres = m->x; g.ldr = D; g.part = m->ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
-            if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, st)) return -1;   // x += MLP branch, statistics for the next LN1
-        }
-        if (i + 1 < c.depth && launch_ln_finalize(m->ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, m->ln_stats, st)) return -1;
-    }
-    for (int i = 0; !fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
-        const Block& b = m->blocks[i];
-        // x += (fc2 output of the previous block), then LayerNorm
-        if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, DP, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
-            g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
-            g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
-            if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
-        }
-        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, TS, st)) return -1;
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
-            g.out_bf16 = m->dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm (columns >= D are padding)
+            GemmLaunch g; g.x = v_h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
+            g.out_bf16 = v_kvb; g.ldo = 2 * D;
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
-        if (launch_layernorm(m->x, 1, D, m->dlt, DP, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
-            g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
-            if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
+        if (launch_pool_attention(v_kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, v_pool_a, D, st)) return -1;
+        return 0;
+    };
+    // Sub-batches on separate streams: a persistent GEMM's last round leaves most CUs idle (736 row blocks over 256 CUs), and another
+    // sub-batch's next kernel takes them.  MSE_SIGLIP_STREAMS=1 keeps the whole batch on one stream.
+    const int parts = std::min(m->n_side + 1, batch / 16);
+    const int per = parts > 1 ? (int)round_up((size_t)(batch + parts - 1) / parts, 8) : batch;
+    if (parts > 1 && per < batch) {
+        MSE_HIP_TRY(hipEventRecord(m->ev_fork, st));
+        int used = 0;
+        for (int b0 = per; b0 < batch; b0 += per, used++) {
+            MSE_HIP_TRY(hipStreamWaitEvent(m->side[used], m->ev_fork, 0));
+            if (trunk(b0, std::min(per, batch - b0), m->side[used])) return -1;
+            MSE_HIP_TRY(hipEventRecord(m->ev_join[used], m->side[used]));
         }
-        {
-            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
-            g.out_bf16 = m->dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm
-            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
-        }
+        if (trunk(0, per, st)) return -1;
+        for (int i = 0; i < used; i++) MSE_HIP_TRY(hipStreamWaitEvent(st, m->ev_join[i], 0));
+    } else if (trunk(0, batch, st)) {
+        return -1;
     }
-    if (launch_layernorm(m->x, 1, D, (c.depth && !fused) ? m->dlt : nullptr, DP, m->lnf_g, m->lnf_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;  // model.py:50,55
-    // MAPHead (model.py:82-111)
-    {
-        GemmLaunch g; g.x = m->h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
-        g.out_bf16 = m->kvb; g.ldo = 2 * D;
-        if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
-    }
-    if (launch_pool_attention(m->kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, m->pool_a, D, st)) return -1;
     // proj, LayerNorm, MLP with residual on the matrix cores: the batch is one (or a few) 256-row block of the same GEMM kernels
     // (rows >= batch are zero padding; the fp32 accumulating epilogue builds pool_o = proj, then pool_o += fc2)
     {
