@@ -409,7 +409,10 @@ def siglip_bench(args, world, rank, dist=None):
                        "weights": "random-init (seeded), architecture of ViT-SO400M-14-SigLIP-384"},
             "steps": args.siglip_steps, "scaling": "weak (replicas)", "text_tower": text,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
-                         "flop_per_image": gflop_img * 1e9, "traffic": None}}
+                         "flop_per_image": gflop_img * 1e9, "traffic": None,
+                         "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.79 of 2.4 GHz "
+                                 "(profiles/r02_power_clocks.txt); the library GEMM alone runs these shapes at 0.38-0.50 of the same peak "
+                                 "(profiles/r02_gemm_calibration.txt)"}}
 
 
 def main():
