@@ -140,6 +140,28 @@ def test_fused_layernorm_equals_separate_layernorm(gpu, mse, ref, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [32, 41])
+def test_sub_batches_on_two_streams_change_nothing(gpu, mse, ref, monkeypatch, batch):
+    """A forward pass of >= 32 images runs as two sub-batches on two streams; every row's arithmetic is the same as on
+    one stream, so the features must be bit-equal (41 images split 24 + 17: the second sub-batch starts on a 256-row block boundary
+    and ends inside one)."""
+    from mse import siglip
+    cfg = dict(ref.CONFIG, depth=2)
+    sd = {"visual." + k: v for k, v in ref.synthetic_weights(cfg).items()}
+    img = ref.synthetic_images(batch, cfg).numpy().astype(np.float16)
+    two = siglip.SiglipImageEngine.from_state_dict(sd, dict(siglip.SO400M_384, depth=2), max_batch=48)
+    got2 = two.encode_image(img)
+    monkeypatch.setenv("MSE_SIGLIP_STREAMS", "1")
+    one = siglip.SiglipImageEngine.from_state_dict(sd, dict(siglip.SO400M_384, depth=2), max_batch=48)
+    monkeypatch.delenv("MSE_SIGLIP_STREAMS")
+    got1 = one.encode_image(img)
+    assert np.array_equal(got1, got2)
+    assert np.isfinite(got2).all() and np.all(np.abs(np.linalg.norm(got2, axis=1) - 1) < 1e-3)
+    # and a small batch (one stream either way) after the large one still equals its rows of the large batch
+    assert np.array_equal(two.encode_image(img[:3]), got2[:3])
+
+
+@pytest.mark.gpu
 def test_engine_with_massive_activation_channels(gpu, mse, ref):
     """Trained ViTs carry a few residual channels hundreds of times larger than the rest ("massive activations"); the seeded
     Gaussian weights of the other tests never do.  Plant them -- biases of +3000 / -800 / +12000 on three channels of the
