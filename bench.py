@@ -694,7 +694,8 @@ def main():
             "dtype": "f16 in, f32 accumulate, i64 fixed-point scores",
             "data": "synthetic (device-generated unit-norm rows, seeds 0x5EED0001/2)",
             "config": {"workload": f"brute-force top-{k} over {n_total} x {D} fp16 rows, {nq} queries/step, "
-                                   f"row-sharded over {n_gpus} GPU(s)" + (" + RCCL all-gather of [Q,k] records" if world > 1 else
+                                   f"row-sharded over {n_gpus} GPU(s)" + (" + FALLBACK gloo all-gather of [Q,k] records (RCCL did not come up)" if host_exchange is not None else
+                                                                          " + RCCL all-gather of [Q,k] records" if world > 1 else
                                                                           " + peer-mapped gather of [Q,k] records" if in_process else ""),
                        "rows_total": n_total, "rows_per_gpu": hi - lo, "queries_per_step": nq, "k": k,
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
