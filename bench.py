@@ -522,6 +522,10 @@ def main():
             # did not (no usable bootstrap interface, ...) ALL ranks fall back to carrying the same packed blocks over the gloo
             # control plane and merging them with the same device kernel -- slower, loudly labelled, but the line is still measured.
             err = ""
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+                # one node, rendezvous on loopback: let RCCL's bootstrap use the loopback interface too when nothing else is
+                # named (boxes without a routable interface otherwise fail with "no socket interface found")
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             with _stdout_to_stderr():
                 try:
                     ids = [mse.Comm.unique_id() if rank == 0 else None]
