@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
             for (int ks = 0; ks < 3; ks++)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
-                    const bf16x8 kf = ABL == 3 ? qf[0][ks] : as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
+                    const bf16x8 kf = (ABL == 3 || ABL == 4) ? qf[0][ks] : as_bf8(*reinterpret_cast<const u32x4*>(kl + (h2 * 16 + i) * ATT_KROW + ks * 64 + g * 16));
                     if (ABL == 2) { s[0][h2][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, kf[0]) << 16); continue; }
 #pragma unroll
                     for (int qt = 0; qt < QT; qt++) s[qt][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][h2], 0, 0, 0);
@@ -1780,9 +1780,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
             for (int t = 0; t < 5; t++) {
                 // Vt row e = 16t + i; keys {4g..+3} and {16+4g..+3} of this half = 8-byte halves of pieces hh*4 + (g>>1), +2
                 const char* vrow = vst + (t * 16 + i) * 128 + (g & 1) * 8;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + (g >> 1)) ^ vsw) * 16));
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((hh * 4 + 2 + (g >> 1)) ^ vsw) * 16));
-                const bf16x8 vf = ABL == 3 ? pf[0] : as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
+                // volatile: keeps these as single ds_read_b64 (2 LDS cycles each, conflict-free in this layout).  Left alone the
+                // compiler pairs the reads of two row tiles into ds_read2st64_b64, whose 16-lane groups and mod-32 banking turn
+                // the same addresses into 11 LDS cycles per instruction (SQ_LDS_BANK_CONFLICT: 36 M cycles per launch, all from here)
+                typedef const volatile __attribute__((address_space(3))) uint64_t* lds_u64_ptr;
+                const uint64_t lo64 = *(lds_u64_ptr)(vrow + (((hh * 4 + (g >> 1)) ^ vsw) * 16));
+                const uint64_t hi64 = *(lds_u64_ptr)(vrow + (((hh * 4 + 2 + (g >> 1)) ^ vsw) * 16));
+                const uint2 lo = uint2{(uint32_t)lo64, (uint32_t)(lo64 >> 32)}, hi = uint2{(uint32_t)hi64, (uint32_t)(hi64 >> 32)};
+                const bf16x8 vf = (ABL == 3 || ABL == 5) ? pf[0] : as_bf8(u32x4{lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
                 for (int qt = 0; qt < QT; qt++) {
                     if (ABL == 2) { o[qt][t][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, vf[0]) << 16) + __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, pf[qt][0]) << 16); continue; }
@@ -2335,7 +2340,7 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
                                             hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
             hipLaunchKernelGGL((attention64_kernel<0, 4, 4>), dim3((unsigned)(B * heads * qblocks)), dim3(256), AT6_NS * AT6_STAGE, st,
                                q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
-        } else if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else MSE_ATT64(0)
+        } else if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else if (abl64 == 4) MSE_ATT64(4) else if (abl64 == 5) MSE_ATT64(5) else MSE_ATT64(0)
 #undef MSE_ATT64
         MSE_HIP_TRY(hipGetLastError());
         return 0;
