@@ -4,6 +4,9 @@
 #include "runtime.h"
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <new>
 
 namespace mse {
@@ -13,6 +16,19 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(const std::string& msg) {
     g_last_error = msg;
     return -1;
+}
+
+int ensure_dyn_lds(const void* kernel, int bytes) {
+    int dev = 0;
+    MSE_HIP_TRY(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> granted;
+    std::lock_guard<std::mutex> lk(mu);
+    int& have = granted[{kernel, dev}];
+    if (have >= bytes) return 0;
+    MSE_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+    return 0;
 }
 
 int DevBuf::ensure(size_t bytes) {

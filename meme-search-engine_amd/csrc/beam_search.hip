@@ -473,11 +473,7 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
     a.err = cnt.as<uint32_t>() + 3 * nq;
     const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16;
-    static bool attr = false;
-    if (!attr) {
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(beam_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attr = true;
-    }
+    MSE_DYN_LDS(beam_search_kernel, 160 * 1024 - 1024);
     hipLaunchKernelGGL(beam_search_kernel, dim3((unsigned)nq), dim3(BS_THREADS), lds, st, a);
     MSE_HIP_TRY(hipGetLastError());
     uint32_t err = 0;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <stdlib.h>
 
 namespace mse {
 
@@ -26,6 +27,23 @@ int fail(const std::string& msg);  // sets the error, returns -1
             ::mse::fail(std::string(#expr) + ": " + hipGetErrorString(_e));                       \
             return nullptr;                                                                       \
         }                                                                                         \
+    } while (0)
+
+// Developer knobs (older kernels for A/B timing, ablations) exist only in the developer library (make dev, -DMSE_DEV_KERNELS):
+// in the product build the environment variable is never read.
+#ifdef MSE_DEV_KERNELS
+#define MSE_DEV_KNOB(name) (getenv(name) != nullptr)
+#else
+#define MSE_DEV_KNOB(name) (false)
+#endif
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remembered per (kernel, device ordinal),
+// raised when a larger request arrives.  (A flag per call site is wrong twice over: a second device never gets the attribute, and
+// kernels of one signature share a function-template's statics.)
+int ensure_dyn_lds(const void* kernel, int bytes);
+#define MSE_DYN_LDS(kernel, bytes)                                                                \
+    do {                                                                                          \
+        if (::mse::ensure_dyn_lds(reinterpret_cast<const void*>(kernel), (int)(bytes))) return -1; \
     } while (0)
 
 constexpr int D_MAX = 4096;  // largest embedding width the kernels accept (multiple of 64)

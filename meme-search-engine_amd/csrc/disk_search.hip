@@ -202,7 +202,7 @@ int mse_dedup_visited(mse_searcher* s, const uint32_t* ids, size_t n, float thre
     hipStream_t st = s->stream;
     if (s->cand_ids.ensure(n * 4) || s->misc.ensure(n * (size_t)words * 8)) return -1;
     MSE_HIP_TRY(hipMemcpyAsync(s->cand_ids.p, ids, n * 4, hipMemcpyHostToDevice, st));
-    static const bool old_sim = getenv("MSE_DEDUP_OLD") != nullptr;   // developer knob
+    static const bool old_sim = MSE_DEV_KNOB("MSE_DEDUP_OLD");
     if (old_sim) {
         const size_t waves = n * (size_t)words;
         hipLaunchKernelGGL(sim_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, b->dev, b->n, (int)b->d,

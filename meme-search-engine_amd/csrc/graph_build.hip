@@ -1107,7 +1107,7 @@ int mfma_bound(const mse_base* b, const mse_build_config* cfg, hipStream_t st, l
 }
 
 template <typename K> int set_lds(K kernel) {
-    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    MSE_DYN_LDS(kernel, 96 * 1024);
     return 0;
 }
 

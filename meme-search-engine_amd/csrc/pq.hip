@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const int64_t* __restrict__ s
 
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream) {
     if (n == 0) return 0;
-    static const bool old_t = getenv("MSE_PQ_OLDTRANSFORM") != nullptr;   // developer knob
+    static const bool old_t = MSE_DEV_KNOB("MSE_PQ_OLDTRANSFORM");
     if (n >= 32 && !old_t) {
         dim3 grid4((d + T4_B - 1) / T4_B, (unsigned)((n + T4_B - 1) / T4_B));
         hipLaunchKernelGGL(pq_transform_tiled_kernel, grid4, dim3(256), 0, stream, T, d, x, n, out);
@@ -434,7 +434,7 @@ int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, 
                        uint8_t* codes, hipStream_t stream) {
     const size_t total = n * (size_t)(d / dpc);
     if (total == 0) return 0;
-    static const bool old_q = getenv("MSE_PQ_OLDQUANT") != nullptr;   // developer knob
+    static const bool old_q = MSE_DEV_KNOB("MSE_PQ_OLDQUANT");
     if (dpc == 18 && n_centroids <= 256 && !old_q) {       // the reference's codec shape (aopq_train.py:9-13)
         constexpr int VPT = 4;
         const size_t per_block = 256 * VPT;
@@ -456,12 +456,7 @@ bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, 
 int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
                         int64_t* gmax, int n_cu, hipStream_t stream) {
     if (n == 0) return 0;
-    static bool attr = false;
-    if (!attr) {
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_scan64_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, PQS_LDS));
-        attr = true;
-    }
+    MSE_DYN_LDS(pq_scan64_kernel<true>, PQS_LDS);
     const size_t groups = (n + 63) / 64;
     // one 133-KiB workgroup per CU, on all but a few CUs: the single-workgroup kernels of another query's tail (radix selects,
     // ~50 KiB of LDS each) can then run beside a scan instead of queueing behind all of its workgroups (-1.6 % scan rate)
@@ -478,14 +473,9 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
                   int n_cu, hipStream_t stream) {
     if (n == 0) return 0;
     const bool desc_ok = !(desc && scales) || n_desc == 4;
-    static const bool old_scan = getenv("MSE_PQ_OLDSCAN") != nullptr;   // developer knob
+    static const bool old_scan = MSE_DEV_KNOB("MSE_PQ_OLDSCAN");
     if (!ids && n_chunks == 64 && n_centroids == 256 && desc_ok && n == n_codes && !old_scan) {
-        static bool attr = false;
-        if (!attr) {
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_scan64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            PQS_LDS));
-            attr = true;
-        }
+        MSE_DYN_LDS(pq_scan64_kernel<false>, PQS_LDS);
         const size_t groups = (n + 63) / 64;
         const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, (size_t)n_cu);
         hipLaunchKernelGGL(pq_scan64_kernel<false>, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
@@ -496,8 +486,7 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
     const size_t lds = (size_t)n_chunks * n_centroids * 4;
     if (lds > 160 * 1024) return fail("PQ table does not fit LDS");
     if (lds > 64 * 1024) {
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_adc_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MSE_DYN_LDS(pq_adc_kernel, lds);
     }
     size_t blocks = (n + 255) / 256;
     const size_t cap = (size_t)n_cu * 8;

@@ -62,6 +62,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mse {
 namespace {
@@ -284,24 +285,403 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
     vm_wait<0>();  // nothing may still be writing this workgroup's LDS when it is released
 }
 
-template <int S, int NCT, int ABL = 0>
-int launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
-                   float* group_max, int nq_pad) {
+
+// Round 3: 2-D wave split of the 256-query pass.  The 8 waves form 4 row groups x 2 query halves; a wave owns 64 rows x 128
+// queries (4 x 8 MFMA tiles, the same 128 accumulator registers).  Per K block a wave now reads 8 A + 16 B fragments from LDS
+// (24 KiB) instead of 4 + 32 (36 KiB), and every B fragment feeds four MFMAs.  The two waves of a row group share one ring
+// (S stages x 64 rows x 128 B); each DMAs the 32 rows of its own half.  No extra barrier: the wait + barrier that publishes
+// the next query tile at the end of iteration kb also covers X block kb+1 (issued one iteration earlier, and older in the
+// in-order vmcnt queue than the query pieces the wait is counted for).
+// MF = 16: v_mfma_f32_16x16x32_f16; MF = 32: v_mfma_f32_32x32x16_f16 (2 x 4 tiles of 32 x 32, 16 accumulators each) over the
+// same LDS images.
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+#ifdef MSE_DEV_KERNELS
+// developer profile of the 2-D kernel (PROF = 1): shader cycles a wave spends [0] issuing a K block (barrier release -> closing wait),
+// [1] in the closing vmcnt wait, [2] at the barrier; [3] = K blocks counted.  s_memtime stamps sit where lgkmcnt is drained anyway.
+__device__ unsigned long long g_scan_prof[4];
+__device__ __forceinline__ uint32_t memtime() { return (uint32_t)__builtin_amdgcn_s_memtime(); }   // deltas fit 32 bits
+#endif
+
+template <int S, int MF, int PROF = 0>
+__global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
+                                                             const uint4* __restrict__ packed_ro,
+                                                             float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
+    constexpr int BN = 256;
+    constexpr int QT_BYTES = BN * 128;
+    constexpr int QI = BN / 64;
+    constexpr int RG_BYTES = 64 * 128;       // one K block of a row group
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rg = wave >> 1, qh = wave & 1;
+    const int nkb = d / KB;
+    const size_t row_bytes = (size_t)d * 2;
+    const size_t n_groups = (n_rows + 31) / 32;
+    char* const qbase = smem;
+    char* const xbase = smem + 2 * QT_BYTES + rg * (S * RG_BYTES);
+    const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)(wave * QI * 64 + lane) * 16;
+
+    size_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+
+    // this wave's DMA share of a K block: rows qh*32 + 8u + (lane>>3) of the row group, u = 0..3
+    auto src_ptr = [&](size_t t, int u) -> const char* {
+        const int r = qh * 32 + 8 * u + (lane >> 3);
+        size_t row = t * TILE_ROWS + rg * 64 + r;
+        if (row >= n_rows) row = n_rows - 1;
+        const int piece = (lane & 7) ^ ((r >> 1) & 7);
+        return reinterpret_cast<const char*>(base) + row * row_bytes + piece * 16;
+    };
+    const char* rp[4];
+    const char* rn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) rp[u] = src_ptr(tile, u);
+    {
+        char* qdst = qbase + wave * (QI * 1024);
+#pragma unroll
+        for (int u = 0; u < QI; u++) dma16(packed + u * 1024, qdst + u * 1024);
+#pragma unroll
+        for (int j = 0; j < S - 1; j++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) dma16(rp[u] + (size_t)(j % nkb) * 128, xbase + j * RG_BYTES + (qh * 4 + u) * 1024);
+    }
+    vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addressing: MF = 16: lane (i = lane & 15, g = lane >> 4): row / query i of a 16-tile, 16-byte k slot 4*ks + g;
+    //                      MF = 32: lane (i = lane & 31, g = lane >> 5): row / query i of a 32-tile, k slot 2*ks + g (ks = 0..3)
+    const int i = MF == 16 ? (lane & 15) : (lane & 31);
+    const int g = MF == 16 ? (lane >> 4) : (lane >> 5);
+    const int swz = (i >> 1) & 7;
+    constexpr int NKS = MF == 16 ? 2 : 4;          // k steps per K block
+    constexpr int NRT = 64 / MF, NCTW = 128 / MF;  // row / column tiles of the wave
+    constexpr int NACC = MF == 16 ? 4 : 16;
+    typedef typename std::conditional<MF == 16, float4v, float16v>::type accv;
+
+    int buf = 0;
+#ifdef MSE_DEV_KERNELS
+    uint32_t pt_issue = 0, pt_wait = 0, pt_bar = 0, pt_n = 0, pt_last = 0;
+    if constexpr (PROF) pt_last = memtime();
+#endif
+    while (true) {
+        accv acc[NRT][NCTW];
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+            for (int ct = 0; ct < NCTW; ct++)
+#pragma unroll
+                for (int r = 0; r < NACC; r++) acc[rt][ct][r] = 0.0f;
+
+        const size_t next_tile = tile + gridDim.x;
+        const bool has_next_tile = next_tile < n_tiles;
+#pragma unroll
+        for (int u = 0; u < 4; u++) rn[u] = has_next_tile ? src_ptr(next_tile, u) : rp[u];
+
+        for (int kb0 = 0; kb0 < nkb; kb0 += S) {
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                const int kb = kb0 + j;
+                const int kq = kb + 1 == nkb ? 0 : kb + 1;
+                const int kf = kb + S - 1;
+                const bool x_next = kf >= nkb;
+                const size_t xoff = (size_t)(kf >= nkb ? kf - nkb : kf) * 128;
+                char* const xdst = xbase + ((j + S - 1) % S) * RG_BYTES + qh * 4096;
+                const char* const qsrc = packed + (size_t)kq * QT_BYTES;
+                char* const qdst = qbase + (buf ^ 1) * QT_BYTES + wave * (QI * 1024);
+                auto issue_piece = [&](int p) {
+                    if (p < QI) dma16(qsrc + p * 1024, qdst + p * 1024);
+                    else dma16((x_next ? rn[p - QI] : rp[p - QI]) + xoff, xdst + (p - QI) * 1024);
+                };
+                if (S == 2) vm_wait<0>();
+
+                const u32x4* xs = reinterpret_cast<const u32x4*>(xbase + j * RG_BYTES) + i * 8;
+                const u32x4* qt = reinterpret_cast<const u32x4*>(qbase + buf * QT_BYTES) + (qh * 128 + i) * 8;
+                auto slot = [&](int ks) { return (MF == 16 ? (4 * ks + g) : (2 * ks + g)) ^ swz; };
+                half8 a[2][NRT];   // A fragments of k step ks live in a[ks & 1]; the next k step's are read while this one multiplies
+#pragma unroll
+                for (int rt = 0; rt < NRT; rt++) a[0][rt] = as_half8(xs[rt * (MF * 8) + slot(0)]);
+                constexpr int NT = NKS * NCTW;   // B fragments per K block: 16 in both forms
+                u32x4 bq[3];
+                bq[0] = qt[0 * (MF * 8) + slot(0)];
+                bq[1] = qt[1 * (MF * 8) + slot(0)];
+#pragma unroll
+                for (int t = 0; t < NT; t++) {   // t = ks * NCTW + ct
+                    const int ks = t / NCTW, ct = t % NCTW;
+                    if (t + 2 < NT) bq[(t + 2) % 3] = qt[((t + 2) % NCTW) * (MF * 8) + slot((t + 2) / NCTW)];
+                    if (ct == NCTW - 2 && ks + 1 < NKS) {
+#pragma unroll
+                        for (int rt = 0; rt < NRT; rt++) a[(ks + 1) & 1][rt] = as_half8(xs[rt * (MF * 8) + slot(ks + 1)]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        constexpr int STEP = NT / (QI + 4);
+                        if (t >= 1 && (t - 1) % STEP == 0 && (t - 1) / STEP < QI + 4) {
+                            issue_piece((t - 1) / STEP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    const half8 b = as_half8(bq[t % 3]);
+#pragma unroll
+                    for (int rt = 0; rt < NRT; rt++) {
+                        if constexpr (MF == 16) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks & 1][rt], b, acc[rt][ct], 0, 0, 0);
+                        else acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][rt], b, acc[rt][ct], 0, 0, 0);
+                    }
+                }
+#ifdef MSE_DEV_KERNELS
+                if constexpr (PROF) {
+                    const uint32_t t0 = memtime();
+                    vm_wait<4>();
+                    const uint32_t t1 = memtime();
+                    __builtin_amdgcn_s_barrier();
+                    const uint32_t t2 = memtime();
+                    pt_issue += t0 - pt_last; pt_wait += t1 - t0; pt_bar += t2 - t1; pt_n++; pt_last = t2;
+                } else
+#endif
+                {
+                    vm_wait<4>();
+#ifdef MSE_DEV_KERNELS
+                    if constexpr (PROF != 2)   // PROF = 2: timing ablation WITHOUT the barrier (racy, results meaningless)
+#endif
+                    __builtin_amdgcn_s_barrier();
+                }
+                buf ^= 1;
+            }
+        }
+
+        // epilogue: per query column, max over each 32-row group of this wave (two groups)
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const size_t group = tile * W + rg * 2 + p;
+#pragma unroll
+            for (int ct = 0; ct < NCTW; ct++) {
+                float m;
+                if constexpr (MF == 16) {
+                    m = fmaxf(fmaxf(acc[2 * p][ct][0], acc[2 * p][ct][1]), fmaxf(acc[2 * p][ct][2], acc[2 * p][ct][3]));
+                    m = fmaxf(m, fmaxf(fmaxf(acc[2 * p + 1][ct][0], acc[2 * p + 1][ct][1]), fmaxf(acc[2 * p + 1][ct][2], acc[2 * p + 1][ct][3])));
+                    m = fmaxf(m, __shfl_xor(m, 16));
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                } else {
+                    m = acc[p][ct][0];
+#pragma unroll
+                    for (int r = 1; r < 16; r++) m = fmaxf(m, acc[p][ct][r]);
+                    m = fmaxf(m, __shfl_xor(m, 32));
+                }
+                if (g == 0 && group < n_groups) gmax[group * (size_t)nq_pad + qh * 128 + ct * MF + i] = m;
+            }
+        }
+
+        if (!has_next_tile) break;
+        tile = next_tile;
+#pragma unroll
+        for (int u = 0; u < 4; u++) rp[u] = rn[u];
+#ifdef MSE_DEV_KERNELS
+        if constexpr (PROF) pt_last = memtime();   // the epilogue is not charged to the next K block
+#endif
+    }
+    vm_wait<0>();
+#ifdef MSE_DEV_KERNELS
+    if constexpr (PROF) {
+        if (lane == 0) {
+            atomicAdd(&g_scan_prof[0], (unsigned long long)pt_issue); atomicAdd(&g_scan_prof[1], (unsigned long long)pt_wait);
+            atomicAdd(&g_scan_prof[2], (unsigned long long)pt_bar); atomicAdd(&g_scan_prof[3], (unsigned long long)pt_n);
+        }
+    }
+#endif
+}
+
+
+#ifdef MSE_DEV_KERNELS
+// Round 3, third form: the 2-D tiling with the DMA ISSUE specialised by wave.  Waves 0-3 issue all row traffic (wave j streams the
+// 64 rows of row group j: 8 pieces per K block), waves 4-7 all query-tile traffic (8 pieces each).  Every wave still multiplies its
+// 64 x 128 tile.  Why: a wave's loads retire in order, so in the mixed form the closing wait for the next query tile (L2 hits
+// issued a few hundred cycles ago) is also a wait for the row pieces in front of them, which pins the row prefetch to ~1.25 K blocks
+// of flight time.  A row wave's queue holds only row pieces: block kb+2 is issued from the START of iteration kb and must land by
+// the end of iteration kb+1 (~1.9 K blocks of flight), with the same 3-stage ring; a query wave's queue holds only L2 hits.
+// Addresses: per lane two 64-bit pointers per tile (row lane>>3 of the row group, even / odd piece swizzle); a piece adds a
+// wave-uniform offset (8u rows + the K block).  Needs n_rows % 256 == 0: the launcher sends a ragged tail through scan_mfma_kernel.
+// MEASURED (1e7 rows, same box, answers equal the exact-order kernel): 5.98-6.01 ms against 5.59-5.60 ms for the mixed 2-D form --
+// the pass is not bound by the flight time of the row prefetch.  Kept in the developer library only.
+
+template <int S>
+__global__ __launch_bounds__(W * 64) void scan_mfma2s_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
+                                                             const uint4* __restrict__ packed_ro,
+                                                             float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
+    static_assert(S == 3, "the specialised schedule is written for the 3-stage ring");
+    constexpr int BN = 256;
+    constexpr int QT_BYTES = BN * 128;
+    constexpr int RG_BYTES = 64 * 128;
+    constexpr int NP = 8;                    // DMA pieces per wave per K block (rows: 64 x 128 B; queries: 1/4 of the 32 KiB tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave >> 1, qh = wave & 1;
+    const bool row_wave = wave < 4;          // wave-uniform
+    const int w4 = wave & 3;
+    const int nkb = d / KB;
+    const size_t row_bytes = (size_t)d * 2;
+    char* const qbase = smem;
+    char* const xring = smem + 2 * QT_BYTES;                      // [4 row groups][S][8 KiB]
+    char* const xbase = xring + rg * (S * RG_BYTES);              // the ring this wave READS
+    char* const xfill = xring + w4 * (S * RG_BYTES);              // the ring a row wave FILLS (row group = wave)
+    char* const qfill = qbase + w4 * (NP * 1024);                 // a query wave's quarter of a query tile
+    const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)w4 * (NP * 1024) + lane * 16;
+
+    size_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+
+    // row wave j, piece u: row 8u + (lane >> 3) of row group j, 16-byte piece (lane & 7) ^ f(row), f(r) = (r >> 1) & 7 =
+    // ((lane >> 4) + 4 (u & 1)) & 7: the odd pieces' lane offset is the even one with bit 6 flipped (row_bytes is a multiple of 128)
+    const size_t lane_off = (size_t)(lane >> 3) * row_bytes + (size_t)(((lane & 7) ^ (lane >> 4)) * 16);
+    const char* const rows0 = reinterpret_cast<const char*>(base) + (size_t)w4 * 64 * row_bytes;
+    auto tile_ptr = [&](size_t t) { return rows0 + t * TILE_ROWS * row_bytes + lane_off; };
+    const char* lp = tile_ptr(tile);   // even pieces; odd pieces: the same address with bit 6 flipped
+    const char* ln = lp;
+    const size_t piece_rows = 8 * row_bytes;
+    auto dma_row_piece = [&](const char* p, int u, size_t koff, char* dst) {
+        const char* q = (u & 1) ? reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(p) ^ 64u) : p;
+        dma16(q + (u * piece_rows + koff), dst + u * 1024);
+    };
+    if (row_wave) {
+#pragma unroll
+        for (int j = 0; j < S - 1; j++)
+#pragma unroll
+            for (int u = 0; u < NP; u++) dma_row_piece(lp, u, (size_t)(j % nkb) * 128, xfill + j * RG_BYTES);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NP; u++) dma16(packed + u * 1024, qfill + u * 1024);
+    }
+    vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+
+    const int i = lane & 15, g = lane >> 4;
+    const int swz = (i >> 1) & 7;
+    int buf = 0;
+    while (true) {
+        float4v acc[4][8];
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[rt][ct][r] = 0.0f;
+
+        const size_t next_tile = tile + gridDim.x;
+        const bool has_next_tile = next_tile < n_tiles;
+        ln = has_next_tile ? tile_ptr(next_tile) : lp;   // the last tile re-reads its own first blocks
+
+        for (int kb0 = 0; kb0 < nkb; kb0 += S) {
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                const int kb = kb0 + j;
+                const int kq = kb + 1 == nkb ? 0 : kb + 1;
+                const int kf = kb + S - 1;
+                const char* const xp = kf >= nkb ? ln : lp;
+                const size_t xoff = (size_t)(kf >= nkb ? kf - nkb : kf) * 128;
+                char* const xdst = xfill + ((j + S - 1) % S) * RG_BYTES;
+                const char* const qsrc = packed + (size_t)kq * QT_BYTES;
+                char* const qdst = qfill + (buf ^ 1) * QT_BYTES;
+                auto issue_piece = [&](int p) {
+                    if (row_wave) dma_row_piece(xp, p, xoff, xdst);
+                    else dma16(qsrc + p * 1024, qdst + p * 1024);
+                };
+
+                const u32x4* xs = reinterpret_cast<const u32x4*>(xbase + j * RG_BYTES) + i * 8;
+                const u32x4* qt = reinterpret_cast<const u32x4*>(qbase + buf * QT_BYTES) + (qh * 128 + i) * 8;
+                auto slot = [&](int ks) { return (4 * ks + g) ^ swz; };
+                half8 a[2][4];
+#pragma unroll
+                for (int rt = 0; rt < 4; rt++) a[0][rt] = as_half8(xs[rt * 128 + slot(0)]);
+                u32x4 bq[3];
+                bq[0] = qt[0 * 128 + slot(0)];
+                bq[1] = qt[1 * 128 + slot(0)];
+#pragma unroll
+                for (int t = 0; t < 16; t++) {   // t = ks * 8 + ct
+                    const int ks = t / 8, ct = t % 8;
+                    if (t + 2 < 16) bq[(t + 2) % 3] = qt[((t + 2) % 8) * 128 + slot((t + 2) / 8)];
+                    if (ct == 6 && ks == 0) {
+#pragma unroll
+                        for (int rt = 0; rt < 4; rt++) a[1][rt] = as_half8(xs[rt * 128 + slot(1)]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t >= 1 && (t - 1) % 2 == 0 && (t - 1) / 2 < NP) {
+                        issue_piece((t - 1) / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const half8 b = as_half8(bq[t % 3]);
+#pragma unroll
+                    for (int rt = 0; rt < 4; rt++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][rt], b, acc[rt][ct], 0, 0, 0);
+                }
+                // row wave: everything but the 8 pieces of block kb+2 just issued has landed -> block kb+1 is in LDS;
+                // query wave: tile kb+1 complete.  The barrier publishes both to all waves.
+                if (row_wave) vm_wait<NP>(); else vm_wait<0>();
+                __builtin_amdgcn_s_barrier();
+                buf ^= 1;
+            }
+        }
+
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const size_t group = tile * W + rg * 2 + p;
+#pragma unroll
+            for (int ct = 0; ct < 8; ct++) {
+                float m = fmaxf(fmaxf(acc[2 * p][ct][0], acc[2 * p][ct][1]), fmaxf(acc[2 * p][ct][2], acc[2 * p][ct][3]));
+                m = fmaxf(m, fmaxf(fmaxf(acc[2 * p + 1][ct][0], acc[2 * p + 1][ct][1]), fmaxf(acc[2 * p + 1][ct][2], acc[2 * p + 1][ct][3])));
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (g == 0) gmax[group * (size_t)nq_pad + qh * 128 + ct * 16 + i] = m;
+            }
+        }
+        if (!has_next_tile) break;
+        tile = next_tile;
+        lp = ln;
+    }
+    vm_wait<0>();
+}
+#endif  // MSE_DEV_KERNELS
+
+template <typename K>
+int launch_kernel(K kernel, size_t lds, size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d,
+                  const uint4* packed, float* group_max, int nq_pad) {
     const size_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     if (grid > n_tiles) grid = n_tiles;
-    const size_t lds = 2 * (size_t)(NCT * 16 * 128) + (size_t)W * S * 4096;  // S = 3: 128 KiB at 128 queries, 160 KiB at 256
-    int dev = 0;
-    MSE_HIP_TRY(hipGetDevice(&dev));
-    static bool attr_set[64] = {};
-    if (dev < 64 && !attr_set[dev]) {
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_mfma_kernel<S, NCT, ABL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL((scan_mfma_kernel<S, NCT, ABL>), dim3((unsigned)grid), dim3(W * 64), lds, stream, base, n_rows, d, packed,
-                       group_max, nq_pad, n_tiles);
+    MSE_DYN_LDS(kernel, lds);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(W * 64), lds, stream, base, n_rows, d, packed, group_max, nq_pad, n_tiles);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int S, int NCT, int ABL>
+int launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
+                   float* group_max, int nq_pad) {
+    const size_t lds = 2 * (size_t)(NCT * 16 * 128) + (size_t)W * S * 4096;  // S = 3: 128 KiB at 128 queries, 160 KiB at 256
+    return launch_kernel(scan_mfma_kernel<S, NCT, ABL>, lds, grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+}
+
+#ifdef MSE_DEV_KERNELS
+template <int S, int NCT, int ABL>
+int launch_variant(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
+                   float* group_max, int nq_pad);
+
+template <int S>
+int launch_2s(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
+              float* group_max, int nq_pad) {
+    const size_t lds = 2 * (size_t)(256 * 128) + (size_t)4 * S * 8192;
+    const size_t n_full = n_rows / TILE_ROWS * TILE_ROWS;
+    if (n_full && launch_kernel(scan_mfma2s_kernel<S>, lds, grid, stream, base, n_full, d, packed, group_max, nq_pad)) return -1;
+    if (n_full < n_rows)   // ragged tail (< 256 rows): one workgroup of the row-clamping kernel
+        return launch_variant<S, 16, 0>(1, stream, base + n_full * (size_t)d, n_rows - n_full, d, packed,
+                                        group_max + (n_full / 32) * (size_t)nq_pad, nq_pad);
+    return 0;
+}
+#endif
+
+template <int S, int MF, int PROF = 0>
+int launch_2d(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d, const uint4* packed,
+              float* group_max, int nq_pad) {
+    const size_t lds = 2 * (size_t)(256 * 128) + (size_t)4 * S * 8192;
+    return launch_kernel(scan_mfma2d_kernel<S, MF, PROF>, lds, grid, stream, base, n_rows, d, packed, group_max, nq_pad);
 }
 
 }  // namespace
@@ -321,37 +701,47 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, nq_pad, packed);
     if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
     const int nkb = d / KB;
-    // developer knob: ring depth (default 3 when the K-block count allows it)
-    static const int env_s = getenv("MSE_SCAN_S") ? atoi(getenv("MSE_SCAN_S")) : 0;
-    int S = nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;
-    if (env_s >= 1 && env_s <= 3 && nkb % env_s == 0) S = env_s;
-    const size_t grid = (size_t)n_cu;  // one 128-KiB workgroup per CU
-    int rc;
-    if (nq_pad == 128 && S == 3 && getenv("MSE_SCAN_ABL") && atoi(getenv("MSE_SCAN_ABL")) == 16) {
-        rc = launch_variant<3, 8, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    } else if (nq_pad == 128) {
-        if (S == 3) rc = launch_variant<3, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else if (S == 2) rc = launch_variant<2, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else rc = launch_variant<1, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    } else if (const char* ea = (S == 3 ? getenv("MSE_SCAN_ABL") : nullptr)) {
-        switch (atoi(ea)) {
+    const int S = nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;   // ring depth: 3 when the K-block count allows it
+    const size_t grid = (size_t)n_cu;  // one workgroup per CU
+    int rc = -2;
+#ifdef MSE_DEV_KERNELS
+    // Developer build only (make dev -> libmse_hip_dev.so, scripts/scan_ablate.py): timing ablations whose RESULTS ARE WRONG
+    // and alternative tilings.  None of this is compiled into the product library.
+    const int abl = getenv("MSE_SCAN_ABL") ? atoi(getenv("MSE_SCAN_ABL")) : 0;
+    const int v2d = getenv("MSE_SCAN_2D") ? atoi(getenv("MSE_SCAN_2D")) : -1;
+    if (nq_pad == 128 && S == 3 && abl == 16) rc = launch_variant<3, 8, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && abl) {   // timing ablations of the round-2 kernel
+        switch (abl) {
             case 1: rc = launch_variant<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 2: rc = launch_variant<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 4: rc = launch_variant<3, 16, 4>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 6: rc = launch_variant<3, 16, 6>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 8: rc = launch_variant<3, 16, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 9: rc = launch_variant<3, 16, 9>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 11: rc = launch_variant<3, 16, 11>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 13: rc = launch_variant<3, 16, 13>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 14: rc = launch_variant<3, 16, 14>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
             case 16: rc = launch_variant<3, 16, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 17: rc = launch_variant<3, 16, 17>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            default: rc = launch_variant<3, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            default: break;
         }
+    }
+    else if (nq_pad == 256 && S == 3 && v2d == 0) rc = launch_variant<3, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && v2d == 161) rc = launch_2d<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && v2d == 162) rc = launch_2d<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && v2d == 17) rc = launch_2s<3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && v2d == 32) rc = launch_2d<3, 32>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    if (rc != -2) {
+        if (rc) return rc;
+        if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));
+        return 0;
+    }
+#endif
+    if (nq_pad == 128) {
+        if (S == 3) rc = launch_variant<3, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else if (S == 2) rc = launch_variant<2, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else rc = launch_variant<1, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     } else {
-        if (S == 3) rc = launch_variant<3, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else if (S == 2) rc = launch_variant<2, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else rc = launch_variant<1, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        if (S == 3) rc = launch_2d<3, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else if (S == 2) rc = launch_variant<2, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        else rc = launch_variant<1, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     }
     if (rc) return rc;
     if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));
@@ -359,3 +749,13 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
 }
 
 }  // namespace mse
+
+#ifdef MSE_DEV_KERNELS
+// developer library only (not in include/mse.h): read and clear the counters of the profiled 2-D scan (MSE_SCAN_2D=161)
+extern "C" __attribute__((visibility("default"))) int mse_dev_scan_prof(unsigned long long out[4]) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mse::g_scan_prof), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mse::g_scan_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -270,14 +270,11 @@ int mse_shard_group_set_shard_device(mse_shard_group* G, size_t shard, const voi
     });
 }
 
-// queries_dev: [nq][d] f16 on the ROOT device (device of shard 0), complete before the call; outputs [nq][k] on the root device.
-// Returns when the merged result is complete.
-int mse_shard_group_search_dev(mse_shard_group* G, const void* queries_dev, size_t nq, size_t k, int mode,
-                               void* scores_dev, void* ids_dev) {
-    if (!G) return fail("null shard group");
-    if (nq == 0 || k == 0) return 0;
-    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
-    std::lock_guard<std::mutex> call(G->call_mu);
+}  // extern "C"
+
+// the search proper; the caller holds G->call_mu (one search at a time per group: gathered / q_root / out_* are group scratch)
+static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t nq, size_t k, int mode, void* scores_dev,
+                             void* ids_dev) {
     for (const Shard& s : G->shards) if (!s.searcher) return fail("shard group: a shard holds no rows yet");
     const size_t n_shards = G->shards.size();
     const size_t B = block_bytes(nq, k), qbytes = nq * G->d * 2;
@@ -310,22 +307,38 @@ int mse_shard_group_search_dev(mse_shard_group* G, const void* queries_dev, size
     return rc;
 }
 
+extern "C" {
+
+// queries_dev: [nq][d] f16 on the ROOT device (device of shard 0), complete before the call; outputs [nq][k] on the root device.
+// Returns when the merged result is complete.
+int mse_shard_group_search_dev(mse_shard_group* G, const void* queries_dev, size_t nq, size_t k, int mode,
+                               void* scores_dev, void* ids_dev) {
+    if (!G) return fail("null shard group");
+    if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    return search_dev_locked(G, queries_dev, nq, k, mode, scores_dev, ids_dev);
+}
+
 int mse_shard_group_search(mse_shard_group* G, const uint16_t* queries, size_t nq, size_t k, int mode, int64_t* scores,
                            uint32_t* ids) {
     if (!G) return fail("null shard group");
     if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
     int prev = 0;
     (void)hipGetDevice(&prev);
     MSE_HIP_TRY(hipSetDevice(G->root_device));
     int rc = 0;
     {
-        std::lock_guard<std::mutex> call(G->call_mu);   // q_root / out_* are group scratch
+        // ONE lock across upload, search and download: two host threads on the same group must not see each other's queries
+        // in q_root or each other's answers in out_s / out_i
+        std::lock_guard<std::mutex> call(G->call_mu);
         rc = G->q_root.ensure(nq * G->d * 2) || G->out_s.ensure(nq * k * 8) || G->out_i.ensure(nq * k * 4);
         if (!rc && hipMemcpy(G->q_root.p, queries, nq * G->d * 2, hipMemcpyHostToDevice) != hipSuccess) rc = fail("query upload failed");
+        if (!rc) rc = search_dev_locked(G, G->q_root.p, nq, k, mode, G->out_s.p, G->out_i.p);
+        if (!rc && (hipMemcpy(scores, G->out_s.p, nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(ids, G->out_i.p, nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail("result download failed");
     }
-    if (!rc) rc = mse_shard_group_search_dev(G, G->q_root.p, nq, k, mode, G->out_s.p, G->out_i.p);
-    if (!rc && (hipMemcpy(scores, G->out_s.p, nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(ids, G->out_i.p, nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail("result download failed");
     (void)hipSetDevice(prev);
     return rc;
 }

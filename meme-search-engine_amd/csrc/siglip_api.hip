@@ -520,7 +520,7 @@ int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
     MSE_HIP_TRY(hipMemset(x.p, 0x3c, (size_t)M * K * 2));   // bf16 0x3c3c ~ 0.0115
     MSE_HIP_TRY(hipMemset(w.p, 0x3c, (size_t)N * K * 2));
     MSE_HIP_TRY(hipMemset(bias.p, 0, (size_t)N * 4));
-    if (const char* e = getenv("MSE_GEMM_RANDOM"); e && atoi(e)) {
+    if (MSE_DEV_KNOB("MSE_GEMM_RANDOM")) {   // developer library: operands with random mantissas
         hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, nullptr, x.as<uint16_t>(), (size_t)M * K, 1u);
         hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, nullptr, w.as<uint16_t>(), (size_t)N * K, 2u);
         MSE_HIP_TRY(hipGetLastError());

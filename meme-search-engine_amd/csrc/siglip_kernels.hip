@@ -1999,22 +1999,21 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, i
 }
 
 template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
-    int dev = 0;
-    MSE_HIP_TRY(hipGetDevice(&dev));
-    static bool attr_set[64] = {};
-    if (dev < 64 && !attr_set[dev]) {
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, GS * STAGE_BYTES));
+    MSE_DYN_LDS((gemm_kernel<EPI>), GS * STAGE_BYTES);
 #ifdef MSE_DEV_KERNELS
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES));
+    MSE_DYN_LDS((gemm256_kernel<EPI>), LDS256_BYTES);
 #endif
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
-        attr_set[dev] = true;
-    }
-    static const bool force128 = getenv("MSE_GEMM_128") != nullptr;   // developer knobs: older kernels only
+    MSE_DYN_LDS((gemm8p_kernel<EPI>), LDS8P_BYTES);
+#ifdef MSE_DEV_KERNELS   // developer knobs (older kernels, for A/B timing): exist only in the developer library
+    static const bool force128 = getenv("MSE_GEMM_128") != nullptr;
     static const bool old256 = getenv("MSE_GEMM_OLD256") != nullptr;
+    static const bool nopersist = getenv("MSE_GEMM_NOPERSIST") != nullptr;
+    static const int stagger = getenv("MSE_GEMM_STAGGER") ? atoi(getenv("MSE_GEMM_STAGGER")) : 0;
+    static const bool narrow_off = getenv("MSE_GEMM_NONARROW") != nullptr || nopersist || force128 || old256;
+#else
+    constexpr bool force128 = false, old256 = false, nopersist = false, narrow_off = false;
+    constexpr int stagger = 0;
+#endif
     // the ping-pong kernels want K >= 128 and, for the QKV scatter, 8-token / 8-column pieces inside WG-uniform q/k/v tiles;
     // anything else (no shipped configuration) runs the first-generation 256 x 128 kernel over all of N
     const bool pp_ok = a_in.K >= 128 &&
@@ -2031,7 +2030,6 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         GemmArgs a = a_in;
         a.N = n256;
         const unsigned grid = (unsigned)((a.M / B2) * (a.N / B2));
-        static const bool nopersist = getenv("MSE_GEMM_NOPERSIST") != nullptr;
         constexpr bool store_only = EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV;
         const unsigned cus = (unsigned)mse::device_cu_count();
 #ifdef MSE_DEV_KERNELS
@@ -2041,18 +2039,10 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
 #endif
         if constexpr (store_only) {
             // persistent ping-pong kernel; for QKV the q/k columns [0, 2D) and the (transposed) v columns are two launches
-            static bool pattr[64] = {};
-            if (dev < 64 && !pattr[dev]) {
-                MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
-                MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
-                MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI, 0, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
-                pattr[dev] = true;
-            }
+            MSE_DYN_LDS((gemm8pp_kernel<EPI, false>), LDSPP_BYTES);
+            MSE_DYN_LDS((gemm8pp_kernel<EPI, true>), LDSPP_BYTES);
+            MSE_DYN_LDS((gemm8p_kernel<EPI, 0, true>), LDS8P_BYTES);
             const bool persist = !nopersist && a.K >= 256;
-            static const int stagger = getenv("MSE_GEMM_STAGGER") ? atoi(getenv("MSE_GEMM_STAGGER")) : 0;
             a.stagger = stagger;
             const int nqk = EPI == EPI_QKV ? std::min(2 * a.heads * a.dh, n256) : n256;
             GemmArgs aq = a;
@@ -2078,8 +2068,6 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
         a.n_off = n256;
         a.w = a_in.w + (size_t)n256 * a_in.K;
         a.bias = a_in.bias + n256;
-        static const bool narrow_off = getenv("MSE_GEMM_NONARROW") != nullptr || getenv("MSE_GEMM_NOPERSIST") != nullptr ||
-                                       getenv("MSE_GEMM_128") != nullptr || getenv("MSE_GEMM_OLD256") != nullptr;
         bool done = false;
         if constexpr (EPI == EPI_BF16 || EPI == EPI_QKV) {
             // 128-column form of the persistent ping-pong kernel (for QKV the remainder lies in the V columns)
@@ -2089,12 +2077,7 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
             if (!narrow_off && a.N == 128 && a.K >= 256 && qkv_ok) {
                 constexpr bool VS = EPI == EPI_QKV;
                 constexpr int lds = 2 * (2 * P8_UNIT + 2 * 8192) + 8 * PP_STAGE;
-                static bool nattr = false;
-                if (!nattr) {
-                    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI, VS, 0, 1>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                    nattr = true;
-                }
+                MSE_DYN_LDS((gemm8pp_kernel<EPI, VS, 0, 1>), lds);
                 a.stagger = 0;
                 const unsigned tiles = (unsigned)(a.M / 256);
                 hipLaunchKernelGGL((gemm8pp_kernel<EPI, VS, 0, 1>), dim3(std::min(tiles, (unsigned)mse::device_cu_count())), dim3(512), lds, st, a);
@@ -2114,6 +2097,10 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
 
 // developer entry: time the 256x256 GELU GEMM alone with an ablation variant (scripts/gemm_ablate.py)
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
+#ifndef MSE_DEV_KERNELS
+    (void)abl; (void)g; (void)st;
+    return fail("gemm ablations are built only into the developer library (make dev, -DMSE_DEV_KERNELS)");
+#else
     GemmArgs a{};
     a.x = g.x; a.w = g.w; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K; a.m_valid = g.m_valid; a.n_off = 0;
     a.out_bf16 = g.out_bf16; a.ldo = g.ldo;
@@ -2121,41 +2108,34 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
     [[maybe_unused]] const size_t lds = LDS256_BYTES;
 #define MSE_ABL(X)                                                                                              \
     case X:                                                                                                     \
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI_GELU, X>),             \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        MSE_DYN_LDS((gemm256_kernel<EPI_GELU, X>), (int)lds);                 \
         hipLaunchKernelGGL((gemm256_kernel<EPI_GELU, X>), dim3(grid), dim3(GW * 64), lds, st, a);               \
         break;
     switch (abl) {
-#ifdef MSE_DEV_KERNELS
         MSE_ABL(0) MSE_ABL(1) MSE_ABL(2) MSE_ABL(3)
-#endif
 #define MSE_ABL8(X)                                                                                             \
     case 10 + X:                                                                                                \
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_GELU, X>),              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));              \
+        MSE_DYN_LDS((gemm8p_kernel<EPI_GELU, X>), LDS8P_BYTES);              \
         hipLaunchKernelGGL((gemm8p_kernel<EPI_GELU, X>), dim3(grid), dim3(512), LDS8P_BYTES, st, a);            \
         break;
         MSE_ABL8(0) MSE_ABL8(1) MSE_ABL8(2) MSE_ABL8(3) MSE_ABL8(4)
 #undef MSE_ABL8
         case 30:  // persistent ping-pong kernel
-            a.stagger = getenv("MSE_GEMM_STAGGER") ? atoi(getenv("MSE_GEMM_STAGGER")) : 0;
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<EPI_GELU, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));
+            a.stagger = getenv("MSE_GEMM_STAGGER") ? atoi(getenv("MSE_GEMM_STAGGER")) : 0;   // (developer library only: this function body is)
+            MSE_DYN_LDS((gemm8pp_kernel<EPI_GELU, false>), LDSPP_BYTES);
             hipLaunchKernelGGL((gemm8pp_kernel<EPI_GELU, false>), dim3(std::min(grid, (unsigned)mse::device_cu_count())), dim3(512),
                                LDSPP_BYTES, st, a);
             break;
 #define MSE_ABLP(CODE, E, X)                                                                                    \
     case CODE:                                                                                                  \
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8pp_kernel<E, false, X>),             \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDSPP_BYTES));              \
+        MSE_DYN_LDS((gemm8pp_kernel<E, false, X>), LDSPP_BYTES);              \
         hipLaunchKernelGGL((gemm8pp_kernel<E, false, X>), dim3(std::min(grid, (unsigned)mse::device_cu_count())), dim3(512), \
                            LDSPP_BYTES, st, a);                                                                 \
         break;
         MSE_ABLP(31, EPI_GELU, 1) MSE_ABLP(32, EPI_GELU, 2) MSE_ABLP(33, EPI_BF16, 0) MSE_ABLP(34, EPI_GELU, 3)
 #undef MSE_ABLP
         case 20:  // plain bf16 epilogue (no GELU)
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<EPI_BF16, 0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES));
+            MSE_DYN_LDS((gemm8p_kernel<EPI_BF16, 0>), LDS8P_BYTES);
             hipLaunchKernelGGL((gemm8p_kernel<EPI_BF16, 0>), dim3(grid), dim3(512), LDS8P_BYTES, st, a);
             break;
         default: return fail("bad ablation");
@@ -2163,6 +2143,7 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
 #undef MSE_ABL
     MSE_HIP_TRY(hipGetLastError());
     return 0;
+#endif
 }
 
 int attention_k_stride() { return ATT_KSTRIDE; }
@@ -2196,7 +2177,7 @@ bool gemm_fused_ok(int M, int D, int mlp_pad, int heads, int dh, int tokens_stri
 
 namespace {
 template <typename KernelT> int launch_pp(KernelT kernel, int lds, const GemmArgs& a, int bnw, hipStream_t st) {
-    MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    MSE_DYN_LDS((kernel), lds);
     const unsigned tiles = (unsigned)((a.M / 256) * (a.N / bnw));
     hipLaunchKernelGGL(kernel, dim3(std::min(tiles, (unsigned)mse::device_cu_count())), dim3(512), lds, st, a);
     MSE_HIP_TRY(hipGetLastError());
@@ -2313,58 +2294,55 @@ int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,
                      int dh_pad, int dv_pad, uint16_t* out, int ldo, int tstride, hipStream_t st) {
     if (dh_pad != 96 || dv_pad != 80 || n_pad % 32) return fail("attention: expects dh_pad 96, dv_pad 80, n_pad % 32 == 0");
-    static const int nw = getenv("MSE_ATT_WAVES") ? atoi(getenv("MSE_ATT_WAVES")) : 8;   // developer knob
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-    static const int abl = getenv("MSE_ATT_ABL") ? atoi(getenv("MSE_ATT_ABL")) : 0;
-    static const bool tile32 = getenv("MSE_ATT_TILE32") != nullptr;   // developer knob: the 32-key-stage kernel
-    if (!tile32 && abl == 0) {
-        const int qblocks = (tokens + 255) / 256;
-        static const int abl64 = getenv("MSE_ATT64_ABL") ? atoi(getenv("MSE_ATT64_ABL")) : 0;   // developer timing ablations
 #define MSE_ATT64(X)                                                                                                        \
     {                                                                                                                       \
-        MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<X>),                               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));                   \
+        MSE_DYN_LDS((attention64_kernel<X>), AT6_NS * AT6_STAGE);                   \
         hipLaunchKernelGGL(attention64_kernel<X>, dim3((unsigned)(B * heads * qblocks)), dim3(512), AT6_NS * AT6_STAGE, st, \
                            q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);             \
     }
-        static const int att_qt = getenv("MSE_ATT_QT") ? atoi(getenv("MSE_ATT_QT")) : 2;   // developer knob: 4 = four query tiles per wave, 4 waves (measured: no faster -- the kernel is not bound by its fragment reads)
+    const int qblocks = (tokens + 255) / 256;
+#ifndef MSE_DEV_KERNELS
+    MSE_ATT64(0)
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+#else
+    // developer library only: timing ablations (MSE_ATT_ABL / MSE_ATT64_ABL: results are wrong), other tilings, the round-1 kernel
+    static const int nw = getenv("MSE_ATT_WAVES") ? atoi(getenv("MSE_ATT_WAVES")) : 8;
+    static const int abl = getenv("MSE_ATT_ABL") ? atoi(getenv("MSE_ATT_ABL")) : 0;
+    static const bool tile32 = getenv("MSE_ATT_TILE32") != nullptr;   // the 32-key-stage kernel
+    if (!tile32 && abl == 0) {
+        static const int abl64 = getenv("MSE_ATT64_ABL") ? atoi(getenv("MSE_ATT64_ABL")) : 0;
+        static const int att_qt = getenv("MSE_ATT_QT") ? atoi(getenv("MSE_ATT_QT")) : 2;   // 4 = four query tiles per wave, 4 waves (measured: no faster)
         if (abl64 == 0 && att_qt == 3) {
             // 8 waves x 3 query tiles = 384 queries per workgroup: 729 tokens take TWO passes over K / Vt instead of three
             const int qb3 = (tokens + 383) / 384;
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<0, 3, 8>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
+            MSE_DYN_LDS((attention64_kernel<0, 3, 8>), AT6_NS * AT6_STAGE);
             hipLaunchKernelGGL((attention64_kernel<0, 3, 8>), dim3((unsigned)(B * heads * qb3)), dim3(512), AT6_NS * AT6_STAGE, st,
                                q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
         } else if (abl64 == 0 && att_qt == 4) {
-            MSE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel<0, 4, 4>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, AT6_NS * AT6_STAGE));
+            MSE_DYN_LDS((attention64_kernel<0, 4, 4>), AT6_NS * AT6_STAGE);
             hipLaunchKernelGGL((attention64_kernel<0, 4, 4>), dim3((unsigned)(B * heads * qblocks)), dim3(256), AT6_NS * AT6_STAGE, st,
                                q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
         } else if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else if (abl64 == 4) MSE_ATT64(4) else if (abl64 == 5) MSE_ATT64(5) else MSE_ATT64(0)
-#undef MSE_ATT64
         MSE_HIP_TRY(hipGetLastError());
         return 0;
     }
-#ifdef MSE_DEV_KERNELS
     if (abl == 1 || abl == 2) {
-        const int qblocks = (tokens + 255) / 256;
         if (abl == 1) hipLaunchKernelGGL((attention_kernel<8, 1>), dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
         else hipLaunchKernelGGL((attention_kernel<8, 2>), dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
     } else if (nw == 8) {
-        const int qblocks = (tokens + 255) / 256;
         hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)(B * heads * qblocks)), dim3(512), 0, st, q, k, vt, heads, tokens, n_pad,
                            dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
     } else {
-        const int qblocks = (tokens + 127) / 128;
-        hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)(B * heads * qblocks)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
+        const int qb128 = (tokens + 127) / 128;
+        hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)(B * heads * qb128)), dim3(256), 0, st, q, k, vt, heads, tokens, n_pad,
                            dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
     }
     MSE_HIP_TRY(hipGetLastError());
     return 0;
-#else
-    (void)nw;
-    return fail("attention: MSE_ATT_TILE32 / MSE_ATT_ABL need a build with -DMSE_DEV_KERNELS");
 #endif
+#undef MSE_ATT64
 }
 
 int launch_bmp24_to_nchw_f16(const uint8_t* in, size_t img_stride, int row_stride, const uint8_t* flags, void* out, int B, int H, int W,

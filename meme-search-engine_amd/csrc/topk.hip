@@ -225,13 +225,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
                 need = total < (uint32_t)a.k ? total : (uint32_t)a.k;
                 if (total <= (uint32_t)a.k) flag = 2;   // take everything
             }
-            if (tid == 0) {
-                s_next_pos = pos - 1;
-                if (pos == 11) { s_valid = total; s_need = need; }
-                s_flag = flag;
-            }
-            // exactly one lane has above < need <= suf (lane 0 takes the walk's default, bucket 0, if none does)
+            // exactly one lane has above < need <= suf (lane 0 takes the walk's default, bucket 0, if none does).  That lane works
+            // out its answer in registers; lane 0 fetches it by shuffle and is the ONLY lane that stores to the shared state
+            // (two lanes storing to s_flag / s_need / s_next_pos relied on the order of divergent LDS stores within a wave).
             const bool mine = flag == 0 && ((above < need && need <= suf) || (tid == 0 && need > suf));
+            uint32_t w_need = need, w_h = 0;
+            int w_b = 0;
             if (mine) {
                 uint32_t cum = above;
                 int b = 4 * tid + 3;
@@ -240,22 +239,39 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
                     if (cum + hh[b - 4 * tid] >= need) break;
                     cum += hh[b - 4 * tid];
                 }
-                s_need = need - cum;
-                if (pos >= 4) s_prefix_hi |= (uint64_t)b << (8 * (pos - 4));
-                else s_prefix_lo |= (uint32_t)b << (8 * pos);
-                if (pos == 11) {
-                    // score digits on which every valid candidate agrees (i64 scores below 2^33 share their top bytes)
-                    // are copied into the threshold without a pass
-                    const unsigned long long diff = s_or_hi ^ s_and_hi;
-                    int np = 10;
-                    while (np >= 4 && ((diff >> (8 * (np - 4))) & 0xffull) == 0ull) {
-                        s_prefix_hi |= ((s_or_hi >> (8 * (np - 4))) & 0xffull) << (8 * (np - 4));
-                        np--;
+                w_need = need - cum;
+                w_b = b;
+                w_h = hh[b - 4 * tid];
+            }
+            const unsigned long long winners = __ballot(mine);
+            const int src = winners ? (int)__ffsll((long long)winners) - 1 : 0;
+            const uint32_t r_need = __shfl(w_need, src), r_h = __shfl(w_h, src);
+            const int r_b = __shfl(w_b, src);
+            if (tid == 0) {
+                int next_pos = pos - 1, f = flag;
+                uint32_t new_need = need;
+                if (pos == 11) s_valid = total;
+                if (winners) {
+                    new_need = r_need;
+                    if (pos >= 4) s_prefix_hi |= (uint64_t)r_b << (8 * (pos - 4));
+                    else s_prefix_lo |= (uint32_t)r_b << (8 * pos);
+                    if (pos == 11) {
+                        // score digits on which every valid candidate agrees (i64 scores below 2^33 share their top bytes)
+                        // are copied into the threshold without a pass
+                        const unsigned long long diff = s_or_hi ^ s_and_hi;
+                        int np = 10;
+                        while (np >= 4 && ((diff >> (8 * (np - 4))) & 0xffull) == 0ull) {
+                            s_prefix_hi |= ((s_or_hi >> (8 * (np - 4))) & 0xffull) << (8 * (np - 4));
+                            np--;
+                        }
+                        next_pos = np;
                     }
-                    s_next_pos = np;
+                    if (r_h == r_need) f = 1;                                                   // bucket taken whole: done
+                    else if (!list_mode && pos > 0 && r_h <= (uint32_t)SEL_LIST_CAP) f = 3;     // gather the bucket
                 }
-                if (hh[b - 4 * tid] == need - cum) s_flag = 1;                                   // bucket taken whole: done
-                else if (!list_mode && pos > 0 && hh[b - 4 * tid] <= (uint32_t)SEL_LIST_CAP) s_flag = 3;   // gather the bucket
+                s_need = new_need;
+                s_next_pos = next_pos;
+                s_flag = f;
             }
         }
         __syncthreads();

@@ -13,7 +13,10 @@
 The payload of an index.bin record is `bitcode::encode(PackedIndexEntry)` (bitcode 0.6.7, src/common.rs:154-164).  bitcode's
 wire format is not described anywhere in the reference tree and the crate's source is not available here: mse/bitcode06.py
 restates it for this struct from knowledge of the crate (parity UNPINNED -- see that module), encoder and decoder written
-together, and is the default `decode_entry`; a caller who has the real crate's output can still plug in another decoder.
+together.  Because no byte string produced by the real crate has been checked against it, it is NOT a default: `DiskIndex` and
+`write_index` take the payload codec as an explicit argument (`UNPINNED_BITCODE06_DECODE` / `UNPINNED_BITCODE06_ENCODE` to opt
+in to the restatement, or a codec backed by the real crate), and a directory written with the restatement is not claimed to be
+readable by the reference until one golden `PackedIndexEntry` from the crate is a test fixture.
 `DiskIndex.to_device()` is the front door of the GPU-resident beam search: vectors, adjacency (+ the "has a URL" flags the
 search filters on, query_disk_index.rs:172), PQ codes and descriptor bytes go to HBM in one step; `write_index` is what
 dump-processor's packing loop writes (dump_processor.rs:463-569) so that the build side of this package produces a directory
@@ -28,6 +31,10 @@ from . import bitcode06
 from .vector import ProductQuantizer, Codes
 
 RECORD_PAD_SIZE = 4096   # dump_processor.rs:135
+
+# opt-in payload codecs (restated bitcode 0.6, parity UNPINNED: never a silent default)
+UNPINNED_BITCODE06_DECODE = bitcode06.decode_packed_index_entry
+UNPINNED_BITCODE06_ENCODE = bitcode06.encode_packed_index_entry
 
 
 class IndexHeader:
@@ -91,7 +98,7 @@ def write_index_header(path, header: IndexHeader):
 class DiskIndex:
     """An index directory opened the way initialize_index / initialize_memory_maps do (query_disk_index.rs:658-709)."""
 
-    def __init__(self, path, decode_entry=bitcode06.decode_packed_index_entry):
+    def __init__(self, path, decode_entry=None):
         self.path = path
         self.header = read_index_header(os.path.join(path, "index.msgpack"))
         h = self.header
@@ -126,11 +133,14 @@ class DiskIndex:
     def read_node(self, idx):
         """read_node (:73-81): the PackedIndexEntry of record `idx` (a dict with the struct's field names)."""
         if self.decode_entry is None:
-            raise NotImplementedError("no decode_entry: index.bin payloads are bitcode-encoded PackedIndexEntry (mse/bitcode06.py)")
+            raise NotImplementedError("no decode_entry: index.bin payloads are bitcode-encoded PackedIndexEntry; pass "
+                                      "decode_entry=UNPINNED_BITCODE06_DECODE to opt in to the unpinned restatement (mse/bitcode06.py)")
         return self.decode_entry(self.record_payload(idx))
 
     def entries(self):
         """All records in id order, read sequentially (one pass over index.bin)."""
+        if self.decode_entry is None:
+            raise NotImplementedError("no decode_entry: pass decode_entry=UNPINNED_BITCODE06_DECODE to opt in to the unpinned restatement")
         pad, h = self.header.record_pad_size, self.header
         with open(self._data, "rb") as f:
             for idx in range(h.count):
@@ -182,11 +192,14 @@ def write_records(path, payloads, record_pad_size=RECORD_PAD_SIZE):
             f.write(len(p).to_bytes(2, "little") + p + bytes(record_pad_size - 2 - len(p)))
 
 
-def write_index(out_dir, header: IndexHeader, entries, pq_codes, descriptor_codes, encode_entry=bitcode06.encode_packed_index_entry):
+def write_index(out_dir, header: IndexHeader, entries, pq_codes, descriptor_codes, encode_entry=None):
     """The files dump-processor's packing loop leaves behind (dump_processor.rs:306-313,463-569): index.bin (one padded record
     per entry; an entry whose payload does not fit loses its URL and is counted dead, :510-517), index.pq-codes.bin,
     index.descriptor-codes.bin and index.msgpack (count / dead_count filled in here).  `entries` yields PackedIndexEntry dicts
     in id order.  Returns the header as written."""
+    if encode_entry is None:
+        raise NotImplementedError("no encode_entry: pass UNPINNED_BITCODE06_ENCODE to opt in to the unpinned bitcode 0.6 restatement "
+                                  "(its output is not known to be readable by the reference), or an encoder backed by the real crate")
     pad = header.record_pad_size
     count = dead = 0
     with open(os.path.join(out_dir, "index.bin"), "wb") as f:

@@ -33,11 +33,23 @@ for _ in range(5):
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / 5
 ms, k = s.scan_timing(0)
-print(f"abl={os.environ.get('MSE_SCAN_ABL', '0')} S={os.environ.get('MSE_SCAN_S', '3')} rows={n} nq={nq}: scan {ms / k:.3f} ms "
+print(f"2d={os.environ.get('MSE_SCAN_2D', '-')} abl={os.environ.get('MSE_SCAN_ABL', '0')} S={os.environ.get('MSE_SCAN_S', '3')} rows={n} nq={nq}: scan {ms / k:.3f} ms "
       f"({n * 2304 / (ms / k) / 1e6:.0f} GB/s), step {wall * 1e3:.3f} ms")
-if os.environ.get("CHECK"):   # the variant's answers against the exact-order kernel (first 8 queries)
+if os.environ.get("CHECK") and os.environ.get("MSE_SCAN_2D") != "162":   # the variant's answers against the exact-order kernel (first 8 queries)
     chk_s = torch.empty((8, 10), dtype=torch.int64, device="cuda")
     chk_i = torch.empty((8, 10), dtype=torch.int32, device="cuda")
     s.bruteforce_topk_dev(qs.device_ptr, 8, 10, chk_s.data_ptr(), chk_i.data_ptr(), mse.MODE_EXACT)
     torch.cuda.synchronize()
     print("answers equal the exact-order kernel:", bool(torch.equal(chk_s, out_s[:8]) and torch.equal(chk_i, out_i[:8])), s.last_stats())
+if os.environ.get("MSE_SCAN_2D") == "161":   # developer library: where a wave's cycles go (scan_mfma.hip, PROF)
+    import ctypes
+    from mse import ffi
+    out = (ctypes.c_ulonglong * 4)()
+    ffi.lib().mse_dev_scan_prof(out)          # clear what the warm-up and the timed loop left
+    s.bruteforce_topk_dev(qs.device_ptr, nq, 10, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA)
+    torch.cuda.synchronize()
+    ffi.lib().mse_dev_scan_prof(out)
+    issue, wait, bar, nkb = [int(x) for x in out]
+    tot = issue + wait + bar
+    print(f"profiled 2-D scan: per K block and wave {tot / nkb:.0f} cycles = issue {issue / nkb:.0f} + vmcnt wait {wait / nkb:.0f} + barrier {bar / nkb:.0f}"
+          f" ({nkb} wave-K-blocks)")

@@ -196,3 +196,24 @@ def test_bench_launch_shapes_are_checked_before_any_device_work():
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+DEV_KNOBS = ["MSE_SCAN_ABL", "MSE_SCAN_2D", "MSE_SCAN_S", "MSE_ATT_ABL", "MSE_ATT64_ABL", "MSE_ATT_WAVES", "MSE_ATT_QT", "MSE_ATT_TILE32",
+             "MSE_GEMM_RANDOM", "MSE_GEMM_OLD256", "MSE_GEMM_128", "MSE_GEMM_NOPERSIST", "MSE_GEMM_STAGGER", "MSE_GEMM_NONARROW",
+             "MSE_PQ_OLDTRANSFORM", "MSE_PQ_OLDQUANT", "MSE_PQ_OLDSCAN", "MSE_DEDUP_OLD"]
+# what the product build may still read from the environment: hooks under which every answer stays correct
+PRODUCT_HOOKS = {"MSE_BUILD_EXACT_BACKEDGE", "MSE_BUILD_EXACT_PRUNE", "MSE_GRAM_EPS_SCALE", "MSE_SHARD_NO_PEER", "MSE_SIGLIP_NOFUSE",
+                 "MSE_SIGLIP_STREAMS", "MSE_VISITED_BUDGET_KB", "MSE_VISITED_MODE", "MSE_VISITED_TABLE_BITS"}
+
+
+def test_product_library_reads_no_developer_knob(mse):
+    """Timing ablations (wrong answers by design) and superseded kernels are compiled only into the developer library
+    (make dev, -DMSE_DEV_KERNELS).  The product .so must not even contain the names of those environment variables, and the
+    only MSE_* names it does contain are the answer-preserving hooks."""
+    import re
+    from mse import ffi
+    blob = open(ffi.LIB_PATH, "rb").read()
+    names = {m.decode() for m in re.findall(rb"MSE_[A-Z0-9_]{3,}", blob)}
+    names = {n for n in names if not n.startswith(("MSE_HIP_TRY", "MSE_DYN_LDS", "MSE_DEV_K", "MSE_ID_", "MSE_API"))}
+    assert not names & set(DEV_KNOBS), names & set(DEV_KNOBS)
+    assert names <= PRODUCT_HOOKS, names - PRODUCT_HOOKS

@@ -109,10 +109,10 @@ def test_write_index_then_open(tmp_path):
         e["vertices"] = e["vertices"] % count
     codes = np.arange(count * 4, dtype=np.uint8).reshape(count, 4)
     desc = np.arange(count * 2, dtype=np.uint8).reshape(count, 2)
-    out = di.write_index(str(tmp_path), hdr, ents, codes, desc)
+    out = di.write_index(str(tmp_path), hdr, ents, codes, desc, encode_entry=di.UNPINNED_BITCODE06_ENCODE)
     assert (out.count, out.dead_count) == (count, 1)
     assert (tmp_path / "index.bin").stat().st_size == count * 512
-    idx = di.DiskIndex(str(tmp_path))
+    idx = di.DiskIndex(str(tmp_path), decode_entry=di.UNPINNED_BITCODE06_DECODE)
     assert idx.header.count == count and idx.header.dead_count == 1
     got = list(idx.entries())
     assert [g["url"] for g in got] == [e["url"] if i != 3 else "" for i, e in enumerate(ents)]

@@ -255,3 +255,24 @@ def test_mfma_error_bound_is_measured_not_assumed(gpu, mse, orc):
     print("max |mfma - exact| / (|q||x|) =", worst)
     assert worst > 0                                  # the two orders do differ: the certificate is not vacuous
     assert 2.8e-4 >= 4 * worst, worst
+
+
+def test_developer_knobs_do_nothing_in_the_product_build(gpu, mse, orc, monkeypatch):
+    """Every environment variable that used to select a timing ablation (answers wrong by design) or a superseded kernel is set
+    to its most destructive value; the product library never reads them, so the batched answer still equals the oracle's and the
+    exact-order kernel's, and a small PQ scan / dedup still equal theirs."""
+    for name, val in [("MSE_SCAN_ABL", "1"), ("MSE_SCAN_2D", "162"), ("MSE_SCAN_S", "1"), ("MSE_ATT_ABL", "1"), ("MSE_ATT64_ABL", "2"),
+                      ("MSE_ATT_WAVES", "4"), ("MSE_ATT_QT", "4"), ("MSE_ATT_TILE32", "1"), ("MSE_GEMM_RANDOM", "1"),
+                      ("MSE_GEMM_OLD256", "1"), ("MSE_GEMM_128", "1"), ("MSE_GEMM_NOPERSIST", "1"), ("MSE_GEMM_STAGGER", "7"),
+                      ("MSE_GEMM_NONARROW", "1"), ("MSE_PQ_OLDTRANSFORM", "1"), ("MSE_PQ_OLDQUANT", "1"), ("MSE_PQ_OLDSCAN", "1"),
+                      ("MSE_DEDUP_OLD", "1")]:
+        monkeypatch.setenv(name, val)
+    n, nq, k = 30_000, 256, 10
+    rows = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    searcher = mse.Searcher(mse.VectorList.generate(SEED_BASE, 0, n))
+    s, i = searcher.bruteforce_topk(q, k, mse.MODE_MFMA)          # the 256-query pass: the kernel the ablations lived in
+    ws, wi = orc.bruteforce_topk(rows, q, k)
+    assert np.array_equal(i, wi) and np.array_equal(s, ws)
+    se, ie = searcher.bruteforce_topk(q[:8], k, mse.MODE_EXACT)
+    assert np.array_equal(ie, wi[:8]) and np.array_equal(se, ws[:8])

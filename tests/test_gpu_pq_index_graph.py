@@ -200,6 +200,86 @@ def test_flat_index_matches_oracle(gpu, mse, orc, n, d):
     assert np.all(res.labels[:, min(n, 7):] == -1)
 
 
+def test_flat_index_at_config0_size(gpu, mse, orc):
+    """BASELINE configs[0]: brute-force top-10 over 1e5 x 1152 through the in-memory index surface (src/main.rs:815-934):
+    1024-row add batches, 11 un-normalised f32 queries, labels AND distances against the oracle's FAISS restatement."""
+    rng = np.random.default_rng(40)
+    n, d, k = 100_000, 1152, 10
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    idx = mse.ScalarQuantizerIndex(d)
+    for lo in range(0, n, 1024):
+        idx.add(x[lo:lo + 1024])
+    assert idx.ntotal() == n
+    q = rng.standard_normal((11, d)).astype(np.float32)
+    res = idx.search(q, k)
+    codes = orc.f16_bits(x)
+    wd, wl = orc.index_search(codes, q, k, order=0)
+    assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
+    _, l1 = orc.index_search(codes, q, k, order=1)          # FAISS's scalar summation order ranks it identically
+    assert np.array_equal(res.labels, l1)
+
+
+def test_query_composed_by_get_total_embedding_end_to_end(gpu, mse, orc):
+    """A16 (src/common.rs:215-274) in its place on the path: the clip server's fp16 rows (HIP text + image engines) are combined by
+    get_total_embedding -- weights of both signs, a raw-embedding term, NO renormalisation -- and the sum is what the in-memory
+    index is searched with (src/main.rs:941-953,900).  Composition against the oracle's restatement (bit-exact: the same f32
+    multiply-adds in term order), then labels and distances of the search against the oracle's on the same query."""
+    import io
+    from PIL import Image
+    from mse import siglip
+    d = 1152
+    eng = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(dict(siglip.SO400M_384, depth=1)),
+                                                   dict(siglip.SO400M_384, depth=1), max_batch=4)
+    tcfg = dict(siglip.SO400M_TEXT, layers=1)
+    teng = siglip.SiglipTextEngine.from_state_dict(siglip.synthetic_text_state_dict(tcfg), tcfg, max_batch=4)
+    rng = np.random.default_rng(41)
+
+    def bmp(seed):
+        im = Image.fromarray(np.random.default_rng(seed).integers(0, 256, size=(384, 384, 3), dtype=np.uint8), "RGB")
+        buf = io.BytesIO()
+        im.save(buf, format="BMP")
+        return buf.getvalue()
+
+    tokens = {"cat": [5, 9, 2], "dog": [7, 3, 11, 2]}
+    served = []
+
+    def query_server(batch):                                  # the clip_server contract: a list of 2304-byte fp16 rows
+        if "images" in batch:
+            rows = eng.encode_bmp(batch["images"], out="f16")
+        else:
+            rows = teng.encode_text(siglip.pad_tokens([tokens[t] for t in batch["text"]]), out="f16")
+        rows = [np.ascontiguousarray(r).view(np.uint16).tobytes() for r in rows]
+        served.extend(rows)
+        return rows
+
+    raw = (rng.standard_normal(d) / np.sqrt(d)).astype(np.float32)
+    terms = [{"image": bmp(1), "weight": 1.5}, {"text": "cat"}, {"text": "dog", "weight": -0.75}, {"image": bmp(2), "weight": -0.25},
+             {"embedding": raw.tolist(), "weight": 0.5}]
+    total = mse.get_total_embedding(terms, d, query_server)
+    assert len(served) == 4 and all(len(r) == 2 * d for r in served)
+    embs = np.stack([np.frombuffer(r, "<u2") for r in served])          # images first, then text (common.rs:252-266)
+    weights = np.array([1.5, -0.25, 1.0, -0.75], np.float32)
+    want = raw * np.float32(0.5) + orc.total_embedding(embs, weights)    # the oracle sums the served rows from zero: same terms,
+    assert np.allclose(total, want, rtol=1e-6, atol=1e-7)                # different association of the raw-embedding term
+    step = raw * np.float32(0.5)                                          # the reference's own order (:238-266), one f32 op at a time
+    for e, w in zip(embs, weights):
+        step = step + e.view(np.float16).astype(np.float32) * w
+    assert np.array_equal(total, step)
+    assert abs(float(np.linalg.norm(total)) - 1.0) > 1e-2                # a weighted sum, not re-normalised
+    # the index: random rows plus the two image embeddings themselves
+    n = 6000
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    x[123] = mse.decode_fp16_buffer(served[0])
+    x[4567] = mse.decode_fp16_buffer(served[1])
+    idx = mse.ScalarQuantizerIndex(d)
+    for lo in range(0, n, 1024):
+        idx.add(x[lo:lo + 1024])
+    res = idx.search(total[None, :], 10)
+    wd, wl = orc.index_search(orc.f16_bits(x), total[None, :], 10, order=0)
+    assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
+    assert res.labels[0, 0] == 123                                       # weight +1.5 on image 1 puts its own row first
+
+
 def test_index_large_k_default_of_server(gpu, mse, orc):
     # handle_request uses k = 1000 by default (src/main.rs:952)
     rng = np.random.default_rng(5)
@@ -540,8 +620,8 @@ def test_index_directory_is_the_front_door_of_the_beam_search(gpu, mse, orc, tmp
                          [np.linspace(0, 1, 5).astype(np.float32)] * 2)
     ents = ({"vector": base[i], "vertices": adj[i, :degs[i]], "id": i, "timestamp": 1_700_000_000 + i, "dimensions": (100 + i, 50),
              "scores": np.array([0.1, 0.2], np.float32), "url": urls[i], "shards": np.array([0], np.uint32)} for i in range(n))
-    di.write_index(str(tmp_path), hdr, ents, codes, desc)
-    idx = di.DiskIndex(str(tmp_path))
+    di.write_index(str(tmp_path), hdr, ents, codes, desc, encode_entry=di.UNPINNED_BITCODE06_ENCODE)
+    idx = di.DiskIndex(str(tmp_path), decode_entry=di.UNPINNED_BITCODE06_DECODE)
     assert idx.header.count == n and idx.header.dead_count == 0       # empty URLs given by the caller are not "dead" by overflow
     vl, dgraph, gcodes, graph, got_urls = idx.to_device()
     assert got_urls == urls and np.array_equal(vl.rows(0, n), base)

@@ -137,9 +137,13 @@ def test_index_directory_records_and_code_files(tmp_path):
     assert [idx.record_payload(i) for i in range(3)] == payloads and idx.read_node(0) == "abc"
     assert idx.pq_codes.tolist() == [[0, 1], [2, 3], [4, 5]] and idx.descriptors.tolist() == [[9], [8], [7]]
     with pytest.raises(NotImplementedError):
-        di.DiskIndex(str(tmp_path), decode_entry=None).read_node(0)
-    with pytest.raises(ValueError):
-        di.DiskIndex(str(tmp_path)).read_node(0)            # b"abc" is not a PackedIndexEntry: the default decoder says so
+        di.DiskIndex(str(tmp_path)).read_node(0)            # no silent default: the bitcode restatement is unpinned, opt-in only
+    with pytest.raises(NotImplementedError):
+        list(di.DiskIndex(str(tmp_path)).entries())
+    with pytest.raises(NotImplementedError):
+        di.write_index(str(tmp_path), hdr, [], np.zeros((0, 2), np.uint8), None)
+    with pytest.raises(ValueError):                         # b"abc" is not a PackedIndexEntry: the opted-in decoder says so
+        di.DiskIndex(str(tmp_path), decode_entry=di.UNPINNED_BITCODE06_DECODE).read_node(0)
     with pytest.raises(ValueError):
         di.write_records(str(tmp_path / "x.bin"), [bytes(63)], 64)
     np.arange(5, dtype=np.uint8).tofile(str(tmp_path / "index.pq-codes.bin"))

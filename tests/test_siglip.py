@@ -12,6 +12,11 @@ from conftest import GOLDEN
 torch.set_grad_enabled(False)
 
 
+def torch_from(a):
+    import torch
+    return torch.from_numpy(np.asarray(a, np.float32))
+
+
 def cosine(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return (a * b).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
@@ -159,6 +164,29 @@ def test_sub_batches_on_two_streams_change_nothing(gpu, mse, ref, monkeypatch, b
     assert np.isfinite(got2).all() and np.all(np.abs(np.linalg.norm(got2, axis=1) - 1) < 1e-3)
     # and a small batch (one stream either way) after the large one still equals its rows of the large batch
     assert np.array_equal(two.encode_image(img[:3]), got2[:3])
+
+
+@pytest.mark.gpu
+def test_batch_256_rows_equal_small_batch_rows(gpu, mse, ref):
+    """BASELINE configs[1]'s batch (256 images, two sub-batches of 128 on two streams), depth 2: a row's arithmetic does not depend
+    on what else is in the batch, so rows of the batch-256 forward are BIT-equal to the same images encoded three at a time --
+    at the start, across the sub-batch seam and at the end -- and within the north star's cosine of the fp32 oracle."""
+    from mse import siglip
+    cfg = dict(ref.CONFIG, depth=2)
+    sd = ref.synthetic_weights(cfg)
+    img = ref.synthetic_images(256, cfg)
+    x16 = img.numpy().astype(np.float16)
+    eng = siglip.SiglipImageEngine.from_state_dict({"visual." + k: v for k, v in sd.items()}, dict(siglip.SO400M_384, depth=2),
+                                                   max_batch=256)
+    big = eng.encode_image(x16)
+    assert big.shape == (256, 1152) and np.isfinite(big).all()
+    assert np.all(np.abs(np.linalg.norm(big, axis=1) - 1) < 1e-3)
+    for lo in (0, 126, 128, 253):
+        assert np.array_equal(eng.encode_image(x16[lo:lo + 3]), big[lo:lo + 3]), lo
+    rows = [0, 127, 128, 255]
+    want = ref.encode_image(torch_from(x16[rows]), sd, cfg).numpy()
+    assert np.all(cosine(big[rows], want) > 1 - 1e-3)
+    assert np.array_equal(eng.encode_image(x16), big)                      # idempotent at full batch
 
 
 @pytest.mark.gpu
