@@ -132,12 +132,12 @@ def cpu_baseline(n_rows, k):
 
 
 def pq_bench(args):
-    """BASELINE configs[4] shape: full ADC scan of 64-byte OPQ codes (+4 descriptor bytes), top-200 by approximate score (the
-    re-rank candidates), all arrays resident in HBM.  Reported end to end per query (query upload, table build, scan keeping one
-    maximum per 64 vectors, tournament, re-score of the best groups, exact top-r, download): one query per call, and 32 queries
-    per call (one upload / download, the scans back to back).  `roofline`: 68 B per vector per query against the HBM peak, from
-    the batched per-query time; the scan is a 64-gather-per-vector LDS loop and HBM-bound only in the sense that each query
-    streams all codes once."""
+    """BASELINE configs[4] shape at BASELINE.md's size: full ADC scan of 1e8 x 64-byte OPQ codes (+4 descriptor bytes), top-200 by
+    approximate score (the re-rank candidates), all arrays resident in HBM.  Reported end to end per query (query upload, table
+    build, scan keeping one maximum per 64 vectors, tournament, re-score of the best groups, exact top-r, download): one query per
+    call, and 32 queries per call (one upload / download; queries go through in PAIRS that share one pass over the codes --
+    pq_scan64x2_kernel -- and pairs alternate between two streams).  `roofline`: 68 B per vector per PASS against the HBM peak,
+    a pass taken as two batched per-query times; the scan is a 64-gather-per-vector LDS loop."""
     import numpy as np
     import mse
     n = int(args.pq_rows)
@@ -145,7 +145,16 @@ def pq_bench(args):
     cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
     T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
     pq = mse.ProductQuantizer(cents, T, 18, D)
-    gc = mse.Codes(rng.integers(0, 256, size=(n, 64), dtype=np.uint8), rng.integers(0, 256, size=(n, 4), dtype=np.uint8))
+    # 6.4 GB of random code rows in seconds: distinct byte-mask copies of one random block
+    blk = min(n, 1_000_000)
+    block = rng.integers(0, 256, size=(blk, 64), dtype=np.uint8)
+    codes = np.empty((n, 64), np.uint8)
+    for c0 in range(0, n, blk):
+        m = min(blk, n - c0)
+        np.bitwise_xor(block[:m], rng.integers(0, 256, size=64, dtype=np.uint8), out=codes[c0:c0 + m])
+    desc = np.resize(rng.integers(0, 256, size=(blk, 4), dtype=np.uint8), (n, 4))
+    gc = mse.Codes(codes, desc)
+    del codes, desc, block
     scales = np.array([0.5, 0, -0.25, 0], np.float32) / np.float32(512)
     qs = (rng.standard_normal((32, D)) / np.sqrt(D)).astype(np.float32)
     pq.scan_topk(gc, qs[0], 200, 10, None, scales)
@@ -158,13 +167,16 @@ def pq_bench(args):
     for _ in range(3):
         pq.scan_topk_batch(gc, qs, 200, 10, None, scales)
     db = (time.perf_counter() - t0) / (3 * len(qs))
-    gbs = n * 68 / db / 1e9
+    gbs_pass = n * 68 / (2 * db) / 1e9
     return {"metric": "OPQ/PQ 64x8-bit ADC scan + top-200", "ms_per_query": dt * 1e3, "ms_per_query_batched": db * 1e3,
-            "queries_per_call_batched": len(qs), "vectors": n,
-            "codes_GBps_end_to_end": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "bytes_per_query": n * 68, "traffic": None},
-            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), table 64 x 256 f32 in LDS, r = 200"}}
+            "queries_per_s_batched": 1.0 / db, "queries_per_call_batched": len(qs), "queries_per_pass_batched": 2, "vectors": n,
+            "codes_GBps_end_to_end_one_query_per_call": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
+            "roofline": {"bound": "hbm", "achieved": gbs_pass, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pass / HBM_PEAK_GBS,
+                         "bytes_per_pass": n * 68, "queries_per_pass": 2, "traffic": None,
+                         "per_query_equivalent_GBps": n * 68 / db / 1e9,
+                         "note": "achieved = 68 B x vectors per pass / (2 x batched per-query time): a pass over the codes serves two "
+                                 "queries; per_query_equivalent_GBps is last round's accounting (one pass per query)"},
+            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), two queries' tables 64 x 256 x {{f32, f32}} in LDS, r = 200"}}
 
 
 def graph_rows(n, seed, centres):
@@ -428,7 +440,7 @@ def main():
                     help="developer dry run of the in-process --gpus N path on fewer devices (shard g on device g mod count)")
     ap.add_argument("--no-siglip", action="store_true", help="skip the SigLIP image-tower leg")
     ap.add_argument("--no-pq", action="store_true", help="skip the OPQ/PQ scan leg")
-    ap.add_argument("--pq-rows", type=float, default=2e7)
+    ap.add_argument("--pq-rows", type=float, default=1e8)
     ap.add_argument("--no-graph", action="store_true", help="skip the GPU-resident beam-search leg")
     ap.add_argument("--graph-rows", type=float, default=2e5)
     ap.add_argument("--no-graph-scale", action="store_true", help="skip the 1e7-row graph-index leg (a ~1 minute build)")
@@ -507,9 +519,22 @@ def main():
         group.generate(SEED_BASE, 0, n_total)                         # every shard's rows made on its own device
         searcher = group.searcher(0)
         peers = sum(group.peer_mapped(g) for g in range(n_gpus))
-        exchange = {"kind": "one process, a host thread per shard; per-shard [Q,k] records written into the root device's buffer",
-                    "shards": n_gpus, "devices": [group.device(g) for g in range(n_gpus)],
-                    "peer_mapped_shards": peers, "ranks": n_gpus}
+        peer_kind = ("peer stores into the root device's gather buffer" if peers == n_gpus else
+                     f"staged copies (hipMemcpyPeerAsync) for {n_gpus - peers} of {n_gpus} shards, peer stores for the rest")
+        exchange = {"kind": "one process, a host thread per shard; " + peer_kind, "shards": n_gpus,
+                    "devices": [group.device(g) for g in range(n_gpus)], "peer_mapped_shards": peers, "rccl_ranks": 0}
+        # the exchange north_star names: ONE ncclAllGather of the packed records per step among the shards' devices, each rank's
+        # collective issued by its shard's host thread (csrc/shard_group.hip).  If RCCL cannot be brought up (shards sharing a
+        # device, no librccl, ncclCommInitAll failing) the line is still measured over the peer-store exchange, labelled as such.
+        try:
+            group.set_exchange(group.EXCHANGE_RCCL)
+            exchange = {"kind": "one process, a host thread per shard; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record "
+                                "blocks per step, rank g = shard g on device g", "shards": n_gpus,
+                        "devices": [group.device(g) for g in range(n_gpus)], "rccl_ranks": group.rccl_ranks,
+                        "bytes_per_rank_per_step": int(ffi.lib().mse_topk_block_bytes(nq, k))}
+        except mse.MseError as e:
+            exchange["rccl_unavailable"] = str(e)
+            print(f"[bench] RCCL exchange unavailable ({e}); measuring the peer-store exchange", file=sys.stderr)
 
         def step(i):
             qptr = qsets.device_ptr + (i % n_batches) * nq * D * 2
@@ -557,7 +582,7 @@ def main():
                                     f"(RCCL init failed: {host_exchange})", "ranks": world, "bytes_per_rank_per_step": B_blk}
             else:
                 exchange = {"kind": "one process per GPU; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record blocks per step",
-                            "ranks": comm.size, "bytes_per_rank_per_step": int(ffi.lib().mse_topk_block_bytes(nq, k))}
+                            "rccl_ranks": comm.size, "bytes_per_rank_per_step": int(ffi.lib().mse_topk_block_bytes(nq, k))}
 
         def step(i):
             qptr = qsets.device_ptr + (i % n_batches) * nq * D * 2
@@ -589,6 +614,44 @@ def main():
     elapsed = time.perf_counter() - t0
     scan_ms, scan_launches = searcher.scan_timing(0)
     stats = searcher.last_stats()
+    # where a step goes (last step of the timed loop): the scan kernel, the rest of the local search (pack + tournament + exact
+    # re-score + certificate), the exchange leg and the merge
+    breakdown = exchange_alt = None
+    try:
+        if in_process:
+            t = group.last_timing()
+            breakdown = {"scan_ms": scan_ms / max(scan_launches, 1), "local_search_ms": t["local_search_ms"],
+                         "tail_ms": t["local_search_ms"] - scan_ms / max(scan_launches, 1), "exchange_ms": t["exchange_ms"],
+                         "merge_ms": t["merge_ms"], "wall_ms": t["wall_ms"], "of": "last timed step; slowest shard per leg"}
+            if group.exchange == group.EXCHANGE_RCCL:
+                # the same index over the peer-store exchange, timed right after the headline (second variant, same line)
+                group.set_exchange(group.EXCHANGE_PEER)
+                for i in range(2):
+                    step(i)
+                sync_all()
+                tb = time.perf_counter()
+                for i in range(args.steps):
+                    step(args.warmup + i)
+                sync_all()
+                dtb = time.perf_counter() - tb
+                tp = group.last_timing()
+                exchange_alt = {"kind": "peer stores into the root device's gather buffer (no collective)",
+                                "peer_mapped_shards": sum(group.peer_mapped(g) for g in range(n_gpus)),
+                                "value": nq * args.steps / dtb, "unit": "queries/s", "ms_per_step": dtb / args.steps * 1e3,
+                                "exchange_ms": tp["exchange_ms"], "merge_ms": tp["merge_ms"], "local_search_ms": tp["local_search_ms"]}
+                group.set_exchange(group.EXCHANGE_RCCL)
+                searcher.scan_timing(2)
+        elif comm is not None:
+            t = comm.last_timing()
+            breakdown = {"scan_ms": scan_ms / max(scan_launches, 1), "local_search_ms": t["local_search_ms"],
+                         "tail_ms": t["local_search_ms"] - scan_ms / max(scan_launches, 1), "exchange_ms": t["exchange_ms"],
+                         "merge_ms": t["merge_ms"], "of": "last timed step on rank 0; exchange_ms includes waiting for the slowest rank"}
+        else:
+            breakdown = {"scan_ms": scan_ms / max(scan_launches, 1),
+                         "tail_ms": elapsed / args.steps * 1e3 - scan_ms / max(scan_launches, 1), "exchange_ms": 0.0,
+                         "of": "averages of the timed loop; tail = pack + tournament + exact re-score + certificate + host hand-off"}
+    except Exception as e:  # noqa: BLE001
+        breakdown = {"error": repr(e)}
 
     # second operating point, outside the headline's timed region: 128 queries per pass, where the scan is HBM-bound
     # (at 256 the same stream feeds twice the MFMA work and the pass is bound by the chip's power budget instead)
@@ -700,6 +763,7 @@ def main():
             "config": {"workload": f"brute-force top-{k} over {n_total} x {D} fp16 rows, {nq} queries/step, "
                                    f"row-sharded over {n_gpus} GPU(s)" + (" + FALLBACK gloo all-gather of [Q,k] records (RCCL did not come up)" if host_exchange is not None else
                                                                           " + RCCL all-gather of [Q,k] records" if world > 1 else
+                                                                          " + RCCL all-gather of [Q,k] records (one process, a thread per GPU)" if in_process and exchange.get("rccl_ranks") else
                                                                           " + peer-mapped gather of [Q,k] records" if in_process else ""),
                        "rows_total": n_total, "rows_per_gpu": hi - lo, "queries_per_step": nq, "k": k,
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
@@ -716,6 +780,8 @@ def main():
                          "launches_timed": scan_launches,
                          # informational: the guide's measured float4-copy ceiling of this chip is 6.29 TB/s
                          "frac_of_measured_copy_ceiling": (achieved / 6290.0) if achieved else None},
+            "step_breakdown": breakdown,
+            "exchange_alt": exchange_alt,
             "verified_vs_exact_kernel": verified,
             "hbm_bound_point": alt,
             "certificate": stats,

@@ -146,6 +146,20 @@ int mse_shard_group_set_shard_device(mse_shard_group* g, size_t shard, const voi
 int mse_shard_group_search(mse_shard_group* g, const uint16_t* queries, size_t nq, size_t k, int mode, int64_t* scores,
                            uint32_t* ids);
 /* queries / outputs on the ROOT device (queries complete before the call); returns when the result is complete. */
+/* How the per-shard [nq][k] records meet (no reference counterpart: the reference has one address space, src/query_disk_index.rs:711-736).
+ * MSE_EXCHANGE_PEER (default): kernels of a shard store its block into the root device's gather buffer through a peer mapping
+ * (or one hipMemcpyPeerAsync per shard when the devices cannot map each other); works with several shards per device.
+ * MSE_EXCHANGE_RCCL: ONE ncclAllGather of the packed 12-byte records per search among the shards' devices (librccl.so, dlopen'ed),
+ * every shard on its own device.  set_exchange returns -1 and leaves the previous exchange in place when RCCL cannot be brought
+ * up (shards sharing a device, no librccl, ncclCommInitAll failing): callers degrade, they do not abort. */
+#define MSE_EXCHANGE_PEER 0
+#define MSE_EXCHANGE_RCCL 1
+int mse_shard_group_set_exchange(mse_shard_group* g, int kind);
+int mse_shard_group_exchange(const mse_shard_group* g);
+int mse_shard_group_rccl_ranks(const mse_shard_group* g);                   /* ranks as ncclCommCount reports them; 0 = RCCL not up */
+/* breakdown of the last search in ms: [0] slowest shard's local search (scan + tournament + re-score + certificate),
+ * [1] slowest shard's exchange leg (all-gather / staged copy; ~0 for peer stores), [2] merge on the root, [3] wall clock of the call */
+int mse_shard_group_last_timing(mse_shard_group* g, double out_ms[4]);
 int mse_shard_group_search_dev(mse_shard_group* g, const void* queries_dev, size_t nq, size_t k, int mode, void* scores_dev,
                                void* ids_dev);
 
@@ -162,6 +176,9 @@ int mse_comm_rank(const mse_comm* c);
 int mse_comm_size(const mse_comm* c);                   /* rank count as RCCL reports it */
 int mse_comm_search_dev(mse_comm* c, mse_searcher* s, const void* queries_dev, size_t nq, size_t k, int mode,
                         uint64_t id_offset, void* scores_dev, void* ids_dev);
+/* breakdown of this rank's last mse_comm_search_dev in ms: [0] local search, [1] all-gather (incl. waiting for the slowest rank),
+ * [2] merge, [3] their sum; waits for that search to finish */
+int mse_comm_last_timing(mse_comm* c, double out_ms[4]);
 
 /* ---- flat in-memory index: FAISS IndexScalarQuantizer(QT_fp16, INNER_PRODUCT) as used by
  * src/main.rs:822 (new), :858,:892 (add), :900 (search), :1015,:1053 (ntotal) -------------- */
@@ -203,6 +220,10 @@ int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, co
  * vectors are then found inside the r best groups (exact, ties by lower id). */
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
+/* test hook: the group maxima (best ADC score + descriptor bias of every 64 vectors, INT64_MIN past the end) the flat scan
+ * nominates with; lut1 == NULL: the one-query kernel, else the two-queries-per-pass kernel.  out0 / out1: [ceil(n/64)] on the host. */
+int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, const float* lut1, const float* scales, int64_t* out0,
+                           int64_t* out1);
 /* descriptor_product (src/query_disk_index.rs:135-142) for one id, host-side helper. */
 int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id);
 

@@ -287,30 +287,29 @@ int mse_pq_adc_gather(mse_pq* pq, const mse_codes* c, const float* lut, const fl
     return 0;
 }
 
-// One query of the flat ADC scan, entirely on the searcher's stream (no host synchronisation):
-//   table(query) -> scan of all codes keeping one maximum per 64 vectors -> tournament over the maxima -> the r best groups'
-//   r x 64 vectors re-scored by the gather kernel (same arithmetic) -> exact top-r by ADC score (ties: lower id)
-//   -> with base vectors: exact fast_dot re-score of those r (+ descriptor bias) and top-k of that
-// t_dev: transformed query (fp32 [d]) scratch, lut_dev: table scratch (64 KiB), qf16_dev: f16 copy of the query (8 rows of scratch)
-static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* query_dev, float* t_dev, float* lut_dev,
-                           uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k, int64_t* out_scores_dev,
-                           uint32_t* out_ids_dev) {
+static int prep_table(mse_pq* pq, mse_searcher* s, const float* query_dev, float* t_dev, float* lut_dev) {
+    if (launch_pq_transform_vec(pq->transform_t, (int)pq->d, query_dev, t_dev, s->stream)) return -1;
+    return launch_pq_lut(pq->centroids, (int)pq->n_centroids, (int)pq->d, (int)pq->dpc, t_dev, lut_dev, s->stream);
+}
+
+// everything after the scan of one query.  gmax: the scan's group maxima [n_groups] (i64), or null when the codec shape has no
+// group-maximum scan (then every vector is scored here).
+static int scan_tail_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const int64_t* gmax, const float* query_dev,
+                           const float* lut_dev, uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k,
+                           int64_t* out_scores_dev, uint32_t* out_ids_dev) {
     hipStream_t st = s->stream;
     const size_t d = pq->d;
-    if (launch_pq_transform_vec(pq->transform_t, (int)d, query_dev, t_dev, st)) return -1;
-    if (launch_pq_lut(pq->centroids, (int)pq->n_centroids, (int)d, (int)pq->dpc, t_dev, lut_dev, st)) return -1;
     const uint8_t* desc = scales_dev ? c->desc : nullptr;
     uint32_t* top_ids = nullptr;           // the r best by approximate score
     const int64_t* top_scores = nullptr;
     if (s->sel_keys.ensure(r * 8)) return -1;
-    if (pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc, (int)c->n_desc, scales_dev)) {
+    if (gmax) {
         const size_t n_groups = (c->n + 63) / 64;
         const size_t rg = std::min(r, n_groups);
-        if (s->scores.ensure(n_groups * 8) || s->gkeys.ensure(rg * 8) || s->cand_ids.ensure(rg * 64 * 4) ||
-            s->cand_scores.ensure(rg * 64 * 8) || s->out_ids.ensure(r * 4)) return -1;
-        if (launch_pq_scan_gmax(lut_dev, c->codes, c->n, desc, scales_dev, s->scores.as<int64_t>(), s->n_cu, st)) return -1;
+        if (s->gkeys.ensure(rg * 8) || s->cand_ids.ensure(rg * 64 * 4) || s->cand_scores.ensure(rg * 64 * 8) || s->out_ids.ensure(r * 4))
+            return -1;
         uint32_t* gsel = nullptr;
-        LevelRef l0{KEY_I64, s->scores.p, n_groups, 1, n_groups, false, 0};
+        LevelRef l0{KEY_I64, const_cast<int64_t*>(gmax), n_groups, 1, n_groups, false, 0};
         if (descend(s, l0, 1, (int)rg, &gsel, s->gkeys.p)) return -1;
         if (launch_expand_groups(gsel, rg, rg, 64, c->n, s->cand_ids.as<uint32_t>(), rg * 64, 1, st)) return -1;
         if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), rg * 64,
@@ -318,7 +317,10 @@ static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, cons
         SelectArgs a{};
         a.kind = KEY_I64; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p; a.list_stride = rg * 64;
         a.n_list = rg * 64; a.k = (int)r; a.out_ids = s->out_ids.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = r; a.nq = 1;
-        if (rg == r) a.floor_hi = s->last_kth;   // r group maxima reach the r-th best group's key, so r vectors do
+        // r group maxima reach the r-th best group's key, so r vectors do: the key is a floor for the select.  This leans on the
+        // scan kernels and pq_adc_kernel producing the SAME i64 for a vector (same adds in the same order, bias added after the
+        // conversion); tests/test_gpu_pq_index_graph.py::test_group_maxima_equal_the_gathered_scores pins exactly that.
+        if (rg == r) a.floor_hi = s->last_kth;
         if (launch_select(a, st)) return -1;
         top_ids = s->out_ids.as<uint32_t>();
     } else {
@@ -350,6 +352,36 @@ static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, cons
     return 0;
 }
 
+// One query (n_q = 1) or a PAIR of queries (n_q = 2) of the flat ADC scan, entirely on the searcher's stream (no host synchronisation):
+//   table(query) -> scan of all codes keeping one maximum per 64 vectors (a pair shares ONE pass over the codes: pq_scan64x2_kernel)
+//   -> per query: tournament over the maxima -> the r best groups' r x 64 vectors re-scored by the gather kernel (same arithmetic)
+//   -> exact top-r by ADC score (ties: lower id) -> with base vectors: exact fast_dot re-score of those r (+ descriptor bias), top-k
+// t_dev: transformed queries (fp32 [2][d]) scratch, lut_dev: table scratch (2 x 64 KiB), qf16_dev: f16 copy of a query (8 rows)
+static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* queries_dev, int n_q, float* t_dev,
+                           float* lut_dev, uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k,
+                           int64_t* out_scores_dev, uint32_t* out_ids_dev) {
+    const size_t d = pq->d, lut_floats = pq->n_chunks * pq->n_centroids;
+    const uint8_t* desc = scales_dev ? c->desc : nullptr;
+    const bool gm = pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc, (int)c->n_desc, scales_dev);
+    for (int j = 0; j < n_q; j++)
+        if (prep_table(pq, s, queries_dev + j * d, t_dev + j * d, lut_dev + j * lut_floats)) return -1;
+    const size_t n_groups = (c->n + 63) / 64;
+    int64_t* g0 = nullptr;
+    int64_t* g1 = nullptr;
+    if (gm) {
+        if (s->scores.ensure(n_groups * 8) || (n_q == 2 && s->gmax.ensure(n_groups * 8))) return -1;
+        g0 = s->scores.as<int64_t>();
+        g1 = s->gmax.as<int64_t>();
+        if (n_q == 2) {
+            if (launch_pq_scan_gmax2(lut_dev, lut_dev + lut_floats, c->codes, c->n, desc, scales_dev, g0, g1, s->n_cu, s->stream)) return -1;
+        } else if (launch_pq_scan_gmax(lut_dev, c->codes, c->n, desc, scales_dev, g0, s->n_cu, s->stream)) return -1;
+    }
+    for (int j = 0; j < n_q; j++)
+        if (scan_tail_async(pq, c, s, gm ? (j ? g1 : g0) : nullptr, queries_dev + j * d, lut_dev + j * lut_floats, qf16_dev, scales_dev,
+                            r, k, out_scores_dev + j * k, out_ids_dev + j * k)) return -1;
+    return 0;
+}
+
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
     if (!pq || !c) return fail("null quantiser or codes");
@@ -375,7 +407,7 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         const size_t sc_off = (nq * d * 4 + 255) & ~(size_t)255;
         const size_t sc_bytes = (scales && c->n_desc) ? c->n_desc * 4 : 0;
         const size_t in_bytes = sc_off + sc_bytes, out_bytes = nq * k * 12;
-        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(d * 4) || pq->c.ensure(pq->n_chunks * pq->n_centroids * 4)) break;
+        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(2 * d * 4) || pq->c.ensure(2 * pq->n_chunks * pq->n_centroids * 4)) break;
         if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(out_bytes)) break;
         if (pq->pin_cap < std::max(in_bytes, out_bytes)) {
             if (pq->pin) (void)hipHostFree(pq->pin);
@@ -399,15 +431,19 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
             if (pq->lane2 && pq->lane2->base != s->base) { mse_searcher_free(pq->lane2); pq->lane2 = nullptr; }
             if (!pq->lane2) pq->lane2 = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
             lanes[1] = pq->lane2;
-            if (!lanes[1] || t2.ensure(d * 4) || lut2.ensure(pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
+            if (!lanes[1] || t2.ensure(2 * d * 4) || lut2.ensure(2 * pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
             if (hipStreamSynchronize(st) != hipSuccess) { fail("H2D failed"); break; }   // uploads visible to both streams
         }
+        // queries go through in PAIRS that share one pass over the codes (pq_scan64x2_kernel); pairs alternate between the streams
         bool ok = true;
-        for (size_t q = 0; q < nq && ok; q++) {
-            const int w = lanes[1] ? (int)(q & 1) : 0;
-            ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, w ? t2.as<float>() : pq->b.as<float>(),
+        size_t q = 0;
+        for (size_t unit = 0; q < nq && ok; unit++) {
+            const int n_q = nq - q >= 2 ? 2 : 1;
+            const int w = lanes[1] ? (int)(unit & 1) : 0;
+            ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, n_q, w ? t2.as<float>() : pq->b.as<float>(),
                                  w ? lut2.as<float>() : pq->c.as<float>(), w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>(),
                                  scales_dev, r, k, out_scores_dev + q * k, out_ids_dev + q * k) == 0;
+            q += n_q;
         }
         if (lanes[1] && hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
         if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
@@ -420,6 +456,35 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         rc = 0;
     } while (0);
     return rc;
+}
+
+// test hook: the group maxima the flat scan nominates with -- lut1 == null: pq_scan64_kernel<true> for one table; otherwise
+// pq_scan64x2_kernel for the pair.  out0 / out1: [ceil(n / 64)] i64 on the host.
+int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, const float* lut1, const float* scales, int64_t* out0,
+                           int64_t* out1) {
+    if (!pq || !c || !lut0 || !out0 || (lut1 && !out1)) return fail("null argument");
+    if (c->code_size != pq->n_chunks) return fail("code size does not match the quantiser");
+    const uint8_t* desc = (scales && c->n_desc) ? c->desc : nullptr;
+    if (!pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc, (int)c->n_desc, scales))
+        return fail("the group-maximum scan serves 64 x 256 codecs (and 4 descriptor bytes) only");
+    if (c->n == 0) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    const size_t lut_bytes = pq->n_chunks * pq->n_centroids * 4, n_groups = (c->n + 63) / 64;
+    if (pq->a.ensure(2 * lut_bytes + 256) || pq->c.ensure(2 * n_groups * 8)) return -1;
+    float* l0 = pq->a.as<float>();
+    float* l1 = reinterpret_cast<float*>(pq->a.as<char>() + lut_bytes);
+    float* sc = reinterpret_cast<float*>(pq->a.as<char>() + 2 * lut_bytes);
+    MSE_HIP_TRY(hipMemcpy(l0, lut0, lut_bytes, hipMemcpyHostToDevice));
+    if (lut1) MSE_HIP_TRY(hipMemcpy(l1, lut1, lut_bytes, hipMemcpyHostToDevice));
+    if (desc) MSE_HIP_TRY(hipMemcpy(sc, scales, c->n_desc * 4, hipMemcpyHostToDevice));
+    int64_t* g0 = pq->c.as<int64_t>();
+    int64_t* g1 = g0 + n_groups;
+    const int rc = lut1 ? launch_pq_scan_gmax2(l0, l1, c->codes, c->n, desc, desc ? sc : nullptr, g0, g1, device_cu_count(), nullptr)
+                        : launch_pq_scan_gmax(l0, c->codes, c->n, desc, desc ? sc : nullptr, g0, device_cu_count(), nullptr);
+    if (rc) return -1;
+    MSE_HIP_TRY(hipMemcpy(out0, g0, n_groups * 8, hipMemcpyDeviceToHost));
+    if (lut1) MSE_HIP_TRY(hipMemcpy(out1, g1, n_groups * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,

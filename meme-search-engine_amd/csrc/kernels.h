@@ -84,6 +84,8 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
 bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, int n_desc, const float* scales);
 int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
                         int64_t* gmax, int n_cu, hipStream_t stream);
+int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* codes, size_t n, const uint8_t* desc,
+                         const float* scales, int64_t* gmax0, int64_t* gmax1, int n_cu, hipStream_t stream);
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,
                           const float* scales, int64_t* out, hipStream_t stream);
 int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stream);

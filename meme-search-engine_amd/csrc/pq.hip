@@ -347,6 +347,94 @@ __global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* 
     }
 }
 
+// Two queries per pass over the codes (round 3).  The scan above is bound by its LDS gathers: 64 random 4-byte reads per vector at
+// ~3.5-way bank conflicts cost as many LDS cycles as the codes cost HBM time, and those cycles buy ONE query.  Here the table holds
+// both queries' entries side by side -- s_lut2[chunk * 256 + code] = {q0, q1} (128 KiB) -- so the same 64 gathers per vector, now
+// ds_read_b64, and the same pass over the codes serve two queries: per query, half the LDS cycles and half the HBM bytes.  Each
+// query's sum is still 64 sequential f32 adds in chunk order (asymmetric_dot_product, vector.rs:387-405) and the descriptor bias is
+// added after the conversion, so both group maxima are bit-identical to pq_scan64_kernel<true>'s for that query.
+// LDS: 128 KiB table + 8 waves x 4 KiB of code staging = all 160 KiB; the 4 descriptor bytes of a vector come straight from
+// global memory (one coalesced dword per lane).
+constexpr int PQ2_WAVES = 8;
+constexpr int PQ2_LUT_BYTES = 64 * 256 * 8;
+constexpr int PQ2_LDS = PQ2_LUT_BYTES + PQ2_WAVES * 4096;
+
+__global__ __launch_bounds__(PQ2_WAVES * 64) void pq_scan64x2_kernel(const float* __restrict__ lut0, const float* __restrict__ lut1,
+                                                                    const uint8_t* __restrict__ codes, size_t n,
+                                                                    const uint8_t* __restrict__ desc /* [n][4] or null */,
+                                                                    const float* __restrict__ scales, int64_t* __restrict__ out0,
+                                                                    int64_t* __restrict__ out1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* s_lut2 = reinterpret_cast<float2*>(smem);
+    for (int e = threadIdx.x; e < 64 * 256; e += blockDim.x) s_lut2[e] = make_float2(lut0[e], lut1[e]);
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (desc)
+        for (int j = 0; j < 4; j++) sc[j] = scales[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* stage = smem + PQ2_LUT_BYTES + wave * 4096;
+    const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
+    uint32_t voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = 16 * j + (lane >> 2);
+        voff[j] = (uint32_t)(r * 64 + (((lane & 3) ^ ((r >> 3) & 3)) * 16));
+    }
+    const size_t ngroups = (n + 63) / 64;
+    const size_t stride = (size_t)gridDim.x * PQ2_WAVES;
+    size_t grp = (size_t)blockIdx.x * PQ2_WAVES + wave;
+    // VMEM operations per group, in issue order: 4 code DMAs, (the descriptor dword load), then -- after the sums -- 2 result stores
+    auto issue = [&](size_t gi) {
+        const uint8_t* base = codes + gi * 4096;   // the allocations carry slack for the last, partial group
+#pragma unroll
+        for (int j = 0; j < 4; j++) pq_dma16(base, voff[j], stage_lds + j * 1024);
+    };
+    auto load_desc = [&](size_t gi) -> uint32_t {
+        const size_t v = gi * 64 + lane;
+        return (desc && v < n) ? reinterpret_cast<const uint32_t*>(desc)[v] : 0u;
+    };
+    uint32_t dw_next = 0;
+    if (grp < ngroups) { issue(grp); dw_next = load_desc(grp); }
+    const int rsw = (lane >> 3) & 3;
+    for (; grp < ngroups; grp += stride) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // codes + descriptor dword of this group (the previous stores as well)
+        const uint32_t dw = dw_next;
+        uint4 w4[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) w4[p] = *reinterpret_cast<const uint4*>(stage + lane * 64 + ((p ^ rsw) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rows are in registers: the staging area may be refilled
+        if (grp + stride < ngroups) { issue(grp + stride); dw_next = load_desc(grp + stride); }
+        const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
+                                w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 16; a++)
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const float2 e = s_lut2[(a * 4 + bb) * 256 + ((w[a] >> (8 * bb)) & 0xff)];
+                s0 = add_rn(s0, e.x);
+                s1 = add_rn(s1, e.y);
+            }
+        const size_t v = grp * 64 + lane;
+        int64_t r0 = scale_dot_result(s0), r1 = scale_dot_result(s1);
+        if (desc) {
+            int64_t bias = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) bias += scale_dot_result(sc[j] * (float)((dw >> (8 * j)) & 0xffu));
+            r0 += bias; r1 += bias;
+        }
+        if (v >= n) { r0 = INT64_MIN; r1 = INT64_MIN; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int64_t o0 = __shfl_xor(r0, o), o1 = __shfl_xor(r1, o);
+            r0 = o0 > r0 ? o0 : r0;
+            r1 = o1 > r1 ? o1 : r1;
+        }
+        if (lane == 0) { out0[grp] = r0; out1[grp] = r1; }
+    }
+}
+
 // out[p] += descriptor_product(scales, ids[p])   (exact re-score path, query_disk_index.rs:169-170)
 __global__ void add_descriptor_kernel(const uint32_t* __restrict__ ids, size_t n, const uint8_t* __restrict__ desc,
                                       int n_desc, size_t n_codes, const float* __restrict__ scales,
@@ -464,6 +552,20 @@ int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const 
     const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, cus);
     hipLaunchKernelGGL(pq_scan64_kernel<true>, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
                        (desc && scales) ? desc : nullptr, scales, gmax);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the same for TWO queries in one pass over the codes (pq_scan64x2_kernel); scales are shared by the two queries (one request)
+int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* codes, size_t n, const uint8_t* desc,
+                         const float* scales, int64_t* gmax0, int64_t* gmax1, int n_cu, hipStream_t stream) {
+    if (n == 0) return 0;
+    MSE_DYN_LDS(pq_scan64x2_kernel, PQ2_LDS);
+    const size_t groups = (n + 63) / 64;
+    const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;   // a few CUs stay free for the previous pair's tail (see above)
+    const unsigned blocks = (unsigned)std::min<size_t>((groups + PQ2_WAVES - 1) / PQ2_WAVES, cus);
+    hipLaunchKernelGGL(pq_scan64x2_kernel, dim3(blocks), dim3(PQ2_WAVES * 64), PQ2_LDS, stream, lut0, lut1, codes, n,
+                       (desc && scales) ? desc : nullptr, scales, gmax0, gmax1);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

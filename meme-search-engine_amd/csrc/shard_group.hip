@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -56,13 +57,60 @@ int merge_packed(mse_searcher* s, const char* gathered, size_t n_shards, size_t 
                            0, 0, nullptr, nullptr, s->stream);
 }
 
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, mse_comm_id, int) = nullptr;   // ncclUniqueId is a 128-byte struct passed by value
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;     // one process, several devices
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy the process already holds (the torch wheel bundles one) is reused; otherwise ROCm's
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!r.lib) for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!r.lib) { r.why = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.why.empty()) r.why = std::string("librccl.so lacks ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+
+int rccl_ready() {
+    Rccl& r = rccl();
+    if (!r.why.empty()) return fail(r.why);
+    return 0;
+}
+int rccl_fail(const char* what, int code) {
+    Rccl& r = rccl();
+    return fail(std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+}
+
 struct Shard {
     int device = 0;
     size_t first_row = 0;       // global id of local row 0
     mse_base* base = nullptr;
     mse_searcher* searcher = nullptr;
-    DevBuf q_local, block;      // on this shard's device (used when it cannot reach the root's memory directly)
+    DevBuf q_local, block;      // on this shard's device (used when it cannot reach the root's memory directly, and by RCCL)
+    DevBuf gathered;            // RCCL exchange: every shard's block, on this shard's device
+    void* comm = nullptr;       // RCCL exchange: this shard's communicator (rank = shard index)
     bool peer = false;          // may read/write root-device memory from kernels
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // step breakdown: start, local search done, exchange done
+    float local_ms = 0.f, exch_ms = 0.f;
     std::string err;
     int rc = 0;
 };
@@ -84,6 +132,10 @@ struct mse_shard_group {
     size_t pending = 0;
     bool stop = false;
     std::mutex call_mu;                 // one search at a time per group (a second group = a second set of scratch)
+    int exchange = 0;                   // MSE_EXCHANGE_PEER (0): peer stores / staged copies; MSE_EXCHANGE_RCCL (1): ncclAllGather
+    int rccl_ranks = 0;                 // as ncclCommCount reports them
+    hipEvent_t ev_merge[2] = {nullptr, nullptr};
+    double last_ms[4] = {0, 0, 0, 0};   // last search: max local search, max exchange, merge, wall
 
     void worker(size_t g) {
         (void)hipSetDevice(shards[g].device);
@@ -197,7 +249,9 @@ void mse_shard_group_free(mse_shard_group* G) {
             if (sh.searcher) mse_searcher_free(sh.searcher);
             if (sh.base) mse_base_free(sh.base);
             sh.searcher = nullptr; sh.base = nullptr;
-            sh.q_local.release(); sh.block.release();
+            sh.q_local.release(); sh.block.release(); sh.gathered.release();
+            if (sh.comm) { (void)rccl().CommDestroy(sh.comm); sh.comm = nullptr; }
+            for (hipEvent_t& e : sh.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             return 0;
         });
         {
@@ -207,6 +261,7 @@ void mse_shard_group_free(mse_shard_group* G) {
         G->cv_job.notify_all();
         for (auto& t : G->threads) t.join();
     }
+    for (hipEvent_t& e : G->ev_merge) if (e) (void)hipEventDestroy(e);
     if (G->root) mse_searcher_free(G->root);
     delete G;
 }
@@ -276,35 +331,116 @@ int mse_shard_group_set_shard_device(mse_shard_group* G, size_t shard, const voi
 static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t nq, size_t k, int mode, void* scores_dev,
                              void* ids_dev) {
     for (const Shard& s : G->shards) if (!s.searcher) return fail("shard group: a shard holds no rows yet");
+    const auto wall0 = std::chrono::steady_clock::now();
     const size_t n_shards = G->shards.size();
     const size_t B = block_bytes(nq, k), qbytes = nq * G->d * 2;
+    const bool use_rccl = G->exchange == MSE_EXCHANGE_RCCL;
     int prev = 0;
     (void)hipGetDevice(&prev);
     MSE_HIP_TRY(hipSetDevice(G->root_device));
-    int rc = G->gathered.ensure(B * n_shards);
+    int rc = use_rccl ? 0 : G->gathered.ensure(B * n_shards);
+    const char* merged_from = nullptr;
     if (!rc) {
         char* const gathered = G->gathered.as<char>();
         rc = G->run([=](size_t g) -> int {
             Shard& sh = G->shards[g];
             hipStream_t st = sh.searcher->stream;
+            for (hipEvent_t& e : sh.ev) if (!e) MSE_HIP_TRY(hipEventCreate(&e));
+            MSE_HIP_TRY(hipEventRecord(sh.ev[0], st));
             const void* q = queries_dev;
-            char* blk = gathered + g * B;
-            if (!sh.peer) {   // no mapping of the root's memory: stage the queries here, copy the block back
-                if (sh.q_local.ensure(qbytes) || sh.block.ensure(B)) return -1;
-                MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
-                q = sh.q_local.p;
-                blk = sh.block.as<char>();
+            const bool on_root = sh.device == G->root_device;
+            if (use_rccl) {
+                // every shard on its own device: queries come over by one peer copy (a device cannot be assumed to map the root's
+                // memory here), the block stays local; the all-gather is issued in a second round, once EVERY shard has its
+                // block (a rank that failed before its collective would leave the others waiting in theirs for ever)
+                if (sh.block.ensure(B) || sh.gathered.ensure(B * n_shards)) return -1;
+                if (!on_root) {
+                    if (sh.q_local.ensure(qbytes)) return -1;
+                    MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
+                    q = sh.q_local.p;
+                }
+                char* blk = sh.block.as<char>();
+                if (mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8)) return -1;
+                MSE_HIP_TRY(hipEventRecord(sh.ev[1], st));
+                return 0;
+            } else {
+                char* blk = gathered + g * B;
+                if (!sh.peer) {   // no mapping of the root's memory: stage the queries here, copy the block back
+                    if (sh.q_local.ensure(qbytes) || sh.block.ensure(B)) return -1;
+                    MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
+                    q = sh.q_local.p;
+                    blk = sh.block.as<char>();
+                }
+                if (mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8)) return -1;
+                MSE_HIP_TRY(hipEventRecord(sh.ev[1], st));
+                if (!sh.peer) MSE_HIP_TRY(hipMemcpyPeerAsync(gathered + g * B, G->root_device, blk, sh.device, B, st));
             }
-            if (mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8)) return -1;
-            if (!sh.peer) MSE_HIP_TRY(hipMemcpyPeerAsync(gathered + g * B, G->root_device, blk, sh.device, B, st));
+            MSE_HIP_TRY(hipEventRecord(sh.ev[2], st));
             MSE_HIP_TRY(hipStreamSynchronize(st));
+            (void)hipEventElapsedTime(&sh.local_ms, sh.ev[0], sh.ev[1]);
+            (void)hipEventElapsedTime(&sh.exch_ms, sh.ev[1], sh.ev[2]);
             return 0;
         });
-        if (!rc) rc = merge_packed(G->root, gathered, n_shards, nq, k, scores_dev, ids_dev);
-        if (!rc && hipStreamSynchronize(G->root->stream) != hipSuccess) rc = fail("shard group: merge failed");
+        if (!rc && use_rccl)   // ONE ncclAllGather of the packed records per search: rank g = shard g, on its own thread and stream
+            rc = G->run([=](size_t g) -> int {
+                Shard& sh = G->shards[g];
+                hipStream_t st = sh.searcher->stream;
+                const int nrc = rccl().AllGather(sh.block.p, sh.gathered.p, B, /*ncclInt8*/ 0, sh.comm, st);
+                if (nrc) return rccl_fail("ncclAllGather", nrc);
+                MSE_HIP_TRY(hipEventRecord(sh.ev[2], st));
+                MSE_HIP_TRY(hipStreamSynchronize(st));
+                (void)hipEventElapsedTime(&sh.local_ms, sh.ev[0], sh.ev[1]);
+                (void)hipEventElapsedTime(&sh.exch_ms, sh.ev[1], sh.ev[2]);
+                return 0;
+            });
+        merged_from = use_rccl ? G->shards[0].gathered.as<char>() : gathered;   // shard 0 lives on the root device
+        hipStream_t rs = G->root->stream;
+        if (!rc) for (hipEvent_t& e : G->ev_merge) if (!e && hipEventCreate(&e) != hipSuccess) rc = fail("shard group: event");
+        if (!rc && hipEventRecord(G->ev_merge[0], rs) != hipSuccess) rc = fail("shard group: event");
+        if (!rc) rc = merge_packed(G->root, merged_from, n_shards, nq, k, scores_dev, ids_dev);
+        if (!rc && hipEventRecord(G->ev_merge[1], rs) != hipSuccess) rc = fail("shard group: event");
+        if (!rc && hipStreamSynchronize(rs) != hipSuccess) rc = fail("shard group: merge failed");
+        if (!rc) {
+            float mm = 0.f;
+            (void)hipEventElapsedTime(&mm, G->ev_merge[0], G->ev_merge[1]);
+            double lmax = 0, emax = 0;
+            for (const Shard& sh : G->shards) { lmax = std::max(lmax, (double)sh.local_ms); emax = std::max(emax, (double)sh.exch_ms); }
+            G->last_ms[0] = lmax; G->last_ms[1] = emax; G->last_ms[2] = mm;
+            G->last_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        }
     }
     (void)hipSetDevice(prev);
     return rc;
+}
+
+// RCCL for the in-process shape: one communicator per shard device, made by ONE ncclCommInitAll from the calling thread;
+// afterwards each shard's own host thread issues its rank's ncclAllGather on its searcher's stream (the multi-thread,
+// one-device-per-thread usage RCCL documents; no group call is needed because no thread drives two devices).
+static int bring_up_rccl(mse_shard_group* G) {
+    const size_t n = G->shards.size();
+    for (size_t a = 0; a < n; a++)
+        for (size_t b = a + 1; b < n; b++)
+            if (G->shards[a].device == G->shards[b].device)
+                return fail("RCCL exchange needs every shard on its own device (shards " + std::to_string(a) + " and " + std::to_string(b) +
+                            " share device " + std::to_string(G->shards[a].device) + "): logical shards keep the peer-store exchange");
+    if (rccl_ready()) return -1;
+    if (!rccl().CommInitAll) return fail("librccl.so lacks ncclCommInitAll");
+    std::vector<void*> comms(n, nullptr);
+    std::vector<int> devs(n);
+    for (size_t g = 0; g < n; g++) devs[g] = G->shards[g].device;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    const int rc = rccl().CommInitAll(comms.data(), (int)n, devs.data());
+    (void)hipSetDevice(prev);
+    if (rc) return rccl_fail("ncclCommInitAll", rc);
+    int count = 0;
+    if (rccl().CommCount(comms[0], &count) || count != (int)n) {
+        for (void* c : comms) if (c) (void)rccl().CommDestroy(c);
+        return fail("RCCL reports " + std::to_string(count) + " ranks for " + std::to_string(n) + " shards");
+    }
+    for (size_t g = 0; g < n; g++) G->shards[g].comm = comms[g];
+    G->rccl_ranks = count;
+    return 0;
 }
 
 extern "C" {
@@ -343,58 +479,32 @@ int mse_shard_group_search(mse_shard_group* G, const uint16_t* queries, size_t n
     return rc;
 }
 
-}  // extern "C"
-
-// ---- one process per GPU: RCCL -------------------------------------------------------------------------------------------
-namespace {
-
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, mse_comm_id, int) = nullptr;   // ncclUniqueId is a 128-byte struct passed by value
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*CommCount)(void*, int*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    std::string why;
-};
-
-Rccl& rccl() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        // a copy the process already holds (the torch wheel bundles one) is reused; otherwise ROCm's
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-        if (!r.lib) for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!r.lib) { r.why = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return; }
-        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.why.empty()) r.why = std::string("librccl.so lacks ") + n; return p; };
-        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    });
-    return r;
-}
-
-int rccl_ready() {
-    Rccl& r = rccl();
-    if (!r.why.empty()) return fail(r.why);
+int mse_shard_group_set_exchange(mse_shard_group* G, int kind) {
+    if (!G) return fail("null shard group");
+    if (kind != MSE_EXCHANGE_PEER && kind != MSE_EXCHANGE_RCCL) return fail("unknown exchange kind");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    if (kind == MSE_EXCHANGE_RCCL && !G->shards[0].comm && bring_up_rccl(G)) return -1;   // the previous exchange stays
+    G->exchange = kind;
     return 0;
 }
-int rccl_fail(const char* what, int code) {
-    Rccl& r = rccl();
-    return fail(std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(code) : "RCCL error") + " (" + std::to_string(code) + ")");
+int mse_shard_group_exchange(const mse_shard_group* G) { return G ? G->exchange : -1; }
+int mse_shard_group_rccl_ranks(const mse_shard_group* G) { return G ? G->rccl_ranks : 0; }
+int mse_shard_group_last_timing(mse_shard_group* G, double out_ms[4]) {
+    if (!G || !out_ms) return fail("null shard group / output");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    for (int i = 0; i < 4; i++) out_ms[i] = G->last_ms[i];
+    return 0;
 }
 
-}  // namespace
+}  // extern "C"
 
 struct mse_comm {
     void* comm = nullptr;
     int rank = 0, world = 1;
     DevBuf local, gathered;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, local search done, all-gather done, merge done
+    hipStream_t ev_stream = nullptr;
+    bool timed = false;
 };
 
 extern "C" {
@@ -420,6 +530,7 @@ mse_comm* mse_comm_init(const mse_comm_id* id, int rank, int world) {
 void mse_comm_free(mse_comm* c) {
     if (!c) return;
     if (c->comm) (void)rccl().CommDestroy(c->comm);
+    for (hipEvent_t& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -441,10 +552,32 @@ int mse_comm_search_dev(mse_comm* c, mse_searcher* s, const void* queries_dev, s
     const size_t B = block_bytes(nq, k);
     if (c->local.ensure(B) || c->gathered.ensure(B * (size_t)c->world)) return -1;
     char* blk = c->local.as<char>();
+    for (hipEvent_t& e : c->ev) if (!e) MSE_HIP_TRY(hipEventCreate(&e));
+    c->timed = false;
+    MSE_HIP_TRY(hipEventRecord(c->ev[0], s->stream));
     if (mse_bruteforce_topk_f16_dev(s, queries_dev, nq, k, mode, id_offset, blk, blk + nq * k * 8)) return -1;
+    MSE_HIP_TRY(hipEventRecord(c->ev[1], s->stream));
     const int rc = rccl().AllGather(blk, c->gathered.p, B, /*ncclInt8*/ 0, c->comm, s->stream);
     if (rc) return rccl_fail("ncclAllGather", rc);
-    return merge_packed(s, c->gathered.as<char>(), (size_t)c->world, nq, k, scores_dev, ids_dev);
+    MSE_HIP_TRY(hipEventRecord(c->ev[2], s->stream));
+    if (merge_packed(s, c->gathered.as<char>(), (size_t)c->world, nq, k, scores_dev, ids_dev)) return -1;
+    MSE_HIP_TRY(hipEventRecord(c->ev[3], s->stream));
+    c->timed = true;
+    return 0;
+}
+
+// breakdown of the last mse_comm_search_dev on this rank, ms: [0] local search, [1] all-gather (includes waiting for the slowest
+// rank), [2] merge, [3] the three together.  Waits for that search to finish.
+int mse_comm_last_timing(mse_comm* c, double out_ms[4]) {
+    if (!c || !out_ms) return fail("null communicator / output");
+    if (!c->timed) return fail("no search has been issued on this communicator");
+    MSE_HIP_TRY(hipEventSynchronize(c->ev[3]));
+    float a = 0, b = 0, m = 0;
+    MSE_HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    MSE_HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    MSE_HIP_TRY(hipEventElapsedTime(&m, c->ev[2], c->ev[3]));
+    out_ms[0] = a; out_ms[1] = b; out_ms[2] = m; out_ms[3] = (double)a + b + m;
+    return 0;
 }
 
 }  // extern "C"

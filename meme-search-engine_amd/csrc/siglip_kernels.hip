@@ -311,7 +311,7 @@ constexpr int B2 = 256, BK2 = 32;
 [[maybe_unused]] constexpr int GS2 = 4;
 constexpr int T2_BYTES = B2 * BK2 * 2;        // 16 KiB per operand tile
 [[maybe_unused]] constexpr int STAGE2_BYTES = 2 * T2_BYTES;    // 32 KiB
-constexpr int LDS256_BYTES = 8 * 64 * 272;   // max(4 stages = 128 KiB, epilogue staging = 136 KiB)
+[[maybe_unused]] constexpr int LDS256_BYTES = 8 * 64 * 272;   // max(4 stages = 128 KiB, epilogue staging = 136 KiB)
 
 __device__ __forceinline__ int swz64(int row) { return (0x1230 >> (4 * ((row >> 2) & 3))) & 3; }  // T = {0,3,2,1}
 

@@ -72,6 +72,10 @@ SIGNATURES = {
     "mse_shard_group_load_host": (C.c_int, [vp, u16p, sz]),
     "mse_shard_group_set_shard_device": (C.c_int, [vp, sz, vp, sz, C.c_uint64]),
     "mse_shard_group_search": (C.c_int, [vp, u16p, sz, sz, C.c_int, i64p, u32p]),
+    "mse_shard_group_set_exchange": (C.c_int, [vp, C.c_int]),
+    "mse_shard_group_exchange": (C.c_int, [vp]),
+    "mse_shard_group_rccl_ranks": (C.c_int, [vp]),
+    "mse_shard_group_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "mse_shard_group_search_dev": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, vp]),
     "mse_comm_unique_id": (C.c_int, [vp]),
     "mse_comm_init": (vp, [vp, C.c_int, C.c_int]),
@@ -79,6 +83,7 @@ SIGNATURES = {
     "mse_comm_rank": (C.c_int, [vp]),
     "mse_comm_size": (C.c_int, [vp]),
     "mse_comm_search_dev": (C.c_int, [vp, vp, vp, sz, sz, C.c_int, C.c_uint64, vp, vp]),
+    "mse_comm_last_timing": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "mse_debug_mfma_group_max": (C.c_int, [vp, u16p, sz, f32p]),
     "mse_searcher_scan_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mse_searcher_last_stats": (C.c_int, [vp, u32p, u32p]),
@@ -99,6 +104,7 @@ SIGNATURES = {
     "mse_pq_adc_gather": (C.c_int, [vp, vp, f32p, f32p, u32p, sz, i64p]),
     "mse_pq_scan_topk": (C.c_int, [vp, vp, vp, f32p, f32p, sz, sz, i64p, u32p]),
     "mse_pq_scan_topk_batch": (C.c_int, [vp, vp, vp, f32p, sz, f32p, sz, sz, i64p, u32p]),
+    "mse_debug_pq_group_max": (C.c_int, [vp, vp, f32p, f32p, f32p, i64p, i64p]),
     "mse_descriptor_product": (C.c_int64, [f32p, sz, u8p, C.c_uint32]),
     "mse_nb_new": (vp, [sz]),
     "mse_nb_free": (None, [vp]),

@@ -86,6 +86,28 @@ class ShardGroup:
     def bruteforce_topk_dev(self, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO):
         check(ffi.lib().mse_shard_group_search_dev(self._h, queries_dev, nq, k, mode, scores_dev, ids_dev), "mse_shard_group_search_dev")
 
+    EXCHANGE_PEER, EXCHANGE_RCCL = 0, 1
+
+    def set_exchange(self, kind):
+        """How the per-shard records meet: EXCHANGE_PEER (peer stores / staged copies, default) or EXCHANGE_RCCL (one
+        ncclAllGather per search; every shard on its own device).  Raises MseError -- and keeps the previous exchange -- when
+        RCCL cannot be brought up."""
+        check(ffi.lib().mse_shard_group_set_exchange(self._h, int(kind)), "mse_shard_group_set_exchange")
+
+    @property
+    def exchange(self):
+        return int(ffi.lib().mse_shard_group_exchange(self._h))
+
+    @property
+    def rccl_ranks(self):
+        return int(ffi.lib().mse_shard_group_rccl_ranks(self._h))
+
+    def last_timing(self):
+        """Breakdown of the last search in ms: local search of the slowest shard, its exchange leg, the merge, wall clock."""
+        out = (C.c_double * 4)()
+        check(ffi.lib().mse_shard_group_last_timing(self._h, out), "mse_shard_group_last_timing")
+        return {"local_search_ms": out[0], "exchange_ms": out[1], "merge_ms": out[2], "wall_ms": out[3]}
+
     def close(self):
         if self._h:
             ffi.lib().mse_shard_group_free(self._h)
@@ -126,6 +148,12 @@ class Comm:
     def search_dev(self, searcher, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO, id_offset=0):
         check(ffi.lib().mse_comm_search_dev(self._h, searcher._h, queries_dev, nq, k, mode, id_offset, scores_dev, ids_dev),
               "mse_comm_search_dev")
+
+    def last_timing(self):
+        """This rank's last search_dev in ms (waits for it): local search, all-gather (incl. waiting for the slowest rank), merge."""
+        out = (C.c_double * 4)()
+        check(ffi.lib().mse_comm_last_timing(self._h, out), "mse_comm_last_timing")
+        return {"local_search_ms": out[0], "exchange_ms": out[1], "merge_ms": out[2], "sum_ms": out[3]}
 
     def close(self):
         if self._h:

@@ -276,6 +276,20 @@ class ProductQuantizer:
                                                _p(scores, C.c_int64), _p(ids, C.c_uint32)), "pq_scan_topk_batch")
         return scores, ids
 
+    def debug_group_max(self, codes, lut0, lut1=None, scales=None):
+        """Test hook: the flat scan's group maxima (one i64 per 64 vectors) for one table, or for a pair through the
+        two-queries-per-pass kernel."""
+        ng = (len(codes) + 63) // 64
+        l0 = np.ascontiguousarray(lut0, np.float32)
+        l1 = None if lut1 is None else np.ascontiguousarray(lut1, np.float32)
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32)
+        o0 = np.empty(ng, np.int64)
+        o1 = np.empty(ng, np.int64) if l1 is not None else None
+        check(ffi.lib().mse_debug_pq_group_max(self._h, codes._h, _p(l0, C.c_float), _p(l1, C.c_float) if l1 is not None else None,
+                                               _p(sc, C.c_float) if sc is not None else None, _p(o0, C.c_int64),
+                                               _p(o1, C.c_int64) if o1 is not None else None), "debug_pq_group_max")
+        return (o0, o1) if l1 is not None else o0
+
     def close(self):
         if self._h:
             ffi.lib().mse_pq_free(self._h)

@@ -179,6 +179,76 @@ def test_pq_scan_group_maxima_ragged_ties_and_batch(gpu, mse, orc, n, r, k):
         assert np.array_equal(i2[j, :m], wi[:m]) and np.array_equal(s2[j, :m], ws[:m])
 
 
+@pytest.mark.parametrize("n", [64 * 300, 64 * 97 + 13])
+def test_group_maxima_equal_the_gathered_scores(gpu, mse, orc, n):
+    """The select after the flat scan uses the r-th best GROUP MAXIMUM as a floor for the re-scored vectors, so the scan kernels
+    (one query per pass, two queries per pass) and the gather kernel must produce the SAME i64 for a vector -- descriptor bias and
+    contraction behaviour included.  Random tables (not from a codec: wide magnitudes, both signs), random codes and descriptors:
+    every group maximum equals the maximum of the gathered scores of its 64 vectors, and both equal the oracle's."""
+    rng = np.random.default_rng(n)
+    cents, T, _, _ = make_pq(orc)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    gcodes = mse.Codes(codes, desc)
+    luts = [(rng.standard_normal(64 * 256) * 10.0 ** rng.uniform(-4, 1, size=64 * 256)).astype(np.float32) for _ in range(2)]
+    ids = np.arange(n, dtype=np.uint32)
+    ng = (n + 63) // 64
+    for scales in (None, np.array([0.5, -0.25, 3.0, 1e-3], np.float32) / np.float32(512)):
+        want = []
+        for lut in luts:
+            g = gpq.adc_gather(gcodes, lut, ids, scales)                        # pq_adc_kernel, one vector per lane
+            o = opq.adc_desc(lut, codes, desc, scales) if scales is not None else opq.asymmetric_dot_product(lut, codes)
+            assert np.array_equal(g, o)
+            pad = np.full(ng * 64, np.iinfo(np.int64).min, np.int64)
+            pad[:n] = g
+            want.append(pad.reshape(ng, 64).max(axis=1))
+        one = [gpq.debug_group_max(gcodes, lut, None, scales) for lut in luts]
+        two = gpq.debug_group_max(gcodes, luts[0], luts[1], scales)
+        for j in range(2):
+            assert np.array_equal(one[j], want[j]) and np.array_equal(two[j], want[j]), (j, scales is None)
+
+
+def test_pq_scan_full_size_1e8(gpu, mse, orc):
+    """BASELINE.md's configs[4] size: 1e8 x 64-byte codes (+ 4 descriptor bytes), 6.8 GB in HBM.  The oracle cannot scan that in a
+    test, so size-independent properties: planted best-possible vectors (the per-chunk argmax codes of a query) come back first,
+    ties by lower id; every returned score is re-derived by the oracle from the returned id's code row; results are sorted; the
+    k-th score bounds 2e5 sampled outsiders; pairs of queries sharing one pass equal the one-query-per-call answers."""
+    n, r, k = 100_000_000, 200, 10
+    rng = np.random.default_rng(77)
+    cents, T, _, _ = make_pq(orc)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    block = rng.integers(0, 256, size=(1_000_000, 64), dtype=np.uint8)
+    masks = rng.integers(0, 256, size=(100, 64), dtype=np.uint8)
+    codes = np.empty((n, 64), np.uint8)
+    for c in range(100):                                   # 100 distinct pseudo-random copies of one block: seconds, not minutes
+        np.bitwise_xor(block, masks[c], out=codes[c * 1_000_000:(c + 1) * 1_000_000])
+    desc = np.tile(rng.integers(0, 256, size=(1_000_000, 4), dtype=np.uint8), (100, 1))
+    scales = np.array([0.5, 0, -0.25, 0], np.float32) / np.float32(512)
+    qs = (rng.standard_normal((5, D)) / np.sqrt(D)).astype(np.float32)
+    luts = [opq.preprocess_query(q) for q in qs]
+    planted = [99_999_999, 64, 63, 50_000_001]            # group seams, the last vector, the middle
+    best = np.argmax(luts[0].reshape(64, 256), axis=1).astype(np.uint8)
+    for p in planted:
+        codes[p] = best
+        desc[p] = (255, 0, 0, 0)                          # the largest bias the scales allow
+    gcodes = mse.Codes(codes, desc)
+    bs, bi = gpq.scan_topk_batch(gcodes, qs, r, k, None, scales)
+    assert sorted(bi[0, :4].tolist()) == sorted(planted) and bi[0, :4].tolist() == sorted(planted)   # equal scores: lower id first
+    assert len(set(bs[0, :4].tolist())) == 1
+    for j in range(5):
+        rows = bi[j].astype(np.int64)
+        assert np.all(rows < n) and len(set(rows.tolist())) == k
+        assert np.array_equal(bs[j], opq.adc_desc(luts[j], codes[rows], desc[rows], scales))     # the oracle's score of that row
+        assert np.all(bs[j, :-1] >= bs[j, 1:])
+        s1, i1 = gpq.scan_topk(gcodes, qs[j], r, k, None, scales)                                 # one query per pass
+        assert np.array_equal(s1, bs[j]) and np.array_equal(i1, bi[j])
+    sample = rng.integers(0, n, 200_000)
+    for j in (1, 4):
+        sc = opq.adc_desc(luts[j], codes[sample], desc[sample], scales)
+        assert np.all(sc[~np.isin(sample, bi[j])] <= bs[j, -1])
+
+
 @pytest.mark.parametrize("n,d", [(0, 128), (1, 128), (777, 128), (3000, 1152), (20000, 256)])
 def test_flat_index_matches_oracle(gpu, mse, orc, n, d):
     rng = np.random.default_rng(4)

@@ -62,6 +62,46 @@ def test_shard_group_without_peer_mappings(gpu, mse, orc, monkeypatch):
     grp.close()
 
 
+def test_shard_group_rccl_exchange(gpu, mse, orc):
+    """north_star's exchange inside ONE process: a communicator per shard device (ncclCommInitAll), one ncclAllGather of the packed
+    records per search, each rank's collective issued by its shard's own host thread.  With one device visible the group of one
+    shard is a world of one (the collective really runs); with several devices every device carries a shard.  Shards that share
+    a device cannot form RCCL ranks: set_exchange fails cleanly and the group keeps answering over the peer-store exchange."""
+    n_dev = gpu
+    G = n_dev if n_dev > 1 else 1
+    n, nq, k = 40_000 + 17, 130, 10
+    rows = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    ws, wi = orc.bruteforce_topk(rows, q, k)
+    grp = mse.ShardGroup(G, D, devices=list(range(G)))
+    grp.load_host(rows)
+    assert grp.exchange == grp.EXCHANGE_PEER and grp.rccl_ranks == 0
+    s0, i0 = grp.bruteforce_topk(q, k, mse.MODE_MFMA)
+    grp.set_exchange(grp.EXCHANGE_RCCL)
+    assert grp.exchange == grp.EXCHANGE_RCCL and grp.rccl_ranks == G        # counted by RCCL, not by the caller
+    for mode in (mse.MODE_MFMA, mse.MODE_EXACT):
+        m = nq if mode == mse.MODE_MFMA else 8
+        s1, i1 = grp.bruteforce_topk(q[:m], k, mode)
+        assert np.array_equal(i1, wi[:m]) and np.array_equal(s1, ws[:m])
+    assert np.array_equal(s0, ws) and np.array_equal(i0, wi)
+    t = grp.last_timing()
+    assert t["wall_ms"] > 0 and t["local_search_ms"] > 0 and t["exchange_ms"] >= 0 and t["merge_ms"] > 0
+    assert t["local_search_ms"] + t["merge_ms"] <= t["wall_ms"] * 1.05
+    grp.set_exchange(grp.EXCHANGE_PEER)                                      # and back
+    s2, i2 = grp.bruteforce_topk(q, k, mse.MODE_MFMA)
+    assert np.array_equal(s2, ws) and np.array_equal(i2, wi)
+    grp.close()
+    # logical shards (two on one device) cannot be RCCL ranks: a labelled failure, never a crash, and the group still works
+    two = mse.ShardGroup(2, D, devices=[0, 0])
+    two.load_host(rows)
+    with pytest.raises(mse.MseError, match="own device"):
+        two.set_exchange(two.EXCHANGE_RCCL)
+    assert two.exchange == two.EXCHANGE_PEER and two.rccl_ranks == 0
+    s3, i3 = two.bruteforce_topk(q, k, mse.MODE_MFMA)
+    assert np.array_equal(s3, ws) and np.array_equal(i3, wi)
+    two.close()
+
+
 def test_shard_group_errors(gpu, mse):
     with pytest.raises(mse.MseError):
         mse.ShardGroup(2, D, devices=[0, 99])
