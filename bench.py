@@ -397,6 +397,12 @@ def siglip_bench(args, world, rank, dist=None):
         t = torch.tensor([dt], dtype=torch.float64)       # the control-plane group is gloo (CPU tensors)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    server = None
+    if rank == 0 and world == 1:
+        try:
+            server = server_bench(eng, cfg, batch)
+        except Exception as e:  # noqa: BLE001
+            server = {"error": repr(e)}
     eng.close()
     # text tower (clip_server.py:98): batch of 256 token rows, random-init weights; small next to the image tower
     import numpy as np
@@ -420,11 +426,71 @@ def siglip_bench(args, world, rank, dist=None):
             "config": {"workload": f"SigLIP-SO400M/14-384 image tower, batch {batch} random 384x384, 1 replica per GPU",
                        "weights": "random-init (seeded), architecture of ViT-SO400M-14-SigLIP-384"},
             "steps": args.siglip_steps, "scaling": "weak (replicas)", "text_tower": text,
+            "server_images_per_s": (server or {}).get("value"), "server": server,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
                          "flop_per_image": gflop_img * 1e9, "traffic": None,
                          "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.79 of 2.4 GHz "
                                  "(profiles/r02_power_clocks.txt); the library GEMM alone runs these shapes at 0.38-0.50 of the same peak "
                                  "(profiles/r02_gemm_calibration.txt)"}}
+
+
+def server_bench(eng, cfg, engine_batch):
+    """The serving path the device-side BMP decode exists for (clip_server.py:131-170, src/common.rs:31-54): requests of 128
+    Rust-style 384 x 384 24-bit BMPs (56.6 MB of msgpack, under the reference's 64 MiB body limit; 256 BMPs would be 113 MB and the
+    reference would answer 413) POSTed to the aiohttp app of mse.clip_server.ClipServer over loopback, four in flight; the answer is
+    the msgpack array of 2304-byte fp16 rows.  End to end: HTTP + msgpack decode, header checks, H2D of the raw files, device
+    BGR->RGB / flip / normalise, the tower, fp16 rows, msgpack encode.  Beside it: what the reference's preprocessing thread does
+    with the same files on one host thread (PIL decode + ToTensor/Normalize/.half()), the stage the device decode removes."""
+    import asyncio
+    import msgpack
+    import numpy as np
+    from aiohttp.test_utils import TestClient, TestServer
+    from mse.clip_server import ClipServer, preprocess_image
+    w = h = cfg["img_size"]
+    per_req, n_req, in_flight = 128, 10, 4
+    rng = np.random.default_rng(11)
+    hdr = (b"BM" + (54 + w * h * 3).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") +
+           w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(24))
+    images = [hdr + rng.integers(0, 256, size=w * h * 3, dtype=np.uint8).tobytes() for _ in range(per_req)]
+    body = msgpack.dumps({"images": images})
+    t0 = time.perf_counter()
+    for im in images[:16]:
+        preprocess_image(im, (w, h))
+    host_decode = 16 / (time.perf_counter() - t0)
+    eng.image_size = (w, h)
+    srv = ClipServer({"device": "cuda:0", "model": "ViT-SO400M-14-SigLIP-384", "model_name": "siglip-so400m-14-384",
+                      "max_batch_size": per_req, "port": 0}, eng)
+    srv.start_threads()
+
+    async def go():
+        client = TestClient(TestServer(srv.make_app()))
+        await client.start_server()
+        try:
+            async def one():
+                r = await client.post("/", data=body)
+                rows = msgpack.loads(await r.read())
+                assert r.status == 200 and len(rows) == per_req and len(rows[0]) == 2 * cfg["emb_dim"], (r.status, rows if r.status != 200 else "")
+            await one()                                   # warm-up
+            sem = asyncio.Semaphore(in_flight)
+
+            async def limited():
+                async with sem:
+                    await one()
+            t1 = time.perf_counter()
+            await asyncio.gather(*[limited() for _ in range(n_req)])
+            return time.perf_counter() - t1
+        finally:
+            await client.close()
+
+    dt = asyncio.run(go())
+    srv.stop_threads()
+    return {"metric": "clip_server images/s end to end (HTTP + msgpack + device BMP decode + tower + fp16 rows)",
+            "value": per_req * n_req / dt, "unit": "images/s", "images_per_request": per_req, "requests": n_req, "in_flight": in_flight,
+            "request_bytes": len(body), "engine_batch_capacity": engine_batch,
+            "host_preprocess_images_per_s_one_thread": host_decode,
+            "note": "the model thread runs the BMP jobs waiting in its queue as one engine call (up to the engine's batch capacity); "
+                    "host_preprocess = PIL decode + normalise + fp16 of the same files on one thread, the reference's preprocessing_thread "
+                    "(clip_server.py:131-146), which the device decode replaces"}
 
 
 def main():
@@ -446,7 +512,7 @@ def main():
     ap.add_argument("--no-graph-scale", action="store_true", help="skip the 1e7-row graph-index leg (a ~1 minute build)")
     ap.add_argument("--graph-scale-rows", type=float, default=1e7)
     ap.add_argument("--siglip-batch", type=int, default=256)
-    ap.add_argument("--siglip-steps", type=int, default=3)
+    ap.add_argument("--siglip-steps", type=int, default=10)
     args = ap.parse_args()
 
     import numpy as np

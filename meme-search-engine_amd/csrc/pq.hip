@@ -274,12 +274,48 @@ __device__ __forceinline__ void pq_dma4(const void* sbase, uint32_t voff, uint32
 // the maximum of its 64 scores: out[group] (0.125 B per vector).  The r best vectors lie inside the r best groups by
 // (maximum desc, group asc) -- a group ranked ahead of v's group holds a vector that precedes v, by score or, on a tie,
 // by its lower id -- so the caller re-scores those r x 64 vectors (pq_adc_kernel, same arithmetic) and selects among them.
+// LDS byte offset of table entry `code` (ENTRY_SHIFT = log2 of the entry size) for byte BB of the code word w: (byte BB of w) << shift
+// in ONE instruction (SDWA byte select); hipcc emits v_bfe_u32 + v_lshl_add_u32, and the scan kernels are VALU-bound next to their
+// LDS gathers (profiles/r03_pmc_pq_scan.txt).
+template <int BB> __device__ __forceinline__ uint32_t code_offset(uint32_t w, uint32_t shift) {
+    uint32_t r;
+    if constexpr (BB == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(shift), "v"(w));
+    else if constexpr (BB == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(shift), "v"(w));
+    else if constexpr (BB == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(shift), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(shift), "v"(w));
+    return r;
+}
+// an LDS location by its byte address (no symbol: hipcc adds the -- zero -- address of the dynamic LDS array with a v_add per gather)
+template <typename T> __device__ __forceinline__ const __attribute__((address_space(3))) T* lds_at(uint32_t addr) {
+    return reinterpret_cast<const __attribute__((address_space(3))) T*>((uintptr_t)addr);
+}
+// the scan kernels address their table from LDS address 0: they declare no static LDS, so the dynamic array starts there; anything else
+// must stop the kernel, not return wrong maxima
+__device__ __forceinline__ void require_lds_base_zero(const void* smem_base) {
+    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem_base != 0u) __builtin_trap();
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// the 16 table entries of code words w[4 * Q .. 4 * Q + 3] (chunks 16 Q .. 16 Q + 15): all offsets, then all gathers
+template <typename T, int ENTRY> __device__ __forceinline__ void gather16(const uint32_t (&w)[16], int Q, uint32_t shift, T (&e)[16]) {
+    uint32_t off[16];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        off[a * 4 + 0] = code_offset<0>(w[Q * 4 + a], shift);
+        off[a * 4 + 1] = code_offset<1>(w[Q * 4 + a], shift);
+        off[a * 4 + 2] = code_offset<2>(w[Q * 4 + a], shift);
+        off[a * 4 + 3] = code_offset<3>(w[Q * 4 + a], shift);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) e[c] = *lds_at<T>(off[c] + (Q * 16 + c) * 256 * ENTRY);
+}
+
 template <bool GMAX>
 __global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* __restrict__ lut, const uint8_t* __restrict__ codes,
                                                                   size_t n, const uint8_t* __restrict__ desc /* [n][4] or null */,
                                                                   const float* __restrict__ scales, int64_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_lut = reinterpret_cast<float*>(smem);
+    require_lds_base_zero(smem);
     for (int e = threadIdx.x; e < 64 * 256; e += blockDim.x) s_lut[e] = lut[e];
     float sc[4] = {0.f, 0.f, 0.f, 0.f};
     if (desc)
@@ -323,10 +359,16 @@ __global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* 
         const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
                                 w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
         float s = 0.0f;
+        uint32_t sh2 = 2;
+        asm volatile("" : "+v"(sh2));   // the shift amount lives in a VGPR (SDWA takes no literal)
+        // the table starts at LDS address 0 (checked above): an entry's byte offset IS its address, the chunk goes into the ds_read's immediate
 #pragma unroll
-        for (int a = 0; a < 16; a++)
+        for (int Q = 0; Q < 4; Q++) {
+            float e[16];
+            gather16<float, 4>(w, Q, sh2, e);
 #pragma unroll
-            for (int bb = 0; bb < 4; bb++) s = add_rn(s, s_lut[(a * 4 + bb) * 256 + ((w[a] >> (8 * bb)) & 0xff)]);
+            for (int c = 0; c < 16; c++) s = add_rn(s, e[c]);     // chunk order 0 .. 63 (asymmetric_dot_product, vector.rs:387-405)
+        }
         const size_t v = grp * 64 + lane;
         int64_t r = scale_dot_result(s);
         if (desc) {
@@ -347,25 +389,27 @@ __global__ __launch_bounds__(PQS_WAVES * 64) void pq_scan64_kernel(const float* 
     }
 }
 
-// Two queries per pass over the codes (round 3).  The scan above is bound by its LDS gathers: 64 random 4-byte reads per vector at
-// ~3.5-way bank conflicts cost as many LDS cycles as the codes cost HBM time, and those cycles buy ONE query.  Here the table holds
-// both queries' entries side by side -- s_lut2[chunk * 256 + code] = {q0, q1} (128 KiB) -- so the same 64 gathers per vector, now
-// ds_read_b64, and the same pass over the codes serve two queries: per query, half the LDS cycles and half the HBM bytes.  Each
-// query's sum is still 64 sequential f32 adds in chunk order (asymmetric_dot_product, vector.rs:387-405) and the descriptor bias is
-// added after the conversion, so both group maxima are bit-identical to pq_scan64_kernel<true>'s for that query.
-// LDS: 128 KiB table + 8 waves x 4 KiB of code staging = all 160 KiB; the 4 descriptor bytes of a vector come straight from
-// global memory (one coalesced dword per lane).
-constexpr int PQ2_WAVES = 8;
+// Two queries per pass over the codes (round 3).  The one-query scan above is bound by its LDS gathers and the VALU work around
+// them (profiles/r03_pmc_pq_scan.txt: LDS 79 % busy, 46 % of the kernel's cycles are bank-conflict cycles of the 64 random 4-byte
+// reads per vector; VALU 70 %), and all of that buys ONE query.  Here the table holds both queries' entries side by side --
+// s_lut2[chunk * 256 + code] = {q0, q1} (128 KiB) -- so the same 64 gathers per vector, now ds_read_b64, and the same pass over the
+// codes serve two queries: per query, half the LDS cycles and half the HBM bytes.  Each query's sum is still 64 sequential f32 adds
+// in chunk order (asymmetric_dot_product, vector.rs:387-405) and the descriptor bias is added after the conversion, so both group
+// maxima are bit-identical to pq_scan64_kernel<true>'s for that query (tests: test_group_maxima_equal_the_gathered_scores).
+// No LDS is left for staging the codes (128 of 160 KiB are table): every lane loads its own 64-byte code row straight from global
+// memory (four 16-byte loads at a 64-byte stride; lane pairs share a 128-byte line, and the four loads of a wave touch the same 32
+// lines back to back), one group ahead.  NW = 12 waves (register-limited; 8 waves 8 % slower, 16 spill).  A form with the round-2
+// LDS-DMA staging (8 waves x 4 KiB) measured 3 % slower at 2e7 codes and was dropped.
 constexpr int PQ2_LUT_BYTES = 64 * 256 * 8;
-constexpr int PQ2_LDS = PQ2_LUT_BYTES + PQ2_WAVES * 4096;
-
-__global__ __launch_bounds__(PQ2_WAVES * 64) void pq_scan64x2_kernel(const float* __restrict__ lut0, const float* __restrict__ lut1,
-                                                                    const uint8_t* __restrict__ codes, size_t n,
-                                                                    const uint8_t* __restrict__ desc /* [n][4] or null */,
-                                                                    const float* __restrict__ scales, int64_t* __restrict__ out0,
-                                                                    int64_t* __restrict__ out1) {
+constexpr int PQ2_WAVES = 12;
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void pq_scan64x2_kernel(const float* __restrict__ lut0, const float* __restrict__ lut1,
+                                                              const uint8_t* __restrict__ codes, size_t n,
+                                                              const uint8_t* __restrict__ desc, const float* __restrict__ scales,
+                                                              int64_t* __restrict__ out0, int64_t* __restrict__ out1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* s_lut2 = reinterpret_cast<float2*>(smem);
+    require_lds_base_zero(smem);
     for (int e = threadIdx.x; e < 64 * 256; e += blockDim.x) s_lut2[e] = make_float2(lut0[e], lut1[e]);
     float sc[4] = {0.f, 0.f, 0.f, 0.f};
     if (desc)
@@ -373,49 +417,39 @@ __global__ __launch_bounds__(PQ2_WAVES * 64) void pq_scan64x2_kernel(const float
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char* stage = smem + PQ2_LUT_BYTES + wave * 4096;
-    const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)stage;
-    uint32_t voff[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int r = 16 * j + (lane >> 2);
-        voff[j] = (uint32_t)(r * 64 + (((lane & 3) ^ ((r >> 3) & 3)) * 16));
-    }
     const size_t ngroups = (n + 63) / 64;
-    const size_t stride = (size_t)gridDim.x * PQ2_WAVES;
-    size_t grp = (size_t)blockIdx.x * PQ2_WAVES + wave;
-    // VMEM operations per group, in issue order: 4 code DMAs, (the descriptor dword load), then -- after the sums -- 2 result stores
-    auto issue = [&](size_t gi) {
-        const uint8_t* base = codes + gi * 4096;   // the allocations carry slack for the last, partial group
+    const size_t stride = (size_t)gridDim.x * NW;
+    size_t grp = (size_t)blockIdx.x * NW + wave;
+    auto load_rows = [&](size_t gi, uint4 (&w4)[4], uint32_t& dw) {
+        const size_t v = gi * 64 + lane;            // the allocations carry slack for the last, partial group
+        typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+        const u32x4v* row = reinterpret_cast<const u32x4v*>(codes + v * 64);
 #pragma unroll
-        for (int j = 0; j < 4; j++) pq_dma16(base, voff[j], stage_lds + j * 1024);
+        for (int p = 0; p < 4; p++) {
+            const u32x4v t = __builtin_nontemporal_load(row + p);
+            w4[p] = uint4{t.x, t.y, t.z, t.w};
+        }
+        dw = (desc && v < n) ? reinterpret_cast<const uint32_t*>(desc)[v] : 0u;
     };
-    auto load_desc = [&](size_t gi) -> uint32_t {
-        const size_t v = gi * 64 + lane;
-        return (desc && v < n) ? reinterpret_cast<const uint32_t*>(desc)[v] : 0u;
-    };
+    uint4 nx[4];
     uint32_t dw_next = 0;
-    if (grp < ngroups) { issue(grp); dw_next = load_desc(grp); }
-    const int rsw = (lane >> 3) & 3;
+    if (grp < ngroups) load_rows(grp, nx, dw_next);
     for (; grp < ngroups; grp += stride) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // codes + descriptor dword of this group (the previous stores as well)
+        uint4 w4[4] = {nx[0], nx[1], nx[2], nx[3]};
         const uint32_t dw = dw_next;
-        uint4 w4[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) w4[p] = *reinterpret_cast<const uint4*>(stage + lane * 64 + ((p ^ rsw) * 16));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rows are in registers: the staging area may be refilled
-        if (grp + stride < ngroups) { issue(grp + stride); dw_next = load_desc(grp + stride); }
+        if (grp + stride < ngroups) load_rows(grp + stride, nx, dw_next);
         const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
                                 w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
         float s0 = 0.0f, s1 = 0.0f;
+        uint32_t sh3 = 3;
+        asm volatile("" : "+v"(sh3));   // the shift amount lives in a VGPR (SDWA takes no literal)
 #pragma unroll
-        for (int a = 0; a < 16; a++)
+        for (int Q = 0; Q < 4; Q++) {
+            f32x2 e[16];
+            gather16<f32x2, 8>(w, Q, sh3, e);
 #pragma unroll
-            for (int bb = 0; bb < 4; bb++) {
-                const float2 e = s_lut2[(a * 4 + bb) * 256 + ((w[a] >> (8 * bb)) & 0xff)];
-                s0 = add_rn(s0, e.x);
-                s1 = add_rn(s1, e.y);
-            }
+            for (int c = 0; c < 16; c++) { s0 = add_rn(s0, e[c].x); s1 = add_rn(s1, e[c].y); }   // chunk order, per query
+        }
         const size_t v = grp * 64 + lane;
         int64_t r0 = scale_dot_result(s0), r1 = scale_dot_result(s1);
         if (desc) {
@@ -560,11 +594,11 @@ int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const 
 int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* codes, size_t n, const uint8_t* desc,
                          const float* scales, int64_t* gmax0, int64_t* gmax1, int n_cu, hipStream_t stream) {
     if (n == 0) return 0;
-    MSE_DYN_LDS(pq_scan64x2_kernel, PQ2_LDS);
     const size_t groups = (n + 63) / 64;
     const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;   // a few CUs stay free for the previous pair's tail (see above)
+    MSE_DYN_LDS(pq_scan64x2_kernel<PQ2_WAVES>, PQ2_LUT_BYTES);
     const unsigned blocks = (unsigned)std::min<size_t>((groups + PQ2_WAVES - 1) / PQ2_WAVES, cus);
-    hipLaunchKernelGGL(pq_scan64x2_kernel, dim3(blocks), dim3(PQ2_WAVES * 64), PQ2_LDS, stream, lut0, lut1, codes, n,
+    hipLaunchKernelGGL(pq_scan64x2_kernel<PQ2_WAVES>, dim3(blocks), dim3(PQ2_WAVES * 64), PQ2_LUT_BYTES, stream, lut0, lut1, codes, n,
                        (desc && scales) ? desc : nullptr, scales, gmax0, gmax1);
     MSE_HIP_TRY(hipGetLastError());
     return 0;

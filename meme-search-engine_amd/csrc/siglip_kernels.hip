@@ -1641,6 +1641,11 @@ constexpr int AT6_NS = 3;
 // <2, 8> is the round-1 shape; <4, 4> (round 2) lets every K / Vt fragment read from LDS feed four MFMAs instead of two --
 // the eight waves of the old shape all re-read the same fragments and the kernel sat at 38 % MFMA-busy behind its LDS
 // traffic -- with two 4-wave workgroups per CU so that one's barrier wait overlaps the other's MFMAs.
+#ifdef MSE_DEV_KERNELS
+// developer profile (ABL = 7): shader cycles of wave 0 of every workgroup in [0] prologue (start -> first stage consumed), [1] main loop,
+// [2] epilogue; [3] = workgroups
+__device__ unsigned long long g_att_prof[4];
+#endif
 template <int ABL, int QT = 2, int NW = 8>   // ABL 0 shipped; timing ablations: 1 no softmax arithmetic, 2 no MFMA, 3 no K/V fragment reads
 __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ vt, int heads, int tokens, int n_pad,
@@ -1650,6 +1655,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
+#ifdef MSE_DEV_KERNELS
+    [[maybe_unused]] unsigned long long pt0 = 0, pt1 = 0, pt2 = 0;
+    if constexpr (ABL == 7) pt0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int PW = 24 / NW;   // DMA pieces per wave per stage
     constexpr int QPW = NW * QT * 16;   // queries per workgroup = per pass over this (image, head)'s K / Vt
     static_assert(24 % NW == 0, "24 DMA pieces per stage");
@@ -1701,6 +1710,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
     for (int tile = 0; tile < nt; tile++) {
         vm_wait_n(min(AT6_NS - 2, nt - 1 - tile) * PW);
         __builtin_amdgcn_s_barrier();
+#ifdef MSE_DEV_KERNELS
+        if constexpr (ABL == 7) if (tile == 0) pt1 = __builtin_amdgcn_s_memtime();
+#endif
         if (tile + AT6_NS - 1 < nt) issue(tile + AT6_NS - 1);
         const char* kst = lds + (tile % AT6_NS) * AT6_STAGE;
         const char* vst = kst + AT6_KT;
@@ -1773,7 +1785,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
                 for (int h2 = 0; h2 < 2; h2++)
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        p[h2 * 4 + r] = ABL == 1 ? s[qt][h2][r] : __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
+                        p[h2 * 4 + r] = ABL == 1 ? s[qt][h2][r] : ABL == 6 ? __builtin_amdgcn_exp2f(s[qt][h2][r]) : __builtin_amdgcn_exp2f(fmaf(s[qt][h2][r], scale_log2e, -m_run[qt]));
                 pf[qt] = as_bf8(u32x4{pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])});
             }
 #pragma unroll
@@ -1796,6 +1808,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
             }
         }
     }
+#ifdef MSE_DEV_KERNELS
+    if constexpr (ABL == 7) pt2 = __builtin_amdgcn_s_memtime();
+#endif
     const int b = bh / heads, hd = bh % heads;
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
@@ -1812,6 +1827,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
             }
         }
     }
+#ifdef MSE_DEV_KERNELS
+    if constexpr (ABL == 7) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            atomicAdd(&g_att_prof[0], pt1 - pt0); atomicAdd(&g_att_prof[1], pt2 - pt1); atomicAdd(&g_att_prof[2], pt3 - pt2);
+            atomicAdd(&g_att_prof[3], 1ull);
+        }
+    }
+#endif
 }
 
 // open_clip's preprocess after decoding (clip_server.py:140-141): ToTensor + Normalize(mean = std = 0.5) + .half(), i.e.
@@ -2324,7 +2349,7 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
             MSE_DYN_LDS((attention64_kernel<0, 4, 4>), AT6_NS * AT6_STAGE);
             hipLaunchKernelGGL((attention64_kernel<0, 4, 4>), dim3((unsigned)(B * heads * qblocks)), dim3(256), AT6_NS * AT6_STAGE, st,
                                q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
-        } else if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else if (abl64 == 4) MSE_ATT64(4) else if (abl64 == 5) MSE_ATT64(5) else MSE_ATT64(0)
+        } else if (abl64 == 1) MSE_ATT64(1) else if (abl64 == 2) MSE_ATT64(2) else if (abl64 == 3) MSE_ATT64(3) else if (abl64 == 4) MSE_ATT64(4) else if (abl64 == 5) MSE_ATT64(5) else if (abl64 == 6) MSE_ATT64(6) else if (abl64 == 7) MSE_ATT64(7) else MSE_ATT64(0)
         MSE_HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -2418,3 +2443,13 @@ int launch_f32_to_bf16_pad(const float* in, int rows, int cols, int ld_in, uint1
 
 }  // namespace siglip
 }  // namespace mse
+
+#ifdef MSE_DEV_KERNELS
+// developer library only (not in include/mse.h): read and clear the counters of the profiled attention kernel (MSE_ATT64_ABL=7)
+extern "C" __attribute__((visibility("default"))) int mse_dev_att_prof(unsigned long long out[4]) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mse::siglip::g_att_prof), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mse::siglip::g_att_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

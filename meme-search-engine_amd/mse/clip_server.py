@@ -158,11 +158,53 @@ class ClipServer:
     def _model_work(self, job):
         job.finish(True, self.run_model(*job.stage))
 
+    def _model_loop(self):
+        """The model thread (do_inference's loop, clip_server.py:91-123,126-128) with one addition the wire contract does not see:
+        BMP jobs already waiting in the queue are run as ONE engine call, up to the engine's own batch capacity (a request is
+        limited to max_batch_size images and 64 MiB; the tower is most efficient at 256).  Rows go back to their own requests."""
+        cap = max(int(getattr(self.image_engine, "max_batch", self.bs)), self.bs)
+        held = None
+        while True:
+            job = held if held is not None else self.model_q.get()
+            held = None
+            if job is self._stop:
+                return
+            group = [job]
+            try:
+                kind, payload = job.stage
+                if kind == "bmp":
+                    total = len(payload)
+                    while total < cap:
+                        try:
+                            nxt = self.model_q.get_nowait()
+                        except queue.Empty:
+                            break
+                        if nxt is self._stop or nxt.stage[0] != "bmp" or total + len(nxt.stage[1]) > cap:
+                            held = nxt             # runs next, on its own
+                            break
+                        group.append(nxt)
+                        total += len(nxt.stage[1])
+                if len(group) == 1:
+                    self._model_work(job)
+                else:
+                    rows = self.run_model("bmp", [im for j in group for im in j.stage[1]])
+                    at = 0
+                    for j in group:
+                        n = len(j.stage[1])
+                        j.finish(True, rows[at:at + n])
+                        at += n
+            except Exception as e:  # noqa: BLE001 - every failure is reported to the client as a 500 string
+                traceback.print_exc()
+                for j in group:
+                    j.finish(False, str(e))
+
     def start_threads(self):
-        for inbox, work in ((self.model_q, self._model_work), (self.prep_q, self._prep_work)):
-            th = threading.Thread(target=self._stage_loop, args=(inbox, work), daemon=True)
-            th.start()
-            self._threads.append(th)
+        th = threading.Thread(target=self._model_loop, daemon=True)
+        th.start()
+        self._threads.append(th)
+        th = threading.Thread(target=self._stage_loop, args=(self.prep_q, self._prep_work), daemon=True)
+        th.start()
+        self._threads.append(th)
 
     def stop_threads(self):
         self.prep_q.put(self._stop)

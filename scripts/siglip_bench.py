@@ -26,3 +26,12 @@ def main():
           f"({batch/dt*gflop_img*1e9/2.5e15*100:.1f}% of 2.5 PF)")
 
 main()
+
+if os.environ.get("MSE_ATT64_ABL") == "7":   # developer library: where an attention workgroup's cycles go
+    import ctypes
+    out = (ctypes.c_ulonglong * 4)()
+    ffi.lib().mse_dev_att_prof(out)
+    pro, loop, epi, n = [int(x) for x in out]
+    if n:
+        print(f"attention workgroups (wave 0, shader cycles per workgroup over {n} workgroups): prologue {pro / n:.0f}, main loop {loop / n:.0f}, "
+              f"epilogue {epi / n:.0f}  -> {100 * pro / (pro + loop + epi):.1f} % / {100 * loop / (pro + loop + epi):.1f} % / {100 * epi / (pro + loop + epi):.1f} %")
