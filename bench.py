@@ -115,7 +115,7 @@ def cpu_baseline(n_rows, k):
         pass
     return {
         "value": qps_sample * sample_rows / n_rows,
-        "unit": "queries/s",
+        "unit": f"queries/s over {n_rows} rows, EXTRAPOLATED x{n_rows // sample_rows} from a {sample_rows}-row DRAM-resident sample (linear in rows)",
         "cores": cores,
         "cores_visible": visible,
         "cpu_time_quota_cores": quota,
@@ -124,7 +124,7 @@ def cpu_baseline(n_rows, k):
         "sample": f"fair mode: {cores} threads x 1 query x {sample_rows} rows x {D} fp16 ({sample_rows * D * 2 / 1e9:.1f} GB, DRAM-resident), "
                   f"top-{k} ({dt:.2f} s wall, {qps_sample:.1f} q/s on the sample); scaled by rows {sample_rows}/{n_rows}",
         "scan_GBps": qps_sample * sample_rows * D * 2 / 1e9,
-        "reference_faithful": {"value": sample_rows / n_rows / df, "unit": "queries/s", "cores": 1,
+        "reference_faithful": {"value": sample_rows / n_rows / df, "unit": f"queries/s over {n_rows} rows, EXTRAPOLATED from the sample", "cores": 1,
                                "sample": f"1 thread, {n_f} queries, {sample_rows} rows: every row scored, full sort, top-{k} "
                                          f"({df:.2f} s per query on the sample); scaled by rows",
                                "scan_GBps": sample_rows * D * 2 / df / 1e9},
@@ -431,62 +431,104 @@ def siglip_bench(args, world, rank, dist=None):
                          "flop_per_image": gflop_img * 1e9, "traffic": None,
                          "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.79 of 2.4 GHz "
                                  "(profiles/r02_power_clocks.txt); the library GEMM alone runs these shapes at 0.38-0.50 of the same peak "
-                                 "(profiles/r02_gemm_calibration.txt)"}}
+                                 "(profiles/r02_gemm_calibration.txt); round-3 measurements of what is left: DESIGN.md 3.4"}}
+
+
+_SERVER_CLIENT = r"""
+import asyncio, sys, time
+import aiohttp, msgpack, numpy as np
+port, w, h, per_req, n_req, in_flight, emb = (int(x) for x in sys.argv[1:8])
+rng = np.random.default_rng(11)
+hdr = (b"BM" + (54 + w * h * 3).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") +
+       w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(24))
+images = [hdr + rng.integers(0, 256, size=w * h * 3, dtype=np.uint8).tobytes() for _ in range(per_req)]
+body = msgpack.dumps({"images": images})       # what common.rs:61-66,91 sends: a msgpack map {"images": [bin, ...]}
+async def main():
+    async with aiohttp.ClientSession() as sess:
+        async def one():
+            async with sess.post(f"http://127.0.0.1:{port}/", data=body) as r:
+                rows = msgpack.loads(await r.read())
+                assert r.status == 200 and len(rows) == per_req and len(rows[0]) == 2 * emb, (r.status, rows if r.status != 200 else "")
+        await one()
+        sem = asyncio.Semaphore(in_flight)
+        async def limited():
+            async with sem:
+                await one()
+        t1 = time.perf_counter()
+        await asyncio.gather(*[limited() for _ in range(n_req)])
+        print("ELAPSED", time.perf_counter() - t1, len(body))
+asyncio.run(main())
+"""
 
 
 def server_bench(eng, cfg, engine_batch):
     """The serving path the device-side BMP decode exists for (clip_server.py:131-170, src/common.rs:31-54): requests of 128
     Rust-style 384 x 384 24-bit BMPs (56.6 MB of msgpack, under the reference's 64 MiB body limit; 256 BMPs would be 113 MB and the
-    reference would answer 413) POSTed to the aiohttp app of mse.clip_server.ClipServer over loopback, four in flight; the answer is
-    the msgpack array of 2304-byte fp16 rows.  End to end: HTTP + msgpack decode, header checks, H2D of the raw files, device
-    BGR->RGB / flip / normalise, the tower, fp16 rows, msgpack encode.  Beside it: what the reference's preprocessing thread does
-    with the same files on one host thread (PIL decode + ToTensor/Normalize/.half()), the stage the device decode removes."""
+    reference would answer 413) POSTed over loopback TCP by a CLIENT PROCESS (four requests in flight) to the aiohttp app of
+    mse.clip_server.ClipServer in this process; the answer is the msgpack array of 2304-byte fp16 rows.  End to end: HTTP + msgpack
+    decode, header checks, H2D of the raw files, device BGR->RGB / flip / normalise, the tower, fp16 rows, msgpack encode.  Beside
+    it: what the reference's preprocessing thread does with the same files on one host thread (PIL decode + ToTensor/Normalize/
+    .half()), the stage the device decode removes."""
     import asyncio
-    import msgpack
+    import subprocess
+    import threading
     import numpy as np
-    from aiohttp.test_utils import TestClient, TestServer
+    from aiohttp import web
     from mse.clip_server import ClipServer, preprocess_image
     w = h = cfg["img_size"]
-    per_req, n_req, in_flight = 128, 10, 4
+    per_req, n_req, in_flight = 128, 24, 6
     rng = np.random.default_rng(11)
     hdr = (b"BM" + (54 + w * h * 3).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") +
            w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(24))
-    images = [hdr + rng.integers(0, 256, size=w * h * 3, dtype=np.uint8).tobytes() for _ in range(per_req)]
-    body = msgpack.dumps({"images": images})
+    sample = [hdr + rng.integers(0, 256, size=w * h * 3, dtype=np.uint8).tobytes() for _ in range(16)]
     t0 = time.perf_counter()
-    for im in images[:16]:
+    for im in sample:
         preprocess_image(im, (w, h))
-    host_decode = 16 / (time.perf_counter() - t0)
+    host_decode = len(sample) / (time.perf_counter() - t0)
     eng.image_size = (w, h)
+    # a second replica of the tower (856 MB of weights): two model threads, so one batch's host side (hand-off, upload of 113 MB of
+    # raw files, download) runs beside the other's device side
+    from mse import siglip
+    eng2 = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=engine_batch)
+    eng2.image_size = (w, h)
     srv = ClipServer({"device": "cuda:0", "model": "ViT-SO400M-14-SigLIP-384", "model_name": "siglip-so400m-14-384",
-                      "max_batch_size": per_req, "port": 0}, eng)
+                      "max_batch_size": per_req, "port": 0}, [eng, eng2])
     srv.start_threads()
+    loop = asyncio.new_event_loop()
+    ready = threading.Event()
+    state = {}
 
-    async def go():
-        client = TestClient(TestServer(srv.make_app()))
-        await client.start_server()
-        try:
-            async def one():
-                r = await client.post("/", data=body)
-                rows = msgpack.loads(await r.read())
-                assert r.status == 200 and len(rows) == per_req and len(rows[0]) == 2 * cfg["emb_dim"], (r.status, rows if r.status != 200 else "")
-            await one()                                   # warm-up
-            sem = asyncio.Semaphore(in_flight)
+    def serve():
+        asyncio.set_event_loop(loop)
+        runner = web.AppRunner(srv.make_app())
+        loop.run_until_complete(runner.setup())
+        site = web.TCPSite(runner, "127.0.0.1", 0)
+        loop.run_until_complete(site.start())
+        state["port"] = site._server.sockets[0].getsockname()[1]
+        state["runner"] = runner
+        ready.set()
+        loop.run_forever()
 
-            async def limited():
-                async with sem:
-                    await one()
-            t1 = time.perf_counter()
-            await asyncio.gather(*[limited() for _ in range(n_req)])
-            return time.perf_counter() - t1
-        finally:
-            await client.close()
-
-    dt = asyncio.run(go())
-    srv.stop_threads()
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    ready.wait(30)
+    try:
+        out = subprocess.run([sys.executable, "-c", _SERVER_CLIENT, str(state["port"]), str(w), str(h), str(per_req), str(n_req),
+                              str(in_flight), str(cfg["emb_dim"])], capture_output=True, text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("ELAPSED")]
+        if not line:
+            raise RuntimeError("client failed: " + (out.stderr or out.stdout)[-400:])
+        dt, body_len = float(line[0].split()[1]), int(line[0].split()[2])
+    finally:
+        asyncio.run_coroutine_threadsafe(state["runner"].cleanup(), loop).result(30)
+        loop.call_soon_threadsafe(loop.stop)
+        srv.stop_threads()
+        for t in srv._threads:
+            t.join(30)
+        eng2.close()
     return {"metric": "clip_server images/s end to end (HTTP + msgpack + device BMP decode + tower + fp16 rows)",
             "value": per_req * n_req / dt, "unit": "images/s", "images_per_request": per_req, "requests": n_req, "in_flight": in_flight,
-            "request_bytes": len(body), "engine_batch_capacity": engine_batch,
+            "request_bytes": body_len, "engine_batch_capacity": engine_batch, "engine_replicas": 2, "client": "separate process, loopback TCP",
             "host_preprocess_images_per_s_one_thread": host_decode,
             "note": "the model thread runs the BMP jobs waiting in its queue as one engine call (up to the engine's batch capacity); "
                     "host_preprocess = PIL decode + normalise + fp16 of the same files on one thread, the reference's preprocessing_thread "
@@ -808,7 +850,7 @@ def main():
         # inside a timed run); only reported when this run is the profiled configuration
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             if pm["rows"] == hi - lo and pm["queries_per_launch"] == min(nq, 256):
                 traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
         except Exception:
@@ -833,16 +875,17 @@ def main():
                                                                           " + peer-mapped gather of [Q,k] records" if in_process else ""),
                        "rows_total": n_total, "rows_per_gpu": hi - lo, "queries_per_step": nq, "k": k,
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
-            "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "scan_mfma2d_kernel<3,16> (256 queries per pass; <= 128: scan_mfma_kernel<3,8>)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
+                         "traffic": traffic, "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms, "queries_per_launch": min(nq, 256),
                          # the same launch against the matrix cores: 2*rows*1152*queries flops; dense f16 peak 2500 TFLOP/s
                          "mfma_tflops": mfma_tflops, "mfma_frac": (mfma_tflops / 2500.0) if mfma_tflops else None,
                          "note": "256 queries per pass: neither HBM nor the matrix cores are saturated; the pass is bound by the "
                                  "power budget (rocm-smi beside it: 1360 W of the 1400 W board limit, engine clock 1.5 GHz of 2.4 -- "
-                                 "profiles/r02_power_clocks.txt; the same kernel on all-zero rows is 17 % faster) -- "
-                                 "scan_mfma.hip header.  hbm_bound_point = the 128-query pass (HBM-bound).",
+                                 "profiles/r02_power_clocks.txt; the same kernel on all-zero rows is 17-20 % faster; tilings with a third "
+                                 "fewer LDS reads, deeper prefetch or no barrier at all take the same 8.9 M cycles per 1e7 rows -- "
+                                 "profiles/r03_scan_variants.txt, DESIGN.md 3.1).  hbm_bound_point = the 128-query pass (HBM-bound).",
                          "launches_timed": scan_launches,
                          # informational: the guide's measured float4-copy ceiling of this chip is 6.29 TB/s
                          "frac_of_measured_copy_ceiling": (achieved / 6290.0) if achieved else None},
@@ -863,7 +906,7 @@ def main():
         if note:
             line["note"] = note
         # not measured by this command (the build takes 20 minutes): the same 1e8-row index served through the graph path
-        line["see_also"] = "profiles/r02_graph_scale_1e8.txt (r01_graph_scale.txt): 1e8 x 1152 on one GPU served through the sharded Vamana index"
+        line["see_also"] = "profiles/r02_graph_scale_1e8.txt (r01_graph_scale.txt): 1e8 x 1152 on one GPU served through the sharded Vamana index (builder-measured, not under this command's clock)"
 
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n_total, k)

@@ -81,6 +81,10 @@ class ClipServer:
         self.config = config
         self.bs = int(config["max_batch_size"])
         self.model_name = config["model_name"]
+        # one engine, or several replicas of it: every replica gets its own model thread, so the host side of one batch (queue
+        # hand-off, upload of the raw files, download of the rows) runs beside the device side of another
+        self.image_engines = list(image_engine) if isinstance(image_engine, (list, tuple)) else [image_engine]
+        image_engine = self.image_engines[0]
         self.image_engine = image_engine
         self.text_engine = text_engine
         self.tokenizer = tokenizer
@@ -122,7 +126,8 @@ class ClipServer:
         raise AssertionError("images or text required")
 
     # ---- model stage (do_inference, clip_server.py:91-123) ----
-    def run_model(self, kind, payload):
+    def run_model(self, kind, payload, engine=None):
+        engine = engine or self.image_engine
         n = len(payload)
         if kind == "tokens":
             if self.text_engine is None:
@@ -136,7 +141,7 @@ class ClipServer:
             with self.inference_time_hist.labels(self.model_name + "-image", n).time():
                 # the engine normalises on the device; result rows are unit norm like `features /= norm`
                 call = {"bmp": "encode_bmp", "rgb8": "encode_rgb8", "nchw": "encode_image"}[kind]
-                f = np.asarray(getattr(self.image_engine, call)(payload), np.float32)
+                f = np.asarray(getattr(engine, call)(payload), np.float32)
         self.batch_count_ctr.labels(self.model_name).inc()
         return f
 
@@ -155,19 +160,21 @@ class ClipServer:
         job.stage = self.prepare(job)
         self.model_q.put(job)
 
-    def _model_work(self, job):
-        job.finish(True, self.run_model(*job.stage))
+    def _model_work(self, job, engine=None):
+        job.finish(True, self.run_model(*job.stage, engine=engine))
 
-    def _model_loop(self):
+    def _model_loop(self, engine=None):
         """The model thread (do_inference's loop, clip_server.py:91-123,126-128) with one addition the wire contract does not see:
         BMP jobs already waiting in the queue are run as ONE engine call, up to the engine's own batch capacity (a request is
         limited to max_batch_size images and 64 MiB; the tower is most efficient at 256).  Rows go back to their own requests."""
-        cap = max(int(getattr(self.image_engine, "max_batch", self.bs)), self.bs)
+        engine = engine or self.image_engine
+        cap = max(int(getattr(engine, "max_batch", self.bs)), self.bs)
         held = None
         while True:
             job = held if held is not None else self.model_q.get()
             held = None
             if job is self._stop:
+                self.model_q.put(job)          # the other model threads stop on it as well
                 return
             group = [job]
             try:
@@ -185,9 +192,9 @@ class ClipServer:
                         group.append(nxt)
                         total += len(nxt.stage[1])
                 if len(group) == 1:
-                    self._model_work(job)
+                    self._model_work(job, engine)
                 else:
-                    rows = self.run_model("bmp", [im for j in group for im in j.stage[1]])
+                    rows = self.run_model("bmp", [im for j in group for im in j.stage[1]], engine)
                     at = 0
                     for j in group:
                         n = len(j.stage[1])
@@ -199,9 +206,10 @@ class ClipServer:
                     j.finish(False, str(e))
 
     def start_threads(self):
-        th = threading.Thread(target=self._model_loop, daemon=True)
-        th.start()
-        self._threads.append(th)
+        for eng in self.image_engines:
+            th = threading.Thread(target=self._model_loop, args=(eng,), daemon=True)
+            th.start()
+            self._threads.append(th)
         th = threading.Thread(target=self._stage_loop, args=(self.prep_q, self._prep_work), daemon=True)
         th.start()
         self._threads.append(th)

@@ -1,5 +1,6 @@
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MSE_HIP_LIB", os.path.join(ROOT, "meme-search-engine_amd", "lib", "libmse_hip_dev.so"))   # developer library (make dev)
 sys.path.insert(0, os.path.join(ROOT, "meme-search-engine_amd"))
 from mse import ffi
 L = ffi.lib()

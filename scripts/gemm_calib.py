@@ -33,7 +33,11 @@ def lib_ms(n, k, iters=5):
 
 
 def mine_ms(n, k, random, abl=33):
-    env = dict(os.environ, MSE_GEMM_RANDOM="1" if random else "0")
+    # developer library (make dev): mse_debug_gemm_ms and its MSE_GEMM_RANDOM switch exist only there
+    env = dict(os.environ, MSE_HIP_LIB=os.path.join(ROOT, "meme-search-engine_amd", "lib", "libmse_hip_dev.so"))
+    env.pop("MSE_GEMM_RANDOM", None)
+    if random:
+        env["MSE_GEMM_RANDOM"] = "1"
     code = ("import sys,ctypes as C;sys.path.insert(0,%r);from mse import ffi;L=ffi.lib();ms=C.c_float();"
             "ffi.check(L.mse_debug_gemm_ms(%d,%d,%d,%d,5,C.byref(ms)));print(ms.value)" % (os.path.join(ROOT, "meme-search-engine_amd"), M, n, k, abl))
     return float(subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()[-1])

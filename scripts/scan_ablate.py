@@ -4,6 +4,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MSE_HIP_LIB", os.path.join(ROOT, "meme-search-engine_amd", "lib", "libmse_hip_dev.so"))   # developer library (make dev)
 sys.path.insert(0, os.path.join(ROOT, "meme-search-engine_amd"))
 import torch  # noqa: F401,E402
 import mse  # noqa: E402
