@@ -535,6 +535,15 @@ def server_bench(eng, cfg, engine_batch):
                     "(clip_server.py:131-146), which the device decode replaces"}
 
 
+def rccl_probe_code(n_gpus):
+    """Child-process probe of the in-process RCCL exchange: tiny shards on devices 0..n-1, bring-up, one search through the all-gather."""
+    return ("import sys; sys.path.insert(0, %r); import torch, numpy as np, mse\n"
+            "g = mse.ShardGroup(%d, %d, devices=list(range(%d))); g.generate(1, 0, %d)\n"
+            "g.set_exchange(g.EXCHANGE_RCCL); q = np.zeros((4, %d), np.uint16); q[:, 0] = 0x3c00\n"
+            "s, i = g.bruteforce_topk(q, 3, mse.MODE_EXACT); assert g.rccl_ranks == %d; print('PROBE_OK')\n"
+            % (os.path.join(ROOT, "meme-search-engine_amd"), n_gpus, D, n_gpus, 4096 * n_gpus, D, n_gpus))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -634,7 +643,21 @@ def main():
         # the exchange north_star names: ONE ncclAllGather of the packed records per step among the shards' devices, each rank's
         # collective issued by its shard's host thread (csrc/shard_group.hip).  If RCCL cannot be brought up (shards sharing a
         # device, no librccl, ncclCommInitAll failing) the line is still measured over the peer-store exchange, labelled as such.
+        # RCCL across several devices has never run on the build's one-GPU boxes: probe it in a CHILD process under a timeout first
+        # (tiny shards, bring-up + one search), so that a bootstrap that hangs costs this run two minutes and a label, not the line
+        probe_err = None
+        if len(set(group.device(g) for g in range(n_gpus))) == n_gpus:
+            import subprocess
+            probe = rccl_probe_code(n_gpus)
+            try:
+                pr = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=150)
+                if "PROBE_OK" not in pr.stdout:
+                    probe_err = "RCCL probe failed: " + (pr.stderr or pr.stdout).strip().splitlines()[-1][:300] if (pr.stderr or pr.stdout).strip() else "RCCL probe failed"
+            except subprocess.TimeoutExpired:
+                probe_err = "RCCL probe (bring-up + one all-gather in a child process) did not finish in 150 s"
         try:
+            if probe_err:
+                raise mse.MseError(probe_err)
             group.set_exchange(group.EXCHANGE_RCCL)
             exchange = {"kind": "one process, a host thread per shard; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record "
                                 "blocks per step, rank g = shard g on device g", "shards": n_gpus,

@@ -2,6 +2,7 @@
 mse_shard_group (one process, a host thread per shard; logical shards share the one device of the test box),
 mse_comm (RCCL all-gather; world of one here: the collective call path and the packed-block merge),
 the threading contract of the ABI (include/mse.h: shared read-only base, one searcher per thread, thread-local errors)."""
+import os
 import threading
 
 import numpy as np
@@ -100,6 +101,17 @@ def test_shard_group_rccl_exchange(gpu, mse, orc):
     s3, i3 = two.bruteforce_topk(q, k, mse.MODE_MFMA)
     assert np.array_equal(s3, ws) and np.array_equal(i3, wi)
     two.close()
+
+
+def test_bench_rccl_probe_runs_in_a_child_process(gpu):
+    """bench.py --gpus N probes the in-process RCCL exchange in a child process under a timeout before relying on it; here the
+    same probe on as many devices as are visible (one device: a world of one)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    pr = subprocess.run([sys.executable, "-c", bench.rccl_probe_code(gpu)], capture_output=True, text=True, timeout=300)
+    assert "PROBE_OK" in pr.stdout, pr.stderr[-500:]
 
 
 def test_shard_group_errors(gpu, mse):
