@@ -228,17 +228,23 @@ def test_last_error_is_thread_local(gpu, mse):
     assert ffi.last_error() == before                                # the failing thread's message did not leak here
 
 
-def test_config4_full_size_1e8_eight_shards(gpu, mse, orc):
+@pytest.mark.parametrize("staged", [False, True])
+def test_config4_full_size_1e8_eight_shards(gpu, mse, orc, monkeypatch, staged):
     """BASELINE configs[3]: the 1e8 x 1152 index sharded 8 ways (12.5 M rows = 28.8 GB per shard), here as eight logical shards
     on the one device (230 GB resident), through mse_shard_group.  The oracle cannot scan 1e8 rows in a test, so:
-    size-independent properties, with every returned score re-derived by the oracle from regenerated rows."""
+    size-independent properties, with every returned score re-derived by the oracle from regenerated rows.
+    staged: MSE_SHARD_NO_PEER=1 -- every shard takes the path of a device that cannot map the root's memory (queries copied in,
+    packed block copied back), at full size."""
     from mse import ffi
+    if staged:
+        monkeypatch.setenv("MSE_SHARD_NO_PEER", "1")
     free_b, total_b = ffi.sz(), ffi.sz()
     ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
     n, G, nq, k = 100_000_000, 8, 136, 10
     if free_b.value < n * D * 2 + (24 << 30):
         pytest.skip(f"needs {n * D * 2 / 1e9:.0f} GB of free HBM, {free_b.value / 1e9:.0f} GB free")
     grp = mse.ShardGroup(G, D, devices=[0] * G)
+    assert sum(grp.peer_mapped(g) for g in range(G)) == (0 if staged else G)
     grp.generate(SEED_BASE, 0, n)
     assert len(grp) == n
     q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
