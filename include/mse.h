@@ -220,6 +220,10 @@ int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, co
  * vectors are then found inside the r best groups (exact, ties by lower id). */
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
+/* Batches of >= 4 queries go through the codes four queries per pass: a 12-bit integer nomination scan whose answer is certified
+ * against the reference-order re-score of the nominated vectors (csrc/pq.hip); a query whose certificate does not hold is repeated
+ * through the exact scan, so results are identical either way.  This counts such repeats in the last batch call. */
+uint32_t mse_pq_last_uncertified(mse_pq* pq);
 /* test hook: the group maxima (best ADC score + descriptor bias of every 64 vectors, INT64_MIN past the end) the flat scan
  * nominates with; lut1 == NULL: the one-query kernel, else the two-queries-per-pass kernel.  out0 / out1: [ceil(n/64)] on the host. */
 int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, const float* lut1, const float* scales, int64_t* out0,

@@ -382,6 +382,71 @@ static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, cons
     return 0;
 }
 
+// FOUR queries in one pass over the codes (pq_scan64x4_kernel: 12-bit integer nomination under a certificate, pq.hip).  Per query:
+// the n_nom best groups by their integer maximum (+ one more, whose key bounds everything excluded) -> their vectors re-scored in the
+// reference's arithmetic (pq_adc_kernel) -> exact top-r among them -> certificate flag (1 = provably the exact top-r of all
+// vectors) -> with base vectors the same fast_dot re-score as the other paths.  flags_dev[j] = 0 asks the caller to repeat query j
+// through the exact scan.  lut_dev: 4 tables; t_dev: 4 transformed queries.
+static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* queries_dev, float* t_dev, float* lut_dev,
+                            uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k, int64_t* out_scores_dev,
+                            uint32_t* out_ids_dev, int* flags_dev) {
+    hipStream_t st = s->stream;
+    const size_t d = pq->d, lut_floats = pq->n_chunks * pq->n_centroids;
+    const uint8_t* desc = scales_dev ? c->desc : nullptr;
+    for (int j = 0; j < 4; j++)
+        if (prep_table(pq, s, queries_dev + j * d, t_dev + j * d, lut_dev + j * lut_floats)) return -1;
+    const size_t n_groups = (c->n + 63) / 64;
+    // nominate r + max(64, r / 2) groups: the certificate needs every group whose integer maximum lies within ~2 eps of the r-th
+    // exact score (a few tens of vectors at 1e8 codes); one more group is selected only for its key
+    const size_t n_nom = std::min(n_groups, r + std::max<size_t>(64, r / 2));
+    const size_t n_sel = std::min(n_groups, n_nom + 1);
+    if (n_sel > (size_t)TOPK_KMAX) return fail("pq scan: r too large for the four-query scan");
+    if (s->levels[5].ensure(pq4_table_bytes() + 4 * sizeof(Pq4Params)) || s->gmax.ensure(4 * n_groups * 4)) return -1;
+    void* table = s->levels[5].p;                                   // levels[5] is never reached by a descent (<= 3 levels at 2^32 rows / 64)
+    Pq4Params* params = reinterpret_cast<Pq4Params*>(s->levels[5].as<char>() + pq4_table_bytes());
+    if (launch_pq4_table(lut_dev, scales_dev, 4, table, params, st)) return -1;
+    if (launch_pq_scan_gmax4(table, c->codes, c->n, desc, s->gmax.as<uint32_t>(), s->n_cu, st)) return -1;
+    // the four tails as ONE chain of launches with a query dimension (their kernels are latency-bound: four chains in a row cost more
+    // than the scan); every buffer at its final size before the first kernel that uses it
+    const size_t n_cand = n_nom * 64;
+    if (s->gkeys.ensure(4 * std::max(k, n_sel) * 8) || s->cand_ids.ensure(4 * n_cand * 4) || s->cand_scores.ensure(4 * std::max(r, n_cand) * 8) ||
+        s->out_ids.ensure(4 * r * 4) || s->sel_keys.ensure(4 * r * 8) || s->misc.ensure(4 * k * 4) || s->scores.ensure(4 * k * 8)) return -1;
+    uint32_t* gsel = nullptr;
+    LevelRef l0{KEY_U32, s->gmax.p, n_groups, 1, n_groups, false, 0};
+    if (descend(s, l0, 4, (int)n_sel, &gsel, s->gkeys.p)) return -1;                       // gsel [4][n_sel], gkeys u32 [4][n_sel]
+    if (launch_expand_groups(gsel, n_sel, n_nom, 64, c->n, s->cand_ids.as<uint32_t>(), n_cand, 4, st)) return -1;
+    if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), n_cand, desc,
+                      (int)c->n_desc, scales_dev, s->cand_scores.as<int64_t>(), s->n_cu, st, 4, n_cand)) return -1;
+    {
+        SelectArgs a{};
+        a.kind = KEY_I64; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p; a.list_stride = n_cand;
+        a.n_list = n_cand; a.k = (int)r; a.out_ids = s->out_ids.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = r; a.nq = 4;
+        if (launch_select(a, st)) return -1;
+    }
+    if (launch_pq4_certify(params, s->gkeys.as<uint32_t>(), (int)n_nom, (int)n_sel, s->out_ids.as<uint32_t>(), s->sel_keys.as<int64_t>(), r,
+                           (int)std::min(r, c->n), 4, flags_dev, st)) return -1;
+    const uint32_t* top_ids = s->out_ids.as<uint32_t>();      // [4][r]
+    const int64_t* top_scores = s->sel_keys.as<int64_t>();
+    size_t top_stride = r;
+    if (s->base) {
+        // exact re-score: f16(query) . base[id] (+ descriptor bias), query_disk_index.rs:168-170,477 -- four queries per launch
+        const mse_base* b = s->base;
+        if (launch_f32_to_f16(queries_dev, 4 * d, qf16_dev, st)) return -1;
+        if (launch_score_rows(b->dev, b->n, (int)d, qf16_dev, false, top_ids, 4 * r, r, s->cand_scores.as<int64_t>(), nullptr, st)) return -1;
+        if (launch_add_descriptor(top_ids, 4 * r, desc, (int)c->n_desc, c->n, scales_dev, s->cand_scores.as<int64_t>(), st)) return -1;
+        SelectArgs b2{};
+        b2.kind = KEY_I64; b2.list_ids = top_ids; b2.list_keys = s->cand_scores.p; b2.list_stride = r; b2.n_list = r;
+        b2.k = (int)k; b2.out_ids = s->misc.as<uint32_t>(); b2.out_keys = s->scores.p; b2.out_stride = k; b2.nq = 4;
+        if (launch_select(b2, st)) return -1;
+        top_ids = s->misc.as<uint32_t>();
+        top_scores = s->scores.as<int64_t>();
+        top_stride = k;
+    }
+    MSE_HIP_TRY(hipMemcpy2DAsync(out_ids_dev, k * 4, top_ids, top_stride * 4, k * 4, 4, hipMemcpyDeviceToDevice, st));
+    MSE_HIP_TRY(hipMemcpy2DAsync(out_scores_dev, k * 8, top_scores, top_stride * 8, k * 8, 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
     if (!pq || !c) return fail("null quantiser or codes");
@@ -392,6 +457,7 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
     for (size_t i = 0; i < nq * k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
     if (c->n == 0) return 0;
     std::lock_guard<std::mutex> g(pq->mu);
+    pq->last_uncertified = 0;
     mse_searcher* s = s_or_null;
     if (!s) {
         if (!pq->scratch && !(pq->scratch = scratch_searcher_new())) return -1;
@@ -406,8 +472,8 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         // all queries (+ scales) go up in ONE copy from pinned memory; every query then runs on the streams; ONE download at the end
         const size_t sc_off = (nq * d * 4 + 255) & ~(size_t)255;
         const size_t sc_bytes = (scales && c->n_desc) ? c->n_desc * 4 : 0;
-        const size_t in_bytes = sc_off + sc_bytes, out_bytes = nq * k * 12;
-        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(2 * d * 4) || pq->c.ensure(2 * pq->n_chunks * pq->n_centroids * 4)) break;
+        const size_t in_bytes = sc_off + sc_bytes, out_bytes = nq * k * 12 + nq * 4;   // scores, ids, certificate flags
+        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(4 * d * 4) || pq->c.ensure(4 * pq->n_chunks * pq->n_centroids * 4)) break;
         if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(out_bytes)) break;
         if (pq->pin_cap < std::max(in_bytes, out_bytes)) {
             if (pq->pin) (void)hipHostFree(pq->pin);
@@ -431,23 +497,51 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
             if (pq->lane2 && pq->lane2->base != s->base) { mse_searcher_free(pq->lane2); pq->lane2 = nullptr; }
             if (!pq->lane2) pq->lane2 = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
             lanes[1] = pq->lane2;
-            if (!lanes[1] || t2.ensure(2 * d * 4) || lut2.ensure(2 * pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
+            if (!lanes[1] || t2.ensure(4 * d * 4) || lut2.ensure(4 * pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
             if (hipStreamSynchronize(st) != hipSuccess) { fail("H2D failed"); break; }   // uploads visible to both streams
         }
-        // queries go through in PAIRS that share one pass over the codes (pq_scan64x2_kernel); pairs alternate between the streams
+        // queries go through in groups that share one pass over the codes: FOURS (integer nomination under a certificate,
+        // pq_scan64x4_kernel), then a PAIR (pq_scan64x2_kernel, exact), then a single one; groups alternate between the streams
+        int* const flags_dev = reinterpret_cast<int*>(s->out_scores.as<char>() + nq * k * 12);
+        if (hipMemsetAsync(flags_dev, 0xff, nq * 4, st) != hipSuccess) { fail("memset failed"); break; }   // non-zero = certified / exact
+        if (lanes[1] && hipStreamSynchronize(st) != hipSuccess) { fail("memset failed"); break; }
+        const uint8_t* desc_dev = scales_dev ? c->desc : nullptr;
+        const bool four_ok = pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc_dev, (int)c->n_desc, scales_dev) &&
+                             r + std::max<size_t>(64, r / 2) + 1 <= (size_t)TOPK_KMAX;
         bool ok = true;
         size_t q = 0;
         for (size_t unit = 0; q < nq && ok; unit++) {
-            const int n_q = nq - q >= 2 ? 2 : 1;
+            const int n_q = (four_ok && nq - q >= 4) ? 4 : nq - q >= 2 ? 2 : 1;
             const int w = lanes[1] ? (int)(unit & 1) : 0;
-            ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, n_q, w ? t2.as<float>() : pq->b.as<float>(),
-                                 w ? lut2.as<float>() : pq->c.as<float>(), w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>(),
-                                 scales_dev, r, k, out_scores_dev + q * k, out_ids_dev + q * k) == 0;
+            float* const tw = w ? t2.as<float>() : pq->b.as<float>();
+            float* const lw = w ? lut2.as<float>() : pq->c.as<float>();
+            uint16_t* const qw = w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>();
+            if (n_q == 4)
+                ok = scan_topk4_async(pq, c, lanes[w], pq->a.as<float>() + q * d, tw, lw, qw, scales_dev, r, k, out_scores_dev + q * k,
+                                      out_ids_dev + q * k, flags_dev + q) == 0;
+            else
+                ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, n_q, tw, lw, qw, scales_dev, r, k,
+                                     out_scores_dev + q * k, out_ids_dev + q * k) == 0;
             q += n_q;
         }
         if (lanes[1] && hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
         if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
-        if (hipMemcpyAsync(pq->pin, s->out_scores.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (four_ok && nq >= 4) {
+            // a query whose certificate did not hold (rare: the band of +-eps around its r-th score reached past the nominated
+            // groups) is repeated through the exact one-query scan, into the same output rows
+            std::vector<int> flags(nq);
+            if (hipMemcpyAsync(flags.data(), flags_dev, nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
+            pq->last_uncertified = 0;
+            for (size_t j = 0; j < nq && ok; j++)
+                if (!flags[j]) {
+                    pq->last_uncertified++;
+                    ok = scan_topk_async(pq, c, s, pq->a.as<float>() + j * d, 1, pq->b.as<float>(), pq->c.as<float>(), s->q_stage.as<uint16_t>(),
+                                         scales_dev, r, k, out_scores_dev + j * k, out_ids_dev + j * k) == 0;
+                }
+            if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
+        }
+        if (hipMemcpyAsync(pq->pin, s->out_scores.p, nq * k * 12, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
         memcpy(scores, pq->pin, nq * k * 8);
         memcpy(ids, static_cast<char*>(pq->pin) + nq * k * 8, nq * k * 4);
@@ -485,6 +579,14 @@ int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, co
     MSE_HIP_TRY(hipMemcpy(out0, g0, n_groups * 8, hipMemcpyDeviceToHost));
     if (lut1) MSE_HIP_TRY(hipMemcpy(out1, g1, n_groups * 8, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// queries of the last mse_pq_scan_topk_batch call whose four-query certificate did not hold and that were repeated through the
+// exact scan (0 for batches of fewer than four queries)
+uint32_t mse_pq_last_uncertified(mse_pq* pq) {
+    if (!pq) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    return pq->last_uncertified;
 }
 
 int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,

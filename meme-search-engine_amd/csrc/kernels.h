@@ -78,14 +78,23 @@ int launch_pq_lut(const float* centroids, int n_centroids, int d, int dpc, const
                   hipStream_t stream);
 int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t n,
                        uint8_t* codes, hipStream_t stream);
+// nq > 1 (gathered ids only): query y uses table lut + y * n_chunks * n_centroids, ids + y * q_stride, out + y * q_stride
 int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t* codes, size_t n_codes,
                   const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, const float* scales, int64_t* out,
-                  int n_cu, hipStream_t stream);
+                  int n_cu, hipStream_t stream, int nq = 1, size_t q_stride = 0);
 bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, int n_desc, const float* scales);
 int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
                         int64_t* gmax, int n_cu, hipStream_t stream);
 int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* codes, size_t n, const uint8_t* desc,
                          const float* scales, int64_t* gmax0, int64_t* gmax1, int n_cu, hipStream_t stream);
+// four queries per pass: 12-bit integer nomination tables + certificate (pq.hip)
+struct Pq4Params { double delta, c, eps; int ok; };
+size_t pq4_table_bytes();
+int launch_pq4_table(const float* luts4, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream);
+int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax4, int n_cu,
+                         hipStream_t stream);
+int launch_pq4_certify(const Pq4Params* params, const uint32_t* group_keys, int n_nominated, int n_sel, const uint32_t* top_ids,
+                       const int64_t* top_scores, size_t top_stride, int r, int nq, int* flag, hipStream_t stream);
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,
                           const float* scales, int64_t* out, hipStream_t stream);
 int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stream);

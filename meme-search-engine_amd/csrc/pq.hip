@@ -208,9 +208,13 @@ __global__ __launch_bounds__(256) void pq_adc_kernel(const float* __restrict__ l
                                                      const uint8_t* __restrict__ codes, size_t n_codes,
                                                      const uint32_t* __restrict__ ids, size_t n,
                                                      const uint8_t* __restrict__ desc, int n_desc,
-                                                     const float* __restrict__ scales, int64_t* __restrict__ out) {
+                                                     const float* __restrict__ scales, int64_t* __restrict__ out,
+                                                     size_t q_stride /* blockIdx.y = query: ids / out advance by this, lut by one table */) {
     extern __shared__ __attribute__((aligned(16))) float s_lut[];
     const int lut_n = n_chunks * n_centroids;
+    lut += (size_t)blockIdx.y * lut_n;
+    if (ids) ids += (size_t)blockIdx.y * q_stride;
+    out += (size_t)blockIdx.y * q_stride;
     for (int e = threadIdx.x; e < lut_n; e += blockDim.x) s_lut[e] = lut[e];
     __syncthreads();
     const bool vec16 = (n_chunks % 16) == 0;
@@ -469,6 +473,193 @@ __global__ __launch_bounds__(NW * 64) void pq_scan64x2_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Four queries per pass: an INTEGER nomination scan under a certificate (round 3).
+// The flat scan only nominates groups of 64 vectors; the nominated vectors are re-scored in the reference's arithmetic by
+// pq_adc_kernel and the answer is taken among those.  So the scan itself need not reproduce the f32 sums -- it needs a score that
+// brackets them.  Per query the table is quantised to 12 bits against ONE step delta (so that integer sums are comparable):
+//     e[c][v] = round((lut[c][v] - lo_c) / delta) in [0, 4095],  delta = max_c (hi_c - lo_c) / 4095
+// and the four descriptor terms sc_j * v (query_disk_index.rs:135-142) become four more chunks of the same table (<= 16383 each).
+// Four queries' entries sit side by side in 8 bytes, so ONE ds_read_b64 gather serves four queries, and their sums ride in packed
+// 16-bit lanes (v_pk_add_u16: 16 x 4095 < 2^16, widened to 32 bits every 16 chunks): per query a quarter of the LDS cycles and of the
+// HBM bytes of the one-query scan.  With S = the integer sum of a vector and C = sum_c lo_c, the real-valued ADC score X satisfies
+// |X - (delta S + C)| <= 34 delta (68 roundings of at most delta / 2), and the reference-order i64 score R satisfies
+// |R / 2^32 - X| <= 64 u A + bias rounding + 5 truncations (u = 2^-24, A = sum_c max |lut[c]|): together eps (pq4_table_kernel).
+// Certificate (pq4_certify_kernel): nominate R' groups by their maximum S, re-score them exactly, take the exact top-r; every vector
+// outside the nominated groups has S <= g = the (R'+1)-th best group maximum, hence R / 2^32 <= delta g + C + eps.  If the r-th exact
+// score is strictly above that, no excluded vector belongs to the top r.  Otherwise the query is repeated through the exact scan.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int PQ4_CHUNKS = 68;                     // 64 code chunks + 4 descriptor bytes
+constexpr int PQ4_TABLE_BYTES = PQ4_CHUNKS * 256 * 8;   // 136 KiB
+constexpr int PQ4_WAVES = 16;   // 74 VGPRs: register-wise even more would fit; 16 x 64 = the largest workgroup
+
+// one workgroup per query j of the group of four: params[j], and lane j of every table entry
+__global__ __launch_bounds__(256) void pq4_table_kernel(const float* __restrict__ luts /* [4][64 * 256] */, const float* __restrict__ scales,
+                                                        int n_valid, uint16_t* __restrict__ table /* [68 * 256][4] */,
+                                                        Pq4Params* __restrict__ params) {
+    const int j = blockIdx.x, t = threadIdx.x;
+    __shared__ float s_lo[64], s_hi[64];
+    __shared__ double s_inv;
+    __shared__ int s_bad;
+    if (j >= n_valid) {      // unused slots of the group: zero entries
+        for (int e = t; e < PQ4_CHUNKS * 256; e += 256) table[(size_t)e * 4 + j] = 0;
+        if (t == 0) params[j] = Pq4Params{0.0, 0.0, 0.0, 0};
+        return;
+    }
+    const float* lut = luts + (size_t)j * 64 * 256;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    if (t < 64) {
+        float lo = lut[t * 256], hi = lo;
+        bool bad = false;
+        for (int v = 0; v < 256; v++) {
+            const float x = lut[t * 256 + v];
+            bad = bad || !(fabsf(x) <= 3.0e38f);     // NaN or infinity: this query takes the exact scan
+            lo = fminf(lo, x); hi = fmaxf(hi, x);
+        }
+        s_lo[t] = lo; s_hi[t] = hi;
+        if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double range = 0.0, a_sum = 0.0, c_sum = 0.0;
+        for (int c = 0; c < 64; c++) {
+            range = fmax(range, (double)s_hi[c] - (double)s_lo[c]);
+            a_sum += fmax(fabs((double)s_lo[c]), fabs((double)s_hi[c]));
+            c_sum += (double)s_lo[c];
+        }
+        double delta = range / 4095.0, bias_err = 0.0;
+        if (scales) {
+            for (int d = 0; d < 4; d++) {
+                const double sc = (double)scales[d];
+                delta = fmax(delta, fabs(sc) * 255.0 / 16383.0);
+                c_sum += fmin(0.0, sc * 255.0);                       // lo of descriptor chunk d
+                bias_err += fabs(sc) * 255.0 * 5.9604644775390625e-8;  // rounding of the f32 product sc * v
+                if (!(fabs(sc) <= 3.0e38)) s_bad = 1;
+            }
+        }
+        if (!(delta > 1e-300)) delta = 1e-300;
+        s_inv = 1.0 / delta;
+        // 34 delta (68 entry roundings) + f32 summation + bias products + five i64 truncations, with a relative cushion for the
+        // double arithmetic of this bound itself
+        const double eps = (34.0 * delta + 64.0 * 5.9604644775390625e-8 * 1.01 * a_sum + bias_err + 5.0 / 4294967296.0) * (1.0 + 1e-9) + 1e-300;
+        params[j] = Pq4Params{delta, c_sum, eps, s_bad ? 0 : 1};
+    }
+    __syncthreads();
+    const double inv = s_inv;
+    for (int c = 0; c < 64; c++) {
+        double q = ((double)lut[c * 256 + t] - (double)s_lo[c]) * inv;
+        q = q < 0.0 ? 0.0 : (q > 4095.0 ? 4095.0 : q);
+        table[((size_t)c * 256 + t) * 4 + j] = (uint16_t)__double2int_rn(q);
+    }
+    for (int d = 0; d < 4; d++) {
+        double q = 0.0;
+        if (scales) {
+            const double sc = (double)scales[d];
+            q = (sc * (double)t - fmin(0.0, sc * 255.0)) * inv;
+            q = q < 0.0 ? 0.0 : (q > 16383.0 ? 16383.0 : q);
+        }
+        table[((size_t)(64 + d) * 256 + t) * 4 + j] = (uint16_t)__double2int_rn(q);
+    }
+}
+
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) + __builtin_bit_cast(u16x2v, b)));
+}
+// maximum of a u32 over the 64 lanes of the wave, returned in an SGPR: four DPP steps inside each 16-lane row, then the four rows
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+    v = dpp_umax<0xb1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_umax<0x4e>(v);    // quad_perm [2,3,0,1]
+    v = dpp_umax<0x141>(v);   // row_half_mirror
+    v = dpp_umax<0x140>(v);   // row_mirror: every lane now holds its row's maximum
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+}
+
+// out[j * n_groups + g] = max over the 64 vectors of group g of query j's integer sum (0 past the end of the codes)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const u32x2v* __restrict__ table, const uint8_t* __restrict__ codes, size_t n,
+                                                             const uint8_t* __restrict__ desc, uint32_t* __restrict__ out, size_t n_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    require_lds_base_zero(smem);
+    u32x2v* s_tab = reinterpret_cast<u32x2v*>(smem);
+    for (int e = threadIdx.x; e < PQ4_CHUNKS * 256; e += blockDim.x) s_tab[e] = table[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t stride = (size_t)gridDim.x * NW;
+    size_t grp = (size_t)blockIdx.x * NW + wave;
+    auto load_rows = [&](size_t gi, uint4 (&w4)[4], uint32_t& dw) {
+        const size_t v = gi * 64 + lane;            // the allocations carry slack for the last, partial group
+        typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+        const u32x4v* row = reinterpret_cast<const u32x4v*>(codes + v * 64);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const u32x4v t = __builtin_nontemporal_load(row + p);
+            w4[p] = uint4{t.x, t.y, t.z, t.w};
+        }
+        dw = (desc && v < n) ? reinterpret_cast<const uint32_t*>(desc)[v] : 0u;
+    };
+    uint4 nx[4];
+    uint32_t dw_next = 0;
+    if (grp < n_groups) load_rows(grp, nx, dw_next);
+    uint32_t sh3 = 3;
+    asm volatile("" : "+v"(sh3));
+    for (; grp < n_groups; grp += stride) {
+        uint4 w4[4] = {nx[0], nx[1], nx[2], nx[3]};
+        const uint32_t dw = dw_next;
+        if (grp + stride < n_groups) load_rows(grp + stride, nx, dw_next);
+        const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
+                                w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
+        uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int Q = 0; Q < 4; Q++) {
+            u32x2v e[16];
+            gather16<u32x2v, 8>(w, Q, sh3, e);
+            uint32_t a = 0, b = 0;                   // packed 16-bit lanes: (q0 | q1 << 16), (q2 | q3 << 16); 16 x 4095 < 2^16
+#pragma unroll
+            for (int c = 0; c < 16; c++) { a = pk_add_u16(a, e[c].x); b = pk_add_u16(b, e[c].y); }
+            s0 += a & 0xffffu; s1 += a >> 16; s2 += b & 0xffffu; s3 += b >> 16;
+        }
+        if (desc) {
+            const u32x2v d0 = *lds_at<u32x2v>(code_offset<0>(dw, sh3) + 64 * 2048), d1 = *lds_at<u32x2v>(code_offset<1>(dw, sh3) + 65 * 2048);
+            const u32x2v d2 = *lds_at<u32x2v>(code_offset<2>(dw, sh3) + 66 * 2048), d3 = *lds_at<u32x2v>(code_offset<3>(dw, sh3) + 67 * 2048);
+            const uint32_t a = pk_add_u16(pk_add_u16(d0.x, d1.x), pk_add_u16(d2.x, d3.x));   // 4 x 16383 < 2^16
+            const uint32_t b = pk_add_u16(pk_add_u16(d0.y, d1.y), pk_add_u16(d2.y, d3.y));
+            s0 += a & 0xffffu; s1 += a >> 16; s2 += b & 0xffffu; s3 += b >> 16;
+        }
+        if (grp * 64 + lane >= n) { s0 = 0; s1 = 0; s2 = 0; s3 = 0; }     // past the end: below every real vector's sum (>= 0)
+        const uint32_t m0 = wave_umax(s0), m1 = wave_umax(s1), m2 = wave_umax(s2), m3 = wave_umax(s3);
+        if (lane == 0) {
+            out[grp] = m0; out[n_groups + grp] = m1; out[2 * n_groups + grp] = m2; out[3 * n_groups + grp] = m3;
+        }
+    }
+}
+
+// flag[0] = 1 when the exact top-r found among the nominated groups is provably the exact top-r of ALL vectors (see the header)
+// one thread per query j: group_keys [nq][n_sel], top_ids / top_scores [nq][top_stride]
+__global__ void pq4_certify_kernel(const Pq4Params* __restrict__ params, const uint32_t* __restrict__ group_keys /* best first */,
+                                   int n_nominated, int n_sel, const uint32_t* __restrict__ top_ids, const int64_t* __restrict__ top_scores,
+                                   size_t top_stride, int r, int nq, int* __restrict__ flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nq) return;
+    int ok = params[j].ok;
+    if (ok && n_sel > n_nominated) {     // a best excluded group exists
+        const double ub = params[j].delta * (double)group_keys[(size_t)j * n_sel + n_nominated] + params[j].c + params[j].eps;
+        // the r-th best nominated vector must exist and beat every excluded one strictly
+        ok = top_ids[j * top_stride + r - 1] != ID_NONE && (double)top_scores[j * top_stride + r - 1] > ub * 4294967296.0;
+    }
+    flag[j] = ok;
+}
+
 // out[p] += descriptor_product(scales, ids[p])   (exact re-score path, query_disk_index.rs:169-170)
 __global__ void add_descriptor_kernel(const uint32_t* __restrict__ ids, size_t n, const uint8_t* __restrict__ desc,
                                       int n_desc, size_t n_codes, const float* __restrict__ scales,
@@ -604,10 +795,38 @@ int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* co
     return 0;
 }
 
+// ---- four queries per pass (integer nomination under a certificate; header above pq4_table_kernel) ----
+size_t pq4_table_bytes() { return PQ4_TABLE_BYTES; }
+int launch_pq4_table(const float* luts4, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream) {
+    hipLaunchKernelGGL(pq4_table_kernel, dim3(4), dim3(256), 0, stream, luts4, scales, n_valid, reinterpret_cast<uint16_t*>(table), params);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax4, int n_cu,
+                         hipStream_t stream) {
+    if (n == 0) return 0;
+    const size_t groups = (n + 63) / 64;
+    const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;
+    MSE_DYN_LDS(pq_scan64x4_kernel<PQ4_WAVES>, PQ4_TABLE_BYTES);
+    const unsigned blocks = (unsigned)std::min<size_t>((groups + PQ4_WAVES - 1) / PQ4_WAVES, cus);
+    hipLaunchKernelGGL(pq_scan64x4_kernel<PQ4_WAVES>, dim3(blocks), dim3(PQ4_WAVES * 64), PQ4_TABLE_BYTES, stream,
+                       reinterpret_cast<const u32x2v*>(table), codes, n, desc, gmax4, groups);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_pq4_certify(const Pq4Params* params, const uint32_t* group_keys, int n_nominated, int n_sel, const uint32_t* top_ids,
+                       const int64_t* top_scores, size_t top_stride, int r, int nq, int* flag, hipStream_t stream) {
+    hipLaunchKernelGGL(pq4_certify_kernel, dim3(1), dim3(64), 0, stream, params, group_keys, n_nominated, n_sel, top_ids, top_scores,
+                       top_stride, r, nq, flag);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t* codes, size_t n_codes,
                   const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, const float* scales, int64_t* out,
-                  int n_cu, hipStream_t stream) {
-    if (n == 0) return 0;
+                  int n_cu, hipStream_t stream, int nq, size_t q_stride) {
+    if (n == 0 || nq <= 0) return 0;
+    if (nq > 1 && !ids) return fail("pq_adc: several queries per launch need gathered ids");
     const bool desc_ok = !(desc && scales) || n_desc == 4;
     static const bool old_scan = MSE_DEV_KNOB("MSE_PQ_OLDSCAN");
     if (!ids && n_chunks == 64 && n_centroids == 256 && desc_ok && n == n_codes && !old_scan) {
@@ -627,8 +846,8 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
     size_t blocks = (n + 255) / 256;
     const size_t cap = (size_t)n_cu * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, lut, n_chunks, n_centroids, codes,
-                       n_codes, ids, n, desc, n_desc, scales, out);
+    hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(256), lds, stream, lut, n_chunks, n_centroids, codes,
+                       n_codes, ids, n, desc, n_desc, scales, out, q_stride);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -85,6 +85,7 @@ struct mse_pq {
     mse_searcher* scratch = nullptr;  // stream + scratch for scan calls that bring no searcher (guarded by mu; made on first use)
     mse_searcher* lane2 = nullptr;    // second stream of the batched scan; bound to the base of the call that made it
     mse::DevBuf t2, lut2, qf2;        // its transformed query, table and f16 query
+    uint32_t last_uncertified = 0;    // four-query scan: queries of the last batch whose certificate failed (re-run through the exact scan)
     void* pin = nullptr;              // pinned host staging of the scan entry points (one upload + one download per call, both
     size_t pin_cap = 0;               // truly asynchronous: a pageable source makes the runtime stage and block per copy)
 };

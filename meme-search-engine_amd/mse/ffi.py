@@ -104,6 +104,7 @@ SIGNATURES = {
     "mse_pq_adc_gather": (C.c_int, [vp, vp, f32p, f32p, u32p, sz, i64p]),
     "mse_pq_scan_topk": (C.c_int, [vp, vp, vp, f32p, f32p, sz, sz, i64p, u32p]),
     "mse_pq_scan_topk_batch": (C.c_int, [vp, vp, vp, f32p, sz, f32p, sz, sz, i64p, u32p]),
+    "mse_pq_last_uncertified": (C.c_uint32, [vp]),
     "mse_debug_pq_group_max": (C.c_int, [vp, vp, f32p, f32p, f32p, i64p, i64p]),
     "mse_descriptor_product": (C.c_int64, [f32p, sz, u8p, C.c_uint32]),
     "mse_nb_new": (vp, [sz]),

@@ -276,6 +276,11 @@ class ProductQuantizer:
                                                _p(scores, C.c_int64), _p(ids, C.c_uint32)), "pq_scan_topk_batch")
         return scores, ids
 
+    @property
+    def last_uncertified(self):
+        """Queries of the last scan_topk_batch call that the four-query scan could not certify and repeated through the exact scan."""
+        return int(ffi.lib().mse_pq_last_uncertified(self._h))
+
     def debug_group_max(self, codes, lut0, lut1=None, scales=None):
         """Test hook: the flat scan's group maxima (one i64 per 64 vectors) for one table, or for a pair through the
         two-queries-per-pass kernel."""

@@ -24,7 +24,7 @@ for _ in range(it):
     pq.scan_topk(gc, q, 200, 10, None, scales)
 dt = (time.perf_counter() - t0) / it
 print(f"n={n}: {dt*1e3:.2f} ms per query scan, {n*68/dt/1e9:.0f} GB/s of codes+descriptors, {1/dt:.1f} q/s")
-if len(sys.argv) > 2:   # batched: queries go through in pairs that share one pass over the codes
+if len(sys.argv) > 2:   # batched: queries go through in fours that share one pass over the codes
     nb = int(sys.argv[2])
     qs = (rng.standard_normal((nb, D)) / np.sqrt(D)).astype(np.float32)
     pq.scan_topk_batch(gc, qs, 200, 10, None, scales)
@@ -32,4 +32,4 @@ if len(sys.argv) > 2:   # batched: queries go through in pairs that share one pa
     for _ in range(3):
         pq.scan_topk_batch(gc, qs, 200, 10, None, scales)
     db = (time.perf_counter() - t0) / (3 * nb)
-    print(f"n={n}: batched ({nb} per call, 2 per pass) {db*1e3:.3f} ms per query, {1/db:.1f} q/s, {n*68/(2*db)/1e9:.0f} GB/s of codes+descriptors per pass")
+    print(f"n={n}: batched ({nb} per call, 4 per pass, {pq.last_uncertified} uncertified) {db*1e3:.3f} ms per query, {1/db:.1f} q/s, {n*68/(4*db)/1e9:.0f} GB/s of codes+descriptors per pass")

@@ -209,6 +209,39 @@ def test_group_maxima_equal_the_gathered_scores(gpu, mse, orc, n):
             assert np.array_equal(one[j], want[j]) and np.array_equal(two[j], want[j]), (j, scales is None)
 
 
+def test_pq_four_queries_per_pass_is_certified_and_exact(gpu, mse, orc):
+    """Batches of >= 4 queries go through the codes four per pass: a 12-bit integer nomination scan, the nominated groups re-scored
+    in the reference's arithmetic, and a certificate that no excluded vector can reach the exact r-th score (pq.hip).  On codes with
+    spread-out scores every query must be certified (the fast path really runs) and equal the oracle's ADC ranking; on codes with
+    massive exact ties the certificate cannot hold (strict >), those queries are repeated through the exact scan, and the answer is
+    still the oracle's."""
+    rng = np.random.default_rng(91)
+    cents, T, _, _ = make_pq(orc)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    n, r, k = 300_000, 120, 10
+    codes = rng.integers(0, 256, size=(n, 64), dtype=np.uint8)
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    scales = np.array([0.5, 0, -0.25, 0.125], np.float32) / np.float32(512)
+    qs = (rng.standard_normal((9, D)) / np.sqrt(D)).astype(np.float32)
+    for sc, ds in ((scales, desc), (None, None)):
+        gcodes = mse.Codes(codes, ds)
+        bs, bi = gpq.scan_topk_batch(gcodes, qs, r, k, None, sc)
+        assert gpq.last_uncertified == 0
+        for j, qv in enumerate(qs):
+            lut = opq.preprocess_query(qv)
+            approx = opq.adc_desc(lut, codes, ds, sc) if sc is not None else opq.asymmetric_dot_product(lut, codes)
+            ws, wi = orc.topk_from_scores(approx, k)
+            assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
+    # seven distinct code rows: thousands of vectors share the r-th score exactly
+    tied = rng.integers(0, 256, size=(7, 64), dtype=np.uint8)[rng.integers(0, 7, size=n)]
+    gt = mse.Codes(tied, None)
+    bs, bi = gpq.scan_topk_batch(gt, qs[:4], r, k)
+    assert gpq.last_uncertified == 4
+    for j in range(4):
+        ws, wi = orc.topk_from_scores(opq.asymmetric_dot_product(opq.preprocess_query(qs[j]), tied), k)
+        assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
+
+
 def test_pq_scan_full_size_1e8(gpu, mse, orc):
     """BASELINE.md's configs[4] size: 1e8 x 64-byte codes (+ 4 descriptor bytes), 6.8 GB in HBM.  The oracle cannot scan that in a
     test, so size-independent properties: planted best-possible vectors (the per-chunk argmax codes of a query) come back first,
@@ -234,6 +267,7 @@ def test_pq_scan_full_size_1e8(gpu, mse, orc):
         desc[p] = (255, 0, 0, 0)                          # the largest bias the scales allow
     gcodes = mse.Codes(codes, desc)
     bs, bi = gpq.scan_topk_batch(gcodes, qs, r, k, None, scales)
+    assert gpq.last_uncertified <= 1          # query 0 has four planted vectors tied at the top, far above rank r; random codes certify
     assert sorted(bi[0, :4].tolist()) == sorted(planted) and bi[0, :4].tolist() == sorted(planted)   # equal scores: lower id first
     assert len(set(bs[0, :4].tolist())) == 1
     for j in range(5):
