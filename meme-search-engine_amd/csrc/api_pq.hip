@@ -357,13 +357,14 @@ static int scan_tail_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, cons
 //   -> per query: tournament over the maxima -> the r best groups' r x 64 vectors re-scored by the gather kernel (same arithmetic)
 //   -> exact top-r by ADC score (ties: lower id) -> with base vectors: exact fast_dot re-score of those r (+ descriptor bias), top-k
 // t_dev: transformed queries (fp32 [2][d]) scratch, lut_dev: table scratch (2 x 64 KiB), qf16_dev: f16 copy of a query (8 rows)
+// prepared: lut_dev already holds this group's tables (the batch entry point builds all tables of a call in two launches)
 static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* queries_dev, int n_q, float* t_dev,
                            float* lut_dev, uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k,
-                           int64_t* out_scores_dev, uint32_t* out_ids_dev) {
+                           int64_t* out_scores_dev, uint32_t* out_ids_dev, bool prepared = false) {
     const size_t d = pq->d, lut_floats = pq->n_chunks * pq->n_centroids;
     const uint8_t* desc = scales_dev ? c->desc : nullptr;
     const bool gm = pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc, (int)c->n_desc, scales_dev);
-    for (int j = 0; j < n_q; j++)
+    for (int j = 0; j < n_q && !prepared; j++)
         if (prep_table(pq, s, queries_dev + j * d, t_dev + j * d, lut_dev + j * lut_floats)) return -1;
     const size_t n_groups = (c->n + 63) / 64;
     int64_t* g0 = nullptr;
@@ -389,11 +390,11 @@ static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, cons
 // through the exact scan.  lut_dev: 4 tables; t_dev: 4 transformed queries.
 static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* queries_dev, float* t_dev, float* lut_dev,
                             uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k, int64_t* out_scores_dev,
-                            uint32_t* out_ids_dev, int* flags_dev) {
+                            uint32_t* out_ids_dev, int* flags_dev, bool prepared) {
     hipStream_t st = s->stream;
     const size_t d = pq->d, lut_floats = pq->n_chunks * pq->n_centroids;
     const uint8_t* desc = scales_dev ? c->desc : nullptr;
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < 4 && !prepared; j++)
         if (prep_table(pq, s, queries_dev + j * d, t_dev + j * d, lut_dev + j * lut_floats)) return -1;
     const size_t n_groups = (c->n + 63) / 64;
     // nominate r + max(64, r / 2) groups: the certificate needs every group whose integer maximum lies within ~2 eps of the r-th
@@ -473,7 +474,12 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         const size_t sc_off = (nq * d * 4 + 255) & ~(size_t)255;
         const size_t sc_bytes = (scales && c->n_desc) ? c->n_desc * 4 : 0;
         const size_t in_bytes = sc_off + sc_bytes, out_bytes = nq * k * 12 + nq * 4;   // scores, ids, certificate flags
-        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(4 * d * 4) || pq->c.ensure(4 * pq->n_chunks * pq->n_centroids * 4)) break;
+        // batches of 4 .. 2048 queries: all transformed queries and tables up front, in two launches (the same kernels the codec's
+        // batch entry points use; same arithmetic as the one-vector forms) instead of two small launches per query in front of every scan
+        const size_t lut_floats_b = pq->n_chunks * pq->n_centroids;
+        const bool prep_all = nq >= 4 && nq <= 2048;
+        const size_t n_tab = prep_all ? nq : 4;
+        if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(n_tab * d * 4) || pq->c.ensure(n_tab * lut_floats_b * 4)) break;
         if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(out_bytes)) break;
         if (pq->pin_cap < std::max(in_bytes, out_bytes)) {
             if (pq->pin) (void)hipHostFree(pq->pin);
@@ -504,6 +510,9 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         // pq_scan64x4_kernel), then a PAIR (pq_scan64x2_kernel, exact), then a single one; groups alternate between the streams
         int* const flags_dev = reinterpret_cast<int*>(s->out_scores.as<char>() + nq * k * 12);
         if (hipMemsetAsync(flags_dev, 0xff, nq * 4, st) != hipSuccess) { fail("memset failed"); break; }   // non-zero = certified / exact
+        if (prep_all && (launch_pq_transform(pq->transform, (int)d, pq->a.as<float>(), nq, pq->b.as<float>(), st) ||
+                         launch_pq_lut_batch(pq->centroids, (int)pq->n_centroids, (int)d, (int)pq->dpc, pq->b.as<float>(), nq, pq->c.as<float>(), st)))
+            break;
         if (lanes[1] && hipStreamSynchronize(st) != hipSuccess) { fail("memset failed"); break; }
         const uint8_t* desc_dev = scales_dev ? c->desc : nullptr;
         const bool four_ok = pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc_dev, (int)c->n_desc, scales_dev) &&
@@ -513,15 +522,15 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         for (size_t unit = 0; q < nq && ok; unit++) {
             const int n_q = (four_ok && nq - q >= 4) ? 4 : nq - q >= 2 ? 2 : 1;
             const int w = lanes[1] ? (int)(unit & 1) : 0;
-            float* const tw = w ? t2.as<float>() : pq->b.as<float>();
-            float* const lw = w ? lut2.as<float>() : pq->c.as<float>();
+            float* const tw = prep_all ? pq->b.as<float>() + q * d : w ? t2.as<float>() : pq->b.as<float>();
+            float* const lw = prep_all ? pq->c.as<float>() + q * lut_floats_b : w ? lut2.as<float>() : pq->c.as<float>();
             uint16_t* const qw = w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>();
             if (n_q == 4)
                 ok = scan_topk4_async(pq, c, lanes[w], pq->a.as<float>() + q * d, tw, lw, qw, scales_dev, r, k, out_scores_dev + q * k,
-                                      out_ids_dev + q * k, flags_dev + q) == 0;
+                                      out_ids_dev + q * k, flags_dev + q, prep_all) == 0;
             else
                 ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, n_q, tw, lw, qw, scales_dev, r, k,
-                                     out_scores_dev + q * k, out_ids_dev + q * k) == 0;
+                                     out_scores_dev + q * k, out_ids_dev + q * k, prep_all) == 0;
             q += n_q;
         }
         if (lanes[1] && hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
@@ -536,8 +545,9 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
             for (size_t j = 0; j < nq && ok; j++)
                 if (!flags[j]) {
                     pq->last_uncertified++;
-                    ok = scan_topk_async(pq, c, s, pq->a.as<float>() + j * d, 1, pq->b.as<float>(), pq->c.as<float>(), s->q_stage.as<uint16_t>(),
-                                         scales_dev, r, k, out_scores_dev + j * k, out_ids_dev + j * k) == 0;
+                    ok = scan_topk_async(pq, c, s, pq->a.as<float>() + j * d, 1, pq->b.as<float>() + (prep_all ? j * d : 0),
+                                         pq->c.as<float>() + (prep_all ? j * lut_floats_b : 0), s->q_stage.as<uint16_t>(), scales_dev, r, k,
+                                         out_scores_dev + j * k, out_ids_dev + j * k, prep_all) == 0;
                 }
             if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
         }

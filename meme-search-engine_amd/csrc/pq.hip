@@ -509,16 +509,24 @@ __global__ __launch_bounds__(256) void pq4_table_kernel(const float* __restrict_
     const float* lut = luts + (size_t)j * 64 * 256;
     if (t == 0) s_bad = 0;
     __syncthreads();
-    if (t < 64) {
-        float lo = lut[t * 256], hi = lo;
+    // per-chunk minimum / maximum over the 256 entries: thread t holds entry t of every chunk, waves reduce by shuffles
+    __shared__ float s_wlo[4][64], s_whi[4][64];
+    {
         bool bad = false;
-        for (int v = 0; v < 256; v++) {
-            const float x = lut[t * 256 + v];
+        for (int c = 0; c < 64; c++) {
+            const float x = lut[c * 256 + t];
             bad = bad || !(fabsf(x) <= 3.0e38f);     // NaN or infinity: this query takes the exact scan
-            lo = fminf(lo, x); hi = fmaxf(hi, x);
+            float lo = x, hi = x;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+            if ((t & 63) == 0) { s_wlo[t >> 6][c] = lo; s_whi[t >> 6][c] = hi; }
         }
-        s_lo[t] = lo; s_hi[t] = hi;
         if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    if (t < 64) {
+        s_lo[t] = fminf(fminf(s_wlo[0][t], s_wlo[1][t]), fminf(s_wlo[2][t], s_wlo[3][t]));
+        s_hi[t] = fmaxf(fmaxf(s_whi[0][t], s_whi[1][t]), fmaxf(s_whi[2][t], s_whi[3][t]));
     }
     __syncthreads();
     if (t == 0) {

@@ -71,8 +71,8 @@ MSE_SIGLIP_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OU
 summarise $(find $OUT/siglip1 -name "*kernel_stats.csv" | head -1) "# MSE_SIGLIP_STREAMS=1 rocprofv3 --kernel-trace --stats -- python scripts/siglip_bench.py 256 3 27   (the same forward on ONE stream: kernels run back to back, the per-kernel durations are an attribution of the wall time; 4 forwards).  $(grep 'img/s' $OUT/siglip1.log | tail -1)" $OUT/r03_siglip_b256_one_stream_kernel_stats.txt
 fi
 if [ "${1:-all}" = "all" ] || [ "$1" = "pq" ]; then
-# 4. PQ scan, batched (pairs of queries share a pass), at BASELINE.md's 1e8 codes
+# 4. PQ scan, batched (four queries share a pass), at BASELINE.md's 1e8 codes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pq -o q -- python $R/scripts/pq_scan_bench.py 1e8 32 > $OUT/pq.log 2>&1
-summarise $(find $OUT/pq -name "*kernel_stats.csv" | head -1) "# rocprofv3 --kernel-trace --stats -- python scripts/pq_scan_bench.py 1e8 32   (1e8 x 64-byte codes + 4 descriptor bytes, top-200; 11 one-query calls, then 4 calls of 32 queries = 64 two-query passes).  $(grep 'per query' $OUT/pq.log | tail -2 | tr '\n' ' ')" $OUT/r03_pq_scan_stats.txt
+summarise $(find $OUT/pq -name "*kernel_stats.csv" | head -1) "# rocprofv3 --kernel-trace --stats -- python scripts/pq_scan_bench.py 1e8 32   (1e8 x 64-byte codes + 4 descriptor bytes, top-200; 11 one-query calls, then 4 calls of 32 queries = 32 four-query passes).  $(grep 'per query' $OUT/pq.log | tail -2 | tr '\n' ' ')" $OUT/r03_pq_scan_stats.txt
 fi
 ls -la $OUT/*.txt $OUT/*.json
