@@ -77,11 +77,24 @@ __global__ __launch_bounds__(256) void reduce_max_gq_kernel(const float* __restr
     if (q >= nq || g >= n_out) return;
     const size_t lo = g * TOPK_FANOUT;
     const size_t hi = lo + TOPK_FANOUT < n_in ? lo + TOPK_FANOUT : n_in;
-    uint32_t best = 0;
-    for (size_t i = lo; i < hi; i++) {
-        const uint32_t k = key_of(in[i * nq_pad + q]);
-        best = k > best ? k : best;
+    // eight independent loads in flight per thread (the plain loop issued them one at a time: 4.0 of a possible ~5.5 TB/s over the
+    // 3.2 GB of group maxima of a 1e8-row, 256-query pass)
+    uint32_t b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = lo;
+    for (; i + 8 <= hi; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t k = key_of(in[(i + u) * nq_pad + q]);
+            b[u] = k > b[u] ? k : b[u];
+        }
     }
+    for (; i < hi; i++) {
+        const uint32_t k = key_of(in[i * nq_pad + q]);
+        b[0] = k > b[0] ? k : b[0];
+    }
+    uint32_t best = b[0];
+#pragma unroll
+    for (int u = 1; u < 8; u++) best = b[u] > best ? b[u] : best;
     out[(size_t)q * out_stride + g] = best;
 }
 
