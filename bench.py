@@ -509,7 +509,7 @@ def server_bench(eng, cfg, engine_batch):
         loop.run_until_complete(runner.setup())
         site = web.TCPSite(runner, "127.0.0.1", 0)
         loop.run_until_complete(site.start())
-        state["port"] = site._server.sockets[0].getsockname()[1]
+        state["port"] = runner.addresses[0][1]
         state["runner"] = runner
         ready.set()
         loop.run_forever()

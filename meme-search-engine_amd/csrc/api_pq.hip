@@ -402,9 +402,9 @@ static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, con
     const size_t n_nom = std::min(n_groups, r + std::max<size_t>(64, r / 2));
     const size_t n_sel = std::min(n_groups, n_nom + 1);
     if (n_sel > (size_t)TOPK_KMAX) return fail("pq scan: r too large for the four-query scan");
-    if (s->levels[5].ensure(pq4_table_bytes() + 4 * sizeof(Pq4Params)) || s->gmax.ensure(4 * n_groups * 4)) return -1;
-    void* table = s->levels[5].p;                                   // levels[5] is never reached by a descent (<= 3 levels at 2^32 rows / 64)
-    Pq4Params* params = reinterpret_cast<Pq4Params*>(s->levels[5].as<char>() + pq4_table_bytes());
+    if (s->pq4.ensure(pq4_table_bytes() + 4 * sizeof(Pq4Params)) || s->gmax.ensure(4 * n_groups * 4)) return -1;
+    void* table = s->pq4.p;
+    Pq4Params* params = reinterpret_cast<Pq4Params*>(s->pq4.as<char>() + pq4_table_bytes());
     if (launch_pq4_table(lut_dev, scales_dev, 4, table, params, st)) return -1;
     if (launch_pq_scan_gmax4(table, c->codes, c->n, desc, s->gmax.as<uint32_t>(), s->n_cu, st)) return -1;
     // the four tails as ONE chain of launches with a query dimension (their kernels are latency-bound: four chains in a row cost more

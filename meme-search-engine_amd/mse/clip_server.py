@@ -193,12 +193,15 @@ class ClipServer:
                         total += len(nxt.stage[1])
                 if len(group) == 1:
                     self._model_work(job, engine)
+                    group = []
                 else:
                     rows = self.run_model("bmp", [im for j in group for im in j.stage[1]], engine)
                     at = 0
-                    for j in group:
+                    while group:
+                        j = group[0]
                         n = len(j.stage[1])
                         j.finish(True, rows[at:at + n])
+                        group.pop(0)           # answered: must not be answered again if a later hand-back fails
                         at += n
             except Exception as e:  # noqa: BLE001 - every failure is reported to the client as a 500 string
                 traceback.print_exc()

@@ -232,6 +232,22 @@ def test_pq_four_queries_per_pass_is_certified_and_exact(gpu, mse, orc):
             approx = opq.adc_desc(lut, codes, ds, sc) if sc is not None else opq.asymmetric_dot_product(lut, codes)
             ws, wi = orc.topk_from_scores(approx, k)
             assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
+    # a query whose table overflows f32 (entries +-inf): no integer table can bracket it -- that query is not certified and takes the
+    # exact scan, the other three of its group are unaffected; r too large for the four-query scan's selection: the exact pair path
+    wild = qs[:4].copy()
+    wild[2] *= np.float32(3e38)
+    gcodes = mse.Codes(codes, None)
+    bs, bi = gpq.scan_topk_batch(gcodes, wild, r, k)
+    assert gpq.last_uncertified == 1
+    for j in range(4):
+        s1, i1 = gpq.scan_topk(gcodes, wild[j], r, k)
+        assert np.array_equal(bs[j], s1) and np.array_equal(bi[j], i1), j
+    big_r = 1900
+    bs, bi = gpq.scan_topk_batch(gcodes, qs[:4], big_r, k)
+    assert gpq.last_uncertified == 0
+    for j in range(4):
+        ws, wi = orc.topk_from_scores(opq.asymmetric_dot_product(opq.preprocess_query(qs[j]), codes), k)
+        assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
     # seven distinct code rows: thousands of vectors share the r-th score exactly
     tied = rng.integers(0, 256, size=(7, 64), dtype=np.uint8)[rng.integers(0, 7, size=n)]
     gt = mse.Codes(tied, None)
