@@ -362,7 +362,7 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __r
     int buf = 0;
 #ifdef MSE_DEV_KERNELS
     uint32_t pt_issue = 0, pt_wait = 0, pt_bar = 0, pt_n = 0, pt_last = 0;
-    if constexpr (PROF) pt_last = memtime();
+    if constexpr (PROF == 1) pt_last = memtime();
 #endif
     while (true) {
         accv acc[NRT][NCTW];
@@ -422,14 +422,16 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __r
                         }
                     }
                     const half8 b = as_half8(bq[t % 3]);
+                    if constexpr (PROF == 3) __builtin_amdgcn_s_setprio(1);   // developer variant: MFMA groups at raised issue priority
 #pragma unroll
                     for (int rt = 0; rt < NRT; rt++) {
                         if constexpr (MF == 16) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks & 1][rt], b, acc[rt][ct], 0, 0, 0);
                         else acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks & 1][rt], b, acc[rt][ct], 0, 0, 0);
                     }
+                    if constexpr (PROF == 3) __builtin_amdgcn_s_setprio(0);
                 }
 #ifdef MSE_DEV_KERNELS
-                if constexpr (PROF) {
+                if constexpr (PROF == 1) {
                     const uint32_t t0 = memtime();
                     vm_wait<4>();
                     const uint32_t t1 = memtime();
@@ -476,12 +478,12 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __r
 #pragma unroll
         for (int u = 0; u < 4; u++) rp[u] = rn[u];
 #ifdef MSE_DEV_KERNELS
-        if constexpr (PROF) pt_last = memtime();   // the epilogue is not charged to the next K block
+        if constexpr (PROF == 1) pt_last = memtime();   // the epilogue is not charged to the next K block
 #endif
     }
     vm_wait<0>();
 #ifdef MSE_DEV_KERNELS
-    if constexpr (PROF) {
+    if constexpr (PROF == 1) {
         if (lane == 0) {
             atomicAdd(&g_scan_prof[0], (unsigned long long)pt_issue); atomicAdd(&g_scan_prof[1], (unsigned long long)pt_wait);
             atomicAdd(&g_scan_prof[2], (unsigned long long)pt_bar); atomicAdd(&g_scan_prof[3], (unsigned long long)pt_n);
@@ -726,6 +728,7 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     else if (nq_pad == 256 && S == 3 && v2d == 0) rc = launch_variant<3, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     else if (nq_pad == 256 && S == 3 && v2d == 161) rc = launch_2d<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     else if (nq_pad == 256 && S == 3 && v2d == 162) rc = launch_2d<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && v2d == 163) rc = launch_2d<3, 16, 3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     else if (nq_pad == 256 && S == 3 && v2d == 17) rc = launch_2s<3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     else if (nq_pad == 256 && S == 3 && v2d == 32) rc = launch_2d<3, 32>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
     if (rc != -2) {
