@@ -666,7 +666,8 @@ def main():
         try:
             if probe_err:
                 raise mse.MseError(probe_err)
-            group.set_exchange(group.EXCHANGE_RCCL)
+            with _stdout_to_stderr():      # librccl's banner goes to fd 1; stdout carries the one JSON line only
+                group.set_exchange(group.EXCHANGE_RCCL)
             exchange = {"kind": "one process, a host thread per shard; ONE ncclAllGather (librccl via the C ABI) of the packed 12 B/record "
                                 "blocks per step, rank g = shard g on device g", "shards": n_gpus,
                         "devices": [group.device(g) for g in range(n_gpus)], "rccl_ranks": group.rccl_ranks,
