@@ -758,8 +758,9 @@ def main():
             gathered_dev[:world * bb].copy_(torch.cat(parts))
             ffi.check(ffi.lib().mse_merge_topk_packed_dev(searcher._h, gathered_dev.data_ptr(), world, n_q, k, dst_s.data_ptr(), dst_i.data_ptr()))
 
-    for i in range(args.warmup):
-        step(i)
+    with _stdout_to_stderr():          # anything a library prints on first use (RCCL at its first collective) stays off stdout
+        for i in range(args.warmup):
+            step(i)
     searcher.scan_timing(2)
     sync_all()
     t0 = time.perf_counter()
