@@ -287,3 +287,66 @@ def test_server_with_hip_engine(gpu, mse):
     want = ref.encode_image(x, sd, dict(ref.CONFIG, depth=2)).numpy()
     cos = (got * want).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(want, axis=1)
     assert np.all(cos > 1 - 1e-3), cos
+
+
+def test_queued_bmp_jobs_run_as_one_call_and_go_back_to_their_requests(mse):
+    """The model thread runs the BMP jobs waiting in its queue as ONE engine call (up to the engine's batch capacity) and hands
+    every request its own rows; replicas get a model thread each.  A stand-in engine that records its calls (no GPU): three jobs
+    queued behind a blocked one are coalesced, rows go back in request order, a job that would overflow the capacity runs alone,
+    and a failing call answers every job of its group with the error -- once."""
+    import threading
+    from mse.clip_server import ClipServer, Job
+
+    class Recorder:
+        embedding_size, max_batch, image_size = 8, 6, (2, 2)
+
+        def __init__(self):
+            self.calls, self.gate = [], threading.Event()
+
+        def encode_bmp(self, files):
+            self.gate.wait(10)
+            self.calls.append(len(files))
+            if any(f == b"boom" for f in files):
+                raise RuntimeError("bad image")
+            return np.stack([np.full(8, float(f[0]), np.float32) for f in files])
+
+    eng = Recorder()
+    srv = ClipServer(dict(CONFIG, max_batch_size=3), eng)
+    loop = asyncio.new_event_loop()
+    jobs = []
+    for tag, n in ((1, 1), (2, 2), (3, 3), (4, 3), (5, 1)):        # 1 runs alone (the thread is already in it); 2 + 3 = 5 <= 6; 4 would make 8
+        j = Job(None, [bytes([tag]) * 4] * n, loop)
+        j.stage = ("bmp", list(j.images))
+        jobs.append(j)
+    srv.model_q.put(jobs[0])
+    th = threading.Thread(target=srv._model_loop, args=(eng,), daemon=True)
+    th.start()
+    import time
+    time.sleep(0.2)                                                # the thread now waits inside call 1
+    for j in jobs[1:]:
+        srv.model_q.put(j)
+    eng.gate.set()
+
+    async def collect():
+        return [await j.done for j in jobs]
+
+    results = loop.run_until_complete(asyncio.wait_for(collect(), 20))
+    assert eng.calls == [1, 5, 4]                                  # [job 1] [jobs 2 + 3] [jobs 4 + 5]
+    for (ok, rows), (tag, n) in zip(results, ((1, 1), (2, 2), (3, 3), (4, 3), (5, 1))):
+        assert ok and rows.shape == (n, 8) and np.all(rows == tag)
+    bad = [Job(None, [b"boom"], loop), Job(None, [b"\x07\x07"], loop)]
+    for j in bad:
+        j.stage = ("bmp", list(j.images))
+    eng.gate.clear()
+    srv.model_q.put(Job(None, [b"\x09"], loop))
+    srv.model_q.queue[-1].stage = ("bmp", [b"\x09"])
+    first = srv.model_q.queue[-1]
+    time.sleep(0.2)
+    for j in bad:
+        srv.model_q.put(j)
+    eng.gate.set()
+    res = loop.run_until_complete(asyncio.wait_for(asyncio.gather(first.done, bad[0].done, bad[1].done), 20))
+    assert res[0][0] and not res[1][0] and not res[2][0] and "bad image" in res[1][1] and res[1][1] == res[2][1]
+    srv.model_q.put(srv._stop)
+    th.join(10)
+    assert not th.is_alive()
