@@ -1716,6 +1716,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attention64_kernel(const uint16_t*
         if (tile + AT6_NS - 1 < nt) issue(tile + AT6_NS - 1);
         const char* kst = lds + (tile % AT6_NS) * AT6_STAGE;
         const char* vst = kst + AT6_KT;
+        // a wave whose queries all lie past the last token (the last wave of the last query block: tokens 736 .. 767 of 729) only
+        // takes part in the staging and the barriers: 1 / 24 of all waves did the full arithmetic for rows nobody stores
+        if (q0 >= tokens) continue;
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int kt = tile * 64 + hh * 32;
