@@ -78,7 +78,8 @@ void mse_searcher_free(mse_searcher* s);
 int mse_searcher_set_stream(mse_searcher* s, void* hip_stream);
 void* mse_searcher_stream(const mse_searcher* s);
 
-#define MSE_MODE_AUTO 0   /* exact scan for <= 8 queries, batched MFMA scan above that */
+#define MSE_MODE_AUTO 0   /* host-pointer searches: coalesced across threads (mse_dispatcher below); device-pointer searches:
+                             exact scan for <= 8 queries, batched MFMA scan above that */
 #define MSE_MODE_EXACT 1  /* every row scored in the reference order on the vector ALU */
 #define MSE_MODE_MFMA 2   /* f16 MFMA scan for candidates + exact re-score + certificate */
 
@@ -120,6 +121,32 @@ int mse_searcher_scan_timing(mse_searcher* s, int enable, double* total_ms, uint
 /* statistics of the last MFMA-mode call: number of queries whose certificate needed a wider
  * candidate set, and the widest group count used. */
 int mse_searcher_last_stats(const mse_searcher* s, uint32_t* n_widened, uint32_t* max_groups);
+
+/* ---- cross-thread query coalescer ----------------------------------------------------------
+ * The reference serves ONE query per request from many threads at once: `index.search(&query, k)` under a shared read
+ * guard per HTTP request (src/main.rs:896-934,1043-1049), and a thread per core with its own Scratch, one search per
+ * request (src/query_disk_index.rs:711-736).  A pass over the rows costs one MI355X the same for 1 query as for 128, so
+ * those callers must share passes: mse_dispatcher_topk_f16 may be called from any number of threads; callers block, ONE
+ * worker thread (on the device that holds the rows) gathers what is waiting -- until as many queries wait as the last
+ * pass answered, or max_queries_per_pass, or the oldest is max_wait_us old -- runs a single pass (matrix-core scan +
+ * exact re-score + certificate: the same answers as every mode of mse_bruteforce_topk_f16) and hands each caller its rows.
+ * A lone caller never waits for company.  Callers may ask for different k (each gets the first k of the largest k's order);
+ * argument errors are returned to their caller without entering the queue, and if a shared pass fails every request of
+ * it is repeated alone, so a caller only ever sees its own failure.
+ * max_queries_per_pass 0 = 256 (one matrix-core pass); max_wait_us 0 = a tenth of a pass over the rows, 200 us .. 5 ms.
+ * mse_bruteforce_topk_f16(..., MSE_MODE_AUTO, ...) goes through a dispatcher the base makes on first use, so the reference's
+ * thread-per-core loop coalesces without knowing; mse_index_search does the same inside every mse_index. */
+typedef struct mse_dispatcher mse_dispatcher;
+mse_dispatcher* mse_dispatcher_new(const mse_base* b, size_t max_queries_per_pass, uint32_t max_wait_us);
+void mse_dispatcher_free(mse_dispatcher* d);               /* no call may be in flight */
+int mse_dispatcher_topk_f16(mse_dispatcher* d, const uint16_t* queries, size_t nq, size_t k, int64_t* scores, uint32_t* ids);
+/* out: [0] queries answered, [1] requests, [2] passes, [3] most queries in one pass, [4] passes started by the wait budget,
+ * [5] requests repeated alone after a failed shared pass */
+int mse_dispatcher_stats(mse_dispatcher* d, uint64_t out[6]);
+mse_searcher* mse_dispatcher_searcher(mse_dispatcher* d);   /* the worker's searcher, for scan timing / certificate stats; owned by d */
+/* test hook: the next n_passes passes that carry more than one request fail before they start, so that the
+ * repeat-each-request-alone path can be exercised (answers must be unaffected) */
+int mse_debug_dispatcher_fail_shared(mse_dispatcher* d, uint32_t n_passes);
 
 /* ---- row-sharded index over the GPUs of one node.  The reference has no multi-GPU
  * code; its query server is a thread per core, each with its own Scratch over shared read-only maps
@@ -188,7 +215,11 @@ void mse_index_free(mse_index* idx);
 int mse_index_add(mse_index* idx, const float* x, size_t n);            /* fp32 -> fp16 RNE, appended */
 size_t mse_index_ntotal(const mse_index* idx);
 /* distances [nq][k] descending, labels [nq][k], -1 where fewer than k vectors exist (:908). */
+/* Any number of threads may search at once (the shared `index.read()` of src/main.rs:1046); `add` excludes them (`index.write()`,
+ * :1016) and is not starved by them.  Concurrent searches meet in the index's coalescer (above) and share passes: <= 8 waiting
+ * queries over a cache-sized index take the exact pass, anything more ONE matrix-core pass + f32 re-score + certificate. */
 int mse_index_search(mse_index* idx, const float* queries, size_t nq, size_t k, float* distances, int64_t* labels);
+int mse_index_stats(mse_index* idx, uint64_t out[6]);     /* as mse_dispatcher_stats */
 
 /* ---- product quantiser: diskann::vector::ProductQuantizer (vector.rs:308-406) ------------ */
 typedef struct mse_pq mse_pq;

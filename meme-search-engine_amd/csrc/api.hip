@@ -284,6 +284,7 @@ static mse_base* base_alloc(size_t n, size_t d, bool owned) {
     mse_base* b = new (std::nothrow) mse_base();
     if (!b) { fail("out of host memory"); return nullptr; }
     b->n = n; b->d = d; b->owned = owned; b->n_cu = device_cu_count();
+    if (hipGetDevice(&b->device) != hipSuccess) b->device = 0;
     return b;
 }
 mse_base* mse_base_from_host(const uint16_t* data, size_t n_rows, size_t d) {
@@ -319,6 +320,7 @@ mse_base* mse_base_generate(uint32_t seed, uint64_t first_row, size_t n_rows, si
 }
 void mse_base_free(mse_base* b) {
     if (!b) return;
+    if (b->disp) mse_dispatcher_free(b->disp);   // joins its worker; no search may be in flight (as for the rows themselves)
     if (b->owned && b->dev) (void)hipFree(const_cast<uint16_t*>(b->dev));
     if (b->norm_bits_dev) (void)hipFree(b->norm_bits_dev);
     delete b;
@@ -470,6 +472,20 @@ int mse_bruteforce_topk_f16(mse_searcher* s, const uint16_t* queries, size_t nq,
                             uint32_t* ids) {
     if (!s) return fail("null searcher");
     if (nq == 0 || k == 0) return 0;
+    if (mode == MSE_MODE_AUTO && s->base) {
+        // The reference's call shape is a thread per core, each with its own Scratch and ONE query per request
+        // (src/query_disk_index.rs:711-736): such callers meet in the base's coalescer and share a pass over the rows.
+        // Answers are those of every other mode; a lone caller fires its pass at once (dispatch.h).
+        const mse_base* b = s->base;
+        mse_dispatcher* disp = nullptr;
+        {
+            std::lock_guard<std::mutex> g(b->disp_mu);
+            if (!b->disp) b->disp = mse_dispatcher_new(b, 0, 0);
+            disp = b->disp;
+        }
+        if (!disp) return -1;
+        return mse_dispatcher_topk_f16(disp, queries, nq, k, scores, ids);
+    }
     const size_t d = s->base->d;
     DevBuf qd;
     if (qd.ensure(nq * d * 2)) return -1;

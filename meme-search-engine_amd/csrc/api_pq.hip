@@ -1,7 +1,10 @@
 // C ABI, part 2: evaluator ranks, flat fp16 index (FAISS SQfp16-IP semantics), product quantiser.
 #include "../../include/mse.h"
 #include "runtime.h"
+#include "dispatch.h"
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <cfloat>
 #include <cstring>
 #include <new>
@@ -9,12 +12,22 @@
 
 using namespace mse;
 
+// Flat index.  Concurrency is the reference's: searches share, `add` excludes (the RwLock of src/main.rs:1016 write / :1046
+// read).  Searches of all threads meet in the index's coalescer (dispatch.h) and are executed by its ONE worker thread, which
+// is the only user of `scratch` while readers hold the lock; `add` runs on the caller's thread with every reader out.
 struct mse_index {
     int d = 0;
+    int device = 0;
     size_t n = 0, cap = 0;
     uint16_t* codes = nullptr;   // [cap][d] fp16, device
+    mse_base view;               // non-owning view of codes[0..n) for the matrix-core scan; its norm bound grows with every add
     mse_searcher* scratch = nullptr;
-    std::mutex mu;               // add() is exclusive; searches take it too (scratch is shared)
+    mse::SharedExclusive rw;
+    std::unique_ptr<mse::Coalescer> co;
+    void* pin = nullptr;         // pinned staging of the worker: queries up, [distances | labels] down
+    size_t pin_cap = 0;
+    mse::DevBuf q32, out;
+    std::atomic<uint64_t> retried_alone{0};
 };
 
 extern "C" {
@@ -51,6 +64,158 @@ int mse_bruteforce_ranks_f16(mse_searcher* s, const uint16_t* query, const uint3
 }
 
 // ---- flat index -----------------------------------------------------------------------------------
+namespace {
+
+// <= 8 f32 queries against every row in the stated FAISS order (scan_exact.hip, QF32), tournament, ids + f32 keys into
+// out_ids / out_keys ([nq][out_stride], ID_NONE-padded)
+int index_pass_exact(mse_index* idx, const float* q32_dev, int nqp, int k, uint32_t* out_ids, float* out_keys, size_t out_stride) {
+    mse_searcher* s = idx->scratch;
+    hipStream_t st = s->stream;
+    const size_t d = idx->d, n = idx->n;
+    if (s->q_stage.ensure(8 * d * 4) || s->scores.ensure((size_t)nqp * n * 4)) return -1;
+    MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, 8 * d * 4, st));
+    MSE_HIP_TRY(hipMemcpyAsync(s->q_stage.p, q32_dev, (size_t)nqp * d * 4, hipMemcpyDeviceToDevice, st));
+    if (launch_scan_exact(idx->codes, n, (int)d, s->q_stage.p, nqp, true, nullptr, n, s->scores.as<float>(), s->n_cu, st)) return -1;
+    if (s->sel_keys.ensure((size_t)nqp * k * 4)) return -1;
+    uint32_t* sel = nullptr;
+    LevelRef l0{KEY_F32, s->scores.p, n, 1, n, false, 0};
+    if (descend(s, l0, nqp, k, &sel, s->sel_keys.p)) return -1;
+    MSE_HIP_TRY(hipMemcpy2DAsync(out_ids, out_stride * 4, sel, (size_t)k * 4, (size_t)k * 4, nqp, hipMemcpyDeviceToDevice, st));
+    MSE_HIP_TRY(hipMemcpy2DAsync(out_keys, out_stride * 4, s->sel_keys.p, (size_t)k * 4, (size_t)k * 4, nqp, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// Up to 256 f32 queries in ONE pass over the rows.  The matrix cores score f16 roundings of the queries and only nominate:
+// group maxima -> tournament -> the rows of the best groups re-scored with the f32 query in the stated order -> top k ->
+// certificate.  The bound on what the nomination can have missed is the f16 scan's (api.hip mfma_pass) plus the query
+// rounding, |x . (q - f16(q))| <= |x| |q - f16(q)| (measured per query, not assumed).  A query whose certificate fails widens
+// its candidate set and finally repeats through the exact pass: answers equal index_pass_exact's.
+int index_pass_mfma(mse_index* idx, const float* q32_dev, int nqp, int k, uint32_t* out_ids, float* out_keys, size_t out_stride) {
+    mse_searcher* s = idx->scratch;
+    hipStream_t st = s->stream;
+    const int d = idx->d;
+    const size_t n = idx->n;
+    const int nq_pad = nqp > 128 ? 256 : 128;
+    if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;
+    MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, (size_t)nq_pad * d * 2, st));
+    if (launch_f32_to_f16(q32_dev, (size_t)nqp * d, s->q_stage.as<uint16_t>(), st)) return -1;
+    const size_t n_groups = (n + GROUP_ROWS - 1) / GROUP_ROWS;
+    if (s->gmax.ensure(n_groups * (size_t)nq_pad * 4) || s->qpacked.ensure(mfma_packed_bytes(d))) return -1;
+    if (launch_scan_mfma(idx->codes, n, d, s->q_stage.as<uint16_t>(), nq_pad, s->qpacked.p, s->gmax.as<float>(), s->n_cu, st,
+                         s->timing ? s->ev0 : nullptr, s->timing ? s->ev1 : nullptr)) return -1;
+    bool timing_pending = s->timing;
+    if (s->eps.ensure((size_t)nqp * 4) || s->margin.ensure((size_t)nqp * 4)) return -1;
+    if (launch_query_eps_f32(q32_dev, s->q_stage.as<uint16_t>(), nqp, d, idx->view.norm_bits_dev, 2.8e-4f, s->eps.as<float>(), st)) return -1;
+    std::vector<float> margin_h(nqp);
+    int kg = (int)std::min<size_t>(std::max(k + 8, 16), TOPK_KMAX);
+    for (;;) {
+        const int kg_eff = (int)std::min<size_t>(kg, TOPK_KMAX);
+        if (s->gkeys.ensure((size_t)nqp * kg_eff * 4)) return -1;
+        uint32_t* gsel = nullptr;
+        LevelRef l0{KEY_F32, s->gmax.p, 1, (size_t)nq_pad, n_groups, true, nq_pad};
+        if (descend(s, l0, nqp, kg_eff, &gsel, s->gkeys.p)) return -1;
+        const size_t n_cand = (size_t)kg_eff * GROUP_ROWS;
+        if (s->cand_ids.ensure((size_t)nqp * n_cand * 4) || s->cand_scores.ensure((size_t)nqp * n_cand * 4)) return -1;
+        if (launch_expand_groups(gsel, kg_eff, kg_eff, GROUP_ROWS, n, s->cand_ids.as<uint32_t>(), n_cand, nqp, st)) return -1;
+        if (launch_score_rows(idx->codes, n, d, q32_dev, true, s->cand_ids.as<uint32_t>(), (size_t)nqp * n_cand, n_cand, nullptr,
+                              s->cand_scores.as<float>(), st)) return -1;
+        SelectArgs a{};
+        a.kind = KEY_F32; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p;
+        a.list_stride = n_cand; a.n_list = n_cand; a.k = k; a.out_ids = out_ids; a.out_keys = out_keys; a.out_stride = out_stride; a.nq = nqp;
+        if (launch_select(a, st)) return -1;
+        if (launch_margin_f32(out_ids, out_keys, out_stride, k, nqp, s->gkeys.as<float>(), kg_eff, kg_eff, n_groups, s->eps.as<float>(),
+                              s->margin.as<float>(), st)) return -1;
+        MSE_HIP_TRY(hipMemcpyAsync(margin_h.data(), s->margin.p, (size_t)nqp * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        if (timing_pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) { s->scan_ms_total += ms; s->scan_launches++; }
+            timing_pending = false;
+        }
+        uint32_t bad = 0;
+        for (int i = 0; i < nqp; i++) bad += !(margin_h[i] > 0.0f);
+        s->last_max_groups = std::max<uint32_t>(s->last_max_groups, (uint32_t)kg_eff);
+        if (bad == 0 || (size_t)kg_eff >= n_groups) return 0;
+        s->last_widened = std::max(s->last_widened, bad);
+        if (kg_eff >= TOPK_KMAX) {
+            for (int q0 = 0; q0 < nqp; q0 += 8) {
+                const int m = std::min(8, nqp - q0);
+                if (index_pass_exact(idx, q32_dev + (size_t)q0 * d, m, k, out_ids + (size_t)q0 * out_stride,
+                                     out_keys + (size_t)q0 * out_stride, out_stride)) return -1;
+            }
+            return 0;
+        }
+        kg = kg_eff * 4;
+    }
+}
+
+// one engine call for a group of requests (worker thread; every caller of the group holds the shared lock)
+int index_run_group(mse_index* idx, DispatchReq* const* reqs, size_t n_req) {
+    mse_searcher* s = idx->scratch;
+    hipStream_t st = s->stream;
+    const size_t d = idx->d, n = idx->n;
+    size_t total = 0, kmax = 0;
+    for (size_t i = 0; i < n_req; i++) { total += reqs[i]->nq; kmax = std::max(kmax, reqs[i]->k); }
+    if (total == 0 || kmax == 0 || n == 0) return 0;   // outputs were pre-filled with "nothing found"
+    const size_t in_bytes = total * d * 4, out_bytes = total * kmax * 8;
+    if (idx->pin_cap < std::max(in_bytes, out_bytes)) {
+        if (idx->pin) (void)hipHostFree(idx->pin);
+        idx->pin = nullptr; idx->pin_cap = 0;
+        const size_t want = std::max<size_t>(2 * std::max(in_bytes, out_bytes), (size_t)1 << 20);
+        MSE_HIP_TRY(hipHostMalloc(&idx->pin, want, hipHostMallocDefault));
+        idx->pin_cap = want;
+    }
+    if (idx->q32.ensure(in_bytes) || idx->out.ensure(out_bytes)) return -1;
+    char* p = static_cast<char*>(idx->pin);
+    for (size_t i = 0, o = 0; i < n_req; i++) { memcpy(p + o, reqs[i]->queries, reqs[i]->nq * d * 4); o += reqs[i]->nq * d * 4; }
+    MSE_HIP_TRY(hipMemcpyAsync(idx->q32.p, idx->pin, in_bytes, hipMemcpyHostToDevice, st));
+    uint32_t* ids_dev = idx->out.as<uint32_t>();
+    float* keys_dev = reinterpret_cast<float*>(idx->out.as<char>() + total * kmax * 4);
+    s->last_widened = 0; s->last_max_groups = 0;
+    // same rule as the f16 dispatcher (dispatch.hip): the matrix-core pass for more than 8 queries, and for any count once the
+    // rows have outgrown the caches
+    const bool mfma = total > 8 || n >= ((size_t)1 << 22);
+    const size_t tile = mfma ? (size_t)mfma_query_tile() : 8;
+    for (size_t q0 = 0; q0 < total; q0 += tile) {
+        const int m = (int)std::min(tile, total - q0);
+        const int rc = mfma ? index_pass_mfma(idx, idx->q32.as<float>() + q0 * d, m, (int)kmax, ids_dev + q0 * kmax, keys_dev + q0 * kmax, kmax)
+                            : index_pass_exact(idx, idx->q32.as<float>() + q0 * d, m, (int)kmax, ids_dev + q0 * kmax, keys_dev + q0 * kmax, kmax);
+        if (rc) return -1;
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(idx->pin, idx->out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t* ids_h = reinterpret_cast<const uint32_t*>(p);
+    const float* keys_h = reinterpret_cast<const float*>(p + total * kmax * 4);
+    for (size_t i = 0, row = 0; i < n_req; i++) {
+        DispatchReq* r = reqs[i];
+        float* dist = static_cast<float*>(r->out_a);
+        int64_t* lab = static_cast<int64_t*>(r->out_b);
+        for (size_t q = 0; q < r->nq; q++, row++)
+            for (size_t j = 0; j < r->k; j++) {
+                const uint32_t id = ids_h[row * kmax + j];
+                if (id == ID_NONE) continue;
+                dist[q * r->k + j] = keys_h[row * kmax + j];
+                lab[q * r->k + j] = (int64_t)id;
+            }
+    }
+    return 0;
+}
+
+void index_run_batch(mse_index* idx, std::vector<DispatchReq*>& batch) {
+    if (index_run_group(idx, batch.data(), batch.size()) == 0) {
+        for (DispatchReq* r : batch) r->rc = 0;
+        return;
+    }
+    if (batch.size() == 1) { batch[0]->rc = -1; batch[0]->err = mse_last_error(); return; }
+    for (DispatchReq* r : batch) {   // a caller only ever sees its own failure
+        idx->retried_alone++;
+        r->rc = index_run_group(idx, &r, 1);
+        if (r->rc) r->err = mse_last_error();
+    }
+}
+
+}  // namespace
+
 mse_index* mse_index_new(int d) {
     if (d <= 0 || d % 64 != 0 || d > D_MAX) {
         fail("index width must be a positive multiple of 64");
@@ -59,14 +224,30 @@ mse_index* mse_index_new(int d) {
     mse_index* idx = new (std::nothrow) mse_index();
     if (!idx) { fail("out of host memory"); return nullptr; }
     idx->d = d;
+    if (hipGetDevice(&idx->device) != hipSuccess) idx->device = 0;
     idx->scratch = scratch_searcher_new();
     if (!idx->scratch) { delete idx; return nullptr; }
+    idx->view.d = d; idx->view.owned = false; idx->view.n_cu = idx->scratch->n_cu; idx->view.device = idx->device;
+    if (hipMalloc((void**)&idx->view.norm_bits_dev, 12) != hipSuccess || hipMemset(idx->view.norm_bits_dev, 0, 12) != hipSuccess) {
+        mse_index_free(idx);
+        fail("device allocation failed for the index");
+        return nullptr;
+    }
+    idx->view.norm_ready = true;   // kept current by add()
+    idx->scratch->base = &idx->view;
+    const int device = idx->device;
+    // at most one matrix-core pass worth of queries per gather; the wait budget follows the row count (add)
+    idx->co.reset(new Coalescer((size_t)mfma_query_tile(), 200, [idx](std::vector<DispatchReq*>& b) { index_run_batch(idx, b); },
+                                [device] { (void)hipSetDevice(device); }));
     return idx;
 }
 void mse_index_free(mse_index* idx) {
     if (!idx) return;
+    idx->co.reset();   // joins the worker
     if (idx->scratch) mse_searcher_free(idx->scratch);
     if (idx->codes) (void)hipFree(idx->codes);
+    if (idx->view.norm_bits_dev) (void)hipFree(idx->view.norm_bits_dev);
+    if (idx->pin) (void)hipHostFree(idx->pin);
     delete idx;
 }
 size_t mse_index_ntotal(const mse_index* idx) { return idx ? idx->n : 0; }
@@ -74,7 +255,7 @@ size_t mse_index_ntotal(const mse_index* idx) { return idx ? idx->n : 0; }
 int mse_index_add(mse_index* idx, const float* x, size_t n) {
     if (!idx) return fail("null index");
     if (n == 0) return 0;
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::lock_guard<SharedExclusive> g(idx->rw);   // index.write() of src/main.rs:1016: waits for the searches in flight, holds new ones off
     const size_t d = idx->d;
     hipStream_t st = idx->scratch->stream;
     if (idx->n + n > 0xFFFFFFFEull) return fail("index full");
@@ -98,43 +279,36 @@ int mse_index_add(mse_index* idx, const float* x, size_t n) {
     if (stage.ensure(n * d * 4)) return -1;
     MSE_HIP_TRY(hipMemcpyAsync(stage.p, x, n * d * 4, hipMemcpyHostToDevice, st));
     if (launch_f32_to_f16(stage.as<float>(), n * d, idx->codes + idx->n * d, st)) return -1;
+    // the certificate's row-norm bound only ever grows: fold the new rows in (atomic maxima on the device)
+    if (launch_row_norm_max(idx->codes + idx->n * d, n, (int)d, idx->view.norm_bits_dev, st)) return -1;
     MSE_HIP_TRY(hipStreamSynchronize(st));
     idx->n += n;
+    idx->view.dev = idx->codes;
+    idx->view.n = idx->n;
+    idx->co->set_max_wait_us(default_wait_us(idx->n, d * 2));
     return 0;
 }
 
 int mse_index_search(mse_index* idx, const float* queries, size_t nq, size_t k, float* distances, int64_t* labels) {
     if (!idx) return fail("null index");
     if (nq == 0 || k == 0) return 0;
+    if (!queries || !distances || !labels) return fail("null argument");
     if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
-    std::lock_guard<std::mutex> g(idx->mu);
-    mse_searcher* s = idx->scratch;
-    hipStream_t st = s->stream;
-    const size_t d = idx->d, n = idx->n;
     for (size_t i = 0; i < nq * k; i++) { distances[i] = -FLT_MAX; labels[i] = -1; }
-    if (n == 0) return 0;
-    std::vector<uint32_t> ids_h(8 * k);
-    std::vector<float> dist_h(8 * k);
-    for (size_t q0 = 0; q0 < nq; q0 += 8) {
-        const int nqp = (int)std::min<size_t>(8, nq - q0);
-        if (s->q_stage.ensure(8 * d * 4) || s->scores.ensure((size_t)nqp * n * 4)) return -1;
-        MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, 8 * d * 4, st));
-        MSE_HIP_TRY(hipMemcpyAsync(s->q_stage.p, queries + q0 * d, (size_t)nqp * d * 4, hipMemcpyHostToDevice, st));
-        if (launch_scan_exact(idx->codes, n, (int)d, s->q_stage.p, nqp, true, nullptr, n, s->scores.as<float>(), s->n_cu,
-                              st)) return -1;
-        if (s->sel_keys.ensure((size_t)nqp * k * 4)) return -1;
-        uint32_t* sel = nullptr;
-        LevelRef l0{KEY_F32, s->scores.p, n, 1, n, false, 0};
-        if (descend(s, l0, nqp, (int)k, &sel, s->sel_keys.p)) return -1;
-        MSE_HIP_TRY(hipMemcpyAsync(ids_h.data(), sel, (size_t)nqp * k * 4, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipMemcpyAsync(dist_h.data(), s->sel_keys.p, (size_t)nqp * k * 4, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipStreamSynchronize(st));
-        for (size_t i = 0; i < (size_t)nqp * k; i++) {
-            if (ids_h[i] == ID_NONE) continue;
-            distances[q0 * k + i] = dist_h[i];
-            labels[q0 * k + i] = (int64_t)ids_h[i];
-        }
-    }
+    // index.read() of src/main.rs:1046: any number of searches at once; they meet in the coalescer and share passes
+    idx->rw.lock_shared();
+    DispatchReq r;
+    r.queries = queries; r.nq = nq; r.k = k; r.out_a = distances; r.out_b = labels;
+    const int rc = idx->co->submit(r);
+    idx->rw.unlock_shared();
+    return rc;
+}
+
+int mse_index_stats(mse_index* idx, uint64_t out[6]) {
+    if (!idx || !out) return fail("null argument");
+    const DispatchStats st = idx->co->stats();
+    out[0] = st.queries; out[1] = st.requests; out[2] = st.passes; out[3] = st.max_pass_queries; out[4] = st.deadline_fires;
+    out[5] = idx->retried_alone.load();
     return 0;
 }
 
@@ -150,6 +324,7 @@ mse_pq* mse_pq_load(const float* centroids, size_t n_centroids, const float* tra
     mse_pq* pq = new (std::nothrow) mse_pq();
     if (!pq) { fail("out of host memory"); return nullptr; }
     pq->n_centroids = n_centroids; pq->d = n_dims; pq->dpc = n_dims_per_code; pq->n_chunks = n_dims / n_dims_per_code;
+    if (hipGetDevice(&pq->device) != hipSuccess) pq->device = 0;
     if (hipMalloc((void**)&pq->centroids, n_centroids * n_dims * 4) != hipSuccess ||
         hipMalloc((void**)&pq->transform, n_dims * n_dims * 4) != hipSuccess ||
         hipMemcpy(pq->centroids, centroids, n_centroids * n_dims * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -173,6 +348,8 @@ mse_pq* mse_pq_load(const float* centroids, size_t n_centroids, const float* tra
 }
 void mse_pq_free(mse_pq* pq) {
     if (!pq) return;
+    delete pq->co;   // joins its worker
+    pq->co = nullptr;
     if (pq->centroids) (void)hipFree(pq->centroids);
     if (pq->transform) (void)hipFree(pq->transform);
     if (pq->transform_t) (void)hipFree(pq->transform_t);
@@ -599,9 +776,86 @@ uint32_t mse_pq_last_uncertified(mse_pq* pq) {
     return pq->last_uncertified;
 }
 
+// One query per call, possibly from many threads at once (the reference: one greedy_search / evaluate per request on a thread per
+// core, src/query_disk_index.rs:711-736).  Calls meet in the quantiser's coalescer; the worker sorts what it gathered into groups
+// that can share a batch call -- same codes, same base rows (or none), same r and k, the same descriptor scales byte for byte --
+// and runs each group through mse_pq_scan_topk_batch (four queries per pass over the codes), on the searcher of the group's first
+// caller (its owner is blocked in this call, so it is free to borrow).  Results are those of the call made alone.
+namespace {
+struct PqKey {
+    const mse_codes* c; const mse_base* base; size_t r, k; const float* scales; size_t n_sc;
+    bool same(const PqKey& o) const {
+        if (c != o.c || base != o.base || r != o.r || k != o.k || (scales == nullptr) != (o.scales == nullptr)) return false;
+        return !scales || (n_sc == o.n_sc && memcmp(scales, o.scales, n_sc * 4) == 0);
+    }
+};
+PqKey pq_key_of(const DispatchReq* q) {
+    const mse_codes* c = static_cast<const mse_codes*>(q->aux0);
+    const mse_searcher* s = static_cast<const mse_searcher*>(q->aux1);
+    return PqKey{c, s ? s->base : nullptr, q->aux_n, q->k, static_cast<const float*>(q->aux2), c->n_desc};
+}
+void pq_run_batch(mse_pq* pq, std::vector<DispatchReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    std::vector<float> qs;
+    std::vector<int64_t> sc;
+    std::vector<uint32_t> id;
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        const PqKey key = pq_key_of(batch[i]);
+        std::vector<DispatchReq*> grp;
+        for (size_t j = i; j < batch.size(); j++)
+            if (!taken[j] && key.same(pq_key_of(batch[j]))) { taken[j] = 1; grp.push_back(batch[j]); }
+        const size_t d = pq->d, k = key.k, n = grp.size();
+        qs.resize(n * d); sc.resize(n * k); id.resize(n * k);
+        for (size_t j = 0; j < n; j++) memcpy(qs.data() + j * d, grp[j]->queries, d * 4);
+        mse_searcher* s = const_cast<mse_searcher*>(static_cast<const mse_searcher*>(grp[0]->aux1));
+        int rc = mse_pq_scan_topk_batch(pq, key.c, s, qs.data(), n, key.scales, key.r, k, sc.data(), id.data());
+        if (rc == 0) {
+            for (size_t j = 0; j < n; j++) {
+                memcpy(grp[j]->out_a, sc.data() + j * k, k * 8);
+                memcpy(grp[j]->out_b, id.data() + j * k, k * 4);
+                grp[j]->rc = 0;
+            }
+            continue;
+        }
+        // the shared call failed: each caller is repeated alone with its own searcher and sees only its own outcome
+        const std::string why = mse_last_error();
+        for (size_t j = 0; j < n; j++) {
+            if (n == 1) { grp[j]->rc = rc; grp[j]->err = why; break; }
+            mse_searcher* sj = const_cast<mse_searcher*>(static_cast<const mse_searcher*>(grp[j]->aux1));
+            grp[j]->rc = mse_pq_scan_topk_batch(pq, key.c, sj, static_cast<const float*>(grp[j]->queries), 1, key.scales, key.r, k,
+                                                static_cast<int64_t*>(grp[j]->out_a), static_cast<uint32_t*>(grp[j]->out_b));
+            if (grp[j]->rc) grp[j]->err = mse_last_error();
+        }
+    }
+}
+}  // namespace
+
 int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* query_f32,
                      const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
-    return mse_pq_scan_topk_batch(pq, c, s_or_null, query_f32, 1, scales, r, k, scores, ids);
+    if (!pq || !c) return fail("null quantiser or codes");
+    if (!query_f32 || !scores || !ids) return fail("null argument");
+    // argument errors belong to this caller alone: they never enter the queue
+    if (c->code_size != pq->n_chunks) return fail("code size does not match the quantiser");
+    if (k == 0) return 0;
+    if (std::max(r, k) > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
+    if (s_or_null && s_or_null->base && s_or_null->base->n != c->n) return fail("base and codes differ in length");
+    if (s_or_null && s_or_null->base && s_or_null->base->d != pq->d) return fail("base width differs from the quantiser");
+    {
+        std::lock_guard<std::mutex> g(pq->co_mu);
+        if (!pq->co) {
+            const int device = pq->device;
+            // up to 64 queries per gather (sixteen passes of four); wait budget from the size of the first code array seen
+            pq->co = new (std::nothrow) Coalescer(64, default_wait_us(c->n, c->code_size + c->n_desc),
+                                                  [pq](std::vector<DispatchReq*>& b) { pq_run_batch(pq, b); },
+                                                  [device] { (void)hipSetDevice(device); });
+            if (!pq->co) return fail("out of host memory");
+        }
+    }
+    DispatchReq q;
+    q.queries = query_f32; q.nq = 1; q.k = k; q.out_a = scores; q.out_b = ids;
+    q.aux0 = c; q.aux1 = s_or_null; q.aux2 = (scales && c->n_desc) ? scales : nullptr; q.aux_n = r;
+    return pq->co->submit(q);
 }
 
 int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id) {

@@ -1,0 +1,270 @@
+// Cross-thread query coalescer (dispatch.h) and its brute-force front: mse_dispatcher_* of include/mse.h.
+#include "../../include/mse.h"
+#include "dispatch.h"
+#include "runtime.h"
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <future>
+#include <memory>
+#include <new>
+
+namespace mse {
+
+uint32_t default_wait_us(size_t n_rows, size_t row_bytes) {
+    const double pass_us = (double)n_rows * (double)row_bytes / 4.0e6;   // bytes / (4 TB/s) in microseconds
+    double w = pass_us / 10.0;
+    if (w < 200.0) w = 200.0;
+    if (w > 5000.0) w = 5000.0;
+    return (uint32_t)w;
+}
+
+Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::function<void()> on_thread_start)
+    : max_queries_(max_queries ? max_queries : 1), max_wait_us_(max_wait_us), run_(std::move(run)),
+      on_start_(std::move(on_thread_start)) {
+    worker_ = std::thread([this] { loop(); });
+}
+
+Coalescer::~Coalescer() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_worker_.notify_all();
+    if (worker_.joinable()) worker_.join();
+}
+
+int Coalescer::submit(DispatchReq& r) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (stop_) return fail("dispatcher is shutting down");
+    r.done = false;
+    r.t_arrive = std::chrono::steady_clock::now();
+    queue_.push_back(&r);
+    queued_queries_ += r.nq;
+    // the worker only needs waking when this arrival can change its decision: first in the queue, or the target reached
+    if (queue_.size() == 1 || queued_queries_ >= std::min(max_queries_, expect_)) cv_worker_.notify_one();
+    r.cv.wait(lk, [&] { return r.done; });
+    lk.unlock();
+    if (r.rc) set_error(r.err.empty() ? std::string("search failed") : r.err);
+    return r.rc;
+}
+
+DispatchStats Coalescer::stats() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return st_;
+}
+
+void Coalescer::loop() {
+    if (on_start_) on_start_();
+    std::vector<DispatchReq*> batch;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+        cv_worker_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (stop_) break;
+        // gather: until as many queries wait as the last pass answered (capped), or the oldest request is max_wait old
+        const auto deadline = queue_.front()->t_arrive + std::chrono::microseconds(max_wait_us_.load());
+        bool by_deadline = false;
+        while (!stop_ && queued_queries_ < std::min(max_queries_, expect_)) {
+            if (cv_worker_.wait_until(lk, deadline) == std::cv_status::timeout) { by_deadline = true; break; }
+        }
+        if (stop_) break;
+        batch.clear();
+        size_t nq = 0;
+        while (!queue_.empty()) {
+            DispatchReq* r = queue_.front();
+            if (!batch.empty() && nq + r->nq > max_queries_) break;   // a request larger than a pass goes alone
+            batch.push_back(r);
+            nq += r->nq;
+            queue_.pop_front();
+        }
+        queued_queries_ -= nq;
+        lk.unlock();
+        run_(batch);
+        lk.lock();
+        st_.passes++;
+        st_.requests += batch.size();
+        st_.queries += nq;
+        st_.max_pass_queries = std::max<uint64_t>(st_.max_pass_queries, nq);
+        if (by_deadline) st_.deadline_fires++;
+        expect_ = std::max<size_t>(1, nq);
+        for (DispatchReq* r : batch) {
+            r->done = true;
+            r->cv.notify_one();
+        }
+    }
+    // shutting down: nobody may stay blocked
+    for (DispatchReq* r : queue_) {
+        r->rc = -1;
+        r->err = "dispatcher closed while the request was queued";
+        r->done = true;
+        r->cv.notify_one();
+    }
+    queue_.clear();
+    queued_queries_ = 0;
+}
+
+}  // namespace mse
+
+using namespace mse;
+
+// Brute-force front: T threads with one f16 query each (or a few) share one pass over the base rows.
+struct mse_dispatcher {
+    const mse_base* base = nullptr;
+    mse_searcher* s = nullptr;          // made on the worker thread (its stream lives on the base's device)
+    std::string start_error;
+    void* pin = nullptr;                // pinned staging: queries up, [scores | ids] down
+    size_t pin_cap = 0;
+    DevBuf q_dev, out_dev;
+    std::unique_ptr<Coalescer> co;
+    std::atomic<uint64_t> retried_alone{0};
+    std::atomic<uint32_t> fail_shared{0};   // test hook: this many shared passes fail before they start
+};
+
+namespace {
+
+// one engine call for a contiguous group of requests; on success every request has its rows
+int run_group(mse_dispatcher* D, DispatchReq* const* reqs, size_t n_req) {
+    const mse_base* b = D->base;
+    const size_t d = b->d;
+    size_t total = 0, kmax = 0;
+    for (size_t i = 0; i < n_req; i++) {
+        total += reqs[i]->nq;
+        kmax = std::max(kmax, reqs[i]->k);
+    }
+    if (total == 0 || kmax == 0) return 0;
+    if (!D->s) return fail(D->start_error.empty() ? std::string("dispatcher has no searcher") : D->start_error);
+    mse_searcher* s = D->s;
+    hipStream_t st = s->stream;
+    const size_t in_bytes = total * d * 2, sc_bytes = total * kmax * 8, id_bytes = total * kmax * 4;
+    const size_t out_bytes = sc_bytes + id_bytes;
+    if (D->pin_cap < std::max(in_bytes, out_bytes)) {
+        if (D->pin) (void)hipHostFree(D->pin);
+        D->pin = nullptr;
+        D->pin_cap = 0;
+        const size_t want = std::max<size_t>(2 * std::max(in_bytes, out_bytes), (size_t)1 << 20);
+        MSE_HIP_TRY(hipHostMalloc(&D->pin, want, hipHostMallocDefault));
+        D->pin_cap = want;
+    }
+    if (D->q_dev.ensure(in_bytes) || D->out_dev.ensure(out_bytes)) return -1;
+    char* p = static_cast<char*>(D->pin);
+    for (size_t i = 0, o = 0; i < n_req; i++) {
+        memcpy(p + o, reqs[i]->queries, reqs[i]->nq * d * 2);
+        o += reqs[i]->nq * d * 2;
+    }
+    MSE_HIP_TRY(hipMemcpyAsync(D->q_dev.p, D->pin, in_bytes, hipMemcpyHostToDevice, st));
+    // a pass of the matrix-core scan costs less than the exact-order pass once the rows no longer fit the caches, whatever the
+    // query count (40 ms against 54 ms at 1e8 rows); below that the exact pass has the shorter tail.  Same answers either way.
+    const int mode = (total > 8 || b->n >= ((size_t)1 << 22)) ? MSE_MODE_MFMA : MSE_MODE_EXACT;
+    int64_t* sc_dev = D->out_dev.as<int64_t>();
+    uint32_t* id_dev = reinterpret_cast<uint32_t*>(D->out_dev.as<char>() + sc_bytes);
+    if (mse_bruteforce_topk_f16_dev(s, D->q_dev.p, total, kmax, mode, 0, sc_dev, id_dev)) return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(D->pin, D->out_dev.p, out_bytes, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    const int64_t* sc = reinterpret_cast<const int64_t*>(p);
+    const uint32_t* id = reinterpret_cast<const uint32_t*>(p + sc_bytes);
+    // the k best of a caller are the first k of the kmax best: the order (score descending, id ascending) is total
+    for (size_t i = 0, row = 0; i < n_req; i++) {
+        DispatchReq* r = reqs[i];
+        for (size_t q = 0; q < r->nq; q++, row++) {
+            memcpy(static_cast<int64_t*>(r->out_a) + q * r->k, sc + row * kmax, r->k * 8);
+            memcpy(static_cast<uint32_t*>(r->out_b) + q * r->k, id + row * kmax, r->k * 4);
+        }
+    }
+    return 0;
+}
+
+void run_batch(mse_dispatcher* D, std::vector<DispatchReq*>& batch) {
+    bool injected = false;
+    if (batch.size() > 1 && D->fail_shared.load() > 0) { D->fail_shared--; injected = true; fail("injected failure of a shared pass (test hook)"); }
+    if (!injected && run_group(D, batch.data(), batch.size()) == 0) {
+        for (DispatchReq* r : batch) r->rc = 0;
+        return;
+    }
+    if (batch.size() == 1) {
+        batch[0]->rc = -1;
+        batch[0]->err = mse_last_error();
+        return;
+    }
+    // the shared pass failed: every request is repeated on its own, so that a caller only ever sees its own failure
+    for (DispatchReq* r : batch) {
+        D->retried_alone++;
+        r->rc = run_group(D, &r, 1);
+        if (r->rc) r->err = mse_last_error();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+mse_dispatcher* mse_dispatcher_new(const mse_base* b, size_t max_queries_per_pass, uint32_t max_wait_us) {
+    if (!b) { fail("null base"); return nullptr; }
+    mse_dispatcher* D = new (std::nothrow) mse_dispatcher();
+    if (!D) { fail("out of host memory"); return nullptr; }
+    D->base = b;
+    const size_t mq = max_queries_per_pass ? max_queries_per_pass : (size_t)mfma_query_tile();
+    const uint32_t wait = max_wait_us ? max_wait_us : default_wait_us(b->n, b->d * 2);
+    const int device = b->device;
+    std::promise<void> started;
+    D->co.reset(new Coalescer(
+        mq, wait, [D](std::vector<DispatchReq*>& batch) { run_batch(D, batch); },
+        [D, device, &started] {
+            // HIP's current device is per thread: the worker lives on the device that holds the rows
+            if (hipSetDevice(device) != hipSuccess) D->start_error = "dispatcher: hipSetDevice failed";
+            else if (!(D->s = mse_searcher_new(D->base))) D->start_error = mse_last_error();
+            started.set_value();
+        }));
+    started.get_future().wait();
+    if (!D->s) {
+        const std::string why = D->start_error;
+        mse_dispatcher_free(D);
+        fail(why.empty() ? std::string("dispatcher: worker failed to start") : why);
+        return nullptr;
+    }
+    return D;
+}
+
+void mse_dispatcher_free(mse_dispatcher* D) {
+    if (!D) return;
+    D->co.reset();   // joins the worker
+    if (D->s) mse_searcher_free(D->s);
+    if (D->pin) (void)hipHostFree(D->pin);
+    delete D;
+}
+
+int mse_dispatcher_topk_f16(mse_dispatcher* D, const uint16_t* queries, size_t nq, size_t k, int64_t* scores, uint32_t* ids) {
+    if (!D) return fail("null dispatcher");
+    if (nq == 0 || k == 0) return 0;
+    // argument errors never enter the queue: they belong to this caller alone
+    if (!queries || !scores || !ids) return fail("null argument");
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    DispatchReq r;
+    r.queries = queries;
+    r.nq = nq;
+    r.k = k;
+    r.out_a = scores;
+    r.out_b = ids;
+    return D->co->submit(r);
+}
+
+int mse_dispatcher_stats(mse_dispatcher* D, uint64_t out[6]) {
+    if (!D || !out) return fail("null argument");
+    const DispatchStats st = D->co->stats();
+    out[0] = st.queries;
+    out[1] = st.requests;
+    out[2] = st.passes;
+    out[3] = st.max_pass_queries;
+    out[4] = st.deadline_fires;
+    out[5] = D->retried_alone.load();
+    return 0;
+}
+
+mse_searcher* mse_dispatcher_searcher(mse_dispatcher* D) { return D ? D->s : nullptr; }
+
+int mse_debug_dispatcher_fail_shared(mse_dispatcher* D, uint32_t n_passes) {
+    if (!D) return fail("null dispatcher");
+    D->fail_shared.store(n_passes);
+    return 0;
+}
+
+}  // extern "C"

@@ -157,7 +157,48 @@ __global__ void query_eps_kernel(const uint16_t* __restrict__ queries, int nq, i
     }
 }
 
+// f32 queries whose f16 roundings q16 went through the matrix-core scan (flat index): the f16 bound above plus the rounding
+// of the query, |x . (q - q16)| <= |x| |q - q16| with |q - q16| measured here (a q16 that overflowed to infinity gives eps = inf,
+// i.e. no certificate, and the query repeats through the exact pass)
+__global__ void query_eps_f32_kernel(const float* __restrict__ q32, const uint16_t* __restrict__ q16, int nq, int d,
+                                     const uint32_t* __restrict__ max_norm_bits, float factor, float* __restrict__ eps) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;  // 64 threads
+    float s = 0.0f, sub = 0.0f, mabs = 0.0f, dl = 0.0f;
+    for (int i = lane; i < d; i += 64) {
+        const float v = (float)__builtin_bit_cast(_Float16, q16[(size_t)q * d + i]);
+        const float e = q32[(size_t)q * d + i] - v;
+        s = fmaf(v, v, s);
+        dl = fmaf(e, e, dl);
+        const float av = fabsf(v);
+        if (av < 6.103515625e-5f) sub += av;
+        if (av == av) mabs = fmaxf(mabs, av);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o);
+        dl += __shfl_xor(dl, o);
+        sub += __shfl_xor(sub, o);
+        mabs = fmaxf(mabs, __shfl_xor(mabs, o));
+    }
+    if (lane == 0) {
+        const float mn = __uint_as_float(*max_norm_bits);
+        float e = factor * sqrtf(s) * 1.0001f * mn + sqrtf(dl) * 1.001f * mn;
+        e += 1.0001f * (__uint_as_float(max_norm_bits[1]) * mabs + sub * __uint_as_float(max_norm_bits[2]));
+        if (!(e == e)) e = __builtin_inff();
+        eps[q] = e;
+    }
+}
+
 }  // namespace
+
+int launch_query_eps_f32(const float* q32, const uint16_t* q16, int nq, int d, const uint32_t* max_norm_bits, float factor, float* eps,
+                         hipStream_t stream) {
+    if (nq == 0) return 0;
+    hipLaunchKernelGGL(query_eps_f32_kernel, dim3(nq), dim3(64), 0, stream, q32, q16, nq, d, max_norm_bits, factor, eps);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int launch_generate_rows(uint16_t* out, uint32_t seed, uint64_t row0, size_t n_rows, int d, hipStream_t stream) {
     if (n_rows == 0) return 0;

@@ -26,6 +26,10 @@ int launch_row_norm_max(const uint16_t* base, size_t n_rows, int d, uint32_t* ou
 int launch_query_eps(const uint16_t* queries, int nq, int d, const uint32_t* max_norm_bits, float factor, float* eps,
                      hipStream_t stream);
 
+// the same for f32 queries scanned as their f16 roundings q16: adds |q32 - q16| * max_norm (flat index)
+int launch_query_eps_f32(const float* q32, const uint16_t* q16, int nq, int d, const uint32_t* max_norm_bits, float factor, float* eps,
+                         hipStream_t stream);
+
 // ---- topk.hip --------------------------------------------------------------------------------
 enum KeyKind { KEY_I64 = 0, KEY_F32 = 1, KEY_U64 = 2, KEY_U32 = 3 };
 // out[q][g] = max over in[q][g*F .. (g+1)*F) as order-preserving unsigned keys
@@ -70,6 +74,10 @@ int launch_finalize(const uint32_t* sel_ids, const int64_t* sel_scores, size_t s
                     uint64_t id_offset, int64_t* out_scores, uint32_t* out_ids, size_t out_stride,
                     const float* group_keys, size_t gk_stride, int kg, size_t n_groups, const float* eps,
                     float* margin, hipStream_t stream);
+
+// certificate margin for f32 keys: margin[q] = sel_keys[q][k-1] - (group_keys[q][kg-1] + eps[q])   (flat index)
+int launch_margin_f32(const uint32_t* sel_ids, const float* sel_keys, size_t sel_stride, int k, int nq, const float* group_keys,
+                      size_t gk_stride, int kg, size_t n_groups, const float* eps, float* margin, hipStream_t stream);
 
 // ---- pq.hip ----------------------------------------------------------------------------------
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream);

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include "dispatch.h"
 #include <mutex>
 #include <vector>
 
@@ -44,6 +45,10 @@ struct mse_base {
     size_t n = 0, d = 0;
     bool owned = false;
     int n_cu = 256;
+    int device = 0;            // HIP ordinal the rows live on (the thread's current device when the base was made)
+    // the coalescer that MSE_MODE_AUTO host-pointer searches of every thread meet in (dispatch.hip), made on first use
+    mutable std::mutex disp_mu;
+    mutable struct mse_dispatcher* disp = nullptr;
     // max row norm (float bits) for the MFMA certificate, computed on first use
     mutable std::mutex norm_mu;
     mutable uint32_t* norm_bits_dev = nullptr;
@@ -87,6 +92,9 @@ struct mse_pq {
     mse_searcher* lane2 = nullptr;    // second stream of the batched scan; bound to the base of the call that made it
     mse::DevBuf t2, lut2, qf2;        // its transformed query, table and f16 query
     uint32_t last_uncertified = 0;    // four-query scan: queries of the last batch whose certificate failed (re-run through the exact scan)
+    int device = 0;                   // HIP ordinal the quantiser was loaded on
+    std::mutex co_mu;                 // guards the creation of `co`
+    mse::Coalescer* co = nullptr;     // meeting point of one-query mse_pq_scan_topk calls from many threads (api_pq.hip), made on first use
     void* pin = nullptr;              // pinned host staging of the scan entry points (one upload + one download per call, both
     size_t pin_cap = 0;               // truly asynchronous: a pageable source makes the runtime stage and block per copy)
 };

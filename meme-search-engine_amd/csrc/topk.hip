@@ -395,6 +395,23 @@ __global__ void finalize_kernel(const uint32_t* __restrict__ sel_ids, const int6
     }
 }
 
+// the same certificate for f32 keys (the flat index keeps FAISS's float distances): margin[q] = k-th exact key - (g + eps)
+__global__ void margin_f32_kernel(const uint32_t* __restrict__ sel_ids, const float* __restrict__ sel_keys, size_t sel_stride, int k,
+                                  const float* __restrict__ group_keys, size_t gk_stride, int kg, size_t n_groups,
+                                  const float* __restrict__ eps, float* __restrict__ margin, int nq) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float m;
+    if ((size_t)kg >= n_groups) {
+        m = __builtin_inff();
+    } else if (sel_ids[(size_t)q * sel_stride + (k - 1)] == ID_NONE) {
+        m = -__builtin_inff();
+    } else {
+        m = sel_keys[(size_t)q * sel_stride + (k - 1)] - (group_keys[(size_t)q * gk_stride + (kg - 1)] + eps[q]);
+    }
+    margin[q] = m;
+}
+
 template <typename T>
 int launch_reduce_t(const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride, size_t n_out, int nq,
                     hipStream_t stream) {
@@ -455,6 +472,15 @@ int launch_expand_groups(const uint32_t* parents, size_t par_stride, size_t n_pa
     if (total == 0) return 0;
     hipLaunchKernelGGL(expand_groups_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, parents,
                        par_stride, n_par, group, n_rows, ids, ids_stride, nq);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_margin_f32(const uint32_t* sel_ids, const float* sel_keys, size_t sel_stride, int k, int nq, const float* group_keys,
+                      size_t gk_stride, int kg, size_t n_groups, const float* eps, float* margin, hipStream_t stream) {
+    if (nq == 0 || k == 0) return 0;
+    hipLaunchKernelGGL(margin_f32_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, sel_ids, sel_keys, sel_stride, k, group_keys,
+                       gk_stride, kg, n_groups, eps, margin, nq);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -4,7 +4,7 @@ No CPU fallback exists: importing is cheap, but any compute call raises MseError
 library is not built or no device is present."""
 from .ffi import MseError, LIB_PATH  # noqa: F401
 from .vector import (SCALE, ID_NONE, MODE_AUTO, MODE_EXACT, MODE_MFMA, scale_dot_result, scale_dot_result_f64,  # noqa: F401
-                     fast_dot, fast_dot_noprefetch, VectorList, Searcher, ProductQuantizer, QueryLUT, Codes,
+                     fast_dot, fast_dot_noprefetch, VectorList, Searcher, Dispatcher, ProductQuantizer, QueryLUT, Codes,
                      descriptor_product)
 from .diskann import (NeighbourBuffer, IndexGraph, greedy_search, disk_greedy_search, DiskSearchResult, medioid,  # noqa: F401
                       select_shard, dedup_visited, DUPLICATES_THRESHOLD, DeviceGraph, disk_search_batch, IndexBuildConfig,

@@ -92,6 +92,13 @@ SIGNATURES = {
     "mse_index_add": (C.c_int, [vp, f32p, sz]),
     "mse_index_ntotal": (sz, [vp]),
     "mse_index_search": (C.c_int, [vp, f32p, sz, sz, f32p, i64p]),
+    "mse_index_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "mse_dispatcher_new": (vp, [vp, sz, C.c_uint32]),
+    "mse_dispatcher_free": (None, [vp]),
+    "mse_dispatcher_topk_f16": (C.c_int, [vp, u16p, sz, sz, i64p, u32p]),
+    "mse_dispatcher_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "mse_dispatcher_searcher": (vp, [vp]),
+    "mse_debug_dispatcher_fail_shared": (C.c_int, [vp, C.c_uint32]),
     "mse_pq_load": (vp, [f32p, sz, f32p, sz, sz]),
     "mse_pq_free": (None, [vp]),
     "mse_pq_apply_transform": (C.c_int, [vp, f32p, sz, f32p]),

@@ -37,6 +37,12 @@ class ScalarQuantizerIndex:
               "index.search")
         return SearchResult(dist, lab)
 
+    def stats(self):
+        """Coalescer counters of this index (mse_index_stats)."""
+        out = (C.c_uint64 * 6)()
+        check(ffi.lib().mse_index_stats(self._h, out), "index.stats")
+        return dict(zip(("queries", "requests", "passes", "max_pass_queries", "deadline_fires", "retried_alone"), map(int, out)))
+
     def close(self):
         if self._h:
             ffi.lib().mse_index_free(self._h)

@@ -188,6 +188,45 @@ class Searcher:
             pass
 
 
+class Dispatcher:
+    """Cross-thread query coalescer over a VectorList (include/mse.h `mse_dispatcher`): the meeting point of the reference's
+    one-query-per-request threads (src/main.rs:896-934,1043-1049; src/query_disk_index.rs:711-736).  `search` may be called
+    from any number of threads; callers waiting at the same time share one pass over the rows."""
+
+    def __init__(self, vecs: VectorList, max_queries_per_pass=0, max_wait_us=0):
+        self.vecs = vecs
+        self._h = check_ptr(ffi.lib().mse_dispatcher_new(vecs._h, max_queries_per_pass, max_wait_us), "mse_dispatcher_new")
+
+    def search(self, queries, k):
+        d = self.vecs.d_emb
+        q = _bits(queries).reshape(-1, d)
+        nq = q.shape[0]
+        scores = np.empty((nq, k), np.int64)
+        ids = np.empty((nq, k), np.uint32)
+        check(ffi.lib().mse_dispatcher_topk_f16(self._h, _p(q, C.c_uint16), nq, k, _p(scores, C.c_int64), _p(ids, C.c_uint32)),
+              "dispatcher.search")
+        return scores, ids
+
+    def stats(self):
+        out = (C.c_uint64 * 6)()
+        check(ffi.lib().mse_dispatcher_stats(self._h, out), "dispatcher.stats")
+        return dict(zip(("queries", "requests", "passes", "max_pass_queries", "deadline_fires", "retried_alone"), map(int, out)))
+
+    def searcher_handle(self):
+        return ffi.lib().mse_dispatcher_searcher(self._h)
+
+    def close(self):
+        if self._h:
+            ffi.lib().mse_dispatcher_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class QueryLUT:
     """vector.rs:316-317: chunk-major table [n_chunks][n_centroids] of f32."""
 

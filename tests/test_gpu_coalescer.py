@@ -1,0 +1,226 @@
+"""The reference's call shape -- ONE query per request from many threads (src/main.rs:896-934,1043-1049;
+src/query_disk_index.rs:711-736) -- through the cross-thread coalescer behind the C ABI (csrc/dispatch.hip): every caller must
+get exactly the oracle's answer for ITS query, whatever it was batched with."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import SEED_BASE, SEED_QUERY, make_pq
+
+pytestmark = pytest.mark.gpu
+D = 1152
+
+
+def run_threads(n, fn):
+    """fn(i) on n threads released together; exceptions are re-raised in the caller."""
+    errs, out = [None] * n, [None] * n
+    gate = threading.Barrier(n)
+
+    def body(i):
+        try:
+            gate.wait()
+            out[i] = fn(i)
+        except BaseException as e:  # noqa: BLE001
+            errs[i] = e
+
+    ts = [threading.Thread(target=body, args=(i,)) for i in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    return out
+
+
+def test_64_threads_one_query_each_get_their_own_oracle_answer(gpu, mse, orc):
+    """64 threads x nq = 1, mixed k, three rounds each, through an explicit dispatcher; the passes really are shared."""
+    n, T = 20000, 64
+    base = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, T * 3)
+    ks = [1, 3, 10, 17, 100]
+    want = {k: orc.bruteforce_topk(base, q, k) for k in ks}
+    vl = mse.VectorList.from_f16s(base, D)
+    disp = mse.Dispatcher(vl, max_wait_us=20000)
+
+    def caller(i):
+        res = []
+        for rnd in range(3):
+            j = rnd * T + i
+            k = ks[(i + rnd) % len(ks)]
+            res.append((j, k) + disp.search(q[j], k))
+        return res
+
+    for res in run_threads(T, caller):
+        for j, k, sc, ids in res:
+            ws, wi = want[k]
+            assert np.array_equal(ids[0], wi[j]) and np.array_equal(sc[0], ws[j])
+    st = disp.stats()
+    assert st["queries"] == 3 * T and st["requests"] == 3 * T
+    assert st["passes"] < 3 * T / 4, st            # callers shared passes (a serial run would need 192)
+    assert st["max_pass_queries"] > 8, st          # ... and the matrix-core pass served them
+    disp.close()
+
+
+def test_auto_mode_of_per_thread_searchers_meets_in_the_base_coalescer(gpu, mse, orc):
+    """The reference's loop unchanged: a Scratch (searcher) per thread, `mse_bruteforce_topk_f16(.., MSE_MODE_AUTO ..)` with one
+    query -- the calls meet in the coalescer the base makes on first use.  A lone caller is answered as well (no company needed)."""
+    n, T = 12000, 32
+    base = orc.gen_rows_f16(SEED_BASE, 7, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 7, T)
+    ws, wi = orc.bruteforce_topk(base, q, 10)
+    vl = mse.VectorList.from_f16s(base, D)
+    searchers = [mse.Searcher(vl) for _ in range(T)]
+    sc, ids = searchers[0].bruteforce_topk(q[0], 10)               # alone: fires at once
+    assert np.array_equal(ids[0], wi[0]) and np.array_equal(sc[0], ws[0])
+    for i, (sc, ids) in enumerate(run_threads(T, lambda i: searchers[i].bruteforce_topk(q[i], 10, mse.MODE_AUTO))):
+        assert np.array_equal(ids[0], wi[i]) and np.array_equal(sc[0], ws[i])
+    # a multi-query request keeps its rows together
+    sc, ids = searchers[1].bruteforce_topk(q[:5], 10, mse.MODE_AUTO)
+    assert np.array_equal(ids, wi[:5]) and np.array_equal(sc, ws[:5])
+
+
+def test_one_callers_error_does_not_leak(gpu, mse, orc):
+    """A bad request fails alone (argument errors never enter the queue), and when a SHARED pass fails every request of it is
+    repeated on its own: the other callers still get their exact answers."""
+    from mse import ffi
+    n, T = 5000, 24
+    base = orc.gen_rows_f16(SEED_BASE, 3, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 3, T)
+    ws, wi = orc.bruteforce_topk(base, q, 5)
+    vl = mse.VectorList.from_f16s(base, D)
+    disp = mse.Dispatcher(vl, max_wait_us=20000)
+
+    def caller(i):
+        if i == 5:
+            with pytest.raises(mse.MseError, match="k too large"):
+                disp.search(q[i], 5000)
+            return None
+        return disp.search(q[i], 5)
+
+    for i, r in enumerate(run_threads(T, caller)):
+        if i != 5:
+            assert np.array_equal(r[1][0], wi[i]) and np.array_equal(r[0][0], ws[i])
+    # injected failure of the next two shared passes: answers unaffected, the repeats are counted
+    ffi.check(ffi.lib().mse_debug_dispatcher_fail_shared(disp._h, 2))
+    for i, r in enumerate(run_threads(T, lambda i: disp.search(q[i], 5))):
+        assert np.array_equal(r[1][0], wi[i]) and np.array_equal(r[0][0], ws[i])
+    assert disp.stats()["retried_alone"] >= 2
+    disp.close()
+
+
+def test_index_searches_from_64_threads_with_an_add_racing_them(gpu, mse, orc):
+    """src/main.rs:1016 (`index.write()` in the reload loop) against :1046 (`index.read()` per request): searches share, add
+    excludes.  Every search must equal the oracle's answer on SOME prefix of the adds (before or after each one, never a torn
+    state), and after the last add on all rows."""
+    d, n0, step, n_adds, T, k = 256, 3000, 1000, 4, 64, 7
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((n0 + step * n_adds, d)) / np.sqrt(d)).astype(np.float32)
+    q = rng.standard_normal((T, d)).astype(np.float32)
+    codes = orc.f16_bits(x)
+    prefixes = [n0 + step * a for a in range(n_adds + 1)]
+    want = [orc.index_search(codes[:m], q, k, order=0) for m in prefixes]
+    idx = mse.ScalarQuantizerIndex(d)
+    idx.add(x[:n0])
+    stop = threading.Event()
+
+    def caller(i):
+        if i == T:                                   # the reload loop
+            for a in range(n_adds):
+                idx.add(x[n0 + step * a:n0 + step * (a + 1)])
+            stop.set()
+            return None
+        seen = []
+        while True:
+            done = stop.is_set()
+            r = idx.search(q[i], k)
+            seen.append((r.distances[0].copy(), r.labels[0].copy()))
+            if done:
+                return seen
+
+    outs = run_threads(T + 1, caller)
+    assert idx.ntotal() == prefixes[-1]
+    for i in range(T):
+        seen = outs[i]
+        last = -1
+        for dist, lab in seen:
+            hits = [p for p, (wd, wl) in enumerate(want) if np.array_equal(lab, wl[i]) and np.array_equal(dist, wd[i])]
+            assert hits, f"caller {i}: a result that matches no prefix of the adds"
+            assert max(hits) >= last                  # the index never goes backwards
+            last = max(last, min(hits))
+        assert len(want) - 1 in [p for p, (wd, wl) in enumerate(want)
+                                 if np.array_equal(seen[-1][1], wl[i]) and np.array_equal(seen[-1][0], wd[i])]
+    st = idx.stats()
+    assert st["passes"] < st["requests"], st          # searches were coalesced
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 1152, 40, 10), (5000, 256, 200, 3), (777, 128, 300, 7), (100, 64, 9, 200)])
+def test_index_many_queries_take_the_matrix_core_pass_and_match_the_oracle(gpu, mse, orc, n, d, nq, k):
+    """nq > 8 on the FAISS surface: one matrix-core pass over f16-rounded queries nominates, the f32 queries re-score in the stated
+    order, a certificate (incl. the query rounding) closes it.  Labels AND float distances equal the oracle's; queries are NOT unit
+    norm (src/common.rs:215-274)."""
+    rng = np.random.default_rng(n + nq)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    q = (rng.standard_normal((nq, d)) * rng.uniform(0.2, 5, (nq, 1))).astype(np.float32)
+    idx = mse.ScalarQuantizerIndex(d)
+    idx.add(x)
+    res = idx.search(q, k)
+    wd, wl = orc.index_search(orc.f16_bits(x), q, k, order=0)
+    assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
+    # the same queries eight at a time (the exact pass) give the same bytes
+    for lo in range(0, min(nq, 24), 8):
+        r8 = idx.search(q[lo:lo + 8], k)
+        assert np.array_equal(r8.labels, wl[lo:lo + 8]) and np.array_equal(r8.distances, wd[lo:lo + 8])
+
+
+def test_index_query_beyond_f16_range_still_exact(gpu, mse, orc):
+    """A query component past the f16 range rounds to infinity in the nomination pass: no certificate, the exact pass answers."""
+    rng = np.random.default_rng(5)
+    n, d = 4000, 128
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    q = rng.standard_normal((12, d)).astype(np.float32)
+    q[3, 5] = 1.0e6
+    q[7] *= 1e-7                                      # and one whose f16 rounding is all subnormals / zeros
+    idx = mse.ScalarQuantizerIndex(d)
+    idx.add(x)
+    res = idx.search(q, 5)
+    wd, wl = orc.index_search(orc.f16_bits(x), q, 5, order=0)
+    assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
+
+
+def test_pq_scan_one_query_per_thread_is_batched_and_unchanged(gpu, mse, orc):
+    """mse_pq_scan_topk with one query from 24 threads (own searcher each, two different descriptor-scale vectors, two k):
+    the calls meet in the quantiser's coalescer, are grouped by what may share a batch call, and return what the call returns
+    when made alone."""
+    n, T, r = 30000, 24, 100
+    centroids, transform, dpc, d = make_pq(orc)
+    rng = np.random.default_rng(9)
+    base_f = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    base = orc.f16_bits(base_f)
+    opq, pq = orc.PQ(centroids, transform, dpc, d), mse.ProductQuantizer(centroids, transform, dpc, d)
+    codes_h = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    codes = mse.Codes(codes_h, desc)
+    vl = mse.VectorList.from_f16s(base, d)
+    q = (rng.standard_normal((T, d)) / np.sqrt(d)).astype(np.float32)
+    scales = [np.array([0.5, 0, -0.25, 0.125], np.float32) / np.float32(512), np.array([0, 0.25, 0.125, 0], np.float32) / np.float32(512)]
+    searchers = [mse.Searcher(vl) for _ in range(T)]
+
+    def call(i):
+        return pq.scan_topk(codes, q[i], r, 10 if i % 3 else 5, searchers[i], scales[i % 2])
+
+    alone = [call(i) for i in range(T)]
+    outs = run_threads(T, call)
+    for i in range(T):
+        assert np.array_equal(outs[i][1], alone[i][1]) and np.array_equal(outs[i][0], alone[i][0])
+    # and the answer is the oracle's pipeline: ADC top-r -> exact re-score (+ bias) -> top-k
+    for i in (1, 2, 3):
+        k = 10 if i % 3 else 5
+        sc_i = scales[i % 2]
+        approx = opq.adc_desc(opq.preprocess_query(q[i]), codes_h, desc, sc_i)
+        _, cand = orc.topk_from_scores(approx, r)
+        exact = orc.score_rows(base, cand, orc.f16_bits(q[i])) + np.array([orc.descriptor_product(sc_i, desc, int(c)) for c in cand])
+        order = np.lexsort((cand, -exact))[:k]
+        assert np.array_equal(outs[i][1], cand[order]) and np.array_equal(outs[i][0], exact[order])
