@@ -43,14 +43,18 @@ class _stdout_to_stderr:
         os.close(self._saved)
 
 
-def cpu_baseline(n_rows, k):
-    """The oracle (C restatement of the reference's AVX2 `fast_dot` loop, oracle/mse_oracle.c) on the host cores, both modes of
-    SURVEY 8(d), on a bounded sample: 1e6 rows x 1152 fp16 = 2.3 GB (ten copies of a 1e5-row generated block: larger than any
-    last-level cache, so the scan streams from DRAM as the 230 GB index would), results scaled linearly in the row count.
-      fair               every host core scores its own queries against the whole sample, heap top-k: the thread-per-core shape
-                         of the reference's query server (src/query_disk_index.rs:720)                      -> `value`
-      reference_faithful ONE thread, one query: every row scored, the whole score list sorted, top-k read off the front -- what
-                         `evaluate` does (src/query_disk_index.rs:225,262-273)"""
+def cpu_baseline(n_rows, k, min_seconds=5.0):
+    """The oracle (C restatement of the reference's AVX2 `fast_dot` loop, oracle/mse_oracle.c; kind "port") on the host cores,
+    as SURVEY 8(d) specifies: MEASURED at N = 1e5 (BASELINE configs[0], 1000 distinct queries) and at N = 1e7 resident in DRAM
+    (23 GB, configs[2]'s size), every mode timed for at least `min_seconds`, nothing extrapolated in `measured`.  Modes:
+      fair               every thread scores its own queries against all rows, heap top-k: the thread-per-core shape of the
+                         reference's query server (src/query_disk_index.rs:720)
+      reference_faithful ONE thread, one query at a time: every row scored, the whole score list ranked, top-k read off the front
+                         -- what `evaluate` does (src/query_disk_index.rs:225,262-273)
+      index_search       (1e5 only) the in-memory index surface: fp32 queries against fp16 codes, FAISS SQfp16-IP arithmetic in its
+                         stated order + heap (src/main.rs:900), thread per request
+    `value` is in the metric's unit (queries/s over the bench's row count): the fair rate measured at 1e7 rows scaled by the row
+    ratio (x10 for 1e8) -- both sizes stream from DRAM, the scan is linear in rows -- and labelled as scaled."""
     import numpy as np
     from oracle import orc
     orc.build()
@@ -62,83 +66,199 @@ def cpu_baseline(n_rows, k):
             quota = max(1, int(round(int(q) / int(per))))
     except Exception:  # noqa: BLE001
         pass
-    # threads: the cores this process can actually use; with a CPU-time quota, twice the quota measured best on the GPU box
-    # (16-core quota on a 256-thread host: 8 / 32 / 64 / 256 threads -> 77 / 100 / 58 / 20 queries/s on the sample)
+    # threads: the cores this process can actually use.  Under a CPU-time quota the kernel throttles the whole group once the
+    # quota of a period is spent, so the best thread count is not the quota: twice the quota measured best on the GPU box
+    # (16-core quota on a 256-thread host: 8 / 32 / 64 / 256 threads -> 77 / 100 / 58 / 20 queries/s on a 1e6-row sample)
     cores = min(visible, 2 * quota) if quota else visible
-    block_rows, copies = 100_000, 10
-    block = orc.gen_rows_f16(SEED_BASE, 0, block_rows)
-    sample_rows = block_rows * copies
-    # filled by all threads at once so that first touch spreads the pages over every memory controller (one thread's np.tile
-    # would put all 2.3 GB on its own NUMA node and the scan would run at one node's bandwidth: measured 51 GB/s on 256 cores)
-    base = np.empty((sample_rows, D), np.uint16)
-    chunk = (sample_rows + cores - 1) // cores
+    n_q = 1000
+    queries = orc.gen_rows_f16(SEED_QUERY, 0, n_q)
 
-    def fill(t):     # contiguous np.copyto = memcpy with the GIL released: the fills really run side by side, each on its own core
-        r, hi = t * chunk, min(sample_rows, (t + 1) * chunk)
+    def run_threads(fn):
+        """fn(t, deadline) -> completed queries; all threads start together; returns (total completed, wall seconds)."""
+        done = [0] * cores
+        t_end = [0.0]
+
+        def body(t):
+            done[t] = fn(t, t_end[0])
+
+        ths = [threading.Thread(target=body, args=(t,)) for t in range(cores)]
+        t0 = time.perf_counter()
+        t_end[0] = t0 + min_seconds
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        return sum(done), time.perf_counter() - t0
+
+    def fair_on(base):
+        def fn(t, deadline):          # thread t: queries t, t + cores, ... (cyclic over the 1000) until the time is up
+            c, j = 0, t
+            while True:
+                orc.bruteforce_topk(base, queries[j % n_q:j % n_q + 1], k)
+                c += 1
+                j += cores
+                if time.perf_counter() >= deadline:
+                    return c
+        n, dt = run_threads(fn)
+        return {"queries": n, "seconds": dt, "queries_per_s": n / dt, "threads": cores, "scan_GBps": n / dt * base.shape[0] * D * 2 / 1e9}
+
+    def faithful_on(base):
+        t0, c = time.perf_counter(), 0
+        while True:
+            sc = orc.score_all(base, queries[c % n_q])
+            ranks = orc.ranks_from_scores(sc)
+            np.flatnonzero(ranks < k)
+            c += 1
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+        dt = time.perf_counter() - t0
+        return {"queries": c, "seconds": dt, "queries_per_s": c / dt, "threads": 1, "scan_GBps": c / dt * base.shape[0] * D * 2 / 1e9}
+
+    measured = {}
+    # ---- N = 1e5: BASELINE configs[0] ----
+    block_rows = 100_000
+    block = orc.gen_rows_f16(SEED_BASE, 0, block_rows)
+    orc.bruteforce_topk(block[:1000], queries[:1], k)  # warm
+    m5 = {"rows": block_rows, "distinct_queries": n_q, "fair": fair_on(block), "reference_faithful": faithful_on(block)}
+    q32 = orc.f16_to_f32(queries).astype(np.float32) * np.float32(3.0)      # un-normalised fp32 queries (src/common.rs:215-274)
+
+    def idx_fn(t, deadline):
+        c, j = 0, t
+        while True:
+            orc.index_search(block, q32[j % n_q:j % n_q + 1], k, 0)
+            c += 1
+            j += cores
+            if time.perf_counter() >= deadline:
+                return c
+    n_i, dt_i = run_threads(idx_fn)
+    m5["index_search"] = {"queries": n_i, "seconds": dt_i, "queries_per_s": n_i / dt_i, "threads": cores,
+                          "what": "orc.index_search: fp32 query x fp16 codes, FAISS SQfp16-IP order 0 + heap, one request per thread"}
+    measured["n_1e5"] = m5
+    # ---- N = 1e7 resident in DRAM (23 GB), if the host has it ----
+    big_rows = 10_000_000
+    avail = None
+    try:
+        avail = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable"))
+    except Exception:  # noqa: BLE001
+        pass
+    need = big_rows * D * 2
+    if avail is not None and avail < need + (12 << 30):
+        big_rows = max(1_000_000, int((avail - (12 << 30)) // (D * 2) // block_rows * block_rows)) if avail > (14 << 30) else 1_000_000
+    # filled by all threads at once so that first touch spreads the pages over every memory controller (one thread's np.tile
+    # would put everything on its own NUMA node and the scan would run at one node's bandwidth)
+    base = np.empty((big_rows, D), np.uint16)
+    chunk = (big_rows + cores - 1) // cores
+
+    def fill(t):     # contiguous np.copyto = memcpy with the GIL released: the fills really run side by side
+        r, hi = t * chunk, min(big_rows, (t + 1) * chunk)
         while r < hi:
             off = r % block_rows
             m = min(hi - r, block_rows - off)
             np.copyto(base[r:r + m], block[off:off + m])
             r += m
 
+    t_fill = time.perf_counter()
     fillers = [threading.Thread(target=fill, args=(t,)) for t in range(cores)]
     for th in fillers:
         th.start()
     for th in fillers:
         th.join()
-    queries = orc.gen_rows_f16(SEED_QUERY, 0, cores + 2)
-    orc.bruteforce_topk(base[:1000], queries[:1], k)  # warm
-
-    def work(t):
-        orc.bruteforce_topk(base, queries[t:t + 1], k)
-
-    threads = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-    t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    dt = time.perf_counter() - t0
-    qps_sample = cores / dt
-    # reference-faithful: single thread, full sort
-    t0 = time.perf_counter()
-    n_f = 2
-    for j in range(n_f):
-        sc = orc.score_all(base, queries[cores + j])
-        ranks = orc.ranks_from_scores(sc)
-        top = np.flatnonzero(ranks < k)
-    df = (time.perf_counter() - t0) / n_f
+    t_fill = time.perf_counter() - t_fill
+    key = "n_1e7" if big_rows == 10_000_000 else f"n_{big_rows}"
+    measured[key] = {"rows": big_rows, "GB": big_rows * D * 2 / 1e9, "fill_seconds": t_fill,
+                     "layout": f"{big_rows // block_rows} copies of the {block_rows}-row generated block (larger than any last-level cache: the scan streams from DRAM)",
+                     "fair": fair_on(base), "reference_faithful": faithful_on(base)}
+    big = measured[key]
+    del base
     model = ""
     try:
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:  # noqa: BLE001
         pass
+    scale = big_rows / n_rows
     return {
-        "value": qps_sample * sample_rows / n_rows,
-        "unit": f"queries/s over {n_rows} rows, EXTRAPOLATED x{n_rows // sample_rows} from a {sample_rows}-row DRAM-resident sample (linear in rows)",
+        "value": big["fair"]["queries_per_s"] * scale,
+        "unit": f"queries/s over {n_rows} rows = the fair rate MEASURED at {big_rows} DRAM-resident rows x {scale:g} (linear in rows; labelled scaling, see `measured` for the unscaled figures)",
         "cores": cores,
         "cores_visible": visible,
         "cpu_time_quota_cores": quota,
+        "cores_note": "threads used = 2 x the cgroup's CPU-time quota (cpu.max): under a quota the group is throttled per period, and "
+                      "oversubscribing by 2 measured best (8 / 32 / 64 / 256 threads -> 77 / 100 / 58 / 20 queries/s on a 1e6-row sample, round 3)",
         "kind": "port",
         "cpu_model": model,
-        "sample": f"fair mode: {cores} threads x 1 query x {sample_rows} rows x {D} fp16 ({sample_rows * D * 2 / 1e9:.1f} GB, DRAM-resident), "
-                  f"top-{k} ({dt:.2f} s wall, {qps_sample:.1f} q/s on the sample); scaled by rows {sample_rows}/{n_rows}",
-        "scan_GBps": qps_sample * sample_rows * D * 2 / 1e9,
-        "reference_faithful": {"value": sample_rows / n_rows / df, "unit": f"queries/s over {n_rows} rows, EXTRAPOLATED from the sample", "cores": 1,
-                               "sample": f"1 thread, {n_f} queries, {sample_rows} rows: every row scored, full sort, top-{k} "
-                                         f"({df:.2f} s per query on the sample); scaled by rows",
-                               "scan_GBps": sample_rows * D * 2 / df / 1e9},
+        "sample": f"measured, >= {min_seconds:g} s per mode: N=1e5 (1000 distinct queries; fair, reference_faithful, index_search) and "
+                  f"N={big_rows} in DRAM (fair: {big['fair']['queries']} queries on {cores} threads in {big['fair']['seconds']:.1f} s; "
+                  f"reference_faithful: {big['reference_faithful']['queries']} in {big['reference_faithful']['seconds']:.1f} s)",
+        "scan_GBps": big["fair"]["scan_GBps"],
+        "measured": measured,
+        "reference_faithful": {"value": big["reference_faithful"]["queries_per_s"] * scale, "unit": f"queries/s over {n_rows} rows, measured at {big_rows} rows x {scale:g}",
+                               "cores": 1, "scan_GBps": big["reference_faithful"]["scan_GBps"]},
     }
+
+
+def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rounds=8):
+    """The reference's call shape at the metric's size: T host threads, ONE query per call, host pointers in and out
+    (src/main.rs:896-934,1043-1049; src/query_disk_index.rs:711-736), through the cross-thread coalescer of the C ABI
+    (mse_dispatcher, csrc/dispatch.hip).  The callers are native threads (scripts/native/mse_callers.c -- what a Rust host's
+    thread-per-core loop looks like to the library), closed loop: each issues its next query when the previous one is answered.
+    Every answer is checked against one batched device pass over the same queries (a separate searcher, matrix-core mode)."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    import mse
+    from mse import ffi
+    so = os.path.join(ROOT, "scripts", "native", "libmse_callers.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
+    H = C.CDLL(so)
+    H.mse_callers_run.restype = C.c_double
+    H.mse_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_int)]
+    fn = C.cast(ffi.lib().mse_dispatcher_topk_f16, C.c_void_p)
+    n_max = max(thread_counts) * rounds
+    qdev = mse.VectorList.generate(SEED_QUERY, 1 << 20, n_max, D)       # fresh queries, copied to the HOST: callers hand over host pointers
+    q = qdev.rows(0, n_max)
+    checker = mse.Searcher(vecs)
+    want_s, want_i = checker.bruteforce_topk(q, k, mse.MODE_MFMA)
+    checker.close()
+    qdev.close()
+    disp = mse.Dispatcher(vecs)                                          # defaults: 256 queries per pass, wait budget from the row count
+    disp.search(q[0], k)                                                 # lone caller: answered at once; allocates the worker's scratch
+    points = []
+    for T in thread_counts:
+        n = T * rounds
+        sc = np.empty((n, k), np.int64)
+        ids = np.empty((n, k), np.uint32)
+        lat = np.zeros(n, np.float64)
+        failed = C.c_int(0)
+        H.mse_callers_run(fn, disp._h, q.ctypes.data, min(n, 2 * T), D, k, T, sc.ctypes.data, ids.ctypes.data, lat.ctypes.data, C.byref(failed))  # warm: two rounds
+        st0 = disp.stats()
+        dt = H.mse_callers_run(fn, disp._h, q.ctypes.data, n, D, k, T, sc.ctypes.data, ids.ctypes.data, lat.ctypes.data, C.byref(failed))
+        st1 = disp.stats()
+        ok = bool(dt > 0 and failed.value == 0 and np.array_equal(ids, want_i[:n]) and np.array_equal(sc, want_s[:n]))
+        passes = st1["passes"] - st0["passes"]
+        points.append({"threads": T, "queries": n, "queries_per_s": n / dt if dt > 0 else None, "seconds": dt,
+                       "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
+                       "passes": passes, "queries_per_pass": n / max(passes, 1), "all_answers_equal_batched_pass": ok,
+                       "vs_resident_batch_headline": (n / dt / headline_qps) if dt > 0 and headline_qps else None})
+    st = disp.stats()
+    disp.close()
+    best = max(points, key=lambda p: p["queries_per_s"] or 0)
+    return {"metric": "queries/s through host pointers, one query per call from T native threads (closed loop), coalesced behind the C ABI",
+            "threads": best["threads"], "queries_per_s": best["queries_per_s"], "latency_ms": best["latency_ms"],
+            "vs_resident_batch_headline": best["vs_resident_batch_headline"], "points": points, "k": k,
+            "dispatcher": {"max_queries_per_pass": 256, "passes_started_by_wait_budget": st["deadline_fires"], "requests_repeated_alone": st["retried_alone"]},
+            "config": {"workload": f"{len(vecs)} x {D} fp16 rows resident; each call: 1 query of {D} f16 from host memory in, top-{k} (i64 scores, u32 ids) to host memory out"}}
 
 
 def pq_bench(args):
     """BASELINE configs[4] shape at BASELINE.md's size: full ADC scan of 1e8 x 64-byte OPQ codes (+4 descriptor bytes), top-200 by
-    approximate score (the re-rank candidates), all arrays resident in HBM.  Reported end to end per query (query upload, table
-    build, scan keeping one maximum per 64 vectors, tournament, re-score of the best groups, exact top-r, download): one query per
-    call, and 32 queries per call (one upload / download; queries go through in FOURS that share one pass over the codes --
-    pq_scan64x4_kernel, integer nomination under a certificate -- and the groups alternate between two streams).  `roofline`: 68 B
-    per vector per PASS against the HBM peak, a pass taken as four batched per-query times; the scan is a 68-gather-per-vector LDS
-    loop."""
+    approximate score (the re-rank candidates), all arrays resident in HBM.  End to end per query (query upload, table build, scan
+    keeping one maximum per 64 vectors, tournament, re-score of the best groups, exact top-r, download): one query per call, and
+    32 queries per call (one upload / download; the queries go through in FOURS that share one pass over the codes --
+    pq_scan64x4_kernel, integer nomination under a certificate -- and the groups alternate between two streams).  Both windows are
+    at least a second long.  `roofline` is the scan KERNEL's (68 B per vector per launch / its HIP-event duration); the end-to-end
+    figure (a pass taken as four batched per-query times) stands beside it."""
     import numpy as np
     import mse
     n = int(args.pq_rows)
@@ -159,29 +279,52 @@ def pq_bench(args):
     scales = np.array([0.5, 0, -0.25, 0], np.float32) / np.float32(512)
     qs = (rng.standard_normal((32, D)) / np.sqrt(D)).astype(np.float32)
     pq.scan_topk(gc, qs[0], 200, 10, None, scales)
-    t0 = time.perf_counter()
-    for i in range(10):
-        pq.scan_topk(gc, qs[i], 200, 10, None, scales)
-    dt = (time.perf_counter() - t0) / 10
-    pq.scan_topk_batch(gc, qs, 200, 10, None, scales)
-    t0 = time.perf_counter()
-    for _ in range(3):
+    t0, calls1 = time.perf_counter(), 0
+    while calls1 < 40 or time.perf_counter() - t0 < 1.0:
+        pq.scan_topk(gc, qs[calls1 % 32], 200, 10, None, scales)
+        calls1 += 1
+    dt = (time.perf_counter() - t0) / calls1
+    for _ in range(2):
         pq.scan_topk_batch(gc, qs, 200, 10, None, scales)
-    db = (time.perf_counter() - t0) / (3 * len(qs))
+    t0, calls = time.perf_counter(), 0
+    while calls < 40 or time.perf_counter() - t0 < 1.0:
+        pq.scan_topk_batch(gc, qs, 200, 10, None, scales)
+        calls += 1
+    wall = time.perf_counter() - t0
+    db = wall / (calls * len(qs))
     uncert = pq.last_uncertified
+    # the scan kernel by itself: calls of FOUR queries run on one stream (nothing beside the scan), HIP events around each launch
+    pq.scan_timing(2)
+    for i in range(24):
+        pq.scan_topk_batch(gc, qs[4 * (i % 8):4 * (i % 8) + 4], 200, 10, None, scales)
+    k_ms, k_n = pq.scan_timing(0)
     gbs_pass = n * 68 / (4 * db) / 1e9
+    k_avg = k_ms / max(k_n, 1)
+    gbs_kernel = n * 68 / (k_avg * 1e-3) / 1e9 if k_n else None
+    traffic = None
+    try:     # HBM bytes per scan launch from the PMC passes (collected offline: a counter pass cannot run inside a timed run)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))["pq_scan64x4"]
+        if pm["vectors"] == n:
+            traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
     return {"metric": "OPQ/PQ 64x8-bit ADC scan + top-200", "ms_per_query": dt * 1e3, "ms_per_query_batched": db * 1e3,
             "queries_per_s_batched": 1.0 / db, "queries_per_call_batched": len(qs), "queries_per_pass_batched": 4, "vectors": n,
+            "timed": {"one_query_calls": calls1, "batched_calls": calls, "batched_seconds": wall},
             "uncertified_queries_last_batch": uncert,
             "codes_GBps_end_to_end_one_query_per_call": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
-            "roofline": {"bound": "hbm", "achieved": gbs_pass, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_pass / HBM_PEAK_GBS,
-                         "bytes_per_pass": n * 68, "queries_per_pass": 4, "traffic": None,
-                         "per_query_equivalent_GBps": n * 68 / db / 1e9,
-                         "note": "achieved = 68 B x vectors per pass / (4 x batched per-query time): a pass over the codes serves four "
-                                 "queries (12-bit integer nomination under a certificate, exact re-score of the nominated groups); the pass "
-                                 "is bound by its LDS gathers and VALU, not by HBM (profiles/r03_pmc_pq_scan.txt); "
-                                 "per_query_equivalent_GBps is round 2's accounting (one pass per query)"},
-            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), four queries' 12-bit tables 68 x 256 x 4 x u16 in LDS, r = 200"}}
+            "roofline": {"bound": "hbm", "kernel": "pq_scan64x4_kernel<16>", "achieved": gbs_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (gbs_kernel / HBM_PEAK_GBS) if gbs_kernel else None, "avg_launch_ms": k_avg, "launches_timed": k_n,
+                         "bytes_per_launch": n * 68, "queries_per_launch": 4, "traffic": traffic,
+                         "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
+                         "end_to_end": {"achieved": gbs_pass, "frac": gbs_pass / HBM_PEAK_GBS,
+                                        "note": "68 B x vectors / (4 x batched per-query time): table build, scan, tournament, re-score of the nominated "
+                                                "groups, exact top-r, certificate, download -- two streams, one group of four queries each"},
+                         "note": "achieved = 68 B x vectors per launch / the kernel's HIP-event duration in 24 four-query calls (one stream: nothing runs "
+                                 "beside the scan; in the 32-query calls two streams interleave and a launch's event interval would include its wait "
+                                 "for the other stream's scan).  Round 4 kernel: bank-conflict-free rotated gathers, sums on the matrix cores "
+                                 "(v_mfma_i32_16x16x64_i8) -- DESIGN.md 3.3"},
+            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), four queries' 12-bit tables (code-major, 138 KiB) in LDS, r = 200"}}
 
 
 def graph_rows(n, seed, centres):
@@ -563,6 +706,7 @@ def main():
                     help="developer dry run of the in-process --gpus N path on fewer devices (shard g on device g mod count)")
     ap.add_argument("--no-siglip", action="store_true", help="skip the SigLIP image-tower leg")
     ap.add_argument("--no-pq", action="store_true", help="skip the OPQ/PQ scan leg")
+    ap.add_argument("--no-callers", action="store_true", help="skip the concurrent-callers leg (T threads x 1 query through the coalescer)")
     ap.add_argument("--pq-rows", type=float, default=1e8)
     ap.add_argument("--no-graph", action="store_true", help="skip the GPU-resident beam-search leg")
     ap.add_argument("--graph-rows", type=float, default=2e5)
@@ -858,6 +1002,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    callers_line = None
+    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_callers:
+        try:
+            callers_line = concurrent_callers_bench(vecs, k, nq * args.steps / elapsed)
+        except Exception as e:  # noqa: BLE001
+            callers_line = {"error": repr(e)}
+
     # ---- second half of BASELINE.json's metric: SigLIP image embeds/s/GPU (replicas, no collective) ----
     siglip_line = None
     if not args.no_siglip:
@@ -943,6 +1094,8 @@ def main():
             "hbm_bound_point": alt,
             "certificate": stats,
         }
+        if callers_line:
+            line["concurrent_callers"] = callers_line
         if siglip_line:
             line["siglip"] = siglip_line
         if pq_line:

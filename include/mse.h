@@ -236,6 +236,10 @@ int mse_pq_adc(mse_pq* pq, const float* lut, const uint8_t* codes, size_t n, int
 typedef struct mse_codes mse_codes;
 mse_codes* mse_codes_from_host(const uint8_t* codes, size_t n, size_t code_size, const uint8_t* descriptors,
                                size_t n_descriptors);
+/* The same from rows already resident in HBM: codes = quantize_batch (vector.rs:331-364) of the f32 widenings of the base's
+ * f16 rows -- the encode step of src/dump_processor.rs:468-481 -- computed on the device, 65536 rows at a time; only the
+ * descriptor bytes (optional) cross PCIe.  Codes equal mse_pq_quantize_batch's on the same rows. */
+mse_codes* mse_codes_quantize_base(mse_pq* pq, const mse_base* b, const uint8_t* descriptors, size_t n_descriptors);
 void mse_codes_free(mse_codes* c);
 size_t mse_codes_len(const mse_codes* c);
 /* out[i] = adc(lut, codes[ids[i]]) + descriptor_product(scales, ids[i])   (query_disk_index.rs:189-203,135-142);
@@ -259,6 +263,13 @@ uint32_t mse_pq_last_uncertified(mse_pq* pq);
  * nominates with; lut1 == NULL: the one-query kernel, else the two-queries-per-pass kernel.  out0 / out1: [ceil(n/64)] on the host. */
 int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, const float* lut1, const float* scales, int64_t* out0,
                            int64_t* out1);
+/* HIP-event timing of the four-queries-per-pass scan kernel inside mse_pq_scan_topk_batch (the dominant kernel, for the
+ * roofline report): returns the totals accumulated so far, then sets the mode: 0 off, 1 on, 2 on and reset. */
+int mse_pq_scan_timing(mse_pq* pq, int enable, double* total_ms, uint64_t* launches);
+/* test hook: the four-queries-per-pass integer nomination scan alone.  luts4 [4][64*256] (n_valid of them used), scales NULL or [4];
+ * out [4][ceil(n/64)] u32 group maxima of the integer sums, params_out [4][4] = delta, c, eps, ok of each query's 12-bit table. */
+int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts4, const float* scales, int n_valid, uint32_t* out,
+                            double* params_out);
 /* descriptor_product (src/query_disk_index.rs:135-142) for one id, host-side helper. */
 int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id);
 

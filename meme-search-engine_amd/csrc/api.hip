@@ -376,6 +376,7 @@ void mse_searcher_free(mse_searcher* s) {
     if (s->own_stream && s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     delete s;
 }
 int mse_searcher_set_stream(mse_searcher* s, void* hip_stream) {

@@ -583,7 +583,20 @@ static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, con
     void* table = s->pq4.p;
     Pq4Params* params = reinterpret_cast<Pq4Params*>(s->pq4.as<char>() + pq4_table_bytes());
     if (launch_pq4_table(lut_dev, scales_dev, 4, table, params, st)) return -1;
+    hipEvent_t te0 = nullptr, te1 = nullptr;
+    if (pq->timing) {
+        while (s->ev_pool.size() < s->ev_used + 2) {
+            hipEvent_t e = nullptr;
+            MSE_HIP_TRY(hipEventCreate(&e));
+            s->ev_pool.push_back(e);
+        }
+        te0 = s->ev_pool[s->ev_used];
+        te1 = s->ev_pool[s->ev_used + 1];
+        s->ev_used += 2;
+        MSE_HIP_TRY(hipEventRecord(te0, st));
+    }
     if (launch_pq_scan_gmax4(table, c->codes, c->n, desc, s->gmax.as<uint32_t>(), s->n_cu, st)) return -1;
+    if (te1) MSE_HIP_TRY(hipEventRecord(te1, st));
     // the four tails as ONE chain of launches with a query dimension (their kernels are latency-bound: four chains in a row cost more
     // than the scan); every buffer at its final size before the first kernel that uses it
     const size_t n_cand = n_nom * 64;
@@ -730,6 +743,14 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         }
         if (hipMemcpyAsync(pq->pin, s->out_scores.p, nq * k * 12, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
+        for (mse_searcher* ln : lanes)      // both streams are idle here: the scan launches' event pairs can be read
+            if (ln) {
+                for (size_t e = 0; e + 1 < ln->ev_used; e += 2) {
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, ln->ev_pool[e], ln->ev_pool[e + 1]) == hipSuccess) { pq->scan_ms_total += ms; pq->scan_launches++; }
+                }
+                ln->ev_used = 0;
+            }
         memcpy(scores, pq->pin, nq * k * 8);
         memcpy(ids, static_cast<char*>(pq->pin) + nq * k * 8, nq * k * 4);
         for (size_t i = 0; i < nq * k; i++)
@@ -765,6 +786,76 @@ int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, co
     if (rc) return -1;
     MSE_HIP_TRY(hipMemcpy(out0, g0, n_groups * 8, hipMemcpyDeviceToHost));
     if (lut1) MSE_HIP_TRY(hipMemcpy(out1, g1, n_groups * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// HIP-event timing of the four-queries-per-pass scan kernel (the dominant kernel of a batched scan): returns the totals so far,
+// then sets the mode: 0 off, 1 on, 2 on and reset
+int mse_pq_scan_timing(mse_pq* pq, int enable, double* total_ms, uint64_t* launches) {
+    if (!pq) return fail("null quantiser");
+    std::lock_guard<std::mutex> g(pq->mu);
+    if (total_ms) *total_ms = pq->scan_ms_total;
+    if (launches) *launches = pq->scan_launches;
+    if (enable == 2) { pq->scan_ms_total = 0.0; pq->scan_launches = 0; }
+    pq->timing = enable != 0;
+    return 0;
+}
+
+// PQ codes of rows that are already resident in HBM: quantize_batch (vector.rs:331-364) over f32 widenings of the base's f16 rows
+// (what dump_processor feeds it, src/dump_processor.rs:468-481), 65536 rows at a time on the device; only the descriptors cross
+// PCIe.  The codes equal mse_pq_quantize_batch's on the same rows.
+mse_codes* mse_codes_quantize_base(mse_pq* pq, const mse_base* b, const uint8_t* descriptors, size_t n_descriptors) {
+    if (!pq || !b) { fail("null quantiser or base"); return nullptr; }
+    if (b->d != pq->d) { fail("base width differs from the quantiser"); return nullptr; }
+    mse_codes* c = new (std::nothrow) mse_codes();
+    if (!c) { fail("out of host memory"); return nullptr; }
+    const size_t n = b->n, cs = pq->n_chunks;
+    c->n = n; c->code_size = cs; c->n_desc = descriptors ? n_descriptors : 0;
+    bool ok = hipMalloc((void**)&c->codes, n * cs + 4096) == hipSuccess;
+    if (ok && c->n_desc) {
+        ok = hipMalloc((void**)&c->desc, n * c->n_desc + 256) == hipSuccess;
+        if (ok && n) ok = hipMemcpy(c->desc, descriptors, n * c->n_desc, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (ok) {
+        std::lock_guard<std::mutex> g(pq->mu);
+        const size_t step = 65536;
+        ok = pq->a.ensure(step * pq->d * 4) == 0 && pq->b.ensure(step * pq->d * 4) == 0;
+        for (size_t r0 = 0; ok && r0 < n; r0 += step) {
+            const size_t m = std::min(step, n - r0);
+            ok = launch_f16_to_f32(b->dev + r0 * b->d, m * b->d, pq->a.as<float>(), nullptr) == 0 &&
+                 launch_pq_transform(pq->transform, (int)pq->d, pq->a.as<float>(), m, pq->b.as<float>(), nullptr) == 0 &&
+                 launch_pq_quantize(pq->centroids, (int)pq->n_centroids, (int)pq->d, (int)pq->dpc, pq->b.as<float>(), m, c->codes + r0 * cs, nullptr) == 0;
+        }
+        if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+    }
+    if (!ok) { mse_codes_free(c); if (std::string(mse_last_error()).empty()) fail("device allocation / quantisation failed"); return nullptr; }
+    return c;
+}
+
+// test hook: the integer nomination scan by itself -- the four queries' group maxima (u32, [4][ceil(n / 64)]) and their
+// certificate parameters (params_out [4][4] = delta, c, eps, ok), so that a test can rebuild the 12-bit tables on the host and
+// check every maximum of the matrix-core scan against plain integer sums
+int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts4, const float* scales, int n_valid, uint32_t* out,
+                            double* params_out) {
+    if (!pq || !c || !luts4 || !out || !params_out) return fail("null argument");
+    if (c->code_size != pq->n_chunks || pq->n_chunks != 64 || pq->n_centroids != 256) return fail("the four-query scan serves 64 x 256 codecs only");
+    if (n_valid < 1 || n_valid > 4) return fail("n_valid must be 1 .. 4");
+    const uint8_t* desc = (scales && c->n_desc) ? c->desc : nullptr;
+    if (desc && c->n_desc != 4) return fail("the four-query scan takes 4 descriptor bytes");
+    if (c->n == 0) return 0;
+    std::lock_guard<std::mutex> g(pq->mu);
+    const size_t lut_bytes = (size_t)4 * 64 * 256 * 4, n_groups = (c->n + 63) / 64;
+    if (pq->a.ensure(lut_bytes + 256) || pq->b.ensure(pq4_table_bytes() + 4 * sizeof(Pq4Params)) || pq->c.ensure(4 * n_groups * 4)) return -1;
+    float* sc = reinterpret_cast<float*>(pq->a.as<char>() + lut_bytes);
+    MSE_HIP_TRY(hipMemcpy(pq->a.p, luts4, lut_bytes, hipMemcpyHostToDevice));
+    if (desc) MSE_HIP_TRY(hipMemcpy(sc, scales, 16, hipMemcpyHostToDevice));
+    Pq4Params* params = reinterpret_cast<Pq4Params*>(pq->b.as<char>() + pq4_table_bytes());
+    if (launch_pq4_table(pq->a.as<float>(), desc ? sc : nullptr, n_valid, pq->b.p, params, nullptr)) return -1;
+    if (launch_pq_scan_gmax4(pq->b.p, c->codes, c->n, desc, pq->c.as<uint32_t>(), device_cu_count(), nullptr)) return -1;
+    Pq4Params ph[4];
+    MSE_HIP_TRY(hipMemcpy(out, pq->c.p, 4 * n_groups * 4, hipMemcpyDeviceToHost));
+    MSE_HIP_TRY(hipMemcpy(ph, params, sizeof(ph), hipMemcpyDeviceToHost));
+    for (int j = 0; j < 4; j++) { params_out[4 * j] = ph[j].delta; params_out[4 * j + 1] = ph[j].c; params_out[4 * j + 2] = ph[j].eps; params_out[4 * j + 3] = ph[j].ok; }
     return 0;
 }
 

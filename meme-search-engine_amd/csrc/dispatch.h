@@ -7,10 +7,11 @@
 // arriving with one query each must share a pass: callers enqueue and block, ONE worker thread per handle gathers what is
 // waiting and runs a single batched pass, then hands every caller exactly its own rows.
 //
-// Gather rule (no fixed batching delay for a lone caller): the worker fires when as many queries are waiting as its last
-// pass answered (those callers are the ones about to come back), or `max_queries`, or when the oldest waiting request is
-// `max_wait` old -- whichever comes first.  A single caller therefore never waits (last pass = 1 query), T closed-loop
-// callers settle at T queries per pass after two passes, and callers that leave cost the rest at most one `max_wait`.
+// Gather rule (no fixed batching delay for a lone caller): the worker fires when its target is waiting -- the queries that
+// queued up during the last pass plus the ones that pass answered (closed-loop callers are back within microseconds) -- or
+// `max_queries`, or when the oldest waiting request is `max_wait` old and the callers just answered had a grace period
+// (<= 1 ms) to return, whichever comes first.  A single caller therefore never waits (target 1), T closed-loop callers settle
+// at T queries per pass after two passes, and callers that do not come back cost one grace period, then the guess backs off.
 #pragma once
 #include "common.h"
 #include <atomic>

@@ -58,11 +58,15 @@ void Coalescer::loop() {
     if (on_start_) on_start_();
     std::vector<DispatchReq*> batch;
     std::unique_lock<std::mutex> lk(mu_);
+    auto grace_until = std::chrono::steady_clock::time_point::min();
+    unsigned miss_streak = 0, since_miss = 0;
     for (;;) {
         cv_worker_.wait(lk, [&] { return stop_ || !queue_.empty(); });
         if (stop_) break;
-        // gather: until as many queries wait as the last pass answered (capped), or the oldest request is max_wait old
-        const auto deadline = queue_.front()->t_arrive + std::chrono::microseconds(max_wait_us_.load());
+        // gather until the target is waiting (dispatch.h), or the oldest request is max_wait old -- but never before the callers
+        // just answered had their grace period to come back
+        auto deadline = queue_.front()->t_arrive + std::chrono::microseconds(max_wait_us_.load());
+        if (grace_until > deadline) deadline = grace_until;
         bool by_deadline = false;
         while (!stop_ && queued_queries_ < std::min(max_queries_, expect_)) {
             if (cv_worker_.wait_until(lk, deadline) == std::cv_status::timeout) { by_deadline = true; break; }
@@ -86,7 +90,23 @@ void Coalescer::loop() {
         st_.queries += nq;
         st_.max_pass_queries = std::max<uint64_t>(st_.max_pass_queries, nq);
         if (by_deadline) st_.deadline_fires++;
-        expect_ = std::max<size_t>(1, nq);
+        // Next target: what queued up during this pass PLUS the callers answered now -- closed-loop callers (a thread per core,
+        // one request at a time) are back within microseconds, and without counting them T callers settle into two groups of T/2
+        // taking turns.  Callers that do not come back (open-loop arrivals) cost one grace period, after which the guess is
+        // retried only every 2, 4, ... 64 passes.
+        bool expect_returners = true;
+        if (by_deadline) {
+            miss_streak++;
+            since_miss = 0;
+            expect_returners = false;
+        } else if (miss_streak) {
+            if (++since_miss >= (1u << std::min(miss_streak, 6u))) since_miss = 0; else expect_returners = false;
+            if (expect_returners && queued_queries_ >= nq) miss_streak = 0;
+        }
+        expect_ = std::max<size_t>(1, queued_queries_ + (expect_returners ? nq : 0));
+        const uint32_t grace_us = std::min<uint32_t>(max_wait_us_.load(), 1000);
+        grace_until = expect_returners ? std::chrono::steady_clock::now() + std::chrono::microseconds(grace_us)
+                                       : std::chrono::steady_clock::time_point::min();
         for (DispatchReq* r : batch) {
             r->done = true;
             r->cv.notify_one();

@@ -106,6 +106,7 @@ int launch_pq4_certify(const Pq4Params* params, const uint32_t* group_keys, int 
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,
                           const float* scales, int64_t* out, hipStream_t stream);
 int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stream);
+int launch_f16_to_f32(const uint16_t* in, size_t n, float* out, hipStream_t stream);
 int launch_pq_lut_batch(const float* centroids, int n_centroids, int d, int dpc, const float* t, size_t nq, float* lut,
                         hipStream_t stream);
 int rank_max_targets();

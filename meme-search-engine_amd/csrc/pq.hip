@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void pq_quantize_tiled_kernel(const float* __r
 // ascending: s += lut[i][code_i] (plain fp32 adds, the reference's order), then `(s * 2^32) as i64`;
 // optional descriptor bias added afterwards in i64 (src/query_disk_index.rs:135-142,202).
 // ids == nullptr: vector p is row p of `codes` (full scan); otherwise row ids[p] (gathered).
-__global__ __launch_bounds__(256) void pq_adc_kernel(const float* __restrict__ lut, int n_chunks, int n_centroids,
+__global__ __launch_bounds__(1024) void pq_adc_kernel(const float* __restrict__ lut, int n_chunks, int n_centroids,
                                                      const uint8_t* __restrict__ codes, size_t n_codes,
                                                      const uint32_t* __restrict__ ids, size_t n,
                                                      const uint8_t* __restrict__ desc, int n_desc,
@@ -215,7 +215,13 @@ __global__ __launch_bounds__(256) void pq_adc_kernel(const float* __restrict__ l
     lut += (size_t)blockIdx.y * lut_n;
     if (ids) ids += (size_t)blockIdx.y * q_stride;
     out += (size_t)blockIdx.y * q_stride;
-    for (int e = threadIdx.x; e < lut_n; e += blockDim.x) s_lut[e] = lut[e];
+    if ((lut_n & 3) == 0 && (reinterpret_cast<uintptr_t>(lut) & 15) == 0) {     // 16 bytes per thread and step
+        const float4* src = reinterpret_cast<const float4*>(lut);
+        float4* dst = reinterpret_cast<float4*>(s_lut);
+        for (int e = threadIdx.x; e < lut_n / 4; e += blockDim.x) dst[e] = src[e];
+    } else {
+        for (int e = threadIdx.x; e < lut_n; e += blockDim.x) s_lut[e] = lut[e];
+    }
     __syncthreads();
     const bool vec16 = (n_chunks % 16) == 0;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
@@ -490,164 +496,246 @@ __global__ __launch_bounds__(NW * 64) void pq_scan64x2_kernel(const float* __res
 // score is strictly above that, no excluded vector belongs to the top r.  Otherwise the query is repeated through the exact scan.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int PQ4_CHUNKS = 68;                     // 64 code chunks + 4 descriptor bytes
-constexpr int PQ4_TABLE_BYTES = PQ4_CHUNKS * 256 * 8;   // 136 KiB
-constexpr int PQ4_WAVES = 16;   // 74 VGPRs: register-wise even more would fit; 16 x 64 = the largest workgroup
+// LDS image of the four queries' table (round 4): the entry of (code v, chunk c) lies at byte (c / 32) * 65536 + v * 256 +
+// (c % 32) * 8 -- code-major, so that the bank pair of a ds_read_b64 is c mod 32 whatever the code, and with the code in byte 1
+// of the address, so that ONE v_perm_b32 assembles an address from a code byte and a lane constant -- and the entry of
+// (descriptor value v, byte d) at 131072 + v * 40 + d * 8.  An entry is 8 bytes, two per query: the value's low 6 bits and the
+// bits above them (<= 63 for the 12-bit code entries, <= 255 for the 14-bit descriptor entries), each XOR 0x80 (the matrix
+// core reads the bytes as signed: stored value = byte - 128).
+constexpr int PQ4_CODE_BYTES = 256 * 64 * 8;
+constexpr int PQ4_DESC_STRIDE = 40;
+constexpr int PQ4_TABLE_BYTES = PQ4_CODE_BYTES + 256 * PQ4_DESC_STRIDE;   // 138 KiB
+constexpr int PQ4_WAVES = 16;
 
-// one workgroup per query j of the group of four: params[j], and lane j of every table entry
-__global__ __launch_bounds__(256) void pq4_table_kernel(const float* __restrict__ luts /* [4][64 * 256] */, const float* __restrict__ scales,
-                                                        int n_valid, uint16_t* __restrict__ table /* [68 * 256][4] */,
-                                                        Pq4Params* __restrict__ params) {
-    const int j = blockIdx.x, t = threadIdx.x;
-    __shared__ float s_lo[64], s_hi[64];
-    __shared__ double s_inv;
-    __shared__ int s_bad;
-    if (j >= n_valid) {      // unused slots of the group: zero entries
-        for (int e = t; e < PQ4_CHUNKS * 256; e += 256) table[(size_t)e * 4 + j] = 0;
-        if (t == 0) params[j] = Pq4Params{0.0, 0.0, 0.0, 0};
-        return;
-    }
-    const float* lut = luts + (size_t)j * 64 * 256;
-    if (t == 0) s_bad = 0;
-    __syncthreads();
-    // per-chunk minimum / maximum over the 256 entries: thread t holds entry t of every chunk, waves reduce by shuffles
-    __shared__ float s_wlo[4][64], s_whi[4][64];
-    {
-        bool bad = false;
-        for (int c = 0; c < 64; c++) {
-            const float x = lut[c * 256 + t];
-            bad = bad || !(fabsf(x) <= 3.0e38f);     // NaN or infinity: this query takes the exact scan
-            float lo = x, hi = x;
+// per (chunk, query): minimum and maximum over the 256 table entries; a query with a NaN / infinite entry is flagged
+__global__ __launch_bounds__(64) void pq4_minmax_kernel(const float* __restrict__ luts /* [4][64 * 256] */, int n_valid,
+                                                       float* __restrict__ lohi /* [4][64][2] */, int* __restrict__ bad /* [4], zeroed */) {
+    const int c = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
+    if (j >= n_valid) return;
+    const float4 x = reinterpret_cast<const float4*>(luts + ((size_t)j * 64 + c) * 256)[t];
+    const bool b = !(fabsf(x.x) <= 3.0e38f) || !(fabsf(x.y) <= 3.0e38f) || !(fabsf(x.z) <= 3.0e38f) || !(fabsf(x.w) <= 3.0e38f);
+    float lo = fminf(fminf(x.x, x.y), fminf(x.z, x.w)), hi = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
-            if ((t & 63) == 0) { s_wlo[t >> 6][c] = lo; s_whi[t >> 6][c] = hi; }
+    for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (__ballot(b) != 0ull && t == 0) atomicOr(&bad[j], 1);
+    if (t == 0) { lohi[(j * 64 + c) * 2] = lo; lohi[(j * 64 + c) * 2 + 1] = hi; }
+}
+
+// block c (0 .. 63: code chunks, 64 .. 67: descriptor bytes), thread v (code / descriptor value): the four queries' entries of
+// (v, c), one 8-byte store.  Every block works out the four queries' parameters for itself (64-term loops in double, in the same
+// order as ever: the numbers are those of round 3's single-workgroup kernel); block 0 publishes them.
+__global__ __launch_bounds__(256) void pq4_quant_kernel(const float* __restrict__ luts, const float* __restrict__ scales, int n_valid,
+                                                       const float* __restrict__ lohi, const int* __restrict__ bad,
+                                                       unsigned long long* __restrict__ table, Pq4Params* __restrict__ params) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    __shared__ double s_inv[4];
+    __shared__ float s_lo[4];
+    if (t < 4) {
+        const int j = t;
+        double inv = 0.0;
+        float lo_c = 0.0f;
+        Pq4Params P{0.0, 0.0, 0.0, 0};
+        if (j < n_valid) {
+            double range = 0.0, a_sum = 0.0, c_sum = 0.0;
+            for (int cc = 0; cc < 64; cc++) {
+                const double lo = (double)lohi[(j * 64 + cc) * 2], hi = (double)lohi[(j * 64 + cc) * 2 + 1];
+                range = fmax(range, hi - lo);
+                a_sum += fmax(fabs(lo), fabs(hi));
+                c_sum += lo;
+            }
+            int is_bad = bad[j];
+            double delta = range / 4095.0, bias_err = 0.0, bias_abs = 0.0;
+            if (scales) {
+                for (int d = 0; d < 4; d++) {
+                    const double sc = (double)scales[d];
+                    delta = fmax(delta, fabs(sc) * 255.0 / 16383.0);
+                    c_sum += fmin(0.0, sc * 255.0);                       // lo of descriptor chunk d
+                    bias_err += fabs(sc) * 255.0 * 5.9604644775390625e-8;  // rounding of the f32 product sc * v
+                    bias_abs += fabs(sc) * 255.0;
+                    if (!(fabs(sc) <= 3.0e38)) is_bad = 1;
+                }
+            }
+            // `(x * 2^32) as i64` saturates from |x| = 2^31 on: the bound below assumes it never does (unreachable for
+            // normalised embeddings; such a query takes the exact scan)
+            if (!(a_sum * 1.001 + bias_abs < 1073741824.0)) is_bad = 1;
+            if (!(delta > 1e-300)) delta = 1e-300;
+            inv = 1.0 / delta;
+            // 34 delta (68 entry roundings) + f32 summation + bias products + five i64 truncations, with a relative cushion for the
+            // double arithmetic of this bound itself
+            const double eps = (34.0 * delta + 64.0 * 5.9604644775390625e-8 * 1.01 * a_sum + bias_err + 5.0 / 4294967296.0) * (1.0 + 1e-9) + 1e-300;
+            P = Pq4Params{delta, c_sum, eps, is_bad ? 0 : 1};
+            if (c < 64) lo_c = lohi[(j * 64 + c) * 2];
         }
-        if (bad) s_bad = 1;
+        s_inv[j] = inv;
+        s_lo[j] = lo_c;
+        if (c == 0) params[j] = P;
     }
     __syncthreads();
-    if (t < 64) {
-        s_lo[t] = fminf(fminf(s_wlo[0][t], s_wlo[1][t]), fminf(s_wlo[2][t], s_wlo[3][t]));
-        s_hi[t] = fmaxf(fmaxf(s_whi[0][t], s_whi[1][t]), fmaxf(s_whi[2][t], s_whi[3][t]));
-    }
-    __syncthreads();
-    if (t == 0) {
-        double range = 0.0, a_sum = 0.0, c_sum = 0.0;
-        for (int c = 0; c < 64; c++) {
-            range = fmax(range, (double)s_hi[c] - (double)s_lo[c]);
-            a_sum += fmax(fabs((double)s_lo[c]), fabs((double)s_hi[c]));
-            c_sum += (double)s_lo[c];
-        }
-        double delta = range / 4095.0, bias_err = 0.0;
-        if (scales) {
-            for (int d = 0; d < 4; d++) {
-                const double sc = (double)scales[d];
-                delta = fmax(delta, fabs(sc) * 255.0 / 16383.0);
-                c_sum += fmin(0.0, sc * 255.0);                       // lo of descriptor chunk d
-                bias_err += fabs(sc) * 255.0 * 5.9604644775390625e-8;  // rounding of the f32 product sc * v
-                if (!(fabs(sc) <= 3.0e38)) s_bad = 1;
+    unsigned long long e8 = 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double q = 0.0;
+        if (j < n_valid) {
+            if (c < 64) {
+                q = ((double)luts[((size_t)j * 64 + c) * 256 + t] - (double)s_lo[j]) * s_inv[j];
+                q = q < 0.0 ? 0.0 : (q > 4095.0 ? 4095.0 : q);
+            } else if (scales) {
+                const double sc = (double)scales[c - 64];
+                q = (sc * (double)t - fmin(0.0, sc * 255.0)) * s_inv[j];
+                q = q < 0.0 ? 0.0 : (q > 16383.0 ? 16383.0 : q);
             }
         }
-        if (!(delta > 1e-300)) delta = 1e-300;
-        s_inv = 1.0 / delta;
-        // 34 delta (68 entry roundings) + f32 summation + bias products + five i64 truncations, with a relative cushion for the
-        // double arithmetic of this bound itself
-        const double eps = (34.0 * delta + 64.0 * 5.9604644775390625e-8 * 1.01 * a_sum + bias_err + 5.0 / 4294967296.0) * (1.0 + 1e-9) + 1e-300;
-        params[j] = Pq4Params{delta, c_sum, eps, s_bad ? 0 : 1};
+        const unsigned long long e = (unsigned long long)(uint16_t)__double2int_rn(q);
+        e8 |= (((e & 63ull) | ((e >> 6) << 8)) ^ 0x8080ull) << (16 * j);
     }
-    __syncthreads();
-    const double inv = s_inv;
-    for (int c = 0; c < 64; c++) {
-        double q = ((double)lut[c * 256 + t] - (double)s_lo[c]) * inv;
-        q = q < 0.0 ? 0.0 : (q > 4095.0 ? 4095.0 : q);
-        table[((size_t)c * 256 + t) * 4 + j] = (uint16_t)__double2int_rn(q);
-    }
-    for (int d = 0; d < 4; d++) {
-        double q = 0.0;
-        if (scales) {
-            const double sc = (double)scales[d];
-            q = (sc * (double)t - fmin(0.0, sc * 255.0)) * inv;
-            q = q < 0.0 ? 0.0 : (q > 16383.0 ? 16383.0 : q);
-        }
-        table[((size_t)(64 + d) * 256 + t) * 4 + j] = (uint16_t)__double2int_rn(q);
-    }
+    const size_t off = c < 64 ? (size_t)(c >> 5) * 65536 + (size_t)t * 256 + (size_t)(c & 31) * 8
+                              : (size_t)PQ4_CODE_BYTES + (size_t)t * PQ4_DESC_STRIDE + (size_t)(c - 64) * 8;
+    table[off / 8] = e8;
 }
 
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, (u16x2v)(__builtin_bit_cast(u16x2v, a) + __builtin_bit_cast(u16x2v, b)));
-}
-// maximum of a u32 over the 64 lanes of the wave, returned in an SGPR: four DPP steps inside each 16-lane row, then the four rows
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-    return o > v ? o : v;
-}
-__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
-    v = dpp_umax<0xb1>(v);    // quad_perm [1,0,3,2]
-    v = dpp_umax<0x4e>(v);    // quad_perm [2,3,0,1]
-    v = dpp_umax<0x141>(v);   // row_half_mirror
-    v = dpp_umax<0x140>(v);   // row_mirror: every lane now holds its row's maximum
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
-    return a > b ? a : b;
-}
 
-// out[j * n_groups + g] = max over the 64 vectors of group g of query j's integer sum (0 past the end of the codes)
+// out[j * n_groups + g] = max over the 64 vectors of group g of query j's integer sum (0 past the end of the codes).
+//
+// Round 4: the sums are taken by the matrix cores and the gathers are bank-conflict free.
+//   * A wave handles 16 vectors at a time; lane (v = lane % 16, g = lane / 16) owns bytes 16g .. 16g+15 of vector v's code row,
+//     i.e. chunks 16g .. 16g+15, and gathers their sixteen 8-byte entries (four queries each).
+//   * The integer sum is order-free, so WHICH of its sixteen chunks a lane fetches at step s is free: lane (v, g) takes chunk
+//     16g + (s + v) % 16.  With the table code-major (bank pair = chunk % 32) the 32 lanes of a ds_read_b64 group then hit 32
+//     different bank pairs at every step, whatever the codes (round 3: 2.4-way conflicts on random codes, 46 % of the kernel's
+//     cycles).  The lane's 16 code bytes arrive by ONE dwordx4 load (a wave covers 1 KiB contiguously) and are rotated left by v
+//     bytes in registers -- two select stages for the dwords, four v_alignbyte_b32 for the bytes -- so that the byte for step s
+//     sits at the static position s.  (Loading the dwords in rotated order instead -- 16 scattered dword loads per lane and
+//     group -- made the texture addresser the bottleneck: TA busy 75 %, kernel 20 % slower than round 3's.)
+//   * A gather address is ONE instruction: v_perm_b32 puts the code byte into byte 1 and the lane's chunk offset (a per-lane
+//     constant per step) into bytes 0 and 2.
+//   * Two gathered entries are sixteen signed bytes = one lane's A operand of v_mfma_i32_16x16x64_i8 (row v, any 16 of the 64
+//     k positions).  B[k][q] = 1 for k % 8 == 2q (low 6 bits) and 64 for k % 8 == 2q + 1 (the bits above): column q of the
+//     16 x 16 result IS query q's integer sum (minus a constant for the signed bytes) -- 8 MFMAs (+1 for the descriptor entries)
+//     replace 2 x 68 packed adds per vector, and nothing is left to combine afterwards.
+//   VALU instructions per 64 vectors: 340 (round 3) -> 344 (first matrix-core form: two-instruction addresses, low/high byte
+//   columns combined by DPP) -> this form; LDS cycles per gather instruction 5.8 -> 2.3.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const u32x2v* __restrict__ table, const uint8_t* __restrict__ codes, size_t n,
+__global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const uint4* __restrict__ table, const uint8_t* __restrict__ codes, size_t n,
                                                              const uint8_t* __restrict__ desc, uint32_t* __restrict__ out, size_t n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     require_lds_base_zero(smem);
-    u32x2v* s_tab = reinterpret_cast<u32x2v*>(smem);
-    for (int e = threadIdx.x; e < PQ4_CHUNKS * 256; e += blockDim.x) s_tab[e] = table[e];
+    {
+        uint4* s_tab = reinterpret_cast<uint4*>(smem);
+        for (int e = threadIdx.x; e < PQ4_TABLE_BYTES / 16; e += blockDim.x) s_tab[e] = table[e];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int v = lane & 15, g = lane >> 4, a = v >> 2;
+    const uint32_t b = (uint32_t)(v & 3);
+    // chunk 16g + (s + v) % 16 as address bytes: byte 2 = chunk / 32, byte 0 = (chunk % 32) * 8; byte 1 will be the code
+    uint32_t choff[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) choff[s] = (uint32_t)(((g >> 1) << 16) | (128 * (g & 1) + 8 * ((s + v) & 15)));
+    // B[k][col]: k % 8 == 2 col -> 1, == 2 col + 1 -> 64 (col < 4); lane (col = v, k block g) holds k = 16g .. 16g+15
+    v4i32 bop = {0, 0, 0, 0};
+    if (v < 4) {
+        const int w = 0x4001 << (16 * (v & 1));
+        if (v < 2) { bop.x = w; bop.z = w; } else { bop.y = w; bop.w = w; }
+    }
+    // this lane's 16 bytes inside a 16-vector block of code rows (1 KiB): the wave's dwordx4 loads cover the block contiguously
+    const uint32_t roff = (uint32_t)(v * 64 + 16 * g);
+    const bool a1 = (a & 1) != 0, a2 = (a & 2) != 0;
+    const uint32_t doff = (uint32_t)(PQ4_CODE_BYTES + 8 * g);   // descriptor entry of byte g: + value * 40
+    const int n_entries = desc ? 68 : 64;
+    const int bias = 128 * 65 * n_entries;
     const size_t stride = (size_t)gridDim.x * NW;
     size_t grp = (size_t)blockIdx.x * NW + wave;
-    auto load_rows = [&](size_t gi, uint4 (&w4)[4], uint32_t& dw) {
-        const size_t v = gi * 64 + lane;            // the allocations carry slack for the last, partial group
-        typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-        const u32x4v* row = reinterpret_cast<const u32x4v*>(codes + v * 64);
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v nx[4];
+    uint32_t dnx[4];
+    auto load_rows = [&](size_t gi) {       // the allocations carry slack for the last, partial group
+        const uint8_t* base = codes + gi * 4096 + roff;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const u32x4v t = __builtin_nontemporal_load(row + p);
-            w4[p] = uint4{t.x, t.y, t.z, t.w};
+        for (int sb = 0; sb < 4; sb++) {
+            nx[sb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(base + sb * 1024));
+            const size_t vec = gi * 64 + sb * 16 + v;
+            dnx[sb] = (desc && vec < n) ? reinterpret_cast<const uint32_t*>(desc)[vec] : 0u;
         }
-        dw = (desc && v < n) ? reinterpret_cast<const uint32_t*>(desc)[v] : 0u;
     };
-    uint4 nx[4];
-    uint32_t dw_next = 0;
-    if (grp < n_groups) load_rows(grp, nx, dw_next);
-    uint32_t sh3 = 3;
-    asm volatile("" : "+v"(sh3));
+    if (grp < n_groups) load_rows(grp);
     for (; grp < n_groups; grp += stride) {
-        uint4 w4[4] = {nx[0], nx[1], nx[2], nx[3]};
-        const uint32_t dw = dw_next;
-        if (grp + stride < n_groups) load_rows(grp + stride, nx, dw_next);
-        const uint32_t w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
-                                w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
-        uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        u32x4v x[4];
+        uint32_t dw[4];
 #pragma unroll
-        for (int Q = 0; Q < 4; Q++) {
-            u32x2v e[16];
-            gather16<u32x2v, 8>(w, Q, sh3, e);
-            uint32_t a = 0, b = 0;                   // packed 16-bit lanes: (q0 | q1 << 16), (q2 | q3 << 16); 16 x 4095 < 2^16
+        for (int i = 0; i < 4; i++) { x[i] = nx[i]; dw[i] = dnx[i]; }
+        if (grp + stride < n_groups) load_rows(grp + stride);
+        int rows[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) { a = pk_add_u16(a, e[c].x); b = pk_add_u16(b, e[c].y); }
-            s0 += a & 0xffffu; s1 += a >> 16; s2 += b & 0xffffu; s3 += b >> 16;
+        for (int pr = 0; pr < 2; pr++) {      // two blocks of 16 vectors at a time: two independent accumulator chains
+            uint32_t rr[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                // rotate the lane's 16 bytes left by v = 4a + b bytes: dwords by a (two select stages), bytes by b (funnel shifts)
+                const u32x4v xx = x[2 * pr + u];
+                const uint32_t z0 = a1 ? xx.y : xx.x, z1 = a1 ? xx.z : xx.y, z2 = a1 ? xx.w : xx.z, z3 = a1 ? xx.x : xx.w;
+                const uint32_t w[4] = {a2 ? z2 : z0, a2 ? z3 : z1, a2 ? z0 : z2, a2 ? z1 : z3};
+#pragma unroll
+                for (int i = 0; i < 4; i++) rr[u][i] = __builtin_amdgcn_alignbyte(w[(i + 1) & 3], w[i], b);
+            }
+            v4i32 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                u32x2v e[2][8];
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int s = 8 * h + t;
+                        // address bytes: [0] chunk offset, [1] code byte s of the rotated row, [2] chunk half, [3] zero
+                        const uint32_t addr = __builtin_amdgcn_perm(rr[u][s >> 2], choff[s], 0x0c020000u | ((4u + (s & 3)) << 8));
+                        e[u][t] = *lds_at<u32x2v>(addr);
+                    }
+#pragma unroll
+                for (int t = 0; t < 8; t += 2)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const v4i32 av = {(int)e[u][t].x, (int)e[u][t].y, (int)e[u][t + 1].x, (int)e[u][t + 1].y};
+                        acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bop, acc[u], 0, 0, 0);
+                    }
+            }
+            if (desc) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t dv = (dw[2 * pr + u] >> (8 * g)) & 0xffu;
+                    const u32x2v e0 = *lds_at<u32x2v>(dv * (uint32_t)PQ4_DESC_STRIDE + doff);
+                    const v4i32 av = {(int)e0.x, (int)e0.y, 0, 0};
+                    acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bop, acc[u], 0, 0, 0);
+                }
+            }
+            // acc[u][i] = column v of row 4g + i of block 2 pr + u: in lanes v = q < 4 query q's sum minus `bias`
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                rows[(2 * pr + u) * 4 + 0] = acc[u].x; rows[(2 * pr + u) * 4 + 1] = acc[u].y;
+                rows[(2 * pr + u) * 4 + 2] = acc[u].z; rows[(2 * pr + u) * 4 + 3] = acc[u].w;
+            }
         }
-        if (desc) {
-            const u32x2v d0 = *lds_at<u32x2v>(code_offset<0>(dw, sh3) + 64 * 2048), d1 = *lds_at<u32x2v>(code_offset<1>(dw, sh3) + 65 * 2048);
-            const u32x2v d2 = *lds_at<u32x2v>(code_offset<2>(dw, sh3) + 66 * 2048), d3 = *lds_at<u32x2v>(code_offset<3>(dw, sh3) + 67 * 2048);
-            const uint32_t a = pk_add_u16(pk_add_u16(d0.x, d1.x), pk_add_u16(d2.x, d3.x));   // 4 x 16383 < 2^16
-            const uint32_t b = pk_add_u16(pk_add_u16(d0.y, d1.y), pk_add_u16(d2.y, d3.y));
-            s0 += a & 0xffffu; s1 += a >> 16; s2 += b & 0xffffu; s3 += b >> 16;
+        if (grp * 64 + 64 > n) {     // the last, partial group: vectors past the end count as all-zero sums
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (grp * 64 + (j >> 2) * 16 + 4 * g + (j & 3) >= n) rows[j] = -bias;
         }
-        if (grp * 64 + lane >= n) { s0 = 0; s1 = 0; s2 = 0; s3 = 0; }     // past the end: below every real vector's sum (>= 0)
-        const uint32_t m0 = wave_umax(s0), m1 = wave_umax(s1), m2 = wave_umax(s2), m3 = wave_umax(s3);
+        int best = max(rows[0], rows[1]);
+#pragma unroll
+        for (int j = 2; j < 16; j += 2) best = max(best, max(rows[j], rows[j + 1]));     // v_max3_i32
+        // lanes (v = q, g = 0 .. 3) hold the maxima of their rows: the group's maximum per query by readlane
+        uint32_t m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int m0 = __builtin_amdgcn_readlane(best, q), m1 = __builtin_amdgcn_readlane(best, 16 + q);
+            const int m2 = __builtin_amdgcn_readlane(best, 32 + q), m3 = __builtin_amdgcn_readlane(best, 48 + q);
+            const int mm = max(max(m0, m1), max(m2, m3));
+            m[q] = (uint32_t)(mm + bias);
+        }
         if (lane == 0) {
-            out[grp] = m0; out[n_groups + grp] = m1; out[2 * n_groups + grp] = m2; out[3 * n_groups + grp] = m3;
+            out[grp] = m[0]; out[n_groups + grp] = m[1]; out[2 * n_groups + grp] = m[2]; out[3 * n_groups + grp] = m[3];
         }
     }
 }
@@ -686,6 +774,11 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, size_t n, uint16
         const _Float16 h = (_Float16)in[i];  // v_cvt_f16_f32: round to nearest even (half::f16::from_f32)
         out[i] = __builtin_bit_cast(uint16_t, h);
     }
+}
+
+__global__ void f16_to_f32_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (float)__builtin_bit_cast(_Float16, in[i]);   // exact widening (half::f16::to_f32)
 }
 
 // rank of each target row in the (score desc, id asc) order = number of rows that precede it
@@ -773,15 +866,20 @@ int launch_pq_quantize(const float* centroids, int n_centroids, int d, int dpc, 
 bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, int n_desc, const float* scales) {
     return n_chunks == 64 && n_centroids == 256 && (!(desc && scales) || n_desc == 4);
 }
+// workgroups of a flat scan: every CU but one per XCD (8 XCDs on MI355X)
+static size_t scan_cus(int n_cu) { return n_cu >= 64 ? (size_t)(n_cu - 8) : (size_t)n_cu; }
+
 // group maxima of a full scan: gmax[g] = max ADC score (+ descriptor bias) of vectors 64g .. 64g+63 (INT64_MIN past the end)
 int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
                         int64_t* gmax, int n_cu, hipStream_t stream) {
     if (n == 0) return 0;
     MSE_DYN_LDS(pq_scan64_kernel<true>, PQS_LDS);
     const size_t groups = (n + 63) / 64;
-    // one 133-KiB workgroup per CU, on all but a few CUs: the single-workgroup kernels of another query's tail (radix selects,
-    // ~50 KiB of LDS each) can then run beside a scan instead of queueing behind all of its workgroups (-1.6 % scan rate)
-    const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;
+    // one 133-KiB workgroup per CU, on all but ONE CU PER XCD: the kernels of another query's tail (radix selects, ~50 KiB of LDS
+    // each) can then run beside a scan instead of queueing behind all of its workgroups.  Workgroups go to the eight XCDs round
+    // robin, so the spare CUs must be spread the same way: with 252 workgroups on 256 CUs XCDs 0-3 were full, and a four-workgroup
+    // select whose workgroups landed there waited for the whole scan (1.99 ms instead of 0.07, profiles/r04_pq_scan_stats.txt).
+    const size_t cus = scan_cus(n_cu);
     const unsigned blocks = (unsigned)std::min<size_t>((groups + PQS_WAVES - 1) / PQS_WAVES, cus);
     hipLaunchKernelGGL(pq_scan64_kernel<true>, dim3(blocks), dim3(PQS_WAVES * 64), PQS_LDS, stream, lut, codes, n,
                        (desc && scales) ? desc : nullptr, scales, gmax);
@@ -794,7 +892,7 @@ int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* co
                          const float* scales, int64_t* gmax0, int64_t* gmax1, int n_cu, hipStream_t stream) {
     if (n == 0) return 0;
     const size_t groups = (n + 63) / 64;
-    const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;   // a few CUs stay free for the previous pair's tail (see above)
+    const size_t cus = scan_cus(n_cu);   // one CU per XCD stays free for the previous pair's tail (see above)
     MSE_DYN_LDS(pq_scan64x2_kernel<PQ2_WAVES>, PQ2_LUT_BYTES);
     const unsigned blocks = (unsigned)std::min<size_t>((groups + PQ2_WAVES - 1) / PQ2_WAVES, cus);
     hipLaunchKernelGGL(pq_scan64x2_kernel<PQ2_WAVES>, dim3(blocks), dim3(PQ2_WAVES * 64), PQ2_LUT_BYTES, stream, lut0, lut1, codes, n,
@@ -804,9 +902,16 @@ int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* co
 }
 
 // ---- four queries per pass (integer nomination under a certificate; header above pq4_table_kernel) ----
-size_t pq4_table_bytes() { return PQ4_TABLE_BYTES; }
+size_t pq4_table_bytes() { return PQ4_TABLE_BYTES + 4 * 64 * 2 * 4 + 64; }   // LDS image + the table build's scratch
 int launch_pq4_table(const float* luts4, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream) {
-    hipLaunchKernelGGL(pq4_table_kernel, dim3(4), dim3(256), 0, stream, luts4, scales, n_valid, reinterpret_cast<uint16_t*>(table), params);
+    // scratch behind the table image: [4][64][2] f32 minima / maxima, [4] i32 flags (pq4_table_bytes() reserves it)
+    char* tail = reinterpret_cast<char*>(table) + PQ4_TABLE_BYTES;
+    float* lohi = reinterpret_cast<float*>(tail);
+    int* bad = reinterpret_cast<int*>(tail + 4 * 64 * 2 * 4);
+    MSE_HIP_TRY(hipMemsetAsync(bad, 0, 16, stream));
+    hipLaunchKernelGGL(pq4_minmax_kernel, dim3(64, 4), dim3(64), 0, stream, luts4, n_valid, lohi, bad);
+    hipLaunchKernelGGL(pq4_quant_kernel, dim3(PQ4_CHUNKS), dim3(256), 0, stream, luts4, scales, n_valid, lohi, bad,
+                       reinterpret_cast<unsigned long long*>(table), params);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -814,11 +919,11 @@ int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, cons
                          hipStream_t stream) {
     if (n == 0) return 0;
     const size_t groups = (n + 63) / 64;
-    const size_t cus = n_cu > 32 ? (size_t)n_cu - 4 : (size_t)n_cu;
+    const size_t cus = scan_cus(n_cu);
     MSE_DYN_LDS(pq_scan64x4_kernel<PQ4_WAVES>, PQ4_TABLE_BYTES);
     const unsigned blocks = (unsigned)std::min<size_t>((groups + PQ4_WAVES - 1) / PQ4_WAVES, cus);
     hipLaunchKernelGGL(pq_scan64x4_kernel<PQ4_WAVES>, dim3(blocks), dim3(PQ4_WAVES * 64), PQ4_TABLE_BYTES, stream,
-                       reinterpret_cast<const u32x2v*>(table), codes, n, desc, gmax4, groups);
+                       reinterpret_cast<const uint4*>(table), codes, n, desc, gmax4, groups);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -851,10 +956,15 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
     if (lds > 64 * 1024) {
         MSE_DYN_LDS(pq_adc_kernel, lds);
     }
-    size_t blocks = (n + 255) / 256;
-    const size_t cap = (size_t)n_cu * 8;
+    // 1024-thread workgroups: every workgroup first copies the whole table (up to 64 KiB+) into LDS, so few fat workgroups beat
+    // many thin ones -- above all when this kernel is part of a scan's tail and only the CUs a concurrent scan leaves free (one per
+    // XCD) are there to take them: 300 workgroups of 256 threads took 1.3 ms there, 30 us on an idle device
+    // (profiles/r04_pq_scan_stats.txt)
+    const int threads = n >= 1024 ? 1024 : 256;
+    size_t blocks = (n + threads - 1) / threads;
+    const size_t cap = (size_t)n_cu * 2;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(256), lds, stream, lut, n_chunks, n_centroids, codes,
+    hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(threads), lds, stream, lut, n_chunks, n_centroids, codes,
                        n_codes, ids, n, desc, n_desc, scales, out, q_stride);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
@@ -872,6 +982,14 @@ int launch_f32_to_f16(const float* in, size_t n, uint16_t* out, hipStream_t stre
     size_t blocks = (n + 255) / 256;
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, out);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_f16_to_f32(const uint16_t* in, size_t n, float* out, hipStream_t stream) {
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, out);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -79,6 +79,9 @@ struct mse_searcher {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double scan_ms_total = 0.0;
     uint64_t scan_launches = 0;
+    // event pairs of the PQ scan launches of one batch call (several per call on this searcher's stream), read when the call ends
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
 };
 
 struct mse_pq {
@@ -95,6 +98,9 @@ struct mse_pq {
     int device = 0;                   // HIP ordinal the quantiser was loaded on
     std::mutex co_mu;                 // guards the creation of `co`
     mse::Coalescer* co = nullptr;     // meeting point of one-query mse_pq_scan_topk calls from many threads (api_pq.hip), made on first use
+    bool timing = false;              // HIP-event timing of the four-query scan kernel (mse_pq_scan_timing), for bench.py's roofline
+    double scan_ms_total = 0.0;
+    uint64_t scan_launches = 0;
     void* pin = nullptr;              // pinned host staging of the scan entry points (one upload + one download per call, both
     size_t pin_cap = 0;               // truly asynchronous: a pageable source makes the runtime stage and block per copy)
 };

@@ -199,14 +199,36 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
     // remaining passes walk that list instead of all M candidates; a pass whose bucket holds exactly the number still
     // needed ends the search (the lower digits of the threshold stay zero).  Both shortcuts are functions of the
     // multiset of composites only, so the result is as deterministic as before.
-    bool list_mode = false;
+    bool list_mode = false, full_list = false;
+    if (a.floor_hi) {
+        // A floor is given (the k-th key of the level above: at least k candidates reach it, and usually not many more): gather
+        // the candidates that reach it ONCE -- if they fit the LDS list every radix pass and the final collection walk that list
+        // instead of all M candidates (the 77 k children of 301 nominated PQ groups hold a few hundred keys above the floor).
+        if (tid == 0) s_list_n = 0;
+        __syncthreads();
+        Composite c;
+        for (size_t i = tid; i < M; i += SEL_THREADS)
+            if (load(i, c)) {
+                const uint32_t slot = atomicAdd(&s_list_n, 1u);
+                if (slot < (uint32_t)SEL_LIST_CAP) s_list[slot] = (uint32_t)i;
+            }
+        __syncthreads();
+        if (s_list_n <= (uint32_t)SEL_LIST_CAP) { list_mode = true; full_list = true; }
+        __syncthreads();
+    }
     for (int pos = 11; pos >= 0; pos--) {
         if (K32 && pos >= 4 && pos < 8) continue;  // low half of `hi` is zero for 32-bit keys
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
         const Composite prefix{s_prefix_hi, s_prefix_lo};
         Composite c;
-        if (list_mode) {
+        if (list_mode && pos == 11) {
+            unsigned long long o = 0ull, n = ~0ull;
+            const uint32_t ln = s_list_n;
+            for (uint32_t j = tid; j < ln; j += SEL_THREADS)
+                if (load(s_list[j], c)) { atomicAdd(&s_hist[digit_of(c, pos)], 1u); o |= c.hi; n &= c.hi; }
+            if (o | ~n) { atomicOr(&s_or_hi, o); atomicAnd(&s_and_hi, n); }
+        } else if (list_mode) {
             const uint32_t ln = s_list_n;
             for (uint32_t j = tid; j < ln; j += SEL_THREADS)
                 if (load(s_list[j], c) && match_above(c, prefix, pos)) atomicAdd(&s_hist[digit_of(c, pos)], 1u);
@@ -311,11 +333,20 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectArgs a, size_
     if (a.kth_hi_out && tid == 0) a.kth_hi_out[q] = take_all ? 0ull : s_prefix_hi;   // a lower bound of the k-th key when the search ended early
     {
         Composite c;
-        for (size_t i = tid; i < M; i += SEL_THREADS)
-            if (load(i, c) && ge(c, thr)) {
-                const uint32_t p = atomicAdd(&s_count, 1u);
-                if (p < (uint32_t)TOPK_KMAX) { s_sel_hi[p] = c.hi; s_sel_lo[p] = c.lo; }
-            }
+        if (full_list) {      // the list holds every valid candidate
+            const uint32_t ln = s_list_n;
+            for (uint32_t j = tid; j < ln; j += SEL_THREADS)
+                if (load(s_list[j], c) && ge(c, thr)) {
+                    const uint32_t p = atomicAdd(&s_count, 1u);
+                    if (p < (uint32_t)TOPK_KMAX) { s_sel_hi[p] = c.hi; s_sel_lo[p] = c.lo; }
+                }
+        } else {
+            for (size_t i = tid; i < M; i += SEL_THREADS)
+                if (load(i, c) && ge(c, thr)) {
+                    const uint32_t p = atomicAdd(&s_count, 1u);
+                    if (p < (uint32_t)TOPK_KMAX) { s_sel_hi[p] = c.hi; s_sel_lo[p] = c.lo; }
+                }
+        }
     }
     __syncthreads();
     const uint32_t n_sel = s_count < (uint32_t)a.k ? s_count : (uint32_t)a.k;

@@ -107,12 +107,15 @@ SIGNATURES = {
     "mse_pq_adc": (C.c_int, [vp, f32p, u8p, sz, i64p]),
     "mse_codes_from_host": (vp, [u8p, sz, sz, u8p, sz]),
     "mse_codes_free": (None, [vp]),
+    "mse_codes_quantize_base": (vp, [vp, vp, u8p, sz]),
+    "mse_pq_scan_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mse_codes_len": (sz, [vp]),
     "mse_pq_adc_gather": (C.c_int, [vp, vp, f32p, f32p, u32p, sz, i64p]),
     "mse_pq_scan_topk": (C.c_int, [vp, vp, vp, f32p, f32p, sz, sz, i64p, u32p]),
     "mse_pq_scan_topk_batch": (C.c_int, [vp, vp, vp, f32p, sz, f32p, sz, sz, i64p, u32p]),
     "mse_pq_last_uncertified": (C.c_uint32, [vp]),
     "mse_debug_pq_group_max": (C.c_int, [vp, vp, f32p, f32p, f32p, i64p, i64p]),
+    "mse_debug_pq4_group_max": (C.c_int, [vp, vp, f32p, f32p, C.c_int, u32p, C.POINTER(C.c_double)]),
     "mse_descriptor_product": (C.c_int64, [f32p, sz, u8p, C.c_uint32]),
     "mse_nb_new": (vp, [sz]),
     "mse_nb_free": (None, [vp]),

@@ -315,6 +315,12 @@ class ProductQuantizer:
                                                _p(scores, C.c_int64), _p(ids, C.c_uint32)), "pq_scan_topk_batch")
         return scores, ids
 
+    def scan_timing(self, enable):
+        """HIP-event totals of the four-query scan kernel so far -> (total_ms, launches); then set mode (0 off, 1 on, 2 on + reset)."""
+        ms, n = C.c_double(), C.c_uint64()
+        check(ffi.lib().mse_pq_scan_timing(self._h, enable, C.byref(ms), C.byref(n)), "pq_scan_timing")
+        return float(ms.value), int(n.value)
+
     @property
     def last_uncertified(self):
         """Queries of the last scan_topk_batch call that the four-query scan could not certify and repeated through the exact scan."""
@@ -360,6 +366,19 @@ class Codes:
         else:
             nd, dp = 0, None
         self._h = check_ptr(ffi.lib().mse_codes_from_host(_p(codes, C.c_uint8), n, cs, dp, nd), "mse_codes_from_host")
+
+    @classmethod
+    def quantize_base(cls, pq, vecs, descriptors=None):
+        """Codes of rows already resident in HBM (mse_codes_quantize_base): quantize_batch over the f32 widenings of the f16 rows,
+        on the device -- the encode step of src/dump_processor.rs:468-481."""
+        self = cls.__new__(cls)
+        if descriptors is not None:
+            descriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(len(vecs), -1)
+            nd, dp = descriptors.shape[1], _p(descriptors, C.c_uint8)
+        else:
+            nd, dp = 0, None
+        self._h = check_ptr(ffi.lib().mse_codes_quantize_base(pq._h, vecs._h, dp, nd), "mse_codes_quantize_base")
+        return self
 
     def __len__(self):
         return int(ffi.lib().mse_codes_len(self._h))

@@ -1,0 +1,82 @@
+/* Closed-loop caller threads for the coalescer measurements (bench.py `concurrent_callers`, tests): the reference's call
+ * shape -- T host threads, ONE query per call (src/main.rs:896-934; src/query_disk_index.rs:711-736) -- as native threads,
+ * the way a Rust host would drive the C ABI.  Bench / test infrastructure: not part of libmse_hip.so; it reaches the
+ * library only through the function pointer it is handed (mse_dispatcher_topk_f16 or a compatible entry point).
+ *
+ * Thread t issues queries t, t + T, t + 2T, ... (n_queries in all, each exactly once), one per call, and records each
+ * call's latency; every answer lands in its query's row of scores / ids so the caller can check all of them. */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <time.h>
+
+typedef int (*topk_fn)(void* handle, const uint16_t* queries, size_t nq, size_t k, int64_t* scores, uint32_t* ids);
+
+typedef struct {
+    topk_fn fn;
+    void* handle;
+    const uint16_t* queries;
+    size_t n_queries, d, k, first, stride;
+    int64_t* scores;
+    uint32_t* ids;
+    double* latency_ms;
+    pthread_barrier_t* gate;
+    int failures;
+} caller_t;
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* caller_main(void* p) {
+    caller_t* c = (caller_t*)p;
+    pthread_barrier_wait(c->gate);
+    for (size_t j = c->first; j < c->n_queries; j += c->stride) {
+        const double t0 = now_s();
+        const int rc = c->fn(c->handle, c->queries + j * c->d, 1, c->k, c->scores + j * c->k, c->ids + j * c->k);
+        c->latency_ms[j] = (now_s() - t0) * 1e3;
+        if (rc) c->failures++;
+    }
+    return NULL;
+}
+
+/* returns the wall-clock seconds from the moment all threads were released until the last one finished (< 0: setup failed);
+ * *n_failed = calls that returned non-zero */
+double mse_callers_run(void* fn, void* handle, const uint16_t* queries, size_t n_queries, size_t d, size_t k, int threads,
+                       int64_t* scores, uint32_t* ids, double* latency_ms, int* n_failed) {
+    if (threads <= 0 || !fn) return -1.0;
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    caller_t* cs = (caller_t*)calloc((size_t)threads, sizeof(caller_t));
+    pthread_barrier_t gate;
+    if (!th || !cs || pthread_barrier_init(&gate, NULL, (unsigned)threads + 1)) { free(th); free(cs); return -1.0; }
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 256 * 1024);
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        cs[t] = (caller_t){(topk_fn)fn, handle, queries, n_queries, d, k, (size_t)t, (size_t)threads, scores, ids, latency_ms, &gate, 0};
+        if (pthread_create(&th[t], &attr, caller_main, &cs[t])) break;
+        started++;
+    }
+    double dt = -1.0;
+    if (started == threads) {
+        pthread_barrier_wait(&gate);
+        const double t0 = now_s();
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+        dt = now_s() - t0;
+        int f = 0;
+        for (int t = 0; t < threads; t++) f += cs[t].failures;
+        if (n_failed) *n_failed = f;
+    } else {
+        /* could not start them all: the ones waiting at the gate are released by a gate re-made for their count */
+        for (int t = 0; t < started; t++) pthread_cancel(th[t]);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    }
+    pthread_attr_destroy(&attr);
+    pthread_barrier_destroy(&gate);
+    free(th);
+    free(cs);
+    return dt;
+}

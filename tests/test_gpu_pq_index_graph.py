@@ -760,3 +760,83 @@ def test_index_directory_is_the_front_door_of_the_beam_search(gpu, mse, orc, tmp
         assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores) and (cm, pc) == (ocm, opc)
         assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc)
         assert all(urls[int(v)] for v in vi)                                             # dead nodes are traversed, never returned
+
+
+@pytest.mark.parametrize("n,n_valid,with_desc", [(64 * 37 + 5, 4, True), (1000, 3, False), (16, 1, True), (64 * 300, 4, True)])
+def test_pq4_matrix_core_scan_equals_integer_sums(gpu, mse, orc, n, n_valid, with_desc):
+    """The four-queries-per-pass nomination scan (pq_scan64x4_kernel: conflict-free rotated gathers, sums on the matrix cores)
+    against plain integer arithmetic: the 12-bit tables are rebuilt on the host from the kernel's own formula
+    (e = rint((lut - lo_c) / delta), descriptor chunks rint((sc v - min(0, 255 sc)) / delta)) and every group maximum must equal
+    max over the group's vectors of sum_c e[c][code_c] (+ descriptor entries)."""
+    import ctypes as C
+    from mse import ffi
+    rng = np.random.default_rng(n + n_valid)
+    cents, T, dpc, d = make_pq(orc)
+    pq = mse.ProductQuantizer(cents, T, dpc, d)
+    codes = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    codes[: min(n, 7)] = 255                                   # extreme codes in the first rows
+    desc = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    gc = mse.Codes(codes, desc)
+    luts = (rng.standard_normal((4, 64, 256)) * rng.uniform(0.01, 0.3, (4, 64, 1))).astype(np.float32)
+    luts[1, 3] = 0.25                                          # a chunk with zero range
+    scales = np.array([0.5, 0, -0.25, 0.125], np.float32) / np.float32(512) if with_desc else None
+    ng = (n + 63) // 64
+    out = np.zeros((4, ng), np.uint32)
+    params = np.zeros((4, 4), np.float64)
+    ffi.check(ffi.lib().mse_debug_pq4_group_max(pq._h, gc._h, luts.ctypes.data_as(ffi.f32p),
+                                                scales.ctypes.data_as(ffi.f32p) if with_desc else None, n_valid,
+                                                out.ctypes.data_as(ffi.u32p), params.ctypes.data_as(C.POINTER(C.c_double))))
+    for j in range(4):
+        if j >= n_valid:
+            assert params[j, 3] == 0 and np.all(out[j] == 0)
+            continue
+        lut = luts[j].astype(np.float64)
+        lo, hi = lut.min(axis=1), lut.max(axis=1)
+        delta = (hi - lo).max() / 4095.0
+        c_sum = 0.0
+        for c in range(64):
+            c_sum += lo[c]
+        if with_desc:
+            for sc in scales.astype(np.float64):
+                delta = max(delta, abs(sc) * 255.0 / 16383.0)
+                c_sum += min(0.0, sc * 255.0)
+        delta = max(delta, 1e-300)
+        assert params[j, 0] == delta and params[j, 1] == c_sum and params[j, 3] == 1
+        inv = 1.0 / delta
+        e = np.clip(np.rint((lut - lo[:, None]) * inv), 0, 4095).astype(np.int64)            # [64][256]
+        sums = e[np.arange(64)[None, :], codes.astype(np.int64)].sum(axis=1)                  # [n]
+        if with_desc:
+            for dd, sc in enumerate(scales.astype(np.float64)):
+                ed = np.clip(np.rint((sc * np.arange(256.0) - min(0.0, sc * 255.0)) * inv), 0, 16383).astype(np.int64)
+                sums = sums + ed[desc[:, dd].astype(np.int64)]
+        pad = np.zeros(ng * 64, np.int64)
+        pad[:n] = sums
+        want = pad.reshape(ng, 64).max(axis=1)
+        assert np.array_equal(out[j].astype(np.int64), want), (j, np.flatnonzero(out[j] != want)[:5])
+
+
+def test_codes_quantized_from_resident_rows_equal_quantize_batch(gpu, mse, orc):
+    """mse_codes_quantize_base: the PQ codes of rows that already live in HBM (f16 -> f32 widening, transform, first-max argmax per
+    chunk, all on the device) equal quantize_batch's on the same rows (vector.rs:331-364), and a scan over them answers the same."""
+    n = 70000                                                   # more than one 65536-row step
+    cents, T, dpc, d = make_pq(orc)
+    rng = np.random.default_rng(12)
+    base = orc.f16_bits((rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32))
+    pq = mse.ProductQuantizer(cents, T, dpc, d)
+    vl = mse.VectorList.from_f16s(base, d)
+    want = np.concatenate([pq.quantize_batch(orc.f16_to_f32(base[s:s + 8192])) for s in range(0, n, 8192)])
+    assert np.array_equal(want[:2000], orc.PQ(cents, T, dpc, d).quantize_batch(orc.f16_to_f32(base[:2000])))
+    desc = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    dev_codes = mse.Codes.quantize_base(pq, vl, desc)
+    host_codes = mse.Codes(want, desc)
+    assert len(dev_codes) == n
+    q = (rng.standard_normal((5, d)) / np.sqrt(d)).astype(np.float32)
+    scales = np.array([0.5, 0, -0.25, 0.125], np.float32) / np.float32(512)
+    s = mse.Searcher(vl)
+    a = pq.scan_topk_batch(dev_codes, q, 100, 10, s, scales)
+    b = pq.scan_topk_batch(host_codes, q, 100, 10, s, scales)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # ADC-only answers expose the codes themselves: identical rankings and scores over all 70000 vectors' best 100
+    a = pq.scan_topk_batch(dev_codes, q, 100, 100, None, scales)
+    b = pq.scan_topk_batch(host_codes, q, 100, 100, None, scales)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
