@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -65,6 +66,7 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     int (*CommCount)(void*, int*) = nullptr;
     int (*CommInitAll)(void**, int, const int*) = nullptr;     // one process, several devices
+    int (*CommAbort)(void*) = nullptr;                         // optional: frees the ranks a failed collective left waiting
     const char* (*GetErrorString)(int) = nullptr;
     std::string why;
 };
@@ -86,6 +88,7 @@ Rccl& rccl() {
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
     });
     return r;
 }
@@ -381,18 +384,46 @@ static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t
             (void)hipEventElapsedTime(&sh.exch_ms, sh.ev[1], sh.ev[2]);
             return 0;
         });
-        if (!rc && use_rccl)   // ONE ncclAllGather of the packed records per search: rank g = shard g, on its own thread and stream
+        if (!rc && use_rccl) {  // ONE ncclAllGather of the packed records per search: rank g = shard g, on its own thread and stream
+            // A rank that fails here (the collective's launch, its event, its stream) leaves the OTHER ranks inside a collective that
+            // can never complete: nobody waits blindly -- every rank polls its completion event and, once any rank has failed,
+            // aborts its own communicator (ncclCommAbort frees the stream).  Afterwards the group drops back to the peer-store
+            // exchange with no communicators, and this search is repeated over it below.
+            std::atomic<int> failed{0};
+            std::atomic<int>* const failed_p = &failed;
             rc = G->run([=](size_t g) -> int {
                 Shard& sh = G->shards[g];
                 hipStream_t st = sh.searcher->stream;
                 const int nrc = rccl().AllGather(sh.block.p, sh.gathered.p, B, /*ncclInt8*/ 0, sh.comm, st);
-                if (nrc) return rccl_fail("ncclAllGather", nrc);
-                MSE_HIP_TRY(hipEventRecord(sh.ev[2], st));
-                MSE_HIP_TRY(hipStreamSynchronize(st));
+                if (nrc) { failed_p->store(1); return rccl_fail("ncclAllGather", nrc); }
+                if (hipEventRecord(sh.ev[2], st) != hipSuccess) { failed_p->store(1); return fail("shard group: event after the all-gather"); }
+                for (;;) {
+                    const hipError_t qe = hipEventQuery(sh.ev[2]);
+                    if (qe == hipSuccess) break;
+                    if (qe != hipErrorNotReady) { failed_p->store(1); return fail(std::string("shard group: all-gather stream: ") + hipGetErrorString(qe)); }
+                    if (failed_p->load()) {
+                        if (rccl().CommAbort && sh.comm) { (void)rccl().CommAbort(sh.comm); sh.comm = nullptr; }
+                        return fail("shard group: another rank's all-gather failed; this rank's communicator was aborted");
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
                 (void)hipEventElapsedTime(&sh.local_ms, sh.ev[0], sh.ev[1]);
                 (void)hipEventElapsedTime(&sh.exch_ms, sh.ev[1], sh.ev[2]);
                 return 0;
             });
+            if (rc) {
+                const std::string why = mse_last_error();
+                for (Shard& sh : G->shards)
+                    if (sh.comm) { if (rccl().CommAbort) (void)rccl().CommAbort(sh.comm); else (void)rccl().CommDestroy(sh.comm); sh.comm = nullptr; }
+                G->exchange = MSE_EXCHANGE_PEER;
+                G->rccl_ranks = 0;
+                (void)hipSetDevice(prev);
+                const int rc2 = search_dev_locked(G, queries_dev, nq, k, mode, scores_dev, ids_dev);   // over the peer-store exchange
+                if (rc2) return rc2;
+                set_error("RCCL exchange failed and was shut down (" + why + "); the search was answered over the peer-store exchange");
+                return 0;
+            }
+        }
         merged_from = use_rccl ? G->shards[0].gathered.as<char>() : gathered;   // shard 0 lives on the root device
         hipStream_t rs = G->root->stream;
         if (!rc) for (hipEvent_t& e : G->ev_merge) if (!e && hipEventCreate(&e) != hipSuccess) rc = fail("shard group: event");

@@ -47,6 +47,9 @@ struct mse_siglip {
     int max_batch = 0;
     size_t m_pad = 0;
     hipStream_t stream = nullptr;
+    // one call at a time per engine: a call enqueues its uploads and kernels on the engine's streams into shared scratch, so two
+    // threads inside one engine would read each other's images (replicas are separate engines and run side by side)
+    std::recursive_mutex call_mu;
     static constexpr int MAX_SIDE = 3;
     hipStream_t side[MAX_SIDE] = {};   // further streams of a forward pass (MSE_SIGLIP_STREAMS = 1 + how many are used; default 2)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
@@ -281,6 +284,7 @@ int mse_siglip_finalize(mse_siglip* m) {
 // preprocessing thread (clip_server.py:131-146) run on the device, and the PCIe copy is the u8 image (1 B/element)
 int mse_siglip_encode_rgb8(mse_siglip* m, const uint8_t* rgb_hwc, int batch, int normalize, float* out_f32, uint16_t* out_f16) {
     if (!m || !rgb_hwc) return fail("null engine or image");
+    std::lock_guard<std::recursive_mutex> call_lock(m->call_mu);
     if (batch <= 0 || batch > m->max_batch) return fail("siglip: batch exceeds max_batch");
     const mse_siglip_config& c = m->cfg;
     const size_t elems = (size_t)batch * c.in_chans * c.img_size * c.img_size;
@@ -317,6 +321,7 @@ int mse_bmp24_info(const uint8_t* data, size_t size, uint32_t* width, uint32_t* 
 int mse_siglip_encode_bmp(mse_siglip* m, const uint8_t* const* bmps, const size_t* sizes, int batch, int normalize, float* out_f32,
                           uint16_t* out_f16) {
     if (!m || !bmps || !sizes) return fail("null engine or image list");
+    std::lock_guard<std::recursive_mutex> call_lock(m->call_mu);
     if (batch <= 0 || batch > m->max_batch) return fail("siglip: batch exceeds max_batch");
     const mse_siglip_config& c = m->cfg;
     if (c.in_chans != 3) return fail("siglip: BMP input needs a 3-channel model");
@@ -346,6 +351,7 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
                             float* out_f32, uint16_t* out_f16) {
     if (!m) return fail("null engine");
     if (!m->finalized) return fail("siglip: call mse_siglip_finalize after loading the weights");
+    std::lock_guard<std::recursive_mutex> call_lock(m->call_mu);
     if (batch <= 0 || batch > m->max_batch) return fail("siglip: batch exceeds max_batch");  // clip_server.py:139
     if (dtype != 0 && dtype != 1) return fail("siglip: dtype must be 0 (f32) or 1 (f16)");
     hipStream_t st = m->stream;

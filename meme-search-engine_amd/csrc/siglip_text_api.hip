@@ -41,6 +41,7 @@ struct mse_siglip_text {
     int max_batch = 0;
     size_t m_pad = 0;
     hipStream_t stream = nullptr;
+    std::mutex call_mu;   // one call at a time: token upload, kernels and scratch of a call share one stream (see mse_siglip)
     std::vector<void*> allocs;
     std::map<std::string, TSlot> slots;
     bool finalized = false;
@@ -181,6 +182,7 @@ int mse_siglip_text_finalize(mse_siglip_text* m) {
 int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize, float* out_f32, uint16_t* out_f16) {
     if (!m) return fail("null engine");
     if (!m->finalized) return fail("siglip text: call mse_siglip_text_finalize after loading the weights");
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
     if (batch <= 0 || batch > m->max_batch) return fail("siglip text: batch exceeds max_batch");  // clip_server.py:136
     hipStream_t st = m->stream;
     const mse_siglip_text_config& c = m->cfg;

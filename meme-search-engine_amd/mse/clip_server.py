@@ -168,13 +168,16 @@ class ClipServer:
         BMP jobs already waiting in the queue are run as ONE engine call, up to the engine's own batch capacity (a request is
         limited to max_batch_size images and 64 MiB; the tower is most efficient at 256).  Rows go back to their own requests."""
         engine = engine or self.image_engine
-        cap = max(int(getattr(engine, "max_batch", self.bs)), self.bs)
+        # never more than the engine takes in one call; a request larger than that fails on its own, as in the reference (:139)
+        cap = int(getattr(engine, "max_batch", self.bs))
         held = None
         while True:
-            job = held if held is not None else self.model_q.get()
-            held = None
+            if held is not None:
+                job, held = held, None
+            else:
+                job = self.model_q.get()
             if job is self._stop:
-                self.model_q.put(job)          # the other model threads stop on it as well
+                self._hand_on_stop()           # the other model threads stop on it as well
                 return
             group = [job]
             try:
@@ -194,19 +197,46 @@ class ClipServer:
                 if len(group) == 1:
                     self._model_work(job, engine)
                     group = []
-                else:
+                    continue
+                try:
                     rows = self.run_model("bmp", [im for j in group for im in j.stage[1]], engine)
-                    at = 0
-                    while group:
-                        j = group[0]
-                        n = len(j.stage[1])
-                        j.finish(True, rows[at:at + n])
-                        group.pop(0)           # answered: must not be answered again if a later hand-back fails
-                        at += n
+                except Exception:  # noqa: BLE001
+                    # the shared call failed: every request of the group is run again on its own, so that a request only ever
+                    # fails for what IT sent (the reference fails the offending request alone)
+                    traceback.print_exc()
+                    pending, group = group, []
+                    for j in pending:
+                        try:
+                            self._model_work(j, engine)
+                        except Exception as e1:  # noqa: BLE001
+                            j.finish(False, str(e1))
+                    continue
+                at = 0
+                while group:
+                    j = group[0]
+                    n = len(j.stage[1])
+                    j.finish(True, rows[at:at + n])
+                    group.pop(0)           # answered: must not be answered again if a later hand-back fails
+                    at += n
             except Exception as e:  # noqa: BLE001 - every failure is reported to the client as a 500 string
                 traceback.print_exc()
                 for j in group:
                     j.finish(False, str(e))
+
+    def _hand_on_stop(self):
+        """Pass the stop marker to the next model thread without ever blocking on a full queue: jobs still queued are answered
+        with an error first (nobody may wait for ever on a server that is going down)."""
+        while True:
+            try:
+                self.model_q.put_nowait(self._stop)
+                return
+            except queue.Full:
+                try:
+                    j = self.model_q.get_nowait()
+                except queue.Empty:
+                    continue
+                if j is not self._stop:
+                    j.finish(False, "server is shutting down")
 
     def start_threads(self):
         for eng in self.image_engines:
@@ -218,8 +248,18 @@ class ClipServer:
         self._threads.append(th)
 
     def stop_threads(self):
-        self.prep_q.put(self._stop)
-        self.model_q.put(self._stop)
+        for q_ in (self.prep_q, self.model_q):
+            while True:
+                try:
+                    q_.put_nowait(self._stop)
+                    break
+                except queue.Full:         # make room: a job that can no longer be served is told so
+                    try:
+                        j = q_.get_nowait()
+                    except queue.Empty:
+                        continue
+                    if j is not self._stop:
+                        j.finish(False, "server is shutting down")
 
     # ---- HTTP (clip_server.py:148-200) ----
     def make_app(self):

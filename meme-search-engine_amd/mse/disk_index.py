@@ -110,6 +110,10 @@ class DiskIndex:
             raise ValueError("index.descriptor-codes.bin does not hold count x n_descriptors bytes")
         self.pq_codes = self.pq_codes.reshape(h.count, h.pq_code_size)
         self.descriptors = self.descriptors.reshape(h.count, max(h.n_descriptors, 1)) if h.n_descriptors else None
+        if decode_entry == "unpinned-bitcode06":      # the same opt-in, spelled as a string (configuration files)
+            decode_entry = UNPINNED_BITCODE06_DECODE
+        if decode_entry is not None and not callable(decode_entry):
+            raise ValueError("decode_entry must be a callable or 'unpinned-bitcode06'")
         self.decode_entry = decode_entry
         self._data = os.path.join(path, "index.bin")
 
@@ -158,6 +162,9 @@ class DiskIndex:
         Records whose URL is empty are graph-only nodes (dump_processor.rs:510-517): traversed, never returned (:172)."""
         from .vector import VectorList
         from .diskann import DeviceGraph, IndexGraph
+        if self.decode_entry is None:     # say so before any work is done, not at the first record
+            raise NotImplementedError("DiskIndex.to_device needs a record codec: open the directory with "
+                                      "decode_entry=UNPINNED_BITCODE06_DECODE (or 'unpinned-bitcode06') to opt in to the unpinned restatement")
         h = self.header
         d = h.quantizer["n_dims"]
         vecs = np.zeros((h.count, d), np.uint16)
