@@ -166,7 +166,7 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
     const mse_base* b = s->base;
     hipStream_t st = s->stream;
     const int d = (int)b->d;
-    const int nq_pad = nq_pass > 128 ? 256 : 128;   // one pass over the rows serves up to 256 queries
+    const int nq_pad = mfma_pad(nq_pass, d);   // one pass over the rows serves up to 256 queries (padded to 128 / 192 / 256)
     if (ensure_base_norm(b, st)) return -1;
     // padded query tile
     if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;
@@ -456,7 +456,7 @@ int mse_debug_mfma_group_max(mse_searcher* s, const uint16_t* queries, size_t nq
     const mse_base* b = s->base;
     if (nq == 0 || nq > 256 || b->n == 0) return fail("mfma_group_max: 1..256 queries, non-empty base");
     const int d = (int)b->d;
-    const int nq_pad = nq > 128 ? 256 : 128;
+    const int nq_pad = mfma_pad((int)nq, d);
     const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;
     if (s->q_stage.ensure((size_t)nq_pad * d * 2) || s->gmax.ensure(n_groups * (size_t)nq_pad * 4) ||
         s->qpacked.ensure(mfma_packed_bytes(d))) return -1;

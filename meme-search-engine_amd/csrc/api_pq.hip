@@ -95,7 +95,7 @@ int index_pass_mfma(mse_index* idx, const float* q32_dev, int nqp, int k, uint32
     hipStream_t st = s->stream;
     const int d = idx->d;
     const size_t n = idx->n;
-    const int nq_pad = nqp > 128 ? 256 : 128;
+    const int nq_pad = mfma_pad(nqp, d);
     if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;
     MSE_HIP_TRY(hipMemsetAsync(s->q_stage.p, 0, (size_t)nq_pad * d * 2, st));
     if (launch_f32_to_f16(q32_dev, (size_t)nqp * d, s->q_stage.as<uint16_t>(), st)) return -1;

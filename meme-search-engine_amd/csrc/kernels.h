@@ -120,5 +120,6 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
                      hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);  // events bracket the scan kernel only
 size_t mfma_packed_bytes(int d);
 int mfma_query_tile();  // queries handled per pass
+int mfma_pad(int nq, int d);   // padded query count of a pass of nq <= 256 queries: 128, 192 or 256
 
 }  // namespace mse

@@ -689,6 +689,12 @@ int launch_2d(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_ro
 }  // namespace
 
 int mfma_query_tile() { return 256; }   // largest pass; passes of <= 128 queries use the 128-query kernel
+// padded query count of a pass of nq queries: 128, 192 (three-stage ring only: the K-block count must divide by 3) or 256
+int mfma_pad(int nq, int d) {
+    if (nq <= 128) return 128;
+    if (nq <= 192 && (d / KB) % 3 == 0) return 192;
+    return 256;
+}
 
 size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * 256 * 128; }
 
@@ -698,7 +704,8 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
                      hipEvent_t ev_end) {
     if (n_rows == 0) return 0;
     if (d % 64 != 0 || d <= 0 || d > D_MAX) return fail("vector width must be a positive multiple of 64");
-    if (nq_pad != 128 && nq_pad != 256) return fail("scan_mfma: query tile must be padded to 128 or 256");
+    if (nq_pad != 128 && nq_pad != 256 && !(nq_pad == 192 && (d / KB) % 3 == 0))
+        return fail("scan_mfma: query tile must be padded to 128, 192 (K blocks divisible by 3) or 256");
     uint4* packed = reinterpret_cast<uint4*>(packed_scratch);
     hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, nq_pad, packed);
     if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
@@ -737,7 +744,11 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
         return 0;
     }
 #endif
-    if (nq_pad == 128) {
+    if (nq_pad == 192) {
+        // 12 column tiles on the one-dimensional wave split (32 rows x 192 queries per wave, 96 accumulators): the point between
+        // the HBM-bound 128-query pass and the power-bound 256-query pass (profiles/r04_scan_variants.txt)
+        rc = launch_variant<3, 12, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    } else if (nq_pad == 128) {
         if (S == 3) rc = launch_variant<3, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
         else if (S == 2) rc = launch_variant<2, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
         else rc = launch_variant<1, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);

@@ -87,7 +87,7 @@ def test_scores_match_oracle(gpu, mse, orc, n, d):
 
 @pytest.mark.parametrize("mode", ["exact", "mfma"])
 @pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (5, 3, 10), (31, 2, 10), (33, 9, 5), (1000, 17, 10), (5000, 1, 1000),
-                                    (20000, 130, 10), (40000, 8, 100), (30000, 256, 10), (9000, 300, 7)])
+                                    (20000, 130, 10), (40000, 8, 100), (30000, 256, 10), (9000, 300, 7), (15000, 192, 10), (3333, 160, 3)])
 def test_topk_matches_oracle(gpu, mse, orc, mode, n, nq, k):
     base = orc.gen_rows_f16(SEED_BASE, 0, n)
     q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
