@@ -32,13 +32,25 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 class _stdout_to_stderr:
     """librccl prints a version banner on fd 1 when a communicator comes up; stdout is reserved for the one JSON line."""
 
+    @staticmethod
+    def _flush_c():
+        # the banner goes through the C library's buffered stdout: when fd 1 is a file or a pipe it would otherwise be written
+        # at exit -- after fd 1 has been restored, behind the JSON line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+
     def __enter__(self):
         sys.stdout.flush()
+        self._flush_c()
         self._saved = os.dup(1)
         os.dup2(2, 1)
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c()
         os.dup2(self._saved, 1)
         os.close(self._saved)
 
@@ -307,8 +319,9 @@ def pq_bench(args):
     """BASELINE configs[4] shape at BASELINE.md's size: full ADC scan of 1e8 x 64-byte OPQ codes (+4 descriptor bytes), top-200 by
     approximate score (the re-rank candidates), all arrays resident in HBM.  End to end per query (query upload, table build, scan
     keeping one maximum per 64 vectors, tournament, re-score of the best groups, exact top-r, download): one query per call, and
-    32 queries per call (one upload / download; the queries go through in FOURS that share one pass over the codes --
-    pq_scan64x4_kernel, integer nomination under a certificate -- and the groups alternate between two streams).  Both windows are
+    32 queries per call (one upload / download; the queries go through in EIGHTS that share one pass over the codes --
+    pq_scan64x4_kernel<.., 8>, 8-bit integer nomination on the matrix cores under a certificate -- and the groups alternate between
+    two streams).  Both windows are
     at least a second long.  `roofline` is the scan KERNEL's (68 B per vector per launch / its HIP-event duration); the end-to-end
     figure (a pass taken as four batched per-query times) stands beside it."""
     import numpy as np
@@ -345,12 +358,13 @@ def pq_bench(args):
     wall = time.perf_counter() - t0
     db = wall / (calls * len(qs))
     uncert = pq.last_uncertified
-    # the scan kernel by itself: calls of FOUR queries run on one stream (nothing beside the scan), HIP events around each launch
+    # the scan kernel by itself: calls of EIGHT queries are one group on one stream (nothing beside the scan), HIP events per launch
     pq.scan_timing(2)
     for i in range(24):
-        pq.scan_topk_batch(gc, qs[4 * (i % 8):4 * (i % 8) + 4], 200, 10, None, scales)
+        pq.scan_topk_batch(gc, qs[8 * (i % 4):8 * (i % 4) + 8], 200, 10, None, scales)
     k_ms, k_n = pq.scan_timing(0)
-    gbs_pass = n * 68 / (4 * db) / 1e9
+    per_pass = 8
+    gbs_pass = n * 68 / (per_pass * db) / 1e9
     k_avg = k_ms / max(k_n, 1)
     gbs_kernel = n * 68 / (k_avg * 1e-3) / 1e9 if k_n else None
     traffic = None
@@ -361,22 +375,22 @@ def pq_bench(args):
     except Exception:  # noqa: BLE001
         pass
     return {"metric": "OPQ/PQ 64x8-bit ADC scan + top-200", "ms_per_query": dt * 1e3, "ms_per_query_batched": db * 1e3,
-            "queries_per_s_batched": 1.0 / db, "queries_per_call_batched": len(qs), "queries_per_pass_batched": 4, "vectors": n,
+            "queries_per_s_batched": 1.0 / db, "queries_per_call_batched": len(qs), "queries_per_pass_batched": per_pass, "vectors": n,
             "timed": {"one_query_calls": calls1, "batched_calls": calls, "batched_seconds": wall},
             "uncertified_queries_last_batch": uncert,
             "codes_GBps_end_to_end_one_query_per_call": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
             "roofline": {"bound": "hbm", "kernel": "pq_scan64x4_kernel<16>", "achieved": gbs_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (gbs_kernel / HBM_PEAK_GBS) if gbs_kernel else None, "avg_launch_ms": k_avg, "launches_timed": k_n,
-                         "bytes_per_launch": n * 68, "queries_per_launch": 4, "traffic": traffic,
+                         "bytes_per_launch": n * 68, "queries_per_launch": per_pass, "traffic": traffic,
                          "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
                          "end_to_end": {"achieved": gbs_pass, "frac": gbs_pass / HBM_PEAK_GBS,
-                                        "note": "68 B x vectors / (4 x batched per-query time): table build, scan, tournament, re-score of the nominated "
-                                                "groups, exact top-r, certificate, download -- two streams, one group of four queries each"},
-                         "note": "achieved = 68 B x vectors per launch / the kernel's HIP-event duration in 24 four-query calls (one stream: nothing runs "
+                                        "note": "68 B x vectors / (8 x batched per-query time): table build, scan, tournament, re-score of the nominated "
+                                                "groups, exact top-r, certificate, download -- two streams, one group of eight queries each"},
+                         "note": "achieved = 68 B x vectors per launch / the kernel's HIP-event duration in 24 eight-query calls (one stream: nothing runs "
                                  "beside the scan; in the 32-query calls two streams interleave and a launch's event interval would include its wait "
                                  "for the other stream's scan).  Round 4 kernel: bank-conflict-free rotated gathers, sums on the matrix cores "
-                                 "(v_mfma_i32_16x16x64_i8) -- DESIGN.md 3.3"},
-            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), four queries' 12-bit tables (code-major, 138 KiB) in LDS, r = 200"}}
+                                 "(v_mfma_i32_16x16x64_i8), eight queries per pass with 8-bit tables under a certificate -- DESIGN.md 3.3"},
+            "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), eight queries' 8-bit tables (code-major, 138 KiB) in LDS, r = 200"}}
 
 
 def graph_rows(n, seed, centres):
@@ -508,7 +522,7 @@ def graph_scale_bench(args):
     import numpy as np
     import torch
     import mse
-    n, nq, K, R, batch = int(args.graph_scale_rows), 2048, 10, 64, 2048   # 1024 tuning + 1024 held-out queries
+    n, nq, K, R, batch = int(args.graph_scale_rows), 2048, 10, 64, int(args.graph_batch)   # 1024 tuning + 1024 held-out queries
     g0 = torch.Generator(device="cuda").manual_seed(0)
     hier = max(8, n // 5000)
     sup = torch.randn(hier, D, device="cuda", generator=g0)
@@ -546,11 +560,30 @@ def graph_scale_bench(args):
     half = nq // 2
     tune, held = slice(0, half), slice(half, nq)
 
+    # Entry points.  The reference starts a search at the medioid of the shard whose centroid is closest to the query
+    # (src/query_disk_index.rs:254-256,447-450).  Here the graph is ONE piece; the same idea without shards: `n_entry` sampled base
+    # rows stand in for the shard medioids and a search starts at the sample row with the largest dot product with its query (an
+    # exact top-1 over the sample, inside the timed region).  With the medioid alone as entry a one-pass graph over 1e8 clustered
+    # rows needs search lists beyond 200 to reach 0.95 (0.924 at L = 200, profiles/r04_graph_index_1e8.json).
+    n_entry = int(args.graph_entries)
+    if n_entry > 0:
+        e_idx = np.sort(np.random.default_rng(5).choice(n, min(n_entry, n), replace=False)).astype(np.int64)
+        e_rows = rows[torch.from_numpy(e_idx).cuda()].contiguous()
+        e_vecs = mse.VectorList.wrap_device(e_rows.data_ptr(), len(e_idx), D, keepalive=e_rows)
+        e_search = mse.Searcher(e_vecs)
+        e_search.bruteforce_topk(qh[:8], 1, mse.MODE_EXACT)
+
+    def entry_points(q):
+        if n_entry <= 0:
+            return np.full(len(q), med, np.uint32)
+        _, top = e_search.bruteforce_topk(q, 1, mse.MODE_MFMA if len(q) > 8 else mse.MODE_EXACT)
+        return e_idx[top[:, 0]].astype(np.uint32)
+
     def run(L, sl, timed):
-        starts = np.full(sl.stop - sl.start, med, np.uint32)
         if timed:   # warm: scratch is allocated on first use
-            mse.disk_search_batch(s, None, None, g, starts, qh[sl], None, None, True, 4, L, 1024, as_arrays=True)
+            mse.disk_search_batch(s, None, None, g, entry_points(qh[sl]), qh[sl], None, None, True, 4, L, 1024, as_arrays=True)
         t0 = time.perf_counter()
+        starts = entry_points(qh[sl])
         res = mse.disk_search_batch(s, None, None, g, starts, qh[sl], None, None, True, 4, L, 1024, as_arrays=True)
         dt = time.perf_counter() - t0
         top = mse.topk_of_visited(res, K)
@@ -559,7 +592,7 @@ def graph_scale_bench(args):
         return {"search_list": L, "queries": m, "queries_per_s": m / dt, "recall_at_10": rec, "node_fetches_per_query": float(res["cmps"].mean())}
 
     sweep, chosen = [], None
-    for L in (32, 48, 64, 100, 200):
+    for L in (32, 48, 64, 100, 200, 400):
         pt = run(L, tune, False)
         sweep.append({"search_list": L, "tuning_recall_at_10": pt["recall_at_10"]})
         if pt["recall_at_10"] >= 0.96:
@@ -597,7 +630,9 @@ def graph_scale_bench(args):
             "operating_point": "search list picked on queries 0..%d (tuning recall >= 0.96), value / recall measured on the held-out queries %d..%d" % (half - 1, half, nq - 1),
             "build": {"seconds": t_build, "points_per_s": n / t_build, "passes": 1, "r": R, "l": 192, "maxc": 750, "batch": batch},
             "exact_scan_same_index_queries_per_s": nq / t_exact,
-            "config": {"workload": f"{n} x {D} fp16 hierarchical synthetic clusters, one-pass Vamana graph built on the device, entry = the medioid"}}
+            "entry_points": (f"{n_entry} sampled base rows; a search starts at the one with the largest dot product with its query (exact top-1, timed); "
+                             "the reference: medioid of the closest shard, src/query_disk_index.rs:447-450") if n_entry > 0 else "the medioid",
+            "config": {"workload": f"{n} x {D} fp16 hierarchical synthetic clusters, one-pass Vamana graph built on the device"}}
 
 
 def cpu_graph_build(n, points=192):
@@ -810,6 +845,9 @@ def main():
     ap.add_argument("--graph-rows", type=float, default=2e5)
     ap.add_argument("--no-graph-scale", action="store_true", help="skip the 1e7-row graph-index leg (a ~1 minute build)")
     ap.add_argument("--graph-scale-rows", type=float, default=1e7)
+    ap.add_argument("--graph-batch", type=int, default=2048, help="points inserted per batch of the graph-scale build")
+    ap.add_argument("--graph-entries", type=int, default=4096,
+                    help="sampled entry points of the graph-scale search (0: the medioid alone)")
     ap.add_argument("--siglip-batch", type=int, default=256)
     ap.add_argument("--siglip-steps", type=int, default=10)
     args = ap.parse_args()

@@ -255,9 +255,11 @@ int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, co
  * vectors are then found inside the r best groups (exact, ties by lower id). */
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
-/* Batches of >= 4 queries go through the codes four queries per pass: a 12-bit integer nomination scan whose answer is certified
- * against the reference-order re-score of the nominated vectors (csrc/pq.hip); a query whose certificate does not hold is repeated
- * through the exact scan, so results are identical either way.  This counts such repeats in the last batch call. */
+/* Batches of >= 4 queries go through the codes four (12-bit tables) or eight (8-bit tables, batches of >= 8) queries per pass: an
+ * integer nomination scan on the matrix cores whose answer is certified against the reference-order re-score of the nominated
+ * vectors (csrc/pq.hip); a query whose certificate does not hold is repeated through the exact scan, so results are identical
+ * either way.  This counts such repeats in the last batch call.  (A quantiser whose data defeats the 8-bit certificate -- more than
+ * an eighth of a batch's eight-per-pass queries repeated -- goes back to four per pass for good.) */
 uint32_t mse_pq_last_uncertified(mse_pq* pq);
 /* test hook: the group maxima (best ADC score + descriptor bias of every 64 vectors, INT64_MIN past the end) the flat scan
  * nominates with; lut1 == NULL: the one-query kernel, else the two-queries-per-pass kernel.  out0 / out1: [ceil(n/64)] on the host. */
@@ -266,10 +268,11 @@ int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, co
 /* HIP-event timing of the four-queries-per-pass scan kernel inside mse_pq_scan_topk_batch (the dominant kernel, for the
  * roofline report): returns the totals accumulated so far, then sets the mode: 0 off, 1 on, 2 on and reset. */
 int mse_pq_scan_timing(mse_pq* pq, int enable, double* total_ms, uint64_t* launches);
-/* test hook: the four-queries-per-pass integer nomination scan alone.  luts4 [4][64*256] (n_valid of them used), scales NULL or [4];
- * out [4][ceil(n/64)] u32 group maxima of the integer sums, params_out [4][4] = delta, c, eps, ok of each query's 12-bit table. */
-int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts4, const float* scales, int n_valid, uint32_t* out,
-                            double* params_out);
+/* test hook: the integer nomination scan alone, per_pass = 4 (12-bit tables) or 8 (8-bit tables) queries per pass over the codes.
+ * luts [per_pass][64*256] (n_valid of them used), scales NULL or [4]; out [per_pass][ceil(n/64)] u32 group maxima of the integer
+ * sums, params_out [per_pass][4] = delta, c, eps, ok of each query's table. */
+int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts, const float* scales, int n_valid, int per_pass,
+                            uint32_t* out, double* params_out);
 /* descriptor_product (src/query_disk_index.rs:135-142) for one id, host-side helper. */
 int64_t mse_descriptor_product(const float* scales, size_t n_descriptors, const uint8_t* descriptors, uint32_t id);
 

@@ -560,29 +560,33 @@ static int scan_topk_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, cons
     return 0;
 }
 
-// FOUR queries in one pass over the codes (pq_scan64x4_kernel: 12-bit integer nomination under a certificate, pq.hip).  Per query:
+// FOUR (12-bit tables) or EIGHT (8-bit tables) queries in one pass over the codes (pq_scan64x4_kernel: integer nomination under a
+// certificate, pq.hip).  Per query:
 // the n_nom best groups by their integer maximum (+ one more, whose key bounds everything excluded) -> their vectors re-scored in the
 // reference's arithmetic (pq_adc_kernel) -> exact top-r among them -> certificate flag (1 = provably the exact top-r of all
 // vectors) -> with base vectors the same fast_dot re-score as the other paths.  flags_dev[j] = 0 asks the caller to repeat query j
-// through the exact scan.  lut_dev: 4 tables; t_dev: 4 transformed queries.
+// through the exact scan.  lut_dev: NQ tables; t_dev: NQ transformed queries.
+// How many groups to nominate: the certificate needs every group whose integer maximum lies within ~2 eps of the r-th exact
+// score.  With 12-bit tables that is a few tens of vectors at 1e8 codes (r + max(64, r / 2) groups); the 8-bit step is 16 times
+// coarser and the band holds ~0.7 r vectors on random codes (simulated at 1e7 codes, r = 200: 339 groups reach it): 2 r + 112.
+static size_t pq_nominated(size_t r, int NQ) { return NQ == 4 ? r + std::max<size_t>(64, r / 2) : 2 * r + 112; }
 static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, const float* queries_dev, float* t_dev, float* lut_dev,
                             uint16_t* qf16_dev, const float* scales_dev, size_t r, size_t k, int64_t* out_scores_dev,
-                            uint32_t* out_ids_dev, int* flags_dev, bool prepared) {
+                            uint32_t* out_ids_dev, int* flags_dev, bool prepared, int NQ) {
     hipStream_t st = s->stream;
     const size_t d = pq->d, lut_floats = pq->n_chunks * pq->n_centroids;
     const uint8_t* desc = scales_dev ? c->desc : nullptr;
-    for (int j = 0; j < 4 && !prepared; j++)
+    for (int j = 0; j < NQ && !prepared; j++)
         if (prep_table(pq, s, queries_dev + j * d, t_dev + j * d, lut_dev + j * lut_floats)) return -1;
     const size_t n_groups = (c->n + 63) / 64;
-    // nominate r + max(64, r / 2) groups: the certificate needs every group whose integer maximum lies within ~2 eps of the r-th
-    // exact score (a few tens of vectors at 1e8 codes); one more group is selected only for its key
-    const size_t n_nom = std::min(n_groups, r + std::max<size_t>(64, r / 2));
+    // one more group than nominated is selected, only for its key
+    const size_t n_nom = std::min(n_groups, pq_nominated(r, NQ));
     const size_t n_sel = std::min(n_groups, n_nom + 1);
     if (n_sel > (size_t)TOPK_KMAX) return fail("pq scan: r too large for the four-query scan");
-    if (s->pq4.ensure(pq4_table_bytes() + 4 * sizeof(Pq4Params)) || s->gmax.ensure(4 * n_groups * 4)) return -1;
+    if (s->pq4.ensure(pq4_table_bytes() + 8 * sizeof(Pq4Params)) || s->gmax.ensure((size_t)NQ * n_groups * 4)) return -1;
     void* table = s->pq4.p;
     Pq4Params* params = reinterpret_cast<Pq4Params*>(s->pq4.as<char>() + pq4_table_bytes());
-    if (launch_pq4_table(lut_dev, scales_dev, 4, table, params, st)) return -1;
+    if (launch_pq4_table(lut_dev, scales_dev, NQ, table, params, st, NQ)) return -1;
     hipEvent_t te0 = nullptr, te1 = nullptr;
     if (pq->timing) {
         while (s->ev_pool.size() < s->ev_used + 2) {
@@ -595,46 +599,47 @@ static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, con
         s->ev_used += 2;
         MSE_HIP_TRY(hipEventRecord(te0, st));
     }
-    if (launch_pq_scan_gmax4(table, c->codes, c->n, desc, s->gmax.as<uint32_t>(), s->n_cu, st)) return -1;
+    if (launch_pq_scan_gmax4(table, c->codes, c->n, desc, s->gmax.as<uint32_t>(), s->n_cu, st, NQ)) return -1;
     if (te1) MSE_HIP_TRY(hipEventRecord(te1, st));
-    // the four tails as ONE chain of launches with a query dimension (their kernels are latency-bound: four chains in a row cost more
+    // the NQ tails as ONE chain of launches with a query dimension (their kernels are latency-bound: four chains in a row cost more
     // than the scan); every buffer at its final size before the first kernel that uses it
     const size_t n_cand = n_nom * 64;
-    if (s->gkeys.ensure(4 * std::max(k, n_sel) * 8) || s->cand_ids.ensure(4 * n_cand * 4) || s->cand_scores.ensure(4 * std::max(r, n_cand) * 8) ||
-        s->out_ids.ensure(4 * r * 4) || s->sel_keys.ensure(4 * r * 8) || s->misc.ensure(4 * k * 4) || s->scores.ensure(4 * k * 8)) return -1;
+    const size_t Q = (size_t)NQ;
+    if (s->gkeys.ensure(Q * std::max(k, n_sel) * 8) || s->cand_ids.ensure(Q * n_cand * 4) || s->cand_scores.ensure(Q * std::max(r, n_cand) * 8) ||
+        s->out_ids.ensure(Q * r * 4) || s->sel_keys.ensure(Q * r * 8) || s->misc.ensure(Q * k * 4) || s->scores.ensure(Q * k * 8)) return -1;
     uint32_t* gsel = nullptr;
     LevelRef l0{KEY_U32, s->gmax.p, n_groups, 1, n_groups, false, 0};
-    if (descend(s, l0, 4, (int)n_sel, &gsel, s->gkeys.p)) return -1;                       // gsel [4][n_sel], gkeys u32 [4][n_sel]
-    if (launch_expand_groups(gsel, n_sel, n_nom, 64, c->n, s->cand_ids.as<uint32_t>(), n_cand, 4, st)) return -1;
+    if (descend(s, l0, NQ, (int)n_sel, &gsel, s->gkeys.p)) return -1;                      // gsel [NQ][n_sel], gkeys u32 [NQ][n_sel]
+    if (launch_expand_groups(gsel, n_sel, n_nom, 64, c->n, s->cand_ids.as<uint32_t>(), n_cand, NQ, st)) return -1;
     if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), n_cand, desc,
-                      (int)c->n_desc, scales_dev, s->cand_scores.as<int64_t>(), s->n_cu, st, 4, n_cand)) return -1;
+                      (int)c->n_desc, scales_dev, s->cand_scores.as<int64_t>(), s->n_cu, st, NQ, n_cand)) return -1;
     {
         SelectArgs a{};
         a.kind = KEY_I64; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p; a.list_stride = n_cand;
-        a.n_list = n_cand; a.k = (int)r; a.out_ids = s->out_ids.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = r; a.nq = 4;
+        a.n_list = n_cand; a.k = (int)r; a.out_ids = s->out_ids.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = r; a.nq = NQ;
         if (launch_select(a, st)) return -1;
     }
     if (launch_pq4_certify(params, s->gkeys.as<uint32_t>(), (int)n_nom, (int)n_sel, s->out_ids.as<uint32_t>(), s->sel_keys.as<int64_t>(), r,
-                           (int)std::min(r, c->n), 4, flags_dev, st)) return -1;
-    const uint32_t* top_ids = s->out_ids.as<uint32_t>();      // [4][r]
+                           (int)std::min(r, c->n), NQ, flags_dev, st)) return -1;
+    const uint32_t* top_ids = s->out_ids.as<uint32_t>();      // [NQ][r]
     const int64_t* top_scores = s->sel_keys.as<int64_t>();
     size_t top_stride = r;
     if (s->base) {
         // exact re-score: f16(query) . base[id] (+ descriptor bias), query_disk_index.rs:168-170,477 -- four queries per launch
         const mse_base* b = s->base;
-        if (launch_f32_to_f16(queries_dev, 4 * d, qf16_dev, st)) return -1;
-        if (launch_score_rows(b->dev, b->n, (int)d, qf16_dev, false, top_ids, 4 * r, r, s->cand_scores.as<int64_t>(), nullptr, st)) return -1;
-        if (launch_add_descriptor(top_ids, 4 * r, desc, (int)c->n_desc, c->n, scales_dev, s->cand_scores.as<int64_t>(), st)) return -1;
+        if (launch_f32_to_f16(queries_dev, Q * d, qf16_dev, st)) return -1;
+        if (launch_score_rows(b->dev, b->n, (int)d, qf16_dev, false, top_ids, Q * r, r, s->cand_scores.as<int64_t>(), nullptr, st)) return -1;
+        if (launch_add_descriptor(top_ids, Q * r, desc, (int)c->n_desc, c->n, scales_dev, s->cand_scores.as<int64_t>(), st)) return -1;
         SelectArgs b2{};
         b2.kind = KEY_I64; b2.list_ids = top_ids; b2.list_keys = s->cand_scores.p; b2.list_stride = r; b2.n_list = r;
-        b2.k = (int)k; b2.out_ids = s->misc.as<uint32_t>(); b2.out_keys = s->scores.p; b2.out_stride = k; b2.nq = 4;
+        b2.k = (int)k; b2.out_ids = s->misc.as<uint32_t>(); b2.out_keys = s->scores.p; b2.out_stride = k; b2.nq = NQ;
         if (launch_select(b2, st)) return -1;
         top_ids = s->misc.as<uint32_t>();
         top_scores = s->scores.as<int64_t>();
         top_stride = k;
     }
-    MSE_HIP_TRY(hipMemcpy2DAsync(out_ids_dev, k * 4, top_ids, top_stride * 4, k * 4, 4, hipMemcpyDeviceToDevice, st));
-    MSE_HIP_TRY(hipMemcpy2DAsync(out_scores_dev, k * 8, top_scores, top_stride * 8, k * 8, 4, hipMemcpyDeviceToDevice, st));
+    MSE_HIP_TRY(hipMemcpy2DAsync(out_ids_dev, k * 4, top_ids, top_stride * 4, k * 4, Q, hipMemcpyDeviceToDevice, st));
+    MSE_HIP_TRY(hipMemcpy2DAsync(out_scores_dev, k * 8, top_scores, top_stride * 8, k * 8, Q, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -668,7 +673,7 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         // batch entry points use; same arithmetic as the one-vector forms) instead of two small launches per query in front of every scan
         const size_t lut_floats_b = pq->n_chunks * pq->n_centroids;
         const bool prep_all = nq >= 4 && nq <= 2048;
-        const size_t n_tab = prep_all ? nq : 4;
+        const size_t n_tab = prep_all ? nq : 8;
         if (pq->a.ensure(in_bytes + 256) || pq->b.ensure(n_tab * d * 4) || pq->c.ensure(n_tab * lut_floats_b * 4)) break;
         if (s->q_stage.ensure(8 * d * 2) || s->out_scores.ensure(out_bytes)) break;
         if (pq->pin_cap < std::max(in_bytes, out_bytes)) {
@@ -693,11 +698,12 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
             if (pq->lane2 && pq->lane2->base != s->base) { mse_searcher_free(pq->lane2); pq->lane2 = nullptr; }
             if (!pq->lane2) pq->lane2 = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
             lanes[1] = pq->lane2;
-            if (!lanes[1] || t2.ensure(4 * d * 4) || lut2.ensure(4 * pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
+            if (!lanes[1] || t2.ensure(8 * d * 4) || lut2.ensure(8 * pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
             if (hipStreamSynchronize(st) != hipSuccess) { fail("H2D failed"); break; }   // uploads visible to both streams
         }
-        // queries go through in groups that share one pass over the codes: FOURS (integer nomination under a certificate,
-        // pq_scan64x4_kernel), then a PAIR (pq_scan64x2_kernel, exact), then a single one; groups alternate between the streams
+        // queries go through in groups that share one pass over the codes: EIGHTS (8-bit tables) and FOURS (12-bit tables) -- integer
+        // nomination under a certificate, pq_scan64x4_kernel --, then a PAIR (pq_scan64x2_kernel, exact), then a single one; groups
+        // alternate between the streams
         int* const flags_dev = reinterpret_cast<int*>(s->out_scores.as<char>() + nq * k * 12);
         if (hipMemsetAsync(flags_dev, 0xff, nq * 4, st) != hipSuccess) { fail("memset failed"); break; }   // non-zero = certified / exact
         if (prep_all && (launch_pq_transform(pq->transform, (int)d, pq->a.as<float>(), nq, pq->b.as<float>(), st) ||
@@ -707,17 +713,23 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         const uint8_t* desc_dev = scales_dev ? c->desc : nullptr;
         const bool four_ok = pq_scan_gmax_supported((int)pq->n_chunks, (int)pq->n_centroids, desc_dev, (int)c->n_desc, scales_dev) &&
                              r + std::max<size_t>(64, r / 2) + 1 <= (size_t)TOPK_KMAX;
+        // eight per pass while the 8-bit certificate holds for this quantiser's data: a batch in which more than an eighth of the
+        // eight-per-pass queries had to be repeated through the exact scan switches the handle back to four per pass for good
+        const bool eight_ok = four_ok && !pq->avoid8 && pq_nominated(r, 8) + 1 <= (size_t)TOPK_KMAX;
+        std::vector<char> in_eight(nq, 0);
         bool ok = true;
         size_t q = 0;
         for (size_t unit = 0; q < nq && ok; unit++) {
-            const int n_q = (four_ok && nq - q >= 4) ? 4 : nq - q >= 2 ? 2 : 1;
+            const int n_q = (eight_ok && nq - q >= 8) ? 8 : (four_ok && nq - q >= 4) ? 4 : nq - q >= 2 ? 2 : 1;
             const int w = lanes[1] ? (int)(unit & 1) : 0;
             float* const tw = prep_all ? pq->b.as<float>() + q * d : w ? t2.as<float>() : pq->b.as<float>();
             float* const lw = prep_all ? pq->c.as<float>() + q * lut_floats_b : w ? lut2.as<float>() : pq->c.as<float>();
             uint16_t* const qw = w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>();
-            if (n_q == 4)
+            if (n_q >= 4) {
                 ok = scan_topk4_async(pq, c, lanes[w], pq->a.as<float>() + q * d, tw, lw, qw, scales_dev, r, k, out_scores_dev + q * k,
-                                      out_ids_dev + q * k, flags_dev + q, prep_all) == 0;
+                                      out_ids_dev + q * k, flags_dev + q, prep_all, n_q) == 0;
+                if (n_q == 8) for (int j = 0; j < 8; j++) in_eight[q + j] = 1;
+            }
             else
                 ok = scan_topk_async(pq, c, lanes[w], pq->a.as<float>() + q * d, n_q, tw, lw, qw, scales_dev, r, k,
                                      out_scores_dev + q * k, out_ids_dev + q * k, prep_all) == 0;
@@ -732,6 +744,9 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
             if (hipMemcpyAsync(flags.data(), flags_dev, nq * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
             pq->last_uncertified = 0;
+            size_t n8 = 0, bad8 = 0;
+            for (size_t j = 0; j < nq; j++) { n8 += in_eight[j]; bad8 += in_eight[j] && !flags[j]; }
+            if (n8 && bad8 * 8 > n8) pq->avoid8 = true;
             for (size_t j = 0; j < nq && ok; j++)
                 if (!flags[j]) {
                     pq->last_uncertified++;
@@ -835,27 +850,29 @@ mse_codes* mse_codes_quantize_base(mse_pq* pq, const mse_base* b, const uint8_t*
 // test hook: the integer nomination scan by itself -- the four queries' group maxima (u32, [4][ceil(n / 64)]) and their
 // certificate parameters (params_out [4][4] = delta, c, eps, ok), so that a test can rebuild the 12-bit tables on the host and
 // check every maximum of the matrix-core scan against plain integer sums
-int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts4, const float* scales, int n_valid, uint32_t* out,
+int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts4, const float* scales, int n_valid, int per_pass, uint32_t* out,
                             double* params_out) {
     if (!pq || !c || !luts4 || !out || !params_out) return fail("null argument");
+    if (per_pass != 4 && per_pass != 8) return fail("per_pass must be 4 or 8");
+    const size_t NQ = (size_t)per_pass;
     if (c->code_size != pq->n_chunks || pq->n_chunks != 64 || pq->n_centroids != 256) return fail("the four-query scan serves 64 x 256 codecs only");
-    if (n_valid < 1 || n_valid > 4) return fail("n_valid must be 1 .. 4");
+    if (n_valid < 1 || n_valid > per_pass) return fail("n_valid must be 1 .. per_pass");
     const uint8_t* desc = (scales && c->n_desc) ? c->desc : nullptr;
     if (desc && c->n_desc != 4) return fail("the four-query scan takes 4 descriptor bytes");
     if (c->n == 0) return 0;
     std::lock_guard<std::mutex> g(pq->mu);
-    const size_t lut_bytes = (size_t)4 * 64 * 256 * 4, n_groups = (c->n + 63) / 64;
-    if (pq->a.ensure(lut_bytes + 256) || pq->b.ensure(pq4_table_bytes() + 4 * sizeof(Pq4Params)) || pq->c.ensure(4 * n_groups * 4)) return -1;
+    const size_t lut_bytes = NQ * 64 * 256 * 4, n_groups = (c->n + 63) / 64;
+    if (pq->a.ensure(lut_bytes + 256) || pq->b.ensure(pq4_table_bytes() + 8 * sizeof(Pq4Params)) || pq->c.ensure(NQ * n_groups * 4)) return -1;
     float* sc = reinterpret_cast<float*>(pq->a.as<char>() + lut_bytes);
     MSE_HIP_TRY(hipMemcpy(pq->a.p, luts4, lut_bytes, hipMemcpyHostToDevice));
     if (desc) MSE_HIP_TRY(hipMemcpy(sc, scales, 16, hipMemcpyHostToDevice));
     Pq4Params* params = reinterpret_cast<Pq4Params*>(pq->b.as<char>() + pq4_table_bytes());
-    if (launch_pq4_table(pq->a.as<float>(), desc ? sc : nullptr, n_valid, pq->b.p, params, nullptr)) return -1;
-    if (launch_pq_scan_gmax4(pq->b.p, c->codes, c->n, desc, pq->c.as<uint32_t>(), device_cu_count(), nullptr)) return -1;
-    Pq4Params ph[4];
-    MSE_HIP_TRY(hipMemcpy(out, pq->c.p, 4 * n_groups * 4, hipMemcpyDeviceToHost));
-    MSE_HIP_TRY(hipMemcpy(ph, params, sizeof(ph), hipMemcpyDeviceToHost));
-    for (int j = 0; j < 4; j++) { params_out[4 * j] = ph[j].delta; params_out[4 * j + 1] = ph[j].c; params_out[4 * j + 2] = ph[j].eps; params_out[4 * j + 3] = ph[j].ok; }
+    if (launch_pq4_table(pq->a.as<float>(), desc ? sc : nullptr, n_valid, pq->b.p, params, nullptr, per_pass)) return -1;
+    if (launch_pq_scan_gmax4(pq->b.p, c->codes, c->n, desc, pq->c.as<uint32_t>(), device_cu_count(), nullptr, per_pass)) return -1;
+    Pq4Params ph[8];
+    MSE_HIP_TRY(hipMemcpy(out, pq->c.p, NQ * n_groups * 4, hipMemcpyDeviceToHost));
+    MSE_HIP_TRY(hipMemcpy(ph, params, NQ * sizeof(Pq4Params), hipMemcpyDeviceToHost));
+    for (int j = 0; j < per_pass; j++) { params_out[4 * j] = ph[j].delta; params_out[4 * j + 1] = ph[j].c; params_out[4 * j + 2] = ph[j].eps; params_out[4 * j + 3] = ph[j].ok; }
     return 0;
 }
 

@@ -380,6 +380,8 @@ mse_graph* mse_graph_from_host(const uint32_t* adj, const uint32_t* deg, size_t 
 
 void mse_graph_free(mse_graph* g) {
     if (!g) return;
+    delete g->co;   // joins its worker; no search may be in flight
+    g->co = nullptr;
     if (g->adj) (void)hipFree(g->adj);
     if (g->deg) (void)hipFree(g->deg);
     if (g->has_url) (void)hipFree(g->has_url);
@@ -502,12 +504,119 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     return 0;
 }
 
+}  // extern "C"
+
+// ---- one query per call from many threads: the reference's request path --------------------------------------------------------
+// query_disk_index serves every HTTP request with ONE greedy_search on its own task / thread (src/query_disk_index.rs:436-540,
+// 711-736).  A one-query launch is one workgroup on a 256-CU part; T of them from T threads are T launches.  So calls of
+// mse_disk_search_batch(_f32) with nq = 1 meet in the graph's coalescer (dispatch.h): the worker sorts what it gathered into groups
+// that can share a launch -- same vectors, codec, codes, graph, search parameters and kind of inputs -- and runs each group as ONE
+// batched search (a workgroup per query) on the searcher of the group's first caller, whose owner is blocked in its call.  Every
+// caller gets exactly what its call returns when made alone (the batched kernel treats queries independently).
+namespace {
+struct BeamCall {
+    mse_searcher* s; mse_pq* pq; const mse_codes* c; const mse_graph* g; const uint32_t* starts;
+    const uint16_t* queries; const float* queries_f32; const float* luts; const float* scales;
+    int disable_pq; size_t beamwidth, search_list, visited_cap;
+    uint32_t* buf_ids; int64_t* buf_scores; uint32_t* buf_len; uint32_t* visited_ids; int64_t* visited_scores;
+    uint32_t *n_visited, *cmps, *pq_cmps;
+    bool shares_with(const BeamCall& o) const {
+        return s->base == o.s->base && pq == o.pq && c == o.c && g == o.g && disable_pq == o.disable_pq && beamwidth == o.beamwidth &&
+               search_list == o.search_list && visited_cap == o.visited_cap && (queries != nullptr) == (o.queries != nullptr) &&
+               (luts != nullptr) == (o.luts != nullptr) && (scales != nullptr) == (o.scales != nullptr) &&
+               (visited_ids != nullptr) == (o.visited_ids != nullptr) && (visited_scores != nullptr) == (o.visited_scores != nullptr);
+    }
+};
+int beam_call_alone(const BeamCall& k) {
+    return disk_search_batch_impl(-1, k.s, k.pq, k.c, k.g, k.starts, k.queries, k.queries_f32, k.luts, k.scales, 1, k.disable_pq, k.beamwidth,
+                                  k.search_list, k.buf_ids, k.buf_scores, k.buf_len, k.visited_ids, k.visited_scores, k.visited_cap, k.n_visited,
+                                  k.cmps, k.pq_cmps);
+}
+void beam_run_batch(std::vector<DispatchReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        const BeamCall& lead = *static_cast<const BeamCall*>(batch[i]->aux0);
+        std::vector<DispatchReq*> grp;
+        for (size_t j = i; j < batch.size(); j++)
+            if (!taken[j] && lead.shares_with(*static_cast<const BeamCall*>(batch[j]->aux0))) { taken[j] = 1; grp.push_back(batch[j]); }
+        (void)hipSetDevice(lead.s->base->device);
+        const size_t n = grp.size(), d = lead.s->base->d, L = lead.search_list, vc = lead.visited_cap;
+        const size_t n_desc = (lead.scales && lead.c) ? lead.c->n_desc : 0;
+        int rc = 0;
+        if (n == 1) {
+            rc = beam_call_alone(lead);
+            grp[0]->rc = rc;
+            if (rc) grp[0]->err = mse_last_error();
+            continue;
+        }
+        std::vector<uint32_t> starts(n), ids(n * L), len(n), nv(n), cm(n), pc(n), vids(lead.visited_ids ? n * vc : 0);
+        std::vector<int64_t> sc(n * L), vsc(lead.visited_scores ? n * vc : 0);
+        std::vector<uint16_t> q16(lead.queries ? n * d : 0);
+        std::vector<float> q32(lead.queries_f32 ? n * d : 0), luts(lead.luts ? n * 16384 : 0), scl(n_desc ? n * n_desc : 0);
+        for (size_t j = 0; j < n; j++) {
+            const BeamCall& k = *static_cast<const BeamCall*>(grp[j]->aux0);
+            starts[j] = k.starts[0];
+            if (k.queries) memcpy(q16.data() + j * d, k.queries, d * 2);
+            if (k.queries_f32) memcpy(q32.data() + j * d, k.queries_f32, d * 4);
+            if (k.luts) memcpy(luts.data() + j * 16384, k.luts, 16384 * 4);
+            if (n_desc) memcpy(scl.data() + j * n_desc, k.scales, n_desc * 4);
+        }
+        rc = disk_search_batch_impl(-1, lead.s, lead.pq, lead.c, lead.g, starts.data(), lead.queries ? q16.data() : nullptr,
+                                    lead.queries_f32 ? q32.data() : nullptr, lead.luts ? luts.data() : nullptr, n_desc ? scl.data() : lead.scales, n,
+                                    lead.disable_pq, lead.beamwidth, L, ids.data(), sc.data(), len.data(), lead.visited_ids ? vids.data() : nullptr,
+                                    lead.visited_scores ? vsc.data() : nullptr, vc, nv.data(), cm.data(), pc.data());
+        for (size_t j = 0; j < n; j++) {
+            const BeamCall& k = *static_cast<const BeamCall*>(grp[j]->aux0);
+            if (rc) {     // the shared launch failed: each caller is repeated alone and sees only its own outcome
+                grp[j]->rc = beam_call_alone(k);
+                if (grp[j]->rc) grp[j]->err = mse_last_error();
+                continue;
+            }
+            memcpy(k.buf_ids, ids.data() + j * L, L * 4);
+            memcpy(k.buf_scores, sc.data() + j * L, L * 8);
+            k.buf_len[0] = len[j]; k.n_visited[0] = nv[j]; k.cmps[0] = cm[j]; k.pq_cmps[0] = pc[j];
+            if (k.visited_ids) memcpy(k.visited_ids, vids.data() + j * vc, vc * 4);
+            if (k.visited_scores) memcpy(k.visited_scores, vsc.data() + j * vc, vc * 8);
+            grp[j]->rc = 0;
+        }
+    }
+}
+// nq == 1: through the graph's coalescer.  Argument errors that belong to one caller are found before it queues.
+int beam_one_query(BeamCall& k) {
+    if (!k.s || !k.s->base || !k.g || !k.starts || (!k.queries && !k.queries_f32) || !k.buf_ids || !k.buf_scores || !k.buf_len || !k.n_visited ||
+        !k.cmps || !k.pq_cmps)
+        return fail("disk_search_batch: null argument");
+    if (k.beamwidth == 0 || k.beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
+    if (k.search_list == 0 || k.search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
+    if (k.starts[0] >= k.g->n) return beam_call_alone(k);   // let the search report it in its own words
+    {
+        std::lock_guard<std::mutex> lk(k.g->co_mu);
+        if (!k.g->co) {
+            k.g->co = new (std::nothrow) Coalescer(1024, 200, [](std::vector<DispatchReq*>& b) { beam_run_batch(b); }, nullptr);
+            if (!k.g->co) return fail("out of host memory");
+        }
+    }
+    DispatchReq r;
+    r.nq = 1;
+    r.aux0 = &k;
+    return k.g->co->submit(r);
+}
+}  // namespace
+
+extern "C" {
+
 int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
                           const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
                           size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
                           uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
                           uint32_t* cmps, uint32_t* pq_cmps) {
     if (!queries) return fail("disk_search_batch: null argument");
+    if (nq == 1) {
+        BeamCall k{s, pq, c, g, starts, queries, nullptr, luts, scales, disable_pq, beamwidth, search_list, visited_cap, buf_ids, buf_scores, buf_len,
+                   visited_ids, visited_scores, n_visited, cmps, pq_cmps};
+        return beam_one_query(k);
+    }
     return disk_search_batch_impl(-1, s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
                                   buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
 }
@@ -517,6 +626,11 @@ int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
                               size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len, uint32_t* visited_ids,
                               int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
     if (!queries_f32) return fail("disk_search_batch_f32: null argument");
+    if (nq == 1) {
+        BeamCall k{s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, disable_pq, beamwidth, search_list, visited_cap, buf_ids, buf_scores,
+                   buf_len, visited_ids, visited_scores, n_visited, cmps, pq_cmps};
+        return beam_one_query(k);
+    }
     return disk_search_batch_impl(-1, s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, nq, disable_pq, beamwidth, search_list,
                                   buf_ids, buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
 }

@@ -98,9 +98,9 @@ int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* co
 // four queries per pass: 12-bit integer nomination tables + certificate (pq.hip)
 struct Pq4Params { double delta, c, eps; int ok; };
 size_t pq4_table_bytes();
-int launch_pq4_table(const float* luts4, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream);
-int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax4, int n_cu,
-                         hipStream_t stream);
+int launch_pq4_table(const float* luts, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream, int nq = 4);
+int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax, int n_cu,
+                         hipStream_t stream, int nq = 4);   // nq = 4: 12-bit tables, 8: 8-bit tables; gmax [nq][n_groups]
 int launch_pq4_certify(const Pq4Params* params, const uint32_t* group_keys, int n_nominated, int n_sel, const uint32_t* top_ids,
                        const int64_t* top_scores, size_t top_stride, int r, int nq, int* flag, hipStream_t stream);
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,

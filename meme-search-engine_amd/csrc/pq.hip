@@ -502,14 +502,21 @@ constexpr int PQ4_CHUNKS = 68;                     // 64 code chunks + 4 descrip
 // (descriptor value v, byte d) at 131072 + v * 40 + d * 8.  An entry is 8 bytes, two per query: the value's low 6 bits and the
 // bits above them (<= 63 for the 12-bit code entries, <= 255 for the 14-bit descriptor entries), each XOR 0x80 (the matrix
 // core reads the bytes as signed: stored value = byte - 128).
+// Eight queries per pass: a code entry holds one byte per query; a DESCRIPTOR entry keeps 14 bits per query in 16 bytes (bytes 0-7
+// the low 6 bits, bytes 8-15 the bits above, rows of 80 bytes) and its MFMA uses a second B operand with weights 1 / 64 -- a
+// descriptor term spans 255 |scale|, often ten times a chunk's range, and 8 bits for it would set the step for everything.
 constexpr int PQ4_CODE_BYTES = 256 * 64 * 8;
-constexpr int PQ4_DESC_STRIDE = 40;
-constexpr int PQ4_TABLE_BYTES = PQ4_CODE_BYTES + 256 * PQ4_DESC_STRIDE;   // 138 KiB
+template <int NQ> struct Pq4Layout {
+    static constexpr int DESC_ENTRY = NQ == 4 ? 8 : 16;
+    static constexpr int DESC_STRIDE = NQ == 4 ? 40 : 80;
+    static constexpr int TABLE_BYTES = PQ4_CODE_BYTES + 256 * DESC_STRIDE;   // 138 KiB / 148 KiB
+};
+constexpr int PQ4_TABLE_BYTES = Pq4Layout<8>::TABLE_BYTES;   // the larger image: what callers reserve
 constexpr int PQ4_WAVES = 16;
 
 // per (chunk, query): minimum and maximum over the 256 table entries; a query with a NaN / infinite entry is flagged
-__global__ __launch_bounds__(64) void pq4_minmax_kernel(const float* __restrict__ luts /* [4][64 * 256] */, int n_valid,
-                                                       float* __restrict__ lohi /* [4][64][2] */, int* __restrict__ bad /* [4], zeroed */) {
+__global__ __launch_bounds__(64) void pq4_minmax_kernel(const float* __restrict__ luts /* [NQ][64 * 256] */, int n_valid,
+                                                       float* __restrict__ lohi /* [NQ][64][2] */, int* __restrict__ bad /* [NQ], zeroed */) {
     const int c = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
     if (j >= n_valid) return;
     const float4 x = reinterpret_cast<const float4*>(luts + ((size_t)j * 64 + c) * 256)[t];
@@ -521,16 +528,20 @@ __global__ __launch_bounds__(64) void pq4_minmax_kernel(const float* __restrict_
     if (t == 0) { lohi[(j * 64 + c) * 2] = lo; lohi[(j * 64 + c) * 2 + 1] = hi; }
 }
 
-// block c (0 .. 63: code chunks, 64 .. 67: descriptor bytes), thread v (code / descriptor value): the four queries' entries of
-// (v, c), one 8-byte store.  Every block works out the four queries' parameters for itself (64-term loops in double, in the same
+// block c (0 .. 63: code chunks, 64 .. 67: descriptor bytes), thread v (code / descriptor value): the NQ queries' entries of
+// (v, c), one 8-byte store.  Every block works out the queries' parameters for itself (64-term loops in double, in the same
 // order as ever: the numbers are those of round 3's single-workgroup kernel); block 0 publishes them.
+// NQ = 4: 12-bit code entries (14-bit descriptor entries), two bytes per query: the value's low 6 bits and the bits above.
+// NQ = 8: 8-bit code entries, one byte per query (delta = the widest chunk range / 255); descriptor entries keep 14 bits (16 bytes).
+template <int NQ>
 __global__ __launch_bounds__(256) void pq4_quant_kernel(const float* __restrict__ luts, const float* __restrict__ scales, int n_valid,
                                                        const float* __restrict__ lohi, const int* __restrict__ bad,
                                                        unsigned long long* __restrict__ table, Pq4Params* __restrict__ params) {
+    constexpr double CODE_MAX = NQ == 4 ? 4095.0 : 255.0, DESC_MAX = 16383.0;
     const int c = blockIdx.x, t = threadIdx.x;
-    __shared__ double s_inv[4];
-    __shared__ float s_lo[4];
-    if (t < 4) {
+    __shared__ double s_inv[NQ];
+    __shared__ float s_lo[NQ];
+    if (t < NQ) {
         const int j = t;
         double inv = 0.0;
         float lo_c = 0.0f;
@@ -544,11 +555,11 @@ __global__ __launch_bounds__(256) void pq4_quant_kernel(const float* __restrict_
                 c_sum += lo;
             }
             int is_bad = bad[j];
-            double delta = range / 4095.0, bias_err = 0.0, bias_abs = 0.0;
+            double delta = range / CODE_MAX, bias_err = 0.0, bias_abs = 0.0;
             if (scales) {
                 for (int d = 0; d < 4; d++) {
                     const double sc = (double)scales[d];
-                    delta = fmax(delta, fabs(sc) * 255.0 / 16383.0);
+                    delta = fmax(delta, fabs(sc) * 255.0 / DESC_MAX);
                     c_sum += fmin(0.0, sc * 255.0);                       // lo of descriptor chunk d
                     bias_err += fabs(sc) * 255.0 * 5.9604644775390625e-8;  // rounding of the f32 product sc * v
                     bias_abs += fabs(sc) * 255.0;
@@ -571,26 +582,37 @@ __global__ __launch_bounds__(256) void pq4_quant_kernel(const float* __restrict_
         if (c == 0) params[j] = P;
     }
     __syncthreads();
-    unsigned long long e8 = 0ull;
+    unsigned long long e8 = 0ull, e8hi = 0ull;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NQ; j++) {
         double q = 0.0;
         if (j < n_valid) {
             if (c < 64) {
                 q = ((double)luts[((size_t)j * 64 + c) * 256 + t] - (double)s_lo[j]) * s_inv[j];
-                q = q < 0.0 ? 0.0 : (q > 4095.0 ? 4095.0 : q);
+                q = q < 0.0 ? 0.0 : (q > CODE_MAX ? CODE_MAX : q);
             } else if (scales) {
                 const double sc = (double)scales[c - 64];
                 q = (sc * (double)t - fmin(0.0, sc * 255.0)) * s_inv[j];
-                q = q < 0.0 ? 0.0 : (q > 16383.0 ? 16383.0 : q);
+                q = q < 0.0 ? 0.0 : (q > DESC_MAX ? DESC_MAX : q);
             }
         }
         const unsigned long long e = (unsigned long long)(uint16_t)__double2int_rn(q);
-        e8 |= (((e & 63ull) | ((e >> 6) << 8)) ^ 0x8080ull) << (16 * j);
+        if constexpr (NQ == 4) {
+            e8 |= (((e & 63ull) | ((e >> 6) << 8)) ^ 0x8080ull) << (16 * j);
+        } else if (c < 64) {
+            e8 |= (e ^ 0x80ull) << (8 * j);
+        } else {
+            e8 |= ((e & 63ull) ^ 0x80ull) << (8 * j);
+            e8hi |= ((e >> 6) ^ 0x80ull) << (8 * j);
+        }
     }
-    const size_t off = c < 64 ? (size_t)(c >> 5) * 65536 + (size_t)t * 256 + (size_t)(c & 31) * 8
-                              : (size_t)PQ4_CODE_BYTES + (size_t)t * PQ4_DESC_STRIDE + (size_t)(c - 64) * 8;
-    table[off / 8] = e8;
+    if (c < 64) {
+        table[((size_t)(c >> 5) * 65536 + (size_t)t * 256 + (size_t)(c & 31) * 8) / 8] = e8;
+    } else {
+        const size_t off = (size_t)PQ4_CODE_BYTES + (size_t)t * Pq4Layout<NQ>::DESC_STRIDE + (size_t)(c - 64) * Pq4Layout<NQ>::DESC_ENTRY;
+        table[off / 8] = e8;
+        if constexpr (NQ == 8) table[off / 8 + 1] = e8hi;
+    }
 }
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -616,14 +638,17 @@ typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 //     replace 2 x 68 packed adds per vector, and nothing is left to combine afterwards.
 //   VALU instructions per 64 vectors: 340 (round 3) -> 344 (first matrix-core form: two-instruction addresses, low/high byte
 //   columns combined by DPP) -> this form; LDS cycles per gather instruction 5.8 -> 2.3.
-template <int NW>
+//   NQ = 8 (round 4): the pass is HBM-bound with every on-chip unit under 55 %, so the same instruction stream serves EIGHT
+//   queries when an entry holds one byte per query (8-bit tables, B = identity): twice the queries per byte of codes read.  The
+//   coarser step (delta x 16) widens the certificate's band; the caller nominates more groups for it (api_pq.hip).
+template <int NW, int NQ>
 __global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const uint4* __restrict__ table, const uint8_t* __restrict__ codes, size_t n,
                                                              const uint8_t* __restrict__ desc, uint32_t* __restrict__ out, size_t n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     require_lds_base_zero(smem);
     {
         uint4* s_tab = reinterpret_cast<uint4*>(smem);
-        for (int e = threadIdx.x; e < PQ4_TABLE_BYTES / 16; e += blockDim.x) s_tab[e] = table[e];
+        for (int e = threadIdx.x; e < Pq4Layout<NQ>::TABLE_BYTES / 16; e += blockDim.x) s_tab[e] = table[e];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -634,18 +659,35 @@ __global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const uint4* __res
     uint32_t choff[16];
 #pragma unroll
     for (int s = 0; s < 16; s++) choff[s] = (uint32_t)(((g >> 1) << 16) | (128 * (g & 1) + 8 * ((s + v) & 15)));
-    // B[k][col]: k % 8 == 2 col -> 1, == 2 col + 1 -> 64 (col < 4); lane (col = v, k block g) holds k = 16g .. 16g+15
+    // B[k][col], lane (col = v, k block g) holds k = 16g .. 16g+15.  NQ = 4: k % 8 == 2 col -> 1, == 2 col + 1 -> 64 (col < 4);
+    // NQ = 8: k % 8 == col -> 1 (col < 8)
     v4i32 bop = {0, 0, 0, 0};
-    if (v < 4) {
-        const int w = 0x4001 << (16 * (v & 1));
-        if (v < 2) { bop.x = w; bop.z = w; } else { bop.y = w; bop.w = w; }
+    if constexpr (NQ == 4) {
+        if (v < 4) {
+            const int w = 0x4001 << (16 * (v & 1));
+            if (v < 2) { bop.x = w; bop.z = w; } else { bop.y = w; bop.w = w; }
+        }
+    } else {
+        if (v < 8) {
+            const int w = 1 << (8 * (v & 3));
+            if (v < 4) { bop.x = w; bop.z = w; } else { bop.y = w; bop.w = w; }
+        }
     }
     // this lane's 16 bytes inside a 16-vector block of code rows (1 KiB): the wave's dwordx4 loads cover the block contiguously
     const uint32_t roff = (uint32_t)(v * 64 + 16 * g);
     const bool a1 = (a & 1) != 0, a2 = (a & 2) != 0;
-    const uint32_t doff = (uint32_t)(PQ4_CODE_BYTES + 8 * g);   // descriptor entry of byte g: + value * 40
+    const uint32_t doff = (uint32_t)(PQ4_CODE_BYTES + Pq4Layout<NQ>::DESC_ENTRY * g);   // descriptor entry of byte g: + value * DESC_STRIDE
+    // B operand of the descriptor MFMA when an entry is 16 bytes (NQ = 8): k % 16 == col -> 1 (low 6 bits), == 8 + col -> 64
+    v4i32 bop_d = bop;
+    if constexpr (NQ == 8) {
+        bop_d = v4i32{0, 0, 0, 0};
+        if (v < 8) {
+            const int w1 = 1 << (8 * (v & 3)), w64 = 64 << (8 * (v & 3));
+            if (v < 4) { bop_d.x = w1; bop_d.z = w64; } else { bop_d.y = w1; bop_d.w = w64; }
+        }
+    }
     const int n_entries = desc ? 68 : 64;
-    const int bias = 128 * 65 * n_entries;
+    const int bias = NQ == 4 ? 128 * 65 * n_entries : 128 * 64 + (desc ? 4 * 128 * 65 : 0);
     const size_t stride = (size_t)gridDim.x * NW;
     size_t grp = (size_t)blockIdx.x * NW + wave;
     typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
@@ -705,9 +747,14 @@ __global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const uint4* __res
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const uint32_t dv = (dw[2 * pr + u] >> (8 * g)) & 0xffu;
-                    const u32x2v e0 = *lds_at<u32x2v>(dv * (uint32_t)PQ4_DESC_STRIDE + doff);
-                    const v4i32 av = {(int)e0.x, (int)e0.y, 0, 0};
-                    acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bop, acc[u], 0, 0, 0);
+                    if constexpr (NQ == 4) {
+                        const u32x2v e0 = *lds_at<u32x2v>(dv * (uint32_t)Pq4Layout<NQ>::DESC_STRIDE + doff);
+                        const v4i32 av = {(int)e0.x, (int)e0.y, 0, 0};
+                        acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bop, acc[u], 0, 0, 0);
+                    } else {
+                        const v4i32 av = *lds_at<v4i32>(dv * (uint32_t)Pq4Layout<NQ>::DESC_STRIDE + doff);
+                        acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bop_d, acc[u], 0, 0, 0);
+                    }
                 }
             }
             // acc[u][i] = column v of row 4g + i of block 2 pr + u: in lanes v = q < 4 query q's sum minus `bias`
@@ -726,16 +773,17 @@ __global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const uint4* __res
 #pragma unroll
         for (int j = 2; j < 16; j += 2) best = max(best, max(rows[j], rows[j + 1]));     // v_max3_i32
         // lanes (v = q, g = 0 .. 3) hold the maxima of their rows: the group's maximum per query by readlane
-        uint32_t m[4];
+        uint32_t m[NQ];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NQ; q++) {
             const int m0 = __builtin_amdgcn_readlane(best, q), m1 = __builtin_amdgcn_readlane(best, 16 + q);
             const int m2 = __builtin_amdgcn_readlane(best, 32 + q), m3 = __builtin_amdgcn_readlane(best, 48 + q);
             const int mm = max(max(m0, m1), max(m2, m3));
             m[q] = (uint32_t)(mm + bias);
         }
         if (lane == 0) {
-            out[grp] = m[0]; out[n_groups + grp] = m[1]; out[2 * n_groups + grp] = m[2]; out[3 * n_groups + grp] = m[3];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) out[(size_t)q * n_groups + grp] = m[q];
         }
     }
 }
@@ -902,28 +950,41 @@ int launch_pq_scan_gmax2(const float* lut0, const float* lut1, const uint8_t* co
 }
 
 // ---- four queries per pass (integer nomination under a certificate; header above pq4_table_kernel) ----
-size_t pq4_table_bytes() { return PQ4_TABLE_BYTES + 4 * 64 * 2 * 4 + 64; }   // LDS image + the table build's scratch
-int launch_pq4_table(const float* luts4, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream) {
-    // scratch behind the table image: [4][64][2] f32 minima / maxima, [4] i32 flags (pq4_table_bytes() reserves it)
+size_t pq4_table_bytes() { return PQ4_TABLE_BYTES + 8 * 64 * 2 * 4 + 64; }   // LDS image + the table build's scratch
+// nq = 4 (12-bit tables) or 8 (8-bit tables): luts [nq][64 * 256], params [nq]
+int launch_pq4_table(const float* luts, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream, int nq) {
+    if (nq != 4 && nq != 8) return fail("pq table: 4 or 8 queries per pass");
+    // scratch behind the table image: [8][64][2] f32 minima / maxima, [8] i32 flags (pq4_table_bytes() reserves it)
     char* tail = reinterpret_cast<char*>(table) + PQ4_TABLE_BYTES;
     float* lohi = reinterpret_cast<float*>(tail);
-    int* bad = reinterpret_cast<int*>(tail + 4 * 64 * 2 * 4);
-    MSE_HIP_TRY(hipMemsetAsync(bad, 0, 16, stream));
-    hipLaunchKernelGGL(pq4_minmax_kernel, dim3(64, 4), dim3(64), 0, stream, luts4, n_valid, lohi, bad);
-    hipLaunchKernelGGL(pq4_quant_kernel, dim3(PQ4_CHUNKS), dim3(256), 0, stream, luts4, scales, n_valid, lohi, bad,
-                       reinterpret_cast<unsigned long long*>(table), params);
+    int* bad = reinterpret_cast<int*>(tail + 8 * 64 * 2 * 4);
+    MSE_HIP_TRY(hipMemsetAsync(bad, 0, 32, stream));
+    hipLaunchKernelGGL(pq4_minmax_kernel, dim3(64, nq), dim3(64), 0, stream, luts, n_valid, lohi, bad);
+    if (nq == 4)
+        hipLaunchKernelGGL(pq4_quant_kernel<4>, dim3(PQ4_CHUNKS), dim3(256), 0, stream, luts, scales, n_valid, lohi, bad,
+                           reinterpret_cast<unsigned long long*>(table), params);
+    else
+        hipLaunchKernelGGL(pq4_quant_kernel<8>, dim3(PQ4_CHUNKS), dim3(256), 0, stream, luts, scales, n_valid, lohi, bad,
+                           reinterpret_cast<unsigned long long*>(table), params);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
-int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax4, int n_cu,
-                         hipStream_t stream) {
+int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax, int n_cu,
+                         hipStream_t stream, int nq) {
     if (n == 0) return 0;
+    if (nq != 4 && nq != 8) return fail("pq scan: 4 or 8 queries per pass");
     const size_t groups = (n + 63) / 64;
     const size_t cus = scan_cus(n_cu);
-    MSE_DYN_LDS(pq_scan64x4_kernel<PQ4_WAVES>, PQ4_TABLE_BYTES);
     const unsigned blocks = (unsigned)std::min<size_t>((groups + PQ4_WAVES - 1) / PQ4_WAVES, cus);
-    hipLaunchKernelGGL(pq_scan64x4_kernel<PQ4_WAVES>, dim3(blocks), dim3(PQ4_WAVES * 64), PQ4_TABLE_BYTES, stream,
-                       reinterpret_cast<const uint4*>(table), codes, n, desc, gmax4, groups);
+    if (nq == 4) {
+        MSE_DYN_LDS((pq_scan64x4_kernel<PQ4_WAVES, 4>), Pq4Layout<4>::TABLE_BYTES);
+        hipLaunchKernelGGL((pq_scan64x4_kernel<PQ4_WAVES, 4>), dim3(blocks), dim3(PQ4_WAVES * 64), Pq4Layout<4>::TABLE_BYTES, stream,
+                           reinterpret_cast<const uint4*>(table), codes, n, desc, gmax, groups);
+    } else {
+        MSE_DYN_LDS((pq_scan64x4_kernel<PQ4_WAVES, 8>), Pq4Layout<8>::TABLE_BYTES);
+        hipLaunchKernelGGL((pq_scan64x4_kernel<PQ4_WAVES, 8>), dim3(blocks), dim3(PQ4_WAVES * 64), Pq4Layout<8>::TABLE_BYTES, stream,
+                           reinterpret_cast<const uint4*>(table), codes, n, desc, gmax, groups);
+    }
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -94,6 +94,7 @@ struct mse_pq {
     mse_searcher* scratch = nullptr;  // stream + scratch for scan calls that bring no searcher (guarded by mu; made on first use)
     mse_searcher* lane2 = nullptr;    // second stream of the batched scan; bound to the base of the call that made it
     mse::DevBuf t2, lut2, qf2;        // its transformed query, table and f16 query
+    bool avoid8 = false;              // eight-per-pass (8-bit tables) gave too many uncertified queries on this data: stay with four per pass
     uint32_t last_uncertified = 0;    // four-query scan: queries of the last batch whose certificate failed (re-run through the exact scan)
     int device = 0;                   // HIP ordinal the quantiser was loaded on
     std::mutex co_mu;                 // guards the creation of `co`
@@ -124,4 +125,7 @@ struct mse_graph {
     uint32_t* deg = nullptr;   // device [n]
     uint8_t* has_url = nullptr;  // device [n] or null (= all)
     size_t n = 0, max_deg = 0;
+    // meeting point of the ONE-query calls of mse_disk_search_batch(_f32) from many threads (beam_search.hip), made on first use
+    mutable std::mutex co_mu;
+    mutable mse::Coalescer* co = nullptr;
 };

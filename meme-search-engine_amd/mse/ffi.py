@@ -115,7 +115,7 @@ SIGNATURES = {
     "mse_pq_scan_topk_batch": (C.c_int, [vp, vp, vp, f32p, sz, f32p, sz, sz, i64p, u32p]),
     "mse_pq_last_uncertified": (C.c_uint32, [vp]),
     "mse_debug_pq_group_max": (C.c_int, [vp, vp, f32p, f32p, f32p, i64p, i64p]),
-    "mse_debug_pq4_group_max": (C.c_int, [vp, vp, f32p, f32p, C.c_int, u32p, C.POINTER(C.c_double)]),
+    "mse_debug_pq4_group_max": (C.c_int, [vp, vp, f32p, f32p, C.c_int, C.c_int, u32p, C.POINTER(C.c_double)]),
     "mse_descriptor_product": (C.c_int64, [f32p, sz, u8p, C.c_uint32]),
     "mse_nb_new": (vp, [sz]),
     "mse_nb_free": (None, [vp]),

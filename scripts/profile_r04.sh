@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round-4 profiles -> gpurun_out/r04/ (summaries are copied into profiles/ by hand):
+#   bench_kernel_stats.txt   rocprofv3 --kernel-trace --stats of the bench command's scan legs (1e8 rows)
+#   scan_variants.txt        128 / 192 / 256 queries per pass with clock and power beside them
+#   pq_kernel_stats.txt      kernel stats of the PQ flat-scan bench at 1e8 codes
+#   pq_pmc.txt, pq_traffic   PMC passes of the PQ scan (2e7 codes: unit utilisation; 1e8 codes: FETCH_SIZE / WRITE_SIZE)
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r04
+rm -rf $OUT; mkdir -p $OUT
+stats() {  # $1 = dir with a *kernel_stats.csv, $2 = output text
+python - $1 <<'PY' > $2
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+print("  calls    total_ms      avg_us       %  kernel")
+for r in rows[:22]:
+    print("%7s %11.3f %11.3f %7s  %s" % (r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"], r["Name"][:160]))
+PY
+}
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o b -- python $R/bench.py --steps 12 --warmup 2 --no-siglip --no-pq --no-graph --no-graph-scale --no-cpu-baseline --no-callers --no-shard-point > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+stats $OUT/bench $OUT/bench_kernel_stats.txt; rm -rf $OUT/bench
+timeout 600 python $R/scripts/scan_pass_probe.py 1e8 4 > $OUT/scan_variants.txt 2> $OUT/scan_variants.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pq -o pq -- python $R/scripts/pq_scan_bench.py 1e8 > $OUT/pq_bench.log 2>&1
+grep "^{" $OUT/pq_bench.log | tail -1 > $OUT/pq_bench_line.json
+stats $OUT/pq $OUT/pq_kernel_stats.txt; rm -rf $OUT/pq
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/scripts/pq_scan_bench.py 1e8 > $OUT/pmc_$c.log 2>&1
+done
+python - $OUT <<'PY' > $OUT/pq_traffic.json
+import csv, glob, json, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(sys.argv[1] + "/pmc_" + c + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "pq_scan64" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                agg["x4" if "x4" in r["Kernel_Name"] else "x1"][c].append(float(r["Counter_Value"]))
+out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python scripts/pq_scan_bench.py 1e8`; averages per dispatch.  FETCH_SIZE is KiB and reports half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE is uncalibrated (KiB * 1024)."}
+for k, name in (("x4", "pq_scan64x4"), ("x1", "pq_scan64")):
+    if agg[k]["FETCH_SIZE"]:
+        f = agg[k]["FETCH_SIZE"]; w = agg[k]["WRITE_SIZE"] or [0.0]
+        out[name] = {"vectors": 100000000, "algorithmic_bytes_per_launch": 6800000000, "dispatches": len(f),
+                     "hbm_read_bytes_per_launch": sum(f) / len(f) * 2048, "hbm_write_bytes_per_launch": sum(w) / len(w) * 1024}
+print(json.dumps(out, indent=1))
+PY
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+bash $R/scripts/pmc_pq_r04.sh > $OUT/pq_pmc.txt 2>&1; rm -rf $R/gpurun_out/pmc_pq_r04
+ls -la $OUT

@@ -224,3 +224,51 @@ def test_pq_scan_one_query_per_thread_is_batched_and_unchanged(gpu, mse, orc):
         exact = orc.score_rows(base, cand, orc.f16_bits(q[i])) + np.array([orc.descriptor_product(sc_i, desc, int(c)) for c in cand])
         order = np.lexsort((cand, -exact))[:k]
         assert np.array_equal(outs[i][1], cand[order]) and np.array_equal(outs[i][0], exact[order])
+
+
+def test_beam_search_one_query_per_thread_is_one_launch_and_unchanged(gpu, mse, orc):
+    """The reference's request path: every HTTP request runs ONE greedy_search on its own task (src/query_disk_index.rs:436-540,
+    711-736).  32 threads, each with its own searcher, call the batched device search with a single query -- f32 queries (tables
+    made on the device) with per-request descriptor scales, and f16 queries with host tables; two different search lists.  The
+    calls meet in the graph's coalescer; every caller gets exactly what the same call returns when made alone, which is the
+    oracle's greedy_search."""
+    from test_gpu_pq_index_graph import clustered_rows, knn_graph, train_pq
+    rng = np.random.default_rng(21)
+    n, deg, T = 3000, 14, 32
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    cents, Tm = train_pq(orc, x[:2000], iters=2)
+    opq, gpq = orc.PQ(cents, Tm, 18, D), mse.ProductQuantizer(cents, Tm, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    has_url = (rng.random(n) > 0.1).astype(np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    vl = mse.VectorList.from_f16s(base, D)
+    searchers = [mse.Searcher(vl) for _ in range(T)]
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs), has_url)
+    qs = clustered_rows(orc, T, n_centres=32, seed=201)
+    qh = orc.f16_bits(qs)
+    starts = rng.integers(0, n, size=T).astype(np.uint32)
+    scales = (rng.standard_normal((T, 4)) / 512).astype(np.float32)
+
+    def call(i):
+        L = 48 if i % 2 else 64
+        if i % 4 < 2:     # f32 query in, per-request scales
+            return mse.disk_search_batch(searchers[i], gpq, gcodes, dgraph, starts[i:i + 1], qs[i:i + 1].astype(np.float32), None,
+                                         scales[i:i + 1], False, 4, search_list=L, visited_cap=n)[0]
+        lut = opq.preprocess_query(qs[i])
+        return mse.disk_search_batch(searchers[i], gpq, gcodes, dgraph, starts[i:i + 1], qh[i:i + 1], lut[None], None, False, 2,
+                                     search_list=L, visited_cap=n)[0]
+
+    alone = [call(i) for i in range(T)]
+    for rnd in range(2):
+        outs = run_threads(T, call)
+        for i in range(T):
+            for a, b in zip(outs[i], alone[i]):
+                assert np.array_equal(a, b), (rnd, i)
+    i = 2                                                        # f16 + host table: the oracle's search
+    obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, desc, int(starts[i]), qh[i], opq.preprocess_query(qs[i]), None,
+                                                          False, 2, 64, has_url)
+    bi, bs, vi, vs, cm, pc = alone[i]
+    assert (cm, pc) == (ocm, opc) and np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores) and np.array_equal(vi, ovids)

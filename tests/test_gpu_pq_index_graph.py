@@ -256,6 +256,25 @@ def test_pq_four_queries_per_pass_is_certified_and_exact(gpu, mse, orc):
     for j in range(4):
         ws, wi = orc.topk_from_scores(opq.asymmetric_dot_product(opq.preprocess_query(qs[j]), tied), k)
         assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
+    # EIGHT per pass (8-bit tables) on the spread-out codes: certified and exact, like the first batch above (9 = 8 + 1 queries);
+    # on the tied codes all eight are repeated through the exact scan -- answers still the oracle's -- and the handle then stays
+    # with four per pass (12-bit tables), which a following batch of eight shows by being repeated as 4 + 4
+    q8 = (rng.standard_normal((8, D)) / np.sqrt(D)).astype(np.float32)
+    gcodes = mse.Codes(codes, desc)
+    bs, bi = gpq.scan_topk_batch(gcodes, q8, r, k, None, scales)
+    assert gpq.last_uncertified == 0
+    for j in range(8):
+        ws, wi = orc.topk_from_scores(opq.adc_desc(opq.preprocess_query(q8[j]), codes, desc, scales), k)
+        assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
+    bs, bi = gpq.scan_topk_batch(gt, q8, r, k)
+    assert gpq.last_uncertified == 8
+    for j in range(8):
+        ws, wi = orc.topk_from_scores(opq.asymmetric_dot_product(opq.preprocess_query(q8[j]), tied), k)
+        assert np.array_equal(bi[j], wi) and np.array_equal(bs[j], ws), j
+    bs2, bi2 = gpq.scan_topk_batch(gcodes, q8, r, k, None, scales)       # four per pass now: same answers
+    assert gpq.last_uncertified == 0
+    bs, bi = gpq.scan_topk_batch(gcodes, q8[:4], r, k, None, scales)
+    assert np.array_equal(bs2[:4], bs) and np.array_equal(bi2[:4], bi)
 
 
 def test_pq_scan_full_size_1e8(gpu, mse, orc):
@@ -762,12 +781,13 @@ def test_index_directory_is_the_front_door_of_the_beam_search(gpu, mse, orc, tmp
         assert all(urls[int(v)] for v in vi)                                             # dead nodes are traversed, never returned
 
 
-@pytest.mark.parametrize("n,n_valid,with_desc", [(64 * 37 + 5, 4, True), (1000, 3, False), (16, 1, True), (64 * 300, 4, True)])
-def test_pq4_matrix_core_scan_equals_integer_sums(gpu, mse, orc, n, n_valid, with_desc):
-    """The four-queries-per-pass nomination scan (pq_scan64x4_kernel: conflict-free rotated gathers, sums on the matrix cores)
-    against plain integer arithmetic: the 12-bit tables are rebuilt on the host from the kernel's own formula
-    (e = rint((lut - lo_c) / delta), descriptor chunks rint((sc v - min(0, 255 sc)) / delta)) and every group maximum must equal
-    max over the group's vectors of sum_c e[c][code_c] (+ descriptor entries)."""
+@pytest.mark.parametrize("n,n_valid,with_desc,per_pass", [(64 * 37 + 5, 4, True, 4), (1000, 3, False, 4), (16, 1, True, 4), (64 * 300, 4, True, 4),
+                                                          (64 * 41 + 9, 8, True, 8), (3000, 5, False, 8), (64 * 300, 8, True, 8)])
+def test_pq4_matrix_core_scan_equals_integer_sums(gpu, mse, orc, n, n_valid, with_desc, per_pass):
+    """The nomination scan (pq_scan64x4_kernel: conflict-free rotated gathers, sums on the matrix cores; four queries per pass with
+    12-bit tables or eight with 8-bit tables) against plain integer arithmetic: the tables are rebuilt on the host from the kernel's
+    own formula (e = rint((lut - lo_c) / delta), descriptor chunks rint((sc v - min(0, 255 sc)) / delta)) and every group maximum
+    must equal max over the group's vectors of sum_c e[c][code_c] (+ descriptor entries)."""
     import ctypes as C
     from mse import ffi
     rng = np.random.default_rng(n + n_valid)
@@ -777,42 +797,52 @@ def test_pq4_matrix_core_scan_equals_integer_sums(gpu, mse, orc, n, n_valid, wit
     codes[: min(n, 7)] = 255                                   # extreme codes in the first rows
     desc = rng.integers(0, 256, (n, 4), dtype=np.uint8)
     gc = mse.Codes(codes, desc)
-    luts = (rng.standard_normal((4, 64, 256)) * rng.uniform(0.01, 0.3, (4, 64, 1))).astype(np.float32)
+    luts = (rng.standard_normal((per_pass, 64, 256)) * rng.uniform(0.01, 0.3, (per_pass, 64, 1))).astype(np.float32)
     luts[1, 3] = 0.25                                          # a chunk with zero range
     scales = np.array([0.5, 0, -0.25, 0.125], np.float32) / np.float32(512) if with_desc else None
+    code_max, desc_max = (4095.0, 16383.0) if per_pass == 4 else (255.0, 16383.0)
     ng = (n + 63) // 64
-    out = np.zeros((4, ng), np.uint32)
-    params = np.zeros((4, 4), np.float64)
+    out = np.zeros((per_pass, ng), np.uint32)
+    params = np.zeros((per_pass, 4), np.float64)
     ffi.check(ffi.lib().mse_debug_pq4_group_max(pq._h, gc._h, luts.ctypes.data_as(ffi.f32p),
-                                                scales.ctypes.data_as(ffi.f32p) if with_desc else None, n_valid,
+                                                scales.ctypes.data_as(ffi.f32p) if with_desc else None, n_valid, per_pass,
                                                 out.ctypes.data_as(ffi.u32p), params.ctypes.data_as(C.POINTER(C.c_double))))
-    for j in range(4):
+    for j in range(per_pass):
         if j >= n_valid:
             assert params[j, 3] == 0 and np.all(out[j] == 0)
             continue
         lut = luts[j].astype(np.float64)
         lo, hi = lut.min(axis=1), lut.max(axis=1)
-        delta = (hi - lo).max() / 4095.0
+        delta = (hi - lo).max() / code_max
         c_sum = 0.0
         for c in range(64):
             c_sum += lo[c]
         if with_desc:
             for sc in scales.astype(np.float64):
-                delta = max(delta, abs(sc) * 255.0 / 16383.0)
+                delta = max(delta, abs(sc) * 255.0 / desc_max)
                 c_sum += min(0.0, sc * 255.0)
         delta = max(delta, 1e-300)
         assert params[j, 0] == delta and params[j, 1] == c_sum and params[j, 3] == 1
         inv = 1.0 / delta
-        e = np.clip(np.rint((lut - lo[:, None]) * inv), 0, 4095).astype(np.int64)            # [64][256]
+        e = np.clip(np.rint((lut - lo[:, None]) * inv), 0, code_max).astype(np.int64)         # [64][256]
         sums = e[np.arange(64)[None, :], codes.astype(np.int64)].sum(axis=1)                  # [n]
         if with_desc:
             for dd, sc in enumerate(scales.astype(np.float64)):
-                ed = np.clip(np.rint((sc * np.arange(256.0) - min(0.0, sc * 255.0)) * inv), 0, 16383).astype(np.int64)
+                ed = np.clip(np.rint((sc * np.arange(256.0) - min(0.0, sc * 255.0)) * inv), 0, desc_max).astype(np.int64)
                 sums = sums + ed[desc[:, dd].astype(np.int64)]
         pad = np.zeros(ng * 64, np.int64)
         pad[:n] = sums
         want = pad.reshape(ng, 64).max(axis=1)
         assert np.array_equal(out[j].astype(np.int64), want), (j, np.flatnonzero(out[j] != want)[:5])
+        # the certificate's premise: the reference-order score of every vector lies within eps of delta * S + C
+        if j == 0 and n <= 4000:
+            adc = np.zeros(n, np.float32)
+            for c in range(64):
+                adc = (adc + luts[j][c][codes[:, c]]).astype(np.float32)
+            x = adc.astype(np.float64)
+            if with_desc:
+                x = x + (scales.astype(np.float64)[None, :] * desc.astype(np.float64)).sum(axis=1)
+            assert np.all(np.abs(x - (delta * sums + c_sum)) <= params[j, 2] * (1 + 1e-6) + 4e-9 * 6)
 
 
 def test_codes_quantized_from_resident_rows_equal_quantize_batch(gpu, mse, orc):

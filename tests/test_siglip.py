@@ -190,6 +190,26 @@ def test_batch_256_rows_equal_small_batch_rows(gpu, mse, ref):
 
 
 @pytest.mark.gpu
+def test_config1_full_shape_depth_27_batch_256_rows_match_the_oracle(gpu, mse, ref):
+    """BASELINE configs[1] at its FULL shape -- SO400M/14-384, all 27 blocks, batch 256 -- checked directly: four rows of the
+    batch-256 forward (first, both sides of the sub-batch seam, last) against the fp32 oracle on the same four images, within the
+    north star's 1e-3 cosine; and the same rows bit-equal to a forward of just those images (row independence at depth 27)."""
+    from mse import siglip
+    cfg = dict(ref.CONFIG)                                                  # depth 27
+    sd = ref.synthetic_weights(cfg)
+    img = ref.synthetic_images(256, cfg)
+    x16 = img.numpy().astype(np.float16)
+    eng = siglip.SiglipImageEngine.from_state_dict({"visual." + k: v for k, v in sd.items()}, dict(siglip.SO400M_384), max_batch=256)
+    big = eng.encode_image(x16)
+    assert big.shape == (256, 1152) and np.isfinite(big).all()
+    rows = [0, 127, 128, 255]
+    want = ref.encode_image(torch_from(x16[rows]), sd, cfg).numpy()
+    cos = cosine(big[rows], want)
+    assert np.all(cos > 1 - 1e-3), cos
+    assert np.array_equal(eng.encode_image(x16[rows]), big[rows])
+
+
+@pytest.mark.gpu
 def test_engine_with_massive_activation_channels(gpu, mse, ref):
     """Trained ViTs carry a few residual channels hundreds of times larger than the rest ("massive activations"); the seeded
     Gaussian weights of the other tests never do.  Plant them -- biases of +3000 / -800 / +12000 on three channels of the
