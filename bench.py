@@ -550,6 +550,8 @@ def graph_scale_bench(args):
     g.random_fill(1)
     order = np.random.default_rng(3).permutation(n).astype(np.uint32)
     g.build(s, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
+    for _ in range(int(args.graph_passes) - 1):    # generate-index-shard's optional second pass (-s), same factors
+        g.build(s, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
     t_build = time.perf_counter() - t0
     qh = queries.cpu().numpy().view(np.uint16)
     t0 = time.perf_counter()
@@ -566,6 +568,8 @@ def graph_scale_bench(args):
     # exact top-1 over the sample, inside the timed region).  With the medioid alone as entry a one-pass graph over 1e8 clustered
     # rows needs search lists beyond 200 to reach 0.95 (0.924 at L = 200, profiles/r04_graph_index_1e8.json).
     n_entry = int(args.graph_entries)
+    if n_entry < 0:      # auto: about one entry per 1500 rows -- a few per top-level cluster of the synthetic set at any size
+        n_entry = max(4096, n // 1500)
     if n_entry > 0:
         e_idx = np.sort(np.random.default_rng(5).choice(n, min(n_entry, n), replace=False)).astype(np.int64)
         e_rows = rows[torch.from_numpy(e_idx).cuda()].contiguous()
@@ -592,7 +596,7 @@ def graph_scale_bench(args):
         return {"search_list": L, "queries": m, "queries_per_s": m / dt, "recall_at_10": rec, "node_fetches_per_query": float(res["cmps"].mean())}
 
     sweep, chosen = [], None
-    for L in (32, 48, 64, 100, 200, 400):
+    for L in (32, 48, 64, 100, 200, 400, 800):
         pt = run(L, tune, False)
         sweep.append({"search_list": L, "tuning_recall_at_10": pt["recall_at_10"]})
         if pt["recall_at_10"] >= 0.96:
@@ -628,7 +632,7 @@ def graph_scale_bench(args):
             "value": chosen["queries_per_s"] if chosen else None, "unit": "queries/s", "recall_at_10": chosen["recall_at_10"] if chosen else None,
             "search_list": chosen["search_list"] if chosen else None, "beamwidth": 4, "batch": half, "sweep": sweep,
             "operating_point": "search list picked on queries 0..%d (tuning recall >= 0.96), value / recall measured on the held-out queries %d..%d" % (half - 1, half, nq - 1),
-            "build": {"seconds": t_build, "points_per_s": n / t_build, "passes": 1, "r": R, "l": 192, "maxc": 750, "batch": batch},
+            "build": {"seconds": t_build, "points_per_s": n * int(args.graph_passes) / t_build, "passes": int(args.graph_passes), "r": R, "l": 192, "maxc": 750, "batch": batch},
             "exact_scan_same_index_queries_per_s": nq / t_exact,
             "entry_points": (f"{n_entry} sampled base rows; a search starts at the one with the largest dot product with its query (exact top-1, timed); "
                              "the reference: medioid of the closest shard, src/query_disk_index.rs:447-450") if n_entry > 0 else "the medioid",
@@ -845,9 +849,10 @@ def main():
     ap.add_argument("--graph-rows", type=float, default=2e5)
     ap.add_argument("--no-graph-scale", action="store_true", help="skip the 1e7-row graph-index leg (a ~1 minute build)")
     ap.add_argument("--graph-scale-rows", type=float, default=1e7)
-    ap.add_argument("--graph-batch", type=int, default=2048, help="points inserted per batch of the graph-scale build")
-    ap.add_argument("--graph-entries", type=int, default=4096,
-                    help="sampled entry points of the graph-scale search (0: the medioid alone)")
+    ap.add_argument("--graph-passes", type=int, default=1, help="Vamana passes of the graph-scale build (generate-index-shard -s = 2)")
+    ap.add_argument("--graph-batch", type=int, default=4096, help="points inserted per batch of the graph-scale build")
+    ap.add_argument("--graph-entries", type=int, default=-1,
+                    help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
     ap.add_argument("--siglip-batch", type=int, default=256)
     ap.add_argument("--siglip-steps", type=int, default=10)
     args = ap.parse_args()

@@ -147,6 +147,11 @@ mse_searcher* mse_dispatcher_searcher(mse_dispatcher* d);   /* the worker's sear
 /* test hook: the next n_passes passes that carry more than one request fail before they start, so that the
  * repeat-each-request-alone path can be exercised (answers must be unaffected) */
 int mse_debug_dispatcher_fail_shared(mse_dispatcher* d, uint32_t n_passes);
+/* test hook that needs no device (the "not gpu" suite): `threads` host threads x `rounds` one-query requests through the coalescer's
+ * queue with a stand-in pass (payload p -> 2 p + 1; payloads divisible by 97 fail, alone).  stats_out as mse_dispatcher_stats;
+ * *mismatches = requests that got a wrong answer, a wrong status or no error text. */
+int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, uint64_t stats_out[6],
+                                 uint64_t* mismatches);
 
 /* ---- row-sharded index over the GPUs of one node.  The reference has no multi-GPU
  * code; its query server is a thread per core, each with its own Scratch over shared read-only maps
@@ -314,6 +319,10 @@ int mse_disk_greedy_search(mse_searcher* s, mse_pq* pq, const mse_codes* c, cons
  * visited_* [nq][visited_cap] in fetch order, n_visited/cmps/pq_cmps [nq].  starts [nq]; queries [nq][d] f16; luts
  * [nq][64*256]; scales [nq][n_descriptors] or NULL.  Limits: 64 x 256 codec, search_list <= 1024, beamwidth <= 8,
  * max_deg <= 128 (merged indexes carry up to SHARD_SPILL x R neighbours per node, src/dump_processor.rs:282-291). */
+/* Called with nq = 1 from many threads at once (the reference's request path: one greedy_search per HTTP request on its own task,
+ * src/query_disk_index.rs:436-540,711-736), mse_disk_search_batch / _f32 meet in the graph's coalescer: calls that can share a launch
+ * (same vectors, codec, codes, graph, search parameters and kind of inputs) run as ONE batched search, a workgroup per query, and
+ * every caller gets exactly what its call returns when made alone. */
 typedef struct mse_graph mse_graph;
 mse_graph* mse_graph_from_host(const uint32_t* adj, const uint32_t* deg, size_t n, size_t max_deg, const uint8_t* has_url);
 void mse_graph_free(mse_graph* g);

@@ -281,6 +281,42 @@ int mse_dispatcher_stats(mse_dispatcher* D, uint64_t out[6]) {
 
 mse_searcher* mse_dispatcher_searcher(mse_dispatcher* D) { return D ? D->s : nullptr; }
 
+// test hook, no device needed: `threads` host threads x `rounds` one-query requests through a Coalescer whose "pass" answers
+// request payload p with 2 p + 1 and fails (for that request alone) every payload divisible by 97.  *mismatches = requests that
+// got somebody else's answer, a wrong status, or a missing error text.
+int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, uint64_t stats_out[6],
+                                 uint64_t* mismatches) {
+    if (threads <= 0 || rounds <= 0 || !stats_out || !mismatches) return fail("bad argument");
+    Coalescer co(max_queries ? max_queries : 256, max_wait_us ? max_wait_us : 200,
+                 [](std::vector<DispatchReq*>& batch) {
+                     for (DispatchReq* r : batch) {
+                         const uint64_t p = *static_cast<const uint64_t*>(r->queries);
+                         if (p % 97 == 0) { r->rc = -1; r->err = "payload " + std::to_string(p) + " refused"; }
+                         else { *static_cast<uint64_t*>(r->out_a) = 2 * p + 1; r->rc = 0; }
+                     }
+                 },
+                 nullptr);
+    std::atomic<uint64_t> bad{0};
+    std::vector<std::thread> ts;
+    for (int t = 0; t < threads; t++)
+        ts.emplace_back([&, t] {
+            for (int r = 0; r < rounds; r++) {
+                uint64_t p = (uint64_t)t * 1000003ull + (uint64_t)r, out = 0;
+                DispatchReq q;
+                q.queries = &p; q.nq = 1; q.k = 1; q.out_a = &out;
+                const int rc = co.submit(q);
+                if (p % 97 == 0) { if (rc == 0 || std::string(mse_last_error()).find(std::to_string(p)) == std::string::npos) bad++; }
+                else if (rc != 0 || out != 2 * p + 1) bad++;
+            }
+        });
+    for (std::thread& th : ts) th.join();
+    const DispatchStats st = co.stats();
+    stats_out[0] = st.queries; stats_out[1] = st.requests; stats_out[2] = st.passes; stats_out[3] = st.max_pass_queries;
+    stats_out[4] = st.deadline_fires; stats_out[5] = 0;
+    *mismatches = bad.load();
+    return 0;
+}
+
 int mse_debug_dispatcher_fail_shared(mse_dispatcher* D, uint32_t n_passes) {
     if (!D) return fail("null dispatcher");
     D->fail_shared.store(n_passes);

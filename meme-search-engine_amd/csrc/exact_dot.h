@@ -25,8 +25,8 @@ __device__ __forceinline__ void quad_fma8(float (&acc)[8], const uint4& x, const
 
 // all four lanes of the quad must call this together (and be active); every lane returns the f32 sum.
 // row, query: device / LDS pointers to d f16 values (16-byte aligned); d % 32 == 0.
+template <int G = 6>
 __device__ __forceinline__ float quad_fast_dot_f32(const uint16_t* row, const uint16_t* query, int d) {
-    constexpr int G = 6;
     const int part = threadIdx.x & 3;
     const uint4* xp = reinterpret_cast<const uint4*>(row) + part;
     const uint4* qp = reinterpret_cast<const uint4*>(query) + part;

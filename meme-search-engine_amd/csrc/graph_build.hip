@@ -267,6 +267,9 @@ inline size_t prune_lds_bytes(int d) { return (size_t)((d * 2 + 15) & ~15) + GB_
 // medioid, the visited list is kept in HBM and merge_existing_neighbours (:215-221) is appended to it -- the candidate
 // list robust_prune starts from; out_dist = its length.  !BUILD: an outside query; the buffer is the output.
 template <bool BUILD>
+// (Round 4 probe: a shallower row prefetch -- three pieces per lane in flight instead of six -- brings the kernel from 126 to 78-92
+// registers and 10-12 workgroups per CU instead of 8; the build rate at 1e7 rows stayed within +-3 % at batch 4096 / 6144
+// (scripts/graph_occupancy_probe.sh): the build is not limited by the searches in flight.  Kept as it was.)
 __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dq = (a.d * 2 + 15) & ~15;

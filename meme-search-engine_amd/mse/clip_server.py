@@ -268,8 +268,12 @@ class ClipServer:
         msgpack_type = "application/msgpack"
 
         async def embed(request):
-            body = msgpack.loads(await request.read())
-            job = Job(body.get("text"), body.get("images"), asyncio.get_running_loop())
+            data = await request.read()
+            loop = asyncio.get_running_loop()
+            # a 128-image request is 56 MB of msgpack: decoding it on the event loop (as the reference does, :150) holds up every
+            # other connection for tens of milliseconds; large bodies are decoded on the default executor instead
+            body = msgpack.loads(data) if len(data) < (1 << 20) else await loop.run_in_executor(None, msgpack.loads, data)
+            job = Job(body.get("text"), body.get("images"), loop)
             self.submit(job)
             ok, payload = await job.done
             if ok:

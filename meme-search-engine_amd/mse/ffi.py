@@ -99,6 +99,7 @@ SIGNATURES = {
     "mse_dispatcher_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "mse_dispatcher_searcher": (vp, [vp]),
     "mse_debug_dispatcher_fail_shared": (C.c_int, [vp, C.c_uint32]),
+    "mse_debug_coalescer_selftest": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mse_pq_load": (vp, [f32p, sz, f32p, sz, sz]),
     "mse_pq_free": (None, [vp]),
     "mse_pq_apply_transform": (C.c_int, [vp, f32p, sz, f32p]),

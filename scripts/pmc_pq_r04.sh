@@ -16,7 +16,9 @@ for f in glob.glob(sys.argv[1] + "/pass*/**/*counter_collection.csv", recursive=
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "pq_scan64" in k:
-            tag = "x4 (four queries per pass, integer nomination)" if "x4" in k else "x2 (two queries per pass)" if "x2" in k else "x1 (one query per pass)"
+            tag = ("x8 (eight queries per pass, 8-bit tables, matrix-core sums)" if "x4_kernel<16, 8>" in k else
+                   "x4 (four queries per pass, 12-bit tables, matrix-core sums)" if "x4" in k else
+                   "x2 (two queries per pass)" if "x2" in k else "x1 (one query per pass)")
             agg[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for tag in sorted(agg):
     print("#", tag)

@@ -34,9 +34,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(sys.argv[1] + "/pmc_" + c + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "pq_scan64" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                agg["x4" if "x4" in r["Kernel_Name"] else "x1"][c].append(float(r["Counter_Value"]))
+                k = r["Kernel_Name"]
+                agg["x8" if "x4_kernel<16, 8>" in k else "x4" if "x4" in k else "x1"][c].append(float(r["Counter_Value"]))
 out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python scripts/pq_scan_bench.py 1e8`; averages per dispatch.  FETCH_SIZE is KiB and reports half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE is uncalibrated (KiB * 1024)."}
-for k, name in (("x4", "pq_scan64x4"), ("x1", "pq_scan64")):
+for k, name in (("x8", "pq_scan64x4"), ("x4", "pq_scan64x4_four_per_pass"), ("x1", "pq_scan64")):
     if agg[k]["FETCH_SIZE"]:
         f = agg[k]["FETCH_SIZE"]; w = agg[k]["WRITE_SIZE"] or [0.0]
         out[name] = {"vectors": 100000000, "algorithmic_bytes_per_launch": 6800000000, "dispatches": len(f),

@@ -217,3 +217,24 @@ def test_product_library_reads_no_developer_knob(mse):
     names = {n for n in names if not n.startswith(("MSE_HIP_TRY", "MSE_DYN_LDS", "MSE_DEV_K", "MSE_ID_", "MSE_API"))}
     assert not names & set(DEV_KNOBS), names & set(DEV_KNOBS)
     assert names <= PRODUCT_HOOKS, names - PRODUCT_HOOKS
+
+
+@pytest.mark.parametrize("threads,rounds,max_queries", [(1, 50, 256), (64, 40, 256), (200, 20, 32), (16, 200, 4)])
+def test_coalescer_queue_hands_every_caller_its_own_answer(mse, threads, rounds, max_queries):
+    """The cross-thread coalescer's queue (csrc/dispatch.hip) without a device: T host threads x R one-query requests through a
+    stand-in pass.  Every caller gets the answer for ITS payload, a failing request fails alone with its own message, nothing
+    deadlocks; a lone caller is never batched with a wait (as many passes as requests), many callers share passes, and no pass
+    carries more than `max_queries`."""
+    import ctypes as C
+    from mse import ffi
+    stats = (C.c_uint64 * 6)()
+    bad = C.c_uint64(12345)
+    ffi.check(ffi.lib().mse_debug_coalescer_selftest(threads, rounds, max_queries, 2000, stats, C.byref(bad)))
+    assert bad.value == 0
+    queries, requests, passes, max_pass = int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
+    assert queries == requests == threads * rounds
+    assert max_pass <= max_queries
+    if threads == 1:
+        assert passes == requests
+    elif threads >= 64:
+        assert passes < requests / 2, (passes, requests)
