@@ -1198,7 +1198,7 @@ def main():
         # inside a timed run); only reported when this run is the profiled configuration
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
             if pm["rows"] == hi - lo and pm["queries_per_launch"] == min(nq, 256):
                 traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
         except Exception:
@@ -1225,7 +1225,7 @@ def main():
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": {256: "scan_mfma2d_kernel<3,16>", 192: "scan_mfma_kernel<3,12>", 128: "scan_mfma_kernel<3,8>"}.get(tile, "scan_mfma") + f" ({nq} queries per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
+                         "traffic": traffic, "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms, "queries_per_launch": min(nq, 256),
                          # the same launch against the matrix cores: 2*rows*1152*queries flops; dense f16 peak 2500 TFLOP/s
                          "mfma_tflops": mfma_tflops, "mfma_frac": (mfma_tflops / 2500.0) if mfma_tflops else None,

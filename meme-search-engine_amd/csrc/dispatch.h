@@ -41,7 +41,6 @@ struct DispatchReq {
     uint32_t flags = 0;
     // queue plumbing
     bool done = false;
-    std::condition_variable cv;
     std::chrono::steady_clock::time_point t_arrive;
 };
 
@@ -71,6 +70,10 @@ class Coalescer {
     std::function<void()> on_start_;
     std::mutex mu_;
     std::condition_variable cv_worker_;
+    // ONE condition variable for all callers, signalled once per pass after the lock is dropped: a variable per request would be
+    // hundreds of futex wake-ups issued under the lock, every woken caller then queueing for that lock (a request record lives on its
+    // caller's stack, so its own variable could not be signalled after the unlock either)
+    std::condition_variable cv_done_;
     std::deque<DispatchReq*> queue_;
     size_t queued_queries_ = 0;
     size_t expect_ = 1;

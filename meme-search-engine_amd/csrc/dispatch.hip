@@ -43,7 +43,7 @@ int Coalescer::submit(DispatchReq& r) {
     queued_queries_ += r.nq;
     // the worker only needs waking when this arrival can change its decision: first in the queue, or the target reached
     if (queue_.size() == 1 || queued_queries_ >= std::min(max_queries_, expect_)) cv_worker_.notify_one();
-    r.cv.wait(lk, [&] { return r.done; });
+    cv_done_.wait(lk, [&] { return r.done; });
     lk.unlock();
     if (r.rc) set_error(r.err.empty() ? std::string("search failed") : r.err);
     return r.rc;
@@ -107,20 +107,21 @@ void Coalescer::loop() {
         const uint32_t grace_us = std::min<uint32_t>(max_wait_us_.load(), 1000);
         grace_until = expect_returners ? std::chrono::steady_clock::now() + std::chrono::microseconds(grace_us)
                                        : std::chrono::steady_clock::time_point::min();
-        for (DispatchReq* r : batch) {
-            r->done = true;
-            r->cv.notify_one();
-        }
+        for (DispatchReq* r : batch) r->done = true;
+        lk.unlock();
+        cv_done_.notify_all();
+        lk.lock();
     }
     // shutting down: nobody may stay blocked
     for (DispatchReq* r : queue_) {
         r->rc = -1;
         r->err = "dispatcher closed while the request was queued";
         r->done = true;
-        r->cv.notify_one();
     }
     queue_.clear();
     queued_queries_ = 0;
+    lk.unlock();
+    cv_done_.notify_all();
 }
 
 }  // namespace mse

@@ -26,24 +26,43 @@ grep "^{" $OUT/pq_bench.log | tail -1 > $OUT/pq_bench_line.json
 stats $OUT/pq $OUT/pq_kernel_stats.txt; rm -rf $OUT/pq
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/scripts/pq_scan_bench.py 1e8 > $OUT/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmcs_$c -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-siglip --no-pq --no-graph --no-graph-scale --no-cpu-baseline --no-callers --no-shard-point > $OUT/pmcs_$c.log 2>&1
 done
-python - $OUT <<'PY' > $OUT/pq_traffic.json
+python - $OUT <<'PY' > $OUT/pmc_traffic.json
 import csv, glob, json, sys, collections
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(sys.argv[1] + "/pmc_" + c + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "pq_scan64" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                k = r["Kernel_Name"]
-                agg["x8" if "x4_kernel<16, 8>" in k else "x4" if "x4" in k else "x1"][c].append(float(r["Counter_Value"]))
-out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `python scripts/pq_scan_bench.py 1e8`; averages per dispatch.  FETCH_SIZE is KiB and reports half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE is uncalibrated (KiB * 1024)."}
+def collect(prefix, match):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in glob.glob(sys.argv[1] + "/" + prefix + c + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == c:
+                    k = match(r["Kernel_Name"])
+                    if k:
+                        agg[k][c].append(float(r["Counter_Value"]))
+    return agg
+out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; scripts/profile_r04.sh): averages per dispatch.  FETCH_SIZE is KiB and reports half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): bytes = FETCH_SIZE * 1024 * 2 (calibrated in round 1 on scan_exact_kernel, profiles/r01_pmc_scan_1e7.txt); WRITE_SIZE is uncalibrated (KiB * 1024).  Scan legs: `python bench.py --steps 4 --warmup 1` (scan legs only, 1e8 rows); PQ: `python scripts/pq_scan_bench.py 1e8`."}
+pq = collect("pmc_", lambda k: ("x8" if "x4_kernel<16, 8>" in k else "x4" if "x4" in k else "x1") if "pq_scan64" in k else None)
 for k, name in (("x8", "pq_scan64x4"), ("x4", "pq_scan64x4_four_per_pass"), ("x1", "pq_scan64")):
-    if agg[k]["FETCH_SIZE"]:
-        f = agg[k]["FETCH_SIZE"]; w = agg[k]["WRITE_SIZE"] or [0.0]
+    if pq[k]["FETCH_SIZE"]:
+        f = pq[k]["FETCH_SIZE"]; w = pq[k]["WRITE_SIZE"] or [0.0]
         out[name] = {"vectors": 100000000, "algorithmic_bytes_per_launch": 6800000000, "dispatches": len(f),
                      "hbm_read_bytes_per_launch": sum(f) / len(f) * 2048, "hbm_write_bytes_per_launch": sum(w) / len(w) * 1024}
+sc = collect("pmcs_", lambda k: "256" if "scan_mfma2d_kernel" in k else "128" if "scan_mfma_kernel<3, 8" in k else "192" if "scan_mfma_kernel<3, 12" in k else None)
+out["rows"] = 100000000
+out["algorithmic_bytes_per_launch"] = 230400000000
+out["per_pass"] = {}
+for k in ("256", "192", "128"):
+    if sc[k]["FETCH_SIZE"]:
+        # only the full-size launches (the pick loop and the timed loop run at 1e8 rows)
+        f = [v for v in sc[k]["FETCH_SIZE"] if v * 2048 > 1e11]; w = [v for v in sc[k]["WRITE_SIZE"] if v > 0] or [0.0]
+        if f:
+            out["per_pass"][k] = {"dispatches": len(f), "hbm_read_bytes_per_launch": sum(f) / len(f) * 2048, "hbm_write_bytes_per_launch": sum(w) / len(w) * 1024}
+if "256" in out["per_pass"]:
+    out["queries_per_launch"] = 256
+    out["hbm_read_bytes_per_launch"] = out["per_pass"]["256"]["hbm_read_bytes_per_launch"]
+    out["hbm_write_bytes_per_launch"] = out["per_pass"]["256"]["hbm_write_bytes_per_launch"]
 print(json.dumps(out, indent=1))
 PY
-rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcs_FETCH_SIZE $OUT/pmcs_WRITE_SIZE
 bash $R/scripts/pmc_pq_r04.sh > $OUT/pq_pmc.txt 2>&1; rm -rf $R/gpurun_out/pmc_pq_r04
 ls -la $OUT
