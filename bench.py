@@ -208,7 +208,7 @@ def cpu_baseline(n_rows, k, min_seconds=5.0):
     }
 
 
-def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rounds=8):
+def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rounds=12):
     """The reference's call shape at the metric's size: T host threads, ONE query per call, host pointers in and out
     (src/main.rs:896-934,1043-1049; src/query_disk_index.rs:711-736), through the cross-thread coalescer of the C ABI
     (mse_dispatcher, csrc/dispatch.hip).  The callers are native threads (scripts/native/mse_callers.c -- what a Rust host's

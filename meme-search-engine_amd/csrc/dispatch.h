@@ -11,7 +11,7 @@
 // queued up during the last pass plus the ones that pass answered (closed-loop callers are back within microseconds) -- or
 // `max_queries`, or when the oldest waiting request is `max_wait` old and the callers just answered had a grace period
 // (<= 1 ms) to return, whichever comes first.  A single caller therefore never waits (target 1), T closed-loop callers settle
-// at T queries per pass after two passes, and callers that do not come back cost one grace period, then the guess backs off.
+// at T queries per pass after two passes, and callers that do not come back cost a grace period on every other pass at most.
 #pragma once
 #include "common.h"
 #include <atomic>

@@ -59,7 +59,7 @@ void Coalescer::loop() {
     std::vector<DispatchReq*> batch;
     std::unique_lock<std::mutex> lk(mu_);
     auto grace_until = std::chrono::steady_clock::time_point::min();
-    unsigned miss_streak = 0, since_miss = 0;
+    bool expected_returners = false;
     for (;;) {
         cv_worker_.wait(lk, [&] { return stop_ || !queue_.empty(); });
         if (stop_) break;
@@ -92,17 +92,10 @@ void Coalescer::loop() {
         if (by_deadline) st_.deadline_fires++;
         // Next target: what queued up during this pass PLUS the callers answered now -- closed-loop callers (a thread per core,
         // one request at a time) are back within microseconds, and without counting them T callers settle into two groups of T/2
-        // taking turns.  Callers that do not come back (open-loop arrivals) cost one grace period, after which the guess is
-        // retried only every 2, 4, ... 64 passes.
-        bool expect_returners = true;
-        if (by_deadline) {
-            miss_streak++;
-            since_miss = 0;
-            expect_returners = false;
-        } else if (miss_streak) {
-            if (++since_miss >= (1u << std::min(miss_streak, 6u))) since_miss = 0; else expect_returners = false;
-            if (expect_returners && queued_queries_ >= nq) miss_streak = 0;
-        }
+        // taking turns.  If the gather that just ended had counted on returners and ran into its deadline instead (they did not
+        // come back: open-loop arrivals, or callers that left), the next one does not count on them; the one after tries again.
+        const bool expect_returners = !(by_deadline && expected_returners);
+        expected_returners = expect_returners;
         expect_ = std::max<size_t>(1, queued_queries_ + (expect_returners ? nq : 0));
         const uint32_t grace_us = std::min<uint32_t>(max_wait_us_.load(), 1000);
         grace_until = expect_returners ? std::chrono::steady_clock::now() + std::chrono::microseconds(grace_us)
