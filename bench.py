@@ -224,8 +224,8 @@ def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rou
         subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
     H = C.CDLL(so)
     H.mse_callers_run.restype = C.c_double
-    H.mse_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.POINTER(C.c_int)]
+    H.mse_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]
     fn = C.cast(ffi.lib().mse_dispatcher_topk_f16, C.c_void_p)
     n_max = max(thread_counts) * rounds
     qdev = mse.VectorList.generate(SEED_QUERY, 1 << 20, n_max, D)       # fresh queries, copied to the HOST: callers hand over host pointers
@@ -243,9 +243,9 @@ def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rou
         ids = np.empty((n, k), np.uint32)
         lat = np.zeros(n, np.float64)
         failed = C.c_int(0)
-        H.mse_callers_run(fn, disp._h, q.ctypes.data, min(n, 2 * T), D, k, T, sc.ctypes.data, ids.ctypes.data, lat.ctypes.data, C.byref(failed))  # warm: two rounds
+        H.mse_callers_run(fn, disp._h, q.ctypes.data, min(n, 2 * T), D * 2, k, T, sc.ctypes.data, 8, ids.ctypes.data, 4, lat.ctypes.data, C.byref(failed))  # warm: two rounds
         st0 = disp.stats()
-        dt = H.mse_callers_run(fn, disp._h, q.ctypes.data, n, D, k, T, sc.ctypes.data, ids.ctypes.data, lat.ctypes.data, C.byref(failed))
+        dt = H.mse_callers_run(fn, disp._h, q.ctypes.data, n, D * 2, k, T, sc.ctypes.data, 8, ids.ctypes.data, 4, lat.ctypes.data, C.byref(failed))
         st1 = disp.stats()
         ok = bool(dt > 0 and failed.value == 0 and np.array_equal(ids, want_i[:n]) and np.array_equal(sc, want_s[:n]))
         passes = st1["passes"] - st0["passes"]
@@ -261,6 +261,56 @@ def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rou
             "vs_resident_batch_headline": best["vs_resident_batch_headline"], "points": points, "k": k,
             "dispatcher": {"max_queries_per_pass": 256, "passes_started_by_wait_budget": st["deadline_fires"], "requests_repeated_alone": st["retried_alone"]},
             "config": {"workload": f"{len(vecs)} x {D} fp16 rows resident; each call: 1 query of {D} f16 from host memory in, top-{k} (i64 scores, u32 ids) to host memory out"}}
+
+
+def index_callers_bench(k, threads=64, rounds=40, n=100_000):
+    """BASELINE configs[0]'s index -- 1e5 x 1152, top-10 through the in-memory index surface (src/main.rs:815-934: fp32 rows added in
+    1024-row batches, SQfp16-IP search) -- in the reference's call shape: `threads` native threads, ONE fp32 query per
+    mse_index_search call (the per-request `index.search(&query, k)` under the shared read guard, :900,:1046), closed loop.  The calls
+    coalesce inside the index; every answer (labels and float distances) is checked against one batched search of the same queries."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    import mse
+    from mse import ffi
+    so = os.path.join(ROOT, "scripts", "native", "libmse_callers.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
+    H = C.CDLL(so)
+    H.mse_callers_run.restype = C.c_double
+    H.mse_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(40)
+    x = (rng.standard_normal((n, D)) / np.sqrt(D)).astype(np.float32)
+    idx = mse.ScalarQuantizerIndex(D)
+    for lo in range(0, n, 1024):                      # INDEX_ADD_BATCH (src/main.rs:815)
+        idx.add(x[lo:lo + 1024])
+    nq = threads * rounds
+    q = rng.standard_normal((nq, D)).astype(np.float32)
+    want = idx.search(q, k)
+    one = idx.search(q[:1], k)                        # a lone caller
+    fn = C.cast(ffi.lib().mse_index_search, C.c_void_p)
+    dist = np.empty((nq, k), np.float32)
+    lab = np.empty((nq, k), np.int64)
+    lat = np.zeros(nq, np.float64)
+    failed = C.c_int(0)
+    H.mse_callers_run(fn, idx._h, q.ctypes.data, min(nq, 4 * threads), D * 4, k, threads, dist.ctypes.data, 4, lab.ctypes.data, 8, lat.ctypes.data, C.byref(failed))
+    st0 = idx.stats()
+    dt = H.mse_callers_run(fn, idx._h, q.ctypes.data, nq, D * 4, k, threads, dist.ctypes.data, 4, lab.ctypes.data, 8, lat.ctypes.data, C.byref(failed))
+    st1 = idx.stats()
+    t0 = time.perf_counter()
+    for i in range(64):
+        idx.search(q[i:i + 1], k)
+    t_alone = (time.perf_counter() - t0) / 64
+    ok = bool(dt > 0 and failed.value == 0 and np.array_equal(lab, want.labels) and np.array_equal(dist, want.distances) and
+              np.array_equal(one.labels[0], want.labels[0]))
+    passes = st1["passes"] - st0["passes"]
+    idx.close()
+    return {"metric": "configs[0] index (1e5 x 1152 fp32 rows -> SQfp16, top-10) searched by T native threads x 1 fp32 query per mse_index_search call",
+            "threads": threads, "queries": nq, "queries_per_s": nq / dt if dt > 0 else None,
+            "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))},
+            "queries_per_pass": nq / max(passes, 1), "one_caller_ms_per_query": t_alone * 1e3, "one_caller_queries_per_s": 1.0 / t_alone,
+            "all_answers_equal_batched_search": ok}
 
 
 def shard_point_bench(k, nq, full_ms_per_step, steps=20, rows=12_500_000):
@@ -358,6 +408,14 @@ def pq_bench(args):
     wall = time.perf_counter() - t0
     db = wall / (calls * len(qs))
     uncert = pq.last_uncertified
+    # the same at 64 queries per call (what the cross-thread coalescer hands over at most): start-up and drain of a call weigh half
+    qs64 = np.concatenate([qs, qs[::-1]])
+    pq.scan_topk_batch(gc, qs64, 200, 10, None, scales)
+    t0, calls64 = time.perf_counter(), 0
+    while calls64 < 20 or time.perf_counter() - t0 < 0.6:
+        pq.scan_topk_batch(gc, qs64, 200, 10, None, scales)
+        calls64 += 1
+    db64 = (time.perf_counter() - t0) / (calls64 * 64)
     # the scan kernel by itself: calls of EIGHT queries are one group on one stream (nothing beside the scan), HIP events per launch
     pq.scan_timing(2)
     for i in range(24):
@@ -376,7 +434,8 @@ def pq_bench(args):
         pass
     return {"metric": "OPQ/PQ 64x8-bit ADC scan + top-200", "ms_per_query": dt * 1e3, "ms_per_query_batched": db * 1e3,
             "queries_per_s_batched": 1.0 / db, "queries_per_call_batched": len(qs), "queries_per_pass_batched": per_pass, "vectors": n,
-            "timed": {"one_query_calls": calls1, "batched_calls": calls, "batched_seconds": wall},
+            "timed": {"one_query_calls": calls1, "batched_calls": calls, "batched_seconds": wall, "calls_of_64": calls64},
+            "at_64_per_call": {"ms_per_query": db64 * 1e3, "queries_per_s": 1.0 / db64, "end_to_end_frac": n * 68 / (8 * db64) / 1e9 / HBM_PEAK_GBS},
             "uncertified_queries_last_batch": uncert,
             "codes_GBps_end_to_end_one_query_per_call": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
             "roofline": {"bound": "hbm", "kernel": "pq_scan64x4_kernel<16>", "achieved": gbs_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1151,6 +1210,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             callers_line = {"error": repr(e)}
 
+    index_line = None
+    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_callers:
+        try:
+            index_line = index_callers_bench(k)
+        except Exception as e:  # noqa: BLE001
+            index_line = {"error": repr(e)}
     shard_line = None
     if rank == 0 and n_gpus == 1 and world == 1 and not args.no_shard_point:
         try:
@@ -1245,6 +1310,8 @@ def main():
         }
         if callers_line:
             line["concurrent_callers"] = callers_line
+        if index_line:
+            line["index_callers_1e5"] = index_line
         if shard_line:
             line["shard_point"] = shard_line
         if siglip_line:

@@ -83,7 +83,7 @@ int descend(mse_searcher* s, const LevelRef& l0, int nq, int k, uint32_t** sel_o
             if (launch_reduce_max_gq(reinterpret_cast<const float*>(cur.ptr), cur.nq_pad, cur.n,
                                      s->levels[li].as<uint32_t>(), n_out, n_out, nq, st)) return -1;
         } else {
-            if (launch_reduce_max(cur.kind, cur.ptr, cur.q_stride, cur.n, s->levels[li].p, n_out, n_out, nq, st))
+            if (launch_reduce_max(cur.kind, cur.ptr, cur.q_stride, cur.n, s->levels[li].p, n_out, n_out, nq, st, cur.e_stride))
                 return -1;
         }
         lv.push_back(LevelRef{k64 ? KEY_U64 : KEY_U32, s->levels[li].p, n_out, 1, n_out, false, 0});

@@ -608,7 +608,7 @@ static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, con
     if (s->gkeys.ensure(Q * std::max(k, n_sel) * 8) || s->cand_ids.ensure(Q * n_cand * 4) || s->cand_scores.ensure(Q * std::max(r, n_cand) * 8) ||
         s->out_ids.ensure(Q * r * 4) || s->sel_keys.ensure(Q * r * 8) || s->misc.ensure(Q * k * 4) || s->scores.ensure(Q * k * 8)) return -1;
     uint32_t* gsel = nullptr;
-    LevelRef l0{KEY_U32, s->gmax.p, n_groups, 1, n_groups, false, 0};
+    LevelRef l0{KEY_U32, s->gmax.p, 1, (size_t)NQ, n_groups, false, 0};   // group-major: element (q, g) at gmax[g * NQ + q]
     if (descend(s, l0, NQ, (int)n_sel, &gsel, s->gkeys.p)) return -1;                      // gsel [NQ][n_sel], gkeys u32 [NQ][n_sel]
     if (launch_expand_groups(gsel, n_sel, n_nom, 64, c->n, s->cand_ids.as<uint32_t>(), n_cand, NQ, st)) return -1;
     if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), n_cand, desc,
@@ -870,7 +870,12 @@ int mse_debug_pq4_group_max(mse_pq* pq, const mse_codes* c, const float* luts4, 
     if (launch_pq4_table(pq->a.as<float>(), desc ? sc : nullptr, n_valid, pq->b.p, params, nullptr, per_pass)) return -1;
     if (launch_pq_scan_gmax4(pq->b.p, c->codes, c->n, desc, pq->c.as<uint32_t>(), device_cu_count(), nullptr, per_pass)) return -1;
     Pq4Params ph[8];
-    MSE_HIP_TRY(hipMemcpy(out, pq->c.p, NQ * n_groups * 4, hipMemcpyDeviceToHost));
+    {   // the scan writes group-major [n_groups][NQ]; the hook hands out [NQ][n_groups]
+        std::vector<uint32_t> gm(NQ * n_groups);
+        MSE_HIP_TRY(hipMemcpy(gm.data(), pq->c.p, NQ * n_groups * 4, hipMemcpyDeviceToHost));
+        for (size_t g2 = 0; g2 < n_groups; g2++)
+            for (size_t j = 0; j < NQ; j++) out[j * n_groups + g2] = gm[g2 * NQ + j];
+    }
     MSE_HIP_TRY(hipMemcpy(ph, params, NQ * sizeof(Pq4Params), hipMemcpyDeviceToHost));
     for (int j = 0; j < per_pass; j++) { params_out[4 * j] = ph[j].delta; params_out[4 * j + 1] = ph[j].c; params_out[4 * j + 2] = ph[j].eps; params_out[4 * j + 3] = ph[j].ok; }
     return 0;

@@ -35,7 +35,7 @@ enum KeyKind { KEY_I64 = 0, KEY_F32 = 1, KEY_U64 = 2, KEY_U32 = 3 };
 // out[q][g] = max over in[q][g*F .. (g+1)*F) as order-preserving unsigned keys
 // (u64 keys for KEY_I64/KEY_U64 input, u32 keys for KEY_F32/KEY_U32 input).
 int launch_reduce_max(KeyKind kind, const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride,
-                      size_t n_out, int nq, hipStream_t stream);
+                      size_t n_out, int nq, hipStream_t stream, size_t in_estride = 1);   // element (q, i) at in[q*in_stride + i*in_estride]
 struct SelectArgs {
     KeyKind kind;            // type of `in` / `list_keys`
     const void* in;          // level array, [nq][in_stride]
@@ -100,7 +100,7 @@ struct Pq4Params { double delta, c, eps; int ok; };
 size_t pq4_table_bytes();
 int launch_pq4_table(const float* luts, const float* scales, int n_valid, void* table, Pq4Params* params, hipStream_t stream, int nq = 4);
 int launch_pq_scan_gmax4(const void* table, const uint8_t* codes, size_t n, const uint8_t* desc, uint32_t* gmax, int n_cu,
-                         hipStream_t stream, int nq = 4);   // nq = 4: 12-bit tables, 8: 8-bit tables; gmax [nq][n_groups]
+                         hipStream_t stream, int nq = 4);   // nq = 4: 12-bit tables, 8: 8-bit tables; gmax [n_groups][nq] (group-major)
 int launch_pq4_certify(const Pq4Params* params, const uint32_t* group_keys, int n_nominated, int n_sel, const uint32_t* top_ids,
                        const int64_t* top_scores, size_t top_stride, int r, int nq, int* flag, hipStream_t stream);
 int launch_add_descriptor(const uint32_t* ids, size_t n, const uint8_t* desc, int n_desc, size_t n_codes,

@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void pq4_quant_kernel(const float* __restrict_
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 
-// out[j * n_groups + g] = max over the 64 vectors of group g of query j's integer sum (0 past the end of the codes).
+// out[g * NQ + j] = max over the 64 vectors of group g of query j's integer sum (0 past the end of the codes).
 //
 // Round 4: the sums are taken by the matrix cores and the gathers are bank-conflict free.
 //   * A wave handles 16 vectors at a time; lane (v = lane % 16, g = lane / 16) owns bytes 16g .. 16g+15 of vector v's code row,
@@ -772,19 +772,16 @@ __global__ __launch_bounds__(NW * 64) void pq_scan64x4_kernel(const uint4* __res
         int best = max(rows[0], rows[1]);
 #pragma unroll
         for (int j = 2; j < 16; j += 2) best = max(best, max(rows[j], rows[j + 1]));     // v_max3_i32
-        // lanes (v = q, g = 0 .. 3) hold the maxima of their rows: the group's maximum per query by readlane
-        uint32_t m[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const int m0 = __builtin_amdgcn_readlane(best, q), m1 = __builtin_amdgcn_readlane(best, 16 + q);
-            const int m2 = __builtin_amdgcn_readlane(best, 32 + q), m3 = __builtin_amdgcn_readlane(best, 48 + q);
-            const int mm = max(max(m0, m1), max(m2, m3));
-            m[q] = (uint32_t)(mm + bias);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NQ; q++) out[(size_t)q * n_groups + grp] = m[q];
-        }
+        // lanes (v = q, g = 0 .. 3) hold the maxima of their rows: the maximum over the four g by two row swaps (gfx950's
+        // v_permlane32_swap / v_permlane16_swap), then lanes q < NQ store the group's NQ results side by side: out is group-major,
+        // [n_groups][NQ] (round 4's first form read them out with 4 NQ v_readlane and stored them from one lane: 265 -> VALU
+        // instructions per group at NQ = 8)
+        typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+        const u32x2s h = __builtin_amdgcn_permlane32_swap((uint32_t)best, (uint32_t)best, false, false);
+        best = max((int)h.x, (int)h.y);
+        const u32x2s r2 = __builtin_amdgcn_permlane16_swap((uint32_t)best, (uint32_t)best, false, false);
+        best = max((int)r2.x, (int)r2.y);
+        if (lane < NQ) out[grp * NQ + lane] = (uint32_t)(best + bias);
     }
 }
 

@@ -46,7 +46,7 @@ template <typename K> __device__ __forceinline__ K wave_max(K v) {
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_max_kernel(const T* __restrict__ in, size_t in_stride, size_t n_in,
                                                          typename KeyT<T>::type* __restrict__ out, size_t out_stride,
-                                                         size_t n_out, int nq) {
+                                                         size_t n_out, int nq, size_t in_estride) {
     using K = typename KeyT<T>::type;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void reduce_max_kernel(const T* __restrict__ i
     for (int u = 0; u < TOPK_FANOUT / 64; u++) {
         const size_t i = lo + (size_t)u * 64 + lane;
         if (i < n_in) {
-            const K k = key_of(src[i]);
+            const K k = key_of(src[i * in_estride]);
             best = k > best ? k : best;
         }
     }
@@ -445,13 +445,13 @@ __global__ void margin_f32_kernel(const uint32_t* __restrict__ sel_ids, const fl
 
 template <typename T>
 int launch_reduce_t(const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride, size_t n_out, int nq,
-                    hipStream_t stream) {
+                    hipStream_t stream, size_t in_estride) {
     const size_t waves = n_out * (size_t)nq;
     const size_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffull) return fail("reduce_max: grid too large");
     hipLaunchKernelGGL(reduce_max_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream,
                        reinterpret_cast<const T*>(in), in_stride, n_in,
-                       reinterpret_cast<typename KeyT<T>::type*>(out), out_stride, n_out, nq);
+                       reinterpret_cast<typename KeyT<T>::type*>(out), out_stride, n_out, nq, in_estride);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -459,13 +459,13 @@ int launch_reduce_t(const void* in, size_t in_stride, size_t n_in, void* out, si
 }  // namespace
 
 int launch_reduce_max(KeyKind kind, const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride,
-                      size_t n_out, int nq, hipStream_t stream) {
+                      size_t n_out, int nq, hipStream_t stream, size_t in_estride) {
     if (n_out == 0 || nq == 0) return 0;
     switch (kind) {
-        case KEY_I64: return launch_reduce_t<int64_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
-        case KEY_U64: return launch_reduce_t<uint64_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
-        case KEY_F32: return launch_reduce_t<float>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
-        case KEY_U32: return launch_reduce_t<uint32_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream);
+        case KEY_I64: return launch_reduce_t<int64_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream, in_estride);
+        case KEY_U64: return launch_reduce_t<uint64_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream, in_estride);
+        case KEY_F32: return launch_reduce_t<float>(in, in_stride, n_in, out, out_stride, n_out, nq, stream, in_estride);
+        case KEY_U32: return launch_reduce_t<uint32_t>(in, in_stride, n_in, out, out_stride, n_out, nq, stream, in_estride);
     }
     return fail("reduce_max: bad key kind");
 }

@@ -10,15 +10,17 @@
 #include <stdlib.h>
 #include <time.h>
 
-typedef int (*topk_fn)(void* handle, const uint16_t* queries, size_t nq, size_t k, int64_t* scores, uint32_t* ids);
+/* mse_dispatcher_topk_f16 (f16 queries, i64 scores, u32 ids) and mse_index_search (f32 queries, f32 distances, i64 labels) share
+ * this shape; element sizes are arguments of the run */
+typedef int (*topk_fn)(void* handle, const void* queries, size_t nq, size_t k, void* out_a, void* out_b);
 
 typedef struct {
     topk_fn fn;
     void* handle;
-    const uint16_t* queries;
-    size_t n_queries, d, k, first, stride;
-    int64_t* scores;
-    uint32_t* ids;
+    const char* queries;
+    size_t n_queries, query_bytes, k, first, stride, a_bytes, b_bytes;
+    char* out_a;
+    char* out_b;
     double* latency_ms;
     pthread_barrier_t* gate;
     int failures;
@@ -35,7 +37,7 @@ static void* caller_main(void* p) {
     pthread_barrier_wait(c->gate);
     for (size_t j = c->first; j < c->n_queries; j += c->stride) {
         const double t0 = now_s();
-        const int rc = c->fn(c->handle, c->queries + j * c->d, 1, c->k, c->scores + j * c->k, c->ids + j * c->k);
+        const int rc = c->fn(c->handle, c->queries + j * c->query_bytes, 1, c->k, c->out_a + j * c->k * c->a_bytes, c->out_b + j * c->k * c->b_bytes);
         c->latency_ms[j] = (now_s() - t0) * 1e3;
         if (rc) c->failures++;
     }
@@ -44,8 +46,8 @@ static void* caller_main(void* p) {
 
 /* returns the wall-clock seconds from the moment all threads were released until the last one finished (< 0: setup failed);
  * *n_failed = calls that returned non-zero */
-double mse_callers_run(void* fn, void* handle, const uint16_t* queries, size_t n_queries, size_t d, size_t k, int threads,
-                       int64_t* scores, uint32_t* ids, double* latency_ms, int* n_failed) {
+double mse_callers_run(void* fn, void* handle, const void* queries, size_t n_queries, size_t query_bytes, size_t k, int threads,
+                       void* out_a, size_t a_bytes, void* out_b, size_t b_bytes, double* latency_ms, int* n_failed) {
     if (threads <= 0 || !fn) return -1.0;
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
     caller_t* cs = (caller_t*)calloc((size_t)threads, sizeof(caller_t));
@@ -56,7 +58,8 @@ double mse_callers_run(void* fn, void* handle, const uint16_t* queries, size_t n
     pthread_attr_setstacksize(&attr, 256 * 1024);
     int started = 0;
     for (int t = 0; t < threads; t++) {
-        cs[t] = (caller_t){(topk_fn)fn, handle, queries, n_queries, d, k, (size_t)t, (size_t)threads, scores, ids, latency_ms, &gate, 0};
+        cs[t] = (caller_t){(topk_fn)fn, handle, (const char*)queries, n_queries, query_bytes, k, (size_t)t, (size_t)threads, a_bytes, b_bytes,
+                           (char*)out_a, (char*)out_b, latency_ms, &gate, 0};
         if (pthread_create(&th[t], &attr, caller_main, &cs[t])) break;
         started++;
     }
