@@ -832,10 +832,14 @@ def server_bench(eng, cfg, engine_batch):
     # a second replica of the tower (856 MB of weights): two model threads, so one batch's host side (hand-off, upload of 113 MB of
     # raw files, download) runs beside the other's device side
     from mse import siglip
-    eng2 = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=engine_batch)
-    eng2.image_size = (w, h)
+    n_rep = int(os.environ.get("MSE_BENCH_SERVER_REPLICAS", "2"))
+    extra = []
+    for _ in range(max(0, n_rep - 1)):
+        e2 = siglip.SiglipImageEngine.from_state_dict(siglip.synthetic_state_dict(cfg), cfg, max_batch=engine_batch)
+        e2.image_size = (w, h)
+        extra.append(e2)
     srv = ClipServer({"device": "cuda:0", "model": "ViT-SO400M-14-SigLIP-384", "model_name": "siglip-so400m-14-384",
-                      "max_batch_size": per_req, "port": 0}, [eng, eng2])
+                      "max_batch_size": per_req, "port": 0}, [eng] + extra)
     srv.start_threads()
     loop = asyncio.new_event_loop()
     ready = threading.Event()
@@ -868,10 +872,11 @@ def server_bench(eng, cfg, engine_batch):
         srv.stop_threads()
         for t in srv._threads:
             t.join(30)
-        eng2.close()
+        for e2 in extra:
+            e2.close()
     return {"metric": "clip_server images/s end to end (HTTP + msgpack + device BMP decode + tower + fp16 rows)",
             "value": per_req * n_req / dt, "unit": "images/s", "images_per_request": per_req, "requests": n_req, "in_flight": in_flight,
-            "request_bytes": body_len, "engine_batch_capacity": engine_batch, "engine_replicas": 2, "client": "separate process, loopback TCP",
+            "request_bytes": body_len, "engine_batch_capacity": engine_batch, "engine_replicas": n_rep, "client": "separate process, loopback TCP",
             "host_preprocess_images_per_s_one_thread": host_decode,
             "note": "the model thread runs the BMP jobs waiting in its queue as one engine call (up to the engine's batch capacity); "
                     "host_preprocess = PIL decode + normalise + fp16 of the same files on one thread, the reference's preprocessing_thread "
