@@ -571,17 +571,10 @@ def graph_bench(args):
             "build": build, "pq_rerank": rerank, "results": out}
 
 
-def graph_scale_bench(args):
-    """The metric's other reading -- queries/s at recall@10 >= 0.95 through the graph index -- under the driver's clock at 1e7 rows
-    (BASELINE configs[2]'s size; the 1e8-row runs are in profiles/).  Synthetic hierarchical clusters made on the device
-    (rows/50 centres around rows/5000 super-centres, noise 0.3: scripts/graph_scale_bench.py), ONE Vamana pass with
-    generate-index-shard's defaults (R 64, L 192, C 750) on the device, then the GPU-resident beam search
-    (query_disk_index::greedy_search, beam 4, neighbours scored exactly) for 1024 fresh queries, host arrays in and out:
-    reported at the smallest search list whose recall@10 against the exact brute-force top-10 reaches 0.95."""
-    import numpy as np
+def clustered_generator(n):
+    """Synthetic hierarchical clusters made on the device (rows/50 centres around rows/5000 super-centres, noise 0.3; unit-norm fp16
+    rows): -> f(m, seed) returning an [m, 1152] fp16 device tensor drawn from the same mixture."""
     import torch
-    import mse
-    n, nq, K, R, batch = int(args.graph_scale_rows), 2048, 10, 64, int(args.graph_batch)   # 1024 tuning + 1024 held-out queries
     g0 = torch.Generator(device="cuda").manual_seed(0)
     hier = max(8, n // 5000)
     sup = torch.randn(hier, D, device="cuda", generator=g0)
@@ -599,6 +592,87 @@ def graph_scale_bench(args):
             out[i:i + c] = (x / x.norm(dim=1, keepdim=True)).half()
         return out
 
+    return clustered
+
+
+def pq_rerank_leg(rows, vecs, s, queries, truth, K=10, r=200, per_call=32):
+    """BASELINE configs[4] as specified, on a quantisable set resident in HBM: OPQ/PQ 64 x 8-bit codes of the rows (codec trained on
+    a 20 000-row sample, codes made on the device), flat ADC scan of ALL codes, the r best by approximate score re-scored exactly
+    in fp16, top-K; recall@K against `truth` (the exact brute-force answers of the same run)."""
+    import numpy as np
+    import torch
+    import mse
+    n, nq = len(vecs), queries.shape[0]
+    rng = np.random.default_rng(4)
+    sel = torch.from_numpy(np.sort(rng.choice(n, min(n, 20000), replace=False))).cuda()
+    cents, T = train_codec(rows[sel].float().cpu().numpy())
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    t0 = time.perf_counter()
+    codes = mse.Codes.quantize_base(pq, vecs)
+    t_quant = time.perf_counter() - t0
+    qf = queries.float().cpu().numpy()
+    pq.scan_topk_batch(codes, qf[:per_call], r, K, s)
+    t0 = time.perf_counter()
+    got = np.concatenate([pq.scan_topk_batch(codes, qf[i:i + per_call], r, K, s)[1] for i in range(0, nq, per_call)])
+    dt = time.perf_counter() - t0
+    rec = sum(len(set(got[i].tolist()) & set(truth[i].tolist())) for i in range(nq)) / (K * nq)
+    out = {"metric": "OPQ/PQ 64x8-bit flat scan of all codes, top-%d by ADC re-scored exactly (fp16 rows), top-%d" % (r, K), "rows": n,
+           "queries": nq, "queries_per_call": per_call, "queries_per_s": nq / dt, "ms_per_query": dt / nq * 1e3, "recall_at_10": rec, "r": r,
+           "uncertified_queries_last_batch": pq.last_uncertified,
+           "codes": {"made_on_device_seconds": t_quant, "vectors_per_s": n / t_quant, "codec": "64 x 256, rotation + per-subspace k-means on a 20 000-row sample (3 iterations)"}}
+    codes.close()
+    return out
+
+
+def ann_scale_bench(args):
+    """A driver-timed approximate-search figure AT THE METRIC'S SIZE: 1e8 x 1152 clustered rows resident in HBM (230 GB), searched by
+    the OPQ/PQ flat scan + fp16 exact re-rank pipeline (BASELINE configs[4]); recall@10 against the exact brute-force answers over
+    the same rows, 1024 queries.  (The graph index at this size needs a 10-20 minute build: profiles/r04_graph_index_1e8*.json.)"""
+    import numpy as np
+    import torch
+    import mse
+    from mse import ffi
+    n, nq, K = int(args.ann_rows), 1024, 10
+    free_b, total_b = ffi.sz(), ffi.sz()
+    ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
+    need = n * D * 2 + n * 68 + (16 << 30)
+    if need > free_b.value:
+        return {"skipped": f"{n} rows need {need / 1e9:.0f} GB, {free_b.value / 1e9:.0f} GB free"}
+    clustered = clustered_generator(n)
+    t0 = time.perf_counter()
+    rows, queries = clustered(n, 1), clustered(nq, 2)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows)
+    s = mse.Searcher(vecs)
+    qh = queries.cpu().numpy().view(np.uint16)
+    s.bruteforce_topk(qh[:8], K)
+    t0 = time.perf_counter()
+    _, truth = s.bruteforce_topk(qh, K)
+    t_exact = time.perf_counter() - t0
+    out = pq_rerank_leg(rows, vecs, s, queries, truth, K)
+    out["metric"] = f"queries/sec over a {n:.0e}x1152 index @ recall@10>=0.95: OPQ/PQ flat scan + fp16 exact re-rank (recall against the exact answers of the same run)"
+    out["value"] = out["queries_per_s"]
+    out["unit"] = "queries/s"
+    out["exact_brute_force_same_rows_queries_per_s"] = nq / t_exact
+    out["config"] = {"workload": f"{n} x {D} fp16 hierarchical synthetic clusters generated on the device in {t_gen:.1f} s; host arrays in and out"}
+    s.close()
+    vecs.close()
+    return out
+
+
+def graph_scale_bench(args):
+    """The metric's other reading -- queries/s at recall@10 >= 0.95 through the graph index -- under the driver's clock at 1e7 rows
+    (BASELINE configs[2]'s size; the 1e8-row runs are in profiles/).  Synthetic hierarchical clusters made on the device
+    (rows/50 centres around rows/5000 super-centres, noise 0.3: scripts/graph_scale_bench.py), ONE Vamana pass with
+    generate-index-shard's defaults (R 64, L 192, C 750) on the device, then the GPU-resident beam search
+    (query_disk_index::greedy_search, beam 4, neighbours scored exactly) for 1024 fresh queries, host arrays in and out:
+    reported at the smallest search list whose recall@10 against the exact brute-force top-10 reaches 0.95."""
+    import numpy as np
+    import torch
+    import mse
+    n, nq, K, R, batch = int(args.graph_scale_rows), 2048, 10, 64, int(args.graph_batch)   # 1024 tuning + 1024 held-out queries
+    clustered = clustered_generator(n)
     rows, queries = clustered(n, 1), clustered(nq, 2)
     torch.cuda.synchronize()
     vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows)
@@ -662,29 +736,9 @@ def graph_scale_bench(args):
             chosen = run(L, held, True)
             break
     g.close()
-    # BASELINE configs[4] as specified, on this quantisable set: OPQ/PQ 64 x 8-bit codes of the 1e7 resident rows (made on the
-    # device), flat ADC scan of ALL codes, the 200 best by approximate score re-scored exactly in fp16, top-10; recall@10 against
-    # the exact brute-force answers above.  Queries go through 32 per call (four per pass over the codes).
-    rerank = None
+    # BASELINE configs[4] as specified, on this quantisable set (pq_rerank_leg); queries go through 32 per call, eight per pass
     try:
-        rng = np.random.default_rng(4)
-        sel = torch.from_numpy(np.sort(rng.choice(n, min(n, 20000), replace=False))).cuda()
-        cents, T = train_codec(rows[sel].float().cpu().numpy())
-        pq = mse.ProductQuantizer(cents, T, 18, D)
-        t0 = time.perf_counter()
-        codes = mse.Codes.quantize_base(pq, vecs)
-        t_quant = time.perf_counter() - t0
-        qf = queries.float().cpu().numpy()
-        pq.scan_topk_batch(codes, qf[:32], 200, K, s)
-        t0 = time.perf_counter()
-        got = np.concatenate([pq.scan_topk_batch(codes, qf[i:i + 32], 200, K, s)[1] for i in range(0, nq, 32)])
-        dt = time.perf_counter() - t0
-        rec = sum(len(set(got[i].tolist()) & set(truth[i].tolist())) for i in range(nq)) / (K * nq)
-        rerank = {"metric": "OPQ/PQ 64x8-bit flat scan of all codes, top-200 by ADC re-scored exactly (fp16 rows), top-10", "rows": n,
-                  "queries": nq, "queries_per_s": nq / dt, "ms_per_query": dt / nq * 1e3, "recall_at_10": rec, "r": 200,
-                  "uncertified_queries_last_batch": pq.last_uncertified,
-                  "codes": {"made_on_device_seconds": t_quant, "vectors_per_s": n / t_quant, "codec": "64 x 256, rotation + per-subspace k-means on a 20 000-row sample (3 iterations)"}}
-        codes.close()
+        rerank = pq_rerank_leg(rows, vecs, s, queries, truth, K)
     except Exception as e:  # noqa: BLE001
         rerank = {"error": repr(e)}
     return {"metric": f"queries/sec over a {n:.0e}x1152 graph index @ recall@10>=0.95 (GPU-resident beam search)", "pq_rerank": rerank,
@@ -912,6 +966,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="skip the GPU-resident beam-search leg")
     ap.add_argument("--graph-rows", type=float, default=2e5)
     ap.add_argument("--no-graph-scale", action="store_true", help="skip the 1e7-row graph-index leg (a ~1 minute build)")
+    ap.add_argument("--no-ann-scale", action="store_true", help="skip the 1e8-row PQ scan + re-rank leg (recall at the metric's size)")
+    ap.add_argument("--ann-rows", type=float, default=1e8)
     ap.add_argument("--graph-scale-rows", type=float, default=1e7)
     ap.add_argument("--graph-passes", type=int, default=1, help="Vamana passes of the graph-scale build (generate-index-shard -s = 2)")
     ap.add_argument("--graph-batch", type=int, default=4096, help="points inserted per batch of the graph-scale build")
@@ -1244,12 +1300,21 @@ def main():
         except Exception as e:  # noqa: BLE001
             graph_line = {"error": repr(e)}
 
-    gscale_line = None
+    gscale_line = ann_line = None
+    if rank == 0 and n_gpus == 1 and not (args.no_graph_scale and args.no_ann_scale):
+        del searcher, vecs                             # the 230 GB index makes room for the clustered sets of the next two legs
+        import gc
+        gc.collect()
+    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_ann_scale:
+        try:
+            ann_line = ann_scale_bench(args)
+        except Exception as e:  # noqa: BLE001
+            ann_line = {"error": repr(e)}
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
     if rank == 0 and n_gpus == 1 and not args.no_graph_scale:
         try:
-            del searcher, vecs                         # the 230 GB index makes room for the 1e7-row graph leg
-            import gc
-            gc.collect()
             gscale_line = graph_scale_bench(args)
         except Exception as e:  # noqa: BLE001
             gscale_line = {"error": repr(e)}
@@ -1325,6 +1390,8 @@ def main():
             line["pq_scan"] = pq_line
         if graph_line:
             line["graph_search"] = graph_line
+        if ann_line:
+            line["ann_1e8"] = ann_line
         if gscale_line:
             line["graph_index_1e7"] = gscale_line
         if note:
