@@ -873,7 +873,7 @@ def server_bench(eng, cfg, engine_batch):
     from aiohttp import web
     from mse.clip_server import ClipServer, preprocess_image
     w = h = cfg["img_size"]
-    per_req, n_req, in_flight = 128, 24, 6
+    per_req, n_req, in_flight = 128, int(os.environ.get("MSE_BENCH_SERVER_REQS", "32")), int(os.environ.get("MSE_BENCH_SERVER_INFLIGHT", "6"))
     rng = np.random.default_rng(11)
     hdr = (b"BM" + (54 + w * h * 3).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") +
            w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(24))

@@ -356,6 +356,7 @@ void mse_pq_free(mse_pq* pq) {
     if (pq->pin) (void)hipHostFree(pq->pin);
     if (pq->scratch) mse_searcher_free(pq->scratch);
     if (pq->lane2) mse_searcher_free(pq->lane2);
+    if (pq->lane3) mse_searcher_free(pq->lane3);
     delete pq;
 }
 
@@ -689,18 +690,29 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         float* scales_dev = sc_bytes ? reinterpret_cast<float*>(pq->a.as<char>() + sc_off) : nullptr;
         int64_t* const out_scores_dev = s->out_scores.as<int64_t>();
         uint32_t* const out_ids_dev = reinterpret_cast<uint32_t*>(s->out_scores.as<char>() + nq * k * 8);
-        // Queries alternate between two streams (each with its own scratch): the chain of small kernels that follows a scan
-        // (tournament, re-score of the best groups, selects: ~0.2 ms, mostly single-workgroup launches) runs beside the NEXT
-        // query's scan, which leaves a few CUs free for it (pq.hip launch_pq_scan_gmax).
-        mse_searcher* lanes[2] = {s, nullptr};
-        DevBuf &t2 = pq->t2, &lut2 = pq->lut2, &qf2 = pq->qf2;
+        // Groups of queries alternate between TWO streams (each with its own scratch): the chain of small kernels that follows a
+        // scan (tournament, re-score of the nominated groups, selects, certificate) runs beside the next group's scan, on the CUs
+        // that scan leaves free.  (A third stream -- so that group u + 2 would not queue behind group u's tail -- and 16 / 24 / 32
+        // spare CUs were measured in round 4: 0.194-0.203 ms per query at 32 per call in every combination, two streams and 8 spare
+        // CUs being the best; the code below keeps room for a third lane.)
+        mse_searcher* lanes[3] = {s, nullptr, nullptr};
+        DevBuf &t2 = pq->t2, &lut2 = pq->lut2;
+        DevBuf* qfs[3] = {&s->q_stage, &pq->qf2, &pq->qf3};
         if (nq >= 4) {
-            if (pq->lane2 && pq->lane2->base != s->base) { mse_searcher_free(pq->lane2); pq->lane2 = nullptr; }
-            if (!pq->lane2) pq->lane2 = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
-            lanes[1] = pq->lane2;
-            if (!lanes[1] || t2.ensure(8 * d * 4) || lut2.ensure(8 * pq->n_chunks * pq->n_centroids * 4) || qf2.ensure(8 * d * 2)) break;
-            if (hipStreamSynchronize(st) != hipSuccess) { fail("H2D failed"); break; }   // uploads visible to both streams
+            mse_searcher** extra[2] = {&pq->lane2, &pq->lane3};
+            const int n_extra = 1;
+            bool lanes_ok = true;
+            for (int e = 0; e < n_extra && lanes_ok; e++) {
+                mse_searcher*& ln = *extra[e];
+                if (ln && ln->base != s->base) { mse_searcher_free(ln); ln = nullptr; }
+                if (!ln) ln = s->base ? mse_searcher_new(s->base) : scratch_searcher_new();
+                lanes[e + 1] = ln;
+                lanes_ok = ln != nullptr && qfs[e + 1]->ensure(8 * d * 2) == 0;
+            }
+            if (!lanes_ok || t2.ensure(8 * d * 4) || lut2.ensure(8 * pq->n_chunks * pq->n_centroids * 4)) break;
+            if (hipStreamSynchronize(st) != hipSuccess) { fail("H2D failed"); break; }   // uploads visible to every stream
         }
+        const int n_lanes = lanes[2] ? 3 : lanes[1] ? 2 : 1;
         // queries go through in groups that share one pass over the codes: EIGHTS (8-bit tables) and FOURS (12-bit tables) -- integer
         // nomination under a certificate, pq_scan64x4_kernel --, then a PAIR (pq_scan64x2_kernel, exact), then a single one; groups
         // alternate between the streams
@@ -721,10 +733,10 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         size_t q = 0;
         for (size_t unit = 0; q < nq && ok; unit++) {
             const int n_q = (eight_ok && nq - q >= 8) ? 8 : (four_ok && nq - q >= 4) ? 4 : nq - q >= 2 ? 2 : 1;
-            const int w = lanes[1] ? (int)(unit & 1) : 0;
-            float* const tw = prep_all ? pq->b.as<float>() + q * d : w ? t2.as<float>() : pq->b.as<float>();
+            const int w = (int)(unit % (size_t)n_lanes);
+            float* const tw = prep_all ? pq->b.as<float>() + q * d : w ? t2.as<float>() : pq->b.as<float>();     // (several lanes imply prep_all)
             float* const lw = prep_all ? pq->c.as<float>() + q * lut_floats_b : w ? lut2.as<float>() : pq->c.as<float>();
-            uint16_t* const qw = w ? qf2.as<uint16_t>() : s->q_stage.as<uint16_t>();
+            uint16_t* const qw = qfs[w]->as<uint16_t>();
             if (n_q >= 4) {
                 ok = scan_topk4_async(pq, c, lanes[w], pq->a.as<float>() + q * d, tw, lw, qw, scales_dev, r, k, out_scores_dev + q * k,
                                       out_ids_dev + q * k, flags_dev + q, prep_all, n_q) == 0;
@@ -735,7 +747,8 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
                                      out_scores_dev + q * k, out_ids_dev + q * k, prep_all) == 0;
             q += n_q;
         }
-        if (lanes[1] && hipStreamSynchronize(lanes[1]->stream) != hipSuccess) ok = false;
+        for (int w = 1; w < n_lanes; w++)
+            if (hipStreamSynchronize(lanes[w]->stream) != hipSuccess) ok = false;
         if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
         if (four_ok && nq >= 4) {
             // a query whose certificate did not hold (rare: the band of +-eps around its r-th score reached past the nominated

@@ -858,7 +858,10 @@ __global__ __launch_bounds__(256) void rank_kernel(const int64_t* __restrict__ s
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream) {
     if (n == 0) return 0;
     static const bool old_t = MSE_DEV_KNOB("MSE_PQ_OLDTRANSFORM");
-    if (n >= 32 && !old_t) {
+    // the register-tiled kernel puts 64 x 64 outputs on a workgroup: a batch of 32-64 query vectors is 18 workgroups on a 256-CU
+    // part (262 us); below 256 vectors the one-output-per-thread kernel (16 x 16 outputs per workgroup, 144+ workgroups) is the
+    // faster one.  Same sums in the same order either way.
+    if (n >= 256 && !old_t) {
         dim3 grid4((d + T4_B - 1) / T4_B, (unsigned)((n + T4_B - 1) / T4_B));
         hipLaunchKernelGGL(pq_transform_tiled_kernel, grid4, dim3(256), 0, stream, T, d, x, n, out);
         MSE_HIP_TRY(hipGetLastError());
@@ -912,7 +915,7 @@ bool pq_scan_gmax_supported(int n_chunks, int n_centroids, const uint8_t* desc, 
     return n_chunks == 64 && n_centroids == 256 && (!(desc && scales) || n_desc == 4);
 }
 // workgroups of a flat scan: every CU but one per XCD (8 XCDs on MI355X)
-static size_t scan_cus(int n_cu) { return n_cu >= 64 ? (size_t)(n_cu - 8) : (size_t)n_cu; }
+static size_t scan_cus(int n_cu) { return n_cu >= 64 ? (size_t)(n_cu - 8) : (size_t)n_cu; }   // (16, 24, 32 spare CUs: no gain, measured)
 
 // group maxima of a full scan: gmax[g] = max ADC score (+ descriptor bias) of vectors 64g .. 64g+63 (INT64_MIN past the end)
 int launch_pq_scan_gmax(const float* lut, const uint8_t* codes, size_t n, const uint8_t* desc, const float* scales,
@@ -1022,6 +1025,10 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
     size_t blocks = (n + threads - 1) / threads;
     const size_t cap = (size_t)n_cu * 2;
     if (blocks > cap) blocks = cap;
+    // several queries per launch = the tail of a batched scan, which runs on the few CUs the next scan leaves free: there the table
+    // copy (64 KiB per workgroup) is what costs, so a workgroup takes 4096 candidates instead of 1024 (8 x 32 768 candidates:
+    // 884 us -> on 8 CUs with 256 workgroups, profiles/r04_pq_timeline.txt)
+    if (nq > 1 && blocks > (n + 4095) / 4096) blocks = (n + 4095) / 4096;
     hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(threads), lds, stream, lut, n_chunks, n_centroids, codes,
                        n_codes, ids, n, desc, n_desc, scales, out, q_stride);
     MSE_HIP_TRY(hipGetLastError());

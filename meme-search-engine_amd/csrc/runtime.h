@@ -92,8 +92,9 @@ struct mse_pq {
     std::mutex mu;
     mse::DevBuf a, b, c;              // call scratch (guarded by mu)
     mse_searcher* scratch = nullptr;  // stream + scratch for scan calls that bring no searcher (guarded by mu; made on first use)
-    mse_searcher* lane2 = nullptr;    // second stream of the batched scan; bound to the base of the call that made it
-    mse::DevBuf t2, lut2, qf2;        // its transformed query, table and f16 query
+    mse_searcher* lane2 = nullptr;    // second and third stream of the batched scan; bound to the base of the call that made them
+    mse_searcher* lane3 = nullptr;
+    mse::DevBuf t2, lut2, qf2, qf3;   // their transformed query, table and f16 queries
     bool avoid8 = false;              // eight-per-pass (8-bit tables) gave too many uncertified queries on this data: stay with four per pass
     uint32_t last_uncertified = 0;    // four-query scan: queries of the last batch whose certificate failed (re-run through the exact scan)
     int device = 0;                   // HIP ordinal the quantiser was loaded on
