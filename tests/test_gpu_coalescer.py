@@ -272,3 +272,32 @@ def test_beam_search_one_query_per_thread_is_one_launch_and_unchanged(gpu, mse, 
                                                           False, 2, 64, has_url)
     bi, bs, vi, vs, cm, pc = alone[i]
     assert (cm, pc) == (ocm, opc) and np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores) and np.array_equal(vi, ovids)
+
+
+def test_requests_of_many_sizes_share_the_queue(gpu, mse, orc):
+    """Requests larger than a pass (300 queries), mid-sized ones and single queries from 12 threads at once, with a small
+    max_queries_per_pass so that passes fill up: a request is never split between callers' rows, one larger than a pass goes alone,
+    and every row is the oracle's."""
+    n = 9000
+    base = orc.gen_rows_f16(SEED_BASE, 11, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 11, 700)
+    ws, wi = orc.bruteforce_topk(base, q, 6)
+    vl = mse.VectorList.from_f16s(base, D)
+    disp = mse.Dispatcher(vl, max_queries_per_pass=64, max_wait_us=5000)
+    spans = [(0, 300), (300, 301), (301, 340), (340, 341), (341, 400), (400, 401), (401, 402), (402, 470), (470, 471), (471, 600), (600, 601), (601, 700)]
+
+    def caller(i):
+        lo, hi = spans[i]
+        out = []
+        for _ in range(3):
+            out.append(disp.search(q[lo:hi], 6))
+        return out
+
+    for i, res in enumerate(run_threads(len(spans), caller)):
+        lo, hi = spans[i]
+        for sc, ids in res:
+            assert np.array_equal(ids, wi[lo:hi]) and np.array_equal(sc, ws[lo:hi]), i
+    st = disp.stats()
+    assert st["queries"] == 3 * 700 and st["requests"] == 3 * len(spans)
+    assert st["max_pass_queries"] >= 300            # the 300-query request went through as one pass of its own
+    disp.close()
