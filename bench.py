@@ -666,12 +666,12 @@ def graph_scale_bench(args):
     (BASELINE configs[2]'s size; the 1e8-row runs are in profiles/).  Synthetic hierarchical clusters made on the device
     (rows/50 centres around rows/5000 super-centres, noise 0.3: scripts/graph_scale_bench.py), ONE Vamana pass with
     generate-index-shard's defaults (R 64, L 192, C 750) on the device, then the GPU-resident beam search
-    (query_disk_index::greedy_search, beam 4, neighbours scored exactly) for 1024 fresh queries, host arrays in and out:
+    (query_disk_index::greedy_search, beam 4, neighbours scored exactly) for 2048 held-out queries per call, host arrays in and out:
     reported at the smallest search list whose recall@10 against the exact brute-force top-10 reaches 0.95."""
     import numpy as np
     import torch
     import mse
-    n, nq, K, R, batch = int(args.graph_scale_rows), 2048, 10, 64, int(args.graph_batch)   # 1024 tuning + 1024 held-out queries
+    n, nq, K, R, batch = int(args.graph_scale_rows), 4096, 10, 64, int(args.graph_batch)   # 2048 tuning + 2048 held-out queries (a call of 2048: 18 % more queries/s than 1024, scripts/beam_batch_probe.py)
     clustered = clustered_generator(n)
     rows, queries = clustered(n, 1), clustered(nq, 2)
     torch.cuda.synchronize()
