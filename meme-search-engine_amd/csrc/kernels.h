@@ -79,6 +79,13 @@ int launch_finalize(const uint32_t* sel_ids, const int64_t* sel_scores, size_t s
 int launch_margin_f32(const uint32_t* sel_ids, const float* sel_keys, size_t sel_stride, int k, int nq, const float* group_keys,
                       size_t gk_stride, int kg, size_t n_groups, const float* eps, float* margin, hipStream_t stream);
 
+// per-query widening helpers: out[g][j] = in[g][idx[j]] (j < nb; -inf in the padding columns) | out row j = in row idx[j] (rows of
+// row_bytes, a multiple of 16) | dst row idx[j] = src row j for the j with take[j] != 0 (take == nullptr: all)
+int launch_gather_columns(const float* in, int nq_pad, size_t n_groups, const uint32_t* idx, int nb, float* out, int nbp, hipStream_t stream);
+int launch_gather_rows16(const void* in, size_t row_bytes, const uint32_t* idx, int nb, void* out, hipStream_t stream);
+int launch_scatter_topk(const uint32_t* idx, const uint8_t* take, int nb, int k, const int64_t* src_s, const uint32_t* src_i, int64_t* dst_s,
+                        uint32_t* dst_i, size_t dst_stride, hipStream_t stream);
+
 // ---- pq.hip ----------------------------------------------------------------------------------
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream);
 int launch_pq_transform_vec(const float* T_transposed, int d, const float* x, float* out, hipStream_t stream);   // n = 1, same arithmetic

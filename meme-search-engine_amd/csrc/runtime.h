@@ -70,6 +70,7 @@ struct mse_searcher {
     mse::DevBuf cand_ids, cand_scores, gkeys, eps, margin;
     mse::DevBuf misc, qpacked;
     mse::DevBuf pq4;          // four-query PQ scan: the packed 12-bit table (136 KiB) + the four queries' certificate parameters
+    mse::DevBuf wq, wg, widx, wout;   // per-query widening of the MFMA pass: the compact set's queries, group maxima, indices, results
     mse::DevBuf thr;          // [2][nq] u64: k-th best score key of each tournament level, the floor of the level below
     const unsigned long long* last_kth = nullptr;   // after descend(): k-th best level-0 key per query (sortable), or null
     mse::DevBuf pool[16];     // scratch of the batched graph searches (kept between calls: no hipMalloc on the query path)

@@ -507,11 +507,60 @@ int launch_expand_groups(const uint32_t* parents, size_t par_stride, size_t n_pa
     return 0;
 }
 
+// ---- helpers of the per-query widening (api.hip mfma_pass): the few queries whose certificate failed are carried on as a compact set
+__global__ void gather_columns_kernel(const float* __restrict__ in, int nq_pad, size_t n_groups, const uint32_t* __restrict__ idx, int nb,
+                                      float* __restrict__ out, int nbp) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t g = t / (size_t)nbp;
+    const int j = (int)(t % (size_t)nbp);
+    if (g >= n_groups) return;
+    out[t] = j < nb ? in[g * (size_t)nq_pad + idx[j]] : -__builtin_inff();
+}
+__global__ void gather_rows16_kernel(const uint4* __restrict__ in, size_t row_u4, const uint32_t* __restrict__ idx, int nb, uint4* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nb * row_u4) return;
+    const size_t j = t / row_u4, c = t % row_u4;
+    out[t] = in[(size_t)idx[j] * row_u4 + c];
+}
+__global__ void scatter_topk_kernel(const uint32_t* __restrict__ idx, const uint8_t* __restrict__ take, int nb, int k, const int64_t* __restrict__ src_s,
+                                    const uint32_t* __restrict__ src_i, int64_t* __restrict__ dst_s, uint32_t* __restrict__ dst_i, size_t dst_stride) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * k) return;
+    const int j = t / k, i = t % k;
+    if (take && !take[j]) return;
+    dst_s[(size_t)idx[j] * dst_stride + i] = src_s[t];
+    dst_i[(size_t)idx[j] * dst_stride + i] = src_i[t];
+}
+
 int launch_margin_f32(const uint32_t* sel_ids, const float* sel_keys, size_t sel_stride, int k, int nq, const float* group_keys,
                       size_t gk_stride, int kg, size_t n_groups, const float* eps, float* margin, hipStream_t stream) {
     if (nq == 0 || k == 0) return 0;
     hipLaunchKernelGGL(margin_f32_kernel, dim3((nq + 63) / 64), dim3(64), 0, stream, sel_ids, sel_keys, sel_stride, k, group_keys,
                        gk_stride, kg, n_groups, eps, margin, nq);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gather_columns(const float* in, int nq_pad, size_t n_groups, const uint32_t* idx, int nb, float* out, int nbp, hipStream_t stream) {
+    const size_t total = n_groups * (size_t)nbp;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, nq_pad, n_groups, idx, nb, out, nbp);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_gather_rows16(const void* in, size_t row_bytes, const uint32_t* idx, int nb, void* out, hipStream_t stream) {
+    const size_t total = (size_t)nb * (row_bytes / 16);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(in),
+                       row_bytes / 16, idx, nb, reinterpret_cast<uint4*>(out));
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+int launch_scatter_topk(const uint32_t* idx, const uint8_t* take, int nb, int k, const int64_t* src_s, const uint32_t* src_i, int64_t* dst_s,
+                        uint32_t* dst_i, size_t dst_stride, hipStream_t stream) {
+    if (nb == 0 || k == 0) return 0;
+    hipLaunchKernelGGL(scatter_topk_kernel, dim3((unsigned)((nb * k + 255) / 256)), dim3(256), 0, stream, idx, take, nb, k, src_s, src_i, dst_s,
+                       dst_i, dst_stride);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

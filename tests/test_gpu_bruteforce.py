@@ -276,3 +276,29 @@ def test_developer_knobs_do_nothing_in_the_product_build(gpu, mse, orc, monkeypa
     assert np.array_equal(i, wi) and np.array_equal(s, ws)
     se, ie = searcher.bruteforce_topk(q[:8], k, mse.MODE_EXACT)
     assert np.array_equal(ie, wi[:8]) and np.array_equal(se, ws[:8])
+
+
+def test_only_the_queries_that_need_it_are_widened(gpu, mse, orc):
+    """Near-duplicates around ONE query's k-th score (600 copies of its best row, spread over ~600 32-row groups, far more than the
+    k + 8 groups the first round nominates): that query's certificate fails and it alone is carried on through wider rounds (its
+    ten results are the ten lowest ids among the copies, exact ties), the other 199 queries are certified in the first round.
+    Results equal the oracle's in both modes; a second planted query whose copies sit in 2200 groups -- more than the widest nomination
+    (2048) -- ends in the exact scan and is still right."""
+    n, nq, k = 100000, 200, 10
+    base = orc.gen_rows_f16(SEED_BASE, 21, n).copy()
+    q = orc.gen_rows_f16(SEED_QUERY, 21, nq)
+    rng = np.random.default_rng(8)
+    groups = rng.permutation(n // 32)
+    pos = np.sort(groups[:600] * 32 + rng.integers(0, 32, 600))
+    base[pos] = q[3]                                           # 600 exact copies of query 3 itself, one per 32-row group
+    pos2 = np.sort(groups[600:600 + 2200] * 32 + rng.integers(0, 32, 2200))
+    base[pos2] = q[77]                                         # one copy in each of 2200 groups: more than any widening reaches (2048)
+    ws, wi = orc.bruteforce_topk(base, q, k)
+    assert np.array_equal(wi[3], np.sort(pos)[:k].astype(np.uint32)) and np.array_equal(wi[77], np.sort(pos2)[:k].astype(np.uint32))
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    sc, ids = s.bruteforce_topk(q, k, mse.MODE_MFMA)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    st = s.last_stats()
+    assert st["widened_queries"] == 2, st                      # queries 3 and 77, nobody else
+    sc, ids = s.bruteforce_topk(q[:8], k, mse.MODE_EXACT)
+    assert np.array_equal(ids, wi[:8]) and np.array_equal(sc, ws[:8])
