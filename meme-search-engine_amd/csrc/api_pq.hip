@@ -104,49 +104,85 @@ int index_pass_mfma(mse_index* idx, const float* q32_dev, int nqp, int k, uint32
     if (launch_scan_mfma(idx->codes, n, d, s->q_stage.as<uint16_t>(), nq_pad, s->qpacked.p, s->gmax.as<float>(), s->n_cu, st,
                          s->timing ? s->ev0 : nullptr, s->timing ? s->ev1 : nullptr)) return -1;
     bool timing_pending = s->timing;
-    if (s->eps.ensure((size_t)nqp * 4) || s->margin.ensure((size_t)nqp * 4)) return -1;
+    if (s->eps.ensure((size_t)nqp * 8) || s->margin.ensure((size_t)nqp * 8)) return -1;   // second halves: the widening's compact set
     if (launch_query_eps_f32(q32_dev, s->q_stage.as<uint16_t>(), nqp, d, idx->view.norm_bits_dev, 2.8e-4f, s->eps.as<float>(), st)) return -1;
     std::vector<float> margin_h(nqp);
-    int kg = (int)std::min<size_t>(std::max(k + 8, 16), TOPK_KMAX);
-    for (;;) {
-        const int kg_eff = (int)std::min<size_t>(kg, TOPK_KMAX);
-        if (s->gkeys.ensure((size_t)nqp * kg_eff * 4)) return -1;
+    const int kg0 = (int)std::min<size_t>(std::max(k + 8, 16), TOPK_KMAX);
+    // one round: tournament -> rows of the kg best groups re-scored with the f32 queries -> top k -> certificate margins (host)
+    auto round = [&](const float* gm, int gm_pad, const float* q32, int nq, int kg_eff, const float* eps_dev, float* margin_dev, uint32_t* dst_i,
+                     float* dst_k, size_t dst_stride) -> int {
+        if (s->gkeys.ensure((size_t)nq * kg_eff * 4)) return -1;
         uint32_t* gsel = nullptr;
-        LevelRef l0{KEY_F32, s->gmax.p, 1, (size_t)nq_pad, n_groups, true, nq_pad};
-        if (descend(s, l0, nqp, kg_eff, &gsel, s->gkeys.p)) return -1;
+        LevelRef l0{KEY_F32, gm, 1, (size_t)gm_pad, n_groups, true, gm_pad};
+        if (descend(s, l0, nq, kg_eff, &gsel, s->gkeys.p)) return -1;
         const size_t n_cand = (size_t)kg_eff * GROUP_ROWS;
-        if (s->cand_ids.ensure((size_t)nqp * n_cand * 4) || s->cand_scores.ensure((size_t)nqp * n_cand * 4)) return -1;
-        if (launch_expand_groups(gsel, kg_eff, kg_eff, GROUP_ROWS, n, s->cand_ids.as<uint32_t>(), n_cand, nqp, st)) return -1;
-        if (launch_score_rows(idx->codes, n, d, q32_dev, true, s->cand_ids.as<uint32_t>(), (size_t)nqp * n_cand, n_cand, nullptr,
+        if (s->cand_ids.ensure((size_t)nq * n_cand * 4) || s->cand_scores.ensure((size_t)nq * n_cand * 4)) return -1;
+        if (launch_expand_groups(gsel, kg_eff, kg_eff, GROUP_ROWS, n, s->cand_ids.as<uint32_t>(), n_cand, nq, st)) return -1;
+        if (launch_score_rows(idx->codes, n, d, q32, true, s->cand_ids.as<uint32_t>(), (size_t)nq * n_cand, n_cand, nullptr,
                               s->cand_scores.as<float>(), st)) return -1;
         SelectArgs a{};
         a.kind = KEY_F32; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p;
-        a.list_stride = n_cand; a.n_list = n_cand; a.k = k; a.out_ids = out_ids; a.out_keys = out_keys; a.out_stride = out_stride; a.nq = nqp;
+        a.list_stride = n_cand; a.n_list = n_cand; a.k = k; a.out_ids = dst_i; a.out_keys = dst_k; a.out_stride = dst_stride; a.nq = nq;
         if (launch_select(a, st)) return -1;
-        if (launch_margin_f32(out_ids, out_keys, out_stride, k, nqp, s->gkeys.as<float>(), kg_eff, kg_eff, n_groups, s->eps.as<float>(),
-                              s->margin.as<float>(), st)) return -1;
-        MSE_HIP_TRY(hipMemcpyAsync(margin_h.data(), s->margin.p, (size_t)nqp * 4, hipMemcpyDeviceToHost, st));
+        if (launch_margin_f32(dst_i, dst_k, dst_stride, k, nq, s->gkeys.as<float>(), kg_eff, kg_eff, n_groups, eps_dev, margin_dev, st)) return -1;
+        MSE_HIP_TRY(hipMemcpyAsync(margin_h.data(), margin_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
         MSE_HIP_TRY(hipStreamSynchronize(st));
-        if (timing_pending) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) { s->scan_ms_total += ms; s->scan_launches++; }
-            timing_pending = false;
-        }
-        uint32_t bad = 0;
-        for (int i = 0; i < nqp; i++) bad += !(margin_h[i] > 0.0f);
         s->last_max_groups = std::max<uint32_t>(s->last_max_groups, (uint32_t)kg_eff);
-        if (bad == 0 || (size_t)kg_eff >= n_groups) return 0;
-        s->last_widened = std::max(s->last_widened, bad);
-        if (kg_eff >= TOPK_KMAX) {
-            for (int q0 = 0; q0 < nqp; q0 += 8) {
-                const int m = std::min(8, nqp - q0);
-                if (index_pass_exact(idx, q32_dev + (size_t)q0 * d, m, k, out_ids + (size_t)q0 * out_stride,
-                                     out_keys + (size_t)q0 * out_stride, out_stride)) return -1;
-            }
-            return 0;
+        return 0;
+    };
+    if (round(s->gmax.as<float>(), nq_pad, q32_dev, nqp, kg0, s->eps.as<float>(), s->margin.as<float>(), out_ids, out_keys, out_stride)) return -1;
+    if (timing_pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) { s->scan_ms_total += ms; s->scan_launches++; }
+        timing_pending = false;
+    }
+    std::vector<uint32_t> bad;
+    for (int i = 0; i < nqp; i++)
+        if (!(margin_h[i] > 0.0f)) bad.push_back((uint32_t)i);
+    if (bad.empty() || (size_t)kg0 >= n_groups) return 0;
+    s->last_widened = std::max<uint32_t>(s->last_widened, (uint32_t)bad.size());
+    // only the queries whose certificate failed go on, as a compact set (api.hip mfma_pass has the same structure)
+    const int nb = (int)bad.size(), nbp = (nb + 31) / 32 * 32;
+    if (s->widx.ensure((size_t)nb * 5) || s->wq.ensure((size_t)nb * d * 6) || s->wg.ensure(n_groups * (size_t)nbp * 4) ||
+        s->wout.ensure((size_t)nb * k * 8)) return -1;
+    uint32_t* idx_dev = s->widx.as<uint32_t>();
+    uint8_t* take_dev = reinterpret_cast<uint8_t*>(idx_dev + nb);
+    float* wq32 = s->wq.as<float>();
+    uint16_t* wq16 = reinterpret_cast<uint16_t*>(s->wq.as<char>() + (size_t)nb * d * 4);
+    MSE_HIP_TRY(hipMemcpyAsync(idx_dev, bad.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+    if (launch_gather_rows16(q32_dev, (size_t)d * 4, idx_dev, nb, wq32, st)) return -1;
+    if (launch_gather_rows16(s->q_stage.p, (size_t)d * 2, idx_dev, nb, wq16, st)) return -1;
+    if (launch_gather_columns(s->gmax.as<float>(), nq_pad, n_groups, idx_dev, nb, s->wg.as<float>(), nbp, st)) return -1;
+    float* eps2 = s->eps.as<float>() + nqp;
+    float* margin2 = s->margin.as<float>() + nqp;
+    if (launch_query_eps_f32(wq32, wq16, nb, d, idx->view.norm_bits_dev, 2.8e-4f, eps2, st)) return -1;
+    uint32_t* w_i = s->wout.as<uint32_t>();
+    float* w_k = reinterpret_cast<float*>(s->wout.as<char>() + (size_t)nb * k * 4);
+    std::vector<uint8_t> open_q(nb, 1);
+    int kg = kg0 * 4;
+    for (;;) {
+        const int kg_eff = (int)std::min<size_t>(kg, TOPK_KMAX);
+        if (round(s->wg.as<float>(), nbp, wq32, nb, kg_eff, eps2, margin2, w_i, w_k, (size_t)k)) return -1;
+        std::vector<uint8_t> take(nb, 0);
+        int still = 0;
+        for (int j = 0; j < nb; j++) {
+            if (!open_q[j]) continue;
+            if (margin_h[j] > 0.0f || (size_t)kg_eff >= n_groups) { take[j] = 1; open_q[j] = 0; } else still++;
         }
+        MSE_HIP_TRY(hipMemcpyAsync(take_dev, take.data(), (size_t)nb, hipMemcpyHostToDevice, st));
+        if (launch_scatter_rows4(idx_dev, take_dev, nb, k, w_i, out_ids, out_stride, st) ||
+            launch_scatter_rows4(idx_dev, take_dev, nb, k, w_k, out_keys, out_stride, st)) return -1;
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        if (still == 0) return 0;
+        if (kg_eff >= TOPK_KMAX) break;
         kg = kg_eff * 4;
     }
+    for (int j = 0; j < nb; j++) {   // cannot widen further: the exact pass, straight into the query's own output rows
+        if (!open_q[j]) continue;
+        if (index_pass_exact(idx, wq32 + (size_t)j * d, 1, k, out_ids + (size_t)bad[j] * out_stride, out_keys + (size_t)bad[j] * out_stride,
+                             out_stride)) return -1;
+    }
+    return 0;
 }
 
 // one engine call for a group of requests (worker thread; every caller of the group holds the shared lock)

@@ -86,6 +86,8 @@ int launch_gather_rows16(const void* in, size_t row_bytes, const uint32_t* idx, 
 int launch_scatter_topk(const uint32_t* idx, const uint8_t* take, int nb, int k, const int64_t* src_s, const uint32_t* src_i, int64_t* dst_s,
                         uint32_t* dst_i, size_t dst_stride, hipStream_t stream);
 
+int launch_scatter_rows4(const uint32_t* idx, const uint8_t* take, int nb, int k, const void* src, void* dst, size_t dst_stride, hipStream_t stream);
+
 // ---- pq.hip ----------------------------------------------------------------------------------
 int launch_pq_transform(const float* T, int d, const float* x, size_t n, float* out, hipStream_t stream);
 int launch_pq_transform_vec(const float* T_transposed, int d, const float* x, float* out, hipStream_t stream);   // n = 1, same arithmetic

@@ -532,6 +532,23 @@ __global__ void scatter_topk_kernel(const uint32_t* __restrict__ idx, const uint
     dst_i[(size_t)idx[j] * dst_stride + i] = src_i[t];
 }
 
+// dst row idx[j] = src row j (rows of k elements of 4 bytes) for the j with take[j] != 0 (take == nullptr: all)
+__global__ void scatter_rows4_kernel(const uint32_t* __restrict__ idx, const uint8_t* __restrict__ take, int nb, int k, const uint32_t* __restrict__ src,
+                                     uint32_t* __restrict__ dst, size_t dst_stride) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * k) return;
+    const int j = t / k, i = t % k;
+    if (take && !take[j]) return;
+    dst[(size_t)idx[j] * dst_stride + i] = src[t];
+}
+int launch_scatter_rows4(const uint32_t* idx, const uint8_t* take, int nb, int k, const void* src, void* dst, size_t dst_stride, hipStream_t stream) {
+    if (nb == 0 || k == 0) return 0;
+    hipLaunchKernelGGL(scatter_rows4_kernel, dim3((unsigned)((nb * k + 255) / 256)), dim3(256), 0, stream, idx, take, nb, k,
+                       reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), dst_stride);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_margin_f32(const uint32_t* sel_ids, const float* sel_keys, size_t sel_stride, int k, int nq, const float* group_keys,
                       size_t gk_stride, int kg, size_t n_groups, const float* eps, float* margin, hipStream_t stream) {
     if (nq == 0 || k == 0) return 0;

@@ -301,3 +301,25 @@ def test_requests_of_many_sizes_share_the_queue(gpu, mse, orc):
     assert st["queries"] == 3 * 700 and st["requests"] == 3 * len(spans)
     assert st["max_pass_queries"] >= 300            # the 300-query request went through as one pass of its own
     disp.close()
+
+
+def test_index_near_duplicates_widen_only_their_query(gpu, mse, orc):
+    """The FAISS surface with re-posted rows: 700 copies of one row (one per 32-row group) make ONE query of a 40-query batch fail
+    its first certificate -- it alone is carried through the wider rounds; a second query with copies in 2200 groups (beyond the
+    widest nomination) ends in the exact pass.  Labels (lowest ids among the ties first) and float distances equal the oracle's."""
+    rng = np.random.default_rng(17)
+    n, d, nq, k = 100_000, 256, 40, 10
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    groups = rng.permutation(n // 32)
+    pos5 = groups[:700] * 32 + rng.integers(0, 32, 700)
+    pos9 = groups[700:2900] * 32 + rng.integers(0, 32, 2200)
+    x[pos5] = (q[5] / np.linalg.norm(q[5]) * 0.9).astype(np.float32)
+    x[pos9] = (q[9] / np.linalg.norm(q[9]) * 0.9).astype(np.float32)
+    idx = mse.ScalarQuantizerIndex(d)
+    for lo in range(0, n, 8192):
+        idx.add(x[lo:lo + 8192])
+    res = idx.search(q, k)
+    wd, wl = orc.index_search(orc.f16_bits(x), q, k, order=0)
+    assert np.array_equal(wl[5], np.sort(pos5)[:k]) and np.array_equal(wl[9], np.sort(pos9)[:k])
+    assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
