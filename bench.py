@@ -234,7 +234,7 @@ def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rou
     want_s, want_i = checker.bruteforce_topk(q, k, mse.MODE_MFMA)
     checker.close()
     qdev.close()
-    disp = mse.Dispatcher(vecs)                                          # defaults: 256 queries per pass, wait budget from the row count
+    disp = mse.Dispatcher(vecs)                                          # defaults: one full pass (320 queries) per gather, wait budget from the row count
     disp.search(q[0], k)                                                 # lone caller: answered at once; allocates the worker's scratch
     points = []
     for T in thread_counts:
@@ -259,7 +259,7 @@ def concurrent_callers_bench(vecs, k, headline_qps, thread_counts=(64, 512), rou
     return {"metric": "queries/s through host pointers, one query per call from T native threads (closed loop), coalesced behind the C ABI",
             "threads": best["threads"], "queries_per_s": best["queries_per_s"], "latency_ms": best["latency_ms"],
             "vs_resident_batch_headline": best["vs_resident_batch_headline"], "points": points, "k": k,
-            "dispatcher": {"max_queries_per_pass": 256, "passes_started_by_wait_budget": st["deadline_fires"], "requests_repeated_alone": st["retried_alone"]},
+            "dispatcher": {"max_queries_per_pass": int(ffi.lib().mse_queries_per_pass_max(D)), "passes_started_by_wait_budget": st["deadline_fires"], "requests_repeated_alone": st["retried_alone"]},
             "config": {"workload": f"{len(vecs)} x {D} fp16 rows resident; each call: 1 query of {D} f16 from host memory in, top-{k} (i64 scores, u32 ids) to host memory out"}}
 
 
@@ -1022,7 +1022,7 @@ def main():
     n_total = int(args.rows)
     auto_nq = args.queries <= 0
     nq, k = (256 if auto_nq else args.queries), args.k
-    tile = 256 if nq > 192 else 192 if nq > 128 else 128
+    tile = 320 if nq > 256 else 256 if nq > 192 else 192 if nq > 128 else 128
     lo, hi = shard.shard_range(n_total, rank, n_gpus) if not in_process else shard.shard_range(n_total, 0, n_gpus)
     free_b, total_b = ffi.sz(), ffi.sz()
     ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
@@ -1037,9 +1037,10 @@ def main():
             raise SystemExit(f"shard does not fit: need {need / 1e9:.0f} GB, free {free_b.value / 1e9:.0f} GB")
 
     n_batches = 4
-    qsets = mse.VectorList.generate(SEED_QUERY, 0, nq * n_batches, D)  # query batches, resident in HBM (root device)
-    out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-    out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    nq_room = max(nq, 320) if auto_nq else nq                          # the widest pass the pick below may choose
+    qsets = mse.VectorList.generate(SEED_QUERY, 0, nq_room * n_batches, D)  # query batches, resident in HBM (root device)
+    out_s = torch.empty((nq_room, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((nq_room, k), dtype=torch.int32, device="cuda")
     comm = group = None
     queries_pick = None
     host_exchange = None
@@ -1092,7 +1093,7 @@ def main():
             # twice the queries from the same stream but is bound by the power budget; whichever is faster is the
             # headline, the other is reported beside it
             pick = {}
-            for cand in (128, 192, 256):
+            for cand in (128, 192, 256, 320):
                 for rep_i in range(4):
                     if rep_i == 1:
                         torch.cuda.synchronize()
@@ -1101,8 +1102,8 @@ def main():
                 torch.cuda.synchronize()
                 pick[cand] = cand * 3 / (time.perf_counter() - tp)
             nq = max(pick, key=pick.get)
-            tile = 256 if nq > 192 else 192 if nq > 128 else 128
-            queries_pick = {"rule": "the fastest of 128 / 192 / 256 queries per pass over 3 timed passes each", "queries_per_s": pick, "chosen": nq}
+            tile = 320 if nq > 256 else 256 if nq > 192 else 192 if nq > 128 else 128
+            queries_pick = {"rule": "the fastest of 128 / 192 / 256 / 320 queries per pass over 3 timed passes each", "queries_per_s": pick, "chosen": nq}
         if world > 1:
             # the exchange of the product path: RCCL through the C ABI.  Every rank reports whether its communicator came up; if any
             # did not (no usable bootstrap interface, ...) ALL ranks fall back to carrying the same packed blocks over the gloo
@@ -1325,7 +1326,7 @@ def main():
         avg_scan_ms = scan_ms / max(scan_launches, 1)
         bytes_per_launch = (hi - lo) * D * 2
         achieved = bytes_per_launch / (avg_scan_ms * 1e-3) / 1e9 if scan_launches else None
-        mfma_tflops = 2.0 * (hi - lo) * D * min(nq, 256) / (avg_scan_ms * 1e-3) / 1e12 if scan_launches else None
+        mfma_tflops = 2.0 * (hi - lo) * D * min(nq, tile) / (avg_scan_ms * 1e-3) / 1e12 if scan_launches else None
         if alt:
             alt["roofline"] = {"bound": "hbm", "achieved": bytes_per_launch / (alt["avg_launch_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_per_launch / (alt["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -1334,8 +1335,9 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-            if pm["rows"] == hi - lo and pm["queries_per_launch"] == min(nq, 256):
-                traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
+            pp = pm["per_pass"].get(str(min(nq, tile))) if pm["rows"] == hi - lo else None
+            if pp:
+                traffic = pp["hbm_read_bytes_per_launch"] + pp["hbm_write_bytes_per_launch"]
         except Exception:
             traffic = None
         line = {
@@ -1358,14 +1360,15 @@ def main():
                                                                           " + peer-mapped gather of [Q,k] records" if in_process else ""),
                        "rows_total": n_total, "rows_per_gpu": hi - lo, "queries_per_step": nq, "queries_per_step_pick": queries_pick, "k": k,
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
-            "roofline": {"bound": "hbm", "kernel": {256: "scan_mfma2d_kernel<3,16>", 192: "scan_mfma_kernel<3,12>", 128: "scan_mfma_kernel<3,8>"}.get(tile, "scan_mfma") + f" ({nq} queries per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": {320: "scan_mfma_kernel<2,20>", 256: "scan_mfma2d_kernel<3,16>", 192: "scan_mfma_kernel<3,12>", 128: "scan_mfma_kernel<3,8>"}.get(tile, "scan_mfma") + f" ({nq} queries per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms, "queries_per_launch": min(nq, 256),
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms, "queries_per_launch": min(nq, tile),
                          # the same launch against the matrix cores: 2*rows*1152*queries flops; dense f16 peak 2500 TFLOP/s
                          "mfma_tflops": mfma_tflops, "mfma_frac": (mfma_tflops / 2500.0) if mfma_tflops else None,
-                         "note": "256 queries per pass: neither HBM nor the matrix cores are saturated; the pass is bound by the "
-                                 "power budget (rocm-smi beside it: 1360 W of the 1400 W board limit, engine clock 1.5 GHz of 2.4 -- "
+                         "note": "256 / 320 queries per pass: neither HBM nor the matrix cores are saturated; the pass is bound by the "
+                                 "power budget (rocm-smi beside it: 1370 W of the 1400 W board limit, engine clock 1.5-1.6 GHz of 2.4 -- "
+                                 "profiles/r04_scan_variants.txt; every 64 more queries per pass cost 9-11 ms on top of the 40 ms stream; "
                                  "profiles/r02_power_clocks.txt; the same kernel on all-zero rows is 17-20 % faster; tilings with a third "
                                  "fewer LDS reads, deeper prefetch or no barrier at all take the same 8.9 M cycles per 1e7 rows -- "
                                  "profiles/r03_scan_variants.txt, DESIGN.md 3.1).  hbm_bound_point = the 128-query pass (HBM-bound).",

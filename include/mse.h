@@ -83,6 +83,11 @@ void* mse_searcher_stream(const mse_searcher* s);
 #define MSE_MODE_EXACT 1  /* every row scored in the reference order on the vector ALU */
 #define MSE_MODE_MFMA 2   /* f16 MFMA scan for candidates + exact re-score + certificate */
 
+/* Most queries one matrix-core pass over the rows serves at vector width d (320; 256 when d / 64 is odd): batches are cut into
+ * passes of this size, and it is the dispatcher's default gather size.  Callers that size their own batches gain nothing
+ * from going beyond a multiple of it. */
+size_t mse_queries_per_pass_max(size_t d);
+
 /* Brute-force top-k: the scan + ranking of `evaluate` (src/query_disk_index.rs:262-273) for a
  * batch of f16 queries.  scores/ids are [nq][k], best first; unfilled slots (k > n_rows) hold
  * INT64_MIN / MSE_ID_NONE.  Returned ids/scores are identical in every mode. */

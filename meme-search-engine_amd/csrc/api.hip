@@ -160,13 +160,13 @@ static int exact_pass(mse_searcher* s, int nq_pass, int k, uint64_t id_offset, i
                            nullptr, 0, 0, 0, nullptr, nullptr, s->stream);
 }
 
-// MFMA mode for up to mfma_query_tile() queries (device pointer to [nq][d] f16, contiguous)
+// MFMA mode for up to mfma_query_tile(d) queries (device pointer to [nq][d] f16, contiguous)
 static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k, uint64_t id_offset,
                      int64_t* out_scores, uint32_t* out_ids, size_t out_stride) {
     const mse_base* b = s->base;
     hipStream_t st = s->stream;
     const int d = (int)b->d;
-    const int nq_pad = mfma_pad(nq_pass, d);   // one pass over the rows serves up to 256 queries (padded to 128 / 192 / 256)
+    const int nq_pad = mfma_pad(nq_pass, d);   // one pass over the rows serves up to 320 queries (padded to 128 / 192 / 256 / 320)
     if (ensure_base_norm(b, st)) return -1;
     // padded query tile
     if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;
@@ -451,6 +451,8 @@ int mse_searcher_last_stats(const mse_searcher* s, uint32_t* n_widened, uint32_t
     return 0;
 }
 
+size_t mse_queries_per_pass_max(size_t d) { return d && d % 64 == 0 ? (size_t)mfma_query_tile((int)d) : 0; }
+
 int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t nq, size_t k, int mode,
                                 uint64_t id_offset, void* scores_dev, void* ids_dev) {
     if (!s) return fail("null searcher");
@@ -484,7 +486,7 @@ int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t
         return 0;
     }
     if (mode == MSE_MODE_MFMA) {
-        const int tile = mfma_query_tile();
+        const int tile = mfma_query_tile((int)d);
         for (size_t q0 = 0; q0 < nq; q0 += tile) {
             const int nqp = (int)std::min<size_t>(tile, nq - q0);
             if (mfma_pass(s, q + q0 * d, nqp, (int)k, id_offset, out_scores + q0 * k, out_ids + q0 * k, k)) return -1;
@@ -499,7 +501,7 @@ int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t
 int mse_debug_mfma_group_max(mse_searcher* s, const uint16_t* queries, size_t nq, float* out) {
     if (!s || !s->base) return fail("null searcher");
     const mse_base* b = s->base;
-    if (nq == 0 || nq > 256 || b->n == 0) return fail("mfma_group_max: 1..256 queries, non-empty base");
+    if (nq == 0 || nq > (size_t)mfma_query_tile((int)b->d) || b->n == 0) return fail("mfma_group_max: 1..320 queries (256 when d / 64 is odd), non-empty base");
     const int d = (int)b->d;
     const int nq_pad = mfma_pad((int)nq, d);
     const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;

@@ -211,7 +211,7 @@ int index_run_group(mse_index* idx, DispatchReq* const* reqs, size_t n_req) {
     // same rule as the f16 dispatcher (dispatch.hip): the matrix-core pass for more than 8 queries, and for any count once the
     // rows have outgrown the caches
     const bool mfma = total > 8 || n >= ((size_t)1 << 22);
-    const size_t tile = mfma ? (size_t)mfma_query_tile() : 8;
+    const size_t tile = mfma ? (size_t)mfma_query_tile((int)d) : 8;
     for (size_t q0 = 0; q0 < total; q0 += tile) {
         const int m = (int)std::min(tile, total - q0);
         const int rc = mfma ? index_pass_mfma(idx, idx->q32.as<float>() + q0 * d, m, (int)kmax, ids_dev + q0 * kmax, keys_dev + q0 * kmax, kmax)
@@ -273,7 +273,7 @@ mse_index* mse_index_new(int d) {
     idx->scratch->base = &idx->view;
     const int device = idx->device;
     // at most one matrix-core pass worth of queries per gather; the wait budget follows the row count (add)
-    idx->co.reset(new Coalescer((size_t)mfma_query_tile(), 200, [idx](std::vector<DispatchReq*>& b) { index_run_batch(idx, b); },
+    idx->co.reset(new Coalescer((size_t)mfma_query_tile((int)idx->view.d), 200, [idx](std::vector<DispatchReq*>& b) { index_run_batch(idx, b); },
                                 [device] { (void)hipSetDevice(device); }));
     return idx;
 }

@@ -216,7 +216,7 @@ mse_dispatcher* mse_dispatcher_new(const mse_base* b, size_t max_queries_per_pas
     mse_dispatcher* D = new (std::nothrow) mse_dispatcher();
     if (!D) { fail("out of host memory"); return nullptr; }
     D->base = b;
-    const size_t mq = max_queries_per_pass ? max_queries_per_pass : (size_t)mfma_query_tile();
+    const size_t mq = max_queries_per_pass ? max_queries_per_pass : (size_t)mfma_query_tile((int)b->d);
     const uint32_t wait = max_wait_us ? max_wait_us : default_wait_us(b->n, b->d * 2);
     const int device = b->device;
     std::promise<void> started;

@@ -128,7 +128,7 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
                      void* packed_scratch, float* group_max, int n_cu, hipStream_t stream,
                      hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);  // events bracket the scan kernel only
 size_t mfma_packed_bytes(int d);
-int mfma_query_tile();  // queries handled per pass
+int mfma_query_tile(int d);  // most queries one pass handles at width d (320 or 256)
 int mfma_pad(int nq, int d);   // padded query count of a pass of nq <= 256 queries: 128, 192 or 256
 
 }  // namespace mse

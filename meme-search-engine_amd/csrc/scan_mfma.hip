@@ -688,15 +688,17 @@ int launch_2d(size_t grid, hipStream_t stream, const uint16_t* base, size_t n_ro
 
 }  // namespace
 
-int mfma_query_tile() { return 256; }   // largest pass; passes of <= 128 queries use the 128-query kernel
+// largest pass: 320 queries on the two-stage ring (the K-block count must be even), else 256
+int mfma_query_tile(int d) { return (d / KB) % 2 == 0 ? 320 : 256; }
 // padded query count of a pass of nq queries: 128, 192 (three-stage ring only: the K-block count must divide by 3) or 256
 int mfma_pad(int nq, int d) {
     if (nq <= 128) return 128;
     if (nq <= 192 && (d / KB) % 3 == 0) return 192;
-    return 256;
+    if (nq <= 256 || (d / KB) % 2 != 0) return 256;
+    return 320;
 }
 
-size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * 256 * 128; }
+size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * 320 * 128; }
 
 // packed_scratch: mfma_packed_bytes(d) bytes of device scratch owned by the caller (per searcher)
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
@@ -704,8 +706,8 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
                      hipEvent_t ev_end) {
     if (n_rows == 0) return 0;
     if (d % 64 != 0 || d <= 0 || d > D_MAX) return fail("vector width must be a positive multiple of 64");
-    if (nq_pad != 128 && nq_pad != 256 && !(nq_pad == 192 && (d / KB) % 3 == 0))
-        return fail("scan_mfma: query tile must be padded to 128, 192 (K blocks divisible by 3) or 256");
+    if (nq_pad != 128 && nq_pad != 256 && !(nq_pad == 192 && (d / KB) % 3 == 0) && !(nq_pad == 320 && (d / KB) % 2 == 0))
+        return fail("scan_mfma: query tile must be padded to 128, 192 (K blocks divisible by 3), 256 or 320 (K blocks even)");
     uint4* packed = reinterpret_cast<uint4*>(packed_scratch);
     hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, nq_pad, packed);
     if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
@@ -744,7 +746,11 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
         return 0;
     }
 #endif
-    if (nq_pad == 192) {
+    if (nq_pad == 320) {
+        // 20 column tiles per wave (32 rows x 320 queries, 160 accumulator registers of 252 used: 24 tiles spill and run 2.6x
+        // slower), two-stage row ring: 2 x 40 KiB of query tiles + 8 x 2 x 4 KiB = 144 KiB of LDS.
+        rc = launch_variant<2, 20, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    } else if (nq_pad == 192) {
         // 12 column tiles on the one-dimensional wave split (32 rows x 192 queries per wave, 96 accumulators): the point between
         // the HBM-bound 128-query pass and the power-bound 256-query pass (profiles/r04_scan_variants.txt)
         rc = launch_variant<3, 12, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mse_device_synchronize": (C.c_int, []),
     "mse_device_mem_info": (C.c_int, [C.POINTER(sz), C.POINTER(sz)]),
     "mse_version": (C.c_char_p, []),
+    "mse_queries_per_pass_max": (sz, [sz]),
     "mse_scale_dot_f32": (C.c_int64, [C.c_float]),
     "mse_scale_dot_f64": (C.c_int64, [C.c_double]),
     "mse_base_from_host": (vp, [u16p, sz, sz]),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 profiles -> gpurun_out/r04/ (summaries are copied into profiles/ by hand):
 #   bench_kernel_stats.txt   rocprofv3 --kernel-trace --stats of the bench command's scan legs (1e8 rows)
-#   scan_variants.txt        128 / 192 / 256 queries per pass with clock and power beside them
+#   scan_variants.txt        128 / 192 / 256 / 320 queries per pass with clock and power beside them
 #   pq_kernel_stats.txt      kernel stats of the PQ flat-scan bench at 1e8 codes
 #   pq_pmc.txt, pq_traffic   PMC passes of the PQ scan (2e7 codes: unit utilisation; 1e8 codes: FETCH_SIZE / WRITE_SIZE)
 cd /tmp && export TMPDIR=/tmp
@@ -47,20 +47,22 @@ for k, name in (("x8", "pq_scan64x4"), ("x4", "pq_scan64x4_four_per_pass"), ("x1
         f = pq[k]["FETCH_SIZE"]; w = pq[k]["WRITE_SIZE"] or [0.0]
         out[name] = {"vectors": 100000000, "algorithmic_bytes_per_launch": 6800000000, "dispatches": len(f),
                      "hbm_read_bytes_per_launch": sum(f) / len(f) * 2048, "hbm_write_bytes_per_launch": sum(w) / len(w) * 1024}
-sc = collect("pmcs_", lambda k: "256" if "scan_mfma2d_kernel" in k else "128" if "scan_mfma_kernel<3, 8" in k else "192" if "scan_mfma_kernel<3, 12" in k else None)
+sc = collect("pmcs_", lambda k: "320" if "scan_mfma_kernel<2, 20" in k else "256" if "scan_mfma2d_kernel" in k else "128" if "scan_mfma_kernel<3, 8" in k else "192" if "scan_mfma_kernel<3, 12" in k else None)
 out["rows"] = 100000000
 out["algorithmic_bytes_per_launch"] = 230400000000
 out["per_pass"] = {}
-for k in ("256", "192", "128"):
+for k in ("320", "256", "192", "128"):
     if sc[k]["FETCH_SIZE"]:
         # only the full-size launches (the pick loop and the timed loop run at 1e8 rows)
         f = [v for v in sc[k]["FETCH_SIZE"] if v * 2048 > 1e11]; w = [v for v in sc[k]["WRITE_SIZE"] if v > 0] or [0.0]
         if f:
             out["per_pass"][k] = {"dispatches": len(f), "hbm_read_bytes_per_launch": sum(f) / len(f) * 2048, "hbm_write_bytes_per_launch": sum(w) / len(w) * 1024}
-if "256" in out["per_pass"]:
-    out["queries_per_launch"] = 256
-    out["hbm_read_bytes_per_launch"] = out["per_pass"]["256"]["hbm_read_bytes_per_launch"]
-    out["hbm_write_bytes_per_launch"] = out["per_pass"]["256"]["hbm_write_bytes_per_launch"]
+for k in ("320", "256"):   # the headline pass: the widest one measured
+    if k in out["per_pass"]:
+        out["queries_per_launch"] = int(k)
+        out["hbm_read_bytes_per_launch"] = out["per_pass"][k]["hbm_read_bytes_per_launch"]
+        out["hbm_write_bytes_per_launch"] = out["per_pass"][k]["hbm_write_bytes_per_launch"]
+        break
 print(json.dumps(out, indent=1))
 PY
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcs_FETCH_SIZE $OUT/pmcs_WRITE_SIZE

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Queries per pass of the brute-force scan at the metric's size: 128 / 192 / 256 queries per pass over 1e8 x 1152 rows, each run
+"""Queries per pass of the brute-force scan at the metric's size: 128 / 192 / 256 / 320 queries per pass over 1e8 x 1152 rows, each run
 for a few seconds with the engine clock and socket power sampled beside it (rocm-smi).  One text block per point -> stdout.
   python scripts/scan_pass_probe.py [rows] [seconds per point]"""
 import json
@@ -34,11 +34,11 @@ def sample():
 
 vecs = mse.VectorList.generate(0x5EED0001, 0, rows, D)
 s = mse.Searcher(vecs)
-qs = mse.VectorList.generate(0x5EED0002, 0, 1024, D)
-out_s = torch.empty((256, 10), dtype=torch.int64, device="cuda")
-out_i = torch.empty((256, 10), dtype=torch.int32, device="cuda")
+qs = mse.VectorList.generate(0x5EED0002, 0, 2048, D)
+out_s = torch.empty((384, 10), dtype=torch.int64, device="cuda")
+out_i = torch.empty((384, 10), dtype=torch.int32, device="cuda")
 print(f"# scripts/scan_pass_probe.py {rows} {secs}: one MI355X, {rows} x {D} fp16 rows resident, top-10, matrix-core mode; sclk / socket power by rocm-smi every 0.5 s")
-for nq in (128, 192, 256):
+for nq in (128, 192, 256, 320):
     for i in range(3):
         s.bruteforce_topk_dev(qs.device_ptr, nq, 10, out_s.data_ptr(), out_i.data_ptr(), mse.MODE_MFMA)
     torch.cuda.synchronize()

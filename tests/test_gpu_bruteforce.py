@@ -87,7 +87,7 @@ def test_scores_match_oracle(gpu, mse, orc, n, d):
 
 @pytest.mark.parametrize("mode", ["exact", "mfma"])
 @pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (5, 3, 10), (31, 2, 10), (33, 9, 5), (1000, 17, 10), (5000, 1, 1000),
-                                    (20000, 130, 10), (40000, 8, 100), (30000, 256, 10), (9000, 300, 7), (15000, 192, 10), (3333, 160, 3)])
+                                    (20000, 130, 10), (40000, 8, 100), (30000, 256, 10), (9000, 300, 7), (15000, 192, 10), (3333, 160, 3), (21000, 320, 10), (5000, 330, 4), (7000, 700, 5)])
 def test_topk_matches_oracle(gpu, mse, orc, mode, n, nq, k):
     base = orc.gen_rows_f16(SEED_BASE, 0, n)
     q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
@@ -97,6 +97,18 @@ def test_topk_matches_oracle(gpu, mse, orc, mode, n, nq, k):
     ws, wi = orc.bruteforce_topk(base, q, k)
     assert np.array_equal(ids, wi)
     assert np.array_equal(sc, ws)
+
+
+@pytest.mark.parametrize("d,nq", [(192, 300), (64, 321), (128, 320), (256, 577), (448, 290)])
+def test_wide_passes_at_other_widths(gpu, mse, orc, d, nq):
+    # the 320-query pass needs an even number of 64-element K blocks; odd widths stay on 256-query passes
+    assert mse.ffi.lib().mse_queries_per_pass_max(d) == (320 if (d // 64) % 2 == 0 else 256)
+    base = orc.gen_rows_f16(SEED_BASE, 0, 6000, d)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq, d)
+    s = mse.Searcher(mse.VectorList.from_f16s(base, d))
+    sc, ids = s.bruteforce_topk(q, 6, mse.MODE_MFMA)
+    ws, wi = orc.bruteforce_topk(base, q, 6)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
 
 
 def test_ties_break_by_lower_id(gpu, mse, orc):
