@@ -646,6 +646,27 @@ static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, con
         s->out_ids.ensure(Q * r * 4) || s->sel_keys.ensure(Q * r * 8) || s->misc.ensure(Q * k * 4) || s->scores.ensure(Q * k * 8)) return -1;
     uint32_t* gsel = nullptr;
     LevelRef l0{KEY_U32, s->gmax.p, 1, (size_t)NQ, n_groups, false, 0};   // group-major: element (q, g) at gmax[g * NQ + q]
+#ifdef MSE_DEV_KERNELS
+    // developer library, MSE_PQ_TAIL_SKIP=mask: the scan WITHOUT parts of its tail (answers are garbage, every query is reported
+    // certified): what the tail costs the scans that run beside it.  1 tournament, 2 expand + re-score, 4 exact top-r, 8 certificate
+    static const int tail_skip = getenv("MSE_PQ_TAIL_SKIP") ? atoi(getenv("MSE_PQ_TAIL_SKIP")) : 0;
+    if (tail_skip) {
+        if (!(tail_skip & 1) && descend(s, l0, NQ, (int)n_sel, &gsel, s->gkeys.p)) return -1;
+        if (!(tail_skip & 2) && gsel) {
+            if (launch_expand_groups(gsel, n_sel, n_nom, 64, c->n, s->cand_ids.as<uint32_t>(), n_cand, NQ, st)) return -1;
+            if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), n_cand, desc,
+                              (int)c->n_desc, scales_dev, s->cand_scores.as<int64_t>(), s->n_cu, st, NQ, n_cand)) return -1;
+        }
+        if (!(tail_skip & 4)) {
+            SelectArgs a{};
+            a.kind = KEY_I64; a.list_ids = s->cand_ids.as<uint32_t>(); a.list_keys = s->cand_scores.p; a.list_stride = n_cand;
+            a.n_list = n_cand; a.k = (int)r; a.out_ids = s->out_ids.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = r; a.nq = NQ;
+            if (launch_select(a, st)) return -1;
+        }
+        MSE_HIP_TRY(hipMemsetAsync(flags_dev, 1, (size_t)NQ * sizeof(int), st));
+        return 0;
+    }
+#endif
     if (descend(s, l0, NQ, (int)n_sel, &gsel, s->gkeys.p)) return -1;                      // gsel [NQ][n_sel], gkeys u32 [NQ][n_sel]
     if (launch_expand_groups(gsel, n_sel, n_nom, 64, c->n, s->cand_ids.as<uint32_t>(), n_cand, NQ, st)) return -1;
     if (launch_pq_adc(lut_dev, (int)pq->n_chunks, (int)pq->n_centroids, c->codes, c->n, s->cand_ids.as<uint32_t>(), n_cand, desc,
@@ -736,7 +757,11 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
         DevBuf* qfs[3] = {&s->q_stage, &pq->qf2, &pq->qf3};
         if (nq >= 4) {
             mse_searcher** extra[2] = {&pq->lane2, &pq->lane3};
+#ifdef MSE_DEV_KERNELS
+            static const int n_extra = getenv("MSE_PQ_LANES") ? std::min(std::max(atoi(getenv("MSE_PQ_LANES")) - 1, 0), 2) : 1;   // developer library: 1-3 streams
+#else
             const int n_extra = 1;
+#endif
             bool lanes_ok = true;
             for (int e = 0; e < n_extra && lanes_ok; e++) {
                 mse_searcher*& ln = *extra[e];

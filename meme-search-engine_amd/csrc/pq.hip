@@ -209,12 +209,55 @@ __global__ __launch_bounds__(1024) void pq_adc_kernel(const float* __restrict__ 
                                                      const uint32_t* __restrict__ ids, size_t n,
                                                      const uint8_t* __restrict__ desc, int n_desc,
                                                      const float* __restrict__ scales, int64_t* __restrict__ out,
-                                                     size_t q_stride /* blockIdx.y = query: ids / out advance by this, lut by one table */) {
+                                                     size_t q_stride /* blockIdx.y = query: ids / out advance by this, lut by one table */
+#ifdef MSE_DEV_KERNELS
+                                                     , int g_adc_variant   // developer library: timing probes beside a running scan (nothing written): see launch_pq_adc
+#endif
+                                                     ) {
     extern __shared__ __attribute__((aligned(16))) float s_lut[];
     const int lut_n = n_chunks * n_centroids;
     lut += (size_t)blockIdx.y * lut_n;
     if (ids) ids += (size_t)blockIdx.y * q_stride;
     out += (size_t)blockIdx.y * q_stride;
+    // The product codec (64 chunks) with gathered ids: a thread takes its candidates four at a time and has every load of a
+    // batch in flight before it uses any -- ids first, before the table copy; then the four 64-byte code rows and descriptor
+    // words; the barrier that publishes the table falls between issue and use.  As the tail of a batched scan this kernel runs on
+    // the CUs the next scan leaves free while that scan saturates HBM, and every dependent round trip costs microseconds there:
+    // one candidate at a time (13 round trips per workgroup) took 750-930 us for 8 x 32 768 candidates, 31 us on an idle device
+    // (profiles/r04_pq_timeline.txt).
+    constexpr int PER = 4;
+    const bool use_desc = desc && scales;
+    const bool fast = n_chunks == 64 && ids && (!use_desc || n_desc == 4);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t base = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rid[PER];
+    bool okv[PER];
+    auto load_ids = [&](size_t b) {
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const size_t p = b + (size_t)j * stride;
+            rid[j] = p < n ? ids[p] : 0xffffffffu;
+        }
+    };
+    uint4 w[PER][4];
+    uint32_t dw[PER];
+    auto load_codes = [&]() {
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            okv[j] = (size_t)rid[j] < n_codes;
+            const size_t row = okv[j] ? (size_t)rid[j] : 0;
+            const uint4* cp = reinterpret_cast<const uint4*>(codes + row * 64);
+#pragma unroll
+            for (int a = 0; a < 4; a++) w[j][a] = cp[a];
+            dw[j] = use_desc ? *reinterpret_cast<const uint32_t*>(desc + row * 4) : 0u;
+        }
+    };
+    float sc4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (fast) {
+        load_ids(base);
+        if (use_desc)
+            for (int j = 0; j < 4; j++) sc4[j] = scales[j];
+    }
     if ((lut_n & 3) == 0 && (reinterpret_cast<uintptr_t>(lut) & 15) == 0) {     // 16 bytes per thread and step
         const float4* src = reinterpret_cast<const float4*>(lut);
         float4* dst = reinterpret_cast<float4*>(s_lut);
@@ -222,9 +265,61 @@ __global__ __launch_bounds__(1024) void pq_adc_kernel(const float* __restrict__ 
     } else {
         for (int e = threadIdx.x; e < lut_n; e += blockDim.x) s_lut[e] = lut[e];
     }
+#ifdef MSE_DEV_KERNELS
+    if (g_adc_variant == 1) { __syncthreads(); if (s_lut[threadIdx.x] == 1234.5f) out[0] = 1; return; }          // table copy only
+    if (g_adc_variant == 2 && fast) {                                                                            // neighbouring rows instead of gathered ones
+#pragma unroll
+        for (int j = 0; j < PER; j++) rid[j] = (uint32_t)((base + (size_t)j * stride) % n_codes);
+    }
+    if (g_adc_variant == 3) {                                                                                    // no table copy wait, no sums: ids + code rows only
+        if (fast) load_codes();
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) x ^= w[j][0].x ^ w[j][1].y ^ w[j][2].z ^ w[j][3].w ^ dw[j];
+        if (x == 0x12345678u) out[0] = 1;
+        return;
+    }
+#endif
+    if (fast) load_codes();
     __syncthreads();
+    if (fast) {
+        for (;;) {
+            const size_t next = base + (size_t)PER * stride;
+            const bool more = next < n;
+            bool okc[PER];
+#pragma unroll
+            for (int j = 0; j < PER; j++) okc[j] = okv[j];
+            if (more) load_ids(next);   // the next batch's ids travel while this one is summed (its code rows follow below)
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const size_t p = base + (size_t)j * stride;
+                float sum = 0.0f;
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const uint32_t ww[4] = {w[j][a].x, w[j][a].y, w[j][a].z, w[j][a].w};
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; b4++)
+#pragma unroll
+                        for (int bb = 0; bb < 4; bb++) {
+                            const int i = a * 16 + b4 * 4 + bb;
+                            sum = add_rn(sum, s_lut[i * n_centroids + ((ww[b4] >> (8 * bb)) & 0xff)]);
+                        }
+                }
+                int64_t r = scale_dot_result(sum);
+                if (use_desc) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) r += scale_dot_result(sc4[q] * (float)((dw[j] >> (8 * q)) & 0xff));
+                }
+                if (p < n) out[p] = okc[j] ? r : INT64_MIN;
+            }
+            if (!more) break;
+            base = next;
+            load_codes();
+        }
+        return;
+    }
     const bool vec16 = (n_chunks % 16) == 0;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    for (size_t p = base; p < n; p += stride) {
         size_t row = ids ? (size_t)ids[p] : p;
         const bool ok = row < n_codes;
         if (!ok) row = 0;
@@ -1025,12 +1120,29 @@ int launch_pq_adc(const float* lut, int n_chunks, int n_centroids, const uint8_t
     size_t blocks = (n + threads - 1) / threads;
     const size_t cap = (size_t)n_cu * 2;
     if (blocks > cap) blocks = cap;
-    // several queries per launch = the tail of a batched scan, which runs on the few CUs the next scan leaves free: there the table
-    // copy (64 KiB per workgroup) is what costs, so a workgroup takes 4096 candidates instead of 1024 (8 x 32 768 candidates:
-    // 884 us -> on 8 CUs with 256 workgroups, profiles/r04_pq_timeline.txt)
-    if (nq > 1 && blocks > (n + 4095) / 4096) blocks = (n + 4095) / 4096;
+    // several queries per launch = the tail of a batched scan, beside which the NEXT scan is resident on all but scan_cus()'s
+    // spare CUs (one per XCD).  A workgroup of this kernel (1024 threads, ~100 VGPRs, 64 KiB of LDS) cannot share a CU with a scan
+    // workgroup, and a dispatch whose workgroups do not ALL fit into what is free at once does not trickle through the spare CUs: it
+    // waits for the scan to end (scripts/native/coresidency_probe.hip: 8 such workgroups beside a 248-workgroup resident kernel
+    // finish in 6 us, 64 of them in 2.4 ms = when the resident kernel ends; profiles/r04_pq_timeline.txt: 64 workgroups took
+    // 750-950 us here, 8 take ~100).  So: as many workgroups as there are spare CUs, each looping over its share.
+    if (nq > 1) {
+        const size_t spare = std::max<size_t>((size_t)n_cu - scan_cus(n_cu), 8);
+        blocks = std::min(blocks, std::max<size_t>(spare / (size_t)nq, 1));
+    }
+#ifdef MSE_DEV_KERNELS
+    // MSE_PQ_ADC_VARIANT=v: one EXTRA launch of timing variant v (1 table copy only, 2 neighbouring rows instead of gathered ones,
+    // 3 ids + code rows only) ahead of the real one, so that a kernel trace shows what each part costs beside a running scan
+    static const int variant = getenv("MSE_PQ_ADC_VARIANT") ? atoi(getenv("MSE_PQ_ADC_VARIANT")) : 0;
+    if (variant > 0)
+        hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(threads), lds, stream, lut, n_chunks, n_centroids, codes,
+                           n_codes, ids, n, desc, n_desc, scales, out, q_stride, variant);
+    hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(threads), lds, stream, lut, n_chunks, n_centroids, codes,
+                       n_codes, ids, n, desc, n_desc, scales, out, q_stride, 0);
+#else
     hipLaunchKernelGGL(pq_adc_kernel, dim3((unsigned)blocks, (unsigned)nq), dim3(threads), lds, stream, lut, n_chunks, n_centroids, codes,
                        n_codes, ids, n, desc, n_desc, scales, out, q_stride);
+#endif
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -2224,6 +2224,32 @@ int launch_gemm_fused(int epi, const GemmLaunch& g, hipStream_t st) {
     a.xres = g.xres; a.part = reinterpret_cast<float2*>(g.part); a.part_rows = g.part_rows; a.n_valid = g.n_valid;
     a.sink = reinterpret_cast<char*>(g.sink);
     constexpr int lds_narrow = 2 * (2 * P8_UNIT + 2 * 8192) + 8 * PP_STAGE;
+#ifdef MSE_DEV_KERNELS
+    // Developer library only (scripts/siglip_bench.py, MSE_GEMM_FUSED_ABL=2): every GEMM of the tower WITHOUT its epilogue -- the
+    // outputs are never written, so the forward's result is garbage; its duration is what a tower whose epilogues were hidden
+    // completely behind the next tile's matrix work could at best reach.
+    if (getenv("MSE_GEMM_FUSED_ABL") && atoi(getenv("MSE_GEMM_FUSED_ABL")) == 2) {
+        switch (epi) {
+            case EPI_RESID_LN: return launch_pp(gemm8pp_kernel<EPI_BF16, false, 2>, LDSPP_BYTES, a, 256, st);
+            case EPI_GELU: return launch_pp(gemm8pp_kernel<EPI_GELU, false, 2, 2, true>, LDSPP_BYTES, a, 256, st);
+            case EPI_QKV: {
+                const int D = g.heads * g.dh, nv = (D / 256) * 256;
+                GemmArgs aq = a;
+                aq.N = 2 * D;
+                if (launch_pp(gemm8pp_kernel<EPI_QKV, false, 2, 2, true>, LDSPP_BYTES, aq, 256, st)) return -1;
+                GemmArgs av = a;
+                av.N = nv; av.n_off = 2 * D; av.w = a.w + (size_t)av.n_off * a.K; av.bias = a.bias + av.n_off; av.csum = a.csum + av.n_off;
+                if (nv && launch_pp(gemm8pp_kernel<EPI_QKV, true, 2, 2, true>, LDSPP_BYTES, av, 256, st)) return -1;
+                if (D - nv == 128) {
+                    GemmArgs at = a;
+                    at.N = 128; at.n_off = 2 * D + nv; at.w = a.w + (size_t)at.n_off * a.K; at.bias = a.bias + at.n_off; at.csum = a.csum + at.n_off;
+                    if (launch_pp(gemm8pp_kernel<EPI_QKV, true, 2, 1, true>, lds_narrow, at, 128, st)) return -1;
+                }
+                return 0;
+            }
+        }
+    }
+#endif
     switch (epi) {
         case EPI_RESID_LN:
             if (g.N % 256 || !g.xres || !g.part || !g.sink || g.n_valid % 64 || g.n_valid > g.N || g.part_rows < (size_t)g.M)

@@ -18,6 +18,9 @@
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
+#include <algorithm>
+
+namespace mse { int device_cu_count(); }   // api.hip
 
 namespace mse {
 namespace {
@@ -42,30 +45,45 @@ template <typename K> __device__ __forceinline__ K wave_max(K v) {
     return v;
 }
 
-// one wave per output group; F must be 256
+// one wave per output group (F must be 256), a bounded number of waves walking the (query, group) pairs.  The grid is capped
+// (launch_reduce_t) so that this kernel never holds more than half of a CU's wave slots: as the first kernel of a batched PQ scan's
+// tail it is dispatched at the same moment as the NEXT scan (other stream), whose 16-wave workgroups need four free slots on every
+// SIMD of a CU -- 12 000 four-wave workgroups churning through all 32 slots kept them out for the kernel's whole 140 us, and a
+// scan workgroup that starts late ends late (static partition): 1.40 ms per scan instead of 1.22 (profiles/r04_pq_timeline.txt).
+// Element-strided input (group-major [n_in][nq], in_estride = nq): consecutive waves take the queries of ONE group run, so the
+// cache lines they share are fetched once per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_max_kernel(const T* __restrict__ in, size_t in_stride, size_t n_in,
                                                          typename KeyT<T>::type* __restrict__ out, size_t out_stride,
                                                          size_t n_out, int nq, size_t in_estride) {
     using K = typename KeyT<T>::type;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
     const size_t total = n_out * (size_t)nq;
-    if (wave >= total) return;
-    const size_t q = wave / n_out, g = wave % n_out;
-    const T* src = in + q * in_stride;
-    K best = 0;
-    const size_t lo = g * TOPK_FANOUT;
+    for (size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wave < total; wave += n_waves) {
+        size_t q, g;
+        if (in_estride > 1) { q = wave % (size_t)nq; g = wave / (size_t)nq; }
+        else { q = wave / n_out; g = wave % n_out; }
+        const T* src = in + q * in_stride;
+        K best = 0;
+        const size_t lo = g * TOPK_FANOUT;
+        T v[TOPK_FANOUT / 64];
 #pragma unroll
-    for (int u = 0; u < TOPK_FANOUT / 64; u++) {
-        const size_t i = lo + (size_t)u * 64 + lane;
-        if (i < n_in) {
-            const K k = key_of(src[i * in_estride]);
-            best = k > best ? k : best;
+        for (int u = 0; u < TOPK_FANOUT / 64; u++) {   // all loads of the run first
+            const size_t i = lo + (size_t)u * 64 + lane;
+            v[u] = i < n_in ? src[i * in_estride] : T(0);
         }
+#pragma unroll
+        for (int u = 0; u < TOPK_FANOUT / 64; u++) {
+            const size_t i = lo + (size_t)u * 64 + lane;
+            if (i < n_in) {
+                const K k = key_of(v[u]);
+                best = k > best ? k : best;
+            }
+        }
+        best = wave_max(best);
+        if (lane == 0) out[q * out_stride + g] = best;
     }
-    best = wave_max(best);
-    if (lane == 0) out[q * out_stride + g] = best;
 }
 
 // group-major float input [n_in][nq_pad] (as written by the MFMA scan): thread = (query, out group)
@@ -447,8 +465,8 @@ template <typename T>
 int launch_reduce_t(const void* in, size_t in_stride, size_t n_in, void* out, size_t out_stride, size_t n_out, int nq,
                     hipStream_t stream, size_t in_estride) {
     const size_t waves = n_out * (size_t)nq;
-    const size_t blocks = (waves + 3) / 4;
-    if (blocks > 0x7fffffffull) return fail("reduce_max: grid too large");
+    // at most four 4-wave workgroups per CU (16 of its 32 wave slots: see the kernel)
+    const size_t blocks = std::min<size_t>((waves + 3) / 4, (size_t)mse::device_cu_count() * 4);
     hipLaunchKernelGGL(reduce_max_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream,
                        reinterpret_cast<const T*>(in), in_stride, n_in,
                        reinterpret_cast<typename KeyT<T>::type*>(out), out_stride, n_out, nq, in_estride);

@@ -14,7 +14,7 @@ for c0 in range(0,n,blk): np.bitwise_xor(block, rng.integers(0,256,size=64,dtype
 desc=np.resize(rng.integers(0,256,size=(blk,4),dtype=np.uint8),(n,4))
 gc=mse.Codes(codes,desc); del codes
 scales=np.array([0.5,0,-0.25,0],np.float32)/np.float32(512)
-qs=(rng.standard_normal((32,D))/np.sqrt(D)).astype(np.float32)
+qs=(rng.standard_normal((int(os.environ.get("PQ_TRACE_NQ","32")),D))/np.sqrt(D)).astype(np.float32)
 for _ in range(3): pq.scan_topk_batch(gc,qs,200,10,None,scales)
 t=time.perf_counter()
 for _ in range(4): pq.scan_topk_batch(gc,qs,200,10,None,scales)
@@ -23,10 +23,10 @@ PY
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python /tmp/pqmini.py > $OUT/log.txt 2>&1
 grep "ms per call" $OUT/log.txt
 python - $OUT <<'PY'
-import csv,glob,sys
+import csv,glob,sys,os
 f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f))); rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-last=int(rows[-1]["End_Timestamp"]); t0=last-7_000_000
+last=int(rows[-1]["End_Timestamp"]); t0=last-int(os.environ.get("PQ_TRACE_WINDOW_US","7000"))*1000
 sel=[r for r in rows if int(r["Start_Timestamp"])>t0]
 for r in sel:
     s=int(r["Start_Timestamp"]); e=int(r["End_Timestamp"])
