@@ -818,6 +818,15 @@ def siglip_bench(args, world, rank, dist=None):
     per_gpu = batch * args.siglip_steps / dt
     gflop_img = 0.988 + 27 * 24.647 + 3.9                     # 670.4 GFLOP per image
     tflops = per_gpu * gflop_img / 1e3
+    # HBM bytes of one forward from the PMC passes (collected offline by scripts/profile_r04.sh: the counters cannot be read inside a timed
+    # run); only reported when this run is the profiled configuration
+    sig_traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))).get("siglip")
+        if pm and pm["batch"] == batch and pm["depth"] == 27:
+            sig_traffic = pm["hbm_read_bytes_per_forward"] + pm["hbm_write_bytes_per_forward"]
+    except Exception:  # noqa: BLE001
+        sig_traffic = None
     return {"metric": "SigLIP img-embeds/sec/GPU", "value": per_gpu, "unit": "images/s/GPU", "total_images_per_s": per_gpu * world,
             "ms_per_batch": dt / args.siglip_steps * 1e3, "dtype": "bf16 (fp32 accumulate; fp16 residual stream, fp32 LayerNorm/softmax/GELU)",
             "config": {"workload": f"SigLIP-SO400M/14-384 image tower, batch {batch} random 384x384, 1 replica per GPU",
@@ -825,10 +834,12 @@ def siglip_bench(args, world, rank, dist=None):
             "steps": args.siglip_steps, "scaling": "weak (replicas)", "text_tower": text,
             "server_images_per_s": (server or {}).get("value"), "server": server,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
-                         "flop_per_image": gflop_img * 1e9, "traffic": None,
-                         "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.79 of 2.4 GHz "
-                                 "(profiles/r02_power_clocks.txt); the library GEMM alone runs these shapes at 0.38-0.50 of the same peak "
-                                 "(profiles/r02_gemm_calibration.txt); round-3 measurements of what is left: DESIGN.md 3.4"}}
+                         "flop_per_image": gflop_img * 1e9, "traffic": sig_traffic,
+                         "traffic_source": "profiles/r04_pmc_traffic.json: HBM bytes of ONE forward of this batch, all kernels (rocprofv3 --pmc FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB)" if sig_traffic else None,
+                         "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.83 of 2.4 GHz "
+                                 "(profiles/r04_siglip_notes.txt); the library GEMM alone runs these shapes at 0.38-0.52 of the same peak "
+                                 "(profiles/r02_gemm_calibration.txt); with every GEMM epilogue removed the forward is 17 % shorter -- the "
+                                 "ceiling of epilogue hiding; DESIGN.md 3.4"}}
 
 
 _SERVER_CLIENT = r"""

@@ -18,7 +18,7 @@ for r in rows[:22]:
     print("%7s %11.3f %11.3f %7s  %s" % (r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"], r["Name"][:160]))
 PY
 }
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o b -- python $R/bench.py --steps 12 --warmup 2 --no-siglip --no-pq --no-graph --no-graph-scale --no-cpu-baseline --no-callers --no-shard-point > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o b -- python $R/bench.py --steps 12 --warmup 2 --no-siglip --no-pq --no-graph --no-graph-scale --no-cpu-baseline --no-callers --no-shard-point --no-ann-scale > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 stats $OUT/bench $OUT/bench_kernel_stats.txt; rm -rf $OUT/bench
 timeout 600 python $R/scripts/scan_pass_probe.py 1e8 4 > $OUT/scan_variants.txt 2> $OUT/scan_variants.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pq -o pq -- python $R/scripts/pq_scan_bench.py 1e8 > $OUT/pq_bench.log 2>&1
@@ -26,7 +26,10 @@ grep "^{" $OUT/pq_bench.log | tail -1 > $OUT/pq_bench_line.json
 stats $OUT/pq $OUT/pq_kernel_stats.txt; rm -rf $OUT/pq
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/scripts/pq_scan_bench.py 1e8 > $OUT/pmc_$c.log 2>&1
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmcs_$c -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-siglip --no-pq --no-graph --no-graph-scale --no-cpu-baseline --no-callers --no-shard-point > $OUT/pmcs_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmcs_$c -o pmc -- python $R/bench.py --steps 4 --warmup 1 --no-siglip --no-pq --no-graph --no-graph-scale --no-cpu-baseline --no-callers --no-shard-point --no-ann-scale > $OUT/pmcs_$c.log 2>&1
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmcg_$c -o pmc -- python $R/scripts/siglip_bench.py 256 2 27 > $OUT/pmcg_$c.log 2>&1
 done
 python - $OUT <<'PY' > $OUT/pmc_traffic.json
 import csv, glob, json, sys, collections
@@ -63,8 +66,21 @@ for k in ("320", "256"):   # the headline pass: the widest one measured
         out["hbm_read_bytes_per_launch"] = out["per_pass"][k]["hbm_read_bytes_per_launch"]
         out["hbm_write_bytes_per_launch"] = out["per_pass"][k]["hbm_write_bytes_per_launch"]
         break
+# SigLIP image tower: every dispatch of the 3 forwards of `scripts/siglip_bench.py 256 2 27` (one warm-up + two timed), summed and divided by 3
+sg = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    tot, names = 0.0, collections.Counter()
+    for f in glob.glob(sys.argv[1] + "/pmcg_" + c + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c and "siglip" in r["Kernel_Name"]:
+                tot += float(r["Counter_Value"]); names[r["Kernel_Name"][:60]] += 1
+    sg[c] = tot / 3.0
+if sg.get("FETCH_SIZE"):
+    out["siglip"] = {"batch": 256, "depth": 27, "forwards_profiled": 3, "hbm_read_bytes_per_forward": sg["FETCH_SIZE"] * 2048,
+                     "hbm_write_bytes_per_forward": sg["WRITE_SIZE"] * 1024,
+                     "note": "all kernels of the mse::siglip namespace; FETCH_SIZE doubled as for the 16-byte-per-lane streams it was calibrated on (the GEMM and attention operand DMAs); WRITE_SIZE uncalibrated"}
 print(json.dumps(out, indent=1))
 PY
-rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcs_FETCH_SIZE $OUT/pmcs_WRITE_SIZE
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcs_FETCH_SIZE $OUT/pmcs_WRITE_SIZE $OUT/pmcg_FETCH_SIZE $OUT/pmcg_WRITE_SIZE
 bash $R/scripts/pmc_pq_r04.sh > $OUT/pq_pmc.txt 2>&1; rm -rf $R/gpurun_out/pmc_pq_r04
 ls -la $OUT
