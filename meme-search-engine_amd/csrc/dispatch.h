@@ -12,6 +12,7 @@
 // `max_queries`, or when the oldest waiting request is `max_wait` old and the callers just answered had a grace period
 // (<= 1 ms) to return, whichever comes first.  A single caller therefore never waits (target 1), T closed-loop callers settle
 // at T queries per pass after two passes, and callers that do not come back cost a grace period on every other pass at most.
+// More expected callers than one pass holds are served in EQUAL passes (512 callers, 320 per pass: 256 + 256, not 320 + 192).
 #pragma once
 #include "common.h"
 #include <atomic>
@@ -59,6 +60,7 @@ class Coalescer {
     int submit(DispatchReq& r);
     DispatchStats stats();
     size_t max_queries() const { return max_queries_; }
+    size_t target() const;   // queries the next pass waits for (call with mu_ held)
     uint32_t max_wait_us() const { return max_wait_us_.load(); }
     void set_max_wait_us(uint32_t us) { max_wait_us_.store(us); }   // takes effect from the next gather
 
