@@ -666,12 +666,13 @@ def graph_scale_bench(args):
     (BASELINE configs[2]'s size; the 1e8-row runs are in profiles/).  Synthetic hierarchical clusters made on the device
     (rows/50 centres around rows/5000 super-centres, noise 0.3: scripts/graph_scale_bench.py), ONE Vamana pass with
     generate-index-shard's defaults (R 64, L 192, C 750) on the device, then the GPU-resident beam search
-    (query_disk_index::greedy_search, beam 4, neighbours scored exactly) for 2048 held-out queries per call, host arrays in and out:
+    (the request path in one call, mse_disk_query_topk: entry by the entry table, query_disk_index::greedy_search with beam 4 and
+    exactly scored neighbours, the visited records cut to the first 10) for 4096 held-out queries per call, host arrays in and out:
     reported at the smallest search list whose recall@10 against the exact brute-force top-10 reaches 0.95."""
     import numpy as np
     import torch
     import mse
-    n, nq, K, R, batch = int(args.graph_scale_rows), 4096, 10, 64, int(args.graph_batch)   # 2048 tuning + 2048 held-out queries (a call of 2048: 18 % more queries/s than 1024, scripts/beam_batch_probe.py)
+    n, nq, K, R, batch = int(args.graph_scale_rows), 8192, 10, 64, int(args.graph_batch)   # 4096 tuning + 4096 held-out queries: one wave per query puts 4096 searches on the chip at once (scripts/beam_batch_probe.py: 0.62 / 0.94 / 1.10 / 1.19 M queries/s at 1024 / 2048 / 4096 / 8192 per call, 2e6 rows)
     clustered = clustered_generator(n)
     rows, queries = clustered(n, 1), clustered(nq, 2)
     torch.cuda.synchronize()
@@ -704,29 +705,21 @@ def graph_scale_bench(args):
     if n_entry < 0:      # auto: about one entry per 1500 rows -- a few per top-level cluster of the synthetic set at any size
         n_entry = max(4096, n // 1500)
     if n_entry > 0:
-        e_idx = np.sort(np.random.default_rng(5).choice(n, min(n_entry, n), replace=False)).astype(np.int64)
-        e_rows = rows[torch.from_numpy(e_idx).cuda()].contiguous()
-        e_vecs = mse.VectorList.wrap_device(e_rows.data_ptr(), len(e_idx), D, keepalive=e_rows)
-        e_search = mse.Searcher(e_vecs)
-        e_search.bruteforce_topk(qh[:8], 1, mse.MODE_EXACT)
-
-    def entry_points(q):
-        if n_entry <= 0:
-            return np.full(len(q), med, np.uint32)
-        _, top = e_search.bruteforce_topk(q, 1, mse.MODE_MFMA if len(q) > 8 else mse.MODE_EXACT)
-        return e_idx[top[:, 0]].astype(np.uint32)
+        e_idx = np.sort(np.random.default_rng(5).choice(n, min(n_entry, n), replace=False)).astype(np.uint32)
+        mse.set_entries(g, vecs, e_idx)      # copies of the entry rows stay with the graph; the top-1 runs on the device inside the call
 
     def run(L, sl, timed):
-        if timed:   # warm: scratch is allocated on first use
-            mse.disk_search_batch(s, None, None, g, entry_points(qh[sl]), qh[sl], None, None, True, 4, L, 1024, as_arrays=True)
-        t0 = time.perf_counter()
-        starts = entry_points(qh[sl])
-        res = mse.disk_search_batch(s, None, None, g, starts, qh[sl], None, None, True, 4, L, 1024, as_arrays=True)
-        dt = time.perf_counter() - t0
-        top = mse.topk_of_visited(res, K)
+        # ONE call = the request path for the batch (mse_disk_query_topk): f16 queries up, entry node by the entry table, beam search,
+        # the visited records by exact score cut to the first K, K ids and scores per query down
         m = sl.stop - sl.start
+        st = None if n_entry > 0 else np.full(m, med, np.uint32)
+        if timed:   # warm: scratch is allocated on first use
+            mse.disk_query_topk(s, None, None, g, qh[sl], K, st, None, None, True, 4, L)
+        t0 = time.perf_counter()
+        top, _, stats = mse.disk_query_topk(s, None, None, g, qh[sl], K, st, None, None, True, 4, L)
+        dt = time.perf_counter() - t0
         rec = sum(len(set(top[i].tolist()) & set(truth[sl.start + i].tolist())) for i in range(m)) / (K * m)
-        return {"search_list": L, "queries": m, "queries_per_s": m / dt, "recall_at_10": rec, "node_fetches_per_query": float(res["cmps"].mean())}
+        return {"search_list": L, "queries": m, "queries_per_s": m / dt, "recall_at_10": rec, "node_fetches_per_query": float(stats["cmps"].mean())}
 
     sweep, chosen = [], None
     for L in (32, 48, 64, 100, 200, 400, 800):

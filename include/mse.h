@@ -336,6 +336,21 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
                           size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores, uint32_t* buf_len,
                           uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap, uint32_t* n_visited,
                           uint32_t* cmps, uint32_t* pq_cmps);
+/* The request path in ONE call (src/query_disk_index.rs:436-540 for a batch of queries): entry node, greedy_search, the visited
+ * records ordered by exact score and cut to the first k -- nothing but the queries goes up and the k results come down.
+ *   mse_graph_set_entries  the entry table: the reference starts a search at the medioid of the shard whose centroid is closest to
+ *                          the query (:254-256,447-450); here node_ids name the entry records (shard medioids, or a sample of the
+ *                          rows of a one-piece index) and a search starts at the one whose vector has the largest dot product
+ *                          with the f16 query (exact top-1 on the device).  Copies of those vectors are kept with the graph.
+ *   mse_disk_query_topk    starts == NULL: start nodes by the entry table; otherwise as given.  queries / luts / scales / disable_pq /
+ *                          beamwidth / search_list as mse_disk_search_batch.  ids / scores [nq][k]: the k best visited records by
+ *                          (exact score + bias) descending -- equal scores by id ascending (the reference's sort is unstable there) --
+ *                          padded with MSE_ID_NONE / INT64_MIN; identical to sorting mse_disk_search_batch's visited list.
+ *                          n_visited / cmps / pq_cmps: [nq] or NULL.  Every visited record takes part (no visited_cap to choose). */
+int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries);
+int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
+                        const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
+                        uint32_t* ids, int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
 /* ---- Vamana graph build on the device (diskann/src/lib.rs:183-389, driven by
  * src/generate_index_shard.rs:85-133) ----
  * The graph being built is an mse_graph with max_deg = r (lists of at most r ids, stride r) that stays in HBM

@@ -160,13 +160,30 @@ static int exact_pass(mse_searcher* s, int nq_pass, int k, uint64_t id_offset, i
                            nullptr, 0, 0, 0, nullptr, nullptr, s->stream);
 }
 
-// MFMA mode for up to mfma_query_tile(d) queries (device pointer to [nq][d] f16, contiguous)
+// How many queries one call of mfma_pass may take: one pass over the rows (mfma_query_tile) for a large base; for a SMALL base -- group
+// maxima of all queries within 256 MiB -- up to 8192, scanned pass by pass into one wide array of group maxima and finished by ONE
+// tournament / re-score / certificate over all of them.  The fixed cost of a pass (a dozen small launches and a host synchronisation
+// for the margins) is what a small base pays for: 4096 queries against a 4096-row entry table (the request path's entry step,
+// beam_search.hip) took 13 passes x 0.28 ms.
+static size_t mfma_call_tile(const mse_base* b) {
+    const size_t tile = (size_t)mfma_query_tile((int)b->d);
+    const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;
+    size_t fit = ((size_t)256 << 20) / (std::max<size_t>(n_groups, 1) * 4) / tile * tile;
+    if (fit > 8192 / tile * tile) fit = 8192 / tile * tile;
+    return std::max(fit, tile);
+}
+
+// MFMA mode for up to mfma_call_tile(base) queries (device pointer to [nq][d] f16, contiguous)
 static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k, uint64_t id_offset,
                      int64_t* out_scores, uint32_t* out_ids, size_t out_stride) {
     const mse_base* b = s->base;
     hipStream_t st = s->stream;
     const int d = (int)b->d;
-    const int nq_pad = mfma_pad(nq_pass, d);   // one pass over the rows serves up to 320 queries (padded to 128 / 192 / 256 / 320)
+    // one pass over the rows serves up to 320 queries (padded to 128 / 192 / 256 / 320); more queries (small base only) = full passes
+    // and a last one, their columns side by side in the array of group maxima
+    const int tile = mfma_query_tile(d);
+    const int n_full = nq_pass / tile, rem = nq_pass - n_full * tile;
+    const int nq_pad = n_full * tile + (rem ? mfma_pad(rem, d) : 0);
     if (ensure_base_norm(b, st)) return -1;
     // padded query tile
     if (s->q_stage.ensure((size_t)nq_pad * d * 2)) return -1;
@@ -175,8 +192,12 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
     const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;
     if (s->gmax.ensure(n_groups * (size_t)nq_pad * 4)) return -1;
     if (s->qpacked.ensure(mfma_packed_bytes(d))) return -1;
-    if (launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>(), nq_pad, s->qpacked.p, s->gmax.as<float>(), s->n_cu,
-                         st, s->timing ? s->ev0 : nullptr, s->timing ? s->ev1 : nullptr)) return -1;
+    for (int q0 = 0; q0 < nq_pad; q0 += tile) {
+        const int w = std::min(tile, nq_pad - q0);   // a whole tile, or the padded remainder
+        const bool last = q0 + w >= nq_pad;
+        if (launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>() + (size_t)q0 * d, w, s->qpacked.p, s->gmax.as<float>() + q0, s->n_cu,
+                             st, s->timing && q0 == 0 ? s->ev0 : nullptr, s->timing && last ? s->ev1 : nullptr, nq_pad)) return -1;
+    }
     bool timing_pending = s->timing;
     if (s->eps.ensure((size_t)nq_pass * 8) || s->margin.ensure((size_t)nq_pass * 8)) return -1;   // second halves: the widening's compact set
     // |mfma score - exact-order score| <= 2 * gamma_1151 * sum|x_i q_i| <= 1.4e-4 * |x||q|; doubled again
@@ -486,7 +507,7 @@ int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t
         return 0;
     }
     if (mode == MSE_MODE_MFMA) {
-        const int tile = mfma_query_tile((int)d);
+        const size_t tile = mfma_call_tile(b);
         for (size_t q0 = 0; q0 < nq; q0 += tile) {
             const int nqp = (int)std::min<size_t>(tile, nq - q0);
             if (mfma_pass(s, q + q0 * d, nqp, (int)k, id_offset, out_scores + q0 * k, out_ids + q0 * k, k)) return -1;

@@ -28,7 +28,7 @@ using namespace mse;
 
 namespace {
 
-constexpr int BS_THREADS = 256;
+constexpr int BS_THREADS_MAX = 256;
 constexpr int BS_LMAX = 1024;
 constexpr int BS_BEAM_MAX = 8;
 constexpr int BS_DEG_MAX = 128;   // merged indexes: up to SHARD_SPILL x R neighbours per node
@@ -44,9 +44,18 @@ struct BeamArgs {
     uint32_t* out_ids; long long* out_scores; uint32_t* out_len;
     uint32_t* vis_ids; long long* vis_scores; size_t vis_cap; uint32_t* n_visited;
     uint32_t* cmps; uint32_t* pq_cmps; uint32_t* err;
+    int fill_vis;   // fused request path: slots of the visited arrays past n_visited are set to (ID_NONE, INT64_MIN) for the device top-k
 };
 
-__global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
+// THREADS = 256: four waves per query (wave 0 walks the list, all four score and merge) -- needed when the 64 KiB distance table of
+// a query sits in LDS (two queries per CU either way) and for the longest lists (4 x THREADS list entries / pre-buffer entries).
+// THREADS = 64 (round 4): ONE wave per query, for searches that score their neighbours exactly (no table) with search_list and
+// pre-buffer <= 256.  The search is a chain of dependent round trips (82 % of the wave-cycles of the four-wave form were waits,
+// profiles/r04_beam_search_pmc.txt) and three of its four waves idle through the sequential parts; one wave per query puts 16
+// queries on a CU instead of 3.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_kernel(BeamArgs a) {
+    constexpr int BS_THREADS = THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lut_bytes = a.disable_pq ? 0 : 65536;   // the distance table is only needed when neighbours are scored by ADC
     float* s_lut = reinterpret_cast<float*>(smem);
@@ -353,6 +362,14 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
         a.out_ids[qi * a.L + e] = nb_id[e];
         a.out_scores[qi * a.L + e] = nb_sc[e];
     }
+    if (a.fill_vis) {
+        if (tid == 0) s_npre = (int)(n_vis < a.vis_cap ? n_vis : a.vis_cap);
+        __syncthreads();
+        for (size_t e = (size_t)s_npre + tid; e < a.vis_cap; e += BS_THREADS) {
+            a.vis_ids[qi * a.vis_cap + e] = 0xffffffffu;
+            a.vis_scores[qi * a.vis_cap + e] = (long long)INT64_MIN;
+        }
+    }
     if (tid == 0) {
         a.out_len[qi] = (uint32_t)len;
         a.n_visited[qi] = n_vis;
@@ -360,6 +377,28 @@ __global__ __launch_bounds__(BS_THREADS) void beam_search_kernel(BeamArgs a) {
         a.pq_cmps[qi] = pq_cmps;
     }
 }
+
+// fused request path: copies of the entry records' vectors; start node of a query = node id of its best entry row
+__global__ void gather_entry_rows_kernel(const uint16_t* __restrict__ base, int d, const uint32_t* __restrict__ ids, uint16_t* __restrict__ out) {
+    const uint4* src = reinterpret_cast<const uint4*>(base + (size_t)ids[blockIdx.x] * d);
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * d);
+    for (int e = threadIdx.x; e < d / 8; e += blockDim.x) dst[e] = src[e];
+}
+__global__ void entry_starts_kernel(const uint32_t* __restrict__ best_row, const uint32_t* __restrict__ entry_ids, size_t n_entries, size_t nq,
+                                    uint32_t* __restrict__ starts) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t r = best_row[q];
+    starts[q] = entry_ids[r < n_entries ? r : 0];
+}
+
+// what the fused request path (mse_disk_query_topk) adds to a batched search: where the start nodes come from and what travels back
+struct FusedQuery {
+    const mse_graph* entries = nullptr;   // start node = node id of the entry row with the largest dot product (NULL: `starts` from the host)
+    size_t k = 0;
+    uint32_t* ids = nullptr;              // host [nq][k]
+    int64_t* scores = nullptr;            // host [nq][k]
+};
 
 }  // namespace
 
@@ -382,6 +421,10 @@ void mse_graph_free(mse_graph* g) {
     if (!g) return;
     delete g->co;   // joins its worker; no search may be in flight
     g->co = nullptr;
+    if (g->entry_s) mse_searcher_free(g->entry_s);
+    if (g->entry_base) mse_base_free(g->entry_base);
+    if (g->entry_rows) (void)hipFree(g->entry_rows);
+    if (g->entry_ids) (void)hipFree(g->entry_ids);
     if (g->adj) (void)hipFree(g->adj);
     if (g->deg) (void)hipFree(g->deg);
     if (g->has_url) (void)hipFree(g->has_url);
@@ -392,13 +435,14 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
                                   const uint16_t* queries, const float* queries_f32, const float* luts, const float* scales, size_t nq,
                                   int disable_pq, size_t beamwidth, size_t search_list, uint32_t* buf_ids, int64_t* buf_scores,
                                   uint32_t* buf_len, uint32_t* visited_ids, int64_t* visited_scores, size_t visited_cap,
-                                  uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
+                                  uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, const FusedQuery* fz = nullptr) {
     // with disable_pq and no descriptor bias neither the codec nor the codes are touched: both may be NULL then
     static const mse_codes no_codes{};
     if (!c && disable_pq && !scales) c = &no_codes;
     const bool codec_needed = !disable_pq;
-    if (!s || !s->base || (!pq && codec_needed) || !c || !g || !starts || (!queries && !queries_f32) || (!luts && !queries_f32 && !disable_pq) || !buf_ids ||
-        !buf_scores || !buf_len || !n_visited || !cmps || !pq_cmps)
+    // fused request path (fz): the search list and the visited records stay on the device, only the k best visited records travel back
+    if (!s || !s->base || (!pq && codec_needed) || !c || !g || (!starts && !(fz && fz->entries)) || (!queries && !queries_f32) ||
+        (!luts && !queries_f32 && !disable_pq) || (!fz && (!buf_ids || !buf_scores || !buf_len)) || !n_visited || !cmps || !pq_cmps)
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
@@ -413,14 +457,16 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         if (nq > piece) {
             for (size_t q0 = 0; q0 < nq; q0 += piece) {
                 const size_t m = std::min(piece, nq - q0);
-                if (disk_search_batch_impl(visited_mode, s, pq, c, g, starts + q0, queries ? queries + q0 * b->d : nullptr,
-                                           queries_f32 ? queries_f32 + q0 * b->d : nullptr, luts ? luts + q0 * 16384 : nullptr,
-                                           scales ? scales + q0 * c->n_desc : nullptr, m, disable_pq, beamwidth, search_list,
-                                           buf_ids + q0 * search_list, buf_scores + q0 * search_list, buf_len + q0,
-                                           visited_ids ? visited_ids + q0 * visited_cap : nullptr,
-                                           visited_scores ? visited_scores + q0 * visited_cap : nullptr, visited_cap, n_visited + q0, cmps + q0,
-                                           pq_cmps + q0))
-                    return -1;
+                FusedQuery fp;
+                if (fz) { fp = *fz; fp.ids = fz->ids + q0 * fz->k; fp.scores = fz->scores + q0 * fz->k; }
+                const int prc = disk_search_batch_impl(visited_mode, s, pq, c, g, starts ? starts + q0 : nullptr, queries ? queries + q0 * b->d : nullptr,
+                                                       queries_f32 ? queries_f32 + q0 * b->d : nullptr, luts ? luts + q0 * 16384 : nullptr,
+                                                       scales ? scales + q0 * c->n_desc : nullptr, m, disable_pq, beamwidth, search_list,
+                                                       buf_ids ? buf_ids + q0 * search_list : nullptr, buf_scores ? buf_scores + q0 * search_list : nullptr,
+                                                       buf_len ? buf_len + q0 : nullptr, visited_ids ? visited_ids + q0 * visited_cap : nullptr,
+                                                       visited_scores ? visited_scores + q0 * visited_cap : nullptr, visited_cap, n_visited + q0, cmps + q0,
+                                                       pq_cmps + q0, fz ? &fp : nullptr);
+                if (prc) return prc;
             }
             return 0;
         }
@@ -432,14 +478,18 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     if (g->max_deg > BS_DEG_MAX) return fail("disk_search_batch: at most 128 neighbours per node");
     if (c->n_desc > BS_DESC_MAX) return fail("disk_search_batch: at most 8 descriptors");
     if (b->d % 32 || b->d > 4096) return fail("disk_search_batch: vector width must be a multiple of 32");
-    if (visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
-    for (size_t q = 0; q < nq; q++)
+    if (!fz && visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
+    if (fz && (fz->k == 0 || fz->k > visited_cap || fz->k > (size_t)TOPK_KMAX - 64 || !fz->ids || !fz->scores)) return fail("disk_query_topk: bad k / outputs");
+    if (fz && fz->entries && (!fz->entries->entry_s || fz->entries->n_entries == 0 || fz->entries->entry_base->d != b->d))
+        return fail("disk_query_topk: the graph has no entry table for these vectors (mse_graph_set_entries)");
+    for (size_t q = 0; starts && q < nq; q++)
         if (starts[q] >= b->n) return fail("disk_search_batch: start node out of range");
     hipStream_t st = s->stream;
     const size_t d = b->d;
     const bool bias = scales && c->n_desc && c->desc;
     DevBuf &dq = s->pool[0], &dl = s->pool[1], &dsc = s->pool[2], &dst = s->pool[3], &bm = s->pool[4], &oi = s->pool[5], &os = s->pool[6],
-           &ol = s->pool[7], &vi = s->pool[8], &vs = s->pool[9], &cnt = s->pool[10], &qf = s->pool[11], &qt = s->pool[12];
+           &ol = s->pool[7], &vi = s->pool[8], &vs = s->pool[9], &cnt = s->pool[10], &qf = s->pool[11], &qt = s->pool[12], &fzb = s->pool[13];
+    if (fz && fzb.ensure(nq * 12 + nq * fz->k * 12 + 64)) return -1;   // entry top-1 [nq] (i64, u32) | k best visited [nq][k] (i64, u32)
     if ((queries_f32 && (qf.ensure(nq * d * 4) || qt.ensure(nq * d * 4))) || dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
         bm.ensure(nq * set_words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
         vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
@@ -459,7 +509,19 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         if (!disable_pq) MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
     }
     if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));
-    MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
+    if (fz && fz->entries) {
+        // the entry step of the request path (src/query_disk_index.rs:254-256,447-450: the medioid of the shard whose centroid is
+        // closest to the query) on the device: exact top-1 of the f16 queries over the entry rows, on this search's stream
+        const mse_graph* eg = fz->entries;
+        int64_t* e_sc = fzb.as<int64_t>();
+        uint32_t* e_row = reinterpret_cast<uint32_t*>(fzb.as<char>() + nq * 8);
+        if (mse_searcher_set_stream(eg->entry_s, st)) return -1;
+        if (mse_bruteforce_topk_f16_dev(eg->entry_s, dq.p, nq, 1, MSE_MODE_AUTO, 0, e_sc, e_row)) return -1;
+        hipLaunchKernelGGL(entry_starts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, e_row, eg->entry_ids, eg->n_entries, nq, dst.as<uint32_t>());
+        MSE_HIP_TRY(hipGetLastError());
+    } else {
+        MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
+    }
     MSE_HIP_TRY(hipMemsetAsync(bm.p, use_hash ? 0xff : 0, nq * set_words * 8, st));
     MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 12 + 16, st));
     const size_t p_cap = beamwidth * ((g->max_deg + 63) / 64 * 64);
@@ -474,14 +536,33 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
     a.err = cnt.as<uint32_t>() + 3 * nq;
+    a.fill_vis = fz ? 1 : 0;
     const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16;
-    MSE_DYN_LDS(beam_search_kernel, 160 * 1024 - 1024);
-    hipLaunchKernelGGL(beam_search_kernel, dim3((unsigned)nq), dim3(BS_THREADS), lds, st, a);
+    static const bool wide_only = MSE_DEV_KNOB("MSE_BEAM_FOUR_WAVES");   // developer library: the four-wave form for every search
+    if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only) {
+        hipLaunchKernelGGL(beam_search_kernel<64>, dim3((unsigned)nq), dim3(64), lds, st, a);
+    } else {
+        MSE_DYN_LDS(beam_search_kernel<BS_THREADS_MAX>, 160 * 1024 - 1024);
+        hipLaunchKernelGGL(beam_search_kernel<BS_THREADS_MAX>, dim3((unsigned)nq), dim3(BS_THREADS_MAX), lds, st, a);
+    }
     MSE_HIP_TRY(hipGetLastError());
     uint32_t err = 0;
-    MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
-    MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
-    MSE_HIP_TRY(hipMemcpyAsync(buf_len, ol.p, nq * 4, hipMemcpyDeviceToHost, st));
+    if (fz) {
+        // the server's last step (src/query_disk_index.rs:529-540: the visited records ordered by exact score) cut to its first k, on
+        // the device: the kernel has padded every visited list to visited_cap with (ID_NONE, INT64_MIN)
+        int64_t* top_sc = reinterpret_cast<int64_t*>(fzb.as<char>() + ((nq * 12 + 15) & ~(size_t)15));
+        uint32_t* top_id = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(top_sc) + nq * fz->k * 8);
+        SelectArgs sa{};
+        sa.kind = KEY_I64; sa.list_ids = vi.as<uint32_t>(); sa.list_keys = vs.p; sa.list_stride = visited_cap; sa.n_list = visited_cap;
+        sa.k = (int)fz->k; sa.out_ids = top_id; sa.out_keys = top_sc; sa.out_stride = fz->k; sa.nq = (int)nq;
+        if (launch_select(sa, st)) return -1;
+        MSE_HIP_TRY(hipMemcpyAsync(fz->ids, top_id, nq * fz->k * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipMemcpyAsync(fz->scores, top_sc, nq * fz->k * 8, hipMemcpyDeviceToHost, st));
+    } else {
+        MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipMemcpyAsync(buf_len, ol.p, nq * 4, hipMemcpyDeviceToHost, st));
+    }
     MSE_HIP_TRY(hipMemcpyAsync(n_visited, a.n_visited, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(cmps, a.cmps, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(pq_cmps, a.pq_cmps, nq * 4, hipMemcpyDeviceToHost, st));
@@ -490,7 +571,12 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     if (err & 1u) return fail("disk_search_batch: a graph edge points outside the index");
     if (err & 4u)   // a search outgrew its table: the bit maps have room for everything
         return disk_search_batch_impl(0, s, pq, c, g, starts, queries, queries_f32, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
-                                      buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
+                                      buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps, fz);
+    if (fz) {   // the reference keeps every visited record: a list that outgrew the device arrays means the caller repeats with larger ones
+        for (size_t q = 0; q < nq; q++)
+            if (n_visited[q] > visited_cap) return -2;
+        return 0;
+    }
     if (visited_cap) {   // only the columns any query filled travel back (entries past n_visited[q] are unspecified)
         size_t widest = 0;
         for (size_t q = 0; q < nq; q++) widest = n_visited[q] > widest ? n_visited[q] : widest;
@@ -619,6 +705,64 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
     }
     return disk_search_batch_impl(-1, s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
                                   buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
+}
+
+// ---- the request path in one call (src/query_disk_index.rs:436-540 for a batch) ---------------------------------------------
+int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries) {
+    if (!g || !b || !b->dev || (!node_ids && n_entries)) return fail("graph_set_entries: null argument");
+    if (b->n != g->n) return fail("graph_set_entries: vectors and graph differ in length");
+    if (b->d % 64 || b->d == 0) return fail("graph_set_entries: vector width must be a multiple of 64");
+    for (size_t i = 0; i < n_entries; i++)
+        if (node_ids[i] >= g->n) return fail("graph_set_entries: entry id out of range");
+    std::lock_guard<std::mutex> lk(g->entry_mu);
+    if (g->entry_s) { mse_searcher_free(g->entry_s); g->entry_s = nullptr; }
+    if (g->entry_base) { mse_base_free(g->entry_base); g->entry_base = nullptr; }
+    if (g->entry_rows) { (void)hipFree(g->entry_rows); g->entry_rows = nullptr; }
+    if (g->entry_ids) { (void)hipFree(g->entry_ids); g->entry_ids = nullptr; }
+    g->n_entries = 0;
+    if (n_entries == 0) return 0;
+    MSE_HIP_TRY(hipMalloc((void**)&g->entry_ids, n_entries * 4));
+    MSE_HIP_TRY(hipMalloc((void**)&g->entry_rows, n_entries * b->d * 2));
+    MSE_HIP_TRY(hipMemcpy(g->entry_ids, node_ids, n_entries * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gather_entry_rows_kernel, dim3((unsigned)n_entries), dim3(64), 0, nullptr, b->dev, (int)b->d, g->entry_ids, g->entry_rows);
+    MSE_HIP_TRY(hipGetLastError());
+    MSE_HIP_TRY(hipDeviceSynchronize());
+    g->entry_base = mse_base_wrap_device(g->entry_rows, n_entries, b->d);
+    if (!g->entry_base) return -1;
+    g->entry_s = mse_searcher_new(g->entry_base);
+    if (!g->entry_s) return -1;
+    g->n_entries = n_entries;
+    return 0;
+}
+
+int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
+                        const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
+                        uint32_t* ids, int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!g || !ids || !scores) return fail("disk_query_topk: null argument");
+    if (nq == 0) return 0;
+    std::vector<uint32_t> tmp;
+    if (!n_visited || !cmps || !pq_cmps) {
+        tmp.resize(3 * nq);
+        if (!n_visited) n_visited = tmp.data();
+        if (!cmps) cmps = tmp.data() + nq;
+        if (!pq_cmps) pq_cmps = tmp.data() + 2 * nq;
+    }
+    FusedQuery fz;
+    fz.entries = starts ? nullptr : g;
+    fz.k = k; fz.ids = ids; fz.scores = scores;
+    // the entry table's searcher and scratch serve one call at a time
+    std::unique_lock<std::mutex> lk(g->entry_mu, std::defer_lock);
+    if (!starts) lk.lock();
+    // visited records per query kept on the device: a search fetches about search_list + a few nodes; a list that outgrows the arrays
+    // is never cut (the reference keeps every record) -- the call is repeated with four times the room
+    size_t cap = (std::max(2 * search_list + 64, k) + 63) / 64 * 64;
+    for (;;) {
+        const int rc = disk_search_batch_impl(-1, s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, nullptr,
+                                              nullptr, nullptr, nullptr, nullptr, cap, n_visited, cmps, pq_cmps, &fz);
+        if (rc != -2) return rc;
+        if (cap >= ((size_t)1 << 16)) return fail("disk_query_topk: a search visited more than 65536 records");
+        cap *= 4;
+    }
 }
 
 int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,

@@ -130,4 +130,12 @@ struct mse_graph {
     // meeting point of the ONE-query calls of mse_disk_search_batch(_f32) from many threads (beam_search.hip), made on first use
     mutable std::mutex co_mu;
     mutable mse::Coalescer* co = nullptr;
+    // entry table of the fused request path (mse_graph_set_entries / mse_disk_query_topk, beam_search.hip): copies of the entry
+    // records' vectors, their node ids, and a searcher over the copies; one fused call at a time uses them (entry_mu)
+    uint16_t* entry_rows = nullptr;
+    uint32_t* entry_ids = nullptr;
+    size_t n_entries = 0;
+    mse_base* entry_base = nullptr;
+    mse_searcher* entry_s = nullptr;
+    mutable std::mutex entry_mu;
 };

@@ -703,8 +703,12 @@ size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * 320 * 128; }
 // packed_scratch: mfma_packed_bytes(d) bytes of device scratch owned by the caller (per searcher)
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
                      void* packed_scratch, float* group_max, int n_cu, hipStream_t stream, hipEvent_t ev_begin,
-                     hipEvent_t ev_end) {
+                     hipEvent_t ev_end, int gm_stride) {
     if (n_rows == 0) return 0;
+    // the kernels use their last integer argument only as the row stride of group_max: a pass may write its nq_pad columns into a
+    // wider array (several passes side by side, api.hip mfma_pass over a small base)
+    const int gs = gm_stride ? gm_stride : nq_pad;
+    if (gs < nq_pad) return fail("scan_mfma: group-maximum stride below the pass width");
     if (d % 64 != 0 || d <= 0 || d > D_MAX) return fail("vector width must be a positive multiple of 64");
     if (nq_pad != 128 && nq_pad != 256 && !(nq_pad == 192 && (d / KB) % 3 == 0) && !(nq_pad == 320 && (d / KB) % 2 == 0))
         return fail("scan_mfma: query tile must be padded to 128, 192 (K blocks divisible by 3), 256 or 320 (K blocks even)");
@@ -720,26 +724,26 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     // and alternative tilings.  None of this is compiled into the product library.
     const int abl = getenv("MSE_SCAN_ABL") ? atoi(getenv("MSE_SCAN_ABL")) : 0;
     const int v2d = getenv("MSE_SCAN_2D") ? atoi(getenv("MSE_SCAN_2D")) : -1;
-    if (nq_pad == 128 && S == 3 && abl == 16) rc = launch_variant<3, 8, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    if (nq_pad == 128 && S == 3 && abl == 16) rc = launch_variant<3, 8, 16>(grid, stream, base, n_rows, d, packed, group_max, gs);
     else if (nq_pad == 256 && S == 3 && abl) {   // timing ablations of the round-2 kernel
         switch (abl) {
-            case 1: rc = launch_variant<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 2: rc = launch_variant<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 4: rc = launch_variant<3, 16, 4>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 6: rc = launch_variant<3, 16, 6>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 8: rc = launch_variant<3, 16, 8>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 9: rc = launch_variant<3, 16, 9>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 14: rc = launch_variant<3, 16, 14>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
-            case 16: rc = launch_variant<3, 16, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad); break;
+            case 1: rc = launch_variant<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 2: rc = launch_variant<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 4: rc = launch_variant<3, 16, 4>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 6: rc = launch_variant<3, 16, 6>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 8: rc = launch_variant<3, 16, 8>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 9: rc = launch_variant<3, 16, 9>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 14: rc = launch_variant<3, 16, 14>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
+            case 16: rc = launch_variant<3, 16, 16>(grid, stream, base, n_rows, d, packed, group_max, gs); break;
             default: break;
         }
     }
-    else if (nq_pad == 256 && S == 3 && v2d == 0) rc = launch_variant<3, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else if (nq_pad == 256 && S == 3 && v2d == 161) rc = launch_2d<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else if (nq_pad == 256 && S == 3 && v2d == 162) rc = launch_2d<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else if (nq_pad == 256 && S == 3 && v2d == 163) rc = launch_2d<3, 16, 3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else if (nq_pad == 256 && S == 3 && v2d == 17) rc = launch_2s<3>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-    else if (nq_pad == 256 && S == 3 && v2d == 32) rc = launch_2d<3, 32>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+    else if (nq_pad == 256 && S == 3 && v2d == 0) rc = launch_variant<3, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
+    else if (nq_pad == 256 && S == 3 && v2d == 161) rc = launch_2d<3, 16, 1>(grid, stream, base, n_rows, d, packed, group_max, gs);
+    else if (nq_pad == 256 && S == 3 && v2d == 162) rc = launch_2d<3, 16, 2>(grid, stream, base, n_rows, d, packed, group_max, gs);
+    else if (nq_pad == 256 && S == 3 && v2d == 163) rc = launch_2d<3, 16, 3>(grid, stream, base, n_rows, d, packed, group_max, gs);
+    else if (nq_pad == 256 && S == 3 && v2d == 17) rc = launch_2s<3>(grid, stream, base, n_rows, d, packed, group_max, gs);
+    else if (nq_pad == 256 && S == 3 && v2d == 32) rc = launch_2d<3, 32>(grid, stream, base, n_rows, d, packed, group_max, gs);
     if (rc != -2) {
         if (rc) return rc;
         if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));
@@ -749,19 +753,19 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     if (nq_pad == 320) {
         // 20 column tiles per wave (32 rows x 320 queries, 160 accumulator registers of 252 used: 24 tiles spill and run 2.6x
         // slower), two-stage row ring: 2 x 40 KiB of query tiles + 8 x 2 x 4 KiB = 144 KiB of LDS.
-        rc = launch_variant<2, 20, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        rc = launch_variant<2, 20, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
     } else if (nq_pad == 192) {
         // 12 column tiles on the one-dimensional wave split (32 rows x 192 queries per wave, 96 accumulators): the point between
         // the HBM-bound 128-query pass and the power-bound 256-query pass (profiles/r04_scan_variants.txt)
-        rc = launch_variant<3, 12, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        rc = launch_variant<3, 12, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
     } else if (nq_pad == 128) {
-        if (S == 3) rc = launch_variant<3, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else if (S == 2) rc = launch_variant<2, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else rc = launch_variant<1, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        if (S == 3) rc = launch_variant<3, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
+        else if (S == 2) rc = launch_variant<2, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
+        else rc = launch_variant<1, 8, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
     } else {
-        if (S == 3) rc = launch_2d<3, 16>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else if (S == 2) rc = launch_variant<2, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
-        else rc = launch_variant<1, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, nq_pad);
+        if (S == 3) rc = launch_2d<3, 16>(grid, stream, base, n_rows, d, packed, group_max, gs);
+        else if (S == 2) rc = launch_variant<2, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
+        else rc = launch_variant<1, 16, 0>(grid, stream, base, n_rows, d, packed, group_max, gs);
     }
     if (rc) return rc;
     if (ev_end) MSE_HIP_TRY(hipEventRecord(ev_end, stream));

@@ -205,6 +205,42 @@ def disk_search_batch(searcher: Searcher, quantizer, codes, dgraph: DeviceGraph,
     return out
 
 
+def set_entries(dgraph, vecs, node_ids):
+    """The entry table of disk_query_topk: `node_ids` name the entry records (the reference: the shard medioids,
+    query_disk_index.rs:254-256,447-450; for a one-piece index a sample of its rows); copies of their vectors stay with the graph."""
+    ids = np.ascontiguousarray(node_ids, np.uint32).reshape(-1)
+    check(ffi.lib().mse_graph_set_entries(dgraph._h, vecs._h, _p(ids, C.c_uint32), ids.size), "graph_set_entries")
+
+
+def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, starts=None, luts=None, descriptor_scales=None,
+                    disable_pq=False, beamwidth=1, search_list=1000):
+    """The request path of query_disk_index (:436-540) for a batch in one device submission: entry node (by the graph's entry table
+    when `starts` is None), greedy_search, the visited records ordered by exact score and cut to the first k.  f16 query rows in,
+    (ids [nq, k] uint32, scores [nq, k] int64, stats dict) out; ids / scores equal topk_of_visited(disk_search_batch(...)) for the
+    same start nodes.  Rows with fewer than k visited records are padded with ID_NONE / INT64_MIN."""
+    q = _bits(queries)
+    q = q.reshape(-1, q.shape[-1])
+    nq = q.shape[0]
+    tables = None
+    if luts is not None:
+        tables = np.ascontiguousarray(np.stack([getattr(t, "table", t) for t in luts]) if not isinstance(luts, np.ndarray) else luts,
+                                      np.float32).reshape(nq, -1)
+    st = None if starts is None else np.ascontiguousarray(starts, np.uint32).reshape(nq)
+    sc = None
+    if descriptor_scales is not None:
+        sc = np.ascontiguousarray(descriptor_scales, np.float32)
+        if sc.ndim == 1:
+            sc = np.ascontiguousarray(np.broadcast_to(sc, (nq, sc.size)))
+    ids, scores = np.empty((nq, k), np.uint32), np.empty((nq, k), np.int64)
+    nv, cm, pc = np.empty(nq, np.uint32), np.empty(nq, np.uint32), np.empty(nq, np.uint32)
+    check(ffi.lib().mse_disk_query_topk(searcher._h, quantizer._h if quantizer is not None else None, codes._h if codes is not None else None,
+                                        dgraph._h, _p(st, C.c_uint32) if st is not None else None, _p(q, C.c_uint16),
+                                        _p(tables, C.c_float) if tables is not None else None, _p(sc, C.c_float) if sc is not None else None,
+                                        nq, int(bool(disable_pq)), int(beamwidth), int(search_list), int(k), _p(ids, C.c_uint32),
+                                        _p(scores, C.c_int64), _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32)), "disk_query_topk")
+    return ids, scores, {"n_visited": nv, "cmps": cm, "pq_cmps": pc}
+
+
 def topk_of_visited(res, k, keep=None):
     """Batch form of the server's last step (query_disk_index.rs:529-540): the reference sorts the WHOLE visited list by exact
     score after the dedup filter (:482-527) and returns all of it; this helper cuts that sorted list to its first k ids per query

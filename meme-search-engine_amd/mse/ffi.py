@@ -137,6 +137,8 @@ SIGNATURES = {
                                         u32p, u32p, u32p]),
     "mse_disk_search_batch_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
                                             u32p, u32p, u32p]),
+    "mse_graph_set_entries": (C.c_int, [vp, vp, u32p, sz]),
+    "mse_disk_query_topk": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
     "mse_graph_new": (vp, [sz, sz]),
     "mse_graph_to_host": (C.c_int, [vp, u32p, u32p]),
     "mse_graph_len": (sz, [vp]),

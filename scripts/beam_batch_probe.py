@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Beam-search throughput against queries per call at 1e7 rows (one-pass graph, sampled entries): python scripts/beam_batch_probe.py [rows]"""
+"""Beam-search throughput (the request path in one call, mse_disk_query_topk) against queries per call (one-pass graph, sampled entries):
+python scripts/beam_batch_probe.py [rows]"""
 import os
 import sys
 import time
@@ -28,20 +29,18 @@ g.build(s, order, med, mse.IndexBuildConfig(r=64, l=192, maxc=750), 4096)
 print("build s", time.perf_counter() - t0)
 qh = queries.cpu().numpy().view(np.uint16)
 _, truth = s.bruteforce_topk(qh, 10)
-e_idx = np.sort(np.random.default_rng(5).choice(n, max(4096, n // 1500), replace=False)).astype(np.int64)
-e_rows = rows[torch.from_numpy(e_idx).cuda()].contiguous()
-es = mse.Searcher(mse.VectorList.wrap_device(e_rows.data_ptr(), len(e_idx), D, keepalive=e_rows))
+e_idx = np.sort(np.random.default_rng(5).choice(n, max(4096, n // 1500), replace=False)).astype(np.uint32)
+mse.set_entries(g, vecs, e_idx)
 for nq in (256, 1024, 2048, 4096, 8192):
     for L in (32,):
         q = qh[:nq]
         def run():
-            _, top = es.bruteforce_topk(q, 1, mse.MODE_MFMA)
-            st = e_idx[top[:, 0]].astype(np.uint32)
-            return mse.disk_search_batch(s, None, None, g, st, q, None, None, True, 4, L, 1024, as_arrays=True)
+            return mse.disk_query_topk(s, None, None, g, q, 10, None, None, None, True, 4, L)
         run()
         t0 = time.perf_counter()
-        res = run()
-        dt = time.perf_counter() - t0
-        top = mse.topk_of_visited(res, 10)
+        reps = 3
+        for _ in range(reps):
+            top, _, stats = run()
+        dt = (time.perf_counter() - t0) / reps
         rec = sum(len(set(top[i].tolist()) & set(truth[i].tolist())) for i in range(nq)) / (10 * nq)
-        print(f"queries per call {nq:5d} L {L}: {nq / dt:9.0f} queries/s, recall@10 {rec:.4f}, {dt * 1e3:.2f} ms per call")
+        print(f"queries per call {nq:5d} L {L}: {nq / dt:9.0f} queries/s, recall@10 {rec:.4f}, {dt * 1e3:.2f} ms per call, {float(stats['cmps'].mean()):.1f} node fetches per query")

@@ -617,6 +617,64 @@ def test_device_resident_beam_search_matches_oracle(gpu, mse, orc, beamwidth, di
         mse.disk_search_batch(searcher, gpq, gcodes, dgraph, np.full(nq, n, np.uint32), qh, luts, scales, disable_pq, 2, search_list=L)
 
 
+@pytest.mark.parametrize("beamwidth,disable_pq,use_scales,L", [(4, True, False, 32), (2, False, True, 48), (4, True, True, 8)])
+def test_request_path_in_one_call_matches_oracle(gpu, mse, orc, beamwidth, disable_pq, use_scales, L):
+    """mse_disk_query_topk = entry node by the entry table + greedy_search + the visited records by exact score, first k
+    (query_disk_index.rs:436-540): against the oracle's search from the oracle-chosen entry and a host sort of its visited list."""
+    rng = np.random.default_rng(21)
+    n, deg, k = 3000, 14, 10
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:2000], iters=2)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    scales = (np.array([0.5, 0, -0.25, 1.0], np.float32) / np.float32(512)) if use_scales else None
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    nq = 37
+    qs = clustered_rows(orc, nq, n_centres=32, seed=300)
+    qh = orc.f16_bits(qs)
+    luts = np.stack([opq.preprocess_query(q) for q in qs])
+    entry_ids = np.sort(rng.choice(n, 40, replace=False)).astype(np.uint32)
+    with pytest.raises(mse.MseError):                                  # no entry table yet
+        mse.disk_query_topk(searcher, gpq, gcodes, dgraph, qh, k, None, luts, scales, disable_pq, beamwidth, L)
+    mse.set_entries(dgraph, vecs, entry_ids)
+    ids, scores, stats = mse.disk_query_topk(searcher, gpq, gcodes, dgraph, qh, k, None, luts, scales, disable_pq, beamwidth, L)
+    assert ids.shape == (nq, k) and scores.shape == (nq, k)
+    # the oracle's entry: the entry row with the largest exact dot product (lower row on a tie), then its search and a sort
+    _, best = orc.bruteforce_topk(base[entry_ids], qh, 1)
+    starts = entry_ids[best[:, 0]]
+    for i in range(nq):
+        _, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, desc, int(starts[i]), qh[i], luts[i], scales,
+                                                          disable_pq, beamwidth, L, None)
+        order = np.array(sorted(range(len(ovids)), key=lambda j: (-int(ovsc[j]), int(ovids[j]))), np.int64)   # score descending, id ascending on equal scores
+        want_ids = np.full(k, 0xFFFFFFFF, np.uint32)
+        want_sc = np.full(k, np.iinfo(np.int64).min, np.int64)
+        m = min(k, len(order))
+        want_ids[:m] = ovids[order[:m]]
+        want_sc[:m] = ovsc[order[:m]]
+        assert np.array_equal(ids[i], want_ids) and np.array_equal(scores[i], want_sc), i
+        assert (int(stats["cmps"][i]), int(stats["pq_cmps"][i]), int(stats["n_visited"][i])) == (ocm, opc, len(ovids)), i
+    # given start nodes: the same call without the entry step; and the batched search's own visited lists agree
+    ids2, scores2, _ = mse.disk_query_topk(searcher, gpq, gcodes, dgraph, qh, k, starts, luts, scales, disable_pq, beamwidth, L)
+    assert np.array_equal(ids2, ids) and np.array_equal(scores2, scores)
+    res = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qh, luts, scales, disable_pq, beamwidth, search_list=L,
+                                visited_cap=n, as_arrays=True)
+    assert np.array_equal(mse.topk_of_visited(res, k), ids.astype(np.int64))
+    # k beyond what a search visits: padded rows
+    ids3, scores3, st3 = mse.disk_query_topk(searcher, gpq, gcodes, dgraph, qh[:3], 200, starts[:3], luts[:3],
+                                             None if scales is None else scales, disable_pq, beamwidth, L)
+    for i in range(3):
+        nv = int(st3["n_visited"][i])
+        assert np.all(ids3[i, nv:] == 0xFFFFFFFF) and np.all(scores3[i, nv:] == np.iinfo(np.int64).min) and np.all(ids3[i, :min(nv, 200)] != 0xFFFFFFFF)
+    with pytest.raises(mse.MseError):
+        mse.set_entries(dgraph, vecs, np.array([n], np.uint32))
+
+
 @pytest.mark.parametrize("disable_pq", [False, True])
 def test_device_resident_beam_search_from_f32_queries(gpu, mse, orc, disable_pq):
     """f32 queries in: the f16 copies (RNE) and the distance tables are made on the device (query_disk_index.rs:475-477);
