@@ -191,13 +191,16 @@ static int mfma_pass(mse_searcher* s, const uint16_t* q_dev, int nq_pass, int k,
     MSE_HIP_TRY(hipMemcpyAsync(s->q_stage.p, q_dev, (size_t)nq_pass * d * 2, hipMemcpyDeviceToDevice, st));
     const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;
     if (s->gmax.ensure(n_groups * (size_t)nq_pad * 4)) return -1;
-    if (s->qpacked.ensure(mfma_packed_bytes(d))) return -1;
-    for (int q0 = 0; q0 < nq_pad; q0 += tile) {
-        const int w = std::min(tile, nq_pad - q0);   // a whole tile, or the padded remainder
-        const bool last = q0 + w >= nq_pad;
-        if (launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>() + (size_t)q0 * d, w, s->qpacked.p, s->gmax.as<float>() + q0, s->n_cu,
-                             st, s->timing && q0 == 0 ? s->ev0 : nullptr, s->timing && last ? s->ev1 : nullptr, nq_pad)) return -1;
-    }
+    // the full passes go out as ONE launch (a small base has few row tiles: its passes fill the chip side by side), then the remainder
+    const size_t one_tile_packed = (size_t)(d / 64) * tile * 128;
+    if (s->qpacked.ensure(std::max(mfma_packed_bytes(d), (size_t)std::max(n_full, 1) * one_tile_packed))) return -1;
+    if (n_full &&
+        launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>(), tile, s->qpacked.p, s->gmax.as<float>(), s->n_cu, st,
+                         s->timing ? s->ev0 : nullptr, s->timing && !rem ? s->ev1 : nullptr, nq_pad, n_full)) return -1;
+    if (rem &&
+        launch_scan_mfma(b->dev, b->n, d, s->q_stage.as<uint16_t>() + (size_t)n_full * tile * d, nq_pad - n_full * tile, s->qpacked.p,
+                         s->gmax.as<float>() + n_full * tile, s->n_cu, st, s->timing && !n_full ? s->ev0 : nullptr,
+                         s->timing ? s->ev1 : nullptr, nq_pad, 1)) return -1;
     bool timing_pending = s->timing;
     if (s->eps.ensure((size_t)nq_pass * 8) || s->margin.ensure((size_t)nq_pass * 8)) return -1;   // second halves: the widening's compact set
     // |mfma score - exact-order score| <= 2 * gamma_1151 * sum|x_i q_i| <= 1.4e-4 * |x||q|; doubled again

@@ -448,7 +448,9 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     const mse_base* b = s->base;
     // visited sets: bit maps, or hash tables once the index is so large that the tables are the smaller ones (visited_set.h)
     const size_t words = (b->n + 31) / 32;
-    const int table_bits = visited_table_bits(std::min<size_t>(b->n, search_list * 192 + 4096));
+    // adjacency set: a search of list L fetches about L + a few nodes and meets <= max_deg new ids at each (measured: 2 400 inserts at
+    // L = 32, R = 64); a search that outgrows its table is caught (half-full check, err bit 4) and the batch repeated with bit maps
+    const int table_bits = visited_table_bits(std::min<size_t>(b->n, search_list * 128 + 2048));
     const char* vm = getenv("MSE_VISITED_MODE");   // test hook: "hash" / "bitmap"
     const bool use_hash = visited_mode >= 0 ? visited_mode == 1 : (vm ? !strcmp(vm, "hash") : words > ((size_t)1 << table_bits));
     const size_t set_words = use_hash ? (size_t)1 << table_bits : words;

@@ -126,7 +126,8 @@ int launch_rank(const int64_t* scores, size_t n, const uint32_t* targets, int m,
 // group_max[q_pad_index][g] layout: [n_groups][nq_pad] floats (group-major), nq_pad multiple of 32
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
                      void* packed_scratch, float* group_max, int n_cu, hipStream_t stream,
-                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, int gm_stride = 0 /* row stride of group_max; 0 = nq_pad */);  // events bracket the scan kernel only
+                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr, int gm_stride = 0 /* row stride of group_max; 0 = nq_pad */,
+                     int n_pass = 1 /* passes in this launch: consecutive nq_pad-row query tiles, consecutive column ranges of group_max */);  // events bracket the scan kernel only
 size_t mfma_packed_bytes(int d);
 int mfma_query_tile(int d);  // most queries one pass handles at width d (320 or 256)
 int mfma_pad(int nq, int d);   // padded query count of a pass of nq <= 256 queries: 128, 192 or 256

@@ -80,6 +80,8 @@ __global__ void pack_queries_kernel(const uint16_t* __restrict__ queries, int d,
     const int nkb = d / KB;
     const int QT_SLOTS = bn * 8;
     const int total = nkb * QT_SLOTS;
+    queries += (size_t)blockIdx.y * bn * d;   // batched passes: pass y = the next bn query rows, the next `total` slots
+    packed += (size_t)blockIdx.y * total;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int kb = idx / QT_SLOTS;
         const int r = idx % QT_SLOTS;
@@ -111,7 +113,7 @@ __device__ __forceinline__ void dma16(const void* gptr, void* lds_wave_base) {
 template <int S, int NCT, int ABL = 0>
 __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
                                                            const uint4* __restrict__ packed_ro,
-                                                           float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
+                                                           float* __restrict__ gmax, int nq_pad, size_t n_tiles, uint32_t y_packed, uint32_t y_cols) {
     constexpr int BN = NCT * 16;
     constexpr int QT_BYTES = BN * 128;       // one query tile: BN x 64 f16
     constexpr int QI = BN / 64;              // DMA instructions per wave per query tile
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(W * 64) void scan_mfma_kernel(const uint16_t* __res
     const size_t n_groups = (n_rows + 31) / 32;
     char* const qbase = smem;                                     // [2][BN x 128 B] query tiles
     char* const xbase = smem + 2 * QT_BYTES + wave * (S * 4096);  // this wave's ring: S stages x 4 KiB
-    const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)(wave * QI * 64 + lane) * 16;
+    gmax += (size_t)blockIdx.y * y_cols;   // batched passes (launch_scan_mfma n_pass > 1): pass y has its own query tiles and columns
+    const char* const packed = reinterpret_cast<const char*>(packed_ro + (size_t)blockIdx.y * y_packed) + (size_t)(wave * QI * 64 + lane) * 16;
 
     size_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
@@ -306,7 +309,7 @@ __device__ __forceinline__ uint32_t memtime() { return (uint32_t)__builtin_amdgc
 template <int S, int MF, int PROF = 0>
 __global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
                                                              const uint4* __restrict__ packed_ro,
-                                                             float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
+                                                             float* __restrict__ gmax, int nq_pad, size_t n_tiles, uint32_t y_packed, uint32_t y_cols) {
     constexpr int BN = 256;
     constexpr int QT_BYTES = BN * 128;
     constexpr int QI = BN / 64;
@@ -320,7 +323,8 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __r
     const size_t n_groups = (n_rows + 31) / 32;
     char* const qbase = smem;
     char* const xbase = smem + 2 * QT_BYTES + rg * (S * RG_BYTES);
-    const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)(wave * QI * 64 + lane) * 16;
+    gmax += (size_t)blockIdx.y * y_cols;   // batched passes (launch_scan_mfma n_pass > 1): pass y has its own query tiles and columns
+    const char* const packed = reinterpret_cast<const char*>(packed_ro + (size_t)blockIdx.y * y_packed) + (size_t)(wave * QI * 64 + lane) * 16;
 
     size_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2d_kernel(const uint16_t* __r
 template <int S>
 __global__ __launch_bounds__(W * 64) void scan_mfma2s_kernel(const uint16_t* __restrict__ base, size_t n_rows, int d,
                                                              const uint4* __restrict__ packed_ro,
-                                                             float* __restrict__ gmax, int nq_pad, size_t n_tiles) {
+                                                             float* __restrict__ gmax, int nq_pad, size_t n_tiles, uint32_t y_packed, uint32_t y_cols) {
     static_assert(S == 3, "the specialised schedule is written for the 3-stage ring");
     constexpr int BN = 256;
     constexpr int QT_BYTES = BN * 128;
@@ -528,7 +532,8 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2s_kernel(const uint16_t* __r
     char* const xbase = xring + rg * (S * RG_BYTES);              // the ring this wave READS
     char* const xfill = xring + w4 * (S * RG_BYTES);              // the ring a row wave FILLS (row group = wave)
     char* const qfill = qbase + w4 * (NP * 1024);                 // a query wave's quarter of a query tile
-    const char* const packed = reinterpret_cast<const char*>(packed_ro) + (size_t)w4 * (NP * 1024) + lane * 16;
+    gmax += (size_t)blockIdx.y * y_cols;
+    const char* const packed = reinterpret_cast<const char*>(packed_ro + (size_t)blockIdx.y * y_packed) + (size_t)w4 * (NP * 1024) + lane * 16;
 
     size_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
@@ -643,13 +648,19 @@ __global__ __launch_bounds__(W * 64) void scan_mfma2s_kernel(const uint16_t* __r
 }
 #endif  // MSE_DEV_KERNELS
 
+// batched passes of one launch_scan_mfma call (set by it around its launches; launch_scan_mfma is not re-entered concurrently with
+// different values on one thread: thread_local)
+thread_local unsigned g_pass_count = 1;
+thread_local uint32_t g_pass_packed = 0, g_pass_cols = 0;
+
 template <typename K>
 int launch_kernel(K kernel, size_t lds, size_t grid, hipStream_t stream, const uint16_t* base, size_t n_rows, int d,
                   const uint4* packed, float* group_max, int nq_pad) {
     const size_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
     if (grid > n_tiles) grid = n_tiles;
     MSE_DYN_LDS(kernel, lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(W * 64), lds, stream, base, n_rows, d, packed, group_max, nq_pad, n_tiles);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid, g_pass_count), dim3(W * 64), lds, stream, base, n_rows, d, packed, group_max, nq_pad, n_tiles,
+                       g_pass_packed, g_pass_cols);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -703,8 +714,10 @@ size_t mfma_packed_bytes(int d) { return (size_t)(d / KB) * 320 * 128; }
 // packed_scratch: mfma_packed_bytes(d) bytes of device scratch owned by the caller (per searcher)
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,
                      void* packed_scratch, float* group_max, int n_cu, hipStream_t stream, hipEvent_t ev_begin,
-                     hipEvent_t ev_end, int gm_stride) {
+                     hipEvent_t ev_end, int gm_stride, int n_pass) {
     if (n_rows == 0) return 0;
+    if (n_pass < 1 || n_pass > 65535) return fail("scan_mfma: 1..65535 passes per launch");
+    if (n_pass > 1 && !gm_stride) return fail("scan_mfma: batched passes need a common group-maximum stride");
     // the kernels use their last integer argument only as the row stride of group_max: a pass may write its nq_pad columns into a
     // wider array (several passes side by side, api.hip mfma_pass over a small base)
     const int gs = gm_stride ? gm_stride : nq_pad;
@@ -713,7 +726,14 @@ int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t*
     if (nq_pad != 128 && nq_pad != 256 && !(nq_pad == 192 && (d / KB) % 3 == 0) && !(nq_pad == 320 && (d / KB) % 2 == 0))
         return fail("scan_mfma: query tile must be padded to 128, 192 (K blocks divisible by 3), 256 or 320 (K blocks even)");
     uint4* packed = reinterpret_cast<uint4*>(packed_scratch);
-    hipLaunchKernelGGL(pack_queries_kernel, dim3(64), dim3(256), 0, stream, queries_dev, d, nq_pad, packed);
+    // n_pass > 1: queries_dev holds n_pass x nq_pad rows, packed_scratch n_pass x mfma_packed_bytes(d), and pass y writes columns
+    // [y * nq_pad, (y + 1) * nq_pad) of group_max -- ONE launch; a small base (a few row tiles) then fills the chip with its passes
+    // side by side instead of running them one after the other on a few CUs
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(64, (unsigned)n_pass), dim3(256), 0, stream, queries_dev, d, nq_pad, packed);
+    struct PassScope {
+        PassScope(unsigned n, uint32_t pk, uint32_t cols) { g_pass_count = n; g_pass_packed = pk; g_pass_cols = cols; }
+        ~PassScope() { g_pass_count = 1; g_pass_packed = 0; g_pass_cols = 0; }
+    } pass_scope((unsigned)n_pass, (uint32_t)((size_t)(d / KB) * nq_pad * 8), (uint32_t)nq_pad);
     if (ev_begin) MSE_HIP_TRY(hipEventRecord(ev_begin, stream));
     const int nkb = d / KB;
     const int S = nkb % 3 == 0 ? 3 : nkb % 2 == 0 ? 2 : 1;   // ring depth: 3 when the K-block count allows it

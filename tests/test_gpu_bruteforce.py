@@ -111,6 +111,18 @@ def test_wide_passes_at_other_widths(gpu, mse, orc, d, nq):
     assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
 
 
+@pytest.mark.parametrize("n,nq,k", [(300, 2000, 1), (4096, 1500, 3), (33, 700, 5)])
+def test_many_queries_against_a_small_base(gpu, mse, orc, n, nq, k):
+    # a small base takes all its queries in ONE matrix-core call: the full passes side by side in one launch, the remainder after
+    # them, one tournament / re-score / certificate over all queries (api.hip mfma_call_tile; the request path's entry step)
+    base = orc.gen_rows_f16(SEED_BASE, 0, n)
+    q = orc.gen_rows_f16(SEED_QUERY, 0, nq)
+    s = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    sc, ids = s.bruteforce_topk(q, k, mse.MODE_MFMA)
+    ws, wi = orc.bruteforce_topk(base, q, k)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
 def test_ties_break_by_lower_id(gpu, mse, orc):
     # duplicated rows => exactly equal scores; order must be (score desc, id asc) in every mode
     rows = orc.gen_rows_f16(SEED_BASE, 0, 40)
