@@ -672,7 +672,7 @@ def graph_scale_bench(args):
     import numpy as np
     import torch
     import mse
-    n, nq, K, R, batch = int(args.graph_scale_rows), 8192, 10, 64, int(args.graph_batch)   # 4096 tuning + 4096 held-out queries: one wave per query puts 4096 searches on the chip at once (scripts/beam_batch_probe.py: 0.62 / 0.94 / 1.10 / 1.19 M queries/s at 1024 / 2048 / 4096 / 8192 per call, 2e6 rows)
+    n, nq, K, R, batch = int(args.graph_scale_rows), 12288, 10, 64, int(args.graph_batch)   # 4096 tuning + 2 x 4096 held-out queries (the second 4096 only for the two-thread figure): one wave per query puts 4096 searches on the chip at once (scripts/beam_batch_probe.py: 0.62 / 0.94 / 1.10 / 1.19 M queries/s at 1024 / 2048 / 4096 / 8192 per call, 2e6 rows)
     clustered = clustered_generator(n)
     rows, queries = clustered(n, 1), clustered(nq, 2)
     torch.cuda.synchronize()
@@ -693,8 +693,8 @@ def graph_scale_bench(args):
     t_exact = time.perf_counter() - t0
     # operating point chosen on the FIRST half of the queries (smallest search list whose recall@10 there reaches 0.95 + 0.01),
     # reported on the SECOND half (held out): timing and recall of the headline figure never saw the tuning queries
-    half = nq // 2
-    tune, held = slice(0, half), slice(half, nq)
+    half = nq // 3
+    tune, held, held2 = slice(0, half), slice(half, 2 * half), slice(half, nq)
 
     # Entry points.  The reference starts a search at the medioid of the shard whose centroid is closest to the query
     # (src/query_disk_index.rs:254-256,447-450).  Here the graph is ONE piece; the same idea without shards: `n_entry` sampled base
@@ -728,16 +728,58 @@ def graph_scale_bench(args):
         if pt["recall_at_10"] >= 0.97:
             chosen = run(L, held, True)
             break
+    # 2 x 4096 held-out queries from TWO request threads, each with its own searcher (scratch + stream) and its own 4096 queries, three
+    # calls each: one thread's upload of 4.7 MB of queries and its host-side work overlap the other's kernels -- the request handler's
+    # shape with more than one request in flight.  Recall is that of the one-call figure (the same searches).
+    two = None
+    if chosen:
+        try:
+            import threading
+            L = chosen["search_list"]
+            hq = qh[held2]
+            parts = [hq[: len(hq) // 2], hq[len(hq) // 2:]]
+            st2 = [None if n_entry > 0 else np.full(len(p), med, np.uint32) for p in parts]
+            s2 = [s, mse.Searcher(vecs)]
+            outs = [None, None]
+            reps = 3
+
+            def worker(i, count):
+                for _ in range(count):
+                    outs[i] = mse.disk_query_topk(s2[i], None, None, g, parts[i], K, st2[i], None, None, True, 4, L)[0]
+
+            for i in range(2):
+                worker(i, 1)          # warm each searcher's scratch
+            th = [threading.Thread(target=worker, args=(i, reps)) for i in range(2)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt2 = time.perf_counter() - t0
+            top2 = np.concatenate(outs)
+            m = len(hq)
+            rec2 = sum(len(set(top2[i].tolist()) & set(truth[held2.start + i].tolist())) for i in range(m)) / (K * m)
+            two = {"threads": 2, "queries_per_call": len(parts[0]), "calls_per_thread": reps, "queries_per_s": reps * m / dt2, "recall_at_10": rec2}
+            s2[1].close()
+        except Exception as e:  # noqa: BLE001
+            two = {"error": repr(e)}
     g.close()
     # BASELINE configs[4] as specified, on this quantisable set (pq_rerank_leg); queries go through 32 per call, eight per pass
     try:
-        rerank = pq_rerank_leg(rows, vecs, s, queries, truth, K)
+        rerank = pq_rerank_leg(rows, vecs, s, queries[:half], truth[:half], K)
     except Exception as e:  # noqa: BLE001
         rerank = {"error": repr(e)}
+    # the figure: the two-request-thread rate when it was measured and is the higher one, else the single call's
+    best = chosen
+    if chosen and two and two.get("queries_per_s", 0) > chosen["queries_per_s"]:
+        best = {"queries_per_s": two["queries_per_s"], "recall_at_10": two["recall_at_10"]}
     return {"metric": f"queries/sec over a {n:.0e}x1152 graph index @ recall@10>=0.95 (GPU-resident beam search)", "pq_rerank": rerank,
-            "value": chosen["queries_per_s"] if chosen else None, "unit": "queries/s", "recall_at_10": chosen["recall_at_10"] if chosen else None,
-            "search_list": chosen["search_list"] if chosen else None, "beamwidth": 4, "batch": half, "sweep": sweep,
-            "operating_point": "search list picked on queries 0..%d (tuning recall >= 0.97), value / recall measured on the held-out queries %d..%d" % (half - 1, half, nq - 1),
+            "value": best["queries_per_s"] if best else None, "unit": "queries/s", "recall_at_10": best["recall_at_10"] if best else None,
+            "value_is": ("two request threads x 4096 queries per call" if best is not chosen else "one call of 4096 queries") if best else None,
+            "one_call": {"queries_per_s": chosen["queries_per_s"], "recall_at_10": chosen["recall_at_10"], "queries": chosen["queries"],
+                         "node_fetches_per_query": chosen["node_fetches_per_query"]} if chosen else None,
+            "search_list": chosen["search_list"] if chosen else None, "beamwidth": 4, "batch": half, "sweep": sweep, "two_request_threads": two,
+            "operating_point": "search list picked on queries 0..%d (tuning recall >= 0.97), value / recall measured on the held-out queries %d..%d (two_request_threads: %d..%d)" % (half - 1, half, 2 * half - 1, half, nq - 1),
             "build": {"seconds": t_build, "points_per_s": n * int(args.graph_passes) / t_build, "passes": int(args.graph_passes), "r": R, "l": 192, "maxc": 750, "batch": batch},
             "exact_scan_same_index_queries_per_s": nq / t_exact,
             "entry_points": (f"{n_entry} sampled base rows; a search starts at the one with the largest dot product with its query (exact top-1, timed); "

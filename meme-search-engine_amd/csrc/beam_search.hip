@@ -395,6 +395,7 @@ __global__ void entry_starts_kernel(const uint32_t* __restrict__ best_row, const
 // what the fused request path (mse_disk_query_topk) adds to a batched search: where the start nodes come from and what travels back
 struct FusedQuery {
     const mse_graph* entries = nullptr;   // start node = node id of the entry row with the largest dot product (NULL: `starts` from the host)
+    mse_searcher* entry_s = nullptr;      // searcher over the entry rows borrowed from the graph's pool for this call
     size_t k = 0;
     uint32_t* ids = nullptr;              // host [nq][k]
     int64_t* scores = nullptr;            // host [nq][k]
@@ -421,7 +422,8 @@ void mse_graph_free(mse_graph* g) {
     if (!g) return;
     delete g->co;   // joins its worker; no search may be in flight
     g->co = nullptr;
-    if (g->entry_s) mse_searcher_free(g->entry_s);
+    for (mse_searcher* es : g->entry_pool) mse_searcher_free(es);
+    g->entry_pool.clear();
     if (g->entry_base) mse_base_free(g->entry_base);
     if (g->entry_rows) (void)hipFree(g->entry_rows);
     if (g->entry_ids) (void)hipFree(g->entry_ids);
@@ -482,7 +484,7 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     if (b->d % 32 || b->d > 4096) return fail("disk_search_batch: vector width must be a multiple of 32");
     if (!fz && visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
     if (fz && (fz->k == 0 || fz->k > visited_cap || fz->k > (size_t)TOPK_KMAX - 64 || !fz->ids || !fz->scores)) return fail("disk_query_topk: bad k / outputs");
-    if (fz && fz->entries && (!fz->entries->entry_s || fz->entries->n_entries == 0 || fz->entries->entry_base->d != b->d))
+    if (fz && fz->entries && (!fz->entry_s || fz->entries->n_entries == 0 || fz->entries->entry_base->d != b->d))
         return fail("disk_query_topk: the graph has no entry table for these vectors (mse_graph_set_entries)");
     for (size_t q = 0; starts && q < nq; q++)
         if (starts[q] >= b->n) return fail("disk_search_batch: start node out of range");
@@ -517,8 +519,8 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         const mse_graph* eg = fz->entries;
         int64_t* e_sc = fzb.as<int64_t>();
         uint32_t* e_row = reinterpret_cast<uint32_t*>(fzb.as<char>() + nq * 8);
-        if (mse_searcher_set_stream(eg->entry_s, st)) return -1;
-        if (mse_bruteforce_topk_f16_dev(eg->entry_s, dq.p, nq, 1, MSE_MODE_AUTO, 0, e_sc, e_row)) return -1;
+        if (mse_searcher_set_stream(fz->entry_s, st)) return -1;
+        if (mse_bruteforce_topk_f16_dev(fz->entry_s, dq.p, nq, 1, MSE_MODE_AUTO, 0, e_sc, e_row)) return -1;
         hipLaunchKernelGGL(entry_starts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, e_row, eg->entry_ids, eg->n_entries, nq, dst.as<uint32_t>());
         MSE_HIP_TRY(hipGetLastError());
     } else {
@@ -717,7 +719,8 @@ int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_
     for (size_t i = 0; i < n_entries; i++)
         if (node_ids[i] >= g->n) return fail("graph_set_entries: entry id out of range");
     std::lock_guard<std::mutex> lk(g->entry_mu);
-    if (g->entry_s) { mse_searcher_free(g->entry_s); g->entry_s = nullptr; }
+    for (mse_searcher* es : g->entry_pool) mse_searcher_free(es);   // (no query may be in flight while the table is replaced)
+    g->entry_pool.clear();
     if (g->entry_base) { mse_base_free(g->entry_base); g->entry_base = nullptr; }
     if (g->entry_rows) { (void)hipFree(g->entry_rows); g->entry_rows = nullptr; }
     if (g->entry_ids) { (void)hipFree(g->entry_ids); g->entry_ids = nullptr; }
@@ -731,9 +734,22 @@ int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_
     MSE_HIP_TRY(hipDeviceSynchronize());
     g->entry_base = mse_base_wrap_device(g->entry_rows, n_entries, b->d);
     if (!g->entry_base) return -1;
-    g->entry_s = mse_searcher_new(g->entry_base);
-    if (!g->entry_s) return -1;
     g->n_entries = n_entries;
+    // one searcher now, used once: whatever the base prepares lazily for the matrix-core path (row norms) exists before callers on
+    // several threads arrive
+    mse_searcher* es = mse_searcher_new(g->entry_base);
+    if (!es) return -1;
+    {
+        DevBuf tmp;
+        const size_t nqw = 16;
+        if (tmp.ensure(nqw * b->d * 2 + nqw * 12)) { mse_searcher_free(es); return -1; }
+        MSE_HIP_TRY(hipMemset(tmp.p, 0, nqw * b->d * 2 + nqw * 12));
+        char* o = tmp.as<char>() + nqw * b->d * 2;
+        const int rc = mse_bruteforce_topk_f16_dev(es, tmp.p, nqw, 1, MSE_MODE_MFMA, 0, o, o + nqw * 8);
+        MSE_HIP_TRY(hipStreamSynchronize(es->stream));
+        if (rc) { mse_searcher_free(es); return -1; }
+    }
+    g->entry_pool.push_back(es);
     return 0;
 }
 
@@ -752,9 +768,20 @@ int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const m
     FusedQuery fz;
     fz.entries = starts ? nullptr : g;
     fz.k = k; fz.ids = ids; fz.scores = scores;
-    // the entry table's searcher and scratch serve one call at a time
-    std::unique_lock<std::mutex> lk(g->entry_mu, std::defer_lock);
-    if (!starts) lk.lock();
+    // a searcher over the entry rows for the duration of this call (made on first use, returned to the graph's pool afterwards)
+    struct Borrow {
+        const mse_graph* g; mse_searcher* es = nullptr;
+        ~Borrow() { if (es) { std::lock_guard<std::mutex> lk(g->entry_mu); g->entry_pool.push_back(es); } }
+    } borrow{g};
+    if (!starts) {
+        if (!g->entry_base || g->n_entries == 0) return fail("disk_query_topk: the graph has no entry table (mse_graph_set_entries)");
+        {
+            std::lock_guard<std::mutex> lk(g->entry_mu);
+            if (!g->entry_pool.empty()) { borrow.es = g->entry_pool.back(); g->entry_pool.pop_back(); }
+        }
+        if (!borrow.es && !(borrow.es = mse_searcher_new(g->entry_base))) return -1;
+        fz.entry_s = borrow.es;
+    }
     // visited records per query kept on the device: a search fetches about search_list + a few nodes; a list that outgrows the arrays
     // is never cut (the reference keeps every record) -- the call is repeated with four times the room
     size_t cap = (std::max(2 * search_list + 64, k) + 63) / 64 * 64;

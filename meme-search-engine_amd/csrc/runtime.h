@@ -136,6 +136,8 @@ struct mse_graph {
     uint32_t* entry_ids = nullptr;
     size_t n_entries = 0;
     mse_base* entry_base = nullptr;
-    mse_searcher* entry_s = nullptr;
+    // searchers over the entry rows: a fused call borrows one for its duration (its scratch is in use until the call's stream is
+    // drained), so that calls from several threads -- each with its own searcher and stream -- overlap instead of queueing
+    mutable std::vector<mse_searcher*> entry_pool;
     mutable std::mutex entry_mu;
 };
