@@ -675,6 +675,43 @@ def test_request_path_in_one_call_matches_oracle(gpu, mse, orc, beamwidth, disab
         mse.set_entries(dgraph, vecs, np.array([n], np.uint32))
 
 
+def test_request_path_from_several_threads(gpu, mse, orc):
+    """Four request threads, each with its own searcher, call mse_disk_query_topk at once (entry searchers come from the graph's
+    pool): every thread gets what the call returns when made alone."""
+    import threading
+    rng = np.random.default_rng(22)
+    n, deg, k, L = 4000, 16, 10, 24
+    x = clustered_rows(orc, n, n_centres=40)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    mse.set_entries(dgraph, vecs, np.sort(rng.choice(n, 64, replace=False)).astype(np.uint32))
+    qsets = [orc.f16_bits(clustered_rows(orc, 300 + 17 * t, n_centres=40, seed=400 + t)) for t in range(4)]
+    ref = mse.Searcher(vecs)
+    want = [mse.disk_query_topk(ref, None, None, dgraph, q, k, None, None, None, True, 4, L) for q in qsets]
+    got, errs = [None] * 4, []
+
+    def worker(t):
+        try:
+            s = mse.Searcher(vecs)
+            for _ in range(5):
+                got[t] = mse.disk_query_topk(s, None, None, dgraph, qsets[t], k, None, None, None, True, 4, L)
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for t in range(4):
+        assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1])
+        assert np.array_equal(got[t][2]["cmps"], want[t][2]["cmps"])
+
+
 @pytest.mark.parametrize("disable_pq", [False, True])
 def test_device_resident_beam_search_from_f32_queries(gpu, mse, orc, disable_pq):
     """f32 queries in: the f16 copies (RNE) and the distance tables are made on the device (query_disk_index.rs:475-477);
