@@ -44,6 +44,7 @@ struct BeamArgs {
     uint32_t* out_ids; long long* out_scores; uint32_t* out_len;
     uint32_t* vis_ids; long long* vis_scores; size_t vis_cap; uint32_t* n_visited;
     uint32_t* cmps; uint32_t* pq_cmps; uint32_t* err;
+    int hash_slots;   // LDS table of a beam iteration's neighbour ids: power of two >= 2 x p_cap
     int fill_vis;   // fused request path: slots of the visited arrays past n_visited are set to (ID_NONE, INT64_MIN) for the device top-k
 };
 
@@ -69,10 +70,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
     uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
     uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += p_cap * 4;
-    int* s_rank = reinterpret_cast<int*>(p);
+    int* s_rank = reinterpret_cast<int*>(p); p += p_cap * 4;
+    uint32_t* s_hash = reinterpret_cast<uint32_t*>(p);   // [hash_slots]: first positions of the ids of one beam iteration's lists
     __shared__ int s_len, s_next, s_npts, s_npre, s_ties, s_abort;
     __shared__ uint32_t s_pts[BS_BEAM_MAX];
     __shared__ int s_seg[BS_BEAM_MAX];
+    __shared__ int s_visok[BS_BEAM_MAX];
     __shared__ long long s_ptsc[BS_BEAM_MAX];
     __shared__ float s_scales[BS_DESC_MAX];
 
@@ -127,7 +130,31 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         const int npts = s_npts;
         if (npts == 0 || s_abort) break;
 
-        // ---- fetched nodes: exact score + bias (:168-170), one lane quad per node ----
+        // ---- everything that needs only the fetched nodes' ids, in flight together (round 4; one node after the other -- degree, then
+        // its list, then the set inserts, per node -- was 16 dependent round trips per beam of four):
+        //   the nodes' adjacency lists, concatenated node-major into LDS (degree and list entries are independent loads);
+        //   their exact scores + bias (:168-170), one lane quad per node;
+        //   their own entries in `visited` (HashSet::insert: the first of equal ids wins).
+        const int md = a.max_deg, ncat = npts * md;   // <= p_cap
+        uint32_t* const s_cat = reinterpret_cast<uint32_t*>(pre_sc);   // [p_cap] neighbour ids (pre_sc is not live here), 0xffffffff = none
+        uint32_t* const s_fresh = s_cat + p_cap;                        // [p_cap] 1 = goes into the pre-buffer
+        for (int e = tid; e < a.hash_slots; e += BS_THREADS) s_hash[e] = 0xffffffffu;
+        for (int e = tid; e < ncat; e += BS_THREADS) {
+            const int j = e / md, pos = e - j * md;
+            const uint32_t pt = s_pts[j];
+            const uint32_t dg = a.deg[pt];
+            uint32_t nb = a.adj[(size_t)pt * md + pos];
+            if ((uint32_t)pos >= dg) nb = 0xffffffffu;
+            else if (nb >= a.n) { nb = 0xffffffffu; atomicOr(a.err, 1u); }
+            s_cat[e] = nb;
+        }
+        if (tid < npts) {
+            const uint32_t pt = s_pts[tid];
+            bool first = true;
+            for (int i = 0; i < tid; i++) first &= s_pts[i] != pt;
+            const bool url = !a.has_url || a.has_url[pt];
+            s_visok[tid] = (first && visited_insert(bm_vis, a.hash_bits, pt) && url) ? 1 : 0;
+        }
         if (wave == 0) {
             const int qd = lane >> 2;
             const uint32_t pt = s_pts[qd < npts ? qd : npts - 1];
@@ -136,44 +163,63 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         }
         __syncthreads();
 
-        // ---- visited list and fresh neighbours, node by node in fetch order (:171-188) ----
+        // ---- fresh neighbours (:171-188).  The reference walks the nodes in fetch order and offers every neighbour to
+        // `visited_adjacent`: an id enters the pre-buffer at its FIRST position in the concatenated lists, if the set did not hold it
+        // before.  First positions by a small open-addressing table in LDS (slot = smallest position seen for an id) ...
+        const uint32_t hmask = (uint32_t)a.hash_slots - 1u;
+        for (int e = tid; e < ncat; e += BS_THREADS) {
+            const uint32_t id = s_cat[e];
+            if (id == 0xffffffffu) continue;
+            uint32_t h = (id * 2654435761u) & hmask;
+            for (;;) {
+                const uint32_t old = atomicCAS(&s_hash[h], 0xffffffffu, (uint32_t)e);
+                if (old == 0xffffffffu) break;
+                if (s_cat[old] == id) { atomicMin(&s_hash[h], (uint32_t)e); break; }
+                h = (h + 1) & hmask;
+            }
+        }
+        __syncthreads();
+        // ... then ONE round of set inserts for the first positions, all lanes at once
+        for (int e = tid; e < ncat; e += BS_THREADS) {
+            const uint32_t id = s_cat[e];
+            uint32_t fresh = 0;
+            if (id != 0xffffffffu) {
+                uint32_t h = (id * 2654435761u) & hmask;
+                uint32_t v = s_hash[h];
+                while (v != 0xffffffffu && s_cat[v] != id) { h = (h + 1) & hmask; v = s_hash[h]; }   // (every id listed was entered above)
+                if (v == (uint32_t)e) fresh = visited_insert(bm_adj, a.hash_bits, id) ? 1u : 0u;
+            }
+            s_fresh[e] = fresh;
+        }
+        __syncthreads();
+        // ... and the pre-buffer in list order; s_seg[j] = entries up to and including node j's; the visited list in fetch order
         if (wave == 0) {
-            int npre = 0;
-            for (int j = 0; j < npts; j++) {
-                const uint32_t pt = s_pts[j];
-                if (lane == 0) {
+            int npre = 0, jb = 0;
+            for (int g0 = 0; g0 < ncat; g0 += 64) {
+                const int e = g0 + lane;
+                const bool f = e < ncat && s_fresh[e];
+                const unsigned long long m = __ballot(f);
+                if (f) pre_id[npre + __popcll(m & ((1ull << lane) - 1ull))] = s_cat[e];
+                while (jb < npts && (jb + 1) * md <= g0 + 64) {   // node jb's list ends inside this group of 64
+                    const int cut = (jb + 1) * md - g0;           // 1..64 entries of the group belong to nodes <= jb
+                    if (lane == 0) s_seg[jb] = npre + __popcll(cut >= 64 ? m : (m & ((1ull << cut) - 1ull)));
+                    jb++;
+                }
+                npre += __popcll(m);
+            }
+            if (lane == 0) {
+                s_npre = npre;
+                for (int j = 0; j < npts; j++) {
                     cmps++;
-                    if (visited_insert(bm_vis, a.hash_bits, pt) && (!a.has_url || a.has_url[pt])) {
+                    if (s_visok[j]) {
                         if (n_vis < a.vis_cap) {
-                            a.vis_ids[qi * a.vis_cap + n_vis] = pt;
+                            a.vis_ids[qi * a.vis_cap + n_vis] = s_pts[j];
                             a.vis_scores[qi * a.vis_cap + n_vis] = s_ptsc[j];
                         }
                         n_vis++;
                     }
                 }
-                int dg_all = (int)a.deg[pt];
-                if (dg_all > a.max_deg) dg_all = a.max_deg;
-                // 64 neighbours per round (merged indexes carry up to 2 R per node, dump_processor.rs:282-291); an id repeated in a
-                // later round finds its bit already set by the earlier one
-                for (int h0 = 0; h0 < dg_all; h0 += 64) {
-                    const int dg = dg_all - h0 < 64 ? dg_all - h0 : 64;
-                    uint32_t nb = lane < dg ? a.adj[(size_t)pt * a.max_deg + h0 + lane] : 0xffffffffu;
-                    bool cand = lane < dg;
-                    if (cand && nb >= a.n) { cand = false; atomicOr(a.err, 1u); }
-                    // an id listed twice in one adjacency list: the first occurrence is the one HashSet::insert accepts
-                    for (int l = 0; l < dg; l++) {
-                        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
-                        if (l < lane && o == nb) cand = false;
-                    }
-                    bool fresh = false;
-                    if (cand) fresh = visited_insert(bm_adj, a.hash_bits, nb);
-                    const unsigned long long m = __ballot(fresh);
-                    if (fresh) pre_id[npre + __popcll(m & ((1ull << lane) - 1ull))] = nb;
-                    npre += __popcll(m);
-                }
-                if (lane == 0) s_seg[j] = npre;
             }
-            if (lane == 0) s_npre = npre;
             n_adj += (uint32_t)npre;
             if (a.hash_bits && n_adj > (1u << (a.hash_bits - 1)) && lane == 0) {   // table half full: give up, the host repeats with bit maps
                 atomicOr(a.err, 4u);
@@ -541,7 +587,10 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
     a.err = cnt.as<uint32_t>() + 3 * nq;
     a.fill_vis = fz ? 1 : 0;
-    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16;
+    size_t hash_slots = 64;
+    while (hash_slots < 2 * p_cap) hash_slots *= 2;
+    a.hash_slots = (int)hash_slots;
+    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16 + hash_slots * 4;
     static const bool wide_only = MSE_DEV_KNOB("MSE_BEAM_FOUR_WAVES");   // developer library: the four-wave form for every search
     if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only) {
         hipLaunchKernelGGL(beam_search_kernel<64>, dim3((unsigned)nq), dim3(64), lds, st, a);
