@@ -165,10 +165,13 @@ static int exact_pass(mse_searcher* s, int nq_pass, int k, uint64_t id_offset, i
 // tournament / re-score / certificate over all of them.  The fixed cost of a pass (a dozen small launches and a host synchronisation
 // for the margins) is what a small base pays for: 4096 queries against a 4096-row entry table (the request path's entry step,
 // beam_search.hip) took 13 passes x 0.28 ms.
-static size_t mfma_call_tile(const mse_base* b) {
+static size_t mfma_call_tile(const mse_base* b, size_t k) {
     const size_t tile = (size_t)mfma_query_tile((int)b->d);
     const size_t n_groups = (b->n + GROUP_ROWS - 1) / GROUP_ROWS;
     size_t fit = ((size_t)256 << 20) / (std::max<size_t>(n_groups, 1) * 4) / tile * tile;
+    // the first round re-scores (k + 8) groups of 32 rows per query: ids + scores of all queries within 1 GiB
+    const size_t per_query = std::min<size_t>(std::max<size_t>(k + 8, 16), TOPK_KMAX) * GROUP_ROWS * 12;
+    fit = std::min(fit, ((size_t)1 << 30) / per_query / tile * tile);
     if (fit > 8192 / tile * tile) fit = 8192 / tile * tile;
     return std::max(fit, tile);
 }
@@ -510,7 +513,7 @@ int mse_bruteforce_topk_f16_dev(mse_searcher* s, const void* queries_dev, size_t
         return 0;
     }
     if (mode == MSE_MODE_MFMA) {
-        const size_t tile = mfma_call_tile(b);
+        const size_t tile = mfma_call_tile(b, k);
         for (size_t q0 = 0; q0 < nq; q0 += tile) {
             const int nqp = (int)std::min<size_t>(tile, nq - q0);
             if (mfma_pass(s, q + q0 * d, nqp, (int)k, id_offset, out_scores + q0 * k, out_ids + q0 * k, k)) return -1;
