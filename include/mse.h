@@ -342,7 +342,8 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *                          the query (:254-256,447-450); here node_ids name the entry records (shard medioids, or a sample of the
  *                          rows of a one-piece index) and a search starts at the one whose vector has the largest dot product
  *                          with the f16 query (exact top-1 on the device).  Copies of those vectors are kept with the graph.
- *   mse_disk_query_topk    starts == NULL: start nodes by the entry table; otherwise as given.  queries / luts / scales / disable_pq /
+ *   mse_disk_query_topk    starts == NULL: start nodes by the entry table; otherwise as given.  `queries` ([nq][d] f16) may be a host
+ *                          OR a device pointer (embeddings that never left the GPU); everything else is host memory.  luts / scales / disable_pq /
  *                          beamwidth / search_list as mse_disk_search_batch.  ids / scores [nq][k]: the k best visited records by
  *                          (exact score + bias) descending -- equal scores by id ascending (the reference's sort is unstable there) --
  *                          padded with MSE_ID_NONE / INT64_MIN; identical to sorting mse_disk_search_batch's visited list.

@@ -555,7 +555,8 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
             if (launch_pq_lut_batch(pq->centroids, (int)pq->n_centroids, (int)d, (int)pq->dpc, qt.as<float>(), nq, dl.as<float>(), st)) return -1;
         }
     } else {
-        MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyHostToDevice, st));
+        // hipMemcpyDefault: the f16 queries may sit in host memory or already on the device (the text tower's output): the runtime tells by the pointer
+        MSE_HIP_TRY(hipMemcpyAsync(dq.p, queries, nq * d * 2, hipMemcpyDefault, st));
         if (!disable_pq) MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
     }
     if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));

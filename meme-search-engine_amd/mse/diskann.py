@@ -215,12 +215,17 @@ def set_entries(dgraph, vecs, node_ids):
 def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, starts=None, luts=None, descriptor_scales=None,
                     disable_pq=False, beamwidth=1, search_list=1000):
     """The request path of query_disk_index (:436-540) for a batch in one device submission: entry node (by the graph's entry table
-    when `starts` is None), greedy_search, the visited records ordered by exact score and cut to the first k.  f16 query rows in,
+    when `starts` is None), greedy_search, the visited records ordered by exact score and cut to the first k.  f16 query rows in
+    (a host array, or `(device_pointer, nq)` for rows already on the device),
     (ids [nq, k] uint32, scores [nq, k] int64, stats dict) out; ids / scores equal topk_of_visited(disk_search_batch(...)) for the
     same start nodes.  Rows with fewer than k visited records are padded with ID_NONE / INT64_MIN."""
-    q = _bits(queries)
-    q = q.reshape(-1, q.shape[-1])
-    nq = q.shape[0]
+    if isinstance(queries, tuple):      # (device pointer, nq): f16 rows already resident on the searcher's device, contiguous
+        q_ptr, nq = C.cast(C.c_void_p(int(queries[0])), C.POINTER(C.c_uint16)), int(queries[1])
+    else:
+        q = _bits(queries)
+        q = q.reshape(-1, q.shape[-1])
+        nq = q.shape[0]
+        q_ptr = _p(q, C.c_uint16)
     tables = None
     if luts is not None:
         tables = np.ascontiguousarray(np.stack([getattr(t, "table", t) for t in luts]) if not isinstance(luts, np.ndarray) else luts,
@@ -234,7 +239,7 @@ def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, st
     ids, scores = np.empty((nq, k), np.uint32), np.empty((nq, k), np.int64)
     nv, cm, pc = np.empty(nq, np.uint32), np.empty(nq, np.uint32), np.empty(nq, np.uint32)
     check(ffi.lib().mse_disk_query_topk(searcher._h, quantizer._h if quantizer is not None else None, codes._h if codes is not None else None,
-                                        dgraph._h, _p(st, C.c_uint32) if st is not None else None, _p(q, C.c_uint16),
+                                        dgraph._h, _p(st, C.c_uint32) if st is not None else None, q_ptr,
                                         _p(tables, C.c_float) if tables is not None else None, _p(sc, C.c_float) if sc is not None else None,
                                         nq, int(bool(disable_pq)), int(beamwidth), int(search_list), int(k), _p(ids, C.c_uint32),
                                         _p(scores, C.c_int64), _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32)), "disk_query_topk")

@@ -659,6 +659,11 @@ def test_request_path_in_one_call_matches_oracle(gpu, mse, orc, beamwidth, disab
         want_sc[:m] = ovsc[order[:m]]
         assert np.array_equal(ids[i], want_ids) and np.array_equal(scores[i], want_sc), i
         assert (int(stats["cmps"][i]), int(stats["pq_cmps"][i]), int(stats["n_visited"][i])) == (ocm, opc, len(ovids)), i
+    # queries that are already on the device (a pointer instead of a host array): the same answer
+    import torch
+    qd = torch.from_numpy(qh.view(np.int16).copy()).cuda()
+    ids_d, scores_d, _ = mse.disk_query_topk(searcher, gpq, gcodes, dgraph, (qd.data_ptr(), nq), k, None, luts, scales, disable_pq, beamwidth, L)
+    assert np.array_equal(ids_d, ids) and np.array_equal(scores_d, scores)
     # given start nodes: the same call without the entry step; and the batched search's own visited lists agree
     ids2, scores2, _ = mse.disk_query_topk(searcher, gpq, gcodes, dgraph, qh, k, starts, luts, scales, disable_pq, beamwidth, L)
     assert np.array_equal(ids2, ids) and np.array_equal(scores2, scores)
