@@ -157,6 +157,9 @@ int mse_debug_dispatcher_fail_shared(mse_dispatcher* d, uint32_t n_passes);
  * *mismatches = requests that got a wrong answer, a wrong status or no error text. */
 int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, uint64_t stats_out[6],
                                  uint64_t* mismatches);
+/* the same through a coalescer with `workers` worker threads (the graph's request path runs two, csrc/dispatch.h) */
+int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, int workers,
+                                         uint64_t stats_out[6], uint64_t* mismatches);
 
 /* ---- row-sharded index over the GPUs of one node.  The reference has no multi-GPU
  * code; its query server is a thread per core, each with its own Scratch over shared read-only maps
@@ -347,11 +350,39 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *                          beamwidth / search_list as mse_disk_search_batch.  ids / scores [nq][k]: the k best visited records by
  *                          (exact score + bias) descending -- equal scores by id ascending (the reference's sort is unstable there) --
  *                          padded with MSE_ID_NONE / INT64_MIN; identical to sorting mse_disk_search_batch's visited list.
- *                          n_visited / cmps / pq_cmps: [nq] or NULL.  Every visited record takes part (no visited_cap to choose). */
+ *                          n_visited / cmps / pq_cmps: [nq] or NULL.  Every visited record takes part (no visited_cap to choose).
+ *   mse_graph_set_entry_centroids  the reference's entry rule itself (:254-256,447-450): centroids [n_entries][d] f32 are the shard
+ *                          centroids of the index header, node_ids the shards' medioids; a search starts at the medioid of the shard
+ *                          maximising scale_dot_result_f64(dot(centroid, query)) -- f32 operands (an f16 query widened exactly), the
+ *                          sum carried in f64 in index order (as mse_select_shard), the LAST maximum on ties (position_max_by_key).
+ *                          Replaces a table set by mse_graph_set_entries and vice versa.  Either setter waits for request-path calls
+ *                          in flight and keeps new ones out while it runs.
+ *   mse_disk_query_topk_f32  the handler as the reference runs it: f32 queries in; the entry step sees the f32 query, the f16 copy
+ *                          (RNE, :477) scores the fetched nodes, preprocess_query (:475) makes the distance tables on the device.
+ * THE REFERENCE'S CALL SHAPE (one request = one query on its own task, :436-540,711-736; perf_test.py: 1000 one-query requests at
+ * concurrency 100): calls of mse_disk_query_topk(_f32) with nq <= 16 whose queries are host memory meet in the graph's coalescer.
+ * Calls that can share a submission (same vectors, codec, codes, graph, disable_pq, beamwidth, search_list, kinds of inputs; k may
+ * differ) run as ONE entry step + ONE search launch + ONE select on a searcher owned by the worker thread, and every caller gets
+ * exactly what its call returns when made alone.  Such a call only reads `s` for the vectors it names: request threads may share one
+ * searcher handle for these calls (4096 request threads do not need 4096 streams).  mse_graph_set_coalescer (before the first such
+ * call, or with none in flight): queries per shared submission (0 = 1024), longest wait of the oldest request in microseconds
+ * (0 = 200; a lone caller never waits), worker threads (0 = 2: one submission's copies overlap the other's kernels).
+ * mse_graph_coalescer_stats: {queries, requests, submissions, most queries in one submission, deadline fires, 0}.
+ * DEVICE-RESIDENT QUERIES: the copy of `queries` runs on the searcher's stream.  If another stream produced them (a tower's), call
+ * mse_searcher_wait_stream(s, that_stream) first -- or synchronise that stream -- else the search may read them half written. */
 int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries);
+int mse_graph_set_entry_centroids(mse_graph* g, const float* centroids, size_t d, const uint32_t* node_ids, size_t n_entries);
 int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
                         const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
                         uint32_t* ids, int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
+int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const float* queries_f32,
+                            const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids,
+                            int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
+int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t max_wait_us, int workers);
+int mse_graph_coalescer_stats(const mse_graph* g, uint64_t out[6]);
+/* everything `producer_stream` (a hipStream_t) holds at the time of the call completes before anything this searcher's stream is
+ * given afterwards starts: an event recorded there, waited for here; no host synchronisation */
+int mse_searcher_wait_stream(mse_searcher* s, void* producer_stream);
 /* ---- Vamana graph build on the device (diskann/src/lib.rs:183-389, driven by
  * src/generate_index_shard.rs:85-133) ----
  * The graph being built is an mse_graph with max_deg = r (lists of at most r ids, stride r) that stays in HBM

@@ -449,6 +449,8 @@ void mse_searcher_free(mse_searcher* s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->ev_wait) (void)hipEventDestroy(s->ev_wait);
+    if (s->pin) (void)hipHostFree(s->pin);
     delete s;
 }
 int mse_searcher_set_stream(mse_searcher* s, void* hip_stream) {

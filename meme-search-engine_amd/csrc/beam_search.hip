@@ -18,6 +18,7 @@
 #include "exact_dot.h"
 #include "visited_set.h"
 #include "runtime.h"
+#include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -438,14 +439,71 @@ __global__ void entry_starts_kernel(const uint32_t* __restrict__ best_row, const
     starts[q] = entry_ids[r < n_entries ? r : 0];
 }
 
+// The reference's own entry rule (src/query_disk_index.rs:254-256,447-450): the shard whose centroid has the largest
+// scale_dot_result_f64(dot(centroid, query)) -- f32 operands, the sum carried in f64 in index order (the oracle's stated order for
+// simsimd's f32 dot) -- `position_max_by_key` keeping the LAST maximum; the search starts at that shard's medioid.  One workgroup
+// per query, a lane per shard (centroids transposed [d][E] so that the lanes of a wave read consecutive floats); the product of two
+// f32 values is exact in f64, so multiply-then-add and a fused multiply-add round alike.
+__global__ __launch_bounds__(256) void entry_by_centroid_kernel(const float* __restrict__ keys_t, int n_entries, int d, const float* __restrict__ q32,
+                                                                const uint16_t* __restrict__ q16, const uint32_t* __restrict__ entry_ids,
+                                                                uint32_t* __restrict__ starts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_q = reinterpret_cast<float*>(smem);
+    __shared__ long long s_key[256];
+    __shared__ int s_idx[256];
+    const int tid = threadIdx.x;
+    const size_t q = blockIdx.x;
+    for (int e = tid; e < d; e += 256) s_q[e] = q32 ? q32[q * d + e] : __half2float(reinterpret_cast<const __half*>(q16)[q * d + e]);
+    __syncthreads();
+    long long best = (long long)INT64_MIN;
+    int bi = -1;
+    for (int e = tid; e < n_entries; e += 256) {
+        double acc = 0.0;
+        for (int k = 0; k < d; k++) acc += (double)keys_t[(size_t)k * n_entries + e] * (double)s_q[k];
+        const long long key = scale_dot_result_f64(acc);
+        if (bi < 0 || key >= best) { best = key; bi = e; }   // e ascends within a lane: >= keeps the last maximum
+    }
+    s_key[tid] = best; s_idx[tid] = bi;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) {
+            const long long ok = s_key[tid + w];
+            const int oi = s_idx[tid + w];
+            if (oi >= 0 && (s_idx[tid] < 0 || ok > s_key[tid] || (ok == s_key[tid] && oi > s_idx[tid]))) { s_key[tid] = ok; s_idx[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) starts[q] = entry_ids[s_idx[0] < 0 ? 0 : s_idx[0]];
+}
+
+// one query's outputs of the fused request path (any of the counter pointers may be null)
+struct QueryDst {
+    uint32_t* ids; int64_t* scores; uint32_t *n_visited, *cmps, *pq_cmps; size_t k;
+};
+
 // what the fused request path (mse_disk_query_topk) adds to a batched search: where the start nodes come from and what travels back
 struct FusedQuery {
-    const mse_graph* entries = nullptr;   // start node = node id of the entry row with the largest dot product (NULL: `starts` from the host)
-    mse_searcher* entry_s = nullptr;      // searcher over the entry rows borrowed from the graph's pool for this call
-    size_t k = 0;
-    uint32_t* ids = nullptr;              // host [nq][k]
-    int64_t* scores = nullptr;            // host [nq][k]
+    const mse_graph* entries = nullptr;   // start node by the graph's entry table (NULL: `starts` from the host)
+    mse_searcher* entry_s = nullptr;      // searcher over the entry rows borrowed from the graph's pool for this call (row tables only)
+    size_t k = 0;                         // records selected per query on the device (the largest k of the batch)
+    // query q's results go to dst[q] (its first dst[q].k records) when dst is given -- the coalesced calls of many threads --
+    // otherwise to row q of the contiguous arrays below ([nq][k], [nq])
+    const QueryDst* dst = nullptr;
+    uint32_t* ids = nullptr;
+    int64_t* scores = nullptr;
+    uint32_t *n_visited = nullptr, *cmps = nullptr, *pq_cmps = nullptr;
 };
+
+// pinned host staging of a searcher (the fused path's ONE download per call; the coalescer's gathered inputs)
+int ensure_pin(void** pin, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return 0;
+    if (*pin) (void)hipHostFree(*pin);
+    *pin = nullptr; *cap = 0;
+    const size_t want = std::max<size_t>(2 * bytes, (size_t)1 << 16);
+    MSE_HIP_TRY(hipHostMalloc(pin, want, hipHostMallocDefault));
+    *cap = want;
+    return 0;
+}
 
 }  // namespace
 
@@ -466,13 +524,19 @@ mse_graph* mse_graph_from_host(const uint32_t* adj, const uint32_t* deg, size_t 
 
 void mse_graph_free(mse_graph* g) {
     if (!g) return;
-    delete g->co;   // joins its worker; no search may be in flight
+    delete g->co;   // joins its workers; no search may be in flight
     g->co = nullptr;
+    for (mse_graph::WorkerCtx& w : g->co_ctx) {
+        if (w.s) mse_searcher_free(w.s);
+        if (w.pin) (void)hipHostFree(w.pin);
+    }
+    g->co_ctx.clear();
     for (mse_searcher* es : g->entry_pool) mse_searcher_free(es);
     g->entry_pool.clear();
     if (g->entry_base) mse_base_free(g->entry_base);
     if (g->entry_rows) (void)hipFree(g->entry_rows);
     if (g->entry_ids) (void)hipFree(g->entry_ids);
+    if (g->entry_keys_t) (void)hipFree(g->entry_keys_t);
     if (g->adj) (void)hipFree(g->adj);
     if (g->deg) (void)hipFree(g->deg);
     if (g->has_url) (void)hipFree(g->has_url);
@@ -490,7 +554,7 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     const bool codec_needed = !disable_pq;
     // fused request path (fz): the search list and the visited records stay on the device, only the k best visited records travel back
     if (!s || !s->base || (!pq && codec_needed) || !c || !g || (!starts && !(fz && fz->entries)) || (!queries && !queries_f32) ||
-        (!luts && !queries_f32 && !disable_pq) || (!fz && (!buf_ids || !buf_scores || !buf_len)) || !n_visited || !cmps || !pq_cmps)
+        (!luts && !queries_f32 && !disable_pq) || (!fz && (!buf_ids || !buf_scores || !buf_len || !n_visited || !cmps || !pq_cmps)))
         return fail("disk_search_batch: null argument");
     if (nq == 0) return 0;
     const mse_base* b = s->base;
@@ -508,14 +572,24 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
             for (size_t q0 = 0; q0 < nq; q0 += piece) {
                 const size_t m = std::min(piece, nq - q0);
                 FusedQuery fp;
-                if (fz) { fp = *fz; fp.ids = fz->ids + q0 * fz->k; fp.scores = fz->scores + q0 * fz->k; }
+                if (fz) {
+                    fp = *fz;
+                    if (fz->dst) fp.dst = fz->dst + q0;
+                    else {
+                        fp.ids = fz->ids + q0 * fz->k; fp.scores = fz->scores + q0 * fz->k;
+                        fp.n_visited = fz->n_visited ? fz->n_visited + q0 : nullptr;
+                        fp.cmps = fz->cmps ? fz->cmps + q0 : nullptr;
+                        fp.pq_cmps = fz->pq_cmps ? fz->pq_cmps + q0 : nullptr;
+                    }
+                }
                 const int prc = disk_search_batch_impl(visited_mode, s, pq, c, g, starts ? starts + q0 : nullptr, queries ? queries + q0 * b->d : nullptr,
                                                        queries_f32 ? queries_f32 + q0 * b->d : nullptr, luts ? luts + q0 * 16384 : nullptr,
                                                        scales ? scales + q0 * c->n_desc : nullptr, m, disable_pq, beamwidth, search_list,
                                                        buf_ids ? buf_ids + q0 * search_list : nullptr, buf_scores ? buf_scores + q0 * search_list : nullptr,
                                                        buf_len ? buf_len + q0 : nullptr, visited_ids ? visited_ids + q0 * visited_cap : nullptr,
-                                                       visited_scores ? visited_scores + q0 * visited_cap : nullptr, visited_cap, n_visited + q0, cmps + q0,
-                                                       pq_cmps + q0, fz ? &fp : nullptr);
+                                                       visited_scores ? visited_scores + q0 * visited_cap : nullptr, visited_cap,
+                                                       n_visited ? n_visited + q0 : nullptr, cmps ? cmps + q0 : nullptr,
+                                                       pq_cmps ? pq_cmps + q0 : nullptr, fz ? &fp : nullptr);
                 if (prc) return prc;
             }
             return 0;
@@ -529,9 +603,14 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     if (c->n_desc > BS_DESC_MAX) return fail("disk_search_batch: at most 8 descriptors");
     if (b->d % 32 || b->d > 4096) return fail("disk_search_batch: vector width must be a multiple of 32");
     if (!fz && visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
-    if (fz && (fz->k == 0 || fz->k > visited_cap || fz->k > (size_t)TOPK_KMAX - 64 || !fz->ids || !fz->scores)) return fail("disk_query_topk: bad k / outputs");
-    if (fz && fz->entries && (!fz->entry_s || fz->entries->n_entries == 0 || fz->entries->entry_base->d != b->d))
-        return fail("disk_query_topk: the graph has no entry table for these vectors (mse_graph_set_entries)");
+    if (fz && (fz->k == 0 || fz->k > visited_cap || fz->k > (size_t)TOPK_KMAX - 64 || (!fz->dst && (!fz->ids || !fz->scores))))
+        return fail("disk_query_topk: bad k / outputs");
+    if (fz && fz->entries) {
+        const mse_graph* eg = fz->entries;
+        const bool by_rows = eg->entry_base && fz->entry_s && eg->entry_base->d == b->d, by_keys = eg->entry_keys_t && eg->entry_keys_d == b->d;
+        if (eg->n_entries == 0 || (!by_rows && !by_keys))
+            return fail("disk_query_topk: the graph has no entry table for these vectors (mse_graph_set_entries / mse_graph_set_entry_centroids)");
+    }
     for (size_t q = 0; starts && q < nq; q++)
         if (starts[q] >= b->n) return fail("disk_search_batch: start node out of range");
     hipStream_t st = s->stream;
@@ -539,7 +618,11 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     const bool bias = scales && c->n_desc && c->desc;
     DevBuf &dq = s->pool[0], &dl = s->pool[1], &dsc = s->pool[2], &dst = s->pool[3], &bm = s->pool[4], &oi = s->pool[5], &os = s->pool[6],
            &ol = s->pool[7], &vi = s->pool[8], &vs = s->pool[9], &cnt = s->pool[10], &qf = s->pool[11], &qt = s->pool[12], &fzb = s->pool[13];
-    if (fz && fzb.ensure(nq * 12 + nq * fz->k * 12 + 64)) return -1;   // entry top-1 [nq] (i64, u32) | k best visited [nq][k] (i64, u32)
+    // fused path: entry top-1 [nq] (i64, u32) | the block that travels back in ONE copy: k best visited [nq][k] i64 scores, [nq][k] u32
+    // ids, counters [3 nq + 1] (n_visited, cmps, pq_cmps, err)
+    const size_t fz_block_off = (nq * 12 + 15) & ~(size_t)15;
+    const size_t fz_block_bytes = fz ? nq * fz->k * 12 + (3 * nq + 1) * 4 : 0;
+    if (fz && (fzb.ensure(fz_block_off + fz_block_bytes + 64) || ensure_pin(&s->pin, &s->pin_cap, fz_block_bytes))) return -1;
     if ((queries_f32 && (qf.ensure(nq * d * 4) || qt.ensure(nq * d * 4))) || dq.ensure(nq * d * 2) || dl.ensure(disable_pq ? 16 : nq * 65536) || dsc.ensure(nq * BS_DESC_MAX * 4 + 16) || dst.ensure(nq * 4) ||
         bm.ensure(nq * set_words * 8) || oi.ensure(nq * search_list * 4) || os.ensure(nq * search_list * 8) || ol.ensure(nq * 4) ||
         vi.ensure(nq * visited_cap * 4 + 16) || vs.ensure(nq * visited_cap * 8 + 16) || cnt.ensure(nq * 12 + 16))
@@ -564,17 +647,26 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         // the entry step of the request path (src/query_disk_index.rs:254-256,447-450: the medioid of the shard whose centroid is
         // closest to the query) on the device: exact top-1 of the f16 queries over the entry rows, on this search's stream
         const mse_graph* eg = fz->entries;
-        int64_t* e_sc = fzb.as<int64_t>();
-        uint32_t* e_row = reinterpret_cast<uint32_t*>(fzb.as<char>() + nq * 8);
-        if (mse_searcher_set_stream(fz->entry_s, st)) return -1;
-        if (mse_bruteforce_topk_f16_dev(fz->entry_s, dq.p, nq, 1, MSE_MODE_AUTO, 0, e_sc, e_row)) return -1;
-        hipLaunchKernelGGL(entry_starts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, e_row, eg->entry_ids, eg->n_entries, nq, dst.as<uint32_t>());
-        MSE_HIP_TRY(hipGetLastError());
+        if (eg->entry_keys_t) {
+            // the reference's rule itself: centroids as keys, f32 query (an f16 query widened exactly), f64 sums, last maximum
+            hipLaunchKernelGGL(entry_by_centroid_kernel, dim3((unsigned)nq), dim3(256), d * 4, st, eg->entry_keys_t, (int)eg->n_entries, (int)d,
+                               queries_f32 ? qf.as<float>() : nullptr, dq.as<uint16_t>(), eg->entry_ids, dst.as<uint32_t>());
+            MSE_HIP_TRY(hipGetLastError());
+        } else {
+            int64_t* e_sc = fzb.as<int64_t>();
+            uint32_t* e_row = reinterpret_cast<uint32_t*>(fzb.as<char>() + nq * 8);
+            if (mse_searcher_set_stream(fz->entry_s, st)) return -1;
+            if (mse_bruteforce_topk_f16_dev(fz->entry_s, dq.p, nq, 1, MSE_MODE_AUTO, 0, e_sc, e_row)) return -1;
+            hipLaunchKernelGGL(entry_starts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, e_row, eg->entry_ids, eg->n_entries, nq, dst.as<uint32_t>());
+            MSE_HIP_TRY(hipGetLastError());
+        }
     } else {
         MSE_HIP_TRY(hipMemcpyAsync(dst.p, starts, nq * 4, hipMemcpyHostToDevice, st));
     }
     MSE_HIP_TRY(hipMemsetAsync(bm.p, use_hash ? 0xff : 0, nq * set_words * 8, st));
-    MSE_HIP_TRY(hipMemsetAsync(cnt.p, 0, nq * 12 + 16, st));
+    // counters: their own buffer, or (fused path) the tail of the block that travels back
+    uint32_t* cnt_dev = fz ? reinterpret_cast<uint32_t*>(fzb.as<char>() + fz_block_off + nq * fz->k * 12) : cnt.as<uint32_t>();
+    MSE_HIP_TRY(hipMemsetAsync(cnt_dev, 0, (3 * nq + 1) * 4, st));
     const size_t p_cap = beamwidth * ((g->max_deg + 63) / 64 * 64);
     BeamArgs a{};
     a.base = b->dev; a.n = b->n; a.d = (int)d;
@@ -585,8 +677,8 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     a.bm_adj = bm.as<uint32_t>(); a.bm_vis = bm.as<uint32_t>() + nq * set_words; a.bm_words = set_words; a.hash_bits = use_hash ? table_bits : 0;
     a.out_ids = oi.as<uint32_t>(); a.out_scores = os.as<long long>(); a.out_len = ol.as<uint32_t>();
     a.vis_ids = vi.as<uint32_t>(); a.vis_scores = vs.as<long long>(); a.vis_cap = visited_cap;
-    a.n_visited = cnt.as<uint32_t>(); a.cmps = cnt.as<uint32_t>() + nq; a.pq_cmps = cnt.as<uint32_t>() + 2 * nq;
-    a.err = cnt.as<uint32_t>() + 3 * nq;
+    a.n_visited = cnt_dev; a.cmps = cnt_dev + nq; a.pq_cmps = cnt_dev + 2 * nq;
+    a.err = cnt_dev + 3 * nq;
     a.fill_vis = fz ? 1 : 0;
     size_t hash_slots = 64;
     while (hash_slots < 2 * p_cap) hash_slots *= 2;
@@ -603,20 +695,44 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     uint32_t err = 0;
     if (fz) {
         // the server's last step (src/query_disk_index.rs:529-540: the visited records ordered by exact score) cut to its first k, on
-        // the device: the kernel has padded every visited list to visited_cap with (ID_NONE, INT64_MIN)
-        int64_t* top_sc = reinterpret_cast<int64_t*>(fzb.as<char>() + ((nq * 12 + 15) & ~(size_t)15));
+        // the device: the kernel has padded every visited list to visited_cap with (ID_NONE, INT64_MIN).  Scores, ids and the counters
+        // come back in ONE copy into the searcher's pinned staging (round 5: five pageable copies before).
+        int64_t* top_sc = reinterpret_cast<int64_t*>(fzb.as<char>() + fz_block_off);
         uint32_t* top_id = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(top_sc) + nq * fz->k * 8);
         SelectArgs sa{};
         sa.kind = KEY_I64; sa.list_ids = vi.as<uint32_t>(); sa.list_keys = vs.p; sa.list_stride = visited_cap; sa.n_list = visited_cap;
         sa.k = (int)fz->k; sa.out_ids = top_id; sa.out_keys = top_sc; sa.out_stride = fz->k; sa.nq = (int)nq;
         if (launch_select(sa, st)) return -1;
-        MSE_HIP_TRY(hipMemcpyAsync(fz->ids, top_id, nq * fz->k * 4, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipMemcpyAsync(fz->scores, top_sc, nq * fz->k * 8, hipMemcpyDeviceToHost, st));
-    } else {
-        MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipMemcpyAsync(buf_len, ol.p, nq * 4, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipMemcpyAsync(s->pin, top_sc, fz_block_bytes, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        const char* blk = static_cast<const char*>(s->pin);
+        const int64_t* h_sc = reinterpret_cast<const int64_t*>(blk);
+        const uint32_t* h_id = reinterpret_cast<const uint32_t*>(blk + nq * fz->k * 8);
+        const uint32_t* h_cnt = reinterpret_cast<const uint32_t*>(blk + nq * fz->k * 12);
+        err = h_cnt[3 * nq];
+        if (err & 1u) return fail("disk_search_batch: a graph edge points outside the index");
+        if (err & 4u)   // a search outgrew its table: the bit maps have room for everything
+            return disk_search_batch_impl(0, s, pq, c, g, starts, queries, queries_f32, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
+                                          buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps, fz);
+        // the reference keeps every visited record: a list that outgrew the device arrays means the caller repeats with larger ones
+        for (size_t q = 0; q < nq; q++)
+            if (h_cnt[q] > visited_cap) return -2;
+        for (size_t q = 0; q < nq; q++) {
+            QueryDst o = fz->dst ? fz->dst[q]
+                                 : QueryDst{fz->ids + q * fz->k, fz->scores + q * fz->k, fz->n_visited ? fz->n_visited + q : nullptr,
+                                            fz->cmps ? fz->cmps + q : nullptr, fz->pq_cmps ? fz->pq_cmps + q : nullptr, fz->k};
+            // a caller's k records are the first k of the largest k's: the order (score descending, id ascending) is total
+            memcpy(o.ids, h_id + q * fz->k, o.k * 4);
+            memcpy(o.scores, h_sc + q * fz->k, o.k * 8);
+            if (o.n_visited) *o.n_visited = h_cnt[q];
+            if (o.cmps) *o.cmps = h_cnt[nq + q];
+            if (o.pq_cmps) *o.pq_cmps = h_cnt[2 * nq + q];
+        }
+        return 0;
     }
+    MSE_HIP_TRY(hipMemcpyAsync(buf_ids, oi.p, nq * search_list * 4, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(buf_scores, os.p, nq * search_list * 8, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipMemcpyAsync(buf_len, ol.p, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(n_visited, a.n_visited, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(cmps, a.cmps, nq * 4, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipMemcpyAsync(pq_cmps, a.pq_cmps, nq * 4, hipMemcpyDeviceToHost, st));
@@ -626,11 +742,6 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     if (err & 4u)   // a search outgrew its table: the bit maps have room for everything
         return disk_search_batch_impl(0, s, pq, c, g, starts, queries, queries_f32, luts, scales, nq, disable_pq, beamwidth, search_list, buf_ids,
                                       buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps, fz);
-    if (fz) {   // the reference keeps every visited record: a list that outgrew the device arrays means the caller repeats with larger ones
-        for (size_t q = 0; q < nq; q++)
-            if (n_visited[q] > visited_cap) return -2;
-        return 0;
-    }
     if (visited_cap) {   // only the columns any query filled travel back (entries past n_visited[q] are unspecified)
         size_t widest = 0;
         for (size_t q = 0; q < nq; q++) widest = n_visited[q] > widest ? n_visited[q] : widest;
@@ -648,12 +759,21 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
 
 // ---- one query per call from many threads: the reference's request path --------------------------------------------------------
 // query_disk_index serves every HTTP request with ONE greedy_search on its own task / thread (src/query_disk_index.rs:436-540,
-// 711-736).  A one-query launch is one workgroup on a 256-CU part; T of them from T threads are T launches.  So calls of
-// mse_disk_search_batch(_f32) with nq = 1 meet in the graph's coalescer (dispatch.h): the worker sorts what it gathered into groups
-// that can share a launch -- same vectors, codec, codes, graph, search parameters and kind of inputs -- and runs each group as ONE
-// batched search (a workgroup per query) on the searcher of the group's first caller, whose owner is blocked in its call.  Every
-// caller gets exactly what its call returns when made alone (the batched kernel treats queries independently).
+// 711-736; the repo's only load test is 1000 one-query requests at concurrency 100, perf_test.py:6-29).  A one-query launch is one
+// workgroup on a 256-CU part; T of them from T threads are T launches.  So small calls meet in the graph's coalescer (dispatch.h):
+//   * mse_disk_search_batch(_f32) with nq = 1 (round 4): groups that can share a launch -- same vectors, codec, codes, graph, search
+//     parameters and kind of inputs -- run as ONE batched search on the searcher of the group's first caller (blocked in its call);
+//   * mse_disk_query_topk(_f32) with nq <= 16 from host memory (round 5): the WHOLE request -- entry node, search, top-k of the
+//     visited records -- of every waiting caller in one entry step + one launch + one select on a searcher the WORKER owns (so
+//     4096 request threads do not need 4096 streams and sets of scratch: a coalesced call only reads its searcher's `base`).
+//     Queries are gathered straight into pinned memory, results come back in one copy and are scattered to the callers.
+// Every caller gets exactly what its call returns when made alone (the batched kernels treat queries independently; a caller's k
+// records are the first k of the largest k's, the order (score descending, id ascending) being total).  Two workers per graph: one
+// pass's copies and host side overlap the other's kernels.
 namespace {
+enum : size_t { REQ_BEAM = 0, REQ_QUERY = 1 };
+constexpr size_t FUSED_COALESCE_MAX = 16;   // calls with more queries go straight to the device on the caller's searcher
+
 struct BeamCall {
     mse_searcher* s; mse_pq* pq; const mse_codes* c; const mse_graph* g; const uint32_t* starts;
     const uint16_t* queries; const float* queries_f32; const float* luts; const float* scales;
@@ -672,56 +792,202 @@ int beam_call_alone(const BeamCall& k) {
                                   k.search_list, k.buf_ids, k.buf_scores, k.buf_len, k.visited_ids, k.visited_scores, k.visited_cap, k.n_visited,
                                   k.cmps, k.pq_cmps);
 }
-void beam_run_batch(std::vector<DispatchReq*>& batch) {
-    std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); i++) {
-        if (taken[i]) continue;
-        const BeamCall& lead = *static_cast<const BeamCall*>(batch[i]->aux0);
-        std::vector<DispatchReq*> grp;
-        for (size_t j = i; j < batch.size(); j++)
-            if (!taken[j] && lead.shares_with(*static_cast<const BeamCall*>(batch[j]->aux0))) { taken[j] = 1; grp.push_back(batch[j]); }
-        (void)hipSetDevice(lead.s->base->device);
-        const size_t n = grp.size(), d = lead.s->base->d, L = lead.search_list, vc = lead.visited_cap;
-        const size_t n_desc = (lead.scales && lead.c) ? lead.c->n_desc : 0;
-        int rc = 0;
-        if (n == 1) {
-            rc = beam_call_alone(lead);
-            grp[0]->rc = rc;
-            if (rc) grp[0]->err = mse_last_error();
+void beam_run_group(std::vector<DispatchReq*>& grp) {
+    const BeamCall& lead = *static_cast<const BeamCall*>(grp[0]->aux0);
+    (void)hipSetDevice(lead.s->base->device);
+    const size_t n = grp.size(), d = lead.s->base->d, L = lead.search_list, vc = lead.visited_cap;
+    const size_t n_desc = (lead.scales && lead.c) ? lead.c->n_desc : 0;
+    int rc = 0;
+    if (n == 1) {
+        rc = beam_call_alone(lead);
+        grp[0]->rc = rc;
+        if (rc) grp[0]->err = mse_last_error();
+        return;
+    }
+    std::vector<uint32_t> starts(n), ids(n * L), len(n), nv(n), cm(n), pc(n), vids(lead.visited_ids ? n * vc : 0);
+    std::vector<int64_t> sc(n * L), vsc(lead.visited_scores ? n * vc : 0);
+    std::vector<uint16_t> q16(lead.queries ? n * d : 0);
+    std::vector<float> q32(lead.queries_f32 ? n * d : 0), luts(lead.luts ? n * 16384 : 0), scl(n_desc ? n * n_desc : 0);
+    for (size_t j = 0; j < n; j++) {
+        const BeamCall& k = *static_cast<const BeamCall*>(grp[j]->aux0);
+        starts[j] = k.starts[0];
+        if (k.queries) memcpy(q16.data() + j * d, k.queries, d * 2);
+        if (k.queries_f32) memcpy(q32.data() + j * d, k.queries_f32, d * 4);
+        if (k.luts) memcpy(luts.data() + j * 16384, k.luts, 16384 * 4);
+        if (n_desc) memcpy(scl.data() + j * n_desc, k.scales, n_desc * 4);
+    }
+    rc = disk_search_batch_impl(-1, lead.s, lead.pq, lead.c, lead.g, starts.data(), lead.queries ? q16.data() : nullptr,
+                                lead.queries_f32 ? q32.data() : nullptr, lead.luts ? luts.data() : nullptr, n_desc ? scl.data() : lead.scales, n,
+                                lead.disable_pq, lead.beamwidth, L, ids.data(), sc.data(), len.data(), lead.visited_ids ? vids.data() : nullptr,
+                                lead.visited_scores ? vsc.data() : nullptr, vc, nv.data(), cm.data(), pc.data());
+    for (size_t j = 0; j < n; j++) {
+        const BeamCall& k = *static_cast<const BeamCall*>(grp[j]->aux0);
+        if (rc) {     // the shared launch failed: each caller is repeated alone and sees only its own outcome
+            grp[j]->rc = beam_call_alone(k);
+            if (grp[j]->rc) grp[j]->err = mse_last_error();
             continue;
         }
-        std::vector<uint32_t> starts(n), ids(n * L), len(n), nv(n), cm(n), pc(n), vids(lead.visited_ids ? n * vc : 0);
-        std::vector<int64_t> sc(n * L), vsc(lead.visited_scores ? n * vc : 0);
-        std::vector<uint16_t> q16(lead.queries ? n * d : 0);
-        std::vector<float> q32(lead.queries_f32 ? n * d : 0), luts(lead.luts ? n * 16384 : 0), scl(n_desc ? n * n_desc : 0);
-        for (size_t j = 0; j < n; j++) {
-            const BeamCall& k = *static_cast<const BeamCall*>(grp[j]->aux0);
-            starts[j] = k.starts[0];
-            if (k.queries) memcpy(q16.data() + j * d, k.queries, d * 2);
-            if (k.queries_f32) memcpy(q32.data() + j * d, k.queries_f32, d * 4);
-            if (k.luts) memcpy(luts.data() + j * 16384, k.luts, 16384 * 4);
-            if (n_desc) memcpy(scl.data() + j * n_desc, k.scales, n_desc * 4);
-        }
-        rc = disk_search_batch_impl(-1, lead.s, lead.pq, lead.c, lead.g, starts.data(), lead.queries ? q16.data() : nullptr,
-                                    lead.queries_f32 ? q32.data() : nullptr, lead.luts ? luts.data() : nullptr, n_desc ? scl.data() : lead.scales, n,
-                                    lead.disable_pq, lead.beamwidth, L, ids.data(), sc.data(), len.data(), lead.visited_ids ? vids.data() : nullptr,
-                                    lead.visited_scores ? vsc.data() : nullptr, vc, nv.data(), cm.data(), pc.data());
-        for (size_t j = 0; j < n; j++) {
-            const BeamCall& k = *static_cast<const BeamCall*>(grp[j]->aux0);
-            if (rc) {     // the shared launch failed: each caller is repeated alone and sees only its own outcome
-                grp[j]->rc = beam_call_alone(k);
-                if (grp[j]->rc) grp[j]->err = mse_last_error();
-                continue;
-            }
-            memcpy(k.buf_ids, ids.data() + j * L, L * 4);
-            memcpy(k.buf_scores, sc.data() + j * L, L * 8);
-            k.buf_len[0] = len[j]; k.n_visited[0] = nv[j]; k.cmps[0] = cm[j]; k.pq_cmps[0] = pc[j];
-            if (k.visited_ids) memcpy(k.visited_ids, vids.data() + j * vc, vc * 4);
-            if (k.visited_scores) memcpy(k.visited_scores, vsc.data() + j * vc, vc * 8);
-            grp[j]->rc = 0;
-        }
+        memcpy(k.buf_ids, ids.data() + j * L, L * 4);
+        memcpy(k.buf_scores, sc.data() + j * L, L * 8);
+        k.buf_len[0] = len[j]; k.n_visited[0] = nv[j]; k.cmps[0] = cm[j]; k.pq_cmps[0] = pc[j];
+        if (k.visited_ids) memcpy(k.visited_ids, vids.data() + j * vc, vc * 4);
+        if (k.visited_scores) memcpy(k.visited_scores, vsc.data() + j * vc, vc * 8);
+        grp[j]->rc = 0;
     }
 }
+
+// the request path in one call: src/query_disk_index.rs:436-540
+struct QueryCall {
+    mse_searcher* s; mse_pq* pq; const mse_codes* c; const mse_graph* g; const uint32_t* starts;
+    const uint16_t* queries; const float* queries_f32; const float* luts; const float* scales; size_t nq;
+    int disable_pq; size_t beamwidth, search_list, k;
+    uint32_t* ids; int64_t* scores; uint32_t *n_visited, *cmps, *pq_cmps;
+    bool shares_with(const QueryCall& o) const {
+        return s->base == o.s->base && pq == o.pq && c == o.c && g == o.g && disable_pq == o.disable_pq && beamwidth == o.beamwidth &&
+               search_list == o.search_list && (starts != nullptr) == (o.starts != nullptr) && (queries != nullptr) == (o.queries != nullptr) &&
+               (luts != nullptr) == (o.luts != nullptr) && (scales != nullptr) == (o.scales != nullptr);
+    }
+};
+
+// Entry searcher (row tables), the shared hold on the entry table, and the grow-and-repeat loop around the batched search.  `fz`
+// arrives with k and its destinations set.
+int fused_run(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* q16, const float* q32,
+              const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, FusedQuery fz) {
+    // the table cannot be replaced under a call in flight (mse_graph_set_entries takes the lock exclusively)
+    struct Shared {
+        SharedExclusive* l = nullptr;
+        ~Shared() { if (l) l->unlock_shared(); }
+    } hold;
+    // a searcher over the entry rows for the duration of this call (made on first use, returned to the graph's pool afterwards)
+    struct Borrow {
+        const mse_graph* g; mse_searcher* es = nullptr;
+        ~Borrow() { if (es) { std::lock_guard<std::mutex> lk(g->entry_mu); g->entry_pool.push_back(es); } }
+    } borrow{g};
+    fz.entries = nullptr;
+    if (!starts) {
+        g->entry_lock.lock_shared();
+        hold.l = &g->entry_lock;
+        if (g->n_entries == 0 || (!g->entry_base && !g->entry_keys_t))
+            return fail("disk_query_topk: the graph has no entry table (mse_graph_set_entries / mse_graph_set_entry_centroids)");
+        fz.entries = g;
+        if (!g->entry_keys_t) {
+            {
+                std::lock_guard<std::mutex> lk(g->entry_mu);
+                if (!g->entry_pool.empty()) { borrow.es = g->entry_pool.back(); g->entry_pool.pop_back(); }
+            }
+            if (!borrow.es && !(borrow.es = mse_searcher_new(g->entry_base))) return -1;
+            fz.entry_s = borrow.es;
+        }
+    }
+    // visited records per query kept on the device: a search fetches about search_list + a few nodes; a list that outgrows the arrays
+    // is never cut (the reference keeps every record) -- the call is repeated with four times the room
+    size_t cap = (std::max(2 * search_list + 64, fz.k) + 63) / 64 * 64;
+    for (;;) {
+        const int rc = disk_search_batch_impl(-1, s, pq, c, g, starts, q16, q32, luts, scales, nq, disable_pq, beamwidth, search_list, nullptr,
+                                              nullptr, nullptr, nullptr, nullptr, cap, nullptr, nullptr, nullptr, &fz);
+        if (rc != -2) return rc;
+        if (cap >= ((size_t)1 << 16)) return fail("disk_query_topk: a search visited more than 65536 records");
+        cap *= 4;
+    }
+}
+
+int query_call_on(mse_searcher* s, const QueryCall& k) {
+    FusedQuery fz;
+    fz.k = k.k; fz.ids = k.ids; fz.scores = k.scores; fz.n_visited = k.n_visited; fz.cmps = k.cmps; fz.pq_cmps = k.pq_cmps;
+    return fused_run(s, k.pq, k.c, k.g, k.starts, k.queries, k.queries_f32, k.luts, k.scales, k.nq, k.disable_pq, k.beamwidth, k.search_list, fz);
+}
+
+// one group of waiting request-path calls = ONE entry step + ONE search launch + ONE select, on the worker's own searcher
+void query_run_group(std::vector<DispatchReq*>& grp) {
+    const QueryCall& lead = *static_cast<const QueryCall*>(grp[0]->aux0);
+    const mse_graph* g = lead.g;
+    const mse_base* b = lead.s->base;
+    (void)hipSetDevice(b->device);
+    const int w = Coalescer::worker_index();
+    mse_graph::WorkerCtx& ctx = g->co_ctx[(size_t)w < g->co_ctx.size() ? (size_t)w : 0];
+    auto fail_all = [&](const std::string& why) {
+        for (DispatchReq* r : grp) { r->rc = -1; r->err = why; }
+    };
+    if (!ctx.s || ctx.s->base != b) {
+        if (ctx.s) mse_searcher_free(ctx.s);
+        ctx.s = mse_searcher_new(b);
+        if (!ctx.s) { fail_all(mse_last_error()); return; }
+    }
+    const size_t d = b->d, n_desc = (lead.scales && lead.c) ? lead.c->n_desc : 0;
+    size_t total = 0, kmax = 0;
+    for (DispatchReq* r : grp) {
+        const QueryCall& k = *static_cast<const QueryCall*>(r->aux0);
+        total += k.nq;
+        kmax = std::max(kmax, k.k);
+    }
+    int rc = 0;
+    if (grp.size() > 1) {
+        // inputs gathered straight into pinned memory (the copies up are then true DMA, not staged by the runtime)
+        const size_t q_bytes = total * d * (lead.queries ? 2 : 4), sc_bytes = total * n_desc * 4, st_bytes = lead.starts ? total * 4 : 0;
+        const size_t lut_bytes = lead.luts ? total * 65536 : 0;
+        const size_t off_sc = (q_bytes + 63) & ~(size_t)63, off_st = (off_sc + sc_bytes + 63) & ~(size_t)63, off_lut = (off_st + st_bytes + 63) & ~(size_t)63;
+        if (ensure_pin(&ctx.pin, &ctx.pin_cap, off_lut + lut_bytes + 64)) { fail_all(mse_last_error()); return; }
+        char* p = static_cast<char*>(ctx.pin);
+        std::vector<QueryDst> dsts(total);
+        size_t row = 0;
+        for (DispatchReq* r : grp) {
+            const QueryCall& k = *static_cast<const QueryCall*>(r->aux0);
+            if (k.queries) memcpy(p + row * d * 2, k.queries, k.nq * d * 2);
+            else memcpy(p + row * d * 4, k.queries_f32, k.nq * d * 4);
+            if (n_desc) memcpy(p + off_sc + row * n_desc * 4, k.scales, k.nq * n_desc * 4);
+            if (k.starts) memcpy(p + off_st + row * 4, k.starts, k.nq * 4);
+            if (k.luts) memcpy(p + off_lut + row * 65536, k.luts, k.nq * 65536);
+            for (size_t q = 0; q < k.nq; q++, row++)
+                dsts[row] = QueryDst{k.ids + q * k.k, k.scores + q * k.k, k.n_visited ? k.n_visited + q : nullptr, k.cmps ? k.cmps + q : nullptr,
+                                     k.pq_cmps ? k.pq_cmps + q : nullptr, k.k};
+        }
+        FusedQuery fz;
+        fz.k = kmax; fz.dst = dsts.data();
+        rc = fused_run(ctx.s, lead.pq, lead.c, g, lead.starts ? reinterpret_cast<const uint32_t*>(p + off_st) : nullptr,
+                       lead.queries ? reinterpret_cast<const uint16_t*>(p) : nullptr, lead.queries ? nullptr : reinterpret_cast<const float*>(p),
+                       lead.luts ? reinterpret_cast<const float*>(p + off_lut) : nullptr, n_desc ? reinterpret_cast<const float*>(p + off_sc) : lead.scales,
+                       total, lead.disable_pq, lead.beamwidth, lead.search_list, fz);
+        if (rc == 0) {
+            for (DispatchReq* r : grp) r->rc = 0;
+            return;
+        }
+    }
+    // alone, or the shared pass failed: each request on its own, so that a caller only ever sees its own outcome
+    for (DispatchReq* r : grp) {
+        r->rc = query_call_on(ctx.s, *static_cast<const QueryCall*>(r->aux0));
+        if (r->rc) r->err = mse_last_error();
+    }
+}
+
+void graph_run_batch(std::vector<DispatchReq*>& batch) {
+    std::vector<char> taken(batch.size(), 0);
+    std::vector<DispatchReq*> grp;
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        grp.clear();
+        const size_t kind = batch[i]->aux_n;
+        for (size_t j = i; j < batch.size(); j++) {
+            if (taken[j] || batch[j]->aux_n != kind) continue;
+            const bool same = kind == REQ_BEAM ? static_cast<const BeamCall*>(batch[i]->aux0)->shares_with(*static_cast<const BeamCall*>(batch[j]->aux0))
+                                               : static_cast<const QueryCall*>(batch[i]->aux0)->shares_with(*static_cast<const QueryCall*>(batch[j]->aux0));
+            if (same) { taken[j] = 1; grp.push_back(batch[j]); }
+        }
+        if (kind == REQ_BEAM) beam_run_group(grp); else query_run_group(grp);
+    }
+}
+
+Coalescer* graph_coalescer(const mse_graph* g) {
+    std::lock_guard<std::mutex> lk(g->co_mu);
+    if (!g->co) {
+        const int workers = g->co_workers > 0 ? g->co_workers : 2;
+        g->co_ctx.resize((size_t)workers);
+        g->co = new (std::nothrow) Coalescer(g->co_max_queries ? g->co_max_queries : 1024, g->co_max_wait_us ? g->co_max_wait_us : 200,
+                                             [](std::vector<DispatchReq*>& b) { graph_run_batch(b); }, nullptr, workers);
+        if (!g->co) fail("out of host memory");
+    }
+    return g->co;
+}
+
 // nq == 1: through the graph's coalescer.  Argument errors that belong to one caller are found before it queues.
 int beam_one_query(BeamCall& k) {
     if (!k.s || !k.s->base || !k.g || !k.starts || (!k.queries && !k.queries_f32) || !k.buf_ids || !k.buf_scores || !k.buf_len || !k.n_visited ||
@@ -730,17 +996,42 @@ int beam_one_query(BeamCall& k) {
     if (k.beamwidth == 0 || k.beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
     if (k.search_list == 0 || k.search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
     if (k.starts[0] >= k.g->n) return beam_call_alone(k);   // let the search report it in its own words
-    {
-        std::lock_guard<std::mutex> lk(k.g->co_mu);
-        if (!k.g->co) {
-            k.g->co = new (std::nothrow) Coalescer(1024, 200, [](std::vector<DispatchReq*>& b) { beam_run_batch(b); }, nullptr);
-            if (!k.g->co) return fail("out of host memory");
-        }
-    }
+    Coalescer* co = graph_coalescer(k.g);
+    if (!co) return -1;
     DispatchReq r;
     r.nq = 1;
     r.aux0 = &k;
-    return k.g->co->submit(r);
+    r.aux_n = REQ_BEAM;
+    return co->submit(r);
+}
+
+// true when p points into device (or managed) memory; plain host memory is unknown to the runtime and reported as an error
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+int query_front(QueryCall& k) {
+    if (!k.g || !k.ids || !k.scores || (!k.queries && !k.queries_f32)) return fail("disk_query_topk: null argument");
+    if (k.nq == 0) return 0;
+    if (!k.s || !k.s->base) return fail("disk_query_topk: null searcher");
+    if (k.k == 0 || k.k > (size_t)TOPK_KMAX - 64) return fail("disk_query_topk: bad k / outputs");
+    if (k.nq > FUSED_COALESCE_MAX || is_device_pointer(k.queries ? static_cast<const void*>(k.queries) : static_cast<const void*>(k.queries_f32)))
+        return query_call_on(k.s, k);
+    // what belongs to this caller alone is found before it queues
+    if (k.beamwidth == 0 || k.beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
+    if (k.search_list == 0 || k.search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
+    if ((!k.disable_pq && (!k.pq || !k.c || (!k.luts && !k.queries_f32))) || (k.scales && !k.c)) return fail("disk_search_batch: null argument");
+    for (size_t q = 0; k.starts && q < k.nq; q++)
+        if (k.starts[q] >= k.g->n) return fail("disk_search_batch: start node out of range");
+    Coalescer* co = graph_coalescer(k.g);
+    if (!co) return -1;
+    DispatchReq r;
+    r.nq = k.nq;
+    r.aux0 = &k;
+    r.aux_n = REQ_QUERY;
+    return co->submit(r);
 }
 }  // namespace
 
@@ -762,20 +1053,21 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
 }
 
 // ---- the request path in one call (src/query_disk_index.rs:436-540 for a batch) ---------------------------------------------
-int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries) {
-    if (!g || !b || !b->dev || (!node_ids && n_entries)) return fail("graph_set_entries: null argument");
-    if (b->n != g->n) return fail("graph_set_entries: vectors and graph differ in length");
-    if (b->d % 64 || b->d == 0) return fail("graph_set_entries: vector width must be a multiple of 64");
-    for (size_t i = 0; i < n_entries; i++)
-        if (node_ids[i] >= g->n) return fail("graph_set_entries: entry id out of range");
-    std::lock_guard<std::mutex> lk(g->entry_mu);
-    for (mse_searcher* es : g->entry_pool) mse_searcher_free(es);   // (no query may be in flight while the table is replaced)
-    g->entry_pool.clear();
+static void clear_entries_locked(mse_graph* g) {   // entry_lock held exclusively
+    {
+        std::lock_guard<std::mutex> lk(g->entry_mu);
+        for (mse_searcher* es : g->entry_pool) mse_searcher_free(es);
+        g->entry_pool.clear();
+    }
     if (g->entry_base) { mse_base_free(g->entry_base); g->entry_base = nullptr; }
     if (g->entry_rows) { (void)hipFree(g->entry_rows); g->entry_rows = nullptr; }
     if (g->entry_ids) { (void)hipFree(g->entry_ids); g->entry_ids = nullptr; }
+    if (g->entry_keys_t) { (void)hipFree(g->entry_keys_t); g->entry_keys_t = nullptr; }
+    g->entry_keys_d = 0;
     g->n_entries = 0;
-    if (n_entries == 0) return 0;
+}
+
+static int set_entries_locked(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries) {
     MSE_HIP_TRY(hipMalloc((void**)&g->entry_ids, n_entries * 4));
     MSE_HIP_TRY(hipMalloc((void**)&g->entry_rows, n_entries * b->d * 2));
     MSE_HIP_TRY(hipMemcpy(g->entry_ids, node_ids, n_entries * 4, hipMemcpyHostToDevice));
@@ -784,64 +1076,105 @@ int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_
     MSE_HIP_TRY(hipDeviceSynchronize());
     g->entry_base = mse_base_wrap_device(g->entry_rows, n_entries, b->d);
     if (!g->entry_base) return -1;
-    g->n_entries = n_entries;
     // one searcher now, used once: whatever the base prepares lazily for the matrix-core path (row norms) exists before callers on
     // several threads arrive
     mse_searcher* es = mse_searcher_new(g->entry_base);
     if (!es) return -1;
+    int rc = 0;
     {
         DevBuf tmp;
         const size_t nqw = 16;
-        if (tmp.ensure(nqw * b->d * 2 + nqw * 12)) { mse_searcher_free(es); return -1; }
-        MSE_HIP_TRY(hipMemset(tmp.p, 0, nqw * b->d * 2 + nqw * 12));
-        char* o = tmp.as<char>() + nqw * b->d * 2;
-        const int rc = mse_bruteforce_topk_f16_dev(es, tmp.p, nqw, 1, MSE_MODE_MFMA, 0, o, o + nqw * 8);
-        MSE_HIP_TRY(hipStreamSynchronize(es->stream));
-        if (rc) { mse_searcher_free(es); return -1; }
+        hipError_t he = hipSuccess;
+        if (tmp.ensure(nqw * b->d * 2 + nqw * 12)) rc = -1;
+        else if ((he = hipMemset(tmp.p, 0, nqw * b->d * 2 + nqw * 12)) != hipSuccess) rc = fail(std::string("hipMemset: ") + hipGetErrorString(he));
+        else {
+            char* o = tmp.as<char>() + nqw * b->d * 2;
+            rc = mse_bruteforce_topk_f16_dev(es, tmp.p, nqw, 1, MSE_MODE_MFMA, 0, o, o + nqw * 8);
+            if ((he = hipStreamSynchronize(es->stream)) != hipSuccess && !rc) rc = fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(he));
+        }
     }
+    if (rc) { mse_searcher_free(es); return -1; }
+    g->n_entries = n_entries;
+    std::lock_guard<std::mutex> lk(g->entry_mu);
     g->entry_pool.push_back(es);
+    return 0;
+}
+
+int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries) {
+    if (!g || !b || !b->dev || (!node_ids && n_entries)) return fail("graph_set_entries: null argument");
+    if (b->n != g->n) return fail("graph_set_entries: vectors and graph differ in length");
+    if (b->d % 64 || b->d == 0) return fail("graph_set_entries: vector width must be a multiple of 64");
+    for (size_t i = 0; i < n_entries; i++)
+        if (node_ids[i] >= g->n) return fail("graph_set_entries: entry id out of range");
+    // exclusive: waits for the request-path calls in flight (they hold the lock shared for their duration) and keeps new ones out
+    std::lock_guard<SharedExclusive> ex(g->entry_lock);
+    clear_entries_locked(g);
+    if (n_entries == 0) return 0;
+    const int rc = set_entries_locked(g, b, node_ids, n_entries);
+    if (rc) { const std::string why = mse_last_error(); clear_entries_locked(g); set_error(why); }   // nothing half-made stays behind
+    return rc;
+}
+
+int mse_graph_set_entry_centroids(mse_graph* g, const float* centroids, size_t d, const uint32_t* node_ids, size_t n_entries) {
+    if (!g || (n_entries && (!centroids || !node_ids))) return fail("graph_set_entry_centroids: null argument");
+    if (n_entries && (d == 0 || d % 32 || d > 4096)) return fail("graph_set_entry_centroids: vector width must be a multiple of 32, at most 4096");
+    for (size_t i = 0; i < n_entries; i++)
+        if (node_ids[i] >= g->n) return fail("graph_set_entry_centroids: entry id out of range");
+    std::lock_guard<SharedExclusive> ex(g->entry_lock);
+    clear_entries_locked(g);
+    if (n_entries == 0) return 0;
+    std::vector<float> t(n_entries * d);   // transposed [d][n_entries]: a lane per shard reads consecutive floats
+    for (size_t e = 0; e < n_entries; e++)
+        for (size_t k = 0; k < d; k++) t[k * n_entries + e] = centroids[e * d + k];
+    hipError_t he = hipMalloc((void**)&g->entry_ids, n_entries * 4);
+    if (he == hipSuccess) he = hipMalloc((void**)&g->entry_keys_t, n_entries * d * 4);
+    if (he == hipSuccess) he = hipMemcpy(g->entry_ids, node_ids, n_entries * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(g->entry_keys_t, t.data(), n_entries * d * 4, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { clear_entries_locked(g); return fail(std::string("graph_set_entry_centroids: ") + hipGetErrorString(he)); }
+    g->entry_keys_d = d;
+    g->n_entries = n_entries;
     return 0;
 }
 
 int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
                         const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
                         uint32_t* ids, int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
-    if (!g || !ids || !scores) return fail("disk_query_topk: null argument");
-    if (nq == 0) return 0;
-    std::vector<uint32_t> tmp;
-    if (!n_visited || !cmps || !pq_cmps) {
-        tmp.resize(3 * nq);
-        if (!n_visited) n_visited = tmp.data();
-        if (!cmps) cmps = tmp.data() + nq;
-        if (!pq_cmps) pq_cmps = tmp.data() + 2 * nq;
+    if (!queries) return fail("disk_query_topk: null argument");
+    QueryCall q{s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, k, ids, scores, n_visited, cmps, pq_cmps};
+    return query_front(q);
+}
+
+int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const float* queries_f32,
+                            const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids,
+                            int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!queries_f32) return fail("disk_query_topk_f32: null argument");
+    QueryCall q{s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, nq, disable_pq, beamwidth, search_list, k, ids, scores, n_visited, cmps, pq_cmps};
+    return query_front(q);
+}
+
+int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t max_wait_us, int workers) {
+    if (!g) return fail("null graph");
+    if (workers < 0 || workers > 8) return fail("graph_set_coalescer: 1..8 workers (0 = default)");
+    Coalescer* old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g->co_mu);
+        old = g->co;
+        g->co = nullptr;
+        g->co_max_queries = max_queries_per_pass; g->co_max_wait_us = max_wait_us; g->co_workers = workers;
     }
-    FusedQuery fz;
-    fz.entries = starts ? nullptr : g;
-    fz.k = k; fz.ids = ids; fz.scores = scores;
-    // a searcher over the entry rows for the duration of this call (made on first use, returned to the graph's pool afterwards)
-    struct Borrow {
-        const mse_graph* g; mse_searcher* es = nullptr;
-        ~Borrow() { if (es) { std::lock_guard<std::mutex> lk(g->entry_mu); g->entry_pool.push_back(es); } }
-    } borrow{g};
-    if (!starts) {
-        if (!g->entry_base || g->n_entries == 0) return fail("disk_query_topk: the graph has no entry table (mse_graph_set_entries)");
-        {
-            std::lock_guard<std::mutex> lk(g->entry_mu);
-            if (!g->entry_pool.empty()) { borrow.es = g->entry_pool.back(); g->entry_pool.pop_back(); }
-        }
-        if (!borrow.es && !(borrow.es = mse_searcher_new(g->entry_base))) return -1;
-        fz.entry_s = borrow.es;
+    delete old;   // joins its workers; no call may be in flight (as for mse_graph_free)
+    return 0;
+}
+
+int mse_graph_coalescer_stats(const mse_graph* g, uint64_t out[6]) {
+    if (!g || !out) return fail("null argument");
+    DispatchStats st;
+    {
+        std::lock_guard<std::mutex> lk(g->co_mu);
+        if (g->co) st = g->co->stats();
     }
-    // visited records per query kept on the device: a search fetches about search_list + a few nodes; a list that outgrows the arrays
-    // is never cut (the reference keeps every record) -- the call is repeated with four times the room
-    size_t cap = (std::max(2 * search_list + 64, k) + 63) / 64 * 64;
-    for (;;) {
-        const int rc = disk_search_batch_impl(-1, s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, nullptr,
-                                              nullptr, nullptr, nullptr, nullptr, cap, n_visited, cmps, pq_cmps, &fz);
-        if (rc != -2) return rc;
-        if (cap >= ((size_t)1 << 16)) return fail("disk_query_topk: a search visited more than 65536 records");
-        cap *= 4;
-    }
+    out[0] = st.queries; out[1] = st.requests; out[2] = st.passes; out[3] = st.max_pass_queries; out[4] = st.deadline_fires; out[5] = st.retried_alone;
+    return 0;
 }
 
 int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts,
@@ -856,6 +1189,16 @@ int mse_disk_search_batch_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
     }
     return disk_search_batch_impl(-1, s, pq, c, g, starts, nullptr, queries_f32, nullptr, scales, nq, disable_pq, beamwidth, search_list,
                                   buf_ids, buf_scores, buf_len, visited_ids, visited_scores, visited_cap, n_visited, cmps, pq_cmps);
+}
+
+// Orders this searcher's stream after everything `producer_stream` holds now: the way to hand device-resident inputs (queries that a
+// tower wrote on ITS stream) to a call that copies them on the searcher's stream.
+int mse_searcher_wait_stream(mse_searcher* s, void* producer_stream) {
+    if (!s) return fail("null searcher");
+    if (!s->ev_wait) MSE_HIP_TRY(hipEventCreateWithFlags(&s->ev_wait, hipEventDisableTiming));
+    MSE_HIP_TRY(hipEventRecord(s->ev_wait, reinterpret_cast<hipStream_t>(producer_stream)));
+    MSE_HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_wait, 0));
+    return 0;
 }
 
 }  // extern "C"

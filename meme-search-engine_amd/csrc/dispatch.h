@@ -13,6 +13,12 @@
 // (<= 1 ms) to return, whichever comes first.  A single caller therefore never waits (target 1), T closed-loop callers settle
 // at T queries per pass after two passes, and callers that do not come back cost a grace period on every other pass at most.
 // More expected callers than one pass holds are served in EQUAL passes (512 callers, 320 per pass: 256 + 256, not 320 + 192).
+//
+// Round 5: a handle may run SEVERAL workers (the graph's request path runs two: one pass's upload / download and host side
+// overlap the other's kernels).  One worker gathers at a time, by the same rule; the others run or sleep.  Completion is
+// signalled through a ring of (mutex, condition variable) slots that requests are assigned to in arrival order, 256 to a slot:
+// a pass wakes the callers of the slots it touched instead of everybody who is waiting (4096 callers, 1024 per pass: one
+// shared variable woke 3072 sleepers for nothing on every pass and sent all of them through one mutex).
 #pragma once
 #include "common.h"
 #include <atomic>
@@ -42,6 +48,7 @@ struct DispatchReq {
     uint32_t flags = 0;
     // queue plumbing
     bool done = false;
+    uint32_t slot = 0;                // completion slot (Coalescer::wake_), assigned on arrival
     std::chrono::steady_clock::time_point t_arrive;
 };
 
@@ -54,8 +61,12 @@ class Coalescer {
     // run(batch): executes the requests of one pass and sets rc / err of each.  Called on the worker thread only, after
     // `on_thread_start` ran there once (device selection).
     using RunFn = std::function<void(std::vector<DispatchReq*>&)>;
-    Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::function<void()> on_thread_start);
-    ~Coalescer();   // requests still queued are answered with an error; the worker is joined
+    Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::function<void()> on_thread_start, int n_workers = 1);
+    ~Coalescer();   // requests still queued are answered with an error; the workers are joined
+    // index of the calling worker thread within its Coalescer (0 .. n_workers-1; 0 on any other thread): run() uses it to pick
+    // its own scratch when a handle has several workers
+    static int worker_index();
+    int n_workers() const { return (int)workers_.size(); }
     // blocks until the request was executed; returns its rc and leaves its message in the thread's mse_last_error()
     int submit(DispatchReq& r);
     DispatchStats stats();
@@ -65,23 +76,29 @@ class Coalescer {
     void set_max_wait_us(uint32_t us) { max_wait_us_.store(us); }   // takes effect from the next gather
 
   private:
-    void loop();
+    void loop(int index);
+    static constexpr uint32_t WAKE_SLOTS = 64, WAKE_RUN = 256;   // 256 consecutive arrivals share a slot
+    struct WakeSlot { std::mutex mu; std::condition_variable cv; };
     const size_t max_queries_;
     std::atomic<uint32_t> max_wait_us_;
     RunFn run_;
     std::function<void()> on_start_;
     std::mutex mu_;
     std::condition_variable cv_worker_;
-    // ONE condition variable for all callers, signalled once per pass after the lock is dropped: a variable per request would be
-    // hundreds of futex wake-ups issued under the lock, every woken caller then queueing for that lock (a request record lives on its
-    // caller's stack, so its own variable could not be signalled after the unlock either)
-    std::condition_variable cv_done_;
+    // Completion: a variable per request would be hundreds of futex wake-ups per pass; ONE variable for all callers wakes every
+    // sleeper of every other pass too.  A ring of slots, 256 consecutive arrivals to a slot (the queue is first in, first out, so a
+    // pass touches few slots): `done` is set under the slot's mutex, the slot's variable is signalled after the unlock.
+    WakeSlot wake_[WAKE_SLOTS];
+    uint64_t arrivals_ = 0;
     std::deque<DispatchReq*> queue_;
     size_t queued_queries_ = 0;
     size_t expect_ = 1;
     bool stop_ = false;
+    bool gathering_ = false;          // one worker gathers at a time
+    bool expected_returners_ = false;
+    std::chrono::steady_clock::time_point grace_until_ = std::chrono::steady_clock::time_point::min();
     DispatchStats st_;
-    std::thread worker_;
+    std::vector<std::thread> workers_;
 };
 
 // Writer-preferring shared/exclusive lock: searches share, `add` excludes -- the RwLock of src/main.rs:1016 (write) and

@@ -19,10 +19,14 @@ uint32_t default_wait_us(size_t n_rows, size_t row_bytes) {
     return (uint32_t)w;
 }
 
-Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::function<void()> on_thread_start)
+static thread_local int tl_worker_index = 0;
+int Coalescer::worker_index() { return tl_worker_index; }
+
+Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::function<void()> on_thread_start, int n_workers)
     : max_queries_(max_queries ? max_queries : 1), max_wait_us_(max_wait_us), run_(std::move(run)),
       on_start_(std::move(on_thread_start)) {
-    worker_ = std::thread([this] { loop(); });
+    if (n_workers < 1) n_workers = 1;
+    for (int w = 0; w < n_workers; w++) workers_.emplace_back([this, w] { loop(w); });
 }
 
 Coalescer::~Coalescer() {
@@ -31,20 +35,47 @@ Coalescer::~Coalescer() {
         stop_ = true;
     }
     cv_worker_.notify_all();
-    if (worker_.joinable()) worker_.join();
+    for (std::thread& t : workers_)
+        if (t.joinable()) t.join();
+    // shutting down: nobody may stay blocked (submit refuses new requests once stop_ is set)
+    std::vector<DispatchReq*> left;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        left.assign(queue_.begin(), queue_.end());
+        queue_.clear();
+        queued_queries_ = 0;
+    }
+    for (DispatchReq* r : left) {
+        WakeSlot& ws = wake_[r->slot];
+        {
+            std::lock_guard<std::mutex> lk(ws.mu);
+            r->rc = -1;
+            r->err = "dispatcher closed while the request was queued";
+            r->done = true;   // (r may be gone from here on)
+        }
+        ws.cv.notify_all();
+    }
 }
 
 int Coalescer::submit(DispatchReq& r) {
-    std::unique_lock<std::mutex> lk(mu_);
-    if (stop_) return fail("dispatcher is shutting down");
-    r.done = false;
-    r.t_arrive = std::chrono::steady_clock::now();
-    queue_.push_back(&r);
-    queued_queries_ += r.nq;
-    // the worker only needs waking when this arrival can change its decision: first in the queue, or the target reached
-    if (queue_.size() == 1 || queued_queries_ >= target()) cv_worker_.notify_one();
-    cv_done_.wait(lk, [&] { return r.done; });
-    lk.unlock();
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (stop_) return fail("dispatcher is shutting down");
+        r.done = false;
+        r.slot = (uint32_t)((arrivals_++ / WAKE_RUN) % WAKE_SLOTS);
+        r.t_arrive = std::chrono::steady_clock::now();
+        queue_.push_back(&r);
+        queued_queries_ += r.nq;
+        // the gathering worker only needs waking when this arrival can change its decision: first in the queue, or the target reached
+        if (queue_.size() == 1 || queued_queries_ >= target()) {
+            if (workers_.size() > 1) cv_worker_.notify_all(); else cv_worker_.notify_one();
+        }
+    }
+    {
+        WakeSlot& ws = wake_[r.slot];
+        std::unique_lock<std::mutex> lk(ws.mu);
+        ws.cv.wait(lk, [&] { return r.done; });
+    }
     if (r.rc) set_error(r.err.empty() ? std::string("search failed") : r.err);
     return r.rc;
 }
@@ -63,24 +94,25 @@ DispatchStats Coalescer::stats() {
     return st_;
 }
 
-void Coalescer::loop() {
+void Coalescer::loop(int index) {
+    tl_worker_index = index;
     if (on_start_) on_start_();
     std::vector<DispatchReq*> batch;
+    std::vector<uint32_t> slots;
     std::unique_lock<std::mutex> lk(mu_);
-    auto grace_until = std::chrono::steady_clock::time_point::min();
-    bool expected_returners = false;
     for (;;) {
-        cv_worker_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        cv_worker_.wait(lk, [&] { return stop_ || (!gathering_ && !queue_.empty()); });
         if (stop_) break;
+        gathering_ = true;
         // gather until the target is waiting (dispatch.h), or the oldest request is max_wait old -- but never before the callers
         // just answered had their grace period to come back
         auto deadline = queue_.front()->t_arrive + std::chrono::microseconds(max_wait_us_.load());
-        if (grace_until > deadline) deadline = grace_until;
+        if (grace_until_ > deadline) deadline = grace_until_;
         bool by_deadline = false;
         while (!stop_ && queued_queries_ < target()) {
             if (cv_worker_.wait_until(lk, deadline) == std::cv_status::timeout) { by_deadline = true; break; }
         }
-        if (stop_) break;
+        if (stop_) { gathering_ = false; break; }
         batch.clear();
         size_t nq = 0;
         // more callers than one pass holds: equal shares (target()), not a full pass and a remainder
@@ -93,6 +125,9 @@ void Coalescer::loop() {
             queue_.pop_front();
         }
         queued_queries_ -= nq;
+        gathering_ = false;
+        const bool had_expected = expected_returners_;
+        if (workers_.size() > 1 && !queue_.empty()) cv_worker_.notify_all();   // what is left is another worker's to gather
         lk.unlock();
         run_(batch);
         lk.lock();
@@ -103,29 +138,33 @@ void Coalescer::loop() {
         if (by_deadline) st_.deadline_fires++;
         // Next target: what queued up during this pass PLUS the callers answered now -- closed-loop callers (a thread per core,
         // one request at a time) are back within microseconds, and without counting them T callers settle into two groups of T/2
-        // taking turns.  If the gather that just ended had counted on returners and ran into its deadline instead (they did not
-        // come back: open-loop arrivals, or callers that left), the next one does not count on them; the one after tries again.
-        const bool expect_returners = !(by_deadline && expected_returners);
-        expected_returners = expect_returners;
-        expect_ = std::max<size_t>(1, queued_queries_ + (expect_returners ? nq : 0));
+        // taking turns.  A CALLER comes back, whatever it asked for: a request of 256 queries counts as one returner, not as 256
+        // (a lone one-query caller arriving after a batch call would otherwise wait for 255 more that never come).  If the gather
+        // that just ended had counted on returners and ran into its deadline instead (they did not come back: open-loop arrivals,
+        // or callers that left), the next one does not count on them; the one after tries again.
+        const bool expect_returners = !(by_deadline && had_expected);
+        expected_returners_ = expect_returners;
+        expect_ = std::max<size_t>(1, queued_queries_ + (expect_returners ? batch.size() : 0));
         const uint32_t grace_us = std::min<uint32_t>(max_wait_us_.load(), 1000);
-        grace_until = expect_returners ? std::chrono::steady_clock::now() + std::chrono::microseconds(grace_us)
-                                       : std::chrono::steady_clock::time_point::min();
-        for (DispatchReq* r : batch) r->done = true;
+        grace_until_ = expect_returners ? std::chrono::steady_clock::now() + std::chrono::microseconds(grace_us)
+                                        : std::chrono::steady_clock::time_point::min();
         lk.unlock();
-        cv_done_.notify_all();
+        // completion, slot by slot: `done` under the slot's mutex, its variable signalled after the unlock.  A request record lives
+        // on its caller's stack and is gone once `done` is seen, so the slots are read out first.
+        slots.resize(batch.size());
+        uint64_t touched = 0;
+        for (size_t i = 0; i < batch.size(); i++) { slots[i] = batch[i]->slot; touched |= 1ull << slots[i]; }
+        for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++) {
+            if (!(touched >> sl & 1ull)) continue;
+            {
+                std::lock_guard<std::mutex> g(wake_[sl].mu);
+                for (size_t i = 0; i < batch.size(); i++)
+                    if (slots[i] == sl) batch[i]->done = true;
+            }
+            wake_[sl].cv.notify_all();
+        }
         lk.lock();
     }
-    // shutting down: nobody may stay blocked
-    for (DispatchReq* r : queue_) {
-        r->rc = -1;
-        r->err = "dispatcher closed while the request was queued";
-        r->done = true;
-    }
-    queue_.clear();
-    queued_queries_ = 0;
-    lk.unlock();
-    cv_done_.notify_all();
 }
 
 }  // namespace mse
@@ -291,16 +330,23 @@ mse_searcher* mse_dispatcher_searcher(mse_dispatcher* D) { return D ? D->s : nul
 // got somebody else's answer, a wrong status, or a missing error text.
 int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, uint64_t stats_out[6],
                                  uint64_t* mismatches) {
-    if (threads <= 0 || rounds <= 0 || !stats_out || !mismatches) return fail("bad argument");
+    return mse_debug_coalescer_selftest_workers(threads, rounds, max_queries, max_wait_us, 1, stats_out, mismatches);
+}
+
+int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, int workers, uint64_t stats_out[6],
+                                         uint64_t* mismatches) {
+    if (threads <= 0 || rounds <= 0 || workers <= 0 || !stats_out || !mismatches) return fail("bad argument");
+    std::atomic<uint64_t> wrong_worker{0};
     Coalescer co(max_queries ? max_queries : 256, max_wait_us ? max_wait_us : 200,
-                 [](std::vector<DispatchReq*>& batch) {
+                 [&wrong_worker, workers](std::vector<DispatchReq*>& batch) {
+                     if (Coalescer::worker_index() < 0 || Coalescer::worker_index() >= workers) wrong_worker++;
                      for (DispatchReq* r : batch) {
                          const uint64_t p = *static_cast<const uint64_t*>(r->queries);
                          if (p % 97 == 0) { r->rc = -1; r->err = "payload " + std::to_string(p) + " refused"; }
                          else { *static_cast<uint64_t*>(r->out_a) = 2 * p + 1; r->rc = 0; }
                      }
                  },
-                 nullptr);
+                 nullptr, workers);
     std::atomic<uint64_t> bad{0};
     std::vector<std::thread> ts;
     for (int t = 0; t < threads; t++)
@@ -318,7 +364,7 @@ int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, 
     const DispatchStats st = co.stats();
     stats_out[0] = st.queries; stats_out[1] = st.requests; stats_out[2] = st.passes; stats_out[3] = st.max_pass_queries;
     stats_out[4] = st.deadline_fires; stats_out[5] = 0;
-    *mismatches = bad.load();
+    *mismatches = bad.load() + wrong_worker.load();
     return 0;
 }
 

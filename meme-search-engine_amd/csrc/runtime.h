@@ -83,6 +83,11 @@ struct mse_searcher {
     // event pairs of the PQ scan launches of one batch call (several per call on this searcher's stream), read when the call ends
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    // pinned host staging of the fused request path (ONE download per call: scores, ids and counters) and the event of
+    // mse_searcher_wait_stream
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    hipEvent_t ev_wait = nullptr;
 };
 
 struct mse_pq {
@@ -128,14 +133,30 @@ struct mse_graph {
     uint8_t* has_url = nullptr;  // device [n] or null (= all)
     size_t n = 0, max_deg = 0;
     // meeting point of the ONE-query calls of mse_disk_search_batch(_f32) from many threads (beam_search.hip), made on first use
+    // and of the small calls of mse_disk_query_topk(_f32) (round 5): the whole request path of every waiting caller in one
+    // submission, on a searcher and pinned staging that belong to the WORKER (one set per worker thread)
     mutable std::mutex co_mu;
     mutable mse::Coalescer* co = nullptr;
-    // entry table of the fused request path (mse_graph_set_entries / mse_disk_query_topk, beam_search.hip): copies of the entry
-    // records' vectors, their node ids, and a searcher over the copies; one fused call at a time uses them (entry_mu)
+    struct WorkerCtx {
+        mse_searcher* s = nullptr;   // made on first use over the callers' base
+        void* pin = nullptr;         // gathered inputs (queries, scales, starts, tables)
+        size_t pin_cap = 0;
+    };
+    mutable std::vector<WorkerCtx> co_ctx;
+    size_t co_max_queries = 0;       // mse_graph_set_coalescer: 0 = defaults (1024 queries per pass, 200 us, two workers)
+    uint32_t co_max_wait_us = 0;
+    int co_workers = 0;
+    // entry table of the fused request path (beam_search.hip), one of two kinds:
+    //   mse_graph_set_entries          copies of the entry records' vectors + their node ids; entry = exact top-1 over the copies
+    //   mse_graph_set_entry_centroids  the reference's rule: f32 shard centroids as keys (transposed [d][n_entries]) + medioid ids
+    // Request-path calls hold entry_lock shared for their duration; replacing the table takes it exclusively.
     uint16_t* entry_rows = nullptr;
     uint32_t* entry_ids = nullptr;
     size_t n_entries = 0;
     mse_base* entry_base = nullptr;
+    float* entry_keys_t = nullptr;
+    size_t entry_keys_d = 0;
+    mutable mse::SharedExclusive entry_lock;
     // searchers over the entry rows: a fused call borrows one for its duration (its scratch is in use until the call's stream is
     // drained), so that calls from several threads -- each with its own searcher and stream -- overlap instead of queueing
     mutable std::vector<mse_searcher*> entry_pool;

@@ -212,6 +212,30 @@ def set_entries(dgraph, vecs, node_ids):
     check(ffi.lib().mse_graph_set_entries(dgraph._h, vecs._h, _p(ids, C.c_uint32), ids.size), "graph_set_entries")
 
 
+def set_entry_centroids(dgraph, centroids, medioid_ids):
+    """The reference's own entry rule (query_disk_index.rs:254-256,447-450): `centroids` [n_shards, d] f32 are the shard centroids of
+    the index header, `medioid_ids` the shards' start nodes; a search starts at the medioid of the shard whose centroid has the largest
+    scale_dot_result_f64(dot(centroid, query)), last maximum on ties."""
+    c = np.ascontiguousarray(centroids, np.float32)
+    ids = np.ascontiguousarray(medioid_ids, np.uint32).reshape(-1)
+    if c.ndim != 2 or c.shape[0] != ids.size:
+        raise MseError("centroids must be [n_shards, d] with one medioid id per shard")
+    check(ffi.lib().mse_graph_set_entry_centroids(dgraph._h, _p(c, C.c_float), c.shape[1], _p(ids, C.c_uint32), ids.size),
+          "graph_set_entry_centroids")
+
+
+def set_coalescer(dgraph, max_queries_per_pass=0, max_wait_us=0, workers=0):
+    """How the graph's coalescer serves small request-path calls from many threads (0 = the defaults: 1024, 200 us, 2 workers)."""
+    check(ffi.lib().mse_graph_set_coalescer(dgraph._h, int(max_queries_per_pass), int(max_wait_us), int(workers)), "graph_set_coalescer")
+
+
+def coalescer_stats(dgraph):
+    out = (C.c_uint64 * 6)()
+    check(ffi.lib().mse_graph_coalescer_stats(dgraph._h, out), "graph_coalescer_stats")
+    return {"queries": int(out[0]), "requests": int(out[1]), "passes": int(out[2]), "max_pass_queries": int(out[3]),
+            "deadline_fires": int(out[4])}
+
+
 def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, starts=None, luts=None, descriptor_scales=None,
                     disable_pq=False, beamwidth=1, search_list=1000):
     """The request path of query_disk_index (:436-540) for a batch in one device submission: entry node (by the graph's entry table
@@ -219,8 +243,15 @@ def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, st
     (a host array, or `(device_pointer, nq)` for rows already on the device),
     (ids [nq, k] uint32, scores [nq, k] int64, stats dict) out; ids / scores equal topk_of_visited(disk_search_batch(...)) for the
     same start nodes.  Rows with fewer than k visited records are padded with ID_NONE / INT64_MIN."""
+    from_f32 = False
     if isinstance(queries, tuple):      # (device pointer, nq): f16 rows already resident on the searcher's device, contiguous
         q_ptr, nq = C.cast(C.c_void_p(int(queries[0])), C.POINTER(C.c_uint16)), int(queries[1])
+    elif np.asarray(queries).dtype == np.float32 and luts is None:
+        # f32 rows in, as the reference's handler gets them (:436-477): f16 copies and distance tables are made on the device
+        from_f32 = True
+        q = np.ascontiguousarray(np.asarray(queries).reshape(-1, np.asarray(queries).shape[-1]), np.float32)
+        nq = q.shape[0]
+        q_ptr = _p(q, C.c_float)
     else:
         q = _bits(queries)
         q = q.reshape(-1, q.shape[-1])
@@ -238,11 +269,15 @@ def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, st
             sc = np.ascontiguousarray(np.broadcast_to(sc, (nq, sc.size)))
     ids, scores = np.empty((nq, k), np.uint32), np.empty((nq, k), np.int64)
     nv, cm, pc = np.empty(nq, np.uint32), np.empty(nq, np.uint32), np.empty(nq, np.uint32)
-    check(ffi.lib().mse_disk_query_topk(searcher._h, quantizer._h if quantizer is not None else None, codes._h if codes is not None else None,
-                                        dgraph._h, _p(st, C.c_uint32) if st is not None else None, q_ptr,
-                                        _p(tables, C.c_float) if tables is not None else None, _p(sc, C.c_float) if sc is not None else None,
-                                        nq, int(bool(disable_pq)), int(beamwidth), int(search_list), int(k), _p(ids, C.c_uint32),
-                                        _p(scores, C.c_int64), _p(nv, C.c_uint32), _p(cm, C.c_uint32), _p(pc, C.c_uint32)), "disk_query_topk")
+    tail = (nq, int(bool(disable_pq)), int(beamwidth), int(search_list), int(k), _p(ids, C.c_uint32), _p(scores, C.c_int64), _p(nv, C.c_uint32),
+            _p(cm, C.c_uint32), _p(pc, C.c_uint32))
+    head = (searcher._h, quantizer._h if quantizer is not None else None, codes._h if codes is not None else None, dgraph._h,
+            _p(st, C.c_uint32) if st is not None else None, q_ptr)
+    scp = _p(sc, C.c_float) if sc is not None else None
+    if from_f32:
+        check(ffi.lib().mse_disk_query_topk_f32(*head, scp, *tail), "disk_query_topk_f32")
+    else:
+        check(ffi.lib().mse_disk_query_topk(*head, _p(tables, C.c_float) if tables is not None else None, scp, *tail), "disk_query_topk")
     return ids, scores, {"n_visited": nv, "cmps": cm, "pq_cmps": pc}
 
 

@@ -138,6 +138,12 @@ SIGNATURES = {
     "mse_disk_search_batch_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
                                             u32p, u32p, u32p]),
     "mse_graph_set_entries": (C.c_int, [vp, vp, u32p, sz]),
+    "mse_graph_set_entry_centroids": (C.c_int, [vp, f32p, sz, u32p, sz]),
+    "mse_disk_query_topk_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
+    "mse_graph_set_coalescer": (C.c_int, [vp, sz, C.c_uint32, C.c_int]),
+    "mse_graph_coalescer_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "mse_searcher_wait_stream": (C.c_int, [vp, vp]),
+    "mse_debug_coalescer_selftest_workers": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mse_disk_query_topk": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
     "mse_graph_new": (vp, [sz, sz]),
     "mse_graph_to_host": (C.c_int, [vp, u32p, u32p]),

@@ -120,6 +120,11 @@ class Searcher:
     def set_stream(self, hip_stream):
         check(ffi.lib().mse_searcher_set_stream(self._h, hip_stream), "set_stream")
 
+    def wait_stream(self, producer_stream):
+        """Order this searcher's stream after what `producer_stream` (a hipStream_t value) holds now: call it before handing the
+        searcher device-resident inputs that another stream wrote."""
+        check(ffi.lib().mse_searcher_wait_stream(self._h, producer_stream), "wait_stream")
+
     def bruteforce_topk(self, queries, k, mode=MODE_AUTO):
         """Brute-force scan + ranking of `evaluate` (query_disk_index.rs:262-273) for a query batch.
         Returns (scores int64 [nq,k], ids uint32 [nq,k])."""

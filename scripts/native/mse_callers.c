@@ -83,3 +83,90 @@ double mse_callers_run(void* fn, void* handle, const void* queries, size_t n_que
     free(cs);
     return dt;
 }
+
+/* ---- the graph index's request path in the reference's call shape (round 5) -------------------------------------------------
+ * query_disk_index answers one request = one query on its own task (src/query_disk_index.rs:436-540,711-736; perf_test.py:6-29:
+ * 1000 one-query requests at concurrency 100).  T native threads, closed loop, ONE query per mse_disk_query_topk /
+ * mse_disk_query_topk_f32 call through host pointers; thread t uses searchers[t % n_searchers] (a coalesced call only reads its
+ * searcher's base, include/mse.h).  scales: [n_queries][n_desc] per-request descriptor scales or NULL. */
+typedef int (*query16_fn)(void* s, void* pq, const void* c, const void* g, const uint32_t* starts, const void* q, const float* luts,
+                          const float* scales, size_t nq, int disable_pq, size_t beam, size_t list, size_t k, uint32_t* ids, int64_t* scores,
+                          uint32_t* nv, uint32_t* cm, uint32_t* pc);
+typedef int (*query32_fn)(void* s, void* pq, const void* c, const void* g, const uint32_t* starts, const void* q, const float* scales, size_t nq,
+                          int disable_pq, size_t beam, size_t list, size_t k, uint32_t* ids, int64_t* scores, uint32_t* nv, uint32_t* cm,
+                          uint32_t* pc);
+
+typedef struct {
+    void* fn;
+    int is_f32;
+    void* searcher;
+    void* pq;
+    const void* codes;
+    const void* graph;
+    const char* queries;
+    const float* scales;
+    size_t n_queries, query_bytes, n_desc, k, beam, list, first, stride;
+    int disable_pq;
+    uint32_t* ids;
+    int64_t* scores;
+    double* latency_ms;
+    pthread_barrier_t* gate;
+    int failures;
+} qcaller_t;
+
+static void* qcaller_main(void* p) {
+    qcaller_t* c = (qcaller_t*)p;
+    pthread_barrier_wait(c->gate);
+    for (size_t j = c->first; j < c->n_queries; j += c->stride) {
+        const float* sc = c->scales ? c->scales + j * c->n_desc : NULL;
+        const double t0 = now_s();
+        int rc;
+        if (c->is_f32)
+            rc = ((query32_fn)c->fn)(c->searcher, c->pq, c->codes, c->graph, NULL, c->queries + j * c->query_bytes, sc, 1, c->disable_pq, c->beam,
+                                     c->list, c->k, c->ids + j * c->k, c->scores + j * c->k, NULL, NULL, NULL);
+        else
+            rc = ((query16_fn)c->fn)(c->searcher, c->pq, c->codes, c->graph, NULL, c->queries + j * c->query_bytes, NULL, sc, 1, c->disable_pq,
+                                     c->beam, c->list, c->k, c->ids + j * c->k, c->scores + j * c->k, NULL, NULL, NULL);
+        c->latency_ms[j] = (now_s() - t0) * 1e3;
+        if (rc) c->failures++;
+    }
+    return NULL;
+}
+
+double mse_callers_run_query(void* fn, int is_f32, void** searchers, int n_searchers, void* pq, const void* codes, const void* graph,
+                             const void* queries, size_t n_queries, size_t query_bytes, const float* scales, size_t n_desc, int disable_pq,
+                             size_t beam, size_t list, size_t k, int threads, uint32_t* ids, int64_t* scores, double* latency_ms, int* n_failed) {
+    if (threads <= 0 || !fn || n_searchers <= 0) return -1.0;
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    qcaller_t* cs = (qcaller_t*)calloc((size_t)threads, sizeof(qcaller_t));
+    pthread_barrier_t gate;
+    if (!th || !cs || pthread_barrier_init(&gate, NULL, (unsigned)threads + 1)) { free(th); free(cs); return -1.0; }
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setstacksize(&attr, 256 * 1024);
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        cs[t] = (qcaller_t){fn, is_f32, searchers[t % n_searchers], pq, codes, graph, (const char*)queries, scales, n_queries, query_bytes, n_desc, k,
+                            beam, list, (size_t)t, (size_t)threads, disable_pq, ids, scores, latency_ms, &gate, 0};
+        if (pthread_create(&th[t], &attr, qcaller_main, &cs[t])) break;
+        started++;
+    }
+    double dt = -1.0;
+    if (started == threads) {
+        pthread_barrier_wait(&gate);
+        const double t0 = now_s();
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+        dt = now_s() - t0;
+        int f = 0;
+        for (int t = 0; t < threads; t++) f += cs[t].failures;
+        if (n_failed) *n_failed = f;
+    } else {
+        for (int t = 0; t < started; t++) pthread_cancel(th[t]);
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    }
+    pthread_attr_destroy(&attr);
+    pthread_barrier_destroy(&gate);
+    free(th);
+    free(cs);
+    return dt;
+}

@@ -238,3 +238,18 @@ def test_coalescer_queue_hands_every_caller_its_own_answer(mse, threads, rounds,
         assert passes == requests
     elif threads >= 64:
         assert passes < requests / 2, (passes, requests)
+
+
+@pytest.mark.parametrize("threads,rounds,max_queries,workers", [(64, 40, 256, 2), (600, 10, 128, 2), (24, 100, 8, 3)])
+def test_coalescer_with_several_workers(mse, threads, rounds, max_queries, workers):
+    """The same queue with several worker threads (the graph's request path runs two) and its slotted completion (256 consecutive
+    arrivals share a wake-up slot): every caller still gets its own answer, nothing deadlocks, no pass exceeds its size."""
+    import ctypes as C
+    from mse import ffi
+    stats = (C.c_uint64 * 6)()
+    bad = C.c_uint64(12345)
+    ffi.check(ffi.lib().mse_debug_coalescer_selftest_workers(threads, rounds, max_queries, 2000, workers, stats, C.byref(bad)))
+    assert bad.value == 0
+    assert int(stats[0]) == int(stats[1]) == threads * rounds
+    assert int(stats[3]) <= max_queries
+    assert int(stats[2]) < threads * rounds / 2

@@ -323,3 +323,141 @@ def test_index_near_duplicates_widen_only_their_query(gpu, mse, orc):
     wd, wl = orc.index_search(orc.f16_bits(x), q, k, order=0)
     assert np.array_equal(wl[5], np.sort(pos5)[:k]) and np.array_equal(wl[9], np.sort(pos9)[:k])
     assert np.array_equal(res.labels, wl) and np.array_equal(res.distances, wd)
+
+
+def _want_topk(ovids, ovsc, k):
+    """The server's last step on the oracle's visited list: by (score descending, id ascending), first k, padded."""
+    order = sorted(range(len(ovids)), key=lambda j: (-int(ovsc[j]), int(ovids[j])))[:k]
+    ids = np.full(k, 0xFFFFFFFF, np.uint32)
+    sc = np.full(k, np.iinfo(np.int64).min, np.int64)
+    ids[:len(order)] = ovids[order]
+    sc[:len(order)] = ovsc[order]
+    return ids, sc
+
+
+def test_request_path_one_query_per_thread_is_shared_and_unchanged(gpu, mse, orc):
+    """The metric's own path in the reference's call shape (src/query_disk_index.rs:436-540,711-736; perf_test.py:6-29): 64 request
+    threads, ONE query per mse_disk_query_topk(_f32) call, all through ONE searcher handle (a coalesced call only reads its base).
+    Mixed k and search lists; f32 queries with per-request descriptor scales, ADC-scored, entry by the reference's shard-centroid rule;
+    and f16 queries scored exactly.  Every caller gets the oracle's answer for ITS query -- shard selection, greedy_search, sort --
+    and the submissions really are shared."""
+    from test_gpu_pq_index_graph import clustered_rows, knn_graph, train_pq
+    rng = np.random.default_rng(31)
+    n, deg, T, S = 3000, 14, 64, 42
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    cents, Tm = train_pq(orc, x[:2000], iters=2)
+    opq, gpq = orc.PQ(cents, Tm, 18, D), mse.ProductQuantizer(cents, Tm, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    has_url = (rng.random(n) > 0.1).astype(np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    vl = mse.VectorList.from_f16s(base, D)
+    shared = mse.Searcher(vl)
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs), has_url)
+    # the index header's shards: centroid + medioid (start node) each; two shards share a centroid, so ties exist (last one wins)
+    centroids = x[rng.choice(n, S, replace=False)].astype(np.float32) * np.float32(0.9)
+    centroids[17] = centroids[5]
+    medioids = rng.choice(n, S, replace=False).astype(np.uint32)
+    mse.set_entry_centroids(dgraph, centroids, medioids)
+    qs = (clustered_rows(orc, T, n_centres=32, seed=301) * np.float32(1.3)).astype(np.float32)
+    qs[7] = centroids[5] * np.float32(2.0)                      # a query for which shards 5 and 17 tie exactly
+    qh = orc.f16_bits(qs)
+    scales = (rng.standard_normal((T, 4)) / 512).astype(np.float32)
+
+    def params(i):
+        return (10 if i % 3 else 25), (48 if i % 2 else 64)
+
+    def call(i):
+        k, L = params(i)
+        if i % 4 < 2:     # the handler as the reference runs it: f32 query, per-request scales, ADC-scored neighbours
+            return mse.disk_query_topk(shared, gpq, gcodes, dgraph, qs[i:i + 1], k, None, None, scales[i:i + 1], False, 4, L)
+        return mse.disk_query_topk(shared, None, None, dgraph, qh[i:i + 1], k, None, None, None, True, 2, L)
+
+    before = mse.coalescer_stats(dgraph)
+    for rnd in range(3):
+        outs = run_threads(T, call)
+        if rnd:
+            continue
+        for i in range(T):
+            k, L = params(i)
+            adc = i % 4 < 2
+            # the f16-query form widens the query exactly for the shard selection
+            shard = orc.select_shard(centroids, qs[i] if adc else orc.f16_to_f32(qh[i]))
+            if i == 7:
+                assert shard == 17
+            _, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, desc, int(medioids[shard]), qh[i],
+                                                              opq.preprocess_query(qs[i]) if adc else np.zeros(64 * 256, np.float32),
+                                                              scales[i] if adc else None, not adc, 4 if adc else 2, L, has_url)
+            want_ids, want_sc = _want_topk(ovids, ovsc, k)
+            ids, sc, st = outs[i]
+            assert np.array_equal(ids[0], want_ids) and np.array_equal(sc[0], want_sc), i
+            assert (int(st["cmps"][0]), int(st["pq_cmps"][0]), int(st["n_visited"][0])) == (ocm, opc, len(ovids)), i
+    after = mse.coalescer_stats(dgraph)
+    requests, passes = after["requests"] - before["requests"], after["passes"] - before["passes"]
+    assert requests == 3 * T and after["queries"] - before["queries"] == 3 * T
+    assert passes <= requests // 4, (passes, requests)             # 192 one-query requests in a few dozen submissions at most
+    assert after["max_pass_queries"] >= 16
+    # small multi-query calls share the queue too; a batch call (beyond 16 queries) goes straight to the device: same answers
+    lone = call(5)
+    assert np.array_equal(lone[0], outs[5][0]) and np.array_equal(lone[1], outs[5][1])
+    few = mse.disk_query_topk(shared, None, None, dgraph, qh[2:12], 10, None, None, None, True, 2, 64)
+    big = mse.disk_query_topk(mse.Searcher(vl), None, None, dgraph, qh, 10, None, None, None, True, 2, 64)
+    assert np.array_equal(few[0], big[0][2:12]) and np.array_equal(few[1], big[1][2:12])
+    # one caller's error stays its own
+    def bad_or_good(i):
+        if i == 3:
+            with pytest.raises(mse.MseError):
+                mse.disk_query_topk(shared, None, None, dgraph, qh[i:i + 1], 10, None, None, None, True, 9, 64)     # beamwidth 9
+            return None
+        return mse.disk_query_topk(shared, None, None, dgraph, qh[i:i + 1], 10, None, None, None, True, 2, 64)
+    outs2 = run_threads(16, bad_or_good)
+    for i in range(16):
+        if i != 3:
+            assert np.array_equal(outs2[i][0][0], big[0][i]) and np.array_equal(outs2[i][1][0], big[1][i])
+
+
+def test_entry_table_replaced_under_request_threads(gpu, mse, orc):
+    """mse_graph_set_entries / _set_entry_centroids while request threads are calling: every answer is the answer under ONE of the
+    tables, never a torn state or a crash (the setters take the entry lock exclusively, calls hold it shared)."""
+    from test_gpu_pq_index_graph import clustered_rows, knn_graph
+    rng = np.random.default_rng(32)
+    n, deg, T = 3000, 12, 12
+    x = clustered_rows(orc, n, n_centres=24)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vl = mse.VectorList.from_f16s(base, D)
+    s = mse.Searcher(vl)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    tables = [np.sort(rng.choice(n, 30, replace=False)).astype(np.uint32) for _ in range(2)]
+    cen = x[rng.choice(n, 9, replace=False)].astype(np.float32)
+    med = rng.choice(n, 9, replace=False).astype(np.uint32)
+    qh = orc.f16_bits(clustered_rows(orc, T, n_centres=24, seed=302))
+    want = []
+    for t in tables:
+        mse.set_entries(dgraph, vl, t)
+        want.append(mse.disk_query_topk(mse.Searcher(vl), None, None, dgraph, qh, 10, None, None, None, True, 2, 32)[0])
+    mse.set_entry_centroids(dgraph, cen, med)
+    want.append(mse.disk_query_topk(mse.Searcher(vl), None, None, dgraph, qh, 10, None, None, None, True, 2, 32)[0])
+    stop = threading.Event()
+    bad = []
+
+    def caller(i):
+        while not stop.is_set():
+            ids = mse.disk_query_topk(s, None, None, dgraph, qh[i:i + 1], 10, None, None, None, True, 2, 32)[0][0]
+            if not any(np.array_equal(ids, w[i]) for w in want):
+                bad.append(i)
+
+    ts = [threading.Thread(target=caller, args=(i,)) for i in range(T)]
+    for t in ts:
+        t.start()
+    for r in range(12):
+        if r % 3 == 2:
+            mse.set_entry_centroids(dgraph, cen, med)
+        else:
+            mse.set_entries(dgraph, vl, tables[r % 3])
+    stop.set()
+    for t in ts:
+        t.join()
+    assert not bad, bad

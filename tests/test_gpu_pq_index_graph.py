@@ -970,3 +970,70 @@ def test_codes_quantized_from_resident_rows_equal_quantize_batch(gpu, mse, orc):
     a = pq.scan_topk_batch(dev_codes, q, 100, 100, None, scales)
     b = pq.scan_topk_batch(host_codes, q, 100, 100, None, scales)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_entry_by_shard_centroids_is_the_reference_rule(gpu, mse, orc):
+    """mse_graph_set_entry_centroids: the start node is the medioid of the shard that orc.select_shard picks (f32 dot summed in f64,
+    scale_dot_result_f64, LAST maximum on ties -- src/query_disk_index.rs:254-256,447-450), for f32 queries and for f16 queries
+    (widened exactly), through the batch call; results equal the call that is given those start nodes."""
+    rng = np.random.default_rng(41)
+    n, deg, S, nq, k, L = 2500, 12, 42, 45, 10, 24
+    x = clustered_rows(orc, n, n_centres=24)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    centroids = (x[rng.choice(n, S, replace=False)] * np.float32(0.8) + rng.standard_normal((S, D)).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+    centroids[40] = centroids[3]                                       # equal keys for every query: shard 40 must win over shard 3
+    medioids = rng.choice(n, S, replace=False).astype(np.uint32)
+    mse.set_entry_centroids(dgraph, centroids, medioids)
+    qs = (clustered_rows(orc, nq, n_centres=24, seed=310) * np.float32(1.1)).astype(np.float32)
+    qs[0] = centroids[3]
+    qh = orc.f16_bits(qs)
+    for q_in, q_for_shard in ((qs, qs), (qh, orc.f16_to_f32(qh))):
+        shards = np.array([orc.select_shard(centroids, q_for_shard[i]) for i in range(nq)])
+        assert shards[0] == 40 and len(set(shards.tolist())) > 3
+        got = mse.disk_query_topk(searcher, None, None, dgraph, q_in, k, None, None, None, True, 2, L)
+        want = mse.disk_query_topk(searcher, None, None, dgraph, qh, k, medioids[shards], None, None, True, 2, L)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert np.array_equal(got[2]["cmps"], want[2]["cmps"])
+    with pytest.raises(mse.MseError):
+        mse.set_entry_centroids(dgraph, centroids, np.full(S, n, np.uint32))
+    # a row table replaces the centroid table (and the other way round)
+    mse.set_entries(dgraph, vecs, medioids)
+    _, best = orc.bruteforce_topk(base[medioids], qh, 1)
+    got = mse.disk_query_topk(searcher, None, None, dgraph, qh, k, None, None, None, True, 2, L)
+    want = mse.disk_query_topk(searcher, None, None, dgraph, qh, k, medioids[best[:, 0]], None, None, True, 2, L)
+    assert np.array_equal(got[0], want[0])
+
+
+def test_device_queries_written_by_another_stream(gpu, mse, orc):
+    """Device-resident queries produced on ANOTHER stream (the text tower's): mse_searcher_wait_stream orders the searcher's copy after
+    the producer without a host synchronisation.  The producer stream is kept busy for tens of milliseconds before it writes the
+    queries, so an unordered copy would read the zeros that were there before."""
+    import torch
+    rng = np.random.default_rng(42)
+    n, deg, nq, k, L = 3000, 12, 40, 10, 24
+    x = clustered_rows(orc, n, n_centres=24)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    mse.set_entries(dgraph, vecs, np.sort(rng.choice(n, 50, replace=False)).astype(np.uint32))
+    qh = orc.f16_bits(clustered_rows(orc, nq, n_centres=24, seed=311))
+    want = mse.disk_query_topk(searcher, None, None, dgraph, qh, k, None, None, None, True, 2, L)
+    src = torch.from_numpy(qh.view(np.int16).copy()).cuda()
+    qd = torch.zeros_like(src)
+    a = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    producer = torch.cuda.Stream()
+    with torch.cuda.stream(producer):
+        for _ in range(60):
+            a = a @ a * 1e-3                                           # tens of milliseconds of work ahead of the write
+        qd.copy_(src)
+    searcher.wait_stream(producer.cuda_stream)
+    got = mse.disk_query_topk(searcher, None, None, dgraph, (qd.data_ptr(), nq), k, None, None, None, True, 2, L)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    torch.cuda.synchronize()
