@@ -116,3 +116,267 @@ def hardness(vecs, searcher, rows, queries_f16, k=10, k_lid=20, n_random=4096):
 def recall_at(top, truth):
     k = truth.shape[1]
     return sum(len(set(top[i, :k].tolist()) & set(truth[i].tolist())) for i in range(truth.shape[0])) / (k * truth.shape[0])
+
+
+def _callers_lib(root):
+    import ctypes as C
+    import os
+    import subprocess
+    so = os.path.join(root, "scripts", "native", "libmse_callers.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
+    H = C.CDLL(so)
+    H.mse_callers_run_query.restype = C.c_double
+    H.mse_callers_run_query.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    return H
+
+
+def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, thread_counts=(64, 512, 4096), one_call_qps=None,
+                  pq=None, codes=None, disable_pq=True, rounds=None, coalescer=(0, 0, 0)):
+    """The metric's path in the reference's call shape (src/query_disk_index.rs:436-540,711-736): T native request threads, closed
+    loop, ONE f32 query per mse_disk_query_topk_f32 call through host pointers (entry step, f16 copy, greedy_search, top-k of the
+    visited records -- all inside the call); the calls meet in the graph's coalescer.  Every answer is compared with the batch call's
+    answer for the same query.  Plus the shape of the repo's own load test (perf_test.py:6-29): 1000 one-query requests at
+    concurrency 100, k = 10."""
+    import ctypes as C
+    import numpy as np
+    import mse
+    from mse import ffi
+    H = _callers_lib(root)
+    fn = C.cast(ffi.lib().mse_disk_query_topk_f32, C.c_void_p)
+    qf = np.ascontiguousarray(queries_f32, np.float32)
+    n_all = qf.shape[0]
+    checker = mse.Searcher(vecs)
+    want_ids, want_sc, _ = mse.disk_query_topk(checker, pq, codes, g, qf, k, None, None, None, disable_pq, beam, search_list)
+    checker.close()
+    mse.set_coalescer(g, *coalescer)
+    n_s = 64
+    searchers = [mse.Searcher(vecs) for _ in range(n_s)]        # thread t uses searcher t % 64: a coalesced call only reads its base
+    sarr = (C.c_void_p * n_s)(*[s._h for s in searchers])
+    pq_h, c_h = (pq._h if pq is not None else None), (codes._h if codes is not None else None)
+
+    def run(T, n):
+        ids = np.full((n, k), 0xFFFFFFFF, np.uint32)
+        sc = np.zeros((n, k), np.int64)
+        lat = np.zeros(n, np.float64)
+        failed = C.c_int(0)
+        st0 = mse.coalescer_stats(g)
+        dt = H.mse_callers_run_query(fn, 1, sarr, n_s, pq_h, c_h, g._h, qf.ctypes.data, n, D * 4, None, 0, int(disable_pq), beam, search_list, k, T,
+                                     ids.ctypes.data, sc.ctypes.data, lat.ctypes.data, C.byref(failed))
+        st1 = mse.coalescer_stats(g)
+        ok = bool(dt > 0 and failed.value == 0 and np.array_equal(ids, want_ids[:n]) and np.array_equal(sc, want_sc[:n]))
+        passes = st1["passes"] - st0["passes"]
+        busy = (st1["run_us"] - st0["run_us"]) * 1e-6
+        return {"threads": T, "queries": n, "queries_per_s": n / dt if dt > 0 else None, "seconds": dt,
+                "worker_seconds_in_submissions": busy, "ms_per_submission": busy / max(passes, 1) * 1e3,
+                "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
+                "submissions": passes, "queries_per_submission": n / max(passes, 1), "all_answers_equal_the_batch_call": ok,
+                "recall_at_10": recall_at(ids, truth[:n]) if truth is not None else None,
+                "vs_one_call_of_4096": (n / dt / one_call_qps) if dt > 0 and one_call_qps else None}
+
+    points = []
+    for T in thread_counts:
+        n = min(n_all, T * rounds if rounds else max(10 * T, 20_000))
+        run(T, min(n, 2 * T))                       # warm: two rounds
+        points.append(run(T, n))
+    run(100, min(n_all, 200))
+    perf_test = run(100, min(n_all, 1000))
+    st = mse.coalescer_stats(g)
+    for s in searchers:
+        s.close()
+    mse.set_coalescer(g, 0, 0, 0)
+    return {"metric": "queries/s through the graph index's request path, ONE f32 query per call from T native threads (closed loop), host pointers in and out",
+            "search_list": search_list, "beamwidth": beam, "k": k, "neighbours_scored": "exactly" if disable_pq else "by ADC (the reference's default)",
+            "points": points, "perf_test_py_shape": dict(perf_test, note="1000 one-query requests at concurrency 100, k = 10 (perf_test.py:6-29)"),
+            "coalescer": {"max_queries_per_submission": coalescer[0] or 1024, "max_wait_us": coalescer[1] or 200, "workers": coalescer[2] or 2,
+                          "submissions_started_by_wait_budget": st["deadline_fires"]}}
+
+
+HARD_PARAMS = dict(cone=0.62, topic=0.35, within=0.65, noise=0.25, decay=0.6, rank=96)   # scripts/hardness_probe.py config "b"
+OOD_GAP, OOD_EXTRA_NOISE = 0.35, 0.30
+
+
+def train_codec(samp, seed=4, iters=3):
+    """OPQ-shaped 64 x 256 codec in aopq_train.py's layout (a rotation + per-subspace max-inner-product k-means), trained on the
+    host over a small sample: -> (centroids [256, 1152], transform [1152, 1152])."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
+    ts = samp @ T.T
+    cents = np.zeros((256, D), np.float32)
+    for i in range(64):
+        sub = ts[:, i * 18:(i + 1) * 18]
+        c = sub[rng.choice(len(sub), 256, replace=False)].copy()
+        for _ in range(iters):
+            asg = np.argmax(sub @ c.T, axis=1)
+            for j in range(256):
+                mem = sub[asg == j]
+                if len(mem):
+                    c[j] = mem.mean(axis=0)
+        cents[:, i * 18:(i + 1) * 18] = c
+    return cents, T
+
+
+def shard_centroid_entries(rows, n_base, n_shards=64, sample=200_000, seed=7):
+    """Stand-ins for the index header's shards (centroid + start node each, src/query_disk_index.rs:254-256,447-450) over a one-piece
+    index: k-means centroids (spherical, two Lloyd rounds on a row sample) and, per centroid, the sample row closest to it as the
+    shard's medioid.  -> (centroids [S, 1152] f32, medioid ids [S] u32)."""
+    import numpy as np
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    idx = torch.randint(0, n_base, (min(sample, n_base),), device="cuda", generator=g)
+    x = rows[idx].float()
+    c = x[torch.randperm(x.shape[0], device="cuda", generator=g)[:n_shards]].clone()
+    for _ in range(2):
+        a = torch.argmax(x @ c.T, dim=1)
+        for j in range(n_shards):
+            m = x[a == j]
+            if m.shape[0]:
+                c[j] = m.mean(dim=0)
+    a = torch.argmax(x @ c.T, dim=1)
+    sims = x @ c.T
+    med = torch.argmax(sims, dim=0)                       # per centroid: the sample row with the largest dot product
+    return c.cpu().numpy().astype(np.float32), idx[med].cpu().numpy().astype(np.uint32)
+
+
+def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget_s=None):
+    """One row of the graph-index table: a Vamana graph (generate-index-shard's defaults R 64, L 192, C 750; one pass) over n synthetic
+    rows of `kind` (easy / hard / ood, see the module docstring), searched through the request path in one call
+    (mse_disk_query_topk): operating points picked on 4096 TUNING queries (smallest search list with recall@10 >= 0.96 there) and
+    reported on 4096 HELD-OUT queries, for exactly scored neighbours (entry: sampled rows; and the reference's closest-shard-centroid
+    rule) and for the reference's default ADC-scored search; the PQ flat scan + fp16 re-rank on the same rows (r picked the same
+    way); hardness statistics of the (base, query) pair."""
+    import numpy as np
+    import torch
+    import mse
+    K, R, nq_t = 10, 64, 4096
+    n_qtrain = 100_000 if kind == "ood" else 0
+    t_all = time.perf_counter()
+    if kind == "easy":
+        gen = easy_generator(n)
+        rows = gen(n, 1)
+        tune_q, held_q = gen(nq_t, 2), gen(nq_t, 3)
+    else:
+        hs = HardSet(n, **HARD_PARAMS)
+        rows = torch.empty(n + n_qtrain, D, device="cuda", dtype=torch.float16)
+        rows[:n] = hs.rows(n, 1)
+        if kind == "ood":
+            rows[n:] = hs.rows(n_qtrain, 4, queries="ood", gap=OOD_GAP, extra_noise=OOD_EXTRA_NOISE)      # the query sample the graph is built with
+            tune_q = hs.rows(nq_t, 2, queries="ood", gap=OOD_GAP, extra_noise=OOD_EXTRA_NOISE)
+            held_q = hs.rows(nq_t, 3, queries="ood", gap=OOD_GAP, extra_noise=OOD_EXTRA_NOISE)
+        else:
+            tune_q, held_q = hs.rows(nq_t, 2), hs.rows(nq_t, 3)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_all
+    n_all = n + n_qtrain
+    vecs = mse.VectorList.wrap_device(rows.data_ptr(), n_all, D, keepalive=rows)         # what the graph is built over (base rows, then the query sample)
+    base_only = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows) if n_qtrain else vecs
+    s = mse.Searcher(vecs)
+    sb = mse.Searcher(base_only) if n_qtrain else s
+    out = {"kind": kind, "rows": n, "generated_on_device_seconds": t_gen}
+    # exact answers + hardness
+    hard_t, truth_t = hardness(base_only, sb, rows[:n], tune_q)
+    _, truth_h = sb.bruteforce_topk(held_q.cpu().numpy().view(np.uint16), K)
+    out["hardness"] = hard_t
+    # build
+    t0 = time.perf_counter()
+    med = mse.medioid(vecs)
+    g = mse.BuildGraph(n_all, R)
+    g.random_fill(1)
+    order = np.random.default_rng(3).permutation(n_all).astype(np.uint32)
+    cfg = mse.IndexBuildConfig(r=R, l=192, maxc=750, query_breakpoint=n if n_qtrain else 0xFFFFFFFF)
+    for _ in range(passes):
+        g.build(s, order, med, cfg, batch)
+    t_pass = time.perf_counter() - t0
+    if n_qtrain:
+        q_order = (n + np.random.default_rng(4).permutation(n_qtrain)).astype(np.uint32)
+        g.robust_stitch(s, q_order, cfg)
+    t_build = time.perf_counter() - t0
+    out["build"] = {"seconds": t_build, "points_per_s": n_all * passes / t_pass, "passes": passes, "r": R, "l": 192, "maxc": 750, "batch": batch,
+                    "query_sample": n_qtrain, "robust_stitch_seconds": (t_build - t_pass) if n_qtrain else None}
+    qt16, qh16 = tune_q.cpu().numpy().view(np.uint16), held_q.cpu().numpy().view(np.uint16)
+    qt32, qh32 = tune_q.float().cpu().numpy(), held_q.float().cpu().numpy()
+
+    def pick(run, grid, goal=0.96):
+        """smallest grid value whose TUNING recall reaches the goal; the held-out point is measured once, warm"""
+        sweep, chosen = [], None
+        for v in grid:
+            top = run(v, qt16, qt32)[0]
+            rec = recall_at(top, truth_t)
+            sweep.append([v, round(rec, 4)])
+            if rec >= goal:
+                run(v, qh16, qh32)
+                t0 = time.perf_counter()
+                top, extra = run(v, qh16, qh32)
+                dt = time.perf_counter() - t0
+                chosen = dict({"value": v, "queries_per_s": nq_t / dt, "recall_at_10": recall_at(top, truth_h), "queries": nq_t}, **extra)
+                break
+        return {"tuning_sweep": sweep, "held_out": chosen}
+
+    grid_L = (12, 16, 24, 32, 48, 64, 100, 150, 200, 300, 400, 600, 800)
+    # (1) exactly scored neighbours, entry = the sampled row with the largest dot product
+    n_entry = max(4096, n // 1500)
+    e_idx = np.sort(np.random.default_rng(5).choice(n, n_entry, replace=False)).astype(np.uint32)
+    mse.set_entries(g, vecs, e_idx)
+
+    def run_exact(L, q16, q32):
+        top, _, st = mse.disk_query_topk(s, None, None, g, q16, K, None, None, None, True, 4, L)
+        return top, {"node_fetches_per_query": float(st["cmps"].mean())}
+    out["exact_scored"] = dict(pick(run_exact, grid_L), entry=f"{n_entry} sampled rows, exact top-1 (timed)", beamwidth=4)
+    L_exact = (out["exact_scored"]["held_out"] or {}).get("value")
+    # (2) the same with the reference's entry rule: closest shard centroid -> that shard's medioid
+    cen, med_ids = shard_centroid_entries(rows, n)
+    mse.set_entry_centroids(g, cen, med_ids)
+
+    def run_cen(L, q16, q32):
+        top, _, st = mse.disk_query_topk(s, None, None, g, q32, K, None, None, None, True, 4, L)
+        return top, {"node_fetches_per_query": float(st["cmps"].mean())}
+    out["exact_scored_reference_entry_rule"] = dict(pick(run_cen, grid_L), entry=f"{len(med_ids)} shard centroids (k-means of a row sample) -> the shard's medioid; "
+                                                    "scale_dot_result_f64(dot(centroid, query)), last maximum (src/query_disk_index.rs:447-450)", beamwidth=4)
+    # (3) the reference's default: neighbours scored by ADC (64 x 8-bit OPQ codes, 64 KiB table per query in LDS), fetched nodes exactly
+    rng = np.random.default_rng(4)
+    sel = torch.from_numpy(np.sort(rng.choice(n, min(n, 20000), replace=False))).cuda()
+    cents, T = train_codec(rows[sel].float().cpu().numpy())
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    t0 = time.perf_counter()
+    codes = mse.Codes.quantize_base(pq, vecs)
+    t_quant = time.perf_counter() - t0
+    mse.set_entries(g, vecs, e_idx)
+
+    def run_adc(L, q16, q32):
+        top, _, st = mse.disk_query_topk(s, pq, codes, g, q32, K, None, None, None, False, 4, L)
+        return top, {"node_fetches_per_query": float(st["cmps"].mean()), "adc_scores_per_query": float(st["pq_cmps"].mean())}
+    try:
+        out["adc_scored"] = dict(pick(run_adc, grid_L), entry=f"{n_entry} sampled rows", beamwidth=4,
+                                 note="query_disk_index's default (disable_pq = false, :195-207): neighbours enter the list by their ADC score, "
+                                      "fetched nodes are scored exactly; f32 queries in, tables made on the device")
+    except Exception as e:  # noqa: BLE001
+        out["adc_scored"] = {"error": repr(e)}
+    # (4) configs[4] on the same rows: flat ADC scan of all codes, top-r, exact fp16 re-rank, top-10; and the ADC-only recall
+    bcodes = codes if not n_qtrain else mse.Codes.quantize_base(pq, base_only)
+
+    def run_pq(r, q16, q32):
+        tops = [pq.scan_topk_batch(bcodes, q32[i:i + 64], r, K, sb)[1] for i in range(0, q32.shape[0], 64)]
+        return np.concatenate(tops), {"queries_per_call": 64}
+    try:
+        out["pq_rerank"] = pick(run_pq, (50, 100, 200, 400, 800, 1600))
+        adc_only = np.concatenate([pq.scan_topk_batch(bcodes, qt32[i:i + 64], K, K, None)[1] for i in range(0, 1024, 64)])
+        out["pq_only_recall_at_10"] = recall_at(adc_only, truth_t[:1024])
+        out["codes"] = {"made_on_device_seconds": t_quant, "vectors_per_s": n_all / t_quant}
+    except Exception as e:  # noqa: BLE001
+        out["pq_rerank"] = {"error": repr(e)}
+    # (5) the request path in the reference's call shape, at the exact-scored operating point
+    if callers and L_exact:
+        try:
+            one_call = out["exact_scored"]["held_out"]["queries_per_s"]
+            call_q = (gen(40960, 6) if kind == "easy" else hs.rows(40960, 6, queries="ood", gap=OOD_GAP, extra_noise=OOD_EXTRA_NOISE) if kind == "ood"
+                      else hs.rows(40960, 6))
+            _, truth_c = sb.bruteforce_topk(call_q.cpu().numpy().view(np.uint16), K)
+            out["graph_callers"] = graph_callers(root, vecs, g, call_q.float().cpu().numpy(), truth_c, L_exact, K, 4, (64, 512, 4096), one_call)
+        except Exception as e:  # noqa: BLE001
+            out["graph_callers"] = {"error": repr(e)}
+    out["seconds"] = time.perf_counter() - t_all
+    g.close()
+    return out

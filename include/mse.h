@@ -78,8 +78,11 @@ void mse_searcher_free(mse_searcher* s);
 int mse_searcher_set_stream(mse_searcher* s, void* hip_stream);
 void* mse_searcher_stream(const mse_searcher* s);
 
-#define MSE_MODE_AUTO 0   /* host-pointer searches: coalesced across threads (mse_dispatcher below); device-pointer searches:
-                             exact scan for <= 8 queries, batched MFMA scan above that */
+#define MSE_MODE_AUTO 0   /* host-pointer searches of at most one pass (mse_queries_per_pass_max): coalesced across threads on a
+                             worker the base owns (mse_dispatcher below; the caller's stream, scan timing and last_stats are not
+                             involved -- mse_dispatcher_searcher has the worker's).  Larger host-pointer batches, device-pointer
+                             searches, and every search if that worker could not be made: on the caller's searcher, exact scan
+                             for <= 8 queries, batched MFMA scan above that */
 #define MSE_MODE_EXACT 1  /* every row scored in the reference order on the vector ALU */
 #define MSE_MODE_MFMA 2   /* f16 MFMA scan for candidates + exact re-score + certificate */
 
@@ -194,6 +197,29 @@ int mse_shard_group_search(mse_shard_group* g, const uint16_t* queries, size_t n
  * up (shards sharing a device, no librccl, ncclCommInitAll failing): callers degrade, they do not abort. */
 #define MSE_EXCHANGE_PEER 0
 #define MSE_EXCHANGE_RCCL 1
+typedef struct mse_pq mse_pq;         /* (declared in full further down) */
+typedef struct mse_codes mse_codes;
+typedef struct mse_graph mse_graph;
+/* ---- the approximate-search paths over the same shards (rows AND their PQ codes / descriptors / graph) ----
+ * A shard's codec, codes (+ descriptor bytes) and graph are ordinary handles made by the caller on the shard's device
+ * (mse_set_device(mse_shard_group_device(g, shard)) first) over the shard's rows (mse_shard_group_searcher(g, shard)->base), speaking
+ * LOCAL ids; the group adds the shard's first row.  Handles stay the caller's and must outlive their attachment (NULLs detach).
+ *   mse_shard_group_pq_scan_topk   mse_pq_scan_topk_batch (ADC top-r, exact fp16 re-score, top-k) over all shards with the answer of the
+ *                                  unsharded call bit for bit: (A) every shard's ADC top-r -> exchange -> the index's top-r;
+ *                                  (B) every shard re-scores ITS members of it exactly -> exchange -> top-k.  scales: [n_desc] or NULL.
+ *   mse_shard_group_query_topk     one graph per shard over its rows (the reference's shards: src/generate_index_shard.rs): every shard
+ *                                  answers the batch from its graph (mse_disk_query_topk: its entry table, greedy_search, the k best
+ *                                  visited records), ONE exchange, merge by (score desc, id asc) = the merge of the per-shard searches.
+ *                                  queries f16 [nq][d] host rows; luts [nq][64*256] (ADC) or NULL with disable_pq; scales [nq][n_desc] or NULL.
+ * Both use the group's exchange (peer stores or ONE ncclAllGather of the packed blocks per exchange). */
+const mse_base* mse_shard_group_base(const mse_shard_group* g, size_t shard);   /* the shard's rows (owned by the group) */
+uint64_t mse_shard_group_first_row(const mse_shard_group* g, size_t shard);
+int mse_shard_group_attach_pq(mse_shard_group* g, size_t shard, mse_pq* pq, const mse_codes* codes);
+int mse_shard_group_attach_graph(mse_shard_group* g, size_t shard, const mse_graph* graph);
+int mse_shard_group_pq_scan_topk(mse_shard_group* g, const float* queries_f32, const float* scales, size_t nq, size_t r, size_t k,
+                                 int64_t* scores, uint32_t* ids);
+int mse_shard_group_query_topk(mse_shard_group* g, const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
+                               size_t beamwidth, size_t search_list, size_t k, int64_t* scores, uint32_t* ids);
 int mse_shard_group_set_exchange(mse_shard_group* g, int kind);
 int mse_shard_group_exchange(const mse_shard_group* g);
 int mse_shard_group_rccl_ranks(const mse_shard_group* g);                   /* ranks as ncclCommCount reports them; 0 = RCCL not up */
@@ -219,6 +245,17 @@ int mse_comm_search_dev(mse_comm* c, mse_searcher* s, const void* queries_dev, s
 /* breakdown of this rank's last mse_comm_search_dev in ms: [0] local search, [1] all-gather (incl. waiting for the slowest rank),
  * [2] merge, [3] their sum; waits for that search to finish */
 int mse_comm_last_timing(mse_comm* c, double out_ms[4]);
+/* The exchange alone -- this rank's packed block of (score, GLOBAL id) records ([nq*k_in] i64, then [nq*k_in] u32; on its device,
+ * complete on the searcher's stream) -> ONE ncclAllGather -> the k best per query of all ranks' records, identical on every rank -- and
+ * the two approximate-search paths composed over it, one process per GPU (the protocols of mse_shard_group_pq_scan_topk /
+ * _query_topk; first_row = global id of this rank's local row 0; host inputs are the same on every rank; outputs [nq][k] on this
+ * rank's device, complete on return). */
+int mse_comm_exchange_dev(mse_comm* c, mse_searcher* s, const void* block_dev, size_t nq, size_t k_in, size_t k, void* scores_dev, void* ids_dev);
+int mse_comm_pq_scan_topk(mse_comm* c, mse_pq* pq, const mse_codes* codes, mse_searcher* s, const float* queries_f32, const float* scales,
+                          size_t nq, size_t r, size_t k, uint64_t first_row, void* scores_dev, void* ids_dev);
+int mse_comm_query_topk(mse_comm* c, mse_searcher* s, mse_pq* pq, const mse_codes* codes, const mse_graph* g, const uint16_t* queries,
+                        const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
+                        uint64_t first_row, void* scores_dev, void* ids_dev);
 
 /* ---- flat in-memory index: FAISS IndexScalarQuantizer(QT_fp16, INNER_PRODUCT) as used by
  * src/main.rs:822 (new), :858,:892 (add), :900 (search), :1015,:1053 (ntotal) -------------- */
@@ -268,6 +305,10 @@ int mse_pq_scan_topk(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, co
  * vectors are then found inside the r best groups (exact, ties by lower id). */
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids);
+/* A shard's form of the batch call: results as a packed block on the device ([nq*k] i64 scores, [nq*k] u32 ids + id_offset; empty slots
+ * INT64_MIN / MSE_ID_NONE), complete on return. */
+int mse_pq_scan_topk_block(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq, const float* scales,
+                           size_t r, size_t k, uint64_t id_offset, void* block_dev);
 /* Batches of >= 4 queries go through the codes four (12-bit tables) or eight (8-bit tables, batches of >= 8) queries per pass: an
  * integer nomination scan on the matrix cores whose answer is certified against the reference-order re-score of the nominated
  * vectors (csrc/pq.hip); a query whose certificate does not hold is repeated through the exact scan, so results are identical
@@ -281,6 +322,9 @@ int mse_debug_pq_group_max(mse_pq* pq, const mse_codes* c, const float* lut0, co
 /* HIP-event timing of the four-queries-per-pass scan kernel inside mse_pq_scan_topk_batch (the dominant kernel, for the
  * roofline report): returns the totals accumulated so far, then sets the mode: 0 off, 1 on, 2 on and reset. */
 int mse_pq_scan_timing(mse_pq* pq, int enable, double* total_ms, uint64_t* launches);
+/* the sustained figure beside it: over the batch calls with at least four scans made while timing was on, *span_ms = time from the
+ * first scan's start to the last scan's end, *scans = scans in those spans (back-to-back passes on two streams); reset with timing */
+int mse_pq_scan_sustained(mse_pq* pq, double* span_ms, uint64_t* scans);
 /* test hook: the integer nomination scan alone, per_pass = 4 (12-bit tables) or 8 (8-bit tables) queries per pass over the codes.
  * luts [per_pass][64*256] (n_valid of them used), scales NULL or [4]; out [per_pass][ceil(n/64)] u32 group maxima of the integer
  * sums, params_out [per_pass][4] = delta, c, eps, ok of each query's table. */
@@ -357,8 +401,8 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *                          sum carried in f64 in index order (as mse_select_shard), the LAST maximum on ties (position_max_by_key).
  *                          Replaces a table set by mse_graph_set_entries and vice versa.  Either setter waits for request-path calls
  *                          in flight and keeps new ones out while it runs.
- *   mse_disk_query_topk_f32  the handler as the reference runs it: f32 queries in; the entry step sees the f32 query, the f16 copy
- *                          (RNE, :477) scores the fetched nodes, preprocess_query (:475) makes the distance tables on the device.
+ *   mse_disk_query_topk_f32  the handler as the reference runs it: f32 queries in (HOST memory); the entry step sees the f32 query, the
+ *                          f16 copy (RNE, :477) scores the fetched nodes, preprocess_query (:475) makes the distance tables on the device.
  * THE REFERENCE'S CALL SHAPE (one request = one query on its own task, :436-540,711-736; perf_test.py: 1000 one-query requests at
  * concurrency 100): calls of mse_disk_query_topk(_f32) with nq <= 16 whose queries are host memory meet in the graph's coalescer.
  * Calls that can share a submission (same vectors, codec, codes, graph, disable_pq, beamwidth, search_list, kinds of inputs; k may
@@ -367,7 +411,8 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  * searcher handle for these calls (4096 request threads do not need 4096 streams).  mse_graph_set_coalescer (before the first such
  * call, or with none in flight): queries per shared submission (0 = 1024), longest wait of the oldest request in microseconds
  * (0 = 200; a lone caller never waits), worker threads (0 = 2: one submission's copies overlap the other's kernels).
- * mse_graph_coalescer_stats: {queries, requests, submissions, most queries in one submission, deadline fires, 0}.
+ * mse_graph_coalescer_stats: {queries, requests, submissions, most queries in one submission, submissions started by the wait
+ * budget, microseconds the workers spent executing submissions}.
  * DEVICE-RESIDENT QUERIES: the copy of `queries` runs on the searcher's stream.  If another stream produced them (a tower's), call
  * mse_searcher_wait_stream(s, that_stream) first -- or synchronise that stream -- else the search may read them half written. */
 int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries);
@@ -378,6 +423,11 @@ int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const m
 int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const float* queries_f32,
                             const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids,
                             int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
+/* A shard's form of the call (multi-GPU, below): the [nq][k] results stay on the device as a packed block -- [nq*k] i64 scores, then
+ * [nq*k] u32 ids + id_offset (mse_topk_block_bytes(nq, k) bytes at block_dev) -- ready for the exchange; never coalesced. */
+int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
+                              const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
+                              uint64_t id_offset, void* block_dev, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
 int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t max_wait_us, int workers);
 int mse_graph_coalescer_stats(const mse_graph* g, uint64_t out[6]);
 /* everything `producer_stream` (a hipStream_t) holds at the time of the call completes before anything this searcher's stream is

@@ -375,6 +375,14 @@ mse_base* mse_base_wrap_device(const void* data_dev, size_t n_rows, size_t d) {
     mse_base* b = base_alloc(n_rows, d, false);
     if (!b) return nullptr;
     b->dev = reinterpret_cast<const uint16_t*>(data_dev);
+    // the device that holds the rows, not the one that happens to be current on the calling thread: worker threads made for this
+    // base (coalescer, shard group) select b->device
+    hipPointerAttribute_t at{};
+    if (data_dev && hipPointerGetAttributes(&at, data_dev) == hipSuccess) {
+        if (at.type == hipMemoryTypeDevice) b->device = at.device;
+    } else {
+        (void)hipGetLastError();
+    }
     return b;
 }
 mse_base* mse_base_generate(uint32_t seed, uint64_t first_row, size_t n_rows, size_t d) {
@@ -549,19 +557,23 @@ int mse_bruteforce_topk_f16(mse_searcher* s, const uint16_t* queries, size_t nq,
                             uint32_t* ids) {
     if (!s) return fail("null searcher");
     if (nq == 0 || k == 0) return 0;
-    if (mode == MSE_MODE_AUTO && s->base) {
+    if (mode == MSE_MODE_AUTO && s->base && nq <= (size_t)mfma_query_tile((int)s->base->d)) {
         // The reference's call shape is a thread per core, each with its own Scratch and ONE query per request
         // (src/query_disk_index.rs:711-736): such callers meet in the base's coalescer and share a pass over the rows.
-        // Answers are those of every other mode; a lone caller fires its pass at once (dispatch.h).
+        // Answers are those of every other mode; a lone caller fires its pass at once (dispatch.h).  Only requests that fit one pass
+        // go there: a larger batch fills passes on its own and stays on the caller's searcher (its stream, its timing, its
+        // last_stats).  If the coalescer cannot be made (no memory for its worker's scratch) the call is answered directly as well.
         const mse_base* b = s->base;
         mse_dispatcher* disp = nullptr;
         {
             std::lock_guard<std::mutex> g(b->disp_mu);
-            if (!b->disp) b->disp = mse_dispatcher_new(b, 0, 0);
+            if (!b->disp && !b->disp_failed) {
+                b->disp = mse_dispatcher_new(b, 0, 0);
+                if (!b->disp) b->disp_failed = true;
+            }
             disp = b->disp;
         }
-        if (!disp) return -1;
-        return mse_dispatcher_topk_f16(disp, queries, nq, k, scores, ids);
+        if (disp) return mse_dispatcher_topk_f16(disp, queries, nq, k, scores, ids);
     }
     const size_t d = s->base->d;
     DevBuf qd;

@@ -701,15 +701,38 @@ static int scan_topk4_async(mse_pq* pq, const mse_codes* c, mse_searcher* s, con
     return 0;
 }
 
+// (a sharded scan hands its results over as a packed block on the device: launch_block_finish, topk.hip)
+static int pq_scan_topk_batch_impl(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
+                                   const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids, uint64_t id_offset, void* block_dev);
+
 int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
                            const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids) {
+    if (!scores || !ids) return fail("null output");
+    return pq_scan_topk_batch_impl(pq, c, s_or_null, queries_f32, nq, scales, r, k, scores, ids, 0, nullptr);
+}
+
+int mse_pq_scan_topk_block(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq, const float* scales,
+                           size_t r, size_t k, uint64_t id_offset, void* block_dev) {
+    if (!block_dev) return fail("null output block");
+    return pq_scan_topk_batch_impl(pq, c, s_or_null, queries_f32, nq, scales, r, k, nullptr, nullptr, id_offset, block_dev);
+}
+
+static int pq_scan_topk_batch_impl(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_null, const float* queries_f32, size_t nq,
+                                   const float* scales, size_t r, size_t k, int64_t* scores, uint32_t* ids, uint64_t id_offset, void* block_dev) {
     if (!pq || !c) return fail("null quantiser or codes");
     if (c->code_size != pq->n_chunks) return fail("code size does not match the quantiser");
     if (k == 0 || nq == 0) return 0;
     if (r < k) r = k;
     if (r > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
-    for (size_t i = 0; i < nq * k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
-    if (c->n == 0) return 0;
+    if (!block_dev)
+        for (size_t i = 0; i < nq * k; i++) { scores[i] = INT64_MIN; ids[i] = MSE_ID_NONE; }
+    if (c->n == 0) {
+        if (block_dev) {   // an empty shard still hands over a block: all slots empty
+            if (launch_block_finish(nullptr, nullptr, nq * k, 0, reinterpret_cast<int64_t*>(block_dev), reinterpret_cast<uint32_t*>(static_cast<char*>(block_dev) + nq * k * 8), nullptr)) return -1;
+            MSE_HIP_TRY(hipStreamSynchronize(nullptr));
+        }
+        return 0;
+    }
     std::lock_guard<std::mutex> g(pq->mu);
     pq->last_uncertified = 0;
     mse_searcher* s = s_or_null;
@@ -830,8 +853,25 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
                 }
             if (!ok) { if (std::string(mse_last_error()).empty()) fail("scan failed"); break; }
         }
-        if (hipMemcpyAsync(pq->pin, s->out_scores.p, nq * k * 12, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
+        if (block_dev) {
+            if (launch_block_finish(out_scores_dev, out_ids_dev, nq * k, id_offset, reinterpret_cast<int64_t*>(block_dev),
+                                    reinterpret_cast<uint32_t*>(static_cast<char*>(block_dev) + nq * k * 8), st) || hipStreamSynchronize(st) != hipSuccess) {
+                fail("block hand-over failed"); break;
+            }
+        } else if (hipMemcpyAsync(pq->pin, s->out_scores.p, nq * k * 12, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                   hipStreamSynchronize(st) != hipSuccess) { fail("D2H failed"); break; }
+        {   // sustained rate: from the first scan's start to the last scan's end of this call, over its scans (they run back to back,
+            // alternating between the streams: what a launch costs when the next one is already waiting behind it)
+            size_t scans = 0;
+            float span = 0.0f;
+            for (mse_searcher* ln : lanes)
+                if (ln && ln->ev_used >= 2 && lanes[0]->ev_used >= 2) {
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, lanes[0]->ev_pool[0], ln->ev_pool[ln->ev_used - 1]) == hipSuccess) span = std::max(span, ms);
+                    scans += ln->ev_used / 2;
+                }
+            if (scans >= 4 && span > 0.0f) { pq->span_ms_total += span; pq->span_scans += scans; }
+        }
         for (mse_searcher* ln : lanes)      // both streams are idle here: the scan launches' event pairs can be read
             if (ln) {
                 for (size_t e = 0; e + 1 < ln->ev_used; e += 2) {
@@ -840,10 +880,12 @@ int mse_pq_scan_topk_batch(mse_pq* pq, const mse_codes* c, mse_searcher* s_or_nu
                 }
                 ln->ev_used = 0;
             }
-        memcpy(scores, pq->pin, nq * k * 8);
-        memcpy(ids, static_cast<char*>(pq->pin) + nq * k * 8, nq * k * 4);
-        for (size_t i = 0; i < nq * k; i++)
-            if (ids[i] == MSE_ID_NONE) scores[i] = INT64_MIN;
+        if (!block_dev) {
+            memcpy(scores, pq->pin, nq * k * 8);
+            memcpy(ids, static_cast<char*>(pq->pin) + nq * k * 8, nq * k * 4);
+            for (size_t i = 0; i < nq * k; i++)
+                if (ids[i] == MSE_ID_NONE) scores[i] = INT64_MIN;
+        }
         rc = 0;
     } while (0);
     return rc;
@@ -885,8 +927,19 @@ int mse_pq_scan_timing(mse_pq* pq, int enable, double* total_ms, uint64_t* launc
     std::lock_guard<std::mutex> g(pq->mu);
     if (total_ms) *total_ms = pq->scan_ms_total;
     if (launches) *launches = pq->scan_launches;
-    if (enable == 2) { pq->scan_ms_total = 0.0; pq->scan_launches = 0; }
+    if (enable == 2) { pq->scan_ms_total = 0.0; pq->scan_launches = 0; pq->span_ms_total = 0.0; pq->span_scans = 0; }
     pq->timing = enable != 0;
+    return 0;
+}
+
+// The SUSTAINED figure beside it: over the batch calls made while timing was on that ran at least four scans, the time from the first
+// scan's start to the last scan's end (HIP events) and the number of scans in those spans.  span / scans = what a pass costs when passes
+// run back to back (two streams, a group's tail beside the next group's scan); reset by mse_pq_scan_timing(pq, 2, ..).
+int mse_pq_scan_sustained(mse_pq* pq, double* span_ms, uint64_t* scans) {
+    if (!pq) return fail("null quantiser");
+    std::lock_guard<std::mutex> g(pq->mu);
+    if (span_ms) *span_ms = pq->span_ms_total;
+    if (scans) *scans = pq->span_scans;
     return 0;
 }
 

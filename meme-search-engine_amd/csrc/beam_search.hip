@@ -439,6 +439,103 @@ __global__ void entry_starts_kernel(const uint32_t* __restrict__ best_row, const
     starts[q] = entry_ids[r < n_entries ? r : 0];
 }
 
+// Entry step of a row table for a SMALL batch (round 5): exact top-1 of every query over the entry rows in two launches.  The
+// brute-force searcher's matrix-core path (scan, tournament, re-score, certificate: a dozen launches and a host synchronisation for
+// the margins) is the right tool for thousands of queries; for the few dozen queries of a coalesced submission its fixed cost was
+// most of the call.  A workgroup takes 8 queries (their f16 copies in LDS) and a range of rows; a lane quad owns a row at a time,
+// loads it ONCE and runs the reference's fast_dot chain (exact_dot.h: accumulator `part`, t ascending, the fixed reduction tree)
+// against all 8 queries; per-quad best (score, row) -> per-workgroup best -> partial[chunk][query]; entry_reduce_kernel picks the
+// best chunk.  Same answer as the searcher's exact top-1: i64 scores in the reference's order, ties by the lower row.
+constexpr int ET_Q = 8, ET_THREADS = 256;
+__global__ __launch_bounds__(ET_THREADS) void entry_top1_rows_kernel(const uint16_t* __restrict__ rows, int n_rows, int d, const uint16_t* __restrict__ queries,
+                                                                     int nq, int rows_per_wg, long long* __restrict__ part_sc, uint32_t* __restrict__ part_row) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* s_q = reinterpret_cast<uint16_t*>(smem);            // [ET_Q][d]
+    __shared__ long long s_best[ET_THREADS / 4][ET_Q];
+    __shared__ uint32_t s_brow[ET_THREADS / 4][ET_Q];
+    const int tid = threadIdx.x, part = tid & 3, quad = tid >> 2;
+    const int q0 = blockIdx.y * ET_Q, nqt = min(ET_Q, nq - q0);
+    const int d8 = d / 8;
+    for (int e = tid; e < ET_Q * d8; e += ET_THREADS) {
+        const int j = e / d8, c = e - j * d8;
+        reinterpret_cast<uint4*>(s_q)[e] = j < nqt ? reinterpret_cast<const uint4*>(queries + (size_t)(q0 + j) * d)[c] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    long long best[ET_Q];
+    uint32_t brow[ET_Q];
+#pragma unroll
+    for (int j = 0; j < ET_Q; j++) { best[j] = (long long)INT64_MIN; brow[j] = 0xffffffffu; }
+    const int r_begin = blockIdx.x * rows_per_wg, r_end = min(n_rows, r_begin + rows_per_wg);
+    const int T = d / 32;
+    for (int r0 = r_begin; r0 < r_end; r0 += ET_THREADS / 4) {
+        const int r = r0 + quad;
+        const int rr = r < r_end ? r : r_end - 1;                  // clamped: all four lanes of every quad stay in the exchanges
+        const uint4* xp = reinterpret_cast<const uint4*>(rows + (size_t)rr * d) + part;
+        float acc[ET_Q][8];
+#pragma unroll
+        for (int j = 0; j < ET_Q; j++)
+#pragma unroll
+            for (int l = 0; l < 8; l++) acc[j][l] = 0.0f;
+        uint4 x = xp[0];
+        for (int t = 0; t < T; t++) {
+            const uint4 xn = xp[(t + 1 < T ? t + 1 : t) * 4];
+#pragma unroll
+            for (int j = 0; j < ET_Q; j++) quad_fma8(acc[j], x, reinterpret_cast<const uint4*>(s_q + (size_t)j * d)[t * 4 + part]);
+            x = xn;
+        }
+#pragma unroll
+        for (int j = 0; j < ET_Q; j++) {
+            float v[8];
+#pragma unroll
+            for (int l = 0; l < 8; l++) v[l] = add_rn(acc[j][l], __shfl_xor(acc[j][l], 1));
+            const float p0 = add_rn(v[0], v[1]), p1 = add_rn(v[2], v[3]);
+            const float p2 = add_rn(v[4], v[5]), p3 = add_rn(v[6], v[7]);
+            const float first = add_rn(p0, p2), second = add_rn(p1, p3);
+            const float of = __shfl_xor(first, 2), os = __shfl_xor(second, 2);
+            const bool low = (part & 2) == 0;
+            const float s0 = low ? first : of, s1 = low ? second : os, s2 = low ? of : first, s3 = low ? os : second;
+            const long long sc = scale_dot_result(add_rn(add_rn(add_rn(s0, s1), s2), s3));
+            if (r < r_end && (sc > best[j] || (sc == best[j] && (uint32_t)r < brow[j]))) { best[j] = sc; brow[j] = (uint32_t)r; }
+        }
+    }
+    if (part == 0) {
+#pragma unroll
+        for (int j = 0; j < ET_Q; j++) { s_best[quad][j] = best[j]; s_brow[quad][j] = brow[j]; }
+    }
+    __syncthreads();
+    if (tid < ET_Q) {
+        long long b = (long long)INT64_MIN;
+        uint32_t br = 0xffffffffu;
+        for (int qd = 0; qd < ET_THREADS / 4; qd++) {
+            const long long sc = s_best[qd][tid];
+            const uint32_t rw = s_brow[qd][tid];
+            if (rw != 0xffffffffu && (br == 0xffffffffu || sc > b || (sc == b && rw < br))) { b = sc; br = rw; }
+        }
+        if (tid < nqt) {
+            part_sc[(size_t)blockIdx.x * nq + q0 + tid] = b;
+            part_row[(size_t)blockIdx.x * nq + q0 + tid] = br;
+        }
+    }
+}
+// one wave per query: lanes over the chunks, then the best of the wave
+__global__ __launch_bounds__(64) void entry_reduce_kernel(const long long* __restrict__ part_sc, const uint32_t* __restrict__ part_row, int n_chunks, int nq,
+                                                          const uint32_t* __restrict__ entry_ids, uint32_t* __restrict__ starts) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    long long b = (long long)INT64_MIN;
+    uint32_t br = 0xffffffffu;
+    for (int c = lane; c < n_chunks; c += 64) {
+        const long long sc = part_sc[(size_t)c * nq + q];
+        const uint32_t rw = part_row[(size_t)c * nq + q];
+        if (rw != 0xffffffffu && (br == 0xffffffffu || sc > b || (sc == b && rw < br))) { b = sc; br = rw; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long sc = __shfl_xor(b, o);
+        const uint32_t rw = __shfl_xor(br, o);
+        if (rw != 0xffffffffu && (br == 0xffffffffu || sc > b || (sc == b && rw < br))) { b = sc; br = rw; }
+    }
+    if (lane == 0) starts[q] = entry_ids[br == 0xffffffffu ? 0 : br];
+}
+
 // The reference's own entry rule (src/query_disk_index.rs:254-256,447-450): the shard whose centroid has the largest
 // scale_dot_result_f64(dot(centroid, query)) -- f32 operands, the sum carried in f64 in index order (the oracle's stated order for
 // simsimd's f32 dot) -- `position_max_by_key` keeping the LAST maximum; the search starts at that shard's medioid.  One workgroup
@@ -459,7 +556,14 @@ __global__ __launch_bounds__(256) void entry_by_centroid_kernel(const float* __r
     int bi = -1;
     for (int e = tid; e < n_entries; e += 256) {
         double acc = 0.0;
-        for (int k = 0; k < d; k++) acc += (double)keys_t[(size_t)k * n_entries + e] * (double)s_q[k];
+        // the sum stays sequential in k (the stated order); 16 loads are in flight ahead of their 16 dependent adds (d % 32 == 0)
+        for (int k0 = 0; k0 < d; k0 += 16) {
+            float c[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) c[u] = keys_t[(size_t)(k0 + u) * n_entries + e];
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc += (double)c[u] * (double)s_q[k0 + u];
+        }
         const long long key = scale_dot_result_f64(acc);
         if (bi < 0 || key >= best) { best = key; bi = e; }   // e ascends within a lane: >= keeps the last maximum
     }
@@ -476,11 +580,6 @@ __global__ __launch_bounds__(256) void entry_by_centroid_kernel(const float* __r
     if (tid == 0) starts[q] = entry_ids[s_idx[0] < 0 ? 0 : s_idx[0]];
 }
 
-// one query's outputs of the fused request path (any of the counter pointers may be null)
-struct QueryDst {
-    uint32_t* ids; int64_t* scores; uint32_t *n_visited, *cmps, *pq_cmps; size_t k;
-};
-
 // what the fused request path (mse_disk_query_topk) adds to a batched search: where the start nodes come from and what travels back
 struct FusedQuery {
     const mse_graph* entries = nullptr;   // start node by the graph's entry table (NULL: `starts` from the host)
@@ -492,6 +591,11 @@ struct FusedQuery {
     uint32_t* ids = nullptr;
     int64_t* scores = nullptr;
     uint32_t *n_visited = nullptr, *cmps = nullptr, *pq_cmps = nullptr;
+    // a shard's hand-over (mse_disk_query_topk_block): the [nq][k] results stay on the device (dev_sc / dev_ids: the two halves of a packed
+    // block) with id_offset added to the ids; only the counters travel to the host (ids / scores / dst are not used then)
+    int64_t* dev_sc = nullptr;
+    uint32_t* dev_ids = nullptr;
+    uint64_t id_offset = 0;
 };
 
 // pinned host staging of a searcher (the fused path's ONE download per call; the coalescer's gathered inputs)
@@ -526,6 +630,7 @@ void mse_graph_free(mse_graph* g) {
     if (!g) return;
     delete g->co;   // joins its workers; no search may be in flight
     g->co = nullptr;
+    g->co_fast.store(nullptr);
     for (mse_graph::WorkerCtx& w : g->co_ctx) {
         if (w.s) mse_searcher_free(w.s);
         if (w.pin) (void)hipHostFree(w.pin);
@@ -574,6 +679,7 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
                 FusedQuery fp;
                 if (fz) {
                     fp = *fz;
+                    if (fz->dev_sc) { fp.dev_sc = fz->dev_sc + q0 * fz->k; fp.dev_ids = fz->dev_ids + q0 * fz->k; }
                     if (fz->dst) fp.dst = fz->dst + q0;
                     else {
                         fp.ids = fz->ids + q0 * fz->k; fp.scores = fz->scores + q0 * fz->k;
@@ -603,7 +709,7 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     if (c->n_desc > BS_DESC_MAX) return fail("disk_search_batch: at most 8 descriptors");
     if (b->d % 32 || b->d > 4096) return fail("disk_search_batch: vector width must be a multiple of 32");
     if (!fz && visited_cap && (!visited_ids || !visited_scores)) return fail("disk_search_batch: null visited arrays");
-    if (fz && (fz->k == 0 || fz->k > visited_cap || fz->k > (size_t)TOPK_KMAX - 64 || (!fz->dst && (!fz->ids || !fz->scores))))
+    if (fz && (fz->k == 0 || fz->k > visited_cap || fz->k > (size_t)TOPK_KMAX - 64 || (!fz->dst && !fz->dev_sc && (!fz->ids || !fz->scores))))
         return fail("disk_query_topk: bad k / outputs");
     if (fz && fz->entries) {
         const mse_graph* eg = fz->entries;
@@ -651,6 +757,23 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
             // the reference's rule itself: centroids as keys, f32 query (an f16 query widened exactly), f64 sums, last maximum
             hipLaunchKernelGGL(entry_by_centroid_kernel, dim3((unsigned)nq), dim3(256), d * 4, st, eg->entry_keys_t, (int)eg->n_entries, (int)d,
                                queries_f32 ? qf.as<float>() : nullptr, dq.as<uint16_t>(), eg->entry_ids, dst.as<uint32_t>());
+            MSE_HIP_TRY(hipGetLastError());
+        } else if (nq * eg->n_entries <= ((size_t)1 << 22) && eg->n_entries <= ((size_t)1 << 20)) {
+            // a small batch: exact top-1 over the entry rows in two launches (entry_top1_rows_kernel)
+            const size_t E = eg->n_entries, n_qt = (nq + ET_Q - 1) / ET_Q;
+            size_t rows_per_wg = (E + std::max<size_t>(1, 512 / n_qt) - 1) / std::max<size_t>(1, 512 / n_qt);
+            rows_per_wg = std::max<size_t>(64, (rows_per_wg + 63) / 64 * 64);
+            const size_t n_chunks = (E + rows_per_wg - 1) / rows_per_wg;
+            DevBuf& ep = s->pool[14];
+            if (ep.ensure(n_chunks * nq * 12 + 64)) return -1;
+            long long* psc = ep.as<long long>();
+            uint32_t* prow = reinterpret_cast<uint32_t*>(ep.as<char>() + n_chunks * nq * 8);
+            MSE_DYN_LDS(entry_top1_rows_kernel, ET_Q * d * 2);
+            hipLaunchKernelGGL(entry_top1_rows_kernel, dim3((unsigned)n_chunks, (unsigned)n_qt), dim3(ET_THREADS), ET_Q * d * 2, st, eg->entry_rows, (int)E,
+                               (int)d, dq.as<uint16_t>(), (int)nq, (int)rows_per_wg, psc, prow);
+            MSE_HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(entry_reduce_kernel, dim3((unsigned)nq), dim3(64), 0, st, psc, prow, (int)n_chunks, (int)nq, eg->entry_ids,
+                               dst.as<uint32_t>());
             MSE_HIP_TRY(hipGetLastError());
         } else {
             int64_t* e_sc = fzb.as<int64_t>();
@@ -703,9 +826,14 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         sa.kind = KEY_I64; sa.list_ids = vi.as<uint32_t>(); sa.list_keys = vs.p; sa.list_stride = visited_cap; sa.n_list = visited_cap;
         sa.k = (int)fz->k; sa.out_ids = top_id; sa.out_keys = top_sc; sa.out_stride = fz->k; sa.nq = (int)nq;
         if (launch_select(sa, st)) return -1;
-        MSE_HIP_TRY(hipMemcpyAsync(s->pin, top_sc, fz_block_bytes, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipStreamSynchronize(st));
         const char* blk = static_cast<const char*>(s->pin);
+        if (fz->dev_sc) {   // results stay on the device (global ids); the counters come back alone, at their usual place in the staging
+            if (launch_block_finish(top_sc, top_id, nq * fz->k, fz->id_offset, fz->dev_sc, fz->dev_ids, st)) return -1;
+            MSE_HIP_TRY(hipMemcpyAsync(s->pin ? static_cast<char*>(s->pin) + nq * fz->k * 12 : nullptr, cnt_dev, (3 * nq + 1) * 4, hipMemcpyDeviceToHost, st));
+        } else {
+            MSE_HIP_TRY(hipMemcpyAsync(s->pin, top_sc, fz_block_bytes, hipMemcpyDeviceToHost, st));
+        }
+        MSE_HIP_TRY(hipStreamSynchronize(st));
         const int64_t* h_sc = reinterpret_cast<const int64_t*>(blk);
         const uint32_t* h_id = reinterpret_cast<const uint32_t*>(blk + nq * fz->k * 8);
         const uint32_t* h_cnt = reinterpret_cast<const uint32_t*>(blk + nq * fz->k * 12);
@@ -722,8 +850,10 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
                                  : QueryDst{fz->ids + q * fz->k, fz->scores + q * fz->k, fz->n_visited ? fz->n_visited + q : nullptr,
                                             fz->cmps ? fz->cmps + q : nullptr, fz->pq_cmps ? fz->pq_cmps + q : nullptr, fz->k};
             // a caller's k records are the first k of the largest k's: the order (score descending, id ascending) is total
-            memcpy(o.ids, h_id + q * fz->k, o.k * 4);
-            memcpy(o.scores, h_sc + q * fz->k, o.k * 8);
+            if (!fz->dev_sc) {
+                memcpy(o.ids, h_id + q * fz->k, o.k * 4);
+                memcpy(o.scores, h_sc + q * fz->k, o.k * 8);
+            }
             if (o.n_visited) *o.n_visited = h_cnt[q];
             if (o.cmps) *o.cmps = h_cnt[nq + q];
             if (o.pq_cmps) *o.pq_cmps = h_cnt[2 * nq + q];
@@ -897,7 +1027,45 @@ int query_call_on(mse_searcher* s, const QueryCall& k) {
     return fused_run(s, k.pq, k.c, k.g, k.starts, k.queries, k.queries_f32, k.luts, k.scales, k.nq, k.disable_pq, k.beamwidth, k.search_list, fz);
 }
 
-// one group of waiting request-path calls = ONE entry step + ONE search launch + ONE select, on the worker's own searcher
+// `n` waiting request-path calls that can share a submission = ONE entry step + ONE search launch + ONE select, on the worker's own
+// searcher.  Inputs are gathered straight into pinned memory -- also for a single request: a pageable source of more than a few KB
+// makes the runtime pin the caller's pages for the copy (a 16-query call from a numpy array: 4.8 ms against 0.5 ms).
+int query_run_requests(mse_graph::WorkerCtx& ctx, DispatchReq* const* reqs, size_t n) {
+    const QueryCall& lead = *static_cast<const QueryCall*>(reqs[0]->aux0);
+    const mse_graph* g = lead.g;
+    const size_t d = lead.s->base->d, n_desc = (lead.scales && lead.c) ? lead.c->n_desc : 0;
+    size_t total = 0, kmax = 0;
+    for (size_t i = 0; i < n; i++) {
+        const QueryCall& k = *static_cast<const QueryCall*>(reqs[i]->aux0);
+        total += k.nq;
+        kmax = std::max(kmax, k.k);
+    }
+    const size_t q_bytes = total * d * (lead.queries ? 2 : 4), sc_bytes = total * n_desc * 4, st_bytes = lead.starts ? total * 4 : 0;
+    const size_t lut_bytes = lead.luts ? total * 65536 : 0;
+    const size_t off_sc = (q_bytes + 63) & ~(size_t)63, off_st = (off_sc + sc_bytes + 63) & ~(size_t)63, off_lut = (off_st + st_bytes + 63) & ~(size_t)63;
+    if (ensure_pin(&ctx.pin, &ctx.pin_cap, off_lut + lut_bytes + 64)) return -1;
+    char* p = static_cast<char*>(ctx.pin);
+    ctx.dsts.resize(total);
+    size_t row = 0;
+    for (size_t i = 0; i < n; i++) {
+        const QueryCall& k = *static_cast<const QueryCall*>(reqs[i]->aux0);
+        if (k.queries) memcpy(p + row * d * 2, k.queries, k.nq * d * 2);
+        else memcpy(p + row * d * 4, k.queries_f32, k.nq * d * 4);
+        if (n_desc) memcpy(p + off_sc + row * n_desc * 4, k.scales, k.nq * n_desc * 4);
+        if (k.starts) memcpy(p + off_st + row * 4, k.starts, k.nq * 4);
+        if (k.luts) memcpy(p + off_lut + row * 65536, k.luts, k.nq * 65536);
+        for (size_t q = 0; q < k.nq; q++, row++)
+            ctx.dsts[row] = QueryDst{k.ids + q * k.k, k.scores + q * k.k, k.n_visited ? k.n_visited + q : nullptr, k.cmps ? k.cmps + q : nullptr,
+                                     k.pq_cmps ? k.pq_cmps + q : nullptr, k.k};
+    }
+    FusedQuery fz;
+    fz.k = kmax; fz.dst = ctx.dsts.data();
+    return fused_run(ctx.s, lead.pq, lead.c, g, lead.starts ? reinterpret_cast<const uint32_t*>(p + off_st) : nullptr,
+                     lead.queries ? reinterpret_cast<const uint16_t*>(p) : nullptr, lead.queries ? nullptr : reinterpret_cast<const float*>(p),
+                     lead.luts ? reinterpret_cast<const float*>(p + off_lut) : nullptr, n_desc ? reinterpret_cast<const float*>(p + off_sc) : lead.scales,
+                     total, lead.disable_pq, lead.beamwidth, lead.search_list, fz);
+}
+
 void query_run_group(std::vector<DispatchReq*>& grp) {
     const QueryCall& lead = *static_cast<const QueryCall*>(grp[0]->aux0);
     const mse_graph* g = lead.g;
@@ -905,56 +1073,27 @@ void query_run_group(std::vector<DispatchReq*>& grp) {
     (void)hipSetDevice(b->device);
     const int w = Coalescer::worker_index();
     mse_graph::WorkerCtx& ctx = g->co_ctx[(size_t)w < g->co_ctx.size() ? (size_t)w : 0];
-    auto fail_all = [&](const std::string& why) {
-        for (DispatchReq* r : grp) { r->rc = -1; r->err = why; }
-    };
     if (!ctx.s || ctx.s->base != b) {
         if (ctx.s) mse_searcher_free(ctx.s);
         ctx.s = mse_searcher_new(b);
-        if (!ctx.s) { fail_all(mse_last_error()); return; }
-    }
-    const size_t d = b->d, n_desc = (lead.scales && lead.c) ? lead.c->n_desc : 0;
-    size_t total = 0, kmax = 0;
-    for (DispatchReq* r : grp) {
-        const QueryCall& k = *static_cast<const QueryCall*>(r->aux0);
-        total += k.nq;
-        kmax = std::max(kmax, k.k);
-    }
-    int rc = 0;
-    if (grp.size() > 1) {
-        // inputs gathered straight into pinned memory (the copies up are then true DMA, not staged by the runtime)
-        const size_t q_bytes = total * d * (lead.queries ? 2 : 4), sc_bytes = total * n_desc * 4, st_bytes = lead.starts ? total * 4 : 0;
-        const size_t lut_bytes = lead.luts ? total * 65536 : 0;
-        const size_t off_sc = (q_bytes + 63) & ~(size_t)63, off_st = (off_sc + sc_bytes + 63) & ~(size_t)63, off_lut = (off_st + st_bytes + 63) & ~(size_t)63;
-        if (ensure_pin(&ctx.pin, &ctx.pin_cap, off_lut + lut_bytes + 64)) { fail_all(mse_last_error()); return; }
-        char* p = static_cast<char*>(ctx.pin);
-        std::vector<QueryDst> dsts(total);
-        size_t row = 0;
-        for (DispatchReq* r : grp) {
-            const QueryCall& k = *static_cast<const QueryCall*>(r->aux0);
-            if (k.queries) memcpy(p + row * d * 2, k.queries, k.nq * d * 2);
-            else memcpy(p + row * d * 4, k.queries_f32, k.nq * d * 4);
-            if (n_desc) memcpy(p + off_sc + row * n_desc * 4, k.scales, k.nq * n_desc * 4);
-            if (k.starts) memcpy(p + off_st + row * 4, k.starts, k.nq * 4);
-            if (k.luts) memcpy(p + off_lut + row * 65536, k.luts, k.nq * 65536);
-            for (size_t q = 0; q < k.nq; q++, row++)
-                dsts[row] = QueryDst{k.ids + q * k.k, k.scores + q * k.k, k.n_visited ? k.n_visited + q : nullptr, k.cmps ? k.cmps + q : nullptr,
-                                     k.pq_cmps ? k.pq_cmps + q : nullptr, k.k};
-        }
-        FusedQuery fz;
-        fz.k = kmax; fz.dst = dsts.data();
-        rc = fused_run(ctx.s, lead.pq, lead.c, g, lead.starts ? reinterpret_cast<const uint32_t*>(p + off_st) : nullptr,
-                       lead.queries ? reinterpret_cast<const uint16_t*>(p) : nullptr, lead.queries ? nullptr : reinterpret_cast<const float*>(p),
-                       lead.luts ? reinterpret_cast<const float*>(p + off_lut) : nullptr, n_desc ? reinterpret_cast<const float*>(p + off_sc) : lead.scales,
-                       total, lead.disable_pq, lead.beamwidth, lead.search_list, fz);
-        if (rc == 0) {
-            for (DispatchReq* r : grp) r->rc = 0;
+        if (!ctx.s) {
+            const std::string why = mse_last_error();
+            for (DispatchReq* r : grp) { r->rc = -1; r->err = why; }
             return;
         }
     }
-    // alone, or the shared pass failed: each request on its own, so that a caller only ever sees its own outcome
+    if (query_run_requests(ctx, grp.data(), grp.size()) == 0) {
+        for (DispatchReq* r : grp) r->rc = 0;
+        return;
+    }
+    if (grp.size() == 1) {
+        grp[0]->rc = -1;
+        grp[0]->err = mse_last_error();
+        return;
+    }
+    // the shared submission failed: each request on its own, so that a caller only ever sees its own outcome
     for (DispatchReq* r : grp) {
-        r->rc = query_call_on(ctx.s, *static_cast<const QueryCall*>(r->aux0));
+        r->rc = query_run_requests(ctx, &r, 1);
         if (r->rc) r->err = mse_last_error();
     }
 }
@@ -977,6 +1116,7 @@ void graph_run_batch(std::vector<DispatchReq*>& batch) {
 }
 
 Coalescer* graph_coalescer(const mse_graph* g) {
+    if (Coalescer* co = g->co_fast.load(std::memory_order_acquire)) return co;   // thousands of request threads pass here: no lock once it exists
     std::lock_guard<std::mutex> lk(g->co_mu);
     if (!g->co) {
         const int workers = g->co_workers > 0 ? g->co_workers : 2;
@@ -984,6 +1124,7 @@ Coalescer* graph_coalescer(const mse_graph* g) {
         g->co = new (std::nothrow) Coalescer(g->co_max_queries ? g->co_max_queries : 1024, g->co_max_wait_us ? g->co_max_wait_us : 200,
                                              [](std::vector<DispatchReq*>& b) { graph_run_batch(b); }, nullptr, workers);
         if (!g->co) fail("out of host memory");
+        g->co_fast.store(g->co, std::memory_order_release);
     }
     return g->co;
 }
@@ -1017,8 +1158,9 @@ int query_front(QueryCall& k) {
     if (k.nq == 0) return 0;
     if (!k.s || !k.s->base) return fail("disk_query_topk: null searcher");
     if (k.k == 0 || k.k > (size_t)TOPK_KMAX - 64) return fail("disk_query_topk: bad k / outputs");
-    if (k.nq > FUSED_COALESCE_MAX || is_device_pointer(k.queries ? static_cast<const void*>(k.queries) : static_cast<const void*>(k.queries_f32)))
-        return query_call_on(k.s, k);
+    // f16 queries may be device-resident (embeddings that never left the GPU): such a call cannot be gathered by the host and goes straight
+    // to the device.  f32 queries are host memory by contract (the handler's input, :436-477): no runtime call on the request thread.
+    if (k.nq > FUSED_COALESCE_MAX || (k.queries && is_device_pointer(k.queries))) return query_call_on(k.s, k);
     // what belongs to this caller alone is found before it queues
     if (k.beamwidth == 0 || k.beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
     if (k.search_list == 0 || k.search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
@@ -1152,6 +1294,23 @@ int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, con
     return query_front(q);
 }
 
+// A shard's form of the request path: the [nq][k] results stay on the device as a packed block ([nq*k] i64 scores, [nq*k] u32 ids +
+// id_offset; mse_topk_block_bytes) ready for the exchange; no coalescing (the shard's thread brings the whole batch).
+int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
+                              const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
+                              uint64_t id_offset, void* block_dev, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps) {
+    if (!g || !queries || !block_dev) return fail("disk_query_topk_block: null argument");
+    if (nq == 0) return 0;
+    if (!s || !s->base) return fail("disk_query_topk_block: null searcher");
+    if (k == 0 || k > (size_t)TOPK_KMAX - 64) return fail("disk_query_topk: bad k / outputs");
+    FusedQuery fz;
+    fz.k = k; fz.n_visited = n_visited; fz.cmps = cmps; fz.pq_cmps = pq_cmps;
+    fz.dev_sc = reinterpret_cast<int64_t*>(block_dev);
+    fz.dev_ids = reinterpret_cast<uint32_t*>(static_cast<char*>(block_dev) + nq * k * 8);
+    fz.id_offset = id_offset;
+    return fused_run(s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, fz);
+}
+
 int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t max_wait_us, int workers) {
     if (!g) return fail("null graph");
     if (workers < 0 || workers > 8) return fail("graph_set_coalescer: 1..8 workers (0 = default)");
@@ -1160,6 +1319,7 @@ int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t 
         std::lock_guard<std::mutex> lk(g->co_mu);
         old = g->co;
         g->co = nullptr;
+        g->co_fast.store(nullptr, std::memory_order_release);
         g->co_max_queries = max_queries_per_pass; g->co_max_wait_us = max_wait_us; g->co_workers = workers;
     }
     delete old;   // joins its workers; no call may be in flight (as for mse_graph_free)
@@ -1173,7 +1333,7 @@ int mse_graph_coalescer_stats(const mse_graph* g, uint64_t out[6]) {
         std::lock_guard<std::mutex> lk(g->co_mu);
         if (g->co) st = g->co->stats();
     }
-    out[0] = st.queries; out[1] = st.requests; out[2] = st.passes; out[3] = st.max_pass_queries; out[4] = st.deadline_fires; out[5] = st.retried_alone;
+    out[0] = st.queries; out[1] = st.requests; out[2] = st.passes; out[3] = st.max_pass_queries; out[4] = st.deadline_fires; out[5] = st.run_us;
     return 0;
 }
 

@@ -16,9 +16,10 @@
 //
 // Round 5: a handle may run SEVERAL workers (the graph's request path runs two: one pass's upload / download and host side
 // overlap the other's kernels).  One worker gathers at a time, by the same rule; the others run or sleep.  Completion is
-// signalled through a ring of (mutex, condition variable) slots that requests are assigned to in arrival order, 256 to a slot:
-// a pass wakes the callers of the slots it touched instead of everybody who is waiting (4096 callers, 1024 per pass: one
-// shared variable woke 3072 sleepers for nothing on every pass and sent all of them through one mutex).
+// signalled through a ring of futex words that requests are assigned to in arrival order, 256 to a word: a request's `done` flag
+// is an atomic of its own, a pass bumps the words of the slots it touched and wakes their sleepers with ONE futex call each --
+// no mutex on the way out (4096 callers, 1024 per pass: one shared condition variable woke 3072 sleepers for nothing on every
+// pass and sent all 4096 through one mutex; a variable per slot still queued 256 woken callers on the slot's mutex).
 #pragma once
 #include "common.h"
 #include <atomic>
@@ -26,6 +27,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -47,13 +49,15 @@ struct DispatchReq {
     std::string err;
     uint32_t flags = 0;
     // queue plumbing
-    bool done = false;
+    std::atomic<uint32_t> done{0};    // set by the worker (release) as the LAST access to this record: it lives on its caller's stack
     uint32_t slot = 0;                // completion slot (Coalescer::wake_), assigned on arrival
+    DispatchReq* next = nullptr;      // inbox link
     std::chrono::steady_clock::time_point t_arrive;
 };
 
 struct DispatchStats {
     uint64_t queries = 0, requests = 0, passes = 0, max_pass_queries = 0, deadline_fires = 0, retried_alone = 0;
+    uint64_t run_us = 0;              // time the workers spent inside run() (summed over workers)
 };
 
 class Coalescer {
@@ -71,34 +75,63 @@ class Coalescer {
     int submit(DispatchReq& r);
     DispatchStats stats();
     size_t max_queries() const { return max_queries_; }
-    size_t target() const;   // queries the next pass waits for (call with mu_ held)
     uint32_t max_wait_us() const { return max_wait_us_.load(); }
     void set_max_wait_us(uint32_t us) { max_wait_us_.store(us); }   // takes effect from the next gather
 
   private:
     void loop(int index);
+    void wake_loop(int index);         // a worker's companion: finishes large passes (the wake-ups) while the worker gathers the next
+    void complete(std::vector<DispatchReq*>& batch);
+    void drain();                      // inbox -> queue_ (the gatherer only)
+    size_t target() const;             // queries the next pass waits for
     static constexpr uint32_t WAKE_SLOTS = 64, WAKE_RUN = 256;   // 256 consecutive arrivals share a slot
-    struct WakeSlot { std::mutex mu; std::condition_variable cv; };
+    struct alignas(64) WakeSlot { std::atomic<uint32_t> gen{0}; };
     const size_t max_queries_;
     std::atomic<uint32_t> max_wait_us_;
     RunFn run_;
     std::function<void()> on_start_;
+    // ---- the callers' side: no lock.  A request is pushed onto a lock-free stack (callers only push, the gatherer takes the whole
+    // stack at once and restores arrival order), the count of queries ever pushed is bumped, and the gatherer's bell is rung only by
+    // the push that takes that count across `wake_at_` -- the first arrival after an idle spell, or the one that completes the
+    // gatherer's target.  (With a mutex here, a thousand callers released by one pass formed a convoy on it: every contended
+    // unlock a futex call and a context switch.)
+    alignas(64) std::atomic<DispatchReq*> inbox_{nullptr};
+    alignas(64) std::atomic<uint64_t> pushed_{0};     // queries ever pushed
+    alignas(64) std::atomic<uint64_t> wake_at_{1};    // ring the bell when pushed_ reaches this
+    std::atomic<uint32_t> bell_{0};                   // futex word the gatherer sleeps on
+    std::atomic<uint64_t> arrivals_{0};
+    std::atomic<uint64_t> taken_{0};                  // queries ever taken into a pass (pushed_ - taken_ = waiting now)
+    std::atomic<bool> stop_{false};
+    // Completion: a wake-up per request would be hundreds of futex calls per pass; ONE variable for all callers wakes every
+    // sleeper of every other pass too.  A ring of futex words, 256 consecutive arrivals to a word (the queue is first in, first out,
+    // so a pass touches few words): the worker sets each request's `done`, bumps the words it touched and wakes their sleepers; a
+    // sleeper that was woken for somebody else's pass finds its own flag still clear and sleeps on the new value.
+    WakeSlot wake_[WAKE_SLOTS];
+    // ---- the workers' side.  mu_ is taken by workers (and stats()) only: it hands the gatherer's token around and guards the
+    // statistics.  queue_ / queued_queries_ / drained_ belong to whoever holds the token.
     std::mutex mu_;
     std::condition_variable cv_worker_;
-    // Completion: a variable per request would be hundreds of futex wake-ups per pass; ONE variable for all callers wakes every
-    // sleeper of every other pass too.  A ring of slots, 256 consecutive arrivals to a slot (the queue is first in, first out, so a
-    // pass touches few slots): `done` is set under the slot's mutex, the slot's variable is signalled after the unlock.
-    WakeSlot wake_[WAKE_SLOTS];
-    uint64_t arrivals_ = 0;
+    bool gathering_ = false;          // one worker gathers at a time
     std::deque<DispatchReq*> queue_;
     size_t queued_queries_ = 0;
-    size_t expect_ = 1;
-    bool stop_ = false;
-    bool gathering_ = false;          // one worker gathers at a time
-    bool expected_returners_ = false;
-    std::chrono::steady_clock::time_point grace_until_ = std::chrono::steady_clock::time_point::min();
+    uint64_t drained_ = 0;            // queries ever moved from the inbox to queue_
+    std::atomic<size_t> expect_{1};
+    std::atomic<bool> expected_returners_{false};
+    std::atomic<int64_t> grace_until_ns_{0};   // steady_clock time since epoch, ns (0 = none)
     DispatchStats st_;
     std::vector<std::thread> workers_;
+    // Waking several hundred sleepers is a futex call that costs about a microsecond per sleeper -- on the worker's critical path that
+    // was as long as the pass itself.  A pass of more than WAKE_INLINE requests is handed to the worker's companion thread, which sets
+    // the flags and rings the slots while the worker is already gathering the next pass.
+    static constexpr size_t WAKE_INLINE = 96;
+    struct Waker {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<DispatchReq*> todo;     // one pass at a time; the worker waits for the previous hand-over to be taken
+        bool has = false, stop = false;
+        std::thread th;
+    };
+    std::vector<std::unique_ptr<Waker>> wakers_;
 };
 
 // Writer-preferring shared/exclusive lock: searches share, `add` excludes -- the RwLock of src/main.rs:1016 (write) and

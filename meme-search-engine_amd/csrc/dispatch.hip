@@ -8,8 +8,27 @@
 #include <future>
 #include <memory>
 #include <new>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <time.h>
 
 namespace mse {
+
+// futex on a 32-bit atomic (std::atomic<uint32_t> is layout-compatible with uint32_t on this target)
+static inline void futex_wait(std::atomic<uint32_t>* w, uint32_t seen) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+}
+static inline void futex_wait_for(std::atomic<uint32_t>* w, uint32_t seen, int64_t ns) {
+    struct timespec ts;
+    ts.tv_sec = (time_t)(ns / 1000000000ll);
+    ts.tv_nsec = (long)(ns % 1000000000ll);
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, seen, &ts, nullptr, 0);   // relative timeout
+}
+static inline void futex_wake_all(std::atomic<uint32_t>* w) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
 
 uint32_t default_wait_us(size_t n_rows, size_t row_bytes) {
     const double pass_us = (double)n_rows * (double)row_bytes / 4.0e6;   // bytes / (4 TB/s) in microseconds
@@ -26,55 +45,103 @@ Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::f
     : max_queries_(max_queries ? max_queries : 1), max_wait_us_(max_wait_us), run_(std::move(run)),
       on_start_(std::move(on_thread_start)) {
     if (n_workers < 1) n_workers = 1;
+    for (int w = 0; w < n_workers; w++) {
+        wakers_.emplace_back(new Waker());
+        wakers_[w]->th = std::thread([this, w] { wake_loop(w); });
+    }
     for (int w = 0; w < n_workers; w++) workers_.emplace_back([this, w] { loop(w); });
 }
 
+// flags first (a request's slot read before its flag is set: the record is gone once the flag is seen), then one wake-up per slot touched
+void Coalescer::complete(std::vector<DispatchReq*>& batch) {
+    uint64_t touched = 0;
+    for (DispatchReq* r : batch) {
+        touched |= 1ull << r->slot;
+        r->done.store(1, std::memory_order_release);
+    }
+    for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++)
+        if (touched >> sl & 1ull) {
+            wake_[sl].gen.fetch_add(1, std::memory_order_release);
+            futex_wake_all(&wake_[sl].gen);
+        }
+}
+
+void Coalescer::wake_loop(int index) {
+    Waker& w = *wakers_[index];
+    std::vector<DispatchReq*> mine;
+    std::unique_lock<std::mutex> lk(w.mu);
+    for (;;) {
+        w.cv.wait(lk, [&] { return w.has || w.stop; });
+        if (!w.has && w.stop) break;
+        mine.swap(w.todo);
+        w.has = false;
+        lk.unlock();
+        w.cv.notify_all();      // the worker may hand over its next pass
+        complete(mine);
+        mine.clear();
+        lk.lock();
+    }
+}
+
 Coalescer::~Coalescer() {
+    stop_.store(true);
+    bell_.fetch_add(1);
+    futex_wake_all(&bell_);
     {
-        std::lock_guard<std::mutex> lk(mu_);
-        stop_ = true;
+        std::lock_guard<std::mutex> lk(mu_);   // (a worker between its predicate and its wait holds mu_: it sees the flag afterwards)
     }
     cv_worker_.notify_all();
     for (std::thread& t : workers_)
         if (t.joinable()) t.join();
-    // shutting down: nobody may stay blocked (submit refuses new requests once stop_ is set)
-    std::vector<DispatchReq*> left;
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        left.assign(queue_.begin(), queue_.end());
-        queue_.clear();
-        queued_queries_ = 0;
-    }
-    for (DispatchReq* r : left) {
-        WakeSlot& ws = wake_[r->slot];
+    for (auto& w : wakers_) {
         {
-            std::lock_guard<std::mutex> lk(ws.mu);
-            r->rc = -1;
-            r->err = "dispatcher closed while the request was queued";
-            r->done = true;   // (r may be gone from here on)
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->stop = true;
         }
-        ws.cv.notify_all();
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();   // (a pass handed over before the stop is still completed: has is checked first)
     }
+    // shutting down: nobody may stay blocked (submit refuses new requests once stop_ is set; what slipped in is answered here)
+    drain();
+    uint64_t touched = 0;
+    for (DispatchReq* r : queue_) {
+        touched |= 1ull << r->slot;
+        r->rc = -1;
+        r->err = "dispatcher closed while the request was queued";
+        r->done.store(1, std::memory_order_release);   // (r may be gone from here on)
+    }
+    queue_.clear();
+    for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++)
+        if (touched >> sl & 1ull) {
+            wake_[sl].gen.fetch_add(1, std::memory_order_release);
+            futex_wake_all(&wake_[sl].gen);
+        }
 }
 
 int Coalescer::submit(DispatchReq& r) {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (stop_) return fail("dispatcher is shutting down");
-        r.done = false;
-        r.slot = (uint32_t)((arrivals_++ / WAKE_RUN) % WAKE_SLOTS);
-        r.t_arrive = std::chrono::steady_clock::now();
-        queue_.push_back(&r);
-        queued_queries_ += r.nq;
-        // the gathering worker only needs waking when this arrival can change its decision: first in the queue, or the target reached
-        if (queue_.size() == 1 || queued_queries_ >= target()) {
-            if (workers_.size() > 1) cv_worker_.notify_all(); else cv_worker_.notify_one();
-        }
+    if (stop_.load(std::memory_order_acquire)) return fail("dispatcher is shutting down");
+    r.done.store(0, std::memory_order_relaxed);
+    r.slot = (uint32_t)((arrivals_.fetch_add(1, std::memory_order_relaxed) / WAKE_RUN) % WAKE_SLOTS);
+    r.t_arrive = std::chrono::steady_clock::now();
+    DispatchReq* head = inbox_.load(std::memory_order_relaxed);
+    do {
+        r.next = head;
+    } while (!inbox_.compare_exchange_weak(head, &r, std::memory_order_release, std::memory_order_relaxed));
+    // the bell: only the push that carries the count across the gatherer's mark (both sides sequentially consistent: either this
+    // thread sees the mark the gatherer published, or the gatherer sees this push when it re-reads the count before sleeping)
+    const uint64_t before = pushed_.fetch_add(r.nq, std::memory_order_seq_cst), after = before + r.nq;
+    const uint64_t mark = wake_at_.load(std::memory_order_seq_cst);
+    if (before < mark && after >= mark) {
+        bell_.fetch_add(1, std::memory_order_release);
+        futex_wake_all(&bell_);
     }
     {
-        WakeSlot& ws = wake_[r.slot];
-        std::unique_lock<std::mutex> lk(ws.mu);
-        ws.cv.wait(lk, [&] { return r.done; });
+        std::atomic<uint32_t>& gen = wake_[r.slot].gen;
+        for (;;) {
+            const uint32_t seen = gen.load(std::memory_order_acquire);
+            if (r.done.load(std::memory_order_acquire)) break;
+            futex_wait(&gen, seen);   // returns at once if the word has moved on since it was read
+        }
     }
     if (r.rc) set_error(r.err.empty() ? std::string("search failed") : r.err);
     return r.rc;
@@ -84,9 +151,10 @@ int Coalescer::submit(DispatchReq& r) {
 // passes -- 512 closed-loop callers against a 320-query pass are served as 256 + 256 (2 x 58 ms), not 320 + 192 (70 + 48 ms and a
 // gather that keeps waiting for the stragglers of the large pass): 3.8-3.9 k -> queries/s of profiles/r04_bench_default.json.
 size_t Coalescer::target() const {
-    if (expect_ <= max_queries_) return expect_;
-    const size_t passes = (expect_ + max_queries_ - 1) / max_queries_;
-    return (expect_ + passes - 1) / passes;
+    const size_t expect = expect_.load(std::memory_order_acquire);
+    if (expect <= max_queries_) return expect;
+    const size_t passes = (expect + max_queries_ - 1) / max_queries_;
+    return (expect + passes - 1) / passes;
 }
 
 DispatchStats Coalescer::stats() {
@@ -94,29 +162,75 @@ DispatchStats Coalescer::stats() {
     return st_;
 }
 
+// the whole inbox at once, back into arrival order, behind what is already queued (the gatherer only)
+void Coalescer::drain() {
+    DispatchReq* h = inbox_.exchange(nullptr, std::memory_order_acquire);
+    DispatchReq* rev = nullptr;
+    size_t nq = 0;
+    while (h) {
+        DispatchReq* n = h->next;
+        h->next = rev;
+        rev = h;
+        h = n;
+    }
+    for (DispatchReq* r = rev; r; r = r->next) {
+        queue_.push_back(r);
+        nq += r->nq;
+    }
+    queued_queries_ += nq;
+    drained_ += nq;
+}
+
+static inline int64_t steady_ns(std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(t.time_since_epoch()).count();
+}
+
 void Coalescer::loop(int index) {
     tl_worker_index = index;
     if (on_start_) on_start_();
     std::vector<DispatchReq*> batch;
-    std::vector<uint32_t> slots;
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
-        cv_worker_.wait(lk, [&] { return stop_ || (!gathering_ && !queue_.empty()); });
-        if (stop_) break;
+        cv_worker_.wait(lk, [&] { return stop_.load() || !gathering_; });
+        if (stop_.load()) break;
         gathering_ = true;
-        // gather until the target is waiting (dispatch.h), or the oldest request is max_wait old -- but never before the callers
-        // just answered had their grace period to come back
-        auto deadline = queue_.front()->t_arrive + std::chrono::microseconds(max_wait_us_.load());
-        if (grace_until_ > deadline) deadline = grace_until_;
+        lk.unlock();
+        // ---- the gatherer: sleeps on the bell, never on a lock the callers touch ----
+        // until the first request is there ...
         bool by_deadline = false;
-        while (!stop_ && queued_queries_ < target()) {
-            if (cv_worker_.wait_until(lk, deadline) == std::cv_status::timeout) { by_deadline = true; break; }
+        auto sleep_until_mark = [&](uint64_t mark, bool timed, int64_t deadline_ns) -> bool {   // false: the deadline passed
+            const uint32_t b = bell_.load(std::memory_order_acquire);
+            wake_at_.store(mark, std::memory_order_seq_cst);
+            if (pushed_.load(std::memory_order_seq_cst) >= mark || stop_.load()) return true;   // it came while the mark was being set
+            if (!timed) { futex_wait(&bell_, b); return true; }
+            const int64_t now = steady_ns(std::chrono::steady_clock::now());
+            if (now >= deadline_ns) return false;
+            futex_wait_for(&bell_, b, deadline_ns - now);
+            return true;
+        };
+        for (;;) {
+            drain();
+            if (!queue_.empty() || stop_.load()) break;
+            (void)sleep_until_mark(drained_ + 1, false, 0);
         }
-        if (stop_) { gathering_ = false; break; }
+        if (stop_.load()) { lk.lock(); gathering_ = false; break; }
+        // ... then until the target is waiting (dispatch.h), or the oldest request is max_wait old -- but never before the callers
+        // just answered had their grace period to come back.  expect_ / the grace period may move while this waits (another worker's
+        // pass ending rings the bell): both are re-read every round.
+        const bool had_expected = expected_returners_.load();
+        for (;;) {
+            drain();
+            const size_t tgt = target();
+            if (queued_queries_ >= tgt || stop_.load()) break;
+            int64_t deadline = steady_ns(queue_.front()->t_arrive) + (int64_t)max_wait_us_.load() * 1000;
+            deadline = std::max(deadline, grace_until_ns_.load(std::memory_order_acquire));
+            if (!sleep_until_mark(drained_ + (tgt - queued_queries_), true, deadline)) { by_deadline = true; drain(); break; }
+        }
+        if (stop_.load()) { lk.lock(); gathering_ = false; break; }
         batch.clear();
         size_t nq = 0;
         // more callers than one pass holds: equal shares (target()), not a full pass and a remainder
-        const size_t cap = expect_ > max_queries_ ? target() : max_queries_;
+        const size_t cap = expect_.load() > max_queries_ ? target() : max_queries_;
         while (!queue_.empty()) {
             DispatchReq* r = queue_.front();
             if (!batch.empty() && nq + r->nq > cap) break;   // a request larger than a pass goes alone
@@ -125,17 +239,15 @@ void Coalescer::loop(int index) {
             queue_.pop_front();
         }
         queued_queries_ -= nq;
-        gathering_ = false;
-        const bool had_expected = expected_returners_;
-        if (workers_.size() > 1 && !queue_.empty()) cv_worker_.notify_all();   // what is left is another worker's to gather
-        lk.unlock();
-        run_(batch);
+        taken_.fetch_add(nq, std::memory_order_release);
         lk.lock();
-        st_.passes++;
-        st_.requests += batch.size();
-        st_.queries += nq;
-        st_.max_pass_queries = std::max<uint64_t>(st_.max_pass_queries, nq);
-        if (by_deadline) st_.deadline_fires++;
+        gathering_ = false;                       // what is left (and what arrives) is the next gatherer's
+        lk.unlock();
+        if (workers_.size() > 1) cv_worker_.notify_one();
+        const auto t_run = std::chrono::steady_clock::now();
+        run_(batch);
+        const auto t_end = std::chrono::steady_clock::now();
+        const uint64_t run_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_run).count();
         // Next target: what queued up during this pass PLUS the callers answered now -- closed-loop callers (a thread per core,
         // one request at a time) are back within microseconds, and without counting them T callers settle into two groups of T/2
         // taking turns.  A CALLER comes back, whatever it asked for: a request of 256 queries counts as one returner, not as 256
@@ -143,28 +255,42 @@ void Coalescer::loop(int index) {
         // that just ended had counted on returners and ran into its deadline instead (they did not come back: open-loop arrivals,
         // or callers that left), the next one does not count on them; the one after tries again.
         const bool expect_returners = !(by_deadline && had_expected);
-        expected_returners_ = expect_returners;
-        expect_ = std::max<size_t>(1, queued_queries_ + (expect_returners ? batch.size() : 0));
+        expected_returners_.store(expect_returners);
+        // waiting now: pushed and not yet part of any pass
+        const uint64_t taken_now = taken_.load(std::memory_order_acquire), pushed_now = pushed_.load(std::memory_order_acquire);
+        const size_t waiting = (size_t)(pushed_now > taken_now ? pushed_now - taken_now : 0);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            st_.run_us += run_us;
+            st_.passes++;
+            st_.requests += batch.size();
+            st_.queries += nq;
+            st_.max_pass_queries = std::max<uint64_t>(st_.max_pass_queries, nq);
+            if (by_deadline) st_.deadline_fires++;
+        }
+        expect_.store(std::max<size_t>(1, waiting + (expect_returners ? batch.size() : 0)), std::memory_order_release);
         const uint32_t grace_us = std::min<uint32_t>(max_wait_us_.load(), 1000);
-        grace_until_ = expect_returners ? std::chrono::steady_clock::now() + std::chrono::microseconds(grace_us)
-                                        : std::chrono::steady_clock::time_point::min();
-        lk.unlock();
-        // completion, slot by slot: `done` under the slot's mutex, its variable signalled after the unlock.  A request record lives
-        // on its caller's stack and is gone once `done` is seen, so the slots are read out first.
-        slots.resize(batch.size());
-        uint64_t touched = 0;
-        for (size_t i = 0; i < batch.size(); i++) { slots[i] = batch[i]->slot; touched |= 1ull << slots[i]; }
-        for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++) {
-            if (!(touched >> sl & 1ull)) continue;
-            {
-                std::lock_guard<std::mutex> g(wake_[sl].mu);
-                for (size_t i = 0; i < batch.size(); i++)
-                    if (slots[i] == sl) batch[i]->done = true;
-            }
-            wake_[sl].cv.notify_all();
+        grace_until_ns_.store(expect_returners ? steady_ns(t_end) + (int64_t)grace_us * 1000 : 0, std::memory_order_release);
+        // completion: inline for a small pass; a large one goes to the companion thread (its wake-ups take as long as a pass)
+        if (batch.size() <= WAKE_INLINE) {
+            complete(batch);
+        } else {
+            Waker& wk = *wakers_[index];
+            std::unique_lock<std::mutex> wl(wk.mu);
+            wk.cv.wait(wl, [&] { return !wk.has; });
+            wk.todo.swap(batch);
+            wk.has = true;
+            wl.unlock();
+            wk.cv.notify_all();
+        }
+        if (workers_.size() > 1) {   // a gatherer waiting for its target re-reads expect_ / the grace period
+            bell_.fetch_add(1, std::memory_order_release);
+            futex_wake_all(&bell_);
         }
         lk.lock();
     }
+    lk.unlock();
+    cv_worker_.notify_all();
 }
 
 }  // namespace mse

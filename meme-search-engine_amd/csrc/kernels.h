@@ -86,6 +86,9 @@ int launch_gather_rows16(const void* in, size_t row_bytes, const uint32_t* idx, 
 int launch_scatter_topk(const uint32_t* idx, const uint8_t* take, int nb, int k, const int64_t* src_s, const uint32_t* src_i, int64_t* dst_s,
                         uint32_t* dst_i, size_t dst_stride, hipStream_t stream);
 
+// a shard's [n] results on their way into a packed block: out_sc[i] = sc[i], out_ids[i] = ids[i] + id_offset; empty slots (ID_NONE, or
+// sc == nullptr) become (INT64_MIN, ID_NONE)
+int launch_block_finish(const int64_t* sc, const uint32_t* ids, size_t n, uint64_t id_offset, int64_t* out_sc, uint32_t* out_ids, hipStream_t stream);
 int launch_scatter_rows4(const uint32_t* idx, const uint8_t* take, int nb, int k, const void* src, void* dst, size_t dst_stride, hipStream_t stream);
 
 // ---- pq.hip ----------------------------------------------------------------------------------

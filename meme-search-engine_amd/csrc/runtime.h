@@ -49,6 +49,7 @@ struct mse_base {
     // the coalescer that MSE_MODE_AUTO host-pointer searches of every thread meet in (dispatch.hip), made on first use
     mutable std::mutex disp_mu;
     mutable struct mse_dispatcher* disp = nullptr;
+    mutable bool disp_failed = false;   // it could not be made once: AUTO calls are answered directly from then on
     // max row norm (float bits) for the MFMA certificate, computed on first use
     mutable std::mutex norm_mu;
     mutable uint32_t* norm_bits_dev = nullptr;
@@ -109,6 +110,8 @@ struct mse_pq {
     bool timing = false;              // HIP-event timing of the four-query scan kernel (mse_pq_scan_timing), for bench.py's roofline
     double scan_ms_total = 0.0;
     uint64_t scan_launches = 0;
+    double span_ms_total = 0.0;       // first scan start .. last scan end of the batch calls with >= 4 scans (mse_pq_scan_sustained)
+    uint64_t span_scans = 0;
     void* pin = nullptr;              // pinned host staging of the scan entry points (one upload + one download per call, both
     size_t pin_cap = 0;               // truly asynchronous: a pageable source makes the runtime stage and block per copy)
 };
@@ -127,6 +130,13 @@ int ensure_base_norm(const mse_base* b, hipStream_t st);
 size_t visited_budget_bytes();
 }  // namespace mse
 
+namespace mse {
+// one query's outputs of the fused request path (any of the counter pointers may be null)
+struct QueryDst {
+    uint32_t* ids; int64_t* scores; uint32_t *n_visited, *cmps, *pq_cmps; size_t k;
+};
+}  // namespace mse
+
 struct mse_graph {
     uint32_t* adj = nullptr;   // device [n][max_deg]
     uint32_t* deg = nullptr;   // device [n]
@@ -137,10 +147,12 @@ struct mse_graph {
     // submission, on a searcher and pinned staging that belong to the WORKER (one set per worker thread)
     mutable std::mutex co_mu;
     mutable mse::Coalescer* co = nullptr;
+    mutable std::atomic<mse::Coalescer*> co_fast{nullptr};   // == co once made: the request threads' lock-free way to it
     struct WorkerCtx {
         mse_searcher* s = nullptr;   // made on first use over the callers' base
         void* pin = nullptr;         // gathered inputs (queries, scales, starts, tables)
         size_t pin_cap = 0;
+        std::vector<mse::QueryDst> dsts;   // where each gathered query's results go
     };
     mutable std::vector<WorkerCtx> co_ctx;
     size_t co_max_queries = 0;       // mse_graph_set_coalescer: 0 = defaults (1024 queries per pass, 200 us, two workers)

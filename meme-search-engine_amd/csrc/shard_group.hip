@@ -37,25 +37,35 @@ namespace {
 inline size_t block_bytes(size_t nq, size_t k) { return (nq * k * 12 + 15) & ~(size_t)15; }
 
 // merge G packed blocks (device memory of the searcher's device) -> out [nq][k]; asynchronous on the searcher's stream
+// k_in records per shard and query in the blocks, the k best of all of them out ([nq][k]; k_in = 0: k_in = k)
 int merge_packed(mse_searcher* s, const char* gathered, size_t n_shards, size_t nq, size_t k, void* out_scores_dev,
-                 void* out_ids_dev) {
-    if (k > (size_t)TOPK_KMAX) return fail("k too large");
+                 void* out_ids_dev, size_t k_in = 0) {
+    if (k_in == 0) k_in = k;
+    if (k > (size_t)TOPK_KMAX || k_in > (size_t)TOPK_KMAX) return fail("k too large");
     if (s->misc.ensure(nq * k * 4) || s->sel_keys.ensure(nq * k * 8)) return -1;
-    const size_t B = block_bytes(nq, k);
+    const size_t B = block_bytes(nq, k_in);
     SelectArgs a{};
     a.kind = KEY_I64;
     a.list_keys = gathered;
-    a.list_ids = reinterpret_cast<const uint32_t*>(gathered + nq * k * 8);
-    a.list_stride = k;                  // query q starts k records into each shard's block
-    a.list_chunk = k;
+    a.list_ids = reinterpret_cast<const uint32_t*>(gathered + nq * k_in * 8);
+    a.list_stride = k_in;               // query q starts k_in records into each shard's block
+    a.list_chunk = k_in;
     a.list_chunk_stride = B / 8;        // next shard, in i64 elements
     a.list_id_chunk_stride = B / 4;     // next shard, in u32 elements
-    a.n_list = n_shards * k;
+    a.n_list = n_shards * k_in;
     a.k = (int)k; a.out_ids = s->misc.as<uint32_t>(); a.out_keys = s->sel_keys.p; a.out_stride = k; a.nq = (int)nq;
     if (launch_select(a, s->stream)) return -1;
     return launch_finalize(s->misc.as<uint32_t>(), s->sel_keys.as<int64_t>(), k, (int)k, (int)nq, 0,
                            reinterpret_cast<int64_t*>(out_scores_dev), reinterpret_cast<uint32_t*>(out_ids_dev), k, nullptr, 0,
                            0, 0, nullptr, nullptr, s->stream);
+}
+
+// rows of the global top-r that live on this shard: local id = global id - first_row, ID_NONE for everybody else's
+__global__ void members_local_kernel(const uint32_t* __restrict__ gids, size_t n, uint64_t first_row, uint64_t n_local, uint32_t* __restrict__ local) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = gids[i];
+    local[i] = (g != ID_NONE && g >= first_row && g - first_row < n_local) ? (uint32_t)(g - first_row) : ID_NONE;
 }
 
 struct Rccl {
@@ -111,6 +121,11 @@ struct Shard {
     DevBuf q_local, block;      // on this shard's device (used when it cannot reach the root's memory directly, and by RCCL)
     DevBuf gathered;            // RCCL exchange: every shard's block, on this shard's device
     void* comm = nullptr;       // RCCL exchange: this shard's communicator (rank = shard index)
+    // approximate-search state of the shard's rows (round 5; handles are the caller's, made on this shard's device):
+    mse_pq* pq = nullptr;               // the codec (the same centroids / rotation on every shard)
+    const mse_codes* codes = nullptr;   // PQ codes (+ descriptor bytes) of THIS shard's rows
+    const mse_graph* graph = nullptr;   // a Vamana graph over THIS shard's rows, with its own entry table
+    DevBuf ann_a, ann_b;                // phase-B scratch of the sharded PQ scan: local ids, exact scores
     bool peer = false;          // may read/write root-device memory from kernels
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // step breakdown: start, local search done, exchange done
     float local_ms = 0.f, exch_ms = 0.f;
@@ -278,6 +293,12 @@ size_t mse_shard_group_len(const mse_shard_group* G) {
 int mse_shard_group_device(const mse_shard_group* G, size_t shard) {
     return (G && shard < G->shards.size()) ? G->shards[shard].device : -1;
 }
+const mse_base* mse_shard_group_base(const mse_shard_group* G, size_t shard) {
+    return (G && shard < G->shards.size()) ? G->shards[shard].base : nullptr;
+}
+uint64_t mse_shard_group_first_row(const mse_shard_group* G, size_t shard) {
+    return (G && shard < G->shards.size()) ? (uint64_t)G->shards[shard].first_row : 0;
+}
 mse_searcher* mse_shard_group_searcher(mse_shard_group* G, size_t shard) {
     return (G && shard < G->shards.size()) ? G->shards[shard].searcher : nullptr;
 }
@@ -331,12 +352,18 @@ int mse_shard_group_set_shard_device(mse_shard_group* G, size_t shard, const voi
 }  // extern "C"
 
 // the search proper; the caller holds G->call_mu (one search at a time per group: gathered / q_root / out_* are group scratch)
-static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t nq, size_t k, int mode, void* scores_dev,
-                             void* ids_dev) {
+// What a shard does with the payload (queries, ...) to fill its packed block [nq * k_in i64 scores | nq * k_in u32 GLOBAL ids] on its own
+// device, asynchronously on its searcher's stream or complete on return.  q: the payload where this shard can read it (its own copy, or
+// the root's memory through the peer mapping).
+using LocalFn = std::function<int(Shard& sh, const void* q, char* blk)>;
+
+// One sharded search: every shard's local step, ONE exchange of the packed blocks, the k best of all shards' k_in records per query.
+static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t qbytes, size_t nq, size_t k_in, size_t k, const LocalFn& local,
+                             void* scores_dev, void* ids_dev) {
     for (const Shard& s : G->shards) if (!s.searcher) return fail("shard group: a shard holds no rows yet");
     const auto wall0 = std::chrono::steady_clock::now();
     const size_t n_shards = G->shards.size();
-    const size_t B = block_bytes(nq, k), qbytes = nq * G->d * 2;
+    const size_t B = block_bytes(nq, k_in);
     const bool use_rccl = G->exchange == MSE_EXCHANGE_RCCL;
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -357,24 +384,24 @@ static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t
                 // memory here), the block stays local; the all-gather is issued in a second round, once EVERY shard has its
                 // block (a rank that failed before its collective would leave the others waiting in theirs for ever)
                 if (sh.block.ensure(B) || sh.gathered.ensure(B * n_shards)) return -1;
-                if (!on_root) {
+                if (!on_root && qbytes) {
                     if (sh.q_local.ensure(qbytes)) return -1;
                     MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
                     q = sh.q_local.p;
                 }
                 char* blk = sh.block.as<char>();
-                if (mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8)) return -1;
+                if (local(sh, q, blk)) return -1;
                 MSE_HIP_TRY(hipEventRecord(sh.ev[1], st));
                 return 0;
             } else {
                 char* blk = gathered + g * B;
                 if (!sh.peer) {   // no mapping of the root's memory: stage the queries here, copy the block back
-                    if (sh.q_local.ensure(qbytes) || sh.block.ensure(B)) return -1;
-                    MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
+                    if (sh.q_local.ensure(std::max<size_t>(qbytes, 16)) || sh.block.ensure(B)) return -1;
+                    if (qbytes) MSE_HIP_TRY(hipMemcpyPeerAsync(sh.q_local.p, sh.device, queries_dev, G->root_device, qbytes, st));
                     q = sh.q_local.p;
                     blk = sh.block.as<char>();
                 }
-                if (mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8)) return -1;
+                if (local(sh, q, blk)) return -1;
                 MSE_HIP_TRY(hipEventRecord(sh.ev[1], st));
                 if (!sh.peer) MSE_HIP_TRY(hipMemcpyPeerAsync(gathered + g * B, G->root_device, blk, sh.device, B, st));
             }
@@ -418,7 +445,7 @@ static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t
                 G->exchange = MSE_EXCHANGE_PEER;
                 G->rccl_ranks = 0;
                 (void)hipSetDevice(prev);
-                const int rc2 = search_dev_locked(G, queries_dev, nq, k, mode, scores_dev, ids_dev);   // over the peer-store exchange
+                const int rc2 = search_dev_locked(G, queries_dev, qbytes, nq, k_in, k, local, scores_dev, ids_dev);   // over the peer-store exchange
                 if (rc2) return rc2;
                 set_error("RCCL exchange failed and was shut down (" + why + "); the search was answered over the peer-store exchange");
                 return 0;
@@ -428,7 +455,7 @@ static int search_dev_locked(mse_shard_group* G, const void* queries_dev, size_t
         hipStream_t rs = G->root->stream;
         if (!rc) for (hipEvent_t& e : G->ev_merge) if (!e && hipEventCreate(&e) != hipSuccess) rc = fail("shard group: event");
         if (!rc && hipEventRecord(G->ev_merge[0], rs) != hipSuccess) rc = fail("shard group: event");
-        if (!rc) rc = merge_packed(G->root, merged_from, n_shards, nq, k, scores_dev, ids_dev);
+        if (!rc) rc = merge_packed(G->root, merged_from, n_shards, nq, k, scores_dev, ids_dev, k_in);
         if (!rc && hipEventRecord(G->ev_merge[1], rs) != hipSuccess) rc = fail("shard group: event");
         if (!rc && hipStreamSynchronize(rs) != hipSuccess) rc = fail("shard group: merge failed");
         if (!rc) {
@@ -474,6 +501,13 @@ static int bring_up_rccl(mse_shard_group* G) {
     return 0;
 }
 
+// the brute-force local step: exact top-k of the shard's rows with global ids (the shard's first row added)
+static LocalFn bruteforce_local(size_t nq, size_t k, int mode) {
+    return [=](Shard& sh, const void* q, char* blk) -> int {
+        return mse_bruteforce_topk_f16_dev(sh.searcher, q, nq, k, mode, sh.first_row, blk, blk + nq * k * 8);
+    };
+}
+
 extern "C" {
 
 // queries_dev: [nq][d] f16 on the ROOT device (device of shard 0), complete before the call; outputs [nq][k] on the root device.
@@ -484,7 +518,7 @@ int mse_shard_group_search_dev(mse_shard_group* G, const void* queries_dev, size
     if (nq == 0 || k == 0) return 0;
     if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
     std::lock_guard<std::mutex> call(G->call_mu);
-    return search_dev_locked(G, queries_dev, nq, k, mode, scores_dev, ids_dev);
+    return search_dev_locked(G, queries_dev, nq * G->d * 2, nq, k, k, bruteforce_local(nq, k, mode), scores_dev, ids_dev);
 }
 
 int mse_shard_group_search(mse_shard_group* G, const uint16_t* queries, size_t nq, size_t k, int mode, int64_t* scores,
@@ -502,7 +536,145 @@ int mse_shard_group_search(mse_shard_group* G, const uint16_t* queries, size_t n
         std::lock_guard<std::mutex> call(G->call_mu);
         rc = G->q_root.ensure(nq * G->d * 2) || G->out_s.ensure(nq * k * 8) || G->out_i.ensure(nq * k * 4);
         if (!rc && hipMemcpy(G->q_root.p, queries, nq * G->d * 2, hipMemcpyHostToDevice) != hipSuccess) rc = fail("query upload failed");
-        if (!rc) rc = search_dev_locked(G, G->q_root.p, nq, k, mode, G->out_s.p, G->out_i.p);
+        if (!rc) rc = search_dev_locked(G, G->q_root.p, nq * G->d * 2, nq, k, k, bruteforce_local(nq, k, mode), G->out_s.p, G->out_i.p);
+        if (!rc && (hipMemcpy(scores, G->out_s.p, nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(ids, G->out_i.p, nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail("result download failed");
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+// ---- the approximate-search paths over the same shards (round 5; SURVEY 8(e): "rows (and their PQ codes / descriptors)") ---------
+// A shard's codes, descriptors and graph cover exactly its rows and speak LOCAL ids; what leaves a shard is the same packed block of
+// (score, global id) records as in the brute-force search, and the same ONE exchange + merge brings the blocks together.
+
+int mse_shard_group_attach_pq(mse_shard_group* G, size_t shard, mse_pq* pq, const mse_codes* codes) {
+    if (!G) return fail("null shard group");
+    if (shard >= G->shards.size()) return fail("shard index out of range");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    Shard& sh = G->shards[shard];
+    if (pq && codes) {
+        if (!sh.base) return fail("shard group: the shard holds no rows yet");
+        if (codes->n != sh.base->n) return fail("shard group: codes and rows of the shard differ in length");
+        if (pq->d != G->d || codes->code_size != pq->n_chunks) return fail("shard group: codec does not fit the vectors / codes");
+        if (pq->device != sh.device) return fail("shard group: the codec lives on another device than the shard");
+    } else if (pq || codes) {
+        return fail("shard group: codec and codes come together");
+    }
+    sh.pq = pq; sh.codes = codes;
+    return 0;
+}
+
+int mse_shard_group_attach_graph(mse_shard_group* G, size_t shard, const mse_graph* graph) {
+    if (!G) return fail("null shard group");
+    if (shard >= G->shards.size()) return fail("shard index out of range");
+    std::lock_guard<std::mutex> call(G->call_mu);
+    Shard& sh = G->shards[shard];
+    if (graph && (!sh.base || graph->n != sh.base->n)) return fail("shard group: graph and rows of the shard differ in length");
+    sh.graph = graph;
+    return 0;
+}
+
+// phase B of the sharded PQ scan on one shard: exact score (+ descriptor bias) of ITS members of the index's top-r, everybody else's
+// slots empty; q16: f16 queries [nq][d], gids: the merged top-r [nq][r] global ids, scales_dev: [n_desc] or null -- all readable from this
+// device; the block is written on `st`
+static int pq_rescore_members(const mse_base* b, const mse_codes* codes, uint64_t first_row, const void* q16, const uint32_t* gids,
+                              const float* scales_dev, size_t nq, size_t r, DevBuf& a, DevBuf& bb, char* blk, hipStream_t st) {
+    const size_t n = nq * r;
+    if (a.ensure(n * 4) || bb.ensure(n * 8)) return -1;
+    uint32_t* local = a.as<uint32_t>();
+    int64_t* ex = bb.as<int64_t>();
+    hipLaunchKernelGGL(members_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gids, n, first_row, (uint64_t)b->n, local);
+    MSE_HIP_TRY(hipGetLastError());
+    if (launch_score_rows(b->dev, b->n, (int)b->d, q16, false, local, n, r, ex, nullptr, st)) return -1;
+    if (scales_dev && codes->n_desc && launch_add_descriptor(local, n, codes->desc, (int)codes->n_desc, codes->n, scales_dev, ex, st)) return -1;
+    return launch_block_finish(ex, local, n, first_row, reinterpret_cast<int64_t*>(blk), reinterpret_cast<uint32_t*>(blk + n * 8), st);
+}
+
+// The OPQ/PQ flat scan + exact re-rank (mse_pq_scan_topk_batch: top-r by ADC, exact fp16 re-score, top-k) over sharded codes, with the
+// answer of the unsharded call bit for bit.  A per-shard re-rank would not give that (a shard's r-th best by ADC is not the index's), so
+// the two selections are done on the whole index, each through one exchange:
+//   A  every shard: ADC top-r of ITS codes (global ids)            -> exchange -> the index's top-r by (ADC score desc, id asc)
+//   B  every shard: exact score (+ descriptor bias) of ITS members of that top-r, (INT64_MIN, none) for the others'
+//                                                                   -> exchange -> top-k by (exact score desc, id asc)
+// Records exchanged: 2 x shards x nq x r x 12 bytes (r = 200, 32 queries, 8 shards: 1.2 MB in all).
+int mse_shard_group_pq_scan_topk(mse_shard_group* G, const float* queries_f32, const float* scales, size_t nq, size_t r, size_t k,
+                                 int64_t* scores, uint32_t* ids) {
+    if (!G || !queries_f32 || !scores || !ids) return fail("shard group pq scan: null argument");
+    if (nq == 0 || k == 0) return 0;
+    if (r < k) r = k;
+    if (r > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
+    for (const Shard& sh : G->shards) if (!sh.pq || !sh.codes) return fail("shard group: a shard has no codec / codes attached (mse_shard_group_attach_pq)");
+    const size_t d = G->d, n_desc = G->shards[0].codes->n_desc;
+    const bool bias = scales && n_desc;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    MSE_HIP_TRY(hipSetDevice(G->root_device));
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> call(G->call_mu);
+        // root staging: [f16 queries nq x d][merged top-r ids nq x r][scales n_desc f32] -- phase B's payload, one buffer so that a shard
+        // that cannot map the root's memory gets it in one peer copy
+        const size_t off_ids = (nq * d * 2 + 255) & ~(size_t)255, off_sc = (off_ids + nq * r * 4 + 255) & ~(size_t)255;
+        const size_t pay_bytes = off_sc + (bias ? n_desc * 4 : 0) + 16, off_q32 = (pay_bytes + 255) & ~(size_t)255;
+        rc = G->q_root.ensure(off_q32 + nq * d * 4) || G->out_s.ensure(nq * r * 8) || G->out_i.ensure(nq * r * 4);
+        hipStream_t rs = G->root->stream;
+        char* const pay = G->q_root.as<char>();
+        float* const q32_dev = reinterpret_cast<float*>(pay + off_q32);   // behind the payload: the f32 queries, only to make their f16 copies
+        if (!rc && hipMemcpyAsync(q32_dev, queries_f32, nq * d * 4, hipMemcpyHostToDevice, rs) != hipSuccess) rc = fail("query upload failed");
+        if (!rc) rc = launch_f32_to_f16(q32_dev, nq * d, reinterpret_cast<uint16_t*>(pay), rs);   // half::f16::from_f32 (RNE), query_disk_index.rs:477
+        if (!rc && bias && hipMemcpyAsync(pay + off_sc, scales, n_desc * 4, hipMemcpyHostToDevice, rs) != hipSuccess) rc = fail("scales upload failed");
+        if (!rc && hipStreamSynchronize(rs) != hipSuccess) rc = fail("query upload failed");
+        // phase A: the index's top-r by ADC (+ bias)
+        if (!rc)
+            rc = search_dev_locked(G, nullptr, 0, nq, r, r, [=](Shard& sh, const void*, char* blk) -> int {
+                return mse_pq_scan_topk_block(sh.pq, sh.codes, nullptr, queries_f32, nq, bias ? scales : nullptr, r, r, sh.first_row, blk);
+            }, G->out_s.p, G->out_i.p);
+        double tA[4] = {G->last_ms[0], G->last_ms[1], G->last_ms[2], G->last_ms[3]};
+        if (!rc && hipMemcpyAsync(pay + off_ids, G->out_i.p, nq * r * 4, hipMemcpyDeviceToDevice, rs) != hipSuccess) rc = fail("shard group: copy failed");
+        if (!rc && hipStreamSynchronize(rs) != hipSuccess) rc = fail("shard group: copy failed");
+        // phase B: exact re-score of the members, top-k
+        if (!rc)
+            rc = search_dev_locked(G, pay, pay_bytes, nq, r, k, [=](Shard& sh, const void* q, char* blk) -> int {
+                const char* p = static_cast<const char*>(q);
+                return pq_rescore_members(sh.base, sh.codes, sh.first_row, p, reinterpret_cast<const uint32_t*>(p + off_ids),
+                                          bias ? reinterpret_cast<const float*>(p + off_sc) : nullptr, nq, r, sh.ann_a, sh.ann_b, blk, sh.searcher->stream);
+            }, G->out_s.p, G->out_i.p);
+        if (!rc) for (int i = 0; i < 4; i++) G->last_ms[i] += tA[i];   // both phases
+        if (!rc && (hipMemcpy(scores, G->out_s.p, nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(ids, G->out_i.p, nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail("result download failed");
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+// The graph index sharded: ONE Vamana graph per shard over its own rows (the reference's shards are exactly that:
+// src/generate_index_shard.rs builds a shard's graph over the shard's vectors).  Every shard answers the whole query batch from ITS
+// graph -- entry by its own entry table, query_disk_index::greedy_search, the k best visited records (mse_disk_query_topk_block) --
+// and the blocks meet in the one exchange: the merged result is the merge of the per-shard searches.  queries: f16 [nq][d] host rows;
+// neighbours scored exactly (disable_pq = 1) or by ADC through the shard's codec and codes with tables from `luts` ([nq][64*256] f32).
+int mse_shard_group_query_topk(mse_shard_group* G, const uint16_t* queries, const float* luts, const float* scales, size_t nq, int disable_pq,
+                               size_t beamwidth, size_t search_list, size_t k, int64_t* scores, uint32_t* ids) {
+    if (!G || !queries || !scores || !ids) return fail("shard group query: null argument");
+    if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    for (const Shard& sh : G->shards) {
+        if (!sh.graph) return fail("shard group: a shard has no graph attached (mse_shard_group_attach_graph)");
+        if (!disable_pq && (!sh.pq || !sh.codes)) return fail("shard group: ADC-scored search needs a codec and codes on every shard");
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    MSE_HIP_TRY(hipSetDevice(G->root_device));
+    int rc = 0;
+    {
+        std::lock_guard<std::mutex> call(G->call_mu);
+        rc = G->q_root.ensure(nq * G->d * 2) || G->out_s.ensure(nq * k * 8) || G->out_i.ensure(nq * k * 4);
+        if (!rc && hipMemcpy(G->q_root.p, queries, nq * G->d * 2, hipMemcpyHostToDevice) != hipSuccess) rc = fail("query upload failed");
+        if (!rc)
+            rc = search_dev_locked(G, G->q_root.p, nq * G->d * 2, nq, k, k, [=](Shard& sh, const void* q, char* blk) -> int {
+                return mse_disk_query_topk_block(sh.searcher, sh.pq, sh.codes, sh.graph, nullptr, static_cast<const uint16_t*>(q), luts, scales, nq, disable_pq,
+                                                 beamwidth, search_list, k, sh.first_row, blk, nullptr, nullptr, nullptr);
+            }, G->out_s.p, G->out_i.p);
         if (!rc && (hipMemcpy(scores, G->out_s.p, nq * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
                     hipMemcpy(ids, G->out_i.p, nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail("result download failed");
     }
@@ -532,7 +704,7 @@ int mse_shard_group_last_timing(mse_shard_group* G, double out_ms[4]) {
 struct mse_comm {
     void* comm = nullptr;
     int rank = 0, world = 1;
-    DevBuf local, gathered;
+    DevBuf local, gathered, ann_a, ann_b;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, local search done, all-gather done, merge done
     hipStream_t ev_stream = nullptr;
     bool timed = false;
@@ -594,6 +766,65 @@ int mse_comm_search_dev(mse_comm* c, mse_searcher* s, const void* queries_dev, s
     if (merge_packed(s, c->gathered.as<char>(), (size_t)c->world, nq, k, scores_dev, ids_dev)) return -1;
     MSE_HIP_TRY(hipEventRecord(c->ev[3], s->stream));
     c->timed = true;
+    return 0;
+}
+
+// The exchange alone: this rank's packed block ([nq*k_in] i64 scores | [nq*k_in] u32 GLOBAL ids, on its device, complete on the
+// searcher's stream) -> ONE all-gather -> the k best of all ranks' records per query, identical on every rank.
+int mse_comm_exchange_dev(mse_comm* c, mse_searcher* s, const void* block_dev, size_t nq, size_t k_in, size_t k, void* scores_dev, void* ids_dev) {
+    if (!c || !s || !block_dev) return fail("null communicator / searcher / block");
+    if (nq == 0 || k == 0) return 0;
+    if (k_in == 0) k_in = k;
+    if (k > (size_t)TOPK_KMAX - 64 || k_in > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    const size_t B = block_bytes(nq, k_in);
+    if (c->gathered.ensure(B * (size_t)c->world)) return -1;
+    const int rc = rccl().AllGather(block_dev, c->gathered.p, B, /*ncclInt8*/ 0, c->comm, s->stream);
+    if (rc) return rccl_fail("ncclAllGather", rc);
+    return merge_packed(s, c->gathered.as<char>(), (size_t)c->world, nq, k, scores_dev, ids_dev, k_in);
+}
+
+// One rank of the sharded PQ scan + exact re-rank (the protocol of mse_shard_group_pq_scan_topk): this rank's codes / rows start at
+// global row first_row; queries_f32 [nq][d] and scales [n_desc] are host memory, the same on every rank.  Outputs [nq][k] on this
+// rank's device, identical on every rank, complete on return.
+int mse_comm_pq_scan_topk(mse_comm* c, mse_pq* pq, const mse_codes* codes, mse_searcher* s, const float* queries_f32, const float* scales,
+                          size_t nq, size_t r, size_t k, uint64_t first_row, void* scores_dev, void* ids_dev) {
+    if (!c || !pq || !codes || !s || !s->base || !queries_f32) return fail("comm pq scan: null argument");
+    if (nq == 0 || k == 0) return 0;
+    if (r < k) r = k;
+    if (r > (size_t)TOPK_KMAX - 64) return fail("r too large (max 1984)");
+    const size_t d = s->base->d, n_desc = codes->n_desc, n = nq * r;
+    const bool bias = scales && n_desc;
+    hipStream_t st = s->stream;
+    const size_t B = block_bytes(nq, r);
+    // scratch: block | merged scores | merged ids | f32 queries | f16 queries | scales
+    const size_t o_ms = B, o_mi = o_ms + n * 8, o_q32 = (o_mi + n * 4 + 255) & ~(size_t)255, o_q16 = o_q32 + nq * d * 4, o_sc = (o_q16 + nq * d * 2 + 255) & ~(size_t)255;
+    if (c->local.ensure(o_sc + n_desc * 4 + 64)) return -1;
+    char* w = c->local.as<char>();
+    if (mse_pq_scan_topk_block(pq, codes, nullptr, queries_f32, nq, bias ? scales : nullptr, r, r, first_row, w)) return -1;   // phase A, complete on return
+    if (mse_comm_exchange_dev(c, s, w, nq, r, r, w + o_ms, w + o_mi)) return -1;
+    MSE_HIP_TRY(hipMemcpyAsync(w + o_q32, queries_f32, nq * d * 4, hipMemcpyHostToDevice, st));
+    if (launch_f32_to_f16(reinterpret_cast<const float*>(w + o_q32), nq * d, reinterpret_cast<uint16_t*>(w + o_q16), st)) return -1;
+    if (bias) MSE_HIP_TRY(hipMemcpyAsync(w + o_sc, scales, n_desc * 4, hipMemcpyHostToDevice, st));
+    if (pq_rescore_members(s->base, codes, first_row, w + o_q16, reinterpret_cast<const uint32_t*>(w + o_mi), bias ? reinterpret_cast<const float*>(w + o_sc) : nullptr,
+                           nq, r, c->ann_a, c->ann_b, w, st)) return -1;
+    if (mse_comm_exchange_dev(c, s, w, nq, r, k, scores_dev, ids_dev)) return -1;
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// One rank of the sharded graph index (mse_shard_group_query_topk's protocol): this rank's graph over its own rows answers the batch,
+// ONE all-gather, merge.  queries: f16 [nq][d], host or device; outputs [nq][k] on this rank's device, complete on return.
+int mse_comm_query_topk(mse_comm* c, mse_searcher* s, mse_pq* pq, const mse_codes* codes, const mse_graph* g, const uint16_t* queries,
+                        const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
+                        uint64_t first_row, void* scores_dev, void* ids_dev) {
+    if (!c || !s || !g || !queries) return fail("comm query: null argument");
+    if (nq == 0 || k == 0) return 0;
+    if (k > (size_t)TOPK_KMAX - 64) return fail("k too large (max 1984)");
+    if (c->local.ensure(block_bytes(nq, k))) return -1;
+    if (mse_disk_query_topk_block(s, pq, codes, g, nullptr, queries, luts, scales, nq, disable_pq, beamwidth, search_list, k, first_row, c->local.p,
+                                  nullptr, nullptr, nullptr)) return -1;
+    if (mse_comm_exchange_dev(c, s, c->local.p, nq, k, k, scores_dev, ids_dev)) return -1;
+    MSE_HIP_TRY(hipStreamSynchronize(s->stream));
     return 0;
 }
 

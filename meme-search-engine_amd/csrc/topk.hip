@@ -611,4 +611,21 @@ int launch_finalize(const uint32_t* sel_ids, const int64_t* sel_scores, size_t s
     return 0;
 }
 
+
+// hand-over of a shard's results as a packed block: out_sc[i] = sc[i], out_ids[i] = ids[i] + id_offset; an empty slot (id ID_NONE, or
+// sc == nullptr: nothing to hand over) becomes (INT64_MIN, ID_NONE)
+__global__ void block_finish_kernel(const int64_t* __restrict__ sc, const uint32_t* __restrict__ ids, size_t n, unsigned long long id_offset,
+                                    int64_t* __restrict__ out_sc, uint32_t* __restrict__ out_ids) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = sc ? ids[i] : ID_NONE;
+    out_sc[i] = id == ID_NONE ? INT64_MIN : sc[i];
+    out_ids[i] = id == ID_NONE ? ID_NONE : (uint32_t)(id + id_offset);
+}
+int launch_block_finish(const int64_t* sc, const uint32_t* ids, size_t n, uint64_t id_offset, int64_t* out_sc, uint32_t* out_ids, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(block_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sc, ids, n, (unsigned long long)id_offset, out_sc, out_ids);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
 }  // namespace mse

@@ -233,7 +233,7 @@ def coalescer_stats(dgraph):
     out = (C.c_uint64 * 6)()
     check(ffi.lib().mse_graph_coalescer_stats(dgraph._h, out), "graph_coalescer_stats")
     return {"queries": int(out[0]), "requests": int(out[1]), "passes": int(out[2]), "max_pass_queries": int(out[3]),
-            "deadline_fires": int(out[4])}
+            "deadline_fires": int(out[4]), "run_us": int(out[5])}
 
 
 def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, starts=None, luts=None, descriptor_scales=None,

@@ -111,6 +111,7 @@ SIGNATURES = {
     "mse_codes_free": (None, [vp]),
     "mse_codes_quantize_base": (vp, [vp, vp, u8p, sz]),
     "mse_pq_scan_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "mse_pq_scan_sustained": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mse_codes_len": (sz, [vp]),
     "mse_pq_adc_gather": (C.c_int, [vp, vp, f32p, f32p, u32p, sz, i64p]),
     "mse_pq_scan_topk": (C.c_int, [vp, vp, vp, f32p, f32p, sz, sz, i64p, u32p]),
@@ -138,6 +139,17 @@ SIGNATURES = {
     "mse_disk_search_batch_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, u32p, i64p, u32p, u32p, i64p, sz,
                                             u32p, u32p, u32p]),
     "mse_graph_set_entries": (C.c_int, [vp, vp, u32p, sz]),
+    "mse_disk_query_topk_block": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, C.c_uint64, vp, u32p, u32p, u32p]),
+    "mse_pq_scan_topk_block": (C.c_int, [vp, vp, vp, f32p, sz, f32p, sz, sz, C.c_uint64, vp]),
+    "mse_shard_group_base": (vp, [vp, sz]),
+    "mse_shard_group_first_row": (C.c_uint64, [vp, sz]),
+    "mse_comm_exchange_dev": (C.c_int, [vp, vp, vp, sz, sz, sz, vp, vp]),
+    "mse_comm_pq_scan_topk": (C.c_int, [vp, vp, vp, vp, f32p, f32p, sz, sz, sz, C.c_uint64, vp, vp]),
+    "mse_comm_query_topk": (C.c_int, [vp, vp, vp, vp, vp, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, C.c_uint64, vp, vp]),
+    "mse_shard_group_attach_pq": (C.c_int, [vp, sz, vp, vp]),
+    "mse_shard_group_attach_graph": (C.c_int, [vp, sz, vp]),
+    "mse_shard_group_pq_scan_topk": (C.c_int, [vp, f32p, f32p, sz, sz, sz, i64p, u32p]),
+    "mse_shard_group_query_topk": (C.c_int, [vp, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, i64p, u32p]),
     "mse_graph_set_entry_centroids": (C.c_int, [vp, f32p, sz, u32p, sz]),
     "mse_disk_query_topk_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
     "mse_graph_set_coalescer": (C.c_int, [vp, sz, C.c_uint32, C.c_int]),

@@ -35,6 +35,25 @@ class _BorrowedSearcher(Searcher):
         self._h = None
 
 
+class _BorrowedVectorList:
+    """A shard's rows, owned by its ShardGroup: what a codec / graph of the shard is built over."""
+
+    def __init__(self, handle, d):
+        self._h = handle
+        self.d_emb = d
+
+    def __len__(self):
+        return int(ffi.lib().mse_base_len(self._h))
+
+    def rows(self, first, n):
+        out = np.empty((n, self.d_emb), np.uint16)
+        check(ffi.lib().mse_base_read_rows(self._h, first, n, _p(out, C.c_uint16)), "mse_base_read_rows")
+        return out
+
+    def close(self):
+        self._h = None
+
+
 class ShardGroup:
     """Row-sharded index driven by one process: mse_shard_group (include/mse.h)."""
 
@@ -85,6 +104,54 @@ class ShardGroup:
 
     def bruteforce_topk_dev(self, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO):
         check(ffi.lib().mse_shard_group_search_dev(self._h, queries_dev, nq, k, mode, scores_dev, ids_dev), "mse_shard_group_search_dev")
+
+    # ---- the approximate-search paths over the same shards ----
+    def base(self, shard):
+        """The shard's rows (a borrowed VectorList): build the shard's codes / graph over it, on the shard's device
+        (mse.ffi.lib().mse_set_device(group.device(shard)) first when shards live on several devices)."""
+        return _BorrowedVectorList(check_ptr(ffi.lib().mse_shard_group_base(self._h, shard), "mse_shard_group_base"), self.d)
+
+    def first_row(self, shard):
+        return int(ffi.lib().mse_shard_group_first_row(self._h, shard))
+
+    def attach_pq(self, shard, quantizer, codes):
+        """The shard's codec and the PQ codes (+ descriptor bytes) of ITS rows; None, None detaches.  The group keeps references."""
+        check(ffi.lib().mse_shard_group_attach_pq(self._h, shard, quantizer._h if quantizer is not None else None,
+                                                  codes._h if codes is not None else None), "mse_shard_group_attach_pq")
+        self.__dict__.setdefault("_keep", {})[("pq", shard)] = (quantizer, codes)
+
+    def attach_graph(self, shard, dgraph):
+        """A graph over the shard's rows (DeviceGraph / BuildGraph, with its entry table set); None detaches."""
+        check(ffi.lib().mse_shard_group_attach_graph(self._h, shard, dgraph._h if dgraph is not None else None), "mse_shard_group_attach_graph")
+        self.__dict__.setdefault("_keep", {})[("graph", shard)] = dgraph
+
+    def pq_scan_topk(self, queries_f32, r, k, scales=None):
+        """ProductQuantizer.scan_topk_batch over the sharded codes with the unsharded call's answer bit for bit: the index's top-r by
+        ADC (exchange 1), exact fp16 re-score of each shard's members (exchange 2), top-k.  Returns (scores, global ids)."""
+        q = np.ascontiguousarray(queries_f32, np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32).reshape(-1)
+        scores, ids = np.empty((nq, k), np.int64), np.empty((nq, k), np.uint32)
+        check(ffi.lib().mse_shard_group_pq_scan_topk(self._h, _p(q, C.c_float), _p(sc, C.c_float) if sc is not None else None, nq, int(r), int(k),
+                                                     _p(scores, C.c_int64), _p(ids, C.c_uint32)), "mse_shard_group_pq_scan_topk")
+        return scores, ids
+
+    def query_topk(self, queries, k, luts=None, scales=None, disable_pq=True, beamwidth=4, search_list=64):
+        """disk_query_topk on every shard's own graph (its entry table, greedy_search, the k best visited records), one exchange,
+        merge by (score desc, id asc).  Returns (scores, global ids)."""
+        q = _bits(queries).reshape(-1, self.d)
+        nq = q.shape[0]
+        tables = None if luts is None else np.ascontiguousarray(luts, np.float32).reshape(nq, -1)
+        sc = None
+        if scales is not None:
+            sc = np.ascontiguousarray(scales, np.float32)
+            if sc.ndim == 1:
+                sc = np.ascontiguousarray(np.broadcast_to(sc, (nq, sc.size)))
+        scores, ids = np.empty((nq, k), np.int64), np.empty((nq, k), np.uint32)
+        check(ffi.lib().mse_shard_group_query_topk(self._h, _p(q, C.c_uint16), _p(tables, C.c_float) if tables is not None else None,
+                                                   _p(sc, C.c_float) if sc is not None else None, nq, int(bool(disable_pq)), int(beamwidth),
+                                                   int(search_list), int(k), _p(scores, C.c_int64), _p(ids, C.c_uint32)), "mse_shard_group_query_topk")
+        return scores, ids
 
     EXCHANGE_PEER, EXCHANGE_RCCL = 0, 1
 
@@ -148,6 +215,33 @@ class Comm:
     def search_dev(self, searcher, queries_dev, nq, k, scores_dev, ids_dev, mode=MODE_AUTO, id_offset=0):
         check(ffi.lib().mse_comm_search_dev(self._h, searcher._h, queries_dev, nq, k, mode, id_offset, scores_dev, ids_dev),
               "mse_comm_search_dev")
+
+    def exchange_dev(self, searcher, block_dev, nq, k_in, k, scores_dev, ids_dev):
+        """This rank's packed block of (score, global id) records -> one all-gather -> the k best per query (device pointers)."""
+        check(ffi.lib().mse_comm_exchange_dev(self._h, searcher._h, block_dev, nq, k_in, k, scores_dev, ids_dev), "mse_comm_exchange_dev")
+
+    def pq_scan_topk(self, quantizer, codes, searcher, queries_f32, r, k, first_row, scores_dev, ids_dev, scales=None):
+        """One rank of the sharded PQ scan + exact re-rank (two exchanges); outputs [nq, k] on this rank's device."""
+        q = np.ascontiguousarray(queries_f32, np.float32).reshape(-1, quantizer.n_dims)
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32).reshape(-1)
+        check(ffi.lib().mse_comm_pq_scan_topk(self._h, quantizer._h, codes._h, searcher._h, _p(q, C.c_float), _p(sc, C.c_float) if sc is not None else None,
+                                              q.shape[0], int(r), int(k), int(first_row), scores_dev, ids_dev), "mse_comm_pq_scan_topk")
+
+    def query_topk(self, searcher, dgraph, queries, k, first_row, scores_dev, ids_dev, quantizer=None, codes=None, luts=None, scales=None,
+                   disable_pq=True, beamwidth=4, search_list=64):
+        """One rank of the sharded graph index: this rank's graph answers the batch, one all-gather, merge; outputs on the device."""
+        if isinstance(queries, tuple):
+            q_ptr, nq = C.cast(C.c_void_p(int(queries[0])), C.POINTER(C.c_uint16)), int(queries[1])
+        else:
+            q = _bits(queries)
+            q = q.reshape(-1, q.shape[-1])
+            nq, q_ptr = q.shape[0], _p(q, C.c_uint16)
+        tables = None if luts is None else np.ascontiguousarray(luts, np.float32).reshape(nq, -1)
+        sc = None if scales is None else np.ascontiguousarray(scales, np.float32)
+        check(ffi.lib().mse_comm_query_topk(self._h, searcher._h, quantizer._h if quantizer is not None else None, codes._h if codes is not None else None,
+                                            dgraph._h, q_ptr, _p(tables, C.c_float) if tables is not None else None,
+                                            _p(sc, C.c_float) if sc is not None else None, nq, int(bool(disable_pq)), int(beamwidth), int(search_list),
+                                            int(k), int(first_row), scores_dev, ids_dev), "mse_comm_query_topk")
 
     def last_timing(self):
         """This rank's last search_dev in ms (waits for it): local search, all-gather (incl. waiting for the slowest rank), merge."""
@@ -227,3 +321,27 @@ def all_gather_topk(local_scores, local_ids, k, group=None):
     dist.all_gather(gs, local_scores.contiguous(), group=group)
     dist.all_gather(gi, local_ids.contiguous(), group=group)
     return merge_topk_torch(torch.cat(gs, 1), torch.cat(gi, 1), k)
+
+
+def two_phase_pq_scan(local_adc_topr, local_exact, lo, hi, r, k, group=None):
+    """Host restatement of the sharded PQ scan's protocol (csrc/shard_group.hip: mse_shard_group_pq_scan_topk / mse_comm_pq_scan_topk),
+    for the CPU (gloo) tests of the plumbing.  local_adc_topr() -> (scores int64 [nq, r], LOCAL ids uint32 [nq, r]) of this rank's
+    codes (ID_NONE = empty); local_exact(q, local_id) -> exact i64 score of this rank's row.  Rows [lo, hi) live here.
+      A  every rank's ADC top-r with global ids -> all-gather -> the index's top-r by (ADC score desc, id asc)
+      B  every rank scores ITS members of that list exactly, the others' slots stay empty -> all-gather -> top-k by (score desc, id asc)
+    Returns (scores [nq, k] int64, ids [nq, k] int64 holding u32 values), identical on every rank."""
+    import torch
+    s, i = local_adc_topr()
+    gid = np.where(i == 0xFFFFFFFF, np.int64(0xFFFFFFFF), i.astype(np.int64) + lo)
+    _, top_ids = all_gather_topk(torch.from_numpy(np.ascontiguousarray(s, np.int64)), torch.from_numpy(gid), r, group)
+    top_ids = top_ids.numpy()
+    nq = top_ids.shape[0]
+    ex_s = np.full((nq, r), np.iinfo(np.int64).min, np.int64)
+    ex_i = np.full((nq, r), 0xFFFFFFFF, np.int64)
+    for q in range(nq):
+        for j in range(r):
+            g = int(top_ids[q, j])
+            if g != 0xFFFFFFFF and lo <= g < hi:
+                ex_s[q, j] = local_exact(q, g - lo)
+                ex_i[q, j] = g
+    return all_gather_topk(torch.from_numpy(ex_s), torch.from_numpy(ex_i), k, group)

@@ -326,6 +326,13 @@ class ProductQuantizer:
         check(ffi.lib().mse_pq_scan_timing(self._h, enable, C.byref(ms), C.byref(n)), "pq_scan_timing")
         return float(ms.value), int(n.value)
 
+    def scan_sustained(self):
+        """(span_ms, scans) of the batch calls with at least four scans made while timing was on: first scan's start to last scan's
+        end -- the back-to-back cost of a pass (reset by scan_timing(2))."""
+        ms, n = C.c_double(), C.c_uint64()
+        check(ffi.lib().mse_pq_scan_sustained(self._h, C.byref(ms), C.byref(n)), "pq_scan_sustained")
+        return float(ms.value), int(n.value)
+
     @property
     def last_uncertified(self):
         """Queries of the last scan_topk_batch call that the four-query scan could not certify and repeated through the exact scan."""

@@ -1037,3 +1037,29 @@ def test_device_queries_written_by_another_stream(gpu, mse, orc):
     got = mse.disk_query_topk(searcher, None, None, dgraph, (qd.data_ptr(), nq), k, None, None, None, True, 2, L)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     torch.cuda.synchronize()
+
+
+def test_entry_step_small_and_large_batches_agree(gpu, mse, orc):
+    """The row-table entry step has two forms -- two launches of exact dots for a small batch, the brute-force searcher's matrix-core
+    path for a large one (nq x entries beyond 2^22) -- and both are the exact top-1 with ties to the lower row: a large batch, the
+    same queries in small calls, and the oracle's top-1 give the same start nodes (duplicate entry rows make ties certain)."""
+    rng = np.random.default_rng(43)
+    n, deg, E, nq, k, L = 9000, 10, 8000, 600, 5, 16
+    x = clustered_rows(orc, n, n_centres=48)
+    x[4000:4100] = x[100:200]                                          # duplicate rows: equal scores for every query
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    entry_ids = np.sort(rng.choice(n, E, replace=False)).astype(np.uint32)
+    mse.set_entries(dgraph, vecs, entry_ids)
+    qh = orc.f16_bits(clustered_rows(orc, nq, n_centres=48, seed=320))
+    qh[:20] = base[100:120]                                            # queries whose best entries are duplicated rows
+    _, best = orc.bruteforce_topk(base[entry_ids], qh, 1)
+    want = mse.disk_query_topk(searcher, None, None, dgraph, qh, k, entry_ids[best[:, 0]], None, None, True, 2, L)
+    large = mse.disk_query_topk(searcher, None, None, dgraph, qh, k, None, None, None, True, 2, L)           # 600 x 8000 > 2^22
+    assert np.array_equal(large[0], want[0]) and np.array_equal(large[1], want[1])
+    for q0 in (0, 17, 200):
+        small = mse.disk_query_topk(searcher, None, None, dgraph, qh[q0:q0 + 33], k, None, None, None, True, 2, L)
+        assert np.array_equal(small[0], want[0][q0:q0 + 33]) and np.array_equal(small[1], want[1][q0:q0 + 33])

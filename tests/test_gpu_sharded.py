@@ -299,3 +299,129 @@ def test_borrowed_base_rows_changed(gpu, mse, orc):
     got2 = s.bruteforce_topk(q, k, mse.MODE_MFMA)
     assert np.array_equal(got2[0], ws2) and np.array_equal(got2[1], wi2)
     assert not np.array_equal(wi, wi2)
+
+
+# ---- the approximate-search paths over the same shards (round 5) --------------------------------------------------------------
+
+def _ann_fixture(mse, orc, n, seed):
+    from test_gpu_pq_index_graph import clustered_rows, train_pq
+    x = clustered_rows(orc, n, n_centres=40, seed=seed)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:2000], iters=2)
+    return x, base, cents, T
+
+
+@pytest.mark.parametrize("no_peer", [False, True])
+def test_sharded_pq_scan_equals_the_unsharded_call_bit_for_bit(gpu, mse, orc, monkeypatch, no_peer):
+    """configs[4] over 8 logical shards (codes + descriptors + rows partitioned by shard_range): ADC top-r of every shard -> exchange
+    -> the index's top-r -> every shard re-scores ITS members exactly -> exchange -> top-k.  The merged result equals the unsharded
+    mse_pq_scan_topk_batch call bit for bit -- ids and i64 scores -- with and without descriptor scales, over both exchange paths
+    (peer stores; staged copies as for devices without a peer mapping), for batches that use the eight-, four- and two-query scans."""
+    if no_peer:
+        monkeypatch.setenv("MSE_SHARD_NO_PEER", "1")
+    rng = np.random.default_rng(51)
+    n, G, r, k = 20_011, 8, 60, 10
+    x, base, cents, T = _ann_fixture(mse, orc, n, 11)
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    vecs = mse.VectorList.from_f16s(base, D)
+    whole_codes = mse.Codes.quantize_base(pq, vecs, desc)
+    whole = mse.Searcher(vecs)
+    grp = mse.ShardGroup(G, D, devices=[0] * G)
+    grp.load_host(base)
+    keep = []
+    for g in range(G):
+        lo, hi = mse.shard_range(n, g, G)
+        assert grp.first_row(g) == lo and len(grp.base(g)) == hi - lo
+        codes_g = mse.Codes.quantize_base(pq, grp.base(g), desc[lo:hi])       # the shard's own codes, made from ITS resident rows
+        grp.attach_pq(g, pq, codes_g)
+        keep.append(codes_g)
+    from test_gpu_pq_index_graph import clustered_rows
+    qs = (clustered_rows(orc, 23, n_centres=40, seed=500) * np.float32(1.2)).astype(np.float32)
+    scales = np.array([0.5, 0, -0.25, 1.0], np.float32) / np.float32(512)
+    for sc in (None, scales):
+        for nq in (23, 3, 1):
+            want_s, want_i = pq.scan_topk_batch(whole_codes, qs[:nq], r, k, whole, sc)
+            got_s, got_i = grp.pq_scan_topk(qs[:nq], r, k, sc)
+            assert np.array_equal(got_i, want_i) and np.array_equal(got_s, want_s), (sc is not None, nq)
+    # and against the oracle's statement of configs[4] for one query: ADC over all codes, top-r (lower id on ties), exact re-score, top-k
+    opq = orc.PQ(cents, T, 18, D)
+    codes_h = opq.quantize_batch(orc.f16_to_f32(base))
+    adc = opq.asymmetric_dot_product(opq.preprocess_query(qs[0]), codes_h)
+    top_r = np.lexsort((np.arange(n), -adc))[:r]
+    exact = np.array([orc.fast_dot(orc.f16_bits(qs[0]), base[i]) for i in top_r], np.int64)
+    order = np.lexsort((top_r, -exact))[:k]
+    got_s, got_i = grp.pq_scan_topk(qs[:1], r, k, None)
+    assert np.array_equal(got_i[0], top_r[order].astype(np.uint32)) and np.array_equal(got_s[0], exact[order])
+    with pytest.raises(mse.MseError):
+        g2 = mse.ShardGroup(2, D, devices=[0, 0])
+        g2.load_host(base[:100])
+        g2.pq_scan_topk(qs[:2], r, k)                              # nothing attached
+    grp.close()
+
+
+def test_sharded_graph_query_equals_the_merge_of_per_shard_oracle_searches(gpu, mse, orc):
+    """One graph per shard over its own rows (the reference's shards), 8 logical shards: every shard answers the batch from ITS graph
+    with ITS entry table, one exchange, merge by (score desc, id asc).  Against the oracle: per shard the oracle's entry choice +
+    disk_greedy_search + sort of the visited list, ids lifted by the shard's first row, merged on the host."""
+    from test_gpu_pq_index_graph import clustered_rows, knn_graph
+    rng = np.random.default_rng(52)
+    n, G, deg, nq, k, L = 12_000, 8, 12, 21, 10, 24
+    x = clustered_rows(orc, n, n_centres=40, seed=12)
+    base = orc.f16_bits(x)
+    qh = orc.f16_bits(clustered_rows(orc, nq, n_centres=40, seed=501))
+    grp = mse.ShardGroup(G, D, devices=[0] * G)
+    grp.load_host(base)
+    shards = []
+    for g in range(G):
+        lo, hi = mse.shard_range(n, g, G)
+        adj, degs = knn_graph(x[lo:hi], deg, rng)
+        dg = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+        entries = np.sort(rng.choice(hi - lo, 16, replace=False)).astype(np.uint32)
+        mse.set_entries(dg, grp.base(g), entries)
+        grp.attach_graph(g, dg)
+        shards.append((lo, hi, adj, degs, entries, dg))
+    got_s, got_i = grp.query_topk(qh, k, None, None, True, 2, L)
+    all_s = np.full((nq, G * k), np.iinfo(np.int64).min, np.int64)
+    all_i = np.full((nq, G * k), 0xFFFFFFFF, np.uint32)
+    for g, (lo, hi, adj, degs, entries, _) in enumerate(shards):
+        rows = base[lo:hi]
+        _, best = orc.bruteforce_topk(rows[entries], qh, 1)
+        for q in range(nq):
+            _, vids, vsc, _, _ = orc.disk_greedy_search(rows, adj, degs, np.zeros((hi - lo, 64), np.uint8), np.zeros((hi - lo, 4), np.uint8),
+                                                         int(entries[best[q, 0]]), qh[q], np.zeros(64 * 256, np.float32), None, True, 2, L, None)
+            order = sorted(range(len(vids)), key=lambda j: (-int(vsc[j]), int(vids[j])))[:k]
+            all_s[q, g * k:g * k + len(order)] = vsc[order]
+            all_i[q, g * k:g * k + len(order)] = vids[order] + np.uint32(lo)
+    want_s, want_i = mse.shard.merge_topk_numpy(all_s, all_i, k)
+    assert np.array_equal(got_i, want_i) and np.array_equal(got_s, want_s)
+    grp.close()
+
+
+def test_comm_world_of_one_ann_paths(gpu, mse, orc):
+    """The one-process-per-GPU forms (mse_comm_pq_scan_topk / mse_comm_query_topk / mse_comm_exchange_dev) as a world of one: the
+    collective call path, both exchanges of the PQ protocol and the packed-block merge run, and the answers are the single-GPU calls'."""
+    import torch
+    from test_gpu_pq_index_graph import clustered_rows, knn_graph
+    rng = np.random.default_rng(53)
+    n, r, k, nq = 6000, 50, 10, 12
+    x, base, cents, T = _ann_fixture(mse, orc, n, 13)
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    vecs = mse.VectorList.from_f16s(base, D)
+    s = mse.Searcher(vecs)
+    codes = mse.Codes.quantize_base(pq, vecs)
+    qs = clustered_rows(orc, nq, n_centres=40, seed=502).astype(np.float32)
+    comm = mse.Comm(mse.Comm.unique_id(), 0, 1)
+    out_s = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int32, device="cuda")
+    comm.pq_scan_topk(pq, codes, s, qs, r, k, 1000, out_s.data_ptr(), out_i.data_ptr())        # rank's first row 1000: ids come back lifted
+    want_s, want_i = pq.scan_topk_batch(codes, qs, r, k, s)
+    assert np.array_equal(out_s.cpu().numpy(), want_s) and np.array_equal(out_i.cpu().numpy().view(np.uint32), want_i + np.uint32(1000))
+    adj, degs = knn_graph(x, 12, rng)
+    dg = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    mse.set_entries(dg, vecs, np.sort(rng.choice(n, 20, replace=False)).astype(np.uint32))
+    qh = orc.f16_bits(qs)
+    comm.query_topk(s, dg, qh, k, 77, out_s.data_ptr(), out_i.data_ptr(), disable_pq=True, beamwidth=2, search_list=24)
+    wi, ws, _ = mse.disk_query_topk(s, None, None, dg, qh, k, None, None, None, True, 2, 24)
+    assert np.array_equal(out_s.cpu().numpy(), ws) and np.array_equal(out_i.cpu().numpy().view(np.uint32), np.where(wi == 0xFFFFFFFF, wi, wi + np.uint32(77)))
+    comm.close()
