@@ -421,6 +421,15 @@ def pq_bench(args):
     for i in range(24):
         pq.scan_topk_batch(gc, qs[8 * (i % 4):8 * (i % 4) + 8], 200, 10, None, scales)
     k_ms, k_n = pq.scan_timing(0)
+    # ... and SUSTAINED: 64-query calls = eight scans back to back, alternating between two streams with the tails beside them;
+    # first scan's start to last scan's end over the scans of each call (mse_pq_scan_sustained)
+    pq.scan_timing(2)
+    for _ in range(12):
+        pq.scan_topk_batch(gc, qs64, 200, 10, None, scales)
+    span_ms, span_n = pq.scan_sustained()
+    pq.scan_timing(0)
+    sus_ms = span_ms / max(span_n, 1)
+    gbs_sustained = n * 68 / (sus_ms * 1e-3) / 1e9 if span_n else None
     per_pass = 8
     gbs_pass = n * 68 / (per_pass * db) / 1e9
     k_avg = k_ms / max(k_n, 1)
@@ -438,18 +447,24 @@ def pq_bench(args):
             "at_64_per_call": {"ms_per_query": db64 * 1e3, "queries_per_s": 1.0 / db64, "end_to_end_frac": n * 68 / (8 * db64) / 1e9 / HBM_PEAK_GBS},
             "uncertified_queries_last_batch": uncert,
             "codes_GBps_end_to_end_one_query_per_call": n * 68 / dt / 1e9, "unit": "GB/s of codes + descriptor bytes",
-            "roofline": {"bound": "hbm", "kernel": "pq_scan64x4_kernel<16>", "achieved": gbs_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (gbs_kernel / HBM_PEAK_GBS) if gbs_kernel else None, "avg_launch_ms": k_avg, "launches_timed": k_n,
+            "roofline": {"bound": "hbm", "kernel": "pq_scan64x4_kernel<16, 8>", "achieved": gbs_sustained, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (gbs_sustained / HBM_PEAK_GBS) if gbs_sustained else None, "avg_launch_ms": sus_ms, "launches_timed": span_n,
+                         "frac_is": "SUSTAINED: scans back to back (64-query calls: eight scans on two streams, tails beside them), first scan's "
+                                    "start to last scan's end / scans; profiles/r05_pq_scan_stats.txt holds the rocprofv3 trace of the same calls",
+                         "burst": {"achieved": gbs_kernel, "frac": (gbs_kernel / HBM_PEAK_GBS) if gbs_kernel else None, "avg_launch_ms": k_avg, "launches_timed": k_n,
+                                   "note": "one scan per call with nothing before or beside it (eight-query calls): the device has paused before every launch"},
                          "bytes_per_launch": n * 68, "queries_per_launch": per_pass, "traffic": traffic,
                          "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
                          "end_to_end": {"achieved": gbs_pass, "frac": gbs_pass / HBM_PEAK_GBS,
                                         "note": "68 B x vectors / (8 x batched per-query time): table build, scan, tournament, re-score of the nominated "
                                                 "groups, exact top-r, certificate, download -- two streams, one group of eight queries each"},
-                         "note": "achieved = 68 B x vectors per launch / the kernel's HIP-event duration in 24 eight-query calls (one stream: nothing runs "
-                                 "beside the scan; in the 32-query calls two streams interleave and a launch's event interval would include its wait "
-                                 "for the other stream's scan).  Round 4 kernel: bank-conflict-free rotated gathers, sums on the matrix cores "
+                         "note": "achieved = 68 B x vectors per launch / the kernel's sustained cost per launch (above); `burst` = its HIP-event duration "
+                                 "in 24 eight-query calls.  Kernel: bank-conflict-free rotated gathers, sums on the matrix cores "
                                  "(v_mfma_i32_16x16x64_i8), eight queries per pass with 8-bit tables under a certificate -- DESIGN.md 3.3"},
             "config": {"workload": f"{n} x (64 B codes + 4 B descriptors), eight queries' 8-bit tables (code-major, 138 KiB) in LDS, r = 200"}}
+
+
+from bench_ann import train_codec, easy_generator as clustered_generator  # noqa: E402  (the synthetic sets live in bench_ann.py)
 
 
 def graph_rows(n, seed, centres):
@@ -465,27 +480,6 @@ def graph_centres(n):
     import numpy as np
     c = np.random.default_rng(0).standard_normal((max(64, n // 50), D)).astype(np.float32)
     return c / np.linalg.norm(c, axis=1, keepdims=True)
-
-
-def train_codec(samp, seed=4, iters=3):
-    """OPQ-shaped 64 x 256 codec in aopq_train.py's layout (a rotation + per-subspace max-inner-product k-means), trained on the
-    host over a small sample: -> (centroids [256, 1152], transform [1152, 1152])."""
-    import numpy as np
-    rng = np.random.default_rng(seed)
-    T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
-    ts = samp @ T.T
-    cents = np.zeros((256, D), np.float32)
-    for i in range(64):
-        sub = ts[:, i * 18:(i + 1) * 18]
-        c = sub[rng.choice(len(sub), 256, replace=False)].copy()
-        for _ in range(iters):
-            asg = np.argmax(sub @ c.T, axis=1)
-            for j in range(256):
-                mem = sub[asg == j]
-                if len(mem):
-                    c[j] = mem.mean(axis=0)
-        cents[:, i * 18:(i + 1) * 18] = c
-    return cents, T
 
 
 def graph_bench(args):
@@ -571,30 +565,6 @@ def graph_bench(args):
             "build": build, "pq_rerank": rerank, "results": out}
 
 
-def clustered_generator(n):
-    """Synthetic hierarchical clusters made on the device (rows/50 centres around rows/5000 super-centres, noise 0.3; unit-norm fp16
-    rows): -> f(m, seed) returning an [m, 1152] fp16 device tensor drawn from the same mixture."""
-    import torch
-    g0 = torch.Generator(device="cuda").manual_seed(0)
-    hier = max(8, n // 5000)
-    sup = torch.randn(hier, D, device="cuda", generator=g0)
-    sup /= sup.norm(dim=1, keepdim=True)
-    nc_ = max(64, n // 50)
-    centres = sup[torch.randint(0, hier, (nc_,), device="cuda", generator=g0)] + torch.randn(nc_, D, device="cuda", generator=g0) * (0.7 / D ** 0.5)
-    centres /= centres.norm(dim=1, keepdim=True)
-
-    def clustered(m, seed):
-        g = torch.Generator(device="cuda").manual_seed(seed)
-        out = torch.empty(m, D, device="cuda", dtype=torch.float16)
-        for i in range(0, m, 1 << 18):
-            c = min(1 << 18, m - i)
-            x = centres[torch.randint(0, nc_, (c,), device="cuda", generator=g)] + torch.randn(c, D, device="cuda", generator=g) * (0.3 / D ** 0.5)
-            out[i:i + c] = (x / x.norm(dim=1, keepdim=True)).half()
-        return out
-
-    return clustered
-
-
 def pq_rerank_leg(rows, vecs, s, queries, truth, K=10, r=200, per_call=32):
     """BASELINE configs[4] as specified, on a quantisable set resident in HBM: OPQ/PQ 64 x 8-bit codes of the rows (codec trained on
     a 20 000-row sample, codes made on the device), flat ADC scan of ALL codes, the r best by approximate score re-scored exactly
@@ -661,155 +631,6 @@ def ann_scale_bench(args):
     return out
 
 
-def graph_scale_bench(args):
-    """The metric's other reading -- queries/s at recall@10 >= 0.95 through the graph index -- under the driver's clock at 1e7 rows
-    (BASELINE configs[2]'s size; the 1e8-row runs are in profiles/).  Synthetic hierarchical clusters made on the device
-    (rows/50 centres around rows/5000 super-centres, noise 0.3: scripts/graph_scale_bench.py), ONE Vamana pass with
-    generate-index-shard's defaults (R 64, L 192, C 750) on the device, then the GPU-resident beam search
-    (the request path in one call, mse_disk_query_topk: entry by the entry table, query_disk_index::greedy_search with beam 4 and
-    exactly scored neighbours, the visited records cut to the first 10) for 4096 held-out queries per call, host arrays in and out:
-    reported at the smallest search list whose recall@10 against the exact brute-force top-10 reaches 0.95."""
-    import numpy as np
-    import torch
-    import mse
-    n, nq, K, R, batch = int(args.graph_scale_rows), 12288, 10, 64, int(args.graph_batch)   # 4096 tuning + 2 x 4096 held-out queries (the second 4096 only for the two-thread figure): one wave per query puts 4096 searches on the chip at once (scripts/beam_batch_probe.py: 0.62 / 0.94 / 1.10 / 1.19 M queries/s at 1024 / 2048 / 4096 / 8192 per call, 2e6 rows)
-    clustered = clustered_generator(n)
-    rows, queries = clustered(n, 1), clustered(nq, 2)
-    torch.cuda.synchronize()
-    vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, D, keepalive=rows)
-    s = mse.Searcher(vecs)
-    t0 = time.perf_counter()
-    med = mse.medioid(vecs)
-    g = mse.BuildGraph(n, R)
-    g.random_fill(1)
-    order = np.random.default_rng(3).permutation(n).astype(np.uint32)
-    g.build(s, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
-    for _ in range(int(args.graph_passes) - 1):    # generate-index-shard's optional second pass (-s), same factors
-        g.build(s, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
-    t_build = time.perf_counter() - t0
-    qh = queries.cpu().numpy().view(np.uint16)
-    t0 = time.perf_counter()
-    _, truth = s.bruteforce_topk(qh, K)
-    t_exact = time.perf_counter() - t0
-    # operating point chosen on the FIRST half of the queries (smallest search list whose recall@10 there reaches 0.95 + 0.01),
-    # reported on the SECOND half (held out): timing and recall of the headline figure never saw the tuning queries
-    half = nq // 3
-    tune, held, held2 = slice(0, half), slice(half, 2 * half), slice(half, nq)
-
-    # Entry points.  The reference starts a search at the medioid of the shard whose centroid is closest to the query
-    # (src/query_disk_index.rs:254-256,447-450).  Here the graph is ONE piece; the same idea without shards: `n_entry` sampled base
-    # rows stand in for the shard medioids and a search starts at the sample row with the largest dot product with its query (an
-    # exact top-1 over the sample, inside the timed region).  With the medioid alone as entry a one-pass graph over 1e8 clustered
-    # rows needs search lists beyond 200 to reach 0.95 (0.924 at L = 200, profiles/r04_graph_index_1e8.json).
-    n_entry = int(args.graph_entries)
-    if n_entry < 0:      # auto: about one entry per 1500 rows -- a few per top-level cluster of the synthetic set at any size
-        n_entry = max(4096, n // 1500)
-    if n_entry > 0:
-        e_idx = np.sort(np.random.default_rng(5).choice(n, min(n_entry, n), replace=False)).astype(np.uint32)
-        mse.set_entries(g, vecs, e_idx)      # copies of the entry rows stay with the graph; the top-1 runs on the device inside the call
-
-    def run(L, sl, timed):
-        # ONE call = the request path for the batch (mse_disk_query_topk): f16 queries up, entry node by the entry table, beam search,
-        # the visited records by exact score cut to the first K, K ids and scores per query down
-        m = sl.stop - sl.start
-        st = None if n_entry > 0 else np.full(m, med, np.uint32)
-        if timed:   # warm: scratch is allocated on first use
-            mse.disk_query_topk(s, None, None, g, qh[sl], K, st, None, None, True, 4, L)
-        t0 = time.perf_counter()
-        top, _, stats = mse.disk_query_topk(s, None, None, g, qh[sl], K, st, None, None, True, 4, L)
-        dt = time.perf_counter() - t0
-        rec = sum(len(set(top[i].tolist()) & set(truth[sl.start + i].tolist())) for i in range(m)) / (K * m)
-        return {"search_list": L, "queries": m, "queries_per_s": m / dt, "recall_at_10": rec, "node_fetches_per_query": float(stats["cmps"].mean())}
-
-    sweep, chosen = [], None
-    for L in (12, 16, 24, 32, 48, 64, 100, 200, 400, 800):
-        pt = run(L, tune, False)
-        sweep.append({"search_list": L, "tuning_recall_at_10": pt["recall_at_10"]})
-        if pt["recall_at_10"] >= 0.97:
-            chosen = run(L, held, True)
-            break
-    if chosen is None:
-        # no search list reached 0.97 on the tuning queries (a one-pass graph over 1e8 clustered rows tops out near 0.965): the smallest
-        # one with at least 0.955 there, labelled by its own held-out recall
-        for pt in sweep:
-            if pt["tuning_recall_at_10"] >= 0.955:
-                chosen = run(pt["search_list"], held, True)
-                break
-    # the same call with the queries already on the device (embeddings that never left the GPU): what the pageable upload costs
-    dev_q = None
-    if chosen:
-        try:
-            L = chosen["search_list"]
-            hq = qh[held]
-            qd = torch.from_numpy(np.ascontiguousarray(hq).view(np.int16)).cuda()
-            stq = None if n_entry > 0 else np.full(len(hq), med, np.uint32)
-            mse.disk_query_topk(s, None, None, g, (qd.data_ptr(), len(hq)), K, stq, None, None, True, 4, L)
-            t0 = time.perf_counter()
-            topd = mse.disk_query_topk(s, None, None, g, (qd.data_ptr(), len(hq)), K, stq, None, None, True, 4, L)[0]
-            dtd = time.perf_counter() - t0
-            recd = sum(len(set(topd[i].tolist()) & set(truth[held.start + i].tolist())) for i in range(len(hq))) / (K * len(hq))
-            dev_q = {"queries_per_s": len(hq) / dtd, "recall_at_10": recd, "queries": len(hq), "note": "f16 queries resident in HBM, k ids + scores per query to the host"}
-        except Exception as e:  # noqa: BLE001
-            dev_q = {"error": repr(e)}
-    # 2 x 4096 held-out queries from TWO request threads, each with its own searcher (scratch + stream) and its own 4096 queries, three
-    # calls each: one thread's upload of 4.7 MB of queries and its host-side work overlap the other's kernels -- the request handler's
-    # shape with more than one request in flight.  Recall is that of the one-call figure (the same searches).
-    two = None
-    if chosen:
-        try:
-            import threading
-            L = chosen["search_list"]
-            hq = qh[held2]
-            parts = [hq[: len(hq) // 2], hq[len(hq) // 2:]]
-            st2 = [None if n_entry > 0 else np.full(len(p), med, np.uint32) for p in parts]
-            s2 = [s, mse.Searcher(vecs)]
-            outs = [None, None]
-            reps = 3
-
-            def worker(i, count):
-                for _ in range(count):
-                    outs[i] = mse.disk_query_topk(s2[i], None, None, g, parts[i], K, st2[i], None, None, True, 4, L)[0]
-
-            for i in range(2):
-                worker(i, 1)          # warm each searcher's scratch
-            th = [threading.Thread(target=worker, args=(i, reps)) for i in range(2)]
-            t0 = time.perf_counter()
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            dt2 = time.perf_counter() - t0
-            top2 = np.concatenate(outs)
-            m = len(hq)
-            rec2 = sum(len(set(top2[i].tolist()) & set(truth[held2.start + i].tolist())) for i in range(m)) / (K * m)
-            two = {"threads": 2, "queries_per_call": len(parts[0]), "calls_per_thread": reps, "queries_per_s": reps * m / dt2, "recall_at_10": rec2}
-            s2[1].close()
-        except Exception as e:  # noqa: BLE001
-            two = {"error": repr(e)}
-    g.close()
-    # BASELINE configs[4] as specified, on this quantisable set (pq_rerank_leg); queries go through 32 per call, eight per pass
-    try:
-        rerank = pq_rerank_leg(rows, vecs, s, queries[:half], truth[:half], K)
-    except Exception as e:  # noqa: BLE001
-        rerank = {"error": repr(e)}
-    # the figure: the two-request-thread rate when it was measured and is the higher one, else the single call's
-    best = chosen
-    if chosen and two and two.get("queries_per_s", 0) > chosen["queries_per_s"]:
-        best = {"queries_per_s": two["queries_per_s"], "recall_at_10": two["recall_at_10"]}
-    return {"metric": f"queries/sec over a {n:.0e}x1152 graph index @ recall@10>=0.95 (GPU-resident beam search)", "pq_rerank": rerank,
-            "value": best["queries_per_s"] if best else None, "unit": "queries/s", "recall_at_10": best["recall_at_10"] if best else None,
-            "value_is": ("two request threads x 4096 queries per call" if best is not chosen else "one call of 4096 queries") if best else None,
-            "one_call": {"queries_per_s": chosen["queries_per_s"], "recall_at_10": chosen["recall_at_10"], "queries": chosen["queries"],
-                         "node_fetches_per_query": chosen["node_fetches_per_query"]} if chosen else None,
-            "search_list": chosen["search_list"] if chosen else None, "beamwidth": 4, "batch": half, "sweep": sweep, "two_request_threads": two, "one_call_device_queries": dev_q,
-            "operating_point": "search list picked on queries 0..%d (tuning recall >= 0.97), value / recall measured on the held-out queries %d..%d (two_request_threads: %d..%d)" % (half - 1, half, 2 * half - 1, half, nq - 1),
-            "build": {"seconds": t_build, "points_per_s": n * int(args.graph_passes) / t_build, "passes": int(args.graph_passes), "r": R, "l": 192, "maxc": 750, "batch": batch},
-            "exact_scan_same_index_queries_per_s": nq / t_exact,
-            "entry_points": (f"{n_entry} sampled base rows; a search starts at the one with the largest dot product with its query (exact top-1, timed); "
-                             "the reference: medioid of the closest shard, src/query_disk_index.rs:447-450") if n_entry > 0 else "the medioid",
-            "config": {"workload": f"{n} x {D} fp16 hierarchical synthetic clusters, one-pass Vamana graph built on the device"}}
-
-
 def cpu_graph_build(n, points=192):
     """CPU side of the build line: the oracle's build_graph (batch form) on a bounded sample of the same workload --
     `points` insertions into the same random initial graph over the same rows, one thread."""
@@ -852,6 +673,20 @@ def siglip_bench(args, world, rank, dist=None):
         t = torch.tensor([dt], dtype=torch.float64)       # the control-plane group is gloo (CPU tensors)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # small batches: the query path sends ONE text (src/query_disk_index.rs:345-381) and a handful of images at a time; median of 15 calls
+    import numpy as np
+
+    def med_ms(fn, reps=15):
+        fn()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        return float(np.median(ts))
+    latency = {"image": {str(b): med_ms(lambda b=b: eng.encode_image_device(img.data_ptr(), b)) for b in (1, 8, 32) if b <= batch}}
     server = None
     if rank == 0 and world == 1:
         try:
@@ -869,10 +704,20 @@ def siglip_bench(args, world, rank, dist=None):
     for _ in range(5):
         teng.encode_text(tok)
     text_dt = (time.perf_counter() - tt0) / 5
+    latency["text"] = {str(b): med_ms(lambda b=b: teng.encode_text(tok[:b])) for b in (1, 8, 32)}
+    # what a forward cannot go below at small batch: every weight read once from HBM (bf16): 27 blocks x (4 d^2 + 2 d mlp) + patch / token embedding rows used
+    w_img = (27 * (4 * 1152 * 1152 + 2 * 1152 * 4304) + 588 * 1152 + 4 * 1152 * 1152 + 2 * 1152 * 4304) * 2
+    w_txt = (27 * (4 * 1152 * 1152 + 2 * 1152 * 4304) + 1152 * 1152) * 2
+    latency["weight_stream_floor_ms"] = {"image": w_img / 8e12 * 1e3, "text": w_txt / 8e12 * 1e3,
+                                         "note": "bf16 weights of one forward read once at 8 TB/s"}
+    latency["image_b1_over_floor"] = latency["image"]["1"] / latency["weight_stream_floor_ms"]["image"] if "1" in latency["image"] else None
+    latency["text_b1_over_floor"] = latency["text"]["1"] / latency["weight_stream_floor_ms"]["text"]
     teng.close()
     text = {"metric": "SigLIP text-embeds/sec/GPU", "value": 256 / text_dt, "unit": "texts/s/GPU", "ms_per_batch": text_dt * 1e3,
             "config": {"workload": "SigLIP-SO400M text tower, batch 256 x 64 tokens (host token ids in, host features out)"},
-            "tflops": 256 / text_dt * 27 * 1.968e9 / 1e12}
+            "tflops": 256 / text_dt * 27 * 1.968e9 / 1e12,
+            "roofline": {"bound": "mfma", "achieved": 256 / text_dt * 27 * 1.968e9 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": 256 / text_dt * 27 * 1.968e9 / 1e12 / 2500.0, "flop_per_text": 27 * 1.968e9}}
     per_gpu = batch * args.siglip_steps / dt
     gflop_img = 0.988 + 27 * 24.647 + 3.9                     # 670.4 GFLOP per image
     tflops = per_gpu * gflop_img / 1e3
@@ -889,7 +734,7 @@ def siglip_bench(args, world, rank, dist=None):
             "ms_per_batch": dt / args.siglip_steps * 1e3, "dtype": "bf16 (fp32 accumulate; fp16 residual stream, fp32 LayerNorm/softmax/GELU)",
             "config": {"workload": f"SigLIP-SO400M/14-384 image tower, batch {batch} random 384x384, 1 replica per GPU",
                        "weights": "random-init (seeded), architecture of ViT-SO400M-14-SigLIP-384"},
-            "steps": args.siglip_steps, "scaling": "weak (replicas)", "text_tower": text,
+            "steps": args.siglip_steps, "scaling": "weak (replicas)", "text_tower": text, "latency_ms": latency,
             "server_images_per_s": (server or {}).get("value"), "server": server,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
                          "flop_per_image": gflop_img * 1e9, "traffic": sig_traffic,
@@ -1042,6 +887,9 @@ def main():
     ap.add_argument("--graph-batch", type=int, default=4096, help="points inserted per batch of the graph-scale build")
     ap.add_argument("--graph-entries", type=int, default=-1,
                     help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
+    ap.add_argument("--graph-kinds", default="easy,hard,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")
+    ap.add_argument("--no-sharded-ann", action="store_true", help="--gpus N > 1: skip the sharded PQ-scan / graph-index legs")
+    ap.add_argument("--ann-rows-per-gpu", type=float, default=2e6, help="--gpus N > 1: rows per GPU of the sharded approximate-search legs")
     ap.add_argument("--siglip-batch", type=int, default=256)
     ap.add_argument("--siglip-steps", type=int, default=10)
     args = ap.parse_args()
@@ -1334,6 +1182,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # --gpus N > 1: the approximate-search paths over the same kind of shards (rows AND their codes / graphs partitioned), same exchange
+    sharded_ann = None
+    if n_gpus > 1 and not args.no_sharded_ann:
+        import bench_ann
+        try:
+            with _stdout_to_stderr():
+                if in_process:
+                    sharded_ann = bench_ann.sharded_ann_inprocess(n_gpus, n_dev, int(args.ann_rows_per_gpu))
+                elif comm is not None:
+                    sharded_ann = bench_ann.sharded_ann_rank(comm, dist, rank, world, int(args.ann_rows_per_gpu))
+                else:
+                    sharded_ann = {"skipped": "RCCL did not come up (the brute-force line fell back to a gloo exchange)"}
+        except Exception as e:  # noqa: BLE001
+            sharded_ann = {"error": repr(e)}
+        ffi.check(ffi.lib().mse_set_device(local_rank), "mse_set_device")
+
     callers_line = None
     if rank == 0 and n_gpus == 1 and world == 1 and not args.no_callers:
         try:
@@ -1384,10 +1248,22 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
     if rank == 0 and n_gpus == 1 and not args.no_graph_scale:
-        try:
-            gscale_line = graph_scale_bench(args)
-        except Exception as e:  # noqa: BLE001
-            gscale_line = {"error": repr(e)}
+        # one row per synthetic set (bench_ann.py): easy (rounds 1-4), hard (no micro-clusters), ood (queries from another distribution,
+        # graph built with a query sample + robust_stitch); the request path's call shape (T threads x 1 query) on the hard set
+        import gc
+        import bench_ann
+        gscale_line = {"metric": f"queries/sec over a {int(args.graph_scale_rows):.0e}x1152 graph index @ recall@10>=0.95 (GPU-resident beam search)", "unit": "queries/s", "sets": {}}
+        for kind in [x for x in args.graph_kinds.split(",") if x]:
+            try:
+                gscale_line["sets"][kind] = bench_ann.graph_index_bench(ROOT, kind, int(args.graph_scale_rows), batch=int(args.graph_batch),
+                                                                        passes=int(args.graph_passes), callers=(kind == "hard" and not args.no_callers))
+            except Exception as e:  # noqa: BLE001
+                gscale_line["sets"][kind] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
+        head = (gscale_line["sets"].get("hard") or {}).get("exact_scored", {}).get("held_out") or {}
+        gscale_line.update({"value": head.get("queries_per_s"), "recall_at_10": head.get("recall_at_10"), "search_list": head.get("value"),
+                            "value_is": "the HARD set, exactly scored neighbours, one call of 4096 held-out queries"})
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -1450,6 +1326,49 @@ def main():
             "hbm_bound_point": alt,
             "certificate": stats,
         }
+        # every headline scalar of the side legs once more, compact, INSIDE the roofline object (the part of the line the driver's record
+        # keeps whole): [queries/s, recall@10, search list or r] for the approximate paths
+        def g(o, *path):
+            for p_ in path:
+                o = o.get(p_) if isinstance(o, dict) else None
+            return o
+
+        def rnd(v, nd=4):
+            return round(v, nd) if isinstance(v, float) else v
+        legs = {"hbm_bound_point": {"queries_per_pass": 128, "frac": rnd(g(alt, "roofline", "frac")), "queries_per_s": rnd(g(alt, "value"), 1)},
+                "concurrent_callers_1e8": {"threads": g(callers_line, "threads"), "queries_per_s": rnd(g(callers_line, "queries_per_s"), 1),
+                                           "vs_headline": rnd(g(callers_line, "vs_resident_batch_headline"))},
+                "shard_point": {"ms_per_step": rnd(g(shard_line, "ms_per_step")), "frac": rnd(g(shard_line, "roofline", "frac")),
+                                "projected_8gpu_efficiency": rnd(g(shard_line, "projected_8gpu", "efficiency_vs_one_gpu_1e8"))},
+                "siglip": {"img_per_s": rnd(g(siglip_line, "value"), 1), "frac": rnd(g(siglip_line, "roofline", "frac")),
+                           "text_per_s": rnd(g(siglip_line, "text_tower", "value"), 1), "text_frac": rnd(g(siglip_line, "text_tower", "roofline", "frac")),
+                           "server_img_per_s": rnd(g(siglip_line, "server_images_per_s"), 1), "latency_ms": g(siglip_line, "latency_ms")},
+                "pq_scan_1e8": {"kernel_frac_sustained": rnd(g(pq_line, "roofline", "frac")), "kernel_frac_burst": rnd(g(pq_line, "roofline", "burst", "frac")),
+                                "end_to_end_frac": rnd(g(pq_line, "roofline", "end_to_end", "frac")), "queries_per_s": rnd(g(pq_line, "queries_per_s_batched"), 1)},
+                "ann_1e8": [rnd(g(ann_line, "queries_per_s"), 1), rnd(g(ann_line, "recall_at_10")), g(ann_line, "r")],
+                "index_callers_1e5_qps": rnd(g(index_line, "queries_per_s"), 1)}
+        if gscale_line:
+            gi = {}
+            for kind, row in (gscale_line.get("sets") or {}).items():
+                def pt(key):
+                    h = g(row, key, "held_out")
+                    return [rnd(g(h, "queries_per_s"), 1), rnd(g(h, "recall_at_10")), g(h, "value")] if h else None
+                gi[kind] = {"exact": pt("exact_scored"), "exact_ref_entry": pt("exact_scored_reference_entry_rule"), "adc": pt("adc_scored"),
+                            "pq_rerank": pt("pq_rerank"), "pq_only_recall": rnd(g(row, "pq_only_recall_at_10")),
+                            "rc": rnd(g(row, "hardness", "relative_contrast_at_10"), 3), "lid": rnd(g(row, "hardness", "lid_mle_k20"), 1),
+                            "build_s": rnd(g(row, "build", "seconds"), 1)}
+                gc_ = g(row, "graph_callers", "points")
+                if gc_:
+                    gi[kind]["callers"] = {str(p_["threads"]): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
+                                                                rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in gc_}
+                    pt_ = g(row, "graph_callers", "perf_test_py_shape")
+                    if pt_:
+                        gi[kind]["callers"]["perf_test_100x1000"] = [rnd(pt_["queries_per_s"], 1), rnd(pt_["latency_ms"]["p50"], 3), rnd(pt_["latency_ms"]["p99"], 3)]
+            legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; callers: [queries/s, p50 ms, p99 ms, vs one call of 4096]")
+        if sharded_ann:
+            legs["sharded_ann"] = {"pq_qps": rnd(g(sharded_ann, "pq_scan_rerank", "queries_per_s"), 1), "pq_equal_unsharded": g(sharded_ann, "pq_scan_rerank", "equals_the_unsharded_call_bit_for_bit"),
+                                   "graph_qps": rnd(g(sharded_ann, "graph_index", "queries_per_s"), 1), "graph_equal_merge": g(sharded_ann, "graph_index", "equals_the_merge_of_per_shard_calls")}
+        line["roofline"]["legs"] = legs
         if callers_line:
             line["concurrent_callers"] = callers_line
         if index_line:
@@ -1466,6 +1385,8 @@ def main():
             line["ann_1e8"] = ann_line
         if gscale_line:
             line["graph_index_1e7"] = gscale_line
+        if sharded_ann:
+            line["sharded_ann"] = sharded_ann
         if note:
             line["note"] = note
         # not measured by this command (the build takes 20 minutes): the same 1e8-row index served through the graph path

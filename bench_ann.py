@@ -219,6 +219,43 @@ def train_codec(samp, seed=4, iters=3):
     return cents, T
 
 
+def train_codec_opq(rows, n_base, sample=100_000, iters=4, seed=4):
+    """The codec as aopq_train.py shapes it -- a LEARNED rotation in front of 64 sub-quantisers of 256 centroids -- trained on the
+    device over a row sample: the rotation is the parametric OPQ solution (eigenvectors of the sample's second-moment matrix dealt out
+    to the 64 subspaces so that their energies balance: largest remaining eigenvalue to the subspace with the least energy that
+    still has room), then max-inner-product k-means per subspace.  A random rotation (train_codec) spreads a low-rank signal thinly
+    over every subspace and leaves the sub-quantisers little to hold on to.  -> (centroids [256, 1152], transform [1152, 1152])."""
+    import numpy as np
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    idx = torch.randint(0, n_base, (min(sample, n_base),), device="cuda", generator=g)
+    x = rows[idx].float()
+    cov = (x.T @ x) / x.shape[0]
+    evals, evecs = torch.linalg.eigh(cov.double())
+    order = torch.argsort(evals, descending=True).cpu().numpy()
+    ev = evals.cpu().numpy()
+    energy, slots = np.zeros(64), [[] for _ in range(64)]
+    for j in order:
+        open_ = [m for m in range(64) if len(slots[m]) < 18]
+        m = min(open_, key=lambda m_: energy[m_])
+        slots[m].append(int(j))
+        energy[m] += max(float(ev[j]), 0.0)
+    cols = [j for m in range(64) for j in slots[m]]
+    T = evecs[:, cols].T.float().contiguous()                 # rows of T = the directions; transformed = T @ v
+    ts = x @ T.T
+    cents = torch.zeros(256, D, device="cuda")
+    for m in range(64):
+        sub = ts[:, m * 18:(m + 1) * 18]
+        c = sub[torch.randperm(sub.shape[0], device="cuda", generator=g)[:256]].clone()
+        for _ in range(iters):
+            asg = torch.argmax(sub @ c.T, dim=1)
+            sums = torch.zeros(256, 18, device="cuda").index_add_(0, asg, sub)
+            cnt = torch.zeros(256, device="cuda").index_add_(0, asg, torch.ones_like(asg, dtype=torch.float32))
+            c = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp(min=1), c)
+        cents[:, m * 18:(m + 1) * 18] = c
+    return cents.cpu().numpy().astype(np.float32), T.cpu().numpy().astype(np.float32)
+
+
 def shard_centroid_entries(rows, n_base, n_shards=64, sample=200_000, seed=7):
     """Stand-ins for the index header's shards (centroid + start node each, src/query_disk_index.rs:254-256,447-450) over a one-piece
     index: k-means centroids (spherical, two Lloyd rounds on a row sample) and, per centroid, the sample row closest to it as the
@@ -336,9 +373,9 @@ def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget
     out["exact_scored_reference_entry_rule"] = dict(pick(run_cen, grid_L), entry=f"{len(med_ids)} shard centroids (k-means of a row sample) -> the shard's medioid; "
                                                     "scale_dot_result_f64(dot(centroid, query)), last maximum (src/query_disk_index.rs:447-450)", beamwidth=4)
     # (3) the reference's default: neighbours scored by ADC (64 x 8-bit OPQ codes, 64 KiB table per query in LDS), fetched nodes exactly
-    rng = np.random.default_rng(4)
-    sel = torch.from_numpy(np.sort(rng.choice(n, min(n, 20000), replace=False))).cuda()
-    cents, T = train_codec(rows[sel].float().cpu().numpy())
+    t0 = time.perf_counter()
+    cents, T = train_codec_opq(rows, n)
+    t_codec = time.perf_counter() - t0
     pq = mse.ProductQuantizer(cents, T, 18, D)
     t0 = time.perf_counter()
     codes = mse.Codes.quantize_base(pq, vecs)
@@ -364,7 +401,9 @@ def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget
         out["pq_rerank"] = pick(run_pq, (50, 100, 200, 400, 800, 1600))
         adc_only = np.concatenate([pq.scan_topk_batch(bcodes, qt32[i:i + 64], K, K, None)[1] for i in range(0, 1024, 64)])
         out["pq_only_recall_at_10"] = recall_at(adc_only, truth_t[:1024])
-        out["codes"] = {"made_on_device_seconds": t_quant, "vectors_per_s": n_all / t_quant}
+        out["codes"] = {"made_on_device_seconds": t_quant, "vectors_per_s": n_all / t_quant, "codec_trained_seconds": t_codec,
+                        "codec": "64 x 256; rotation = eigenvectors of a 100 000-row sample's second moments dealt to the subspaces by energy "
+                                 "(parametric OPQ), max-inner-product k-means per subspace (4 rounds), on the device"}
     except Exception as e:  # noqa: BLE001
         out["pq_rerank"] = {"error": repr(e)}
     # (5) the request path in the reference's call shape, at the exact-scored operating point
@@ -380,3 +419,192 @@ def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget
     out["seconds"] = time.perf_counter() - t_all
     g.close()
     return out
+
+
+# ---- the approximate-search paths over several GPUs (bench.py --gpus N) ---------------------------------------------------------
+ANN_SEED = 0x5EED0011
+
+
+def _random_codec(seed=0):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+    T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
+    return cents, T
+
+
+def _shard_ann_state(mse, vecs, searcher, n_g, device, cents, T, graph_list=64, batch=4096):
+    """codec, codes and a one-pass Vamana graph (with a sampled entry table) over one shard's rows, on the shard's device"""
+    import numpy as np
+    from mse import ffi
+    ffi.check(ffi.lib().mse_set_device(device), "mse_set_device")
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    codes = mse.Codes.quantize_base(pq, vecs)
+    g = mse.BuildGraph(n_g, 64)
+    g.random_fill(1)
+    order = np.random.default_rng(3).permutation(n_g).astype(np.uint32)
+    g.build(searcher, order, int(order[0]), mse.IndexBuildConfig(r=64, l=graph_list, maxc=300), batch)
+    entries = np.sort(np.random.default_rng(5).choice(n_g, max(256, n_g // 1500), replace=False)).astype(np.uint32)
+    mse.set_entries(g, vecs, entries)
+    return pq, codes, g
+
+
+def sharded_ann_inprocess(n_gpus, n_dev, rows_per_gpu=2_000_000, k=10, r=200, search_list=32):
+    """`python bench.py --gpus N` (one process, a host thread per shard): the PQ flat scan + exact re-rank and the graph index over
+    N shards of `rows_per_gpu` rows each -- codes, descriptors-free, one graph per shard -- through mse_shard_group_pq_scan_topk /
+    mse_shard_group_query_topk (the brute-force path's exchange: RCCL all-gather of the packed blocks when every shard has its own
+    device, peer stores otherwise).  Checked in the run: the sharded PQ answer against the UNSHARDED call over a full copy of the rows
+    on device 0 (bit for bit), the sharded graph answer against the host merge of the per-shard calls."""
+    import threading
+    import numpy as np
+    import mse
+    from mse import ffi, shard
+    n = rows_per_gpu * n_gpus
+    devs = [g % n_dev for g in range(n_gpus)]
+    grp = mse.ShardGroup(n_gpus, D, devices=devs)
+    grp.generate(ANN_SEED, 0, n)
+    exchange = "peer stores"
+    if len(set(devs)) == n_gpus:
+        try:
+            grp.set_exchange(grp.EXCHANGE_RCCL)
+            exchange = f"ONE ncclAllGather per exchange, {grp.rccl_ranks} ranks"
+        except mse.MseError as e:
+            exchange = f"peer stores (RCCL unavailable: {e})"
+    cents, T = _random_codec()
+    state, errs = [None] * n_gpus, []
+
+    def make(gi):
+        try:
+            state[gi] = _shard_ann_state(mse, grp.base(gi), grp.searcher(gi), len(grp.base(gi)), devs[gi], cents, T)
+        except Exception as e:  # noqa: BLE001
+            errs.append(f"shard {gi}: {e!r}")
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=make, args=(gi,)) for gi in range(n_gpus)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ffi.check(ffi.lib().mse_set_device(devs[0]), "mse_set_device")
+    if errs:
+        grp.close()
+        return {"error": "; ".join(errs)}
+    t_prep = time.perf_counter() - t0
+    for gi, (pq, codes, g) in enumerate(state):
+        grp.attach_pq(gi, pq, codes)
+        grp.attach_graph(gi, g)
+    rng = np.random.default_rng(9)
+    q32 = rng.standard_normal((1024, D)).astype(np.float32)
+    q32 /= np.linalg.norm(q32, axis=1, keepdims=True)
+    q16 = q32.astype(np.float16).view(np.uint16)
+    out = {"shards": n_gpus, "devices": devs, "rows_per_gpu": rows_per_gpu, "rows": n, "exchange": exchange, "prepare_seconds": t_prep,
+           "prepare": "per shard, in parallel: 64 x 8-bit codes of the resident rows, a one-pass Vamana graph (R 64, L 64), a sampled entry table"}
+    # PQ scan + exact re-rank, 32 queries per call
+    grp.pq_scan_topk(q32[:32], r, k)
+    t0, calls = time.perf_counter(), 0
+    while calls < 10 or time.perf_counter() - t0 < 1.0:
+        ps, pi = grp.pq_scan_topk(q32[32 * (calls % 8):32 * (calls % 8) + 32], r, k)
+        calls += 1
+    dt = time.perf_counter() - t0
+    out["pq_scan_rerank"] = {"queries_per_s": 32 * calls / dt, "ms_per_call_of_32": dt / calls * 1e3, "r": r, "k": k, "timing_ms": grp.last_timing(),
+                             "exchanges_per_call": 2, "bytes_per_rank_per_exchange": int(ffi.lib().mse_topk_block_bytes(32, r))}
+    # the graph index, 1024 queries per call, neighbours scored exactly
+    grp.query_topk(q16, k, None, None, True, 4, search_list)
+    t0, calls = time.perf_counter(), 0
+    while calls < 5 or time.perf_counter() - t0 < 1.0:
+        gs, gi_ = grp.query_topk(q16, k, None, None, True, 4, search_list)
+        calls += 1
+    dt = time.perf_counter() - t0
+    out["graph_index"] = {"queries_per_s": 1024 * calls / dt, "ms_per_call_of_1024": dt / calls * 1e3, "search_list": search_list, "beamwidth": 4,
+                          "timing_ms": grp.last_timing(), "bytes_per_rank_per_exchange": int(ffi.lib().mse_topk_block_bytes(1024, k))}
+    # checks
+    try:
+        parts_s, parts_i = [], []
+        for gi, (pq, codes, g) in enumerate(state):
+            ffi.check(ffi.lib().mse_set_device(devs[gi]), "mse_set_device")
+            s_g = mse.Searcher(grp.base(gi))
+            ids, sc, _ = mse.disk_query_topk(s_g, None, None, g, q16, k, None, None, None, True, 4, search_list)
+            parts_s.append(sc)
+            parts_i.append(np.where(ids == 0xFFFFFFFF, ids, ids + np.uint32(grp.first_row(gi))))
+            s_g.close()
+        ffi.check(ffi.lib().mse_set_device(devs[0]), "mse_set_device")
+        ws, wi = shard.merge_topk_numpy(np.concatenate(parts_s, 1), np.concatenate(parts_i, 1), k)
+        out["graph_index"]["equals_the_merge_of_per_shard_calls"] = bool(np.array_equal(gs, ws) and np.array_equal(gi_, wi))
+        free_b, total_b = ffi.sz(), ffi.sz()
+        ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
+        if n * (D * 2 + 64) + (4 << 30) < free_b.value:
+            full = mse.VectorList.generate(ANN_SEED, 0, n, D)
+            pq0 = mse.ProductQuantizer(cents, T, 18, D)
+            codes0 = mse.Codes.quantize_base(pq0, full)
+            s0 = mse.Searcher(full)
+            us, ui = pq0.scan_topk_batch(codes0, q32[:32], r, k, s0)
+            ps, pi = grp.pq_scan_topk(q32[:32], r, k)
+            out["pq_scan_rerank"]["equals_the_unsharded_call_bit_for_bit"] = bool(np.array_equal(ps, us) and np.array_equal(pi, ui))
+            s0.close(); codes0.close(); full.close()
+        else:
+            out["pq_scan_rerank"]["equals_the_unsharded_call_bit_for_bit"] = "not checked: a full copy of the rows does not fit beside the index on device 0"
+    except Exception as e:  # noqa: BLE001
+        out["check_error"] = repr(e)
+    grp.close()
+    return out
+
+
+def sharded_ann_rank(comm, dist, rank, world, rows_per_gpu=2_000_000, k=10, r=200, search_list=32):
+    """torchrun's shape (one process per GPU): this rank's shard of the same index, mse_comm_pq_scan_topk / mse_comm_query_topk; rank 0
+    also checks the PQ answer against the unsharded call over a full copy of the rows."""
+    import numpy as np
+    import torch
+    import mse
+    from mse import ffi
+    n = rows_per_gpu * world
+    lo, hi = rank * rows_per_gpu, (rank + 1) * rows_per_gpu
+    vecs = mse.VectorList.generate(ANN_SEED, lo, hi - lo, D)
+    s = mse.Searcher(vecs)
+    cents, T = _random_codec()
+    t0 = time.perf_counter()
+    pq, codes, g = _shard_ann_state(mse, vecs, s, hi - lo, torch.cuda.current_device(), cents, T)
+    dist.barrier()
+    t_prep = time.perf_counter() - t0
+    rng = np.random.default_rng(9)
+    q32 = rng.standard_normal((1024, D)).astype(np.float32)
+    q32 /= np.linalg.norm(q32, axis=1, keepdims=True)
+    q16 = q32.astype(np.float16).view(np.uint16)
+    out_s = torch.empty((1024, k), dtype=torch.int64, device="cuda")
+    out_i = torch.empty((1024, k), dtype=torch.int32, device="cuda")
+    res = {"ranks": world, "rows_per_gpu": rows_per_gpu, "rows": n, "prepare_seconds": t_prep, "exchange": "ONE ncclAllGather per exchange (mse_comm)"}
+
+    def timed(fn, per_call, min_calls):
+        fn(0)
+        dist.barrier()
+        t0, calls = time.perf_counter(), 0
+        while calls < min_calls:
+            fn(calls)
+            calls += 1
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return per_call * calls / float(t.item()), float(t.item()) / calls * 1e3
+
+    qps, ms = timed(lambda c: comm.pq_scan_topk(pq, codes, s, q32[32 * (c % 8):32 * (c % 8) + 32], r, k, lo, out_s.data_ptr(), out_i.data_ptr()), 32, 40)
+    res["pq_scan_rerank"] = {"queries_per_s": qps, "ms_per_call_of_32": ms, "r": r, "k": k, "exchanges_per_call": 2}
+    qps, ms = timed(lambda c: comm.query_topk(s, g, q16, k, lo, out_s.data_ptr(), out_i.data_ptr(), disable_pq=True, beamwidth=4, search_list=search_list), 1024, 20)
+    res["graph_index"] = {"queries_per_s": qps, "ms_per_call_of_1024": ms, "search_list": search_list, "beamwidth": 4}
+    comm.pq_scan_topk(pq, codes, s, q32[:32], r, k, lo, out_s.data_ptr(), out_i.data_ptr())
+    ps, pi = out_s[:32].cpu().numpy(), out_i[:32].cpu().numpy().view(np.uint32)
+    if rank == 0:
+        try:
+            free_b, total_b = ffi.sz(), ffi.sz()
+            ffi.check(ffi.lib().mse_device_mem_info(free_b, total_b))
+            if n * (D * 2 + 64) + (4 << 30) < free_b.value:
+                full = mse.VectorList.generate(ANN_SEED, 0, n, D)
+                codes0 = mse.Codes.quantize_base(pq, full)
+                s0 = mse.Searcher(full)
+                us, ui = pq.scan_topk_batch(codes0, q32[:32], r, k, s0)
+                res["pq_scan_rerank"]["equals_the_unsharded_call_bit_for_bit"] = bool(np.array_equal(ps, us) and np.array_equal(pi, ui))
+                s0.close(); codes0.close(); full.close()
+        except Exception as e:  # noqa: BLE001
+            res["check_error"] = repr(e)
+    dist.barrier()
+    g.close(); codes.close(); s.close(); vecs.close()
+    return res
