@@ -26,6 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "meme-search-engine_amd")):
 
 D = 1152
 SEED_BASE, SEED_QUERY = 0x5EED0001, 0x5EED0002
+PMC_TRAFFIC = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json")) if os.path.exists(p)), "")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -436,7 +437,7 @@ def pq_bench(args):
     gbs_kernel = n * 68 / (k_avg * 1e-3) / 1e9 if k_n else None
     traffic = None
     try:     # HBM bytes per scan launch from the PMC passes (collected offline: a counter pass cannot run inside a timed run)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))["pq_scan64x4"]
+        pm = json.load(open(PMC_TRAFFIC))["pq_scan64x4"]
         if pm["vectors"] == n:
             traffic = pm["hbm_read_bytes_per_launch"] + pm["hbm_write_bytes_per_launch"]
     except Exception:  # noqa: BLE001
@@ -454,7 +455,7 @@ def pq_bench(args):
                          "burst": {"achieved": gbs_kernel, "frac": (gbs_kernel / HBM_PEAK_GBS) if gbs_kernel else None, "avg_launch_ms": k_avg, "launches_timed": k_n,
                                    "note": "one scan per call with nothing before or beside it (eight-query calls): the device has paused before every launch"},
                          "bytes_per_launch": n * 68, "queries_per_launch": per_pass, "traffic": traffic,
-                         "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
+                         "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
                          "end_to_end": {"achieved": gbs_pass, "frac": gbs_pass / HBM_PEAK_GBS,
                                         "note": "68 B x vectors / (8 x batched per-query time): table build, scan, tournament, re-score of the nominated "
                                                 "groups, exact top-r, certificate, download -- two streams, one group of eight queries each"},
@@ -725,7 +726,7 @@ def siglip_bench(args, world, rank, dist=None):
     # run); only reported when this run is the profiled configuration
     sig_traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))).get("siglip")
+        pm = json.load(open(PMC_TRAFFIC)).get("siglip")
         if pm and pm["batch"] == batch and pm["depth"] == 27:
             sig_traffic = pm["hbm_read_bytes_per_forward"] + pm["hbm_write_bytes_per_forward"]
     except Exception:  # noqa: BLE001
@@ -738,7 +739,7 @@ def siglip_bench(args, world, rank, dist=None):
             "server_images_per_s": (server or {}).get("value"), "server": server,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
                          "flop_per_image": gflop_img * 1e9, "traffic": sig_traffic,
-                         "traffic_source": "profiles/r04_pmc_traffic.json: HBM bytes of ONE forward of this batch, all kernels (rocprofv3 --pmc FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB)" if sig_traffic else None,
+                         "traffic_source": "profiles/r05_pmc_traffic.json: HBM bytes of ONE forward of this batch, all kernels (rocprofv3 --pmc FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB)" if sig_traffic else None,
                          "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.83 of 2.4 GHz "
                                  "(profiles/r04_siglip_notes.txt); the library GEMM alone runs these shapes at 0.38-0.52 of the same peak "
                                  "(profiles/r02_gemm_calibration.txt); with every GEMM epilogue removed the forward is 17 % shorter -- the "
@@ -888,6 +889,8 @@ def main():
     ap.add_argument("--graph-entries", type=int, default=-1,
                     help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
     ap.add_argument("--graph-kinds", default="easy,hard,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")
+    ap.add_argument("--no-graph-1e8", action="store_true", help="skip the 1e8-row graph-index leg (a ~10 minute one-pass build, guarded by a time budget)")
+    ap.add_argument("--graph-1e8-budget", type=float, default=900.0, help="seconds the predicted 1e8-row build may take; beyond it the leg is skipped with that reason")
     ap.add_argument("--no-sharded-ann", action="store_true", help="--gpus N > 1: skip the sharded PQ-scan / graph-index legs")
     ap.add_argument("--ann-rows-per-gpu", type=float, default=2e6, help="--gpus N > 1: rows per GPU of the sharded approximate-search legs")
     ap.add_argument("--siglip-batch", type=int, default=256)
@@ -1234,7 +1237,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             graph_line = {"error": repr(e)}
 
-    gscale_line = ann_line = None
+    gscale_line = ann_line = g1e8_line = None
     if rank == 0 and n_gpus == 1 and not (args.no_graph_scale and args.no_ann_scale):
         del searcher, vecs                             # the 230 GB index makes room for the clustered sets of the next two legs
         import gc
@@ -1261,6 +1264,14 @@ def main():
                 gscale_line["sets"][kind] = {"error": repr(e)}
             gc.collect()
             torch.cuda.empty_cache()
+        if not args.no_graph_1e8 and world == 1:
+            rate = ((gscale_line["sets"].get("easy") or {}).get("build") or {}).get("points_per_s")
+            try:
+                g1e8_line = bench_ann.graph_index_1e8(ROOT, rate, float(args.graph_1e8_budget))
+            except Exception as e:  # noqa: BLE001
+                g1e8_line = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
         head = (gscale_line["sets"].get("hard") or {}).get("exact_scored", {}).get("held_out") or {}
         gscale_line.update({"value": head.get("queries_per_s"), "recall_at_10": head.get("recall_at_10"), "search_list": head.get("value"),
                             "value_is": "the HARD set, exactly scored neighbours, one call of 4096 held-out queries"})
@@ -1279,7 +1290,7 @@ def main():
         # inside a timed run); only reported when this run is the profiled configuration
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            pm = json.load(open(PMC_TRAFFIC))
             pp = pm["per_pass"].get(str(min(nq, tile))) if pm["rows"] == hi - lo else None
             if pp:
                 traffic = pp["hbm_read_bytes_per_launch"] + pp["hbm_write_bytes_per_launch"]
@@ -1307,7 +1318,7 @@ def main():
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": {320: "scan_mfma_kernel<2,20>", 256: "scan_mfma2d_kernel<3,16>", 192: "scan_mfma_kernel<3,12>", 128: "scan_mfma_kernel<3,8>"}.get(tile, "scan_mfma") + f" ({nq} queries per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
+                         "traffic": traffic, "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms, "queries_per_launch": min(nq, tile),
                          # the same launch against the matrix cores: 2*rows*1152*queries flops; dense f16 peak 2500 TFLOP/s
                          "mfma_tflops": mfma_tflops, "mfma_frac": (mfma_tflops / 2500.0) if mfma_tflops else None,
@@ -1364,6 +1375,10 @@ def main():
                     pt_ = g(row, "graph_callers", "perf_test_py_shape")
                     if pt_:
                         gi[kind]["callers"]["perf_test_100x1000"] = [rnd(pt_["queries_per_s"], 1), rnd(pt_["latency_ms"]["p50"], 3), rnd(pt_["latency_ms"]["p99"], 3)]
+            if g1e8_line:
+                legs["graph_index_1e8"] = ({"qps_recall_L": [rnd(g1e8_line.get("value"), 1), rnd(g1e8_line.get("recall_at_10")), g1e8_line.get("search_list")],
+                                            "build_s": rnd(g(g1e8_line, "build", "seconds"), 1)} if "value" in g1e8_line else
+                                           {"skipped": g1e8_line.get("skipped") or g1e8_line.get("error")})
             legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; callers: [queries/s, p50 ms, p99 ms, vs one call of 4096]")
         if sharded_ann:
             legs["sharded_ann"] = {"pq_qps": rnd(g(sharded_ann, "pq_scan_rerank", "queries_per_s"), 1), "pq_equal_unsharded": g(sharded_ann, "pq_scan_rerank", "equals_the_unsharded_call_bit_for_bit"),
@@ -1385,6 +1400,8 @@ def main():
             line["ann_1e8"] = ann_line
         if gscale_line:
             line["graph_index_1e7"] = gscale_line
+        if g1e8_line:
+            line["graph_index_1e8"] = g1e8_line
         if sharded_ann:
             line["sharded_ann"] = sharded_ann
         if note:

@@ -808,7 +808,10 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     a.hash_slots = (int)hash_slots;
     const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16 + hash_slots * 4;
     static const bool wide_only = MSE_DEV_KNOB("MSE_BEAM_FOUR_WAVES");   // developer library: the four-wave form for every search
-    if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only) {
+    // one wave per query once the batch fills the chip on its own (16 queries per CU); a smaller batch is latency-bound, and four waves
+    // finish a search sooner (round 5, scripts/beam_latency_probe.py, hard set: 64 queries at L = 12 0.40 ms against 0.98, at L = 200
+    // 5.7 against 8.9; from 2048 queries on the two forms are level)
+    if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only && nq > 1024) {
         hipLaunchKernelGGL(beam_search_kernel<64>, dim3((unsigned)nq), dim3(64), lds, st, a);
     } else {
         MSE_DYN_LDS(beam_search_kernel<BS_THREADS_MAX>, 160 * 1024 - 1024);

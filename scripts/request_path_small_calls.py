@@ -13,6 +13,8 @@ import bench_ann as ba  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
 only = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+build = only <= 0          # a negative batch size: that batch only, but on a built graph (for traces)
+only = abs(only)
 K, R, L = 10, 64, 12
 gen = ba.easy_generator(n)
 rows, queries = gen(n, 1), gen(4096, 2)
@@ -21,7 +23,7 @@ vecs = mse.VectorList.wrap_device(rows.data_ptr(), n, ba.D, keepalive=rows)
 s = mse.Searcher(vecs)
 g = mse.BuildGraph(n, R)
 g.random_fill(1)
-if not only:
+if build:
     med = mse.medioid(vecs)
     g.build(s, np.random.default_rng(3).permutation(n).astype(np.uint32), med, mse.IndexBuildConfig(r=R, l=192, maxc=750), 4096)
 qf = queries.float().cpu().numpy()

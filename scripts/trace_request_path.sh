@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/trace_rp
-rocprofv3 --kernel-trace -d $R/gpurun_out/trace_rp -o rp --output-format csv -- python $R/scripts/request_path_small_calls.py 2e6 64 > $R/gpurun_out/trace_rp.log 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/trace_rp -o rp --output-format csv -- python $R/scripts/request_path_small_calls.py 2e6 -64 > $R/gpurun_out/trace_rp.log 2>&1
 tail -3 $R/gpurun_out/trace_rp.log
 python - <<PY
 import csv, glob
