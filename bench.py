@@ -1259,7 +1259,7 @@ def main():
         for kind in [x for x in args.graph_kinds.split(",") if x]:
             try:
                 gscale_line["sets"][kind] = bench_ann.graph_index_bench(ROOT, kind, int(args.graph_scale_rows), batch=int(args.graph_batch),
-                                                                        passes=int(args.graph_passes), callers=(kind == "hard" and not args.no_callers))
+                                                                        passes=int(args.graph_passes), callers=(kind in ("easy", "hard") and not args.no_callers))
             except Exception as e:  # noqa: BLE001
                 gscale_line["sets"][kind] = {"error": repr(e)}
             gc.collect()
@@ -1363,7 +1363,7 @@ def main():
             for kind, row in (gscale_line.get("sets") or {}).items():
                 def pt(key):
                     h = g(row, key, "held_out")
-                    return [rnd(g(h, "queries_per_s"), 1), rnd(g(h, "recall_at_10")), g(h, "value")] if h else None
+                    return ([rnd(g(h, "queries_per_s"), 1), rnd(g(h, "recall_at_10")), g(h, "value")] + ([] if g(h, "goal_reached") else ["tuning goal 0.96 not reached: best point"])) if h else None
                 gi[kind] = {"exact": pt("exact_scored"), "exact_ref_entry": pt("exact_scored_reference_entry_rule"), "adc": pt("adc_scored"),
                             "pq_rerank": pt("pq_rerank"), "pq_only_recall": rnd(g(row, "pq_only_recall_at_10")),
                             "rc": rnd(g(row, "hardness", "relative_contrast_at_10"), 3), "lid": rnd(g(row, "hardness", "lid_mle_k20"), 1),

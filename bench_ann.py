@@ -219,43 +219,6 @@ def train_codec(samp, seed=4, iters=3):
     return cents, T
 
 
-def train_codec_opq(rows, n_base, sample=100_000, iters=4, seed=4):
-    """The codec as aopq_train.py shapes it -- a LEARNED rotation in front of 64 sub-quantisers of 256 centroids -- trained on the
-    device over a row sample: the rotation is the parametric OPQ solution (eigenvectors of the sample's second-moment matrix dealt out
-    to the 64 subspaces so that their energies balance: largest remaining eigenvalue to the subspace with the least energy that
-    still has room), then max-inner-product k-means per subspace.  A random rotation (train_codec) spreads a low-rank signal thinly
-    over every subspace and leaves the sub-quantisers little to hold on to.  -> (centroids [256, 1152], transform [1152, 1152])."""
-    import numpy as np
-    import torch
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    idx = torch.randint(0, n_base, (min(sample, n_base),), device="cuda", generator=g)
-    x = rows[idx].float()
-    cov = (x.T @ x) / x.shape[0]
-    evals, evecs = torch.linalg.eigh(cov.double())
-    order = torch.argsort(evals, descending=True).cpu().numpy()
-    ev = evals.cpu().numpy()
-    energy, slots = np.zeros(64), [[] for _ in range(64)]
-    for j in order:
-        open_ = [m for m in range(64) if len(slots[m]) < 18]
-        m = min(open_, key=lambda m_: energy[m_])
-        slots[m].append(int(j))
-        energy[m] += max(float(ev[j]), 0.0)
-    cols = [j for m in range(64) for j in slots[m]]
-    T = evecs[:, cols].T.float().contiguous()                 # rows of T = the directions; transformed = T @ v
-    ts = x @ T.T
-    cents = torch.zeros(256, D, device="cuda")
-    for m in range(64):
-        sub = ts[:, m * 18:(m + 1) * 18]
-        c = sub[torch.randperm(sub.shape[0], device="cuda", generator=g)[:256]].clone()
-        for _ in range(iters):
-            asg = torch.argmax(sub @ c.T, dim=1)
-            sums = torch.zeros(256, 18, device="cuda").index_add_(0, asg, sub)
-            cnt = torch.zeros(256, device="cuda").index_add_(0, asg, torch.ones_like(asg, dtype=torch.float32))
-            c = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp(min=1), c)
-        cents[:, m * 18:(m + 1) * 18] = c
-    return cents.cpu().numpy().astype(np.float32), T.cpu().numpy().astype(np.float32)
-
-
 def shard_centroid_entries(rows, n_base, n_shards=64, sample=200_000, seed=7):
     """Stand-ins for the index header's shards (centroid + start node each, src/query_disk_index.rs:254-256,447-450) over a one-piece
     index: k-means centroids (spherical, two Lloyd rounds on a row sample) and, per centroid, the sample row closest to it as the
@@ -337,20 +300,25 @@ def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget
     qt32, qh32 = tune_q.float().cpu().numpy(), held_q.float().cpu().numpy()
 
     def pick(run, grid, goal=0.96):
-        """smallest grid value whose TUNING recall reaches the goal; the held-out point is measured once, warm"""
-        sweep, chosen = [], None
+        """smallest grid value whose TUNING recall reaches the goal (when none does: the one with the best tuning recall, labelled); the
+        held-out point is measured once, warm"""
+        sweep, at, best = [], None, None
         for v in grid:
             top = run(v, qt16, qt32)[0]
             rec = recall_at(top, truth_t)
             sweep.append([v, round(rec, 4)])
+            if best is None or rec > best[1]:
+                best = (v, rec)
             if rec >= goal:
-                run(v, qh16, qh32)
-                t0 = time.perf_counter()
-                top, extra = run(v, qh16, qh32)
-                dt = time.perf_counter() - t0
-                chosen = dict({"value": v, "queries_per_s": nq_t / dt, "recall_at_10": recall_at(top, truth_h), "queries": nq_t}, **extra)
+                at = v
                 break
-        return {"tuning_sweep": sweep, "held_out": chosen}
+        v = at if at is not None else best[0]
+        run(v, qh16, qh32)
+        t0 = time.perf_counter()
+        top, extra = run(v, qh16, qh32)
+        dt = time.perf_counter() - t0
+        chosen = dict({"value": v, "queries_per_s": nq_t / dt, "recall_at_10": recall_at(top, truth_h), "queries": nq_t, "goal_reached": at is not None}, **extra)
+        return {"tuning_sweep": sweep, "held_out": chosen, "tuning_goal": goal}
 
     grid_L = (12, 16, 24, 32, 48, 64, 100, 150, 200, 300, 400, 600, 800)
     # (1) exactly scored neighbours, entry = the sampled row with the largest dot product
@@ -374,7 +342,8 @@ def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget
                                                     "scale_dot_result_f64(dot(centroid, query)), last maximum (src/query_disk_index.rs:447-450)", beamwidth=4)
     # (3) the reference's default: neighbours scored by ADC (64 x 8-bit OPQ codes, 64 KiB table per query in LDS), fetched nodes exactly
     t0 = time.perf_counter()
-    cents, T = train_codec_opq(rows, n)
+    sel = torch.from_numpy(np.sort(np.random.default_rng(4).choice(n, min(n, 20000), replace=False))).cuda()
+    cents, T = train_codec(rows[sel].float().cpu().numpy())
     t_codec = time.perf_counter() - t0
     pq = mse.ProductQuantizer(cents, T, 18, D)
     t0 = time.perf_counter()
@@ -402,8 +371,8 @@ def graph_index_bench(root, kind, n, batch=4096, passes=1, callers=False, budget
         adc_only = np.concatenate([pq.scan_topk_batch(bcodes, qt32[i:i + 64], K, K, None)[1] for i in range(0, 1024, 64)])
         out["pq_only_recall_at_10"] = recall_at(adc_only, truth_t[:1024])
         out["codes"] = {"made_on_device_seconds": t_quant, "vectors_per_s": n_all / t_quant, "codec_trained_seconds": t_codec,
-                        "codec": "64 x 256; rotation = eigenvectors of a 100 000-row sample's second moments dealt to the subspaces by energy "
-                                 "(parametric OPQ), max-inner-product k-means per subspace (4 rounds), on the device"}
+                        "codec": "64 x 256 in aopq_train.py's layout at ITS starting point: a random rotation + per-subspace max-inner-product "
+                                 "k-means on a 20 000-row sample (3 rounds); the trainer's gradient steps and rotation updates are not part of it"}
     except Exception as e:  # noqa: BLE001
         out["pq_rerank"] = {"error": repr(e)}
     # (5) the request path in the reference's call shape, at the exact-scored operating point
@@ -662,7 +631,7 @@ def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=900.0, n=100_000_000, 
         sweep.append([L, round(rec, 4)])
         if best is None or rec > best[1]:
             best = (L, rec)
-        if rec >= 0.96:
+        if rec >= 0.955:
             chosen = L
             break
     L = chosen or best[0]
@@ -672,7 +641,7 @@ def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=900.0, n=100_000_000, 
     dt = time.perf_counter() - t0
     out = {"metric": "queries/sec over a 1e8x1152 graph index @ recall@10>=0.95 (ONE Vamana graph, one pass, GPU-resident beam search)",
            "value": nq_t / dt, "unit": "queries/s", "recall_at_10": recall_at(top, truth_h), "search_list": L, "beamwidth": 4, "queries": nq_t,
-           "operating_point": "smallest search list with tuning recall >= 0.96" if chosen else "no search list reached 0.96 on the tuning queries: the best one",
+           "operating_point": "smallest search list with tuning recall >= 0.955" if chosen else "no search list reached 0.955 on the tuning queries: the best one",
            "tuning_sweep": sweep, "node_fetches_per_query": float(st["cmps"].mean()),
            "build": {"seconds": t_build, "points_per_s": n / t_build, "passes": 1, "r": R, "l": 192, "maxc": 750, "batch": batch,
                      "predicted_seconds": predicted},

@@ -22,6 +22,7 @@ struct GemmLaunch {
     int heads = 0, dh = 0, dh_pad = 0, n_pad = 0, dv_pad = 0;
     int kdh_pad = 0;               // k row stride in elements (attention_k_stride()); 0 = dh_pad
     int gelu_tanh = 0;
+    int skinny = 0;                // launch_gemm: few rows (m_valid <= 512) may take the K-split skinny kernel (text tower)
     // LayerNorm-fused launches (launch_gemm_fused)
     const float* ln_stats = nullptr;   // consumers (QKV, GELU): (mean, 1/std) per row of x, which is then the FP16 residual stream
     const float* csum = nullptr;       // consumers: sum_k w'[n][k]; `w` holds the fp16 gamma-folded weights, `bias` the beta-folded bias
@@ -33,6 +34,7 @@ struct GemmLaunch {
 };
 
 int attention_k_stride();   // row stride (elements) launch_attention expects of the K buffer
+
 int gemm_bm();
 int gemm_bn();
 int gemm_bk();

@@ -130,6 +130,7 @@ struct GemmArgs {
     int kdh_pad;                           // k row stride in elements (112: the 224-byte rows the attention DMA wants)
     int gelu_tanh;
     int stagger;          // persistent kernel: 64-cycle sleep units per K tile and XCD index at start (0 = none)
+    int skinny;           // launch_gemm: m_valid <= 512 may take gemm_skinny_kernel (the text tower sets it)
     // LayerNorm folded into the GEMMs around it (gemm8pp_kernel only; see "Fused LayerNorm" above that kernel)
     const float2* ln_stats;   // LNF consumers: (mean, 1/std) of every row of x
     const float* csum;        // LNF consumers: c[n] = sum_k w'[n][k] (pre-offset like bias)
@@ -2067,7 +2068,91 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Skinny GEMM (round 5): a few dozen to a few hundred rows -- the text tower at batch 1..8.  The query path sends ONE text
+// (src/query_disk_index.rs:345-381): 64 token rows.  The 256 x 256-tile kernels above then run 5-17 workgroups on a 256-CU part, each
+// walking its whole K range alone: 21-56 us per GEMM whatever the batch, 8.6 ms per text forward against 0.1 ms to stream the weights.
+// Here a workgroup owns a 64 (m) x 32 (n) tile and its 12 waves SPLIT K: wave w multiplies its slice (operand fragments straight
+// from global memory in MFMA layout: a lane's eight bf16 values of a 16 x 32 fragment are 16 contiguous bytes of a K-contiguous row --
+// no LDS staging, up to three K steps of loads in flight at once), the partial tiles meet in LDS, and the waves share the epilogue
+// (store_quad: the same bias / GELU / QKV-scatter code as the first-generation kernel).  K = 1152 with 12 waves is ONE round trip to
+// memory per wave; N / 32 x M / 64 workgroups (108 for QKV, 136 for fc1, 36 for the projections at batch 1) fill more of the chip.
+// The summation order differs from the large kernels' (K split 12 or 8 ways): a text encoded alone and the same text inside a batch
+// of more than 8 agree to bf16 rounding, not bit for bit (the image tower's batch invariance is untouched: only the text tower asks
+// for this path).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SK_NW = 12;   // waves per workgroup: K = 1152 is 36 steps of 32 = three per wave, one round trip to memory
+template <int EPI, int R>   // R: K steps whose loads are in flight together (3: one round covers K = 1152; 4 for longer K: fc2's 12 steps per wave in 3 rounds)
+__global__ __launch_bounds__(SK_NW * 64) void gemm_skinny_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4v* red = reinterpret_cast<float4v*>(smem);   // [SK_NW][8 tiles][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
+    // K in steps of 32, dealt to the waves in contiguous runs (the last run may be short)
+    const int steps = a.K / 32, per_wave = (steps + SK_NW - 1) / SK_NW;
+    const int lo = wave * per_wave, hi = min(steps, lo + per_wave);
+    const uint16_t* xp = a.x + (size_t)(m0 + i) * a.K + 8 * g;
+    const uint16_t* wp = a.w + (size_t)(n0 + i) * a.K + 8 * g;
+    const size_t row16 = (size_t)16 * a.K;
+    float4v acc[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) acc[nt][mt] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = lo; s < hi; s += R) {   // up to R K steps per round: all their loads first, then their MFMAs
+        u32x4 xf[R][4], wf[R][2];
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (s + u < hi) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) xf[u][mt] = *reinterpret_cast<const u32x4*>(xp + mt * row16 + (size_t)(s + u) * 32);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) wf[u][nt] = *reinterpret_cast<const u32x4*>(wp + nt * row16 + (size_t)(s + u) * 32);
+            }
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            if (s + u < hi) {
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt++) acc[nt][mt] = mfma16<false>(as_bf8(wf[u][nt]), as_bf8(xf[u][mt]), acc[nt][mt]);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) red[(wave * 8 + t) * 64 + lane] = acc[t >> 2][t & 3];
+    __syncthreads();
+    // the workgroup's tile: the waves' partial sums in a fixed order (deterministic); waves 0..7 own one 16 x 16 piece each
+    float4v sum = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    const int t = wave;
+    if (t < 8) {
+        sum = red[t * 64 + lane];
+        for (int w = 1; w < SK_NW; w++) sum += red[(w * 8 + t) * 64 + lane];
+    }
+    if (t < 8) store_quad<EPI>(a, (size_t)(m0 + (t & 3) * 16 + i), n0 + (t >> 2) * 16 + 4 * g, sum);
+}
+
+template <int EPI> int launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
+    // (K split across WORKGROUPS as well -- partial tiles through a workspace, a ticket per tile, the last arrival finishes -- was
+    // measured and dropped: the device-scope fences it needs write back and invalidate the L2, 48-91 us per launch against 11)
+    const dim3 grid((unsigned)(a.N / 32), (unsigned)((a.m_valid + 63) / 64));
+    if (a.K / 32 <= 3 * SK_NW) {
+        MSE_DYN_LDS((gemm_skinny_kernel<EPI, 3>), SK_NW * 8 * 64 * 16);
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 3>), grid, dim3(SK_NW * 64), SK_NW * 8 * 64 * 16, st, a);
+    } else {
+        MSE_DYN_LDS((gemm_skinny_kernel<EPI, 4>), SK_NW * 8 * 64 * 16);
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4>), grid, dim3(SK_NW * 64), SK_NW * 8 * 64 * 16, st, a);
+    }
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV) {
+        // (a.n_off == 0 here; rows past the last 64-row tile keep what they held -- finite values of an earlier call or the zero fill)
+        if (a_in.skinny && a_in.m_valid > 0 && a_in.m_valid <= 512 && a_in.N % 32 == 0 && a_in.K % 32 == 0 &&
+            (EPI != EPI_QKV || (a_in.dh % 4 == 0 && (a_in.heads * a_in.dh) % 4 == 0)))
+            return launch_gemm_skinny<EPI>(a_in, st);
+    }
     MSE_DYN_LDS((gemm_kernel<EPI>), GS * STAGE_BYTES);
 #ifdef MSE_DEV_KERNELS
     MSE_DYN_LDS((gemm256_kernel<EPI>), LDS256_BYTES);
@@ -2216,6 +2301,7 @@ int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st) {
 }
 
 int attention_k_stride() { return ATT_KSTRIDE; }
+
 int gemm_bm() { return BM; }
 int gemm_bn() { return BN; }
 int gemm_bk() { return BK; }
@@ -2227,6 +2313,7 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     a.out_bf16 = g.out_bf16; a.ldo = g.ldo; a.resid = g.resid; a.ldr = g.ldr; a.pos = g.pos; a.tokens = g.tokens;
     a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
     a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh; a.kdh_pad = g.kdh_pad ? g.kdh_pad : g.dh_pad;
+    a.skinny = g.skinny;
     switch (epi) {
         case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, st);
         case EPI_GELU: return launch_gemm_t<EPI_GELU>(a, st);

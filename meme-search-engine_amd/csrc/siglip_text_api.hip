@@ -40,7 +40,8 @@ struct mse_siglip_text {
     int D = 0, H = 0, dh = 0, mlp = 0, mlp_pad = 0, ctx = 0, n_pad = 0, dh_pad = 96, dv_pad = 80;
     int max_batch = 0;
     size_t m_pad = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the second half of a large batch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex call_mu;   // one call at a time: token upload, kernels and scratch of a call share one stream (see mse_siglip)
     std::vector<void*> allocs;
     std::map<std::string, TSlot> slots;
@@ -88,6 +89,11 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->ctx = c->context_length; m->n_pad = m->ctx; m->max_batch = c->max_batch;
     m->m_pad = round_up((size_t)m->max_batch * m->ctx, 256);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
+    if (hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->stream2) { (void)hipStreamDestroy(m->stream2); m->stream2 = nullptr; }   // one stream then: correct, only slower
+    }
     const size_t D = m->D, MP = m->mlp_pad;
     m->add_f32("text.token_embedding.weight", &m->tok_emb, c->vocab_size, D);
     m->add_f32("text.positional_embedding", &m->pos, m->ctx, D);
@@ -129,6 +135,9 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
 
 void mse_siglip_text_destroy(mse_siglip_text* m) {
     if (!m) return;
+    if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stage) (void)hipFree(m->stage);
@@ -186,37 +195,61 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     if (batch <= 0 || batch > m->max_batch) return fail("siglip text: batch exceeds max_batch");  // clip_server.py:136
     hipStream_t st = m->stream;
     const mse_siglip_text_config& c = m->cfg;
-    const int D = m->D, T = m->ctx, M = batch * T, Mp = (int)round_up(M, 256);
+    const int D = m->D, T = m->ctx, M = batch * T;
     MSE_HIP_TRY(hipMemcpyAsync(m->tokens_dev, tokens, (size_t)M * 8, hipMemcpyHostToDevice, st));
     if (launch_embed_tokens(m->tokens_dev, m->tok_emb, m->pos, c.vocab_size, T, D, M, m->x, st)) return -1;
-    for (int i = 0; i < c.layers; i++) {
-        const TBlock& b = m->blocks[i];
-        // x += (fc2 output of the previous block), then LayerNorm
-        if (launch_layernorm(m->x, 1, D, i ? m->dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = T;
-            g.q = m->qb; g.k = m->kb; g.vt = m->vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
-            g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
-            if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
+    // The blocks over the sequences [b0, b0 + nb) on stream `ss`: rows b0 * T .. of every activation buffer, (sequence, head) matrices
+    // b0 * H .. of the attention operands.  b0 * T is a multiple of 256, so the GEMMs' row padding stays inside the range's own rows
+    // (or behind the last range).
+    auto blocks = [&](hipStream_t ss, int b0, int nb) -> int {
+        const size_t r0 = (size_t)b0 * T;
+        const int Ms = nb * T, Msp = (int)round_up(Ms, 256);
+        uint16_t *x = m->x + r0 * D, *h = m->h + r0 * D, *dlt = m->dlt + r0 * D, *mlp_h = m->mlp_h + r0 * m->mlp_pad;
+        uint16_t* qb = m->qb + (size_t)b0 * m->H * m->n_pad * m->dh_pad;
+        uint16_t* kb = m->kb + (size_t)b0 * m->H * m->n_pad * attention_k_stride();
+        uint16_t* vtb = m->vtb + (size_t)b0 * m->H * m->dv_pad * m->n_pad;
+        for (int i = 0; i < c.layers; i++) {
+            const TBlock& b = m->blocks[i];
+            // x += (fc2 output of the previous block), then LayerNorm
+            if (launch_layernorm(x, 1, D, i ? dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;
+            {
+                GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Msp; g.N = 3 * D; g.K = D; g.m_valid = Ms; g.tokens = T;
+                g.q = qb; g.k = kb; g.vt = vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+                g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+                if (launch_gemm(GEMM_EPI_QKV, g, ss)) return -1;
+            }
+            if (launch_attention(qb, kb, vtb, nb, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, h, D, T, ss)) return -1;
+            {
+                GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.wproj; g.bias = b.bproj; g.M = Msp; g.N = D; g.K = D; g.m_valid = Ms;
+                g.out_bf16 = dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+                if (launch_gemm(GEMM_EPI_BF16, g, ss)) return -1;
+            }
+            if (launch_layernorm(x, 1, D, dlt, D, b.ln2_g, b.ln2_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;   // x += attention branch
+            {
+                GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.w1; g.bias = b.b1; g.M = Msp; g.N = m->mlp_pad; g.K = D; g.m_valid = Ms;
+                g.out_bf16 = mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
+                if (launch_gemm(GEMM_EPI_GELU, g, ss)) return -1;
+            }
+            {
+                GemmLaunch g; g.skinny = 1; g.x = mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Msp; g.N = D; g.K = m->mlp_pad; g.m_valid = Ms;
+                g.out_bf16 = dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+                if (launch_gemm(GEMM_EPI_BF16, g, ss)) return -1;
+            }
         }
-        if (launch_attention(m->qb, m->kb, m->vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, m->h, D, T, st)) return -1;
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = D; g.K = D; g.m_valid = M;
-            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
-            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
-        }
-        if (launch_layernorm(m->x, 1, D, m->dlt, D, b.ln2_g, b.ln2_b, c.eps, D, M, m->h, D, nullptr, st)) return -1;   // x += attention branch
-        {
-            GemmLaunch g; g.x = m->h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
-            g.out_bf16 = m->mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
-            if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
-        }
-        {
-            GemmLaunch g; g.x = m->mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = D; g.K = m->mlp_pad; g.m_valid = M;
-            g.out_bf16 = m->dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
-            if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
-        }
+        return 0;
+    };
+    // A large batch runs as TWO halves on two streams (round 5, as the image tower does since round 2): the output-projection and fc2
+    // GEMMs have 4.5 column tiles, so their last round of 256 x 256 tiles leaves most of the chip idle -- the other half's next kernel
+    // takes those CUs.  The first half is a multiple of four sequences (256 rows).
+    const int b_first = batch >= 32 && m->stream2 ? (batch / 2) / 4 * 4 : batch;
+    if (b_first < batch) {
+        MSE_HIP_TRY(hipEventRecord(m->ev_fork, st));
+        MSE_HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+        if (blocks(m->stream2, b_first, batch - b_first)) return -1;
+        MSE_HIP_TRY(hipEventRecord(m->ev_join, m->stream2));
     }
+    if (blocks(st, 0, b_first)) return -1;
+    if (b_first < batch) MSE_HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
     if (launch_layernorm(m->x + (size_t)(T - 1) * D, 1, T * D, c.layers ? m->dlt + (size_t)(T - 1) * D : nullptr, T * D, m->lnf_g, m->lnf_b,
                          c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
