@@ -885,7 +885,7 @@ def main():
     ap.add_argument("--ann-rows", type=float, default=1e8)
     ap.add_argument("--graph-scale-rows", type=float, default=1e7)
     ap.add_argument("--graph-passes", type=int, default=1, help="Vamana passes of the graph-scale build (generate-index-shard -s = 2)")
-    ap.add_argument("--graph-batch", type=int, default=4096, help="points inserted per batch of the graph-scale build")
+    ap.add_argument("--graph-batch", type=int, default=16384, help="points inserted per batch of the graph-scale build")
     ap.add_argument("--graph-entries", type=int, default=-1,
                     help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
     ap.add_argument("--graph-kinds", default="easy,hard,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")

@@ -709,7 +709,122 @@ struct BackArgs {
     const uint32_t* targets; const uint32_t* src_off; const uint32_t* srcs;
     uint32_t qb; int maxc, saturate; long long alpha, qalpha;
     uint32_t n; uint32_t* err;
+    const uint32_t* src_cnt;   // sources of target i: srcs[src_off[i] .. src_off[i] + src_cnt[i]); null: .. src_off[i + 1])
 };
+__device__ __forceinline__ uint32_t back_end(const BackArgs& a, uint32_t i) { return a.src_cnt ? a.src_off[i] + a.src_cnt[i] : a.src_off[i + 1]; }
+
+// ---- back edges grouped by the list they touch, on the device (round 5) ---------------------------------------------
+// The batch's new lists name, entry by entry (k = position in the batch, j = position in the list), the lists that receive a back
+// edge.  They are applied per TARGET list, its sources in (k, j) order.  Rounds 1-4 grouped them on the host: staged lists down, a
+// counting sort through a table of one slot per graph node, three arrays up -- 40-110 ms per batch of 16 384 points at 1e8 nodes
+// (400 MB of random reads and writes), about as long as the batch's kernels, with the device idle meanwhile.  Here: an
+// open-addressing table keyed by target (sized for the batch, not the graph), counts by atomics, targets compacted with the
+// "four or more newcomers" class in front (scheduling only: the lists are independent), source segments placed by an atomic
+// running total, filled in arrival order and then SORTED by entry number -- so what each list receives, and in which order, is
+// exactly what the host grouping produced.  Only the number of targets travels to the host (the launch size of the back-edge kernel).
+struct GroupArgs {
+    const uint32_t* stg; const uint32_t* len; const uint32_t* points; int r; uint32_t nb;
+    uint32_t* keys; uint32_t* cnt; uint32_t* tidx; int bits;          // the table: target id, entries, index in targets[]
+    uint32_t* ent_slot;                                             // [nb * r] table slot of every entry (0xffffffff: none)
+    uint32_t* counters;   // [0] targets with >= 4 entries, [1] the others, [2] / [3] their running indices, [4] running source total
+    uint32_t *targets, *t_off, *t_cnt, *t_slot, *t_fill, *srcs, *srcs_pts;   // srcs: entry numbers as they arrived; srcs_pts: source points in order
+};
+__global__ void group_count_kernel(GroupArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.nb * (uint32_t)a.r) return;
+    const uint32_t k = e / (uint32_t)a.r, j = e - k * (uint32_t)a.r;
+    uint32_t slot = 0xffffffffu;
+    if (j < a.len[k]) {
+        const uint32_t t = a.stg[e], mask = (1u << a.bits) - 1u;
+        uint32_t h = (t * 2654435761u) >> (32 - a.bits);
+        for (;;) {   // the table has at least twice as many slots as the batch has entries
+            const uint32_t old = atomicCAS(&a.keys[h], 0xffffffffu, t);
+            if (old == 0xffffffffu || old == t) break;
+            h = (h + 1) & mask;
+        }
+        atomicAdd(&a.cnt[h], 1u);
+        slot = h;
+    }
+    a.ent_slot[e] = slot;
+}
+// (one atomic per WAVE and counter: a million lanes adding to two words took 2.7 ms per batch)
+__global__ void group_classify_kernel(GroupArgs a) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool used = h < (1u << a.bits) && a.keys[h] != 0xffffffffu;
+    const bool big = used && a.cnt[h] >= 4;
+    const unsigned long long mb = __ballot(big), ms = __ballot(used && !big);
+    if ((threadIdx.x & 63) == 0) {
+        if (mb) atomicAdd(&a.counters[0], (uint32_t)__popcll(mb));
+        if (ms) atomicAdd(&a.counters[1], (uint32_t)__popcll(ms));
+    }
+}
+__global__ void group_compact_kernel(GroupArgs a) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool used = h < (1u << a.bits) && a.keys[h] != 0xffffffffu;
+    const uint32_t c = used ? a.cnt[h] : 0u;
+    const bool big = used && c >= 4, small = used && !big;
+    const unsigned long long mb = __ballot(big), ms = __ballot(small), below = (1ull << lane) - 1ull;
+    // the wave's total of c and every lane's share before it (inclusive scan by shuffles)
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t base_b = 0, base_s = 0, base_o = 0;
+    if (lane == 0) {
+        if (mb) base_b = atomicAdd(&a.counters[2], (uint32_t)__popcll(mb));
+        if (ms) base_s = atomicAdd(&a.counters[3], (uint32_t)__popcll(ms));
+        if (total) base_o = atomicAdd(&a.counters[4], total);
+    }
+    base_b = __shfl(base_b, 0); base_s = __shfl(base_s, 0); base_o = __shfl(base_o, 0);
+    if (!used) return;
+    const uint32_t idx = big ? base_b + (uint32_t)__popcll(mb & below) : a.counters[0] + base_s + (uint32_t)__popcll(ms & below);
+    a.targets[idx] = a.keys[h];
+    a.t_cnt[idx] = c;
+    a.t_off[idx] = base_o + incl - c;
+    a.t_slot[idx] = h;
+    a.tidx[h] = idx;
+}
+__global__ void group_fill_kernel(GroupArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.nb * (uint32_t)a.r) return;
+    const uint32_t h = a.ent_slot[e];
+    if (h == 0xffffffffu) return;
+    const uint32_t idx = a.tidx[h];
+    a.srcs[a.t_off[idx] + atomicAdd(&a.t_fill[idx], 1u)] = e;
+}
+// per target: its entries into (k, j) order (rank = entries of the segment that are smaller; entry numbers are unique), entries ->
+// source points in srcs_pts; the table slot and the fill counter go back to empty.  Targets with >= 4 entries (the first n_big)
+// get a workgroup each -- a hub of the first batches collects thousands --, the others a thread.
+__global__ __launch_bounds__(256) void group_order_big_kernel(GroupArgs a) {
+    const uint32_t idx = blockIdx.x, off = a.t_off[idx], c = a.t_cnt[idx];
+    const uint32_t* seg = a.srcs + off;
+    for (uint32_t i = threadIdx.x; i < c; i += 256) {
+        const uint32_t v = seg[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < c; j++) rank += seg[j] < v;
+        a.srcs_pts[off + rank] = a.points[v / (uint32_t)a.r];
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t h = a.t_slot[idx];
+        a.keys[h] = 0xffffffffu; a.cnt[h] = 0u; a.t_fill[idx] = 0u;
+    }
+}
+__global__ void group_order_small_kernel(GroupArgs a, uint32_t first, uint32_t n_targets) {
+    const uint32_t idx = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_targets) return;
+    const uint32_t off = a.t_off[idx], c = a.t_cnt[idx];   // c <= 3
+    uint32_t v[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    for (uint32_t i = 0; i < c && i < 3; i++) v[i] = a.srcs[off + i];
+    if (v[0] > v[1]) { const uint32_t t = v[0]; v[0] = v[1]; v[1] = t; }
+    if (v[1] > v[2]) { const uint32_t t = v[1]; v[1] = v[2]; v[2] = t; }
+    if (v[0] > v[1]) { const uint32_t t = v[0]; v[0] = v[1]; v[1] = t; }
+    for (uint32_t i = 0; i < c && i < 3; i++) a.srcs_pts[off + i] = a.points[v[i] / (uint32_t)a.r];
+    const uint32_t h = a.t_slot[idx];
+    a.keys[h] = 0xffffffffu; a.cnt[h] = 0u; a.t_fill[idx] = 0u;
+}
 
 // Back edges (lib.rs:311-322): workgroup b owns list targets[b] and applies its sources in order.
 __global__ __launch_bounds__(GB_THREADS) void backedge_kernel(BackArgs a) {
@@ -731,7 +846,7 @@ __global__ __launch_bounds__(GB_THREADS) void backedge_kernel(BackArgs a) {
     PruneParams pp{a.base, d, a.qb, a.alpha, a.qalpha, a.r, a.saturate, a.n, a.err};
     int N = 2;
     while (N < a.r + 1) N <<= 1;
-    for (uint32_t si = a.src_off[blockIdx.x]; si < a.src_off[blockIdx.x + 1]; si++) {
+    for (uint32_t si = a.src_off[blockIdx.x], se = back_end(a, blockIdx.x); si < se; si++) {
         const uint32_t p = a.srcs[si];
         const int len = s_len;
         __syncthreads();   // everyone has the length before thread 0 may change it below
@@ -808,7 +923,7 @@ __global__ __launch_bounds__(256) void backedge_gram_kernel(GramArgs ga) {
     uint32_t cur = lane < len ? a.adj[(size_t)t * r + lane] : 0u;   // lane l holds list entry l
     const int i16 = lane & 15, g4 = lane >> 4;
 
-    for (uint32_t si = a.src_off[ti]; si < a.src_off[ti + 1]; si++) {
+    for (uint32_t si = a.src_off[ti], se = back_end(a, (uint32_t)ti); si < se; si++) {
         const uint32_t p = a.srcs[si];
         if (len != r) {   // lib.rs:319-321
             if (!__ballot(lane < len && cur == p) && len < r) {
@@ -1168,21 +1283,45 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     const size_t words = (b->n + 31) / 32;
     const char* vm = getenv("MSE_VISITED_MODE");   // test hook: "hash" / "bitmap"
     size_t vl_cap = std::max<size_t>(4096, 2 * cfg->l * cfg->r) + cfg->r;
-    DevBuf d_order, bm, vli, vls, stg, stg_len, err, d_tg, d_off, d_src, cnts;
+    DevBuf d_order, bm, vli, vls, stg, stg_len, err, cnts, grp;
     // visited sets: bit maps, or hash tables once the index is so large that the tables are the smaller ones (visited_set.h)
     int table_bits = visited_table_bits(std::min<size_t>(b->n, vl_cap));
     bool use_hash = vm ? !strcmp(vm, "hash") : words > ((size_t)1 << table_bits);
     size_t set_words = use_hash ? (size_t)1 << table_bits : words;
     if (cnts.ensure(batch * 4) || d_order.ensure(n_order * 4) || bm.ensure(batch * set_words * 4) || vli.ensure(batch * vl_cap * 4) || vls.ensure(batch * vl_cap * 8) ||
-        stg.ensure(batch * r * 4) || stg_len.ensure(batch * 4) || err.ensure(4) || d_tg.ensure(batch * r * 4 + 4) ||
-        d_off.ensure(batch * r * 4 + 8) || d_src.ensure(batch * r * 4 + 4))
+        stg.ensure(batch * r * 4) || stg_len.ensure(batch * 4) || err.ensure(8))
         return -1;
+    // back-edge grouping on the device (group_*_kernel): a table of >= 2 slots per entry of a batch + per-entry / per-target arrays
+    const size_t n_ent = batch * (size_t)r;
+    int gbits = 10;
+    while (((size_t)1 << gbits) < 2 * n_ent) gbits++;
+    const size_t TS = (size_t)1 << gbits;
+    if (grp.ensure(TS * 12 + n_ent * 4 * 8 + 64)) return -1;
+    GroupArgs ga{};
+    {
+        char* q = grp.as<char>();
+        ga.keys = reinterpret_cast<uint32_t*>(q); q += TS * 4;
+        ga.cnt = reinterpret_cast<uint32_t*>(q); q += TS * 4;
+        ga.tidx = reinterpret_cast<uint32_t*>(q); q += TS * 4;
+        ga.ent_slot = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.targets = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.t_off = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.t_cnt = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.t_slot = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.t_fill = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.srcs = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.srcs_pts = reinterpret_cast<uint32_t*>(q); q += n_ent * 4;
+        ga.counters = reinterpret_cast<uint32_t*>(q);
+        ga.bits = gbits; ga.r = r; ga.stg = stg.as<uint32_t>(); ga.len = stg_len.as<uint32_t>();
+    }
+    MSE_HIP_TRY(hipMemsetAsync(ga.keys, 0xff, TS * 4, st));                 // empty table; the kernels leave it empty again
+    MSE_HIP_TRY(hipMemsetAsync(ga.cnt, 0, TS * 4, st));
+    MSE_HIP_TRY(hipMemsetAsync(ga.t_fill, 0, n_ent * 4, st));
+    MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 8, st));                           // [0] search / prune (reset per try), [1] back edges (sticky)
     MSE_HIP_TRY(hipMemcpyAsync(d_order.p, order, n_order * 4, hipMemcpyHostToDevice, st));
     if (set_lds(graph_search_kernel<true>) || set_lds(prune_kernel<false>) || set_lds(prune_kernel<true>)) return -1;
     const size_t lds = search_lds_bytes(d, (int)cfg->l);
     PruneParams pp{b->dev, d, cfg->query_breakpoint, cfg->alpha, cfg->query_alpha, r, (int)cfg->saturate_graph, (uint32_t)b->n, err.as<uint32_t>(), 0};
-    std::vector<uint32_t> h_stg(batch * r), h_len(batch), targets, offs, srcs;
-    std::vector<uint32_t> slot(b->n, 0xffffffffu), first_seen, counts, fill;
     GraphArgs a{};
     a.base = b->dev; a.n = (uint32_t)b->n; a.d = d;
     a.adj = g->adj; a.deg = g->deg; a.r = r;
@@ -1192,7 +1331,7 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
     a.err = err.as<uint32_t>();
     BackArgs ba{};
     ba.base = b->dev; ba.d = d; ba.adj = g->adj; ba.deg = g->deg; ba.r = r;
-    ba.n = (uint32_t)b->n; ba.err = err.as<uint32_t>();
+    ba.n = (uint32_t)b->n; ba.err = err.as<uint32_t>() + 1;
     ba.qb = cfg->query_breakpoint; ba.maxc = (int)cfg->maxc; ba.saturate = (int)cfg->saturate_graph; ba.alpha = cfg->alpha; ba.qalpha = cfg->query_alpha;
     const size_t back_lds = 2 * (size_t)((d * 2 + 15) & ~15);
     // candidate products from the matrix cores wherever the error bound can be stated (finite norms, sane factors)
@@ -1209,7 +1348,7 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
             a.vl_ids = vli.as<uint32_t>(); a.vl_sc = vls.as<long long>(); a.vl_cap = (uint32_t)vl_cap;
             a.bitmap = bm.as<uint32_t>(); a.bm_words = set_words; a.hash_bits = use_hash ? table_bits : 0;
             MSE_HIP_TRY(hipMemsetAsync(bm.p, use_hash ? 0xff : 0, nb * set_words * 4, st));
-            MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));
+            MSE_HIP_TRY(hipMemsetAsync(err.p, 0, 4, st));   // word 0 only
             hipLaunchKernelGGL(graph_search_kernel<true>, dim3((unsigned)nb), dim3(GS_THREADS), lds, st, a);
             MSE_HIP_TRY(hipGetLastError());
             if (pp.eps_fix > 0)
@@ -1219,11 +1358,11 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
                 hipLaunchKernelGGL(prune_kernel<false>, dim3((unsigned)nb), dim3(GB_THREADS), prune_lds_bytes(d), st, pp, a.vl_ids, a.vl_sc, vl_cap,
                                    cnts.as<uint32_t>(), a.points, (int)cfg->maxc, stg.as<uint32_t>(), stg_len.as<uint32_t>());
             MSE_HIP_TRY(hipGetLastError());
-            uint32_t e = 0;
-            MSE_HIP_TRY(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
-            MSE_HIP_TRY(hipMemcpyAsync(h_stg.data(), stg.p, nb * r * 4, hipMemcpyDeviceToHost, st));
-            MSE_HIP_TRY(hipMemcpyAsync(h_len.data(), stg_len.p, nb * 4, hipMemcpyDeviceToHost, st));
+            uint32_t e2[2] = {0, 0};
+            MSE_HIP_TRY(hipMemcpyAsync(e2, err.p, 8, hipMemcpyDeviceToHost, st));
             MSE_HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t e = e2[0];
+            if (e2[1]) return fail("build_graph: internal error " + std::to_string(e2[1]) + " (a candidate id outside the index)");   // the previous batch's back edges
             if (e & 1u) return fail("build_graph: a graph edge points outside the index");
             if (!(e & 6u)) break;
             // a search visited more nodes than there was room for (list or table): repeat the batch with more (the graph is untouched so far)
@@ -1242,50 +1381,38 @@ int mse_build_graph(mse_searcher* s, mse_graph* g, const uint32_t* order, size_t
         hipLaunchKernelGGL(apply_lists_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, g->adj, g->deg, r, a.points, stg.as<uint32_t>(),
                            stg_len.as<uint32_t>(), (int)nb);
         MSE_HIP_TRY(hipGetLastError());
-        // back edges grouped by the list they touch, each group in (position in batch, position in list) order: a
-        // counting sort over the touched lists; lists with many newcomers go first (one workgroup works through them alone)
-        first_seen.clear(); counts.clear();
-        for (size_t k = 0; k < nb; k++)
-            for (uint32_t j = 0; j < h_len[k]; j++) {
-                const uint32_t t = h_stg[k * r + j];
-                if (slot[t] == 0xffffffffu) { slot[t] = (uint32_t)first_seen.size(); first_seen.push_back(t); counts.push_back(0); }
-                counts[slot[t]]++;
-            }
-        if (first_seen.empty()) continue;
-        targets.clear(); offs.clear();
-        uint32_t run = 0;
-        for (int pass = 0; pass < 2; pass++)
-            for (size_t i = 0; i < first_seen.size(); i++)
-                if ((counts[i] >= 4) == (pass == 0)) {
-                    slot[first_seen[i]] = (uint32_t)targets.size();
-                    targets.push_back(first_seen[i]); offs.push_back(run);
-                    run += counts[i];
-                }
-        offs.push_back(run);
-        srcs.resize(run);
-        fill.assign(targets.size(), 0);
-        for (size_t k = 0; k < nb; k++)
-            for (uint32_t j = 0; j < h_len[k]; j++) {
-                const uint32_t ti = slot[h_stg[k * r + j]];
-                srcs[offs[ti] + fill[ti]++] = order[b0 + k];
-            }
-        for (uint32_t t : targets) slot[t] = 0xffffffffu;
-        MSE_HIP_TRY(hipMemcpyAsync(d_tg.p, targets.data(), targets.size() * 4, hipMemcpyHostToDevice, st));
-        MSE_HIP_TRY(hipMemcpyAsync(d_off.p, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, st));
-        MSE_HIP_TRY(hipMemcpyAsync(d_src.p, srcs.data(), srcs.size() * 4, hipMemcpyHostToDevice, st));
-        ba.targets = d_tg.as<uint32_t>(); ba.src_off = d_off.as<uint32_t>(); ba.srcs = d_src.as<uint32_t>();
+        // back edges grouped by the list they touch, each group in (position in batch, position in list) order, lists with many
+        // newcomers first -- on the device (group_*_kernel above); only the number of lists comes back
+        ga.nb = (uint32_t)nb; ga.points = a.points;
+        MSE_HIP_TRY(hipMemsetAsync(ga.counters, 0, 32, st));
+        const unsigned g_ent = (unsigned)((nb * (size_t)r + 255) / 256), g_tab = (unsigned)(TS / 256);
+        hipLaunchKernelGGL(group_count_kernel, dim3(g_ent), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL(group_classify_kernel, dim3(g_tab), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL(group_compact_kernel, dim3(g_tab), dim3(256), 0, st, ga);
+        MSE_HIP_TRY(hipGetLastError());
+        uint32_t h_cnt[2] = {0, 0};
+        MSE_HIP_TRY(hipMemcpyAsync(h_cnt, ga.counters, 8, hipMemcpyDeviceToHost, st));
+        MSE_HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t n_targets = h_cnt[0] + h_cnt[1];
+        if (n_targets == 0) continue;
+        hipLaunchKernelGGL(group_fill_kernel, dim3(g_ent), dim3(256), 0, st, ga);
+        if (h_cnt[0]) hipLaunchKernelGGL(group_order_big_kernel, dim3(h_cnt[0]), dim3(256), 0, st, ga);
+        if (h_cnt[1]) hipLaunchKernelGGL(group_order_small_kernel, dim3((h_cnt[1] + 255) / 256), dim3(256), 0, st, ga, h_cnt[0], n_targets);
+        MSE_HIP_TRY(hipGetLastError());
+        ba.targets = ga.targets; ba.src_off = ga.t_off; ba.src_cnt = ga.t_cnt; ba.srcs = ga.srcs_pts;
         if (use_gram) {
-            GramArgs ga{ba, (int)targets.size(), eps_fix};
-            hipLaunchKernelGGL(backedge_gram_kernel, dim3((unsigned)((targets.size() + 3) / 4)), dim3(256), 4 * GR_WAVE_LDS, st, ga);
+            GramArgs gg{ba, (int)n_targets, eps_fix};
+            hipLaunchKernelGGL(backedge_gram_kernel, dim3((unsigned)((n_targets + 3) / 4)), dim3(256), 4 * GR_WAVE_LDS, st, gg);
         } else {
-            hipLaunchKernelGGL(backedge_kernel, dim3((unsigned)targets.size()), dim3(GB_THREADS), back_lds, st, ba);
+            hipLaunchKernelGGL(backedge_kernel, dim3((unsigned)n_targets), dim3(GB_THREADS), back_lds, st, ba);
         }
         MSE_HIP_TRY(hipGetLastError());
-        uint32_t e2 = 0;
-        MSE_HIP_TRY(hipMemcpyAsync(&e2, err.p, 4, hipMemcpyDeviceToHost, st));
-        MSE_HIP_TRY(hipStreamSynchronize(st));   // the host vectors above are reused by the next batch
-        if (e2) return fail("build_graph: internal error " + std::to_string(e2) + " (a candidate id outside the index)");
+        // (no wait here: the back edges' error word is sticky and is read with the next batch's, or below)
     }
+    uint32_t e_last[2] = {0, 0};
+    MSE_HIP_TRY(hipMemcpyAsync(e_last, err.p, 8, hipMemcpyDeviceToHost, st));
+    MSE_HIP_TRY(hipStreamSynchronize(st));
+    if (e_last[1]) return fail("build_graph: internal error " + std::to_string(e_last[1]) + " (a candidate id outside the index)");
     return 0;
 }
 

@@ -23,6 +23,8 @@ struct GemmLaunch {
     int kdh_pad = 0;               // k row stride in elements (attention_k_stride()); 0 = dh_pad
     int gelu_tanh = 0;
     int skinny = 0;                // launch_gemm: few rows (m_valid <= 512) may take the K-split skinny kernel (text tower)
+    hipStream_t side = nullptr;    // launch_gemm: the 128-column remainder launch runs here, beside the full column tiles (ev_fork / ev_join order it)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // LayerNorm-fused launches (launch_gemm_fused)
     const float* ln_stats = nullptr;   // consumers (QKV, GELU): (mean, 1/std) per row of x, which is then the FP16 residual stream
     const float* csum = nullptr;       // consumers: sum_k w'[n][k]; `w` holds the fp16 gamma-folded weights, `bias` the beta-folded bias

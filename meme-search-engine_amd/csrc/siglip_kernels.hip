@@ -131,6 +131,10 @@ struct GemmArgs {
     int gelu_tanh;
     int stagger;          // persistent kernel: 64-cycle sleep units per K tile and XCD index at start (0 = none)
     int skinny;           // launch_gemm: m_valid <= 512 may take gemm_skinny_kernel (the text tower sets it)
+    // host side only: the 128-column remainder launch of N = 1152 / 3456 may run on `side` BESIDE the full column tiles (it reads the same
+    // inputs and writes other columns); ev_fork / ev_join order it after what `st` held before the GEMM and before what follows it
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
     // LayerNorm folded into the GEMMs around it (gemm8pp_kernel only; see "Fused LayerNorm" above that kernel)
     const float2* ln_stats;   // LNF consumers: (mean, 1/std) of every row of x
     const float* csum;        // LNF consumers: c[n] = sum_k w'[n][k] (pre-offset like bias)
@@ -2180,6 +2184,11 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
     (void)old256;
 #endif
     const int n256 = use256 ? (a_in.N / B2) * B2 : 0;
+    const bool beside = a_in.side && n256 > 0 && n256 < a_in.N;
+    if (beside) {   // the remainder's stream sees everything `st` holds so far
+        MSE_HIP_TRY(hipEventRecord(a_in.ev_fork, st));
+        MSE_HIP_TRY(hipStreamWaitEvent(a_in.side, a_in.ev_fork, 0));
+    }
     if (n256 > 0) {
         GemmArgs a = a_in;
         a.N = n256;
@@ -2234,15 +2243,19 @@ template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
                 MSE_DYN_LDS((gemm8pp_kernel<EPI, VS, 0, 1>), lds);
                 a.stagger = 0;
                 const unsigned tiles = (unsigned)(a.M / 256);
-                hipLaunchKernelGGL((gemm8pp_kernel<EPI, VS, 0, 1>), dim3(std::min(tiles, (unsigned)mse::device_cu_count())), dim3(512), lds, st, a);
+                hipLaunchKernelGGL((gemm8pp_kernel<EPI, VS, 0, 1>), dim3(std::min(tiles, (unsigned)mse::device_cu_count())), dim3(512), lds, beside ? a_in.side : st, a);
                 done = true;
             }
         }
         if (!done) {
             const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
-            hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), GS * STAGE_BYTES, st, a);
+            hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(grid), dim3(GW * 64), GS * STAGE_BYTES, beside ? a_in.side : st, a);
         }
         MSE_HIP_TRY(hipGetLastError());
+        if (beside) {
+            MSE_HIP_TRY(hipEventRecord(a_in.ev_join, a_in.side));
+            MSE_HIP_TRY(hipStreamWaitEvent(st, a_in.ev_join, 0));
+        }
     }
     return 0;
 }
@@ -2313,7 +2326,7 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     a.out_bf16 = g.out_bf16; a.ldo = g.ldo; a.resid = g.resid; a.ldr = g.ldr; a.pos = g.pos; a.tokens = g.tokens;
     a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
     a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh; a.kdh_pad = g.kdh_pad ? g.kdh_pad : g.dh_pad;
-    a.skinny = g.skinny;
+    a.skinny = g.skinny; a.side = g.side; a.ev_fork = g.ev_fork; a.ev_join = g.ev_join;
     switch (epi) {
         case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, st);
         case EPI_GELU: return launch_gemm_t<EPI_GELU>(a, st);

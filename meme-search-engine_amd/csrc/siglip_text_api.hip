@@ -42,6 +42,8 @@ struct mse_siglip_text {
     size_t m_pad = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the second half of a large batch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};          // per half: where the 128-column remainder launches of its GEMMs run
+    hipEvent_t side_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     std::mutex call_mu;   // one call at a time: token upload, kernels and scratch of a call share one stream (see mse_siglip)
     std::vector<void*> allocs;
     std::map<std::string, TSlot> slots;
@@ -94,6 +96,12 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
         (void)hipGetLastError();
         if (m->stream2) { (void)hipStreamDestroy(m->stream2); m->stream2 = nullptr; }   // one stream then: correct, only slower
     }
+    for (int hlf = 0; hlf < 2; hlf++)
+        if (hipStreamCreateWithFlags(&m->side[hlf], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->side_ev[hlf][0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->side_ev[hlf][1], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (m->side[hlf]) { (void)hipStreamDestroy(m->side[hlf]); m->side[hlf] = nullptr; }
+        }
     const size_t D = m->D, MP = m->mlp_pad;
     m->add_f32("text.token_embedding.weight", &m->tok_emb, c->vocab_size, D);
     m->add_f32("text.positional_embedding", &m->pos, m->ctx, D);
@@ -135,6 +143,10 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
 
 void mse_siglip_text_destroy(mse_siglip_text* m) {
     if (!m) return;
+    for (int hlf = 0; hlf < 2; hlf++) {
+        if (m->side[hlf]) { (void)hipStreamSynchronize(m->side[hlf]); (void)hipStreamDestroy(m->side[hlf]); }
+        for (hipEvent_t e : m->side_ev[hlf]) if (e) (void)hipEventDestroy(e);
+    }
     if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -201,8 +213,12 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     // The blocks over the sequences [b0, b0 + nb) on stream `ss`: rows b0 * T .. of every activation buffer, (sequence, head) matrices
     // b0 * H .. of the attention operands.  b0 * T is a multiple of 256, so the GEMMs' row padding stays inside the range's own rows
     // (or behind the last range).
-    auto blocks = [&](hipStream_t ss, int b0, int nb) -> int {
+    auto blocks = [&](hipStream_t ss, int b0, int nb, int half) -> int {
         const size_t r0 = (size_t)b0 * T;
+        // large halves: the remainder launches of the N = 1152 / 3456 GEMMs beside their full column tiles (32-64 workgroups that ran
+        // alone for 43 us after the 56 us of the four full tiles)
+        hipStream_t sd = nb * T > 512 ? m->side[half] : nullptr;
+        auto with_side = [&](GemmLaunch& g) { g.side = sd; g.ev_fork = m->side_ev[half][0]; g.ev_join = m->side_ev[half][1]; };
         const int Ms = nb * T, Msp = (int)round_up(Ms, 256);
         uint16_t *x = m->x + r0 * D, *h = m->h + r0 * D, *dlt = m->dlt + r0 * D, *mlp_h = m->mlp_h + r0 * m->mlp_pad;
         uint16_t* qb = m->qb + (size_t)b0 * m->H * m->n_pad * m->dh_pad;
@@ -216,12 +232,14 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
                 GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Msp; g.N = 3 * D; g.K = D; g.m_valid = Ms; g.tokens = T;
                 g.q = qb; g.k = kb; g.vt = vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
                 g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+                with_side(g);
                 if (launch_gemm(GEMM_EPI_QKV, g, ss)) return -1;
             }
             if (launch_attention(qb, kb, vtb, nb, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, h, D, T, ss)) return -1;
             {
                 GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.wproj; g.bias = b.bproj; g.M = Msp; g.N = D; g.K = D; g.m_valid = Ms;
                 g.out_bf16 = dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+                with_side(g);
                 if (launch_gemm(GEMM_EPI_BF16, g, ss)) return -1;
             }
             if (launch_layernorm(x, 1, D, dlt, D, b.ln2_g, b.ln2_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;   // x += attention branch
@@ -233,6 +251,7 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
             {
                 GemmLaunch g; g.skinny = 1; g.x = mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Msp; g.N = D; g.K = m->mlp_pad; g.m_valid = Ms;
                 g.out_bf16 = dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
+                with_side(g);
                 if (launch_gemm(GEMM_EPI_BF16, g, ss)) return -1;
             }
         }
@@ -245,10 +264,10 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     if (b_first < batch) {
         MSE_HIP_TRY(hipEventRecord(m->ev_fork, st));
         MSE_HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
-        if (blocks(m->stream2, b_first, batch - b_first)) return -1;
+        if (blocks(m->stream2, b_first, batch - b_first, 1)) return -1;
         MSE_HIP_TRY(hipEventRecord(m->ev_join, m->stream2));
     }
-    if (blocks(st, 0, b_first)) return -1;
+    if (blocks(st, 0, b_first, 0)) return -1;
     if (b_first < batch) MSE_HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
     if (launch_layernorm(m->x + (size_t)(T - 1) * D, 1, T * D, c.layers ? m->dlt + (size_t)(T - 1) * D : nullptr, T * D, m->lnf_g, m->lnf_b,

@@ -30,14 +30,8 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "pq_scan64x4_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# calls of 64 queries = runs of eight scans; a new call starts after a gap of more than 1 ms without a scan running
-calls, cur = [], []
-for r in rows:
-    if cur and int(r["Start_Timestamp"]) - max(int(x["End_Timestamp"]) for x in cur) > 1_000_000:
-        calls.append(cur); cur = []
-    cur.append(r)
-if cur: calls.append(cur)
-calls = [c for c in calls if len(c) == 8][2:]          # the first two calls are warm-up
+# a call of 64 queries = eight scans, and a call ends before the next begins: consecutive groups of eight in start order
+calls = [rows[i:i + 8] for i in range(0, len(rows) - 7, 8)][2:]      # the first two calls are warm-up
 tot = sum((max(int(x["End_Timestamp"]) for x in c) - int(c[0]["Start_Timestamp"])) for c in calls)
 n = sum(len(c) for c in calls)
 print("pq_scan64x4_kernel<16, 8>: %d calls of eight scans; first scan's start to last scan's end / 8 = %.1f us per scan (sustained, two streams)" % (len(calls), tot / n / 1e3))

@@ -278,3 +278,20 @@ def test_build_graph_rejects_bad_arguments(gpu, mse, orc):
     g2 = mse.BuildGraph(n, r, mse.IndexGraph(bad, np.full(n, r, np.uint32)))
     with pytest.raises(mse.MseError):
         g2.build(s, np.arange(n, dtype=np.uint32), 0, mse.IndexBuildConfig(r=r, l=32, maxc=50))
+
+
+def test_back_edges_grouped_on_the_device_hubs_and_ragged_batches(gpu, mse, orc):
+    """The back edges of a batch are grouped by target on the device (round 5: an open-addressing table, atomics, segments sorted by
+    entry number).  One batch that holds EVERY point of a small set sends hundreds of back edges to the same few lists (every search
+    starts at the medioid of a random graph) -- the workgroup-per-target ordering kernel -- next to thousands of targets with one or two;
+    a second run uses a batch size that does not divide the point count.  Edge for edge against the oracle's batched form."""
+    n, r = 900, 16
+    vecs = rows(orc, n, seed=12)
+    order = np.random.default_rng(7).permutation(n).astype(np.uint32)
+    med = int(orc.medioid(vecs))
+    for batch in (n, 257):
+        adj, deg, g, _ = build_both(orc, mse, vecs, r, order, med, [dict(r=r, l=40, maxc=90)], batch, seed=22)
+        h = g.to_host()
+        assert np.array_equal(h.deg, deg), batch
+        for i in range(n):
+            assert np.array_equal(h.adj[i, :deg[i]], adj[i, :deg[i]]), (batch, i)
