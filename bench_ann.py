@@ -579,7 +579,7 @@ def sharded_ann_rank(comm, dist, rank, world, rows_per_gpu=2_000_000, k=10, r=20
     return res
 
 
-def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=900.0, n=100_000_000, batch=16384):
+def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=1000.0, n=100_000_000, batch=16384):
     """The graph index AT THE METRIC'S SIZE under the command's own clock: ONE Vamana graph over 1e8 x 1152 easy-set rows (230 GB of
     rows + 26 GB of graph in the 288 GB of one MI355X), one pass (generate-index-shard's default), searched through the request path
     in one call; operating point on 4096 tuning queries, reported on 4096 held-out ones.  Guarded by time: the build is predicted
@@ -591,8 +591,11 @@ def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=900.0, n=100_000_000, 
     from mse import ffi
     if not rate_1e7_points_per_s:
         return {"skipped": "no 1e7-row build rate measured in this run to predict the build from"}
-    predicted = n / (0.75 * rate_1e7_points_per_s)
-    if predicted > budget_s:
+    per_pass = n / (0.75 * rate_1e7_points_per_s)
+    # generate-index-shard's second pass (-s) when two fit the budget (a one-pass graph of this size tops out at recall@10 0.96), else one
+    passes = 2 if 2 * per_pass + 60 <= budget_s else 1
+    predicted = passes * per_pass
+    if predicted + 30 > budget_s:
         return {"skipped": f"a one-pass build of {n:.0e} rows is predicted to take {predicted:.0f} s (0.75 x the {rate_1e7_points_per_s:.0f} points/s "
                            f"measured at 1e7 rows in this run) against a budget of {budget_s:.0f} s", "predicted_build_seconds": predicted}
     free_b, total_b = ffi.sz(), ffi.sz()
@@ -619,19 +622,23 @@ def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=900.0, n=100_000_000, 
     g = mse.BuildGraph(n, R)
     g.random_fill(1)
     order = np.random.default_rng(3).permutation(n).astype(np.uint32)
-    g.build(s, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
+    pass_s = []
+    for _ in range(passes):
+        tp = time.perf_counter()
+        g.build(s, order, med, mse.IndexBuildConfig(r=R, l=192, maxc=750), batch)
+        pass_s.append(time.perf_counter() - tp)
     t_build = time.perf_counter() - t0
     n_entry = n // 1500
     e_idx = np.sort(np.random.default_rng(5).choice(n, n_entry, replace=False)).astype(np.uint32)
     mse.set_entries(g, vecs, e_idx)
     sweep, chosen, best = [], None, None
-    for L in (16, 24, 32, 48, 64, 100, 200, 400):
+    for L in (12, 16, 24, 32, 48, 64, 100, 200, 400):
         top, _, _ = mse.disk_query_topk(s, None, None, g, qt16, K, None, None, None, True, 4, L)
         rec = recall_at(top, truth_t)
         sweep.append([L, round(rec, 4)])
         if best is None or rec > best[1]:
             best = (L, rec)
-        if rec >= 0.955:
+        if rec >= (0.97 if passes > 1 else 0.955):
             chosen = L
             break
     L = chosen or best[0]
@@ -639,12 +646,12 @@ def graph_index_1e8(root, rate_1e7_points_per_s, budget_s=900.0, n=100_000_000, 
     t0 = time.perf_counter()
     top, _, st = mse.disk_query_topk(s, None, None, g, qh16, K, None, None, None, True, 4, L)
     dt = time.perf_counter() - t0
-    out = {"metric": "queries/sec over a 1e8x1152 graph index @ recall@10>=0.95 (ONE Vamana graph, one pass, GPU-resident beam search)",
+    out = {"metric": "queries/sec over a 1e8x1152 graph index @ recall@10>=0.95 (ONE Vamana graph, %d pass%s, GPU-resident beam search)" % (passes, "es" if passes > 1 else ""),
            "value": nq_t / dt, "unit": "queries/s", "recall_at_10": recall_at(top, truth_h), "search_list": L, "beamwidth": 4, "queries": nq_t,
-           "operating_point": "smallest search list with tuning recall >= 0.955" if chosen else "no search list reached 0.955 on the tuning queries: the best one",
+           "operating_point": ("smallest search list with tuning recall >= %s" % (0.97 if passes > 1 else 0.955)) if chosen else "no search list reached the tuning goal: the best one",
            "tuning_sweep": sweep, "node_fetches_per_query": float(st["cmps"].mean()),
-           "build": {"seconds": t_build, "points_per_s": n / t_build, "passes": 1, "r": R, "l": 192, "maxc": 750, "batch": batch,
-                     "predicted_seconds": predicted},
+           "build": {"seconds": t_build, "points_per_s": n * passes / sum(pass_s), "passes": passes, "seconds_per_pass": pass_s, "r": R, "l": 192, "maxc": 750,
+                     "batch": batch, "predicted_seconds": predicted},
            "entry": f"{n_entry} sampled rows, exact top-1 (timed)", "exact_scan_same_rows_queries_per_s": 2 * nq_t / t_exact,
            "config": {"workload": f"{n} x {D} fp16 easy-set rows generated on the device in {t_gen:.1f} s; host arrays in and out"},
            "seconds": time.perf_counter() - t_all}
