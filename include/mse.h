@@ -428,6 +428,12 @@ int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, con
 int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,
                               const float* luts, const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k,
                               uint64_t id_offset, void* block_dev, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
+/* The handler's runtime de-duplication (src/query_disk_index.rs:482-527, DUPLICATES_THRESHOLD 0.95 :99) INSIDE mse_disk_query_topk(_f32)
+ * and its block form: before the visited records are ordered, a record whose vector has a dot product above `threshold` with an ALREADY
+ * KEPT record (f32 products of the f16 rows, summed k-ascending as mse_dedup_visited; visit order) is dropped -- for every query of the
+ * batch on the device.  0 = off (the default: the k best of ALL visited records).  n_visited still counts every visited record.
+ * At most 4096 visited records per query (search lists up to ~2000).  Set while no request-path call is in flight. */
+int mse_graph_set_dedup(mse_graph* g, float threshold);
 int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t max_wait_us, int workers);
 int mse_graph_coalescer_stats(const mse_graph* g, uint64_t out[6]);
 /* everything `producer_stream` (a hipStream_t) holds at the time of the call completes before anything this searcher's stream is

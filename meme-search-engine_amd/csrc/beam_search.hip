@@ -825,6 +825,13 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         // come back in ONE copy into the searcher's pinned staging (round 5: five pageable copies before).
         int64_t* top_sc = reinterpret_cast<int64_t*>(fzb.as<char>() + fz_block_off);
         uint32_t* top_id = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(top_sc) + nq * fz->k * 8);
+        if (g->dedup_threshold > 0.0f) {
+            // the handler's runtime de-duplication (:482-527) before its sort: a visited record that resembles an already kept one (dot of
+            // the f32-widened vectors above the threshold, visit order) leaves the list -- on the device, for every query of the batch
+            DevBuf& db = s->pool[15];
+            if (db.ensure(dedup_batch_scratch_bytes(nq, visited_cap))) return -1;
+            if (launch_dedup_batch(b->dev, (int)d, vi.as<uint32_t>(), vs.as<long long>(), visited_cap, cnt_dev, nq, g->dedup_threshold, db.p, st)) return -1;
+        }
         SelectArgs sa{};
         sa.kind = KEY_I64; sa.list_ids = vi.as<uint32_t>(); sa.list_keys = vs.p; sa.list_stride = visited_cap; sa.n_list = visited_cap;
         sa.k = (int)fz->k; sa.out_ids = top_id; sa.out_keys = top_sc; sa.out_stride = fz->k; sa.nq = (int)nq;
@@ -1312,6 +1319,13 @@ int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
     fz.dev_ids = reinterpret_cast<uint32_t*>(static_cast<char*>(block_dev) + nq * k * 8);
     fz.id_offset = id_offset;
     return fused_run(s, pq, c, g, starts, queries, nullptr, luts, scales, nq, disable_pq, beamwidth, search_list, fz);
+}
+
+int mse_graph_set_dedup(mse_graph* g, float threshold) {
+    if (!g) return fail("null graph");
+    if (!(threshold >= 0.0f)) return fail("graph_set_dedup: threshold must be >= 0 (0 = off)");
+    g->dedup_threshold = threshold;   // no request-path call may be in flight
+    return 0;
 }
 
 int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t max_wait_us, int workers) {

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void sim_bits_kernel(const uint16_t* __restric
 // (i, j) dot is still the chain s = fmaf(a_k, b_k, s) for k ascending, so the comparison against the threshold is unchanged
 // (the first kernel spent its time in per-lane 2-byte loads: 3.3 ms for 1000 visited rows, 40 ms for 4000).
 constexpr int SB_T = 64, SB_K = 32;
-__global__ __launch_bounds__(256) void sim_bits_tiled_kernel(const uint16_t* __restrict__ base, int d, const uint32_t* __restrict__ ids,
-                                                             int n, float threshold, unsigned long long* __restrict__ bits, int words) {
+__device__ __forceinline__ void sim_bits_tile(const uint16_t* __restrict__ base, int d, const uint32_t* __restrict__ ids, int n, float threshold,
+                                              unsigned long long* __restrict__ bits, int words) {
     __shared__ __attribute__((aligned(16))) float As[SB_K][SB_T + 4];   // rows i0 .. i0+63
     __shared__ __attribute__((aligned(16))) float Bs[SB_K][SB_T + 4];   // rows j0 .. j0+63
     __shared__ unsigned long long mask[SB_T];
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void sim_bits_tiled_kernel(const uint16_t* __r
     while (bi * (bi + 1) / 2 > (int)blockIdx.x) bi--;
     const int bj = (int)blockIdx.x - bi * (bi + 1) / 2;
     const int i0 = bi * SB_T, j0 = bj * SB_T;
+    if (i0 >= n) return;   // (batched form: a list shorter than the grid was sized for; uniform for the workgroup)
     const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
     if (tid < SB_T) mask[tid] = 0ull;
     float acc[4][4];   // [a: row i][b: row j]
@@ -186,8 +187,64 @@ __global__ __launch_bounds__(256) void sim_bits_tiled_kernel(const uint16_t* __r
     __syncthreads();
     if (tid < SB_T && i0 + tid < n) bits[(size_t)(i0 + tid) * words + bj] = mask[tid];
 }
+__global__ __launch_bounds__(256) void sim_bits_tiled_kernel(const uint16_t* __restrict__ base, int d, const uint32_t* __restrict__ ids,
+                                                             int n, float threshold, unsigned long long* __restrict__ bits, int words) {
+    sim_bits_tile(base, d, ids, n, threshold, bits, words);
+}
+// The request path's runtime de-duplication INSIDE the call (src/query_disk_index.rs:482-527), for every query of a batch: the same
+// similarity bits over the query's visited records (blockIdx.y = query; lists are [cap] wide, n_visited[q] long) ...
+__global__ __launch_bounds__(256) void sim_bits_batch_kernel(const uint16_t* __restrict__ base, int d, const uint32_t* __restrict__ vis_ids, size_t cap,
+                                                             const uint32_t* __restrict__ n_visited, float threshold, unsigned long long* __restrict__ bits,
+                                                             int words) {
+    const size_t q = blockIdx.y;
+    const int n = (int)min((size_t)n_visited[q], cap);
+    sim_bits_tile(base, d, vis_ids + q * cap, n, threshold, bits + q * cap * (size_t)words, words);
+}
+// ... and the greedy keep-first filter in visit order (:514-527), one wave per query: lane w holds word w of the "kept" set; a record
+// that resembles an already kept one leaves the list (id none, score minimal: the select that follows skips it)
+__global__ __launch_bounds__(64) void dedup_filter_batch_kernel(const unsigned long long* __restrict__ bits, int words, size_t cap,
+                                                                const uint32_t* __restrict__ n_visited, uint32_t* __restrict__ vis_ids,
+                                                                long long* __restrict__ vis_scores) {
+    const size_t q = blockIdx.x;
+    const int lane = threadIdx.x, n = (int)min((size_t)n_visited[q], cap);
+    const unsigned long long* b = bits + q * cap * (size_t)words;
+    unsigned long long kept = 0ull;
+    unsigned long long row = lane < words && n > 0 ? b[lane] : 0ull;
+    for (int i = 0; i < n; i++) {
+        const unsigned long long next = (lane < words && i + 1 < n) ? b[(size_t)(i + 1) * words + lane] : 0ull;   // in flight during the vote
+        const bool dropped = __ballot((row & kept) != 0ull) != 0ull;
+        if (dropped) {
+            if (lane == 0) { vis_ids[q * cap + i] = 0xffffffffu; vis_scores[q * cap + i] = (long long)INT64_MIN; }
+        } else if (lane == i / 64) {
+            kept |= 1ull << (i % 64);
+        }
+        row = next;
+    }
+}
 
 }  // namespace
+
+namespace mse {
+// scratch_bytes(nq, cap): what `bits` must hold; cap <= 4096 (64 words of 64 records)
+size_t dedup_batch_scratch_bytes(size_t nq, size_t cap) { return nq * cap * ((cap + 63) / 64) * 8; }
+int launch_dedup_batch(const uint16_t* base, int d, uint32_t* vis_ids, long long* vis_scores, size_t cap, const uint32_t* n_visited, size_t nq,
+                       float threshold, void* bits, hipStream_t st) {
+    const int words = (int)((cap + 63) / 64);
+    if (words > 64) return fail("request-path de-duplication: more than 4096 visited records per query");
+    if (nq == 0 || cap == 0) return 0;
+    MSE_HIP_TRY(hipMemsetAsync(bits, 0, dedup_batch_scratch_bytes(nq, cap), st));   // words above the diagonal are never written
+    for (size_t q0 = 0; q0 < nq; q0 += 65535) {   // gridDim.y
+        const size_t m = std::min<size_t>(65535, nq - q0);
+        hipLaunchKernelGGL(sim_bits_batch_kernel, dim3((unsigned)(words * (words + 1) / 2), (unsigned)m), dim3(256), 0, st, base, d, vis_ids + q0 * cap, cap,
+                           n_visited + q0, threshold, static_cast<unsigned long long*>(bits) + q0 * cap * (size_t)words, words);
+    }
+    MSE_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dedup_filter_batch_kernel, dim3((unsigned)nq), dim3(64), 0, st, static_cast<const unsigned long long*>(bits), words, cap, n_visited,
+                       vis_ids, vis_scores);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace mse
 
 extern "C" {
 

@@ -125,6 +125,12 @@ int rank_max_targets();
 int launch_rank(const int64_t* scores, size_t n, const uint32_t* targets, int m, unsigned long long* counts, int n_cu,
                 hipStream_t stream);
 
+// ---- disk_search.hip: the runtime de-duplication of the request path for a batch, on the device ------------------------------------
+// per query q: similarity bits over its visited records (vis_ids [nq][cap], n_visited[q] of them, visit order), greedy keep-first
+// filter; a dropped record becomes (ID_NONE, INT64_MIN) in place.  bits: dedup_batch_scratch_bytes(nq, cap) bytes of scratch.
+size_t dedup_batch_scratch_bytes(size_t nq, size_t cap);
+int launch_dedup_batch(const uint16_t* base, int d, uint32_t* vis_ids, long long* vis_scores, size_t cap, const uint32_t* n_visited, size_t nq,
+                       float threshold, void* bits, hipStream_t st);
 // ---- scan_mfma.hip ---------------------------------------------------------------------------
 // group_max[q_pad_index][g] layout: [n_groups][nq_pad] floats (group-major), nq_pad multiple of 32
 int launch_scan_mfma(const uint16_t* base, size_t n_rows, int d, const uint16_t* queries_dev, int nq_pad,

@@ -169,6 +169,8 @@ struct mse_graph {
     float* entry_keys_t = nullptr;
     size_t entry_keys_d = 0;
     mutable mse::SharedExclusive entry_lock;
+    // runtime de-duplication of the request path (src/query_disk_index.rs:482-527) inside mse_disk_query_topk(_f32): 0 = off
+    float dedup_threshold = 0.0f;
     // searchers over the entry rows: a fused call borrows one for its duration (its scratch is in use until the call's stream is
     // drained), so that calls from several threads -- each with its own searcher and stream -- overlap instead of queueing
     mutable std::vector<mse_searcher*> entry_pool;

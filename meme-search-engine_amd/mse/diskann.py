@@ -224,6 +224,12 @@ def set_entry_centroids(dgraph, centroids, medioid_ids):
           "graph_set_entry_centroids")
 
 
+def set_dedup(dgraph, threshold=DUPLICATES_THRESHOLD):
+    """The handler's runtime de-duplication (query_disk_index.rs:482-527) inside disk_query_topk: visited records that resemble an
+    already kept one (dot above `threshold`, visit order) leave the list before it is ordered.  0 switches it off (the default)."""
+    check(ffi.lib().mse_graph_set_dedup(dgraph._h, float(threshold)), "graph_set_dedup")
+
+
 def set_coalescer(dgraph, max_queries_per_pass=0, max_wait_us=0, workers=0):
     """How the graph's coalescer serves small request-path calls from many threads (0 = the defaults: 1024, 200 us, 2 workers)."""
     check(ffi.lib().mse_graph_set_coalescer(dgraph._h, int(max_queries_per_pass), int(max_wait_us), int(workers)), "graph_set_coalescer")

@@ -152,6 +152,7 @@ SIGNATURES = {
     "mse_shard_group_query_topk": (C.c_int, [vp, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, i64p, u32p]),
     "mse_graph_set_entry_centroids": (C.c_int, [vp, f32p, sz, u32p, sz]),
     "mse_disk_query_topk_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
+    "mse_graph_set_dedup": (C.c_int, [vp, C.c_float]),
     "mse_graph_set_coalescer": (C.c_int, [vp, sz, C.c_uint32, C.c_int]),
     "mse_graph_coalescer_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "mse_searcher_wait_stream": (C.c_int, [vp, vp]),

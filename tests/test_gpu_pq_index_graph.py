@@ -1063,3 +1063,57 @@ def test_entry_step_small_and_large_batches_agree(gpu, mse, orc):
     for q0 in (0, 17, 200):
         small = mse.disk_query_topk(searcher, None, None, dgraph, qh[q0:q0 + 33], k, None, None, None, True, 2, L)
         assert np.array_equal(small[0], want[0][q0:q0 + 33]) and np.array_equal(small[1], want[1][q0:q0 + 33])
+
+
+@pytest.mark.parametrize("disable_pq", [True, False])
+def test_request_path_with_the_handlers_deduplication(gpu, mse, orc, disable_pq):
+    """The handler drops visited records that resemble an already kept one (dot > 0.95 of the f32-widened vectors, visit order)
+    BEFORE it orders them (src/query_disk_index.rs:482-527).  mse_graph_set_dedup runs that inside mse_disk_query_topk for every
+    query of the batch: against the oracle's search + orc.dedup_keep + sort, on a base in which a fifth of the rows have a
+    near-duplicate; off again, the plain k best visited records come back."""
+    rng = np.random.default_rng(61)
+    n, deg, k, L, nq = 3000, 14, 10, 40, 29
+    x = clustered_rows(orc, n, n_centres=32)
+    twins = rng.choice(n // 2, 600, replace=False)
+    x[n // 2 + np.arange(600)] = x[twins] + rng.standard_normal((600, D)).astype(np.float32) * np.float32(0.002)   # dot ~ 0.995 with its twin
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:2000], iters=2)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = np.zeros((n, 4), np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    qs = clustered_rows(orc, nq, n_centres=32, seed=330).astype(np.float32)
+    qs[:5] = x[twins[:5]]                                              # queries whose best matches are twin pairs
+    qh = orc.f16_bits(qs)
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    starts[:5] = twins[:5]
+    luts = np.stack([opq.preprocess_query(q) for q in qs])
+    args = (searcher, gpq, gcodes, dgraph, qh, k, starts, luts, None, disable_pq, 4, L)
+    plain = mse.disk_query_topk(*args)
+    mse.set_dedup(dgraph, mse.DUPLICATES_THRESHOLD)
+    got = mse.disk_query_topk(*args)
+    changed = 0
+    for i in range(nq):
+        _, ovids, ovsc, _, _ = orc.disk_greedy_search(base, adj, degs, codes, desc, int(starts[i]), qh[i], luts[i], None, disable_pq, 4, L, None)
+        keep = orc.dedup_keep(base[ovids], 0.95).astype(bool)
+        kid, ksc = ovids[keep], ovsc[keep]
+        order = sorted(range(len(kid)), key=lambda j: (-int(ksc[j]), int(kid[j])))[:k]
+        want_ids = np.full(k, 0xFFFFFFFF, np.uint32)
+        want_sc = np.full(k, np.iinfo(np.int64).min, np.int64)
+        want_ids[:len(order)] = kid[order]
+        want_sc[:len(order)] = ksc[order]
+        assert np.array_equal(got[0][i], want_ids) and np.array_equal(got[1][i], want_sc), i
+        assert int(got[2]["n_visited"][i]) == len(ovids)
+        changed += not np.array_equal(got[0][i], plain[0][i])
+    assert changed >= 5                                                # the filter really removed something
+    # one query per call through the coalescer: the same
+    one = mse.disk_query_topk(searcher, gpq, gcodes, dgraph, qh[3:4], k, starts[3:4], luts[3:4], None, disable_pq, 4, L)
+    assert np.array_equal(one[0][0], got[0][3]) and np.array_equal(one[1][0], got[1][3])
+    mse.set_dedup(dgraph, 0.0)
+    again = mse.disk_query_topk(*args)
+    assert np.array_equal(again[0], plain[0]) and np.array_equal(again[1], plain[1])
