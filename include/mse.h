@@ -562,6 +562,12 @@ const void* mse_siglip_output_device(const mse_siglip* m, int which);  /* device
 void* mse_siglip_stream(const mse_siglip* m);
 int mse_siglip_debug_residual(mse_siglip* m, float* out);             /* test hook: residual stream after the last block */
 int mse_debug_gemm_ms(int M, int N, int K, int ablation, int iters, float* ms_out); /* developer hook: GEMM timing/ablation */
+/* developer / test hook for the small-batch GEMM kernels of the towers (one image, a few texts): `rows` real rows, bias (epi 0) or
+ * bias + GELU (epi 1) epilogue, run by `variant` (0 = large-batch kernels, 1 = chosen by size, 2 = K-split skinny, 3 = 64 x 64 tiles,
+ * 4 = 128 x 128 tiles).  ms_out = average launch time with weights streaming from HBM; n_diff (optional, TWO words) = output
+ * elements that differ from the large-batch kernels' result, and those more than two bf16 steps apart (the kernels differ in
+ * summation order only: the second word must be 0). */
+int mse_debug_gemm_small(int rows, int N, int K, int epi, int variant, int iters, float* ms_out, uint64_t* n_diff);
 
 /* ---- SigLIP text tower: `model.encode_text(tokens)` + normalisation + fp16 serialisation
  * (clip_server.py:98-99,128-131,166).  open_clip's TextTransformer is a third-party dependency not vendored in

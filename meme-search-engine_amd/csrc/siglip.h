@@ -8,7 +8,7 @@
 namespace mse {
 namespace siglip {
 
-enum { GEMM_EPI_BF16 = 0, GEMM_EPI_GELU = 1, GEMM_EPI_RESID = 2, GEMM_EPI_PATCH = 3, GEMM_EPI_QKV = 4, GEMM_EPI_RESID_LN = 5 };
+enum { GEMM_EPI_BF16 = 0, GEMM_EPI_GELU = 1, GEMM_EPI_RESID = 2, GEMM_EPI_PATCH = 3, GEMM_EPI_QKV = 4, GEMM_EPI_RESID_LN = 5, GEMM_EPI_PART = 6 };
 
 struct GemmLaunch {
     const uint16_t* x = nullptr;   // [M][K] bf16
@@ -22,7 +22,8 @@ struct GemmLaunch {
     int heads = 0, dh = 0, dh_pad = 0, n_pad = 0, dv_pad = 0;
     int kdh_pad = 0;               // k row stride in elements (attention_k_stride()); 0 = dh_pad
     int gelu_tanh = 0;
-    int skinny = 0;                // launch_gemm: few rows (m_valid <= 512) may take the K-split skinny kernel (text tower)
+    int skinny = 0;                // launch_gemm: few rows may take the small-batch kernels: 1 = chosen by size (K-split skinny <= 512 rows,
+                                   // 64 x 64 / 128 x 128 tiles <= 3072 rows); 2 / 3 / 4 force one of them (developer timing)
     hipStream_t side = nullptr;    // launch_gemm: the 128-column remainder launch runs here, beside the full column tiles (ev_fork / ev_join order it)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // LayerNorm-fused launches (launch_gemm_fused)
@@ -33,6 +34,18 @@ struct GemmLaunch {
     size_t part_rows = 0;
     int n_valid = 0;                   // RESID_LN: real output columns (the rest of N is tile padding)
     void* sink = nullptr;              // RESID_LN: >= 2 KiB of scratch
+    // GEMM_EPI_PART (few rows, long K): K split `ksplit` ways across workgroups, split s stores raw fp32 sums to
+    // kpart[s * kpart_stride + m * ldr + n] (no bias); the consuming LayerNorm adds them (LnDelta.parts)
+    float* kpart = nullptr;
+    size_t kpart_stride = 0;
+    int ksplit = 0;
+};
+
+// What a LayerNorm adds to x before normalising (and writes back): the bf16 output of the preceding GEMM, or that GEMM's K-split
+// partial sums (n_parts fp32 slabs, part_stride elements apart, rows of ldp) plus its bias.
+struct LnDelta {
+    const uint16_t* bf16 = nullptr; int ldd = 0;
+    const float* parts = nullptr; int n_parts = 0; size_t part_stride = 0; int ldp = 0; const float* bias = nullptr;
 };
 
 int attention_k_stride();   // row stride (elements) launch_attention expects of the K buffer
@@ -41,6 +54,10 @@ int gemm_bm();
 int gemm_bn();
 int gemm_bk();
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
+// K ranges a GEMM of `rows` rows with a LayerNorm behind it should be split into (1 = none: use the bf16 epilogue), and the rows a
+// slab of its partial sums must hold (kpart_stride >= that * ldr)
+int gemm_small_ksplit(int rows, int N, int K);
+int gemm_small_ksplit_rows(int rows);
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
 // LayerNorm folded into the GEMMs on either side of it (siglip_kernels.hip, "Fused LayerNorm"): epi = GEMM_EPI_QKV / GEMM_EPI_GELU
 // (consumers) or GEMM_EPI_RESID_LN (producer); gemm_fused_ok says whether a geometry can run them
@@ -55,6 +72,8 @@ int launch_ln_finalize(const float* part, size_t part_rows, int groups, size_t r
 int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,
                      int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st);
 // token rows of image b are rows b * tstride + t (t < tokens; the rest of the stride is padding)
+int launch_layernorm_d(void* x, int x_is_f16, int ldx, const LnDelta& delta, const float* gamma, const float* beta, float eps,
+                       int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st);
 int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
                     hipStream_t st);
 int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, int B, int heads, int tokens, int n_pad, int dh,

@@ -51,6 +51,7 @@ struct mse_siglip {
     // threads inside one engine would read each other's images (replicas are separate engines and run side by side)
     std::recursive_mutex call_mu;
     static constexpr int MAX_SIDE = 3;
+    static constexpr int SMALL_BATCH = 4;   // images per call that still take the small-batch GEMM kernels (4 x 736 rows <= 3072)
     hipStream_t side[MAX_SIDE] = {};   // further streams of a forward pass (MSE_SIGLIP_STREAMS = 1 + how many are used; default 2)
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
     int n_side = 0;
@@ -77,8 +78,10 @@ struct mse_siglip {
     int last_batch = 0;
     // fused LayerNorm path (siglip_kernels.hip "Fused LayerNorm"); MSE_SIGLIP_NOFUSE=1 keeps LN1 / LN2 as kernels of their own
     bool fused = false;
+    bool no_small = false;       // MSE_SIGLIP_NOSMALL=1: calls of 1..4 images run the batch kernels too (bit-equal to rows of larger batches)
     float* ln_stats = nullptr;   // [m_pad] (mean, 1/std)
     float* ln_part = nullptr;    // [D / 64][m_pad] (sum, M2)
+    float* kparts = nullptr;     // small-batch path: fp32 partial sums of a K-split fc2 (launch_gemm GEMM_EPI_PART)
     void* sink = nullptr;
 
     template <typename T> T* dalloc(size_t n, bool zero = false) {
@@ -152,6 +155,10 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
         m->add_bf16(p + "mlp.fc2.weight", &b.w2, D, m->mlp, DP, MP); m->add_f32(p + "mlp.fc2.bias", &b.b2, 1, D, DP);
     }
     {
+        const char* e = getenv("MSE_SIGLIP_NOSMALL");
+        m->no_small = e && atoi(e);
+    }
+    {
         const char* e = getenv("MSE_SIGLIP_NOFUSE");
         m->fused = !(e && atoi(e)) && gemm_fused_ok((int)m->m_pad, (int)D, (int)MP, m->H, m->dh, m->n_pad, m->n_pad, 8);
     }
@@ -190,12 +197,13 @@ mse_siglip* mse_siglip_create(const mse_siglip_config* c) {
     m->vtb = m->dalloc<uint16_t>((BH + m->H) * m->dv_pad * m->n_pad, true);
     m->kvb = m->dalloc<uint16_t>(M * 2 * D, true);
     m->qlat = m->dalloc<float>(D, true);
+    m->kparts = m->dalloc<float>((size_t)4 * 768 * D, true);   // K-split partial sums of fc2 for ONE image (4 ranges x 768 rows)
     m->pool_rows = round_up(B, 256);
     m->pool_a = m->dalloc<float>(B * D); m->pool_o = m->dalloc<float>(m->pool_rows * D, true);
     m->pool_a16 = m->dalloc<uint16_t>(m->pool_rows * D, true); m->pool_ln16 = m->dalloc<uint16_t>(m->pool_rows * D, true);
     m->pool_h16 = m->dalloc<uint16_t>(m->pool_rows * MP, true);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
-    bool ok = m->img_dev && m->patches && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat &&
+    bool ok = m->img_dev && m->patches && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->kvb && m->qlat && m->kparts &&
               m->pool_a && m->pool_o && m->pool_a16 && m->pool_ln16 && m->pool_h16 && m->out_f32 && m->out_f16;
     ok = ok && fused_alloc_ok;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
@@ -368,6 +376,13 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
     // The trunk (patch embedding .. MAP-head pooling) of images [b0, b0 + batch) on stream st: every activation buffer is indexed by
     // image or by token row b * n_pad + t, so a sub-batch that starts at a multiple of 8 images (= 23 whole 256-row blocks) is just
     // an offset into each of them.
+    // Up to SMALL_BATCH images (<= 3072 token rows) take the small-batch GEMM kernels (siglip_kernels.hip "Mid-size GEMM") with
+    // LayerNorm as a pass of its own: the 256-row tiles of the batch kernels put 15-200 workgroups on 256 CUs (7.6 ms for ONE image,
+    // 3.3 with these).  Decided by the CALL's batch, so every row of a larger batch still runs the same arithmetic whatever its
+    // sub-batch; an image encoded alone agrees with the same image inside a batch of more than SMALL_BATCH to bf16 rounding (both
+    // within the oracle's tolerance), not bit for bit.  MSE_SIGLIP_NOSMALL=1 (read when the engine is created) keeps the batch kernels
+    // for every size.
+    const int sk = (!m->no_small && batch <= mse_siglip::SMALL_BATCH) ? 1 : 0;
     auto trunk = [&](int b0, int batch, hipStream_t st) -> int {
         const size_t r0 = (size_t)b0 * TS, bh0 = (size_t)b0 * m->H;
         const void* v_img = reinterpret_cast<const char*>(img) + (size_t)b0 * img_stride;
@@ -387,9 +402,10 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         {
             GemmLaunch g; g.x = v_patches; g.w = m->wpe; g.bias = m->bpe; g.M = Mp; g.N = D; g.K = m->kpe_pad; g.m_valid = M;
             g.out_bf16 = v_x; g.ldo = D; g.ldr = D; g.pos = m->pos; g.tokens = TS;   // writes the fp16 residual stream
+            g.skinny = sk;
             if (launch_gemm(GEMM_EPI_PATCH, g, st)) return -1;
         }
-        const bool fused = m->fused && gemm_fused_ok(Mp, D, m->mlp_pad, m->H, m->dh, TS, m->n_pad, M);
+        const bool fused = !sk && m->fused && gemm_fused_ok(Mp, D, m->mlp_pad, m->H, m->dh, TS, m->n_pad, M);
         if (fused && launch_row_stats(v_x, D, D, (size_t)Mp, c.eps, v_ln_stats, st)) return -1;
         for (int i = 0; fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44) with LN1 / LN2 folded into the GEMMs around them
             const Block& b = m->blocks[i];
@@ -419,39 +435,54 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
             }
             if (i + 1 < c.depth && launch_ln_finalize(v_ln_part, m->m_pad, D / 64, (size_t)Mp, c.eps, v_ln_stats, st)) return -1;
         }
+        // one image: fc2 (K = 4352 for 1152 columns) is split four ways along K across workgroups; its partial sums and bias are added
+        // by the LayerNorm that consumes the branch (siglip_kernels.hip gemm_small_ksplit)
+        const int ksp = sk ? gemm_small_ksplit(M, D, m->mlp_pad) : 1;
+        LnDelta fc2_delta;   // what the LayerNorm after an fc2 adds to x (bias filled in per block)
+        if (ksp > 1) { fc2_delta.parts = m->kparts; fc2_delta.n_parts = ksp; fc2_delta.part_stride = (size_t)gemm_small_ksplit_rows(M) * D; fc2_delta.ldp = D; }
+        else { fc2_delta.bf16 = v_dlt; fc2_delta.ldd = DP; }
         for (int i = 0; !fused && i < c.depth; i++) {  // Encoder1DBlock (model.py:26-44)
             const Block& b = m->blocks[i];
             // x += (fc2 output of the previous block), then LayerNorm
-            if (launch_layernorm(v_x, 1, D, i ? v_dlt : nullptr, DP, b.ln1_g, b.ln1_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;
+            LnDelta d1;
+            if (i) { d1 = fc2_delta; d1.bias = m->blocks[i - 1].b2; }
+            if (launch_layernorm_d(v_x, 1, D, d1, b.ln1_g, b.ln1_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;
             {
                 GemmLaunch g; g.x = v_h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Mp; g.N = 3 * D; g.K = D; g.m_valid = M; g.tokens = TS;
                 g.q = v_qb; g.k = v_kb; g.vt = v_vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
-                g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+                g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride(); g.skinny = sk;
                 if (launch_gemm(GEMM_EPI_QKV, g, st)) return -1;
             }
             if (launch_attention(v_qb, v_kb, v_vtb, batch, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, v_h, D, TS, st)) return -1;
             {
-                GemmLaunch g; g.x = v_h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = DP; g.K = D; g.m_valid = M;
+                GemmLaunch g; g.x = v_h; g.w = b.wproj; g.bias = b.bproj; g.M = Mp; g.N = sk ? D : DP; g.K = D; g.m_valid = M;
                 g.out_bf16 = v_dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm (columns >= D are padding)
+                g.skinny = sk;
                 if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
             }
             if (launch_layernorm(v_x, 1, D, v_dlt, DP, b.ln2_g, b.ln2_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;   // x += attention branch
             {
                 GemmLaunch g; g.x = v_h; g.w = b.w1; g.bias = b.b1; g.M = Mp; g.N = m->mlp_pad; g.K = D; g.m_valid = M;
-                g.out_bf16 = v_mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh;
+                g.out_bf16 = v_mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = gelu_tanh; g.skinny = sk;
                 if (launch_gemm(GEMM_EPI_GELU, g, st)) return -1;
             }
             {
-                GemmLaunch g; g.x = v_mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = DP; g.K = m->mlp_pad; g.m_valid = M;
+                GemmLaunch g; g.x = v_mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Mp; g.N = sk ? D : DP; g.K = m->mlp_pad; g.m_valid = M;
                 g.out_bf16 = v_dlt; g.ldo = DP;   // residual branch: added to x by the next LayerNorm
-                if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
+                g.skinny = sk;
+                if (ksp > 1) { g.kpart = m->kparts; g.kpart_stride = fc2_delta.part_stride; g.ksplit = ksp; g.ldr = D; }
+                if (launch_gemm(ksp > 1 ? GEMM_EPI_PART : GEMM_EPI_BF16, g, st)) return -1;
             }
         }
-        if (launch_layernorm(v_x, 1, D, (c.depth && !fused) ? v_dlt : nullptr, DP, m->lnf_g, m->lnf_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;  // model.py:50,55
+        {
+            LnDelta df;
+            if (c.depth && !fused) { df = fc2_delta; df.bias = m->blocks[c.depth - 1].b2; }
+            if (launch_layernorm_d(v_x, 1, D, df, m->lnf_g, m->lnf_b, c.eps, D, M, v_h, D, nullptr, st)) return -1;  // model.py:50,55
+        }
         // MAPHead (model.py:82-111)
         {
             GemmLaunch g; g.x = v_h; g.w = m->wkv; g.bias = m->bkv; g.M = Mp; g.N = 2 * D; g.K = D; g.m_valid = M;
-            g.out_bf16 = v_kvb; g.ldo = 2 * D;
+            g.out_bf16 = v_kvb; g.ldo = 2 * D; g.skinny = sk;
             if (launch_gemm(GEMM_EPI_BF16, g, st)) return -1;
         }
         if (launch_pool_attention(v_kvb, 2 * D, m->qlat, batch, m->H, m->dh, T, TS, v_pool_a, D, st)) return -1;
@@ -481,14 +512,14 @@ int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on
         if (launch_f32_to_bf16_pad(m->pool_a, batch, D, D, m->pool_a16, Bp, D, st)) return -1;
         MSE_HIP_TRY(hipMemsetAsync(m->pool_o, 0, (size_t)Bp * D * 4, st));
         GemmLaunch g; g.x = m->pool_a16; g.w = m->wpp; g.bias = m->bpp; g.M = Bp; g.N = D; g.K = D; g.m_valid = batch;
-        g.resid = m->pool_o; g.ldr = D;
+        g.resid = m->pool_o; g.ldr = D; g.skinny = sk;
         if (launch_gemm(GEMM_EPI_RESID, g, st)) return -1;
         if (launch_layernorm(m->pool_o, 0, D, nullptr, 0, m->lnp_g, m->lnp_b, c.eps, D, batch, m->pool_ln16, D, nullptr, st)) return -1;
         GemmLaunch g1; g1.x = m->pool_ln16; g1.w = m->wp1; g1.bias = m->bp1; g1.M = Bp; g1.N = m->mlp_pad; g1.K = D; g1.m_valid = batch;
-        g1.out_bf16 = m->pool_h16; g1.ldo = m->mlp_pad; g1.gelu_tanh = gelu_tanh;
+        g1.out_bf16 = m->pool_h16; g1.ldo = m->mlp_pad; g1.gelu_tanh = gelu_tanh; g1.skinny = sk;
         if (launch_gemm(GEMM_EPI_GELU, g1, st)) return -1;
         GemmLaunch g2; g2.x = m->pool_h16; g2.w = m->wp2; g2.bias = m->bp2; g2.M = Bp; g2.N = D; g2.K = m->mlp_pad; g2.m_valid = batch;
-        g2.resid = m->pool_o; g2.ldr = D;
+        g2.resid = m->pool_o; g2.ldr = D; g2.skinny = sk;
         if (launch_gemm(GEMM_EPI_RESID, g2, st)) return -1;
     }
     // features /= norm (clip_server.py:115); fp16 rows are what the server serialises (clip_server.py:166)
@@ -542,6 +573,67 @@ int mse_debug_gemm_ms(int M, int N, int K, int abl, int iters, float* ms_out) {
     MSE_HIP_TRY(hipEventSynchronize(e1));
     float ms = 0; MSE_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// developer / test hook for the small-batch GEMM kernels: `rows` real rows of a [rows][K] x [N][K]^T product with the bias (epi 0) or
+// bias + GELU (epi 1) epilogue, run by `variant` (0 = the large-batch kernels, 1 = chosen by size, 2 = K-split skinny, 3 = 64 x 64
+// tiles, 4 = 128 x 128 tiles).  ms_out: average over `iters` launches, each with its OWN weight matrix out of a ring larger than
+// the last-level cache (weights stream from HBM in a forward pass); n_diff (optional, two words): output elements that differ from
+// the large-batch kernels', and those that differ by more than two bf16 steps (must be 0: the kernels differ in summation order only).
+int mse_debug_gemm_small(int rows, int N, int K, int epi, int variant, int iters, float* ms_out, uint64_t* n_diff) {
+    if (rows <= 0 || N % 128 || K % 64 || iters <= 0 || (epi != 0 && epi != 1) || variant < 0 || variant > 4)
+        return fail("debug gemm small: rows > 0, N % 128 == 0, K % 64 == 0, epi 0 / 1, variant 0..4");
+    const int M = (int)round_up((size_t)rows, 256);
+    const size_t wbytes = (size_t)N * K * 2;
+    const int ring = (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)768 << 20) / wbytes));
+    DevBuf x, w, bias, out, ref;
+    if (x.ensure((size_t)M * K * 2) || w.ensure(wbytes * ring) || bias.ensure((size_t)N * 4) || out.ensure((size_t)M * N * 2) ||
+        ref.ensure((size_t)M * N * 2)) return -1;
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, nullptr, x.as<uint16_t>(), (size_t)M * K, 1u);
+    hipLaunchKernelGGL(fill_random_bf16_kernel, dim3(4096), dim3(256), 0, nullptr, w.as<uint16_t>(), (size_t)N * K * ring, 2u);
+    MSE_HIP_TRY(hipGetLastError());
+    {
+        std::vector<float> hb(N);
+        for (int n = 0; n < N; n++) hb[n] = 0.01f * (float)((n * 37) % 101 - 50);
+        MSE_HIP_TRY(hipMemcpy(bias.p, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    }
+    MSE_HIP_TRY(hipMemset(out.p, 0, (size_t)M * N * 2));
+    MSE_HIP_TRY(hipMemset(ref.p, 0, (size_t)M * N * 2));
+    auto run = [&](int var, int slot, uint16_t* dst) -> int {
+        GemmLaunch g; g.x = x.as<uint16_t>(); g.w = w.as<uint16_t>() + (size_t)slot * N * K; g.bias = bias.as<float>();
+        g.M = M; g.N = N; g.K = K; g.m_valid = rows; g.out_bf16 = dst; g.ldo = N; g.skinny = var;
+        return launch_gemm(epi ? GEMM_EPI_GELU : GEMM_EPI_BF16, g, nullptr);
+    };
+    if (n_diff) {
+        if (run(0, 0, ref.as<uint16_t>()) || run(variant, 0, out.as<uint16_t>())) return -1;
+        MSE_HIP_TRY(hipDeviceSynchronize());
+        std::vector<uint16_t> ha((size_t)M * N), hb((size_t)M * N);
+        MSE_HIP_TRY(hipMemcpy(ha.data(), ref.p, ha.size() * 2, hipMemcpyDeviceToHost));
+        MSE_HIP_TRY(hipMemcpy(hb.data(), out.p, hb.size() * 2, hipMemcpyDeviceToHost));
+        uint64_t d = 0, far = 0;
+        auto f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float v; memcpy(&v, &u, 4); return v; };
+        for (size_t r = 0; r < (size_t)rows; r++)
+            for (size_t n = 0; n < (size_t)N; n++) {
+                const uint16_t p = ha[r * N + n], q = hb[r * N + n];
+                if (p == q) continue;
+                d++;
+                const float x = f(p), y = f(q);
+                if (!(fabsf(x - y) <= 0.0157f * std::max(fabsf(x), fabsf(y)) + 1e-3f)) far++;   // more than two bf16 steps apart (or not finite)
+            }
+        n_diff[0] = d;
+        n_diff[1] = far;
+    }
+    hipEvent_t e0, e1;
+    MSE_HIP_TRY(hipEventCreate(&e0)); MSE_HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < std::min(ring, 4); i++) if (run(variant, i, out.as<uint16_t>())) return -1;
+    MSE_HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; i++) if (run(variant, i % ring, out.as<uint16_t>())) return -1;
+    MSE_HIP_TRY(hipEventRecord(e1, nullptr));
+    MSE_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0; MSE_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }

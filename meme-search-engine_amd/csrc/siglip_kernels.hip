@@ -130,7 +130,7 @@ struct GemmArgs {
     int kdh_pad;                           // k row stride in elements (112: the 224-byte rows the attention DMA wants)
     int gelu_tanh;
     int stagger;          // persistent kernel: 64-cycle sleep units per K tile and XCD index at start (0 = none)
-    int skinny;           // launch_gemm: m_valid <= 512 may take gemm_skinny_kernel (the text tower sets it)
+    int skinny;           // launch_gemm: few rows may take the small-batch kernels (1 = by size; 2 / 3 / 4 force skinny / 64 x 64 / 128 x 128)
     // host side only: the 128-column remainder launch of N = 1152 / 3456 may run on `side` BESIDE the full column tiles (it reads the same
     // inputs and writes other columns); ev_fork / ev_join order it after what `st` held before the GEMM and before what follows it
     hipStream_t side;
@@ -143,9 +143,14 @@ struct GemmArgs {
     size_t part_rows;
     int n_valid;              // EPI_RESID_LN: real columns (multiple of 64); the rest of N is tile padding
     char* sink;               // EPI_RESID_LN: >= 2 KiB that the waves of padding columns store to
+    // K split across workgroups (gemm_mid_kernel<EPI_PART>): split s multiplies K range s and stores its raw fp32 sums to
+    // kpart[s * kpart_stride + m * ldr + n]; the LayerNorm that consumes the branch adds the splits in order, then the bias
+    float* kpart;
+    size_t kpart_stride;
+    int ksplit;
 };
 
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4, EPI_RESID_LN = 5 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_QKV = 4, EPI_RESID_LN = 5, EPI_PART = 6 };
 
 // One accumulator quad of the epilogue: row m, columns n..n+3 (n = column inside this launch; a.n_off is
 // added for the output address), acc = raw MFMA sums.
@@ -1259,11 +1264,14 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmArgs a) {
 // The row is held in registers (width <= 2048): one read of x, one optional write.
 // XT = float, or _Float16 for the residual stream of the towers (the reference's engines keep it in fp16 too,
 // aitemplate/run.py; the sum x + delta is formed in fp32 and the statistics use the unrounded value).
+// Round 5: the delta may also arrive as the K-split partial sums of its GEMM (fp32 slabs) plus the bias: added here in a fixed order.
 template <typename XT>
-__global__ __launch_bounds__(256) void layernorm_kernel(XT* __restrict__ x, int ldx, const uint16_t* __restrict__ delta, int ldd,
+__global__ __launch_bounds__(256) void layernorm_kernel(XT* __restrict__ x, int ldx, const LnDelta dl,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         int width, size_t rows, uint16_t* __restrict__ out, int ldo,
                                                         float* __restrict__ out_f32) {
+    const uint16_t* __restrict__ delta = dl.bf16;
+    const int ldd = dl.ldd;
     const int lane = threadIdx.x & 63;
     const size_t row = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (row >= rows) return;
@@ -1286,6 +1294,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* __restrict__ x, int 
                 const uint2 d = *reinterpret_cast<const uint2*>(delta + row * ldd + c);
                 v[j].x += __uint_as_float(d.x << 16); v[j].y += __uint_as_float(d.x & 0xffff0000u);
                 v[j].z += __uint_as_float(d.y << 16); v[j].w += __uint_as_float(d.y & 0xffff0000u);
+                if constexpr (sizeof(XT) == 4) *reinterpret_cast<float4*>(xr + c) = v[j];
+                else *reinterpret_cast<half4v*>(xr + c) = half4v{(_Float16)v[j].x, (_Float16)v[j].y, (_Float16)v[j].z, (_Float16)v[j].w};
+            } else if (dl.parts) {
+                float4 d = *reinterpret_cast<const float4*>(dl.parts + row * dl.ldp + c);
+                for (int p = 1; p < dl.n_parts; p++) {
+                    const float4 e = *reinterpret_cast<const float4*>(dl.parts + (size_t)p * dl.part_stride + row * dl.ldp + c);
+                    d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+                }
+                const float4 bv = *reinterpret_cast<const float4*>(dl.bias + c);
+                v[j].x += d.x + bv.x; v[j].y += d.y + bv.y; v[j].z += d.z + bv.z; v[j].w += d.w + bv.w;
                 if constexpr (sizeof(XT) == 4) *reinterpret_cast<float4*>(xr + c) = v[j];
                 else *reinterpret_cast<half4v*>(xr + c) = half4v{(_Float16)v[j].x, (_Float16)v[j].y, (_Float16)v[j].z, (_Float16)v[j].w};
             }
@@ -2085,6 +2103,11 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, i
 // of more than 8 agree to bf16 rounding, not bit for bit (the image tower's batch invariance is untouched: only the text tower asks
 // for this path).
 // ---------------------------------------------------------------------------------------------------------
+// row thresholds of the small-batch kernels (scripts/gemm_small_probe.py measures every variant at every size,
+// profiles/r05_gemm_small_probe.txt): the K-split kernel for one text, 64 x 64 tiles up to 3072 rows (128 x 128 for the long-K fc2
+// above 2048 rows), the large-batch kernels beyond -- at 4096 rows they are level, at 5888 a quarter faster
+constexpr int SMALL_SKINNY_ROWS = 64, SMALL_MID_ROWS = 3072, SMALL_T128_ROWS = 2048;
+constexpr int SPLIT_MAX_ROWS = 768, SPLIT_T128_ROWS = 384;   // K split: up to one image; 128 x 128 tiles above 384 rows
 constexpr int SK_NW = 12;   // waves per workgroup: K = 1152 is 36 steps of 32 = three per wave, one round trip to memory
 template <int EPI, int R>   // R: K steps whose loads are in flight together (3: one round covers K = 1152; 4 for longer K: fc2's 12 steps per wave in 3 rounds)
 __global__ __launch_bounds__(SK_NW * 64) void gemm_skinny_kernel(GemmArgs a) {
@@ -2150,12 +2173,145 @@ template <int EPI> int launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Mid-size GEMM (round 5): a few hundred to a few thousand rows -- ONE image (736 token rows), 2-48 texts.  The 256-row tiles above
+// then make 3-23 row blocks x 4.5-17 column blocks = 15-200 workgroups, each pulling its whole K range through ONE CU's L1-miss path
+// (~13-18 B/clk, profiles/r01_pmc_siglip_gemm.txt): 30-145 us per GEMM of one image whatever the arithmetic (266 us per layer from
+// 64 to 2048 rows, profiles/r05_gemm_small_probe.txt).  With so few rows the time is set by how many bytes the busiest CU must
+// fetch, so the tiles are small enough to put work on every CU: 64 x 64 (4 waves as 2 x 2, each 32 x 32; 61-157 us per layer from
+// 64 to 2048 rows), 128 x 128 (each wave 64 x 64) for the long-K fc2 of 2048-3072 rows.  Same DMA ring,
+// swizzle, half-step pipeline and store_quad epilogue as the first-generation kernel; the K order of the MFMA accumulation is
+// the same as every other kernel's (sequential steps of 32).  Workgroups are numbered m fastest: the row blocks that share a
+// column block of the WEIGHTS (which stream from HBM once per forward) are neighbours on one XCD, so its L2 reads them once.
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI, int WT>   // WT: 16-row fragments per wave and side (4: 128 x 128 tile, 2: 64 x 64)
+__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs a) {
+    constexpr int TB = 32 * WT;               // tile rows = tile columns
+    constexpr int TILE_BYTES = TB * BK * 2;   // one operand tile of a stage
+    constexpr int STG = 2 * TILE_BYTES;
+    constexpr int NI = TB / 32;               // DMA instructions (8 rows x 128 B) per wave and operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int swz = (i >> 1) & 7;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_blocks = a.N / TB, m_blocks = (a.m_valid + TB - 1) / TB;
+    const int tiles = n_blocks * m_blocks;
+    const int splits = EPI == EPI_PART ? a.ksplit : 1;   // K ranges (EPI_PART only): the slowest index, so a range's tiles run together
+    const int nwg = tiles * splits;
+    int b = blockIdx.x;
+    {   // a contiguous run of tiles per XCD (the dispatcher places block b on XCD b % 8)
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8, idx = b / 8;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int ks = b / tiles, tile = b % tiles;
+    const int nb = tile / m_blocks, mb = tile % m_blocks;
+    const size_t m0 = (size_t)mb * TB, n0 = (size_t)nb * TB;
+    const size_t kbytes = (size_t)a.K * 2;
+    const int nk = a.K / BK / splits;
+    const size_t k0 = (size_t)ks * nk * (BK * 2);   // byte offset of this split's K range inside a row
+    const char* xsrc[NI];
+    const char* wsrc[NI];
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+        const int r = (wave * NI + u) * 8 + (lane >> 3);
+        const int piece = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        xsrc[u] = reinterpret_cast<const char*>(a.x) + (m0 + r) * kbytes + k0 + piece;
+        wsrc[u] = reinterpret_cast<const char*>(a.w) + (n0 + r) * kbytes + k0 + piece;
+    }
+    auto issue = [&](int kstep, int stage) {
+        char* xs = smem + stage * STG;
+        char* ws = xs + TILE_BYTES;
+#pragma unroll
+        for (int u = 0; u < NI; u++) dma16(xsrc[u] + (size_t)kstep * (BK * 2), xs + (wave * NI + u) * 1024);
+#pragma unroll
+        for (int u = 0; u < NI; u++) dma16(wsrc[u] + (size_t)kstep * (BK * 2), ws + (wave * NI + u) * 1024);
+    };
+    float4v acc[WT][WT];  // [n tile][m tile]
+#pragma unroll
+    for (int nt = 0; nt < WT; nt++)
+#pragma unroll
+        for (int mt = 0; mt < WT; mt++) acc[nt][mt] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+    const int slot0 = g ^ swz, slot1 = (4 + g) ^ swz;
+    auto load_frags = [&](bf16x8(&af)[WT], bf16x8(&bfr)[WT], int stage, int slot) {
+        const char* xs = smem + stage * STG;
+        const u32x4* xt = reinterpret_cast<const u32x4*>(xs) + (wm * 16 * WT + i) * 8;
+        const u32x4* wt = reinterpret_cast<const u32x4*>(xs + TILE_BYTES) + (wn * 16 * WT + i) * 8;
+#pragma unroll
+        for (int t = 0; t < WT; t++) {
+            af[t] = as_bf8(wt[t * 128 + slot]);
+            bfr[t] = as_bf8(xt[t * 128 + slot]);
+        }
+    };
+    auto mma = [&](const bf16x8(&af)[WT], const bf16x8(&bfr)[WT]) {
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < WT; mt++)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+    };
+    bf16x8 a0[WT], b0[WT], a1[WT], b1[WT];
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) issue(2, 2);
+    if (nk > 2) vm_wait<4 * NI>(); else if (nk > 1) vm_wait<2 * NI>(); else vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(a0, b0, 0, slot0);
+    for (int kt = 0; kt < nk; kt++) {
+        load_frags(a1, b1, kt % GS, slot1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (kt + 2 < nk) vm_wait<2 * NI>(); else vm_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < nk) issue(kt + 3, kt % GS);
+            load_frags(a0, b0, (kt + 1) % GS, slot0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < WT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++) {
+            const size_t m = m0 + wm * 16 * WT + mt * 16 + i;
+            const int n = (int)n0 + wn * 16 * WT + nt * 16 + 4 * g;
+            if constexpr (EPI == EPI_PART) {   // raw sums of this K range (rows up to the tile edge: the slabs are padded to whole tiles)
+                const float4v v = acc[nt][mt];
+                *reinterpret_cast<float4*>(a.kpart + (size_t)ks * a.kpart_stride + m * a.ldr + n) = float4{v[0], v[1], v[2], v[3]};
+            } else {
+                store_quad<EPI>(a, m, n, acc[nt][mt]);
+            }
+        }
+}
+
+template <int EPI, int WT> int launch_gemm_mid(const GemmArgs& a, hipStream_t st) {
+    constexpr int TB = 32 * WT, lds = GS * 2 * TB * BK * 2;
+    MSE_DYN_LDS((gemm_mid_kernel<EPI, WT>), lds);
+    const unsigned grid = (unsigned)((a.N / TB) * ((a.m_valid + TB - 1) / TB) * (EPI == EPI_PART ? a.ksplit : 1));
+    hipLaunchKernelGGL((gemm_mid_kernel<EPI, WT>), dim3(grid), dim3(256), lds, st, a);
+    MSE_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int EPI> int launch_gemm_t(const GemmArgs& a_in, hipStream_t st) {
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV) {
+    {
         // (a.n_off == 0 here; rows past the last 64-row tile keep what they held -- finite values of an earlier call or the zero fill)
-        if (a_in.skinny && a_in.m_valid > 0 && a_in.m_valid <= 512 && a_in.N % 32 == 0 && a_in.K % 32 == 0 &&
-            (EPI != EPI_QKV || (a_in.dh % 4 == 0 && (a_in.heads * a_in.dh) % 4 == 0)))
-            return launch_gemm_skinny<EPI>(a_in, st);
+        // few rows (the caller allows it with `skinny`: 1 = choose by size, 2 / 3 / 4 = skinny / 64 x 64 / 128 x 128 whatever the size)
+        const bool geo_ok = a_in.m_valid > 0 && a_in.K % 64 == 0 && (EPI != EPI_QKV || (a_in.dh % 4 == 0 && (a_in.heads * a_in.dh) % 4 == 0));
+        if (a_in.skinny && geo_ok) {
+            const int rows = a_in.m_valid;
+            int pick = 0;
+            if (a_in.skinny >= 2) pick = a_in.skinny;
+            else if (rows <= SMALL_SKINNY_ROWS) pick = 2;
+            else if (rows <= SMALL_MID_ROWS) pick = (rows > SMALL_T128_ROWS && a_in.K > 2048) ? 4 : 3;
+            if (pick == 2 && a_in.N % 32 == 0) return launch_gemm_skinny<EPI>(a_in, st);
+            if (pick == 3 && a_in.N % 64 == 0 && a_in.M % 64 == 0) return launch_gemm_mid<EPI, 2>(a_in, st);
+            if (pick == 4 && a_in.N % 128 == 0 && a_in.M % 128 == 0) return launch_gemm_mid<EPI, 4>(a_in, st);
+        }
     }
     MSE_DYN_LDS((gemm_kernel<EPI>), GS * STAGE_BYTES);
 #ifdef MSE_DEV_KERNELS
@@ -2319,6 +2475,16 @@ int gemm_bm() { return BM; }
 int gemm_bn() { return BN; }
 int gemm_bk() { return BK; }
 
+// K split of a long-K GEMM whose output feeds a LayerNorm (fc2: K = 4352 against N = 1152 columns -- at up to 768 rows the
+// unsplit tiles are 18-216 workgroups that each walk 68 K tiles, 29 us whatever the row count): the number of K ranges (1 = do
+// not split), and the rows a slab of partial sums must hold
+static inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
+int gemm_small_ksplit(int rows, int N, int K) {
+    if (rows <= 0 || rows > SPLIT_MAX_ROWS || K < 2048 || (K / BK) % 4 || N % 128 || K % BK) return 1;
+    return 4;
+}
+int gemm_small_ksplit_rows(int rows) { return round_up_i(rows, 128); }
+
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     if (g.M % BM || g.N % BN || g.K % BK) return fail("gemm: sizes must be padded to 256 x 128 x 64");
     GemmArgs a{};
@@ -2327,6 +2493,14 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     a.q = g.q; a.k = g.k; a.vt = g.vt; a.heads = g.heads; a.dh = g.dh; a.dh_pad = g.dh_pad; a.n_pad = g.n_pad;
     a.dv_pad = g.dv_pad; a.gelu_tanh = g.gelu_tanh; a.kdh_pad = g.kdh_pad ? g.kdh_pad : g.dh_pad;
     a.skinny = g.skinny; a.side = g.side; a.ev_fork = g.ev_fork; a.ev_join = g.ev_join;
+    if (epi == EPI_PART) {   // K split across workgroups: raw partial sums for the consuming LayerNorm (gemm_small_ksplit says when)
+        const int tb = g.m_valid > SPLIT_T128_ROWS ? 128 : 64;
+        if (g.ksplit < 2 || (g.K / BK) % g.ksplit || !g.kpart || g.N % tb || g.ldr % 4 ||
+            g.kpart_stride < (size_t)round_up_i(g.m_valid, tb) * g.ldr || g.M < round_up_i(g.m_valid, tb))
+            return fail("gemm: bad K-split arguments");
+        a.kpart = g.kpart; a.kpart_stride = g.kpart_stride; a.ksplit = g.ksplit; a.ldr = g.ldr;
+        return tb == 128 ? launch_gemm_mid<EPI_PART, 4>(a, st) : launch_gemm_mid<EPI_PART, 2>(a, st);
+    }
     switch (epi) {
         case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, st);
         case EPI_GELU: return launch_gemm_t<EPI_GELU>(a, st);
@@ -2452,18 +2626,26 @@ int launch_ln_finalize(const float* part, size_t part_rows, int groups, size_t r
     return 0;
 }
 
-int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,
-                     int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
+int launch_layernorm_d(void* x, int x_is_f16, int ldx, const LnDelta& delta, const float* gamma, const float* beta, float eps,
+                       int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
     if (rows == 0) return 0;
     if (width % 4 || width > 2048) return fail("layernorm: width must be a multiple of 4, at most 2048");
+    if (delta.parts && (delta.bf16 || delta.n_parts < 1 || !delta.bias || delta.ldp % 4)) return fail("layernorm: bad partial-sum delta");
     if (x_is_f16)
         hipLaunchKernelGGL(layernorm_kernel<_Float16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<_Float16*>(x),
-                           ldx, delta, ldd, gamma, beta, eps, width, rows, out, ldo, out_f32);
+                           ldx, delta, gamma, beta, eps, width, rows, out, ldo, out_f32);
     else
         hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<float*>(x), ldx,
-                           delta, ldd, gamma, beta, eps, width, rows, out, ldo, out_f32);
+                           delta, gamma, beta, eps, width, rows, out, ldo, out_f32);
     MSE_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int launch_layernorm(void* x, int x_is_f16, int ldx, const uint16_t* delta, int ldd, const float* gamma, const float* beta, float eps,
+                     int width, size_t rows, uint16_t* out, int ldo, float* out_f32, hipStream_t st) {
+    LnDelta d;
+    d.bf16 = delta; d.ldd = ldd;
+    return launch_layernorm_d(x, x_is_f16, ldx, d, gamma, beta, eps, width, rows, out, ldo, out_f32, st);
 }
 
 int launch_patchify(const void* img, int is_f16, int B, int C, int H, int W, int P, int k_pad, int tstride, uint16_t* out,
@@ -2502,6 +2684,25 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
                            q, k, vt, heads, tokens, n_pad, dh, dh_pad, dv_pad, scale_log2e, out, ldo, tstride);             \
     }
     const int qblocks = (tokens + 255) / 256;
+    // One or two images: 256 queries per workgroup make 48-96 workgroups that each walk all the keys of their head (24 us for one
+    // image, 12 K tiles of 2 us).  Fewer query tiles per wave and fewer waves per workgroup put 192 on the chip; a query row's
+    // arithmetic (its 16-row tile against the keys in order) is the same in every tiling.
+    if (B * heads * qblocks < 128) {
+        const bool four = B * heads * ((tokens + 127) / 128) < 128;   // 4 waves x 16 queries, else 8 waves x 16
+        const int qpw = four ? 64 : 128;
+        const unsigned grid = (unsigned)(B * heads * ((tokens + qpw - 1) / qpw));
+        if (four) {
+            MSE_DYN_LDS((attention64_kernel<0, 1, 4>), AT6_NS * AT6_STAGE);
+            hipLaunchKernelGGL((attention64_kernel<0, 1, 4>), dim3(grid), dim3(256), AT6_NS * AT6_STAGE, st, q, k, vt, heads, tokens, n_pad, dh,
+                               dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        } else {
+            MSE_DYN_LDS((attention64_kernel<0, 1, 8>), AT6_NS * AT6_STAGE);
+            hipLaunchKernelGGL((attention64_kernel<0, 1, 8>), dim3(grid), dim3(512), AT6_NS * AT6_STAGE, st, q, k, vt, heads, tokens, n_pad, dh,
+                               dh_pad, dv_pad, scale_log2e, out, ldo, tstride);
+        }
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #ifndef MSE_DEV_KERNELS
     MSE_ATT64(0)
     MSE_HIP_TRY(hipGetLastError());

@@ -55,6 +55,7 @@ struct mse_siglip_text {
     uint16_t* x = nullptr;   // residual stream [M][D], fp16
     float *pooled = nullptr, *feat = nullptr, *out_f32 = nullptr;
     uint16_t *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *out_f16 = nullptr;
+    float* kparts = nullptr;   // fp32 partial sums of a K-split fc2 (few rows; launch_gemm GEMM_EPI_PART)
     float* stage = nullptr; size_t stage_elems = 0;
 
     template <typename T> T* dalloc(size_t n, bool zero = false) {
@@ -123,6 +124,7 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->x = m->dalloc<uint16_t>(M * D, true);
     m->h = m->dalloc<uint16_t>(M * D, true);
     m->dlt = m->dalloc<uint16_t>(M * D, true);
+    m->kparts = m->dalloc<float>((size_t)4 * 768 * D, true);   // K-split partial sums of fc2 for up to 12 texts (4 ranges x 768 rows)
     m->mlp_h = m->dalloc<uint16_t>(M * MP, true);
     // + 4 sequences of slack: the GEMM epilogues store the rows of the M padding (up to 255) unconditionally
     m->qb = m->dalloc<uint16_t>((BH + 4 * m->H) * m->n_pad * m->dh_pad, true);
@@ -130,7 +132,7 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->vtb = m->dalloc<uint16_t>((BH + 4 * m->H) * m->dv_pad * m->n_pad, true);
     m->pooled = m->dalloc<float>(B * D); m->feat = m->dalloc<float>(B * D);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
-    bool ok = m->tokens_dev && m->x && m->h && m->dlt && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
+    bool ok = m->tokens_dev && m->x && m->h && m->dlt && m->kparts && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_text_destroy(m); fail("siglip text: device allocation failed"); return nullptr; }
     (void)hipDeviceSynchronize();   // the zero fills above ran on the null stream; m->stream does not wait for it
@@ -213,6 +215,11 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     // The blocks over the sequences [b0, b0 + nb) on stream `ss`: rows b0 * T .. of every activation buffer, (sequence, head) matrices
     // b0 * H .. of the attention operands.  b0 * T is a multiple of 256, so the GEMMs' row padding stays inside the range's own rows
     // (or behind the last range).
+    // Up to 12 texts (768 rows): fc2 (K = 4352 for 1152 columns) is split four ways along K across workgroups, its partial sums and
+    // bias added by the LayerNorm that consumes the branch (siglip_kernels.hip gemm_small_ksplit).  Such a call is one range of rows.
+    const int ksp = gemm_small_ksplit(M, D, m->mlp_pad);
+    LnDelta fc2_delta_call;   // what the LayerNorm after an fc2 adds to x (bias filled in per block; the bf16 branch per range of rows)
+    if (ksp > 1) { fc2_delta_call.parts = m->kparts; fc2_delta_call.n_parts = ksp; fc2_delta_call.part_stride = (size_t)gemm_small_ksplit_rows(M) * D; fc2_delta_call.ldp = D; }
     auto blocks = [&](hipStream_t ss, int b0, int nb, int half) -> int {
         const size_t r0 = (size_t)b0 * T;
         // large halves: the remainder launches of the N = 1152 / 3456 GEMMs beside their full column tiles (32-64 workgroups that ran
@@ -221,13 +228,17 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
         auto with_side = [&](GemmLaunch& g) { g.side = sd; g.ev_fork = m->side_ev[half][0]; g.ev_join = m->side_ev[half][1]; };
         const int Ms = nb * T, Msp = (int)round_up(Ms, 256);
         uint16_t *x = m->x + r0 * D, *h = m->h + r0 * D, *dlt = m->dlt + r0 * D, *mlp_h = m->mlp_h + r0 * m->mlp_pad;
+        LnDelta fc2_delta = fc2_delta_call;
+        if (ksp <= 1) { fc2_delta.bf16 = dlt; fc2_delta.ldd = D; }
         uint16_t* qb = m->qb + (size_t)b0 * m->H * m->n_pad * m->dh_pad;
         uint16_t* kb = m->kb + (size_t)b0 * m->H * m->n_pad * attention_k_stride();
         uint16_t* vtb = m->vtb + (size_t)b0 * m->H * m->dv_pad * m->n_pad;
         for (int i = 0; i < c.layers; i++) {
             const TBlock& b = m->blocks[i];
             // x += (fc2 output of the previous block), then LayerNorm
-            if (launch_layernorm(x, 1, D, i ? dlt : nullptr, D, b.ln1_g, b.ln1_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;
+            LnDelta d1;
+            if (i) { d1 = fc2_delta; d1.bias = m->blocks[i - 1].b2; }
+            if (launch_layernorm_d(x, 1, D, d1, b.ln1_g, b.ln1_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;
             {
                 GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.wqkv; g.bias = b.bqkv; g.M = Msp; g.N = 3 * D; g.K = D; g.m_valid = Ms; g.tokens = T;
                 g.q = qb; g.k = kb; g.vt = vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
@@ -252,7 +263,8 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
                 GemmLaunch g; g.skinny = 1; g.x = mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Msp; g.N = D; g.K = m->mlp_pad; g.m_valid = Ms;
                 g.out_bf16 = dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
                 with_side(g);
-                if (launch_gemm(GEMM_EPI_BF16, g, ss)) return -1;
+                if (ksp > 1) { g.kpart = m->kparts; g.kpart_stride = fc2_delta.part_stride; g.ksplit = ksp; g.ldr = D; }
+                if (launch_gemm(ksp > 1 ? GEMM_EPI_PART : GEMM_EPI_BF16, g, ss)) return -1;
             }
         }
         return 0;
@@ -270,8 +282,15 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     if (blocks(st, 0, b_first, 0)) return -1;
     if (b_first < batch) MSE_HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
-    if (launch_layernorm(m->x + (size_t)(T - 1) * D, 1, T * D, c.layers ? m->dlt + (size_t)(T - 1) * D : nullptr, T * D, m->lnf_g, m->lnf_b,
-                         c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
+    {
+        LnDelta df;   // rows b * T + (T - 1): row stride T * D of x, of the bf16 branch and of the partial sums alike
+        if (c.layers && ksp > 1) {
+            df = fc2_delta_call; df.parts += (size_t)(T - 1) * D; df.ldp = T * D; df.bias = m->blocks[c.layers - 1].b2;
+        } else if (c.layers) {
+            df.bf16 = m->dlt + (size_t)(T - 1) * D; df.ldd = T * D;
+        }
+        if (launch_layernorm_d(m->x + (size_t)(T - 1) * D, 1, T * D, df, m->lnf_g, m->lnf_b, c.eps, D, batch, nullptr, D, m->pooled, st)) return -1;
+    }
     if (launch_small_linear(m->pooled, D, m->wproj, D, m->bproj, D, D, batch, 0, nullptr, 0, m->feat, D, st)) return -1;
     if (launch_l2norm(m->feat, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
     if (out_f32) MSE_HIP_TRY(hipMemcpyAsync(out_f32, m->out_f32, (size_t)batch * D * 4, hipMemcpyDeviceToHost, st));

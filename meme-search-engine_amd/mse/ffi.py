@@ -189,6 +189,7 @@ SIGNATURES = {
     "mse_siglip_stream": (vp, [vp]),
     "mse_siglip_debug_residual": (C.c_int, [vp, f32p]),
     "mse_debug_gemm_ms": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+    "mse_debug_gemm_small": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(C.c_uint64)]),
     "mse_siglip_text_create": (vp, [vp]),
     "mse_siglip_text_destroy": (None, [vp]),
     "mse_siglip_text_n_weights": (C.c_int, [vp]),

@@ -84,16 +84,19 @@ def test_engine_rejects_bad_use(mse):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth,gelu,batch", [(2, "tanh", 2), (2, "erf", 3), (27, "erf", 2)])
+@pytest.mark.parametrize("depth,gelu,batch", [(2, "tanh", 2), (2, "erf", 3), (27, "erf", 2), (2, "erf", 5), (27, "tanh", 6)])
 def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
+    """Batches of up to 4 images run the small-batch kernels (LayerNorm as its own pass), larger ones the batch kernels with
+    LayerNorm folded into the GEMMs: both against the oracle."""
     from mse import siglip
+    max_batch = 4 if batch <= 4 else 8
     cfg = dict(ref.CONFIG, depth=depth)
     sd = ref.synthetic_weights(cfg)
     img = ref.synthetic_images(batch, cfg)
     taps = {}
     want = ref.encode_image(img, sd, cfg, gelu=gelu, normalize=True, taps=taps).numpy()
     eng = siglip.SiglipImageEngine.from_state_dict({"visual." + k: v for k, v in sd.items()},
-                                                   dict(siglip.SO400M_384, depth=depth), max_batch=4, gelu=gelu)
+                                                   dict(siglip.SO400M_384, depth=depth), max_batch=max_batch, gelu=gelu)
     got = eng.encode_image(img.numpy())
     resid = eng.debug_residual(batch)
     cos_resid = cosine(resid.reshape(batch, -1), taps[f"block{depth - 1}"].numpy().reshape(batch, -1))
@@ -111,7 +114,7 @@ def test_engine_matches_oracle(gpu, mse, ref, depth, gelu, batch):
     got1 = eng.encode_image(img.numpy()[:1])
     assert np.all(cosine(got1, want[:1]) > 1 - 1e-3)
     with pytest.raises(mse.MseError):
-        eng.encode_image(np.zeros((5, 3, 384, 384), np.float32))           # > max_batch (clip_server.py:139)
+        eng.encode_image(np.zeros((max_batch + 1, 3, 384, 384), np.float32))   # > max_batch (clip_server.py:139)
 
 
 @pytest.mark.gpu
@@ -127,20 +130,20 @@ def test_fused_layernorm_equals_separate_layernorm(gpu, mse, ref, monkeypatch):
         for nm in ("norm1", "norm2"):
             sd[f"trunk.blocks.{i}.{nm}.weight"] = 0.5 + torch.rand(1152, generator=g)
             sd[f"trunk.blocks.{i}.{nm}.bias"] = 0.2 * torch.randn(1152, generator=g)
-    img = ref.synthetic_images(3, cfg)
+    img = ref.synthetic_images(5, cfg)                                      # (more than 4 images: the batch kernels)
     want = ref.encode_image(img, sd, cfg, normalize=True).numpy()
     named = {"visual." + k: v for k, v in sd.items()}
-    fused = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=4)
+    fused = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=8)
     got_f = fused.encode_image(img.numpy())
-    res_f = fused.debug_residual(3)
+    res_f = fused.debug_residual(5)
     monkeypatch.setenv("MSE_SIGLIP_NOFUSE", "1")
-    plain = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=4)
+    plain = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=8)
     monkeypatch.delenv("MSE_SIGLIP_NOFUSE")
     got_p = plain.encode_image(img.numpy())
-    res_p = plain.debug_residual(3)
+    res_p = plain.debug_residual(5)
     assert np.all(cosine(got_f, want) > 1 - 1e-3) and np.all(cosine(got_p, want) > 1 - 1e-3)
     assert np.all(cosine(got_f, got_p) > 1 - 1e-4), cosine(got_f, got_p)
-    assert np.all(cosine(res_f.reshape(3, -1), res_p.reshape(3, -1)) > 1 - 1e-4)
+    assert np.all(cosine(res_f.reshape(5, -1), res_p.reshape(5, -1)) > 1 - 1e-4)
     assert not np.array_equal(got_f, got_p)     # two different code paths really ran
 
 
@@ -163,14 +166,15 @@ def test_sub_batches_on_two_streams_change_nothing(gpu, mse, ref, monkeypatch, b
     assert np.array_equal(got1, got2)
     assert np.isfinite(got2).all() and np.all(np.abs(np.linalg.norm(got2, axis=1) - 1) < 1e-3)
     # and a small batch (one stream either way) after the large one still equals its rows of the large batch
-    assert np.array_equal(two.encode_image(img[:3]), got2[:3])
+    assert np.array_equal(two.encode_image(img[:5]), got2[:5])
 
 
 @pytest.mark.gpu
 def test_batch_256_rows_equal_small_batch_rows(gpu, mse, ref):
     """BASELINE configs[1]'s batch (256 images, two sub-batches of 128 on two streams), depth 2: a row's arithmetic does not depend
-    on what else is in the batch, so rows of the batch-256 forward are BIT-equal to the same images encoded three at a time --
-    at the start, across the sub-batch seam and at the end -- and within the north star's cosine of the fp32 oracle."""
+    on what else is in the batch, so rows of the batch-256 forward are BIT-equal to the same images encoded five at a time --
+    at the start, across the sub-batch seam and at the end -- and within the north star's cosine of the fp32 oracle.  (Calls of up to
+    four images run other kernels -- test_small_batches_agree_with_the_batch_kernels.)"""
     from mse import siglip
     cfg = dict(ref.CONFIG, depth=2)
     sd = ref.synthetic_weights(cfg)
@@ -181,12 +185,62 @@ def test_batch_256_rows_equal_small_batch_rows(gpu, mse, ref):
     big = eng.encode_image(x16)
     assert big.shape == (256, 1152) and np.isfinite(big).all()
     assert np.all(np.abs(np.linalg.norm(big, axis=1) - 1) < 1e-3)
-    for lo in (0, 126, 128, 253):
-        assert np.array_equal(eng.encode_image(x16[lo:lo + 3]), big[lo:lo + 3]), lo
+    for lo in (0, 125, 128, 251):
+        assert np.array_equal(eng.encode_image(x16[lo:lo + 5]), big[lo:lo + 5]), lo
     rows = [0, 127, 128, 255]
     want = ref.encode_image(torch_from(x16[rows]), sd, cfg).numpy()
     assert np.all(cosine(big[rows], want) > 1 - 1e-3)
     assert np.array_equal(eng.encode_image(x16), big)                      # idempotent at full batch
+
+
+@pytest.mark.gpu
+def test_small_batches_agree_with_the_batch_kernels(gpu, mse, ref, monkeypatch):
+    """Calls of 1..4 images (<= 3072 token rows) run the small-batch GEMM kernels and LayerNorm as a pass of its own (one image:
+    7.6 -> 3.3 ms).  Same weights, same images: both within the oracle's tolerance, each
+    other far inside it, every small call idempotent and independent of what ran before; and the GEMM kernels themselves, shape by
+    shape at ragged row counts, within two bf16 steps of the batch kernels' output (summation order is all that differs)."""
+    import ctypes as C
+    from mse import ffi, siglip
+    cfg = dict(ref.CONFIG, depth=3)
+    sd = ref.synthetic_weights(cfg)
+    g = torch.Generator().manual_seed(9)
+    for i in range(3):
+        for nm in ("norm1", "norm2"):
+            sd[f"trunk.blocks.{i}.{nm}.weight"] = 0.5 + torch.rand(1152, generator=g)
+            sd[f"trunk.blocks.{i}.{nm}.bias"] = 0.2 * torch.randn(1152, generator=g)
+    img = ref.synthetic_images(6, cfg)
+    x16 = img.numpy().astype(np.float16)
+    want = ref.encode_image(torch_from(x16), sd, cfg, normalize=True).numpy()
+    named = {"visual." + k: v for k, v in sd.items()}
+    eng = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=8)
+    big = eng.encode_image(x16)                                             # six images: the batch kernels
+    assert np.all(cosine(big, want) > 1 - 1e-3)
+    for b in (1, 2, 3, 4):
+        got = eng.encode_image(x16[:b])
+        assert np.all(cosine(got, want[:b]) > 1 - 1e-3), (b, cosine(got, want[:b]))
+        assert np.all(cosine(got, big[:b]) > 1 - 1e-4), (b, cosine(got, big[:b]))
+        assert not np.array_equal(got, big[:b])                             # other kernels really ran
+        assert np.array_equal(eng.encode_image(x16[:b]), got)
+    one = eng.encode_image(x16[5:6])
+    eng.encode_image(x16)                                                   # a larger batch in between leaves nothing behind
+    assert np.array_equal(eng.encode_image(x16[5:6]), one)
+    # a row of a small call does not depend on its neighbours (two to four images run the same kernels with the same K order; ONE
+    # image also splits fc2's K range across workgroups, which changes the summation order)
+    four = eng.encode_image(x16[2:6])
+    assert np.array_equal(four[2:], eng.encode_image(x16[4:6])) and np.array_equal(four[:3], eng.encode_image(x16[2:5]))
+    assert cosine(four[3:4], one)[0] > 1 - 1e-4
+    # MSE_SIGLIP_NOSMALL=1 (read when an engine is created): small calls run the batch kernels too, bit-equal to a larger batch's rows
+    monkeypatch.setenv("MSE_SIGLIP_NOSMALL", "1")
+    plain = siglip.SiglipImageEngine.from_state_dict(named, dict(siglip.SO400M_384, depth=3), max_batch=8)
+    monkeypatch.delenv("MSE_SIGLIP_NOSMALL")
+    assert np.array_equal(plain.encode_image(x16), big) and np.array_equal(plain.encode_image(x16[:3]), big[:3])
+    L = ffi.lib()
+    for rows in (1, 37, 100, 736, 1000, 2944):
+        for (N, K, epi) in ((3456, 1152, 0), (1152, 1152, 0), (4352, 1152, 1), (1152, 4352, 0)):
+            for variant in (1, 3, 4) + ((2,) if rows <= 512 else ()):
+                ms, nd = C.c_float(), (C.c_uint64 * 2)()
+                ffi.check(L.mse_debug_gemm_small(rows, N, K, epi, variant, 1, C.byref(ms), nd))
+                assert nd[1] == 0, (rows, N, K, epi, variant, nd[0], nd[1])
 
 
 @pytest.mark.gpu
@@ -206,7 +260,15 @@ def test_config1_full_shape_depth_27_batch_256_rows_match_the_oracle(gpu, mse, r
     want = ref.encode_image(torch_from(x16[rows]), sd, cfg).numpy()
     cos = cosine(big[rows], want)
     assert np.all(cos > 1 - 1e-3), cos
-    assert np.array_equal(eng.encode_image(x16[rows]), big[rows])
+    five = rows + [64]                                                      # (five images: still the batch kernels)
+    assert np.array_equal(eng.encode_image(x16[five]), big[five])
+    # the same four images as ONE call each and as a call of four: the small-batch kernels at depth 27, against the oracle and
+    # against the batch kernels' rows
+    alone = np.concatenate([eng.encode_image(x16[r:r + 1]) for r in rows])
+    four = eng.encode_image(x16[rows])
+    for got in (alone, four):
+        assert np.all(cosine(got, want) > 1 - 1e-3), cosine(got, want)
+        assert np.all(cosine(got, big[rows]) > 1 - 2e-4), cosine(got, big[rows])
 
 
 @pytest.mark.gpu
@@ -234,7 +296,7 @@ def test_engine_with_massive_activation_channels(gpu, mse, ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layers,gelu,batch", [(2, "tanh", 3), (27, "erf", 5)])
+@pytest.mark.parametrize("layers,gelu,batch", [(2, "tanh", 3), (27, "erf", 5), (3, "erf", 8), (2, "erf", 2)])
 def test_text_engine_matches_oracle(gpu, mse, ref, layers, gelu, batch):
     from mse import siglip
     cfg = dict(ref.TEXT_CONFIG, layers=layers)
