@@ -1380,6 +1380,10 @@ def main():
                 if gc_:
                     gi[kind]["callers"] = {str(p_["threads"]): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
                                                                 rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in gc_}
+                    tk_ = g(row, "graph_callers", "tickets", "points")
+                    if tk_:
+                        gi[kind]["tickets"] = {str(p_["in_flight"]): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
+                                                                      rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in tk_}
                     pt_ = g(row, "graph_callers", "perf_test_py_shape")
                     if pt_:
                         gi[kind]["callers"]["perf_test_100x1000"] = [rnd(pt_["queries_per_s"], 1), rnd(pt_["latency_ms"]["p50"], 3), rnd(pt_["latency_ms"]["p99"], 3)]
@@ -1387,7 +1391,7 @@ def main():
                 legs["graph_index_1e8"] = ({"qps_recall_L": [rnd(g1e8_line.get("value"), 1), rnd(g1e8_line.get("recall_at_10")), g1e8_line.get("search_list")],
                                             "build_s": rnd(g(g1e8_line, "build", "seconds"), 1)} if "value" in g1e8_line else
                                            {"skipped": g1e8_line.get("skipped") or g1e8_line.get("error")})
-            legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; callers: [queries/s, p50 ms, p99 ms, vs one call of 4096]")
+            legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; callers (T request threads) / tickets (ONE thread, W requests in flight): [queries/s, p50 ms, p99 ms, vs one call of 4096]")
         if sharded_ann:
             legs["sharded_ann"] = {"pq_qps": rnd(g(sharded_ann, "pq_scan_rerank", "queries_per_s"), 1), "pq_equal_unsharded": g(sharded_ann, "pq_scan_rerank", "equals_the_unsharded_call_bit_for_bit"),
                                    "graph_qps": rnd(g(sharded_ann, "graph_index", "queries_per_s"), 1), "graph_equal_merge": g(sharded_ann, "graph_index", "equals_the_merge_of_per_shard_calls")}

@@ -126,6 +126,9 @@ def _callers_lib(root):
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.dirname(so)], stdout=subprocess.DEVNULL)
     H = C.CDLL(so)
+    H.mse_callers_run_async.restype = C.c_double
+    H.mse_callers_run_async.argtypes = [C.c_void_p] * 10 + [C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     H.mse_callers_run_query.restype = C.c_double
     H.mse_callers_run_query.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
@@ -134,7 +137,7 @@ def _callers_lib(root):
 
 
 def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, thread_counts=(64, 512, 4096), one_call_qps=None,
-                  pq=None, codes=None, disable_pq=True, rounds=None, coalescer=(0, 0, 0)):
+                  pq=None, codes=None, disable_pq=True, rounds=None, coalescer=(0, 0, 0), pin_to_quota=True):
     """The metric's path in the reference's call shape (src/query_disk_index.rs:436-540,711-736): T native request threads, closed
     loop, ONE f32 query per mse_disk_query_topk_f32 call through host pointers (entry step, f16 copy, greedy_search, top-k of the
     visited records -- all inside the call); the calls meet in the graph's coalescer.  Every answer is compared with the batch call's
@@ -152,6 +155,22 @@ def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, 
     want_ids, want_sc, _ = mse.disk_query_topk(checker, pq, codes, g, qf, k, None, None, None, disable_pq, beam, search_list)
     checker.close()
     mse.set_coalescer(g, *coalescer)
+    # A container may see every core of the host (256 here) and own 16 cores' worth of their TIME (cgroup cpu.max): 4096 request
+    # threads spread over 256 mostly idle cores pay for every wake-up with an inter-processor interrupt to a sleeping core and for
+    # every queue word with a cache line crossing sockets.  A server is pinned to its allocation; so is this leg: the request threads
+    # (and the coalescer's workers, made by the first request) inherit 2 x quota cores (scripts/graph_callers_probe.py ... affinity:
+    # 4096 threads 0.36 M queries/s on 256 cores, 0.54 / 0.64 / 0.54 M on 16 / 32 / 64).
+    import os
+    all_cores, pinned = sorted(os.sched_getaffinity(0)), None
+    if pin_to_quota:
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = int(round(int(q) / int(per))) if q != "max" else 0
+        except Exception:  # noqa: BLE001
+            quota = 0
+        if quota and len(all_cores) > 4 * quota:
+            pinned = all_cores[:2 * quota]
+            os.sched_setaffinity(0, pinned)
     n_s = 64
     searchers = [mse.Searcher(vecs) for _ in range(n_s)]        # thread t uses searcher t % 64: a coalesced call only reads its base
     sarr = (C.c_void_p * n_s)(*[s._h for s in searchers])
@@ -176,20 +195,53 @@ def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, 
                 "recall_at_10": recall_at(ids, truth[:n]) if truth is not None else None,
                 "vs_one_call_of_4096": (n / dt / one_call_qps) if dt > 0 and one_call_qps else None}
 
-    points = []
+    L = ffi.lib()
+    afn = [C.cast(getattr(L, nm), C.c_void_p) for nm in ("mse_disk_query_submit_f32", "mse_graph_completions", "mse_ticket_status", "mse_ticket_user", "mse_ticket_free")]
+
+    def run_async(W, n):
+        """the same requests WITHOUT a thread per request: ONE native thread keeps W one-query requests in flight as tickets"""
+        ids = np.full((n, k), 0xFFFFFFFF, np.uint32)
+        sc = np.zeros((n, k), np.int64)
+        lat = np.zeros(n, np.float64)
+        failed = C.c_int(0)
+        st0 = mse.coalescer_stats(g)
+        dt = H.mse_callers_run_async(*afn, searchers[0]._h, pq_h, c_h, g._h, qf.ctypes.data, n, D * 4, int(disable_pq), beam, search_list, k, W,
+                                     ids.ctypes.data, sc.ctypes.data, lat.ctypes.data, C.byref(failed))
+        st1 = mse.coalescer_stats(g)
+        ok = bool(dt > 0 and failed.value == 0 and np.array_equal(ids, want_ids[:n]) and np.array_equal(sc, want_sc[:n]))
+        passes = st1["passes"] - st0["passes"]
+        busy = (st1["run_us"] - st0["run_us"]) * 1e-6
+        return {"in_flight": W, "host_threads": 1, "queries": n, "queries_per_s": n / dt if dt > 0 else None, "seconds": dt,
+                "worker_seconds_in_submissions": busy, "ms_per_submission": busy / max(passes, 1) * 1e3,
+                "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
+                "submissions": passes, "queries_per_submission": n / max(passes, 1), "all_answers_equal_the_batch_call": ok,
+                "vs_one_call_of_4096": (n / dt / one_call_qps) if dt > 0 and one_call_qps else None}
+
+    points, tickets = [], []
     for T in thread_counts:
         n = min(n_all, T * rounds if rounds else max(10 * T, 20_000))
         run(T, min(n, 2 * T))                       # warm: two rounds
         points.append(run(T, n))
+    for W in thread_counts:
+        n = min(n_all, W * rounds if rounds else max(10 * W, 20_000))
+        run_async(W, min(n, 2 * W))
+        tickets.append(run_async(W, n))
     run(100, min(n_all, 200))
     perf_test = run(100, min(n_all, 1000))
     st = mse.coalescer_stats(g)
     for s in searchers:
         s.close()
     mse.set_coalescer(g, 0, 0, 0)
+    if pinned:
+        os.sched_setaffinity(0, all_cores)
     return {"metric": "queries/s through the graph index's request path, ONE f32 query per call from T native threads (closed loop), host pointers in and out",
+            "request_threads_pinned_to_cores": len(pinned) if pinned else None,
             "search_list": search_list, "beamwidth": beam, "k": k, "neighbours_scored": "exactly" if disable_pq else "by ADC (the reference's default)",
-            "points": points, "perf_test_py_shape": dict(perf_test, note="1000 one-query requests at concurrency 100, k = 10 (perf_test.py:6-29)"),
+            "points": points,
+            "tickets": {"what": "the same one-query requests WITHOUT a thread per request: ONE native thread keeps `in_flight` of them queued as tickets "
+                                "(mse_disk_query_submit_f32 / mse_graph_completions), the way the reference's monoio tasks would "
+                                "(src/query_disk_index.rs:640-655); latency = submit to collection", "points": tickets},
+            "perf_test_py_shape": dict(perf_test, note="1000 one-query requests at concurrency 100, k = 10 (perf_test.py:6-29)"),
             "coalescer": {"max_queries_per_submission": coalescer[0] or 1024, "max_wait_us": coalescer[1] or 200, "workers": coalescer[2] or 2,
                           "submissions_started_by_wait_budget": st["deadline_fires"]}}
 

@@ -163,6 +163,11 @@ int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, 
 /* the same through a coalescer with `workers` worker threads (the graph's request path runs two, csrc/dispatch.h) */
 int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, int workers,
                                          uint64_t stats_out[6], uint64_t* mismatches);
+/* the asynchronous side of the same queue (submit_async / completions), no device needed: async_threads threads keep `window` records
+ * each in flight while sync_threads blocking callers share the handle; stats_out[5] = records collected; *mismatches = records handed
+ * back twice or never, wrong answers / statuses / error texts */
+int mse_debug_coalescer_selftest_async(int async_threads, int window, int n_requests, int sync_threads, uint32_t max_queries, int workers,
+                                       uint64_t stats_out[6], uint64_t* mismatches);
 
 /* ---- row-sharded index over the GPUs of one node.  The reference has no multi-GPU
  * code; its query server is a thread per core, each with its own Scratch over shared read-only maps
@@ -415,6 +420,28 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  * budget, microseconds the workers spent executing submissions}.
  * DEVICE-RESIDENT QUERIES: the copy of `queries` runs on the searcher's stream.  If another stream produced them (a tower's), call
  * mse_searcher_wait_stream(s, that_stream) first -- or synchronise that stream -- else the search may read them half written. */
+/* WITHOUT A THREAD PER REQUEST (round 5).  The device wants thousands of queries per submission; a sleeping OS thread per request is
+ * the wrong vehicle for that (4096 request threads on a 16-core CPU allowance: 25 us of CPU per request just for being woken).  An
+ * async host -- the reference serves every connection as a monoio task on a runtime per core (src/query_disk_index.rs:640-655,716-732) -- keeps its requests in flight as tickets:
+ *   mse_disk_query_submit_f32  as mse_disk_query_topk_f32 with nq = 1..16 and entry by the graph's table, but returns as soon as the
+ *                          request is queued.  The query (and scales) are copied: the caller's buffers are free at once.  ids / scores
+ *                          (/ n_visited / cmps / pq_cmps) are written when the request is executed and must stay valid until its
+ *                          ticket has come back.  `user` travels with the ticket (a oneshot sender, a request id).
+ *   mse_graph_completions  hands back up to `max` tickets of executed requests of this graph, each exactly once, in completion order;
+ *                          sleeps up to timeout_us for the first (0: poll, < 0: no limit).  Returns how many (0: none in time), -1 on
+ *                          error.  Any number of threads may submit and collect; a ticket comes back to whichever thread asks next.
+ *   mse_ticket_status / _error / _user / _free   0 or the request's error (with its message); the user pointer; release.
+ * Results are those of the synchronous call, bit for bit (the same shared submissions execute both kinds).  Do not free the graph,
+ * change its coalescer settings or its entry table while tickets are out. */
+typedef struct mse_ticket mse_ticket;
+int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
+                              size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
+                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_ticket** ticket_out);
+long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, long timeout_us);
+int mse_ticket_status(const mse_ticket* t);
+const char* mse_ticket_error(const mse_ticket* t);
+void* mse_ticket_user(const mse_ticket* t);
+void mse_ticket_free(mse_ticket* t);
 int mse_graph_set_entries(mse_graph* g, const mse_base* b, const uint32_t* node_ids, size_t n_entries);
 int mse_graph_set_entry_centroids(mse_graph* g, const float* centroids, size_t d, const uint32_t* node_ids, size_t n_entries);
 int mse_disk_query_topk(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,

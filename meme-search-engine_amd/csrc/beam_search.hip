@@ -1304,6 +1304,73 @@ int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, con
     return query_front(q);
 }
 
+// ---- the request path without a thread per request (round 5) ----------------------------------------------------------------
+// A ticket owns everything a queued request needs after the submitting call returned: the request record, the call's arguments and
+// a copy of the query (the caller's buffer is free again at once; the OUTPUT arrays stay the caller's and must outlive the ticket's
+// completion).
+struct mse_ticket {
+    DispatchReq r;
+    QueryCall k;
+    std::vector<float> q32;
+    std::vector<float> scales;
+    void* user = nullptr;
+};
+
+int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
+                              size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
+                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_ticket** ticket_out) {
+    if (!queries_f32 || !ticket_out || !g || !ids || !scores) return fail("disk_query_submit_f32: null argument");
+    if (!s || !s->base) return fail("disk_query_submit_f32: null searcher");
+    if (nq == 0 || nq > FUSED_COALESCE_MAX) return fail("disk_query_submit_f32: 1.." + std::to_string(FUSED_COALESCE_MAX) + " queries per request");
+    if (k == 0 || k > (size_t)TOPK_KMAX - 64) return fail("disk_query_topk: bad k / outputs");
+    if (beamwidth == 0 || beamwidth > BS_BEAM_MAX) return fail("disk_search_batch: beamwidth must be 1..8");
+    if (search_list == 0 || search_list > BS_LMAX) return fail("disk_search_batch: search_list must be 1..1024");
+    if ((!disable_pq && (!pq || !c)) || (scales && !c)) return fail("disk_search_batch: null argument");
+    Coalescer* co = graph_coalescer(g);
+    if (!co) return -1;
+    mse_ticket* t = new (std::nothrow) mse_ticket();
+    if (!t) return fail("out of host memory");
+    const size_t d = s->base->d;
+    try {
+        t->q32.assign(queries_f32, queries_f32 + nq * d);
+        if (scales) t->scales.assign(scales, scales + nq * c->n_desc);
+    } catch (const std::bad_alloc&) {
+        delete t;
+        return fail("out of host memory");
+    }
+    t->user = user;
+    t->k = QueryCall{s, pq, c, g, nullptr, nullptr, t->q32.data(), nullptr, scales ? t->scales.data() : nullptr, nq, disable_pq, beamwidth, search_list, k,
+                     ids, scores, n_visited, cmps, pq_cmps};
+    t->r.nq = nq;
+    t->r.aux0 = &t->k;
+    t->r.aux_n = REQ_QUERY;
+    t->r.owner = t;
+    *ticket_out = t;   // (before the record is queued: it may complete, and be handed to another thread, before submit_async returns)
+    if (co->submit_async(t->r)) {
+        *ticket_out = nullptr;
+        delete t;
+        return -1;
+    }
+    return 0;
+}
+
+long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, long timeout_us) {
+    if (!g || !out) return fail("graph_completions: null argument");
+    if (max == 0) return 0;
+    Coalescer* co = graph_coalescer(g);
+    if (!co) return -1;
+    constexpr size_t CHUNK = 256;
+    DispatchReq* got[CHUNK];
+    const size_t n = co->completions(got, std::min(max, CHUNK), (int64_t)timeout_us);
+    for (size_t i = 0; i < n; i++) out[i] = static_cast<mse_ticket*>(got[i]->owner);
+    return (long)n;
+}
+
+int mse_ticket_status(const mse_ticket* t) { return t ? t->r.rc : -1; }
+const char* mse_ticket_error(const mse_ticket* t) { return t ? t->r.err.c_str() : "null ticket"; }
+void* mse_ticket_user(const mse_ticket* t) { return t ? t->user : nullptr; }
+void mse_ticket_free(mse_ticket* t) { delete t; }
+
 // A shard's form of the request path: the [nq][k] results stay on the device as a packed block ([nq*k] i64 scores, [nq*k] u32 ids +
 // id_offset; mse_topk_block_bytes) ready for the exchange; no coalescing (the shard's thread brings the whole batch).
 int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const uint32_t* starts, const uint16_t* queries,

@@ -53,6 +53,11 @@ struct DispatchReq {
     uint32_t slot = 0;                // completion slot (Coalescer::wake_), assigned on arrival
     DispatchReq* next = nullptr;      // inbox link
     std::chrono::steady_clock::time_point t_arrive;
+    // asynchronous requests (submit_async): nobody sleeps on them; when executed they go onto the handle's completion list, which
+    // is the worker's last access to the record (its owner may free it as soon as it pops it)
+    bool async = false;
+    DispatchReq* cnext = nullptr;
+    void* owner = nullptr;            // the object an asynchronous record is part of (the owner's to interpret)
 };
 
 struct DispatchStats {
@@ -73,6 +78,13 @@ class Coalescer {
     int n_workers() const { return (int)workers_.size(); }
     // blocks until the request was executed; returns its rc and leaves its message in the thread's mse_last_error()
     int submit(DispatchReq& r);
+    // Asynchronous form (round 5): ONE host thread keeps thousands of requests in flight -- the device wants thousands of queries per
+    // pass, and a sleeping OS thread per request is the wrong vehicle for that (4096 request threads on a 16-core CPU allowance spend
+    // 25 us of CPU per request on being woken).  submit_async queues the record (owned by the caller, alive until it comes back) and
+    // returns; completions() hands back up to `max` executed records, each exactly once, sleeping up to timeout_us for the first
+    // (< 0: no limit); a shut-down handle answers what it still held with an error.  Any number of threads may call either.
+    int submit_async(DispatchReq& r);
+    size_t completions(DispatchReq** out, size_t max, int64_t timeout_us);
     DispatchStats stats();
     size_t max_queries() const { return max_queries_; }
     uint32_t max_wait_us() const { return max_wait_us_.load(); }
@@ -82,6 +94,7 @@ class Coalescer {
     void loop(int index);
     void wake_loop(int index);         // a worker's companion: finishes large passes (the wake-ups) while the worker gathers the next
     void complete(std::vector<DispatchReq*>& batch);
+    void enqueue(DispatchReq& r);      // the callers' side of submit / submit_async
     void drain();                      // inbox -> queue_ (the gatherer only)
     size_t target() const;             // queries the next pass waits for
     static constexpr uint32_t WAKE_SLOTS = 64, WAKE_RUN = 256;   // 256 consecutive arrivals share a slot
@@ -107,6 +120,12 @@ class Coalescer {
     // so a pass touches few words): the worker sets each request's `done`, bumps the words it touched and wakes their sleepers; a
     // sleeper that was woken for somebody else's pass finds its own flag still clear and sleeps on the new value.
     WakeSlot wake_[WAKE_SLOTS];
+    // executed asynchronous requests: pushed by whoever completes a pass (lock-free), taken by completions() (its callers share
+    // comp_mu_ and the arrival-ordered comp_ready_); comp_bell_ moves once per pass that completed any
+    alignas(64) std::atomic<DispatchReq*> comp_{nullptr};
+    std::atomic<uint32_t> comp_bell_{0};
+    std::mutex comp_mu_;
+    std::deque<DispatchReq*> comp_ready_;
     // ---- the workers' side.  mu_ is taken by workers (and stats()) only: it hands the gatherer's token around and guards the
     // statistics.  queue_ / queued_queries_ / drained_ belong to whoever holds the token.
     std::mutex mu_;

@@ -55,7 +55,16 @@ Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::f
 // flags first (a request's slot read before its flag is set: the record is gone once the flag is seen), then one wake-up per slot touched
 void Coalescer::complete(std::vector<DispatchReq*>& batch) {
     uint64_t touched = 0;
+    bool any_async = false;
     for (DispatchReq* r : batch) {
+        if (r->async) {   // onto the completion list: from the successful exchange on the record belongs to whoever pops it
+            any_async = true;
+            DispatchReq* head = comp_.load(std::memory_order_relaxed);
+            do {
+                r->cnext = head;
+            } while (!comp_.compare_exchange_weak(head, r, std::memory_order_release, std::memory_order_relaxed));
+            continue;
+        }
         touched |= 1ull << r->slot;
         r->done.store(1, std::memory_order_release);
     }
@@ -64,6 +73,51 @@ void Coalescer::complete(std::vector<DispatchReq*>& batch) {
             wake_[sl].gen.fetch_add(1, std::memory_order_release);
             futex_wake_all(&wake_[sl].gen);
         }
+    if (any_async) {
+        comp_bell_.fetch_add(1, std::memory_order_release);
+        futex_wake_all(&comp_bell_);
+    }
+}
+
+size_t Coalescer::completions(DispatchReq** out, size_t max, int64_t timeout_us) {
+    if (!out || max == 0) return 0;
+    const bool timed = timeout_us >= 0;
+    const int64_t deadline = timed ? std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() +
+                                         timeout_us * 1000
+                                   : 0;
+    for (;;) {
+        const uint32_t bell = comp_bell_.load(std::memory_order_acquire);
+        {
+            std::lock_guard<std::mutex> lk(comp_mu_);
+            DispatchReq* h = comp_.exchange(nullptr, std::memory_order_acquire);
+            DispatchReq* rev = nullptr;   // the stack holds the newest first: back into completion order
+            while (h) {
+                DispatchReq* n = h->cnext;
+                h->cnext = rev;
+                rev = h;
+                h = n;
+            }
+            for (DispatchReq* r = rev; r;) {
+                DispatchReq* n = r->cnext;
+                comp_ready_.push_back(r);
+                r = n;
+            }
+            size_t got = 0;
+            while (got < max && !comp_ready_.empty()) {
+                out[got++] = comp_ready_.front();
+                comp_ready_.pop_front();
+            }
+            if (got) return got;
+        }
+        if (stop_.load(std::memory_order_acquire)) return 0;
+        if (!timed) {
+            futex_wait(&comp_bell_, bell);
+            continue;
+        }
+        const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (now >= deadline) return 0;
+        futex_wait_for(&comp_bell_, bell, deadline - now);
+    }
 }
 
 void Coalescer::wake_loop(int index) {
@@ -105,12 +159,18 @@ Coalescer::~Coalescer() {
     drain();
     uint64_t touched = 0;
     for (DispatchReq* r : queue_) {
-        touched |= 1ull << r->slot;
         r->rc = -1;
         r->err = "dispatcher closed while the request was queued";
+        if (r->async) {   // stays its owner's: marked executed (with the error), never handed out by this handle any more
+            r->done.store(1, std::memory_order_release);
+            continue;
+        }
+        touched |= 1ull << r->slot;
         r->done.store(1, std::memory_order_release);   // (r may be gone from here on)
     }
     queue_.clear();
+    comp_bell_.fetch_add(1, std::memory_order_release);   // anyone asleep in completions() sees stop_ and leaves
+    futex_wake_all(&comp_bell_);
     for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++)
         if (touched >> sl & 1ull) {
             wake_[sl].gen.fetch_add(1, std::memory_order_release);
@@ -118,23 +178,21 @@ Coalescer::~Coalescer() {
         }
 }
 
+int Coalescer::submit_async(DispatchReq& r) {
+    if (stop_.load(std::memory_order_acquire)) return fail("dispatcher is shutting down");
+    r.async = true;
+    r.done.store(0, std::memory_order_relaxed);
+    r.slot = 0;
+    enqueue(r);
+    return 0;
+}
+
 int Coalescer::submit(DispatchReq& r) {
     if (stop_.load(std::memory_order_acquire)) return fail("dispatcher is shutting down");
+    r.async = false;
     r.done.store(0, std::memory_order_relaxed);
     r.slot = (uint32_t)((arrivals_.fetch_add(1, std::memory_order_relaxed) / WAKE_RUN) % WAKE_SLOTS);
-    r.t_arrive = std::chrono::steady_clock::now();
-    DispatchReq* head = inbox_.load(std::memory_order_relaxed);
-    do {
-        r.next = head;
-    } while (!inbox_.compare_exchange_weak(head, &r, std::memory_order_release, std::memory_order_relaxed));
-    // the bell: only the push that carries the count across the gatherer's mark (both sides sequentially consistent: either this
-    // thread sees the mark the gatherer published, or the gatherer sees this push when it re-reads the count before sleeping)
-    const uint64_t before = pushed_.fetch_add(r.nq, std::memory_order_seq_cst), after = before + r.nq;
-    const uint64_t mark = wake_at_.load(std::memory_order_seq_cst);
-    if (before < mark && after >= mark) {
-        bell_.fetch_add(1, std::memory_order_release);
-        futex_wake_all(&bell_);
-    }
+    enqueue(r);
     {
         std::atomic<uint32_t>& gen = wake_[r.slot].gen;
         for (;;) {
@@ -145,6 +203,23 @@ int Coalescer::submit(DispatchReq& r) {
     }
     if (r.rc) set_error(r.err.empty() ? std::string("search failed") : r.err);
     return r.rc;
+}
+
+void Coalescer::enqueue(DispatchReq& r) {
+    r.t_arrive = std::chrono::steady_clock::now();
+    const size_t r_nq = r.nq;   // (an asynchronous record may be executed, handed back and freed as soon as it is in the inbox)
+    DispatchReq* head = inbox_.load(std::memory_order_relaxed);
+    do {
+        r.next = head;
+    } while (!inbox_.compare_exchange_weak(head, &r, std::memory_order_release, std::memory_order_relaxed));
+    // the bell: only the push that carries the count across the gatherer's mark (both sides sequentially consistent: either this
+    // thread sees the mark the gatherer published, or the gatherer sees this push when it re-reads the count before sleeping)
+    const uint64_t before = pushed_.fetch_add(r_nq, std::memory_order_seq_cst), after = before + r_nq;
+    const uint64_t mark = wake_at_.load(std::memory_order_seq_cst);
+    if (before < mark && after >= mark) {
+        bell_.fetch_add(1, std::memory_order_release);
+        futex_wake_all(&bell_);
+    }
 }
 
 // How many queries the next pass waits for: everything expected if one pass holds it; otherwise the expected population in EQUAL
@@ -491,6 +566,82 @@ int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_q
     stats_out[0] = st.queries; stats_out[1] = st.requests; stats_out[2] = st.passes; stats_out[3] = st.max_pass_queries;
     stats_out[4] = st.deadline_fires; stats_out[5] = 0;
     *mismatches = bad.load() + wrong_worker.load();
+    return 0;
+}
+
+// test hook, no device needed: the asynchronous side of the queue.  `async_threads` threads each keep `window` one-query records in
+// flight (n_requests each, collecting whatever completes -- their own records or another thread's) while `sync_threads` blocking
+// callers run beside them through the same Coalescer; the stand-in pass is the one above.  *mismatches = records handed back twice or
+// never, wrong answers / statuses / error texts.
+int mse_debug_coalescer_selftest_async(int async_threads, int window, int n_requests, int sync_threads, uint32_t max_queries, int workers,
+                                       uint64_t stats_out[6], uint64_t* mismatches) {
+    if (async_threads <= 0 || window <= 0 || n_requests <= 0 || sync_threads < 0 || workers <= 0 || !stats_out || !mismatches) return fail("bad argument");
+    struct Rec {
+        DispatchReq r;
+        uint64_t p = 0, out = 0;
+        std::atomic<int> handed{0};
+    };
+    const size_t total = (size_t)async_threads * (size_t)n_requests;
+    std::vector<std::unique_ptr<Rec>> recs(total);
+    for (size_t i = 0; i < total; i++) {
+        recs[i].reset(new Rec());
+        recs[i]->p = 5000000ull + i;
+        recs[i]->r.queries = &recs[i]->p; recs[i]->r.nq = 1; recs[i]->r.k = 1; recs[i]->r.out_a = &recs[i]->out; recs[i]->r.owner = recs[i].get();
+    }
+    std::atomic<uint64_t> bad{0}, collected{0};
+    std::atomic<int64_t> in_flight{0};
+    {
+        Coalescer co(max_queries ? max_queries : 256, 200,
+                     [](std::vector<DispatchReq*>& batch) {
+                         for (DispatchReq* r : batch) {
+                             const uint64_t p = *static_cast<const uint64_t*>(r->queries);
+                             if (p % 97 == 0) { r->rc = -1; r->err = "payload " + std::to_string(p) + " refused"; }
+                             else { *static_cast<uint64_t*>(r->out_a) = 2 * p + 1; r->rc = 0; }
+                         }
+                     },
+                     nullptr, workers);
+        std::vector<std::thread> ts;
+        for (int t = 0; t < async_threads; t++)
+            ts.emplace_back([&, t] {
+                size_t next = 0;
+                DispatchReq* got[64];
+                while (collected.load() < total) {
+                    // the windows are shared: completions go to whichever thread asks, so the count in flight is kept for all of them
+                    while (next < (size_t)n_requests && in_flight.load() < (int64_t)window * async_threads) {
+                        in_flight.fetch_add(1);
+                        if (co.submit_async(recs[(size_t)t * n_requests + next]->r)) bad++;
+                        next++;
+                    }
+                    const size_t n = co.completions(got, 64, 2000);
+                    for (size_t i = 0; i < n; i++) {
+                        Rec* rc = static_cast<Rec*>(got[i]->owner);
+                        if (rc->handed.fetch_add(1) != 0) bad++;
+                        if (rc->p % 97 == 0) { if (rc->r.rc == 0 || rc->r.err.find(std::to_string(rc->p)) == std::string::npos) bad++; }
+                        else if (rc->r.rc != 0 || rc->out != 2 * rc->p + 1) bad++;
+                    }
+                    in_flight.fetch_sub((int64_t)n);
+                    collected.fetch_add(n);
+                }
+            });
+        for (int t = 0; t < sync_threads; t++)
+            ts.emplace_back([&, t] {
+                for (int r = 0; r < 200; r++) {
+                    uint64_t p = 900000000ull + (uint64_t)t * 1000ull + (uint64_t)r, out = 0;
+                    DispatchReq q;
+                    q.queries = &p; q.nq = 1; q.k = 1; q.out_a = &out;
+                    const int rc = co.submit(q);
+                    if (p % 97 == 0) { if (rc == 0) bad++; }
+                    else if (rc != 0 || out != 2 * p + 1) bad++;
+                }
+            });
+        for (std::thread& th : ts) th.join();
+        const DispatchStats st = co.stats();
+        stats_out[0] = st.queries; stats_out[1] = st.requests; stats_out[2] = st.passes; stats_out[3] = st.max_pass_queries;
+        stats_out[4] = st.deadline_fires; stats_out[5] = collected.load();
+    }
+    for (size_t i = 0; i < total; i++)
+        if (recs[i]->handed.load() != 1) bad++;
+    *mismatches = bad.load();
     return 0;
 }
 

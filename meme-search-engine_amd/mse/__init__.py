@@ -8,7 +8,7 @@ from .vector import (SCALE, ID_NONE, MODE_AUTO, MODE_EXACT, MODE_MFMA, scale_dot
                      descriptor_product)
 from .diskann import (NeighbourBuffer, IndexGraph, greedy_search, disk_greedy_search, DiskSearchResult, medioid,  # noqa: F401
                       select_shard, dedup_visited, DUPLICATES_THRESHOLD, DeviceGraph, disk_search_batch, IndexBuildConfig,
-                      BuildGraph, robust_prune, topk_of_visited, set_entries, disk_query_topk, set_entry_centroids,
+                      BuildGraph, robust_prune, topk_of_visited, set_entries, disk_query_topk, QueryTickets, set_entry_centroids,
                       set_coalescer, coalescer_stats, set_dedup)
 from .index import ScalarQuantizerIndex  # noqa: F401
 from .common import decode_fp16_buffer, chunk_fp16_buffer, get_total_embedding  # noqa: F401

@@ -287,6 +287,82 @@ def disk_query_topk(searcher: Searcher, quantizer, codes, dgraph, queries, k, st
     return ids, scores, {"n_visited": nv, "cmps": cm, "pq_cmps": pc}
 
 
+class QueryTickets:
+    """The request path without a thread per request (include/mse.h "WITHOUT A THREAD PER REQUEST"): one host thread keeps many
+    one-query requests of a graph in flight, the way the reference's monoio tasks would (src/query_disk_index.rs:640-655,716-732).
+    submit() queues a request and returns its key; collect() hands back requests executed since, as (key, ids [nq, k], scores
+    [nq, k]) -- the answers of disk_query_topk for the same queries, bit for bit.  A graph has ONE completion list: collect() of any
+    QueryTickets object of that graph returns whatever has completed, whichever object (search settings) submitted it; the output
+    arrays of requests in flight are kept alive on the graph object."""
+
+    def __init__(self, searcher: Searcher, quantizer, codes, dgraph, k, disable_pq=False, beamwidth=1, search_list=1000):
+        import threading
+        self._s, self._pq, self._codes, self._g = searcher, quantizer, codes, dgraph
+        self.k, self.disable_pq, self.beamwidth, self.search_list = int(k), bool(disable_pq), int(beamwidth), int(search_list)
+        if not hasattr(dgraph, "_tickets"):
+            dgraph._tickets = {"lock": threading.Lock(), "next": 1, "out": {}}
+        self._reg = dgraph._tickets
+
+    @property
+    def in_flight(self):
+        """Requests of the whole graph submitted and not yet collected."""
+        return len(self._reg["out"])
+
+    def submit(self, query_f32, descriptor_scales=None, key=None):
+        q = np.ascontiguousarray(np.asarray(query_f32, np.float32).reshape(-1, np.asarray(query_f32).shape[-1]))
+        nq = q.shape[0]
+        sc = None
+        if descriptor_scales is not None:
+            sc = np.asarray(descriptor_scales, np.float32)
+            sc = np.ascontiguousarray(np.broadcast_to(sc, (nq, sc.shape[-1])))
+        ids, scores = np.empty((nq, self.k), np.uint32), np.empty((nq, self.k), np.int64)
+        with self._reg["lock"]:
+            tag = self._reg["next"]
+            self._reg["next"] += 1
+            self._reg["out"][tag] = (key if key is not None else tag, ids, scores)   # before the request can complete
+        t = C.c_void_p()
+        try:
+            check(ffi.lib().mse_disk_query_submit_f32(self._s._h, self._pq._h if self._pq is not None else None,
+                                                      self._codes._h if self._codes is not None else None, self._g._h, _p(q, C.c_float),
+                                                      _p(sc, C.c_float) if sc is not None else None, nq, int(self.disable_pq), self.beamwidth,
+                                                      self.search_list, self.k, _p(ids, C.c_uint32), _p(scores, C.c_int64), None, None, None,
+                                                      C.c_void_p(tag), C.byref(t)), "disk_query_submit_f32")
+        except MseError:
+            with self._reg["lock"]:
+                self._reg["out"].pop(tag, None)
+            raise
+        return key if key is not None else tag
+
+    def collect(self, max_tickets=256, timeout_us=-1):
+        """Executed requests of the graph, in completion order: [(key, ids, scores)].  Sleeps up to timeout_us for the first (0: poll,
+        < 0: until one is there); [] if none came in time.  A request that failed when executed raises MseError with its own
+        message once the successful ones of the same call have been returned (they are handed out first, the failure on the next
+        call)."""
+        pending = self._reg.setdefault("failed", [])
+        if pending:
+            raise pending.pop(0)
+        buf = (C.c_void_p * int(max_tickets))()
+        n = ffi.lib().mse_graph_completions(self._g._h, buf, int(max_tickets), int(timeout_us))
+        if n < 0:
+            check(-1, "graph_completions")
+        done = []
+        for i in range(n):
+            t = buf[i]
+            tag = int(ffi.lib().mse_ticket_user(t) or 0)
+            rc = ffi.lib().mse_ticket_status(t)
+            msg = ffi.lib().mse_ticket_error(t).decode() if rc else ""
+            ffi.lib().mse_ticket_free(t)
+            with self._reg["lock"]:
+                key, ids, scores = self._reg["out"].pop(tag)
+            if rc:
+                pending.append(MseError(f"request {key!r}: {msg or 'search failed'}"))
+            else:
+                done.append((key, ids, scores))
+        if not done and pending:
+            raise pending.pop(0)
+        return done
+
+
 def topk_of_visited(res, k, keep=None):
     """Batch form of the server's last step (query_disk_index.rs:529-540): the reference sorts the WHOLE visited list by exact
     score after the dedup filter (:482-527) and returns all of it; this helper cuts that sorted list to its first k ids per query

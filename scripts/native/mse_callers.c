@@ -170,3 +170,57 @@ double mse_callers_run_query(void* fn, int is_f32, void** searchers, int n_searc
     free(cs);
     return dt;
 }
+
+/* ---- the same requests WITHOUT a thread per request (round 5): ONE thread keeps `window` one-query requests in flight through
+ * mse_disk_query_submit_f32 / mse_graph_completions -- what an async host (the reference's monoio tasks,
+ * src/query_disk_index.rs:640-655) would do.  Request j's latency runs from its submit to the moment its ticket is collected. */
+typedef int (*submit32_fn)(void* s, void* pq, const void* c, const void* g, const void* q, const float* scales, size_t nq, int disable_pq,
+                           size_t beam, size_t list, size_t k, uint32_t* ids, int64_t* scores, uint32_t* nv, uint32_t* cm, uint32_t* pc, void* user,
+                           void** ticket);
+typedef long (*completions_fn)(const void* g, void** out, size_t max, long timeout_us);
+typedef int (*tstatus_fn)(const void* t);
+typedef void* (*tuser_fn)(const void* t);
+typedef void (*tfree_fn)(void* t);
+
+double mse_callers_run_async(void* submit, void* completions, void* status, void* user, void* release, void* searcher, void* pq, const void* codes,
+                             const void* graph, const void* queries, size_t n_queries, size_t query_bytes, int disable_pq, size_t beam, size_t list,
+                             size_t k, size_t window, uint32_t* ids, int64_t* scores, double* latency_ms, int* n_failed) {
+    if (!submit || !completions || !status || !user || !release || window == 0) return -1.0;
+    double* t_sub = (double*)calloc(n_queries ? n_queries : 1, sizeof(double));
+    if (!t_sub) return -1.0;
+    enum { CHUNK = 256 };
+    void* got[CHUNK];
+    size_t next = 0, done = 0, in_flight = 0;
+    int failures = 0;
+    const double t0 = now_s();
+    while (done < n_queries) {
+        while (in_flight < window && next < n_queries) {
+            void* ticket = NULL;
+            t_sub[next] = now_s();
+            if (((submit32_fn)submit)(searcher, pq, codes, graph, (const char*)queries + next * query_bytes, NULL, 1, disable_pq, beam, list, k,
+                                      ids + next * k, scores + next * k, NULL, NULL, NULL, (void*)(uintptr_t)(next + 1), &ticket)) {
+                failures++;
+                done++;        /* never queued: nothing will come back for it */
+            } else {
+                in_flight++;
+            }
+            next++;
+        }
+        if (in_flight == 0) continue;
+        const long n = ((completions_fn)completions)(graph, got, CHUNK, -1);
+        if (n < 0) { failures += (int)in_flight; break; }
+        const double t1 = now_s();
+        for (long i = 0; i < n; i++) {
+            const size_t j = (size_t)(uintptr_t)((tuser_fn)user)(got[i]) - 1;
+            if (((tstatus_fn)status)(got[i])) failures++;
+            if (j < n_queries) latency_ms[j] = (t1 - t_sub[j]) * 1e3;
+            ((tfree_fn)release)(got[i]);
+        }
+        in_flight -= (size_t)n;
+        done += (size_t)n;
+    }
+    const double dt = now_s() - t0;
+    free(t_sub);
+    if (n_failed) *n_failed = failures;
+    return dt;
+}

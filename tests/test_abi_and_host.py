@@ -240,6 +240,27 @@ def test_coalescer_queue_hands_every_caller_its_own_answer(mse, threads, rounds,
         assert passes < requests / 2, (passes, requests)
 
 
+@pytest.mark.parametrize("async_threads,window,n,sync_threads,max_queries,workers", [(1, 1, 300, 0, 256, 1), (1, 512, 6000, 0, 128, 2),
+                                                                                      (3, 64, 2000, 8, 64, 2), (2, 4096, 9000, 16, 1024, 2)])
+def test_coalescer_asynchronous_requests(mse, async_threads, window, n, sync_threads, max_queries, workers):
+    """submit_async / completions of the coalescer without a device: threads that keep a window of records in flight and collect
+    whatever has completed (theirs or another thread's), beside blocking callers on the same handle.  Every record comes back exactly
+    once with ITS answer or ITS error; the blocking callers are unaffected; a window of one is never batched with a wait."""
+    import ctypes as C
+    from mse import ffi
+    stats = (C.c_uint64 * 6)()
+    bad = C.c_uint64(12345)
+    ffi.check(ffi.lib().mse_debug_coalescer_selftest_async(async_threads, window, n, sync_threads, max_queries, workers, stats, C.byref(bad)))
+    assert bad.value == 0
+    assert stats[5] == async_threads * n                       # every asynchronous record collected
+    assert stats[0] == async_threads * n + sync_threads * 200  # and all of them, blocking ones included, executed
+    assert stats[3] <= max_queries
+    if window == 1 and async_threads == 1 and sync_threads == 0:
+        assert stats[2] == n                                   # a lone request in flight: one pass each, no batching delay
+    if window >= 512:
+        assert stats[2] < stats[0] / 8                         # windows share passes
+
+
 @pytest.mark.parametrize("threads,rounds,max_queries,workers", [(64, 40, 256, 2), (600, 10, 128, 2), (24, 100, 8, 3)])
 def test_coalescer_with_several_workers(mse, threads, rounds, max_queries, workers):
     """The same queue with several worker threads (the graph's request path runs two) and its slotted completion (256 consecutive

@@ -461,3 +461,78 @@ def test_entry_table_replaced_under_request_threads(gpu, mse, orc):
     for t in ts:
         t.join()
     assert not bad, bad
+
+
+def test_request_path_without_a_thread_per_request(gpu, mse, orc):
+    """mse_disk_query_submit_f32 / mse_graph_completions (mse.QueryTickets): ONE host thread keeps hundreds of one-query requests in
+    flight, the way the reference's monoio tasks would (src/query_disk_index.rs:640-655,716-732).  Every ticket comes back exactly
+    once with the answer the batch call gives for ITS query (ADC-scored with per-request scales, and exactly scored), the requests
+    share submissions, blocking callers on other threads are served beside them, a refused request fails alone with its own
+    message, and a poll with nothing in flight returns at once."""
+    from test_gpu_pq_index_graph import clustered_rows, knn_graph, train_pq
+    rng = np.random.default_rng(41)
+    n, deg, Q = 4000, 14, 600
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    cents, Tm = train_pq(orc, x[:2000], iters=2)
+    gpq = mse.ProductQuantizer(cents, Tm, 18, D)
+    codes = orc.PQ(cents, Tm, 18, D).quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    adj, degs = knn_graph(x, deg, rng)
+    vl = mse.VectorList.from_f16s(base, D)
+    s = mse.Searcher(vl)
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs), None)
+    mse.set_entries(dgraph, vl, np.sort(rng.choice(n, 64, replace=False)).astype(np.uint32))
+    qs = (clustered_rows(orc, Q, n_centres=32, seed=401) * np.float32(1.2)).astype(np.float32)
+    scales = (rng.standard_normal((Q, 4)) / 512).astype(np.float32)
+    want_adc = mse.disk_query_topk(mse.Searcher(vl), gpq, gcodes, dgraph, qs, 10, None, None, scales, False, 4, 48)
+    want_exact = mse.disk_query_topk(mse.Searcher(vl), None, None, dgraph, qs, 7, None, None, None, True, 2, 32)
+    adc = mse.QueryTickets(s, gpq, gcodes, dgraph, 10, False, 4, 48)
+    exact = mse.QueryTickets(s, None, None, dgraph, 7, True, 2, 32)
+    assert adc.collect(timeout_us=0) == []                       # nothing in flight: a poll returns at once
+    before = mse.coalescer_stats(dgraph)
+    # blocking callers on other threads share the queue with the tickets
+    stop, blocked_bad = threading.Event(), []
+
+    def blocking(i):
+        while not stop.is_set():
+            ids = mse.disk_query_topk(s, None, None, dgraph, qs[i:i + 1], 7, None, None, None, True, 2, 32)[0]
+            if not np.array_equal(ids[0], want_exact[0][i]):
+                blocked_bad.append(i)
+
+    ts = [threading.Thread(target=blocking, args=(i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    got = {}
+    window, nxt = 256, 0
+    while len(got) < 2 * Q:
+        while adc.in_flight < window and nxt < 2 * Q:
+            i, kind = nxt // 2, nxt % 2
+            if kind == 0:
+                adc.submit(qs[i], scales[i], key=("adc", i))
+            else:
+                exact.submit(qs[i], key=("exact", i))
+            nxt += 1
+        # a graph has ONE completion list: either object's collect() returns whatever has completed, of both kinds
+        buf = (adc if nxt % 3 else exact).collect(max_tickets=64, timeout_us=2_000_000)
+        assert buf, "no completion within two seconds"
+        for key, ids, sc in buf:
+            assert key not in got
+            got[key] = (ids, sc)
+    stop.set()
+    for t in ts:
+        t.join()
+    assert not blocked_bad
+    for i in range(Q):
+        assert np.array_equal(got[("adc", i)][0][0], want_adc[0][i]) and np.array_equal(got[("adc", i)][1][0], want_adc[1][i]), i
+        assert np.array_equal(got[("exact", i)][0][0], want_exact[0][i]) and np.array_equal(got[("exact", i)][1][0], want_exact[1][i]), i
+    after = mse.coalescer_stats(dgraph)
+    assert after["requests"] - before["requests"] >= 2 * Q
+    assert after["passes"] - before["passes"] <= (after["requests"] - before["requests"]) // 8      # shared submissions
+    # a refused request (search list beyond the limit) is refused at submit; one that fails when executed fails alone
+    with pytest.raises(mse.MseError):
+        mse.QueryTickets(s, None, None, dgraph, 7, True, 2, 5000).submit(qs[0])
+    with pytest.raises(mse.MseError):
+        mse.QueryTickets(s, None, None, dgraph, 7, True, 2, 32).submit(qs[:17])                     # more than 16 queries per request
+    assert adc.in_flight == 0 and exact.in_flight == 0
