@@ -62,7 +62,7 @@ def main():
             ts.append((time.perf_counter() - t0) * 1e3)
         print("call of", nb, "ms min/median/max", min(ts), sorted(ts)[20], max(ts), flush=True)
     # argv[3]: "affinity" = repeat the default setting with the process pinned to 16 / 32 / 64 cores (the box's CPU-time quota is 16)
-    plan = [((0, 0, 0), None), ((1024, 200, 1), None), ((2048, 200, 2), None), ((0, 0, 0), None)]
+    plan = [((0, 0, 0), None), ((2048, 200, 2), 32), ((4096, 200, 2), 32), ((4096, 200, 3), 32), ((0, 0, 0), 32)]
     if len(sys.argv) > 3 and sys.argv[3] == "affinity":
         plan = [((0, 0, 0), None), ((0, 0, 0), 16), ((0, 0, 0), 32), ((0, 0, 0), 64), ((4096, 1000, 2), 32), ((4096, 1000, 2), None), ((4096, 3000, 2), 32)]
     all_cores = sorted(os.sched_getaffinity(0))
@@ -71,7 +71,7 @@ def main():
         print("cores", cores, flush=True)
         out = ba.graph_callers(ROOT, vecs, g, qf, truth, L, K, 4, (64, 512, 4096), one_call, coalescer=co, pin_to_quota=False)
         print("cgroup", cg(), flush=True)
-        print("tickets", json.dumps([{k: p[k] for k in ("in_flight", "queries_per_s", "latency_ms", "queries_per_submission", "ms_per_submission", "all_answers_equal_the_batch_call", "vs_one_call_of_4096")} for p in out["tickets"]["points"]]), flush=True)
+        print("tickets", json.dumps([{k: p[k] for k in ("in_flight", "host_threads", "queries_per_s", "latency_ms", "queries_per_submission", "ms_per_submission", "all_answers_equal_the_batch_call", "vs_one_call_of_4096")} for p in out["tickets"]["points"]]), flush=True)
         print(json.dumps({"coalescer": co, "points": [{k: p[k] for k in ("threads", "queries_per_s", "latency_ms", "queries_per_submission", "ms_per_submission", "worker_seconds_in_submissions", "seconds", "all_answers_equal_the_batch_call", "vs_one_call_of_4096")} for p in out["points"]],
                           "perf_test": {k: out["perf_test_py_shape"][k] for k in ("queries_per_s", "latency_ms", "queries_per_submission")}}), flush=True)
 

@@ -6,6 +6,7 @@
  * Thread t issues queries t, t + T, t + 2T, ... (n_queries in all, each exactly once), one per call, and records each
  * call's latency; every answer lands in its query's row of scores / ids so the caller can check all of them. */
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <time.h>
@@ -182,45 +183,89 @@ typedef int (*tstatus_fn)(const void* t);
 typedef void* (*tuser_fn)(const void* t);
 typedef void (*tfree_fn)(void* t);
 
-double mse_callers_run_async(void* submit, void* completions, void* status, void* user, void* release, void* searcher, void* pq, const void* codes,
-                             const void* graph, const void* queries, size_t n_queries, size_t query_bytes, int disable_pq, size_t beam, size_t list,
-                             size_t k, size_t window, uint32_t* ids, int64_t* scores, double* latency_ms, int* n_failed) {
-    if (!submit || !completions || !status || !user || !release || window == 0) return -1.0;
-    double* t_sub = (double*)calloc(n_queries ? n_queries : 1, sizeof(double));
-    if (!t_sub) return -1.0;
+typedef struct {
+    void *submit, *completions, *status, *user, *release, *searcher, *pq;
+    const void *codes, *graph, *queries;
+    size_t n_queries, query_bytes, beam, list, k, window;
+    int disable_pq;
+    uint32_t* ids;
+    int64_t* scores;
+    double *latency_ms, *t_sub;
+    _Atomic size_t *next, *done;
+    _Atomic long* in_flight;
+    _Atomic int* failures;
+    pthread_barrier_t* gate;
+} acaller_t;
+
+/* one submitting / collecting thread: the windows are shared (a ticket comes back to whichever thread asks next), so the count in
+ * flight and the next query to submit are common to all of them */
+static void* acaller_main(void* p) {
+    acaller_t* c = (acaller_t*)p;
     enum { CHUNK = 256 };
     void* got[CHUNK];
-    size_t next = 0, done = 0, in_flight = 0;
-    int failures = 0;
-    const double t0 = now_s();
-    while (done < n_queries) {
-        while (in_flight < window && next < n_queries) {
+    if (c->gate) pthread_barrier_wait(c->gate);
+    while (atomic_load(c->done) < c->n_queries) {
+        while (atomic_load(c->in_flight) < (long)c->window) {
+            const size_t j = atomic_fetch_add(c->next, 1);
+            if (j >= c->n_queries) break;
             void* ticket = NULL;
-            t_sub[next] = now_s();
-            if (((submit32_fn)submit)(searcher, pq, codes, graph, (const char*)queries + next * query_bytes, NULL, 1, disable_pq, beam, list, k,
-                                      ids + next * k, scores + next * k, NULL, NULL, NULL, (void*)(uintptr_t)(next + 1), &ticket)) {
-                failures++;
-                done++;        /* never queued: nothing will come back for it */
-            } else {
-                in_flight++;
+            atomic_fetch_add(c->in_flight, 1);
+            c->t_sub[j] = now_s();
+            if (((submit32_fn)c->submit)(c->searcher, c->pq, c->codes, c->graph, (const char*)c->queries + j * c->query_bytes, NULL, 1, c->disable_pq,
+                                         c->beam, c->list, c->k, c->ids + j * c->k, c->scores + j * c->k, NULL, NULL, NULL, (void*)(uintptr_t)(j + 1),
+                                         &ticket)) {
+                atomic_fetch_add(c->failures, 1);   /* never queued: nothing will come back for it */
+                atomic_fetch_sub(c->in_flight, 1);
+                atomic_fetch_add(c->done, 1);
             }
-            next++;
         }
-        if (in_flight == 0) continue;
-        const long n = ((completions_fn)completions)(graph, got, CHUNK, -1);
-        if (n < 0) { failures += (int)in_flight; break; }
+        if (atomic_load(c->done) >= c->n_queries) break;
+        const long n = ((completions_fn)c->completions)(c->graph, got, CHUNK, 2000);
+        if (n < 0) { atomic_fetch_add(c->failures, 1); break; }
         const double t1 = now_s();
         for (long i = 0; i < n; i++) {
-            const size_t j = (size_t)(uintptr_t)((tuser_fn)user)(got[i]) - 1;
-            if (((tstatus_fn)status)(got[i])) failures++;
-            if (j < n_queries) latency_ms[j] = (t1 - t_sub[j]) * 1e3;
-            ((tfree_fn)release)(got[i]);
+            const size_t j = (size_t)(uintptr_t)((tuser_fn)c->user)(got[i]) - 1;
+            if (((tstatus_fn)c->status)(got[i])) atomic_fetch_add(c->failures, 1);
+            if (j < c->n_queries) c->latency_ms[j] = (t1 - c->t_sub[j]) * 1e3;
+            ((tfree_fn)c->release)(got[i]);
         }
-        in_flight -= (size_t)n;
-        done += (size_t)n;
+        atomic_fetch_sub(c->in_flight, n);
+        atomic_fetch_add(c->done, (size_t)n);
     }
-    const double dt = now_s() - t0;
+    return NULL;
+}
+
+double mse_callers_run_async(void* submit, void* completions, void* status, void* user, void* release, void* searcher, void* pq, const void* codes,
+                             const void* graph, const void* queries, size_t n_queries, size_t query_bytes, int disable_pq, size_t beam, size_t list,
+                             size_t k, size_t window, int threads, uint32_t* ids, int64_t* scores, double* latency_ms, int* n_failed) {
+    if (!submit || !completions || !status || !user || !release || window == 0 || threads <= 0 || threads > 64) return -1.0;
+    double* t_sub = (double*)calloc(n_queries ? n_queries : 1, sizeof(double));
+    if (!t_sub) return -1.0;
+    _Atomic size_t next = 0, done = 0;
+    _Atomic long in_flight = 0;
+    _Atomic int failures = 0;
+    pthread_barrier_t gate;
+    if (pthread_barrier_init(&gate, NULL, (unsigned)threads)) { free(t_sub); return -1.0; }
+    acaller_t c = {submit, completions, status, user, release, searcher, pq, codes, graph, queries, n_queries, query_bytes, beam, list, k, window,
+                   disable_pq, ids, scores, latency_ms, t_sub, &next, &done, &in_flight, &failures, threads > 1 ? &gate : NULL};
+    pthread_t th[64];
+    int started = 0;
+    const double t0 = now_s();
+    for (int t = 1; t < threads; t++) {
+        if (pthread_create(&th[t], NULL, acaller_main, &c)) break;
+        started++;
+    }
+    double dt = -1.0;
+    if (started == threads - 1) {
+        acaller_main(&c);                        /* the calling thread is one of them */
+        for (int t = 1; t < threads; t++) pthread_join(th[t], NULL);
+        dt = now_s() - t0;
+    } else {
+        for (int t = 1; t <= started; t++) pthread_cancel(th[t]);
+        for (int t = 1; t <= started; t++) pthread_join(th[t], NULL);
+    }
+    pthread_barrier_destroy(&gate);
     free(t_sub);
-    if (n_failed) *n_failed = failures;
+    if (n_failed) *n_failed = atomic_load(&failures);
     return dt;
 }
