@@ -137,6 +137,8 @@ class Coalescer {
     std::atomic<size_t> expect_{1};
     std::atomic<bool> expected_returners_{false};
     std::atomic<int64_t> grace_until_ns_{0};   // steady_clock time since epoch, ns (0 = none)
+    std::atomic<int> running_{0};              // passes executing now (several workers)
+    bool hold_while_busy_ = true;              // a gatherer does not start a second pass by the wait budget while one is executing
     DispatchStats st_;
     std::vector<std::thread> workers_;
     // Waking several hundred sleepers is a futex call that costs about a microsecond per sleeper -- on the worker's critical path that

@@ -45,6 +45,10 @@ Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::f
     : max_queries_(max_queries ? max_queries : 1), max_wait_us_(max_wait_us), run_(std::move(run)),
       on_start_(std::move(on_thread_start)) {
     if (n_workers < 1) n_workers = 1;
+    {
+        const char* e = getenv("MSE_COALESCE_NO_HOLD");
+        hold_while_busy_ = !(e && atoi(e));
+    }
     for (int w = 0; w < n_workers; w++) {
         wakers_.emplace_back(new Waker());
         wakers_[w]->th = std::thread([this, w] { wake_loop(w); });
@@ -299,6 +303,20 @@ void Coalescer::loop(int index) {
             if (queued_queries_ >= tgt || stop_.load()) break;
             int64_t deadline = steady_ns(queue_.front()->t_arrive) + (int64_t)max_wait_us_.load() * 1000;
             deadline = std::max(deadline, grace_until_ns_.load(std::memory_order_acquire));
+            // While another worker's pass is executing the device is busy anyway: a second pass started by the wait budget would only
+            // be a smaller one (4096 requests in flight ran as passes of 400-700 queries at 1.6 us per query; a pass of 2048 costs 0.8).
+            // The gatherer then waits for its target or for that pass to end (its end rings the bell), whichever comes first.
+            if (hold_while_busy_) {
+                // (the bell word is read BEFORE the count of executing passes: a pass that ends after that read rings a bell this wait
+                // still sees -- its decrement comes before its ring)
+                const uint32_t b = bell_.load(std::memory_order_acquire);
+                if (running_.load(std::memory_order_acquire) > 0) {
+                    const uint64_t mark = drained_ + (tgt - queued_queries_);
+                    wake_at_.store(mark, std::memory_order_seq_cst);
+                    if (pushed_.load(std::memory_order_seq_cst) < mark && !stop_.load()) futex_wait(&bell_, b);
+                    continue;
+                }
+            }
             if (!sleep_until_mark(drained_ + (tgt - queued_queries_), true, deadline)) { by_deadline = true; drain(); break; }
         }
         if (stop_.load()) { lk.lock(); gathering_ = false; break; }
@@ -320,7 +338,9 @@ void Coalescer::loop(int index) {
         lk.unlock();
         if (workers_.size() > 1) cv_worker_.notify_one();
         const auto t_run = std::chrono::steady_clock::now();
+        running_.fetch_add(1, std::memory_order_acq_rel);
         run_(batch);
+        running_.fetch_sub(1, std::memory_order_acq_rel);
         const auto t_end = std::chrono::steady_clock::now();
         const uint64_t run_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_run).count();
         // Next target: what queued up during this pass PLUS the callers answered now -- closed-loop callers (a thread per core,
