@@ -40,10 +40,13 @@ struct mse_siglip_text {
     int D = 0, H = 0, dh = 0, mlp = 0, mlp_pad = 0, ctx = 0, n_pad = 0, dh_pad = 96, dv_pad = 80;
     int max_batch = 0;
     size_t m_pad = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the second half of a large batch
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t side[2] = {nullptr, nullptr};          // per half: where the 128-column remainder launches of its GEMMs run
-    hipEvent_t side_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    static constexpr int MAX_PARTS = 4;
+    hipStream_t stream = nullptr;
+    hipStream_t part_s[MAX_PARTS] = {};                // streams of the parts of a large batch beyond the first (index 0 unused)
+    hipEvent_t ev_fork = nullptr, part_join[MAX_PARTS] = {};
+    int n_parts = 2;                                   // parts a batch of >= 32 texts runs as (MSE_SIGLIP_TEXT_PARTS)
+    hipStream_t side[MAX_PARTS] = {};                  // per part: where the 128-column remainder launches of its GEMMs run
+    hipEvent_t side_ev[MAX_PARTS][2] = {};
     std::mutex call_mu;   // one call at a time: token upload, kernels and scratch of a call share one stream (see mse_siglip)
     std::vector<void*> allocs;
     std::map<std::string, TSlot> slots;
@@ -92,12 +95,19 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->ctx = c->context_length; m->n_pad = m->ctx; m->max_batch = c->max_batch;
     m->m_pad = round_up((size_t)m->max_batch * m->ctx, 256);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; fail("hipStreamCreate failed"); return nullptr; }
-    if (hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        if (m->stream2) { (void)hipStreamDestroy(m->stream2); m->stream2 = nullptr; }   // one stream then: correct, only slower
+    {
+        const char* e = getenv("MSE_SIGLIP_TEXT_PARTS");
+        m->n_parts = std::min(std::max(e ? atoi(e) : 2, 1), (int)mse_siglip_text::MAX_PARTS);
     }
-    for (int hlf = 0; hlf < 2; hlf++)
+    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); m->n_parts = 1; }
+    for (int pt = 1; pt < m->n_parts; pt++)
+        if (hipStreamCreateWithFlags(&m->part_s[pt], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->part_join[pt], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            m->n_parts = pt;   // fewer streams then: correct, only slower
+            break;
+        }
+    for (int hlf = 0; hlf < m->n_parts; hlf++)
         if (hipStreamCreateWithFlags(&m->side[hlf], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->side_ev[hlf][0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&m->side_ev[hlf][1], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
@@ -145,13 +155,13 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
 
 void mse_siglip_text_destroy(mse_siglip_text* m) {
     if (!m) return;
-    for (int hlf = 0; hlf < 2; hlf++) {
+    for (int hlf = 0; hlf < mse_siglip_text::MAX_PARTS; hlf++) {
         if (m->side[hlf]) { (void)hipStreamSynchronize(m->side[hlf]); (void)hipStreamDestroy(m->side[hlf]); }
         for (hipEvent_t e : m->side_ev[hlf]) if (e) (void)hipEventDestroy(e);
+        if (m->part_s[hlf]) { (void)hipStreamSynchronize(m->part_s[hlf]); (void)hipStreamDestroy(m->part_s[hlf]); }
+        if (m->part_join[hlf]) (void)hipEventDestroy(m->part_join[hlf]);
     }
-    if (m->stream2) { (void)hipStreamSynchronize(m->stream2); (void)hipStreamDestroy(m->stream2); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->stage) (void)hipFree(m->stage);
@@ -272,15 +282,20 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     // A large batch runs as TWO halves on two streams (round 5, as the image tower does since round 2): the output-projection and fc2
     // GEMMs have 4.5 column tiles, so their last round of 256 x 256 tiles leaves most of the chip idle -- the other half's next kernel
     // takes those CUs.  The first half is a multiple of four sequences (256 rows).
-    const int b_first = batch >= 32 && m->stream2 ? (batch / 2) / 4 * 4 : batch;
-    if (b_first < batch) {
+    // (MSE_SIGLIP_TEXT_PARTS, read when the engine is created: 1..4 parts; every part but the last is a multiple of four sequences.)
+    const int parts = batch >= 32 ? std::min(m->n_parts, batch / 16) : 1;
+    const int per = parts > 1 ? std::max(4, (batch / parts) / 4 * 4) : batch;
+    if (parts > 1) {
         MSE_HIP_TRY(hipEventRecord(m->ev_fork, st));
-        MSE_HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
-        if (blocks(m->stream2, b_first, batch - b_first, 1)) return -1;
-        MSE_HIP_TRY(hipEventRecord(m->ev_join, m->stream2));
+        for (int pt = 1; pt < parts; pt++) {
+            const int b0 = pt * per, nb = pt + 1 == parts ? batch - b0 : per;
+            MSE_HIP_TRY(hipStreamWaitEvent(m->part_s[pt], m->ev_fork, 0));
+            if (blocks(m->part_s[pt], b0, nb, pt)) return -1;
+            MSE_HIP_TRY(hipEventRecord(m->part_join[pt], m->part_s[pt]));
+        }
     }
-    if (blocks(st, 0, b_first, 0)) return -1;
-    if (b_first < batch) MSE_HIP_TRY(hipStreamWaitEvent(st, m->ev_join, 0));
+    if (blocks(st, 0, parts > 1 ? per : batch, 0)) return -1;
+    for (int pt = 1; pt < parts; pt++) MSE_HIP_TRY(hipStreamWaitEvent(st, m->part_join[pt], 0));
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
     {
         LnDelta df;   // rows b * T + (T - 1): row stride T * D of x, of the bf16 branch and of the partial sums alike
