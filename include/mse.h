@@ -430,6 +430,9 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *   mse_graph_completions  hands back up to `max` tickets of executed requests of this graph, each exactly once, in completion order;
  *                          sleeps up to timeout_us for the first (0: poll, < 0: no limit).  Returns how many (0: none in time), -1 on
  *                          error.  Any number of threads may submit and collect; a ticket comes back to whichever thread asks next.
+ *   mse_graph_completion_fd  an eventfd owned by the graph (valid until its coalescer settings change or it is freed; -1 on error)
+ *                          whose counter is bumped once per submission that completed tickets: register it with epoll / io_uring, read
+ *                          the 8-byte counter when it fires, then call mse_graph_completions(…, 0) until it returns 0.
  *   mse_ticket_status / _error / _user / _free   0 or the request's error (with its message); the user pointer; release.
  * Results are those of the synchronous call, bit for bit (the same shared submissions execute both kinds).  Do not free the graph,
  * change its coalescer settings or its entry table while tickets are out. */
@@ -438,6 +441,7 @@ int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
                               size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
                               uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_ticket** ticket_out);
 long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, long timeout_us);
+int mse_graph_completion_fd(const mse_graph* g);
 int mse_ticket_status(const mse_ticket* t);
 const char* mse_ticket_error(const mse_ticket* t);
 void* mse_ticket_user(const mse_ticket* t);

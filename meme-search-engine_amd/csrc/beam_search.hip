@@ -1366,6 +1366,13 @@ long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, lon
     return (long)n;
 }
 
+int mse_graph_completion_fd(const mse_graph* g) {
+    if (!g) return fail("graph_completion_fd: null argument");
+    Coalescer* co = graph_coalescer(g);
+    if (!co) return -1;
+    return co->completion_fd();
+}
+
 int mse_ticket_status(const mse_ticket* t) { return t ? t->r.rc : -1; }
 const char* mse_ticket_error(const mse_ticket* t) { return t ? t->r.err.c_str() : "null ticket"; }
 void* mse_ticket_user(const mse_ticket* t) { return t ? t->user : nullptr; }

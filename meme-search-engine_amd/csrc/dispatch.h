@@ -85,6 +85,9 @@ class Coalescer {
     // (< 0: no limit); a shut-down handle answers what it still held with an error.  Any number of threads may call either.
     int submit_async(DispatchReq& r);
     size_t completions(DispatchReq** out, size_t max, int64_t timeout_us);
+    // an eventfd (made on first call, owned by the handle) whose counter is bumped once per pass that completed asynchronous requests:
+    // an event loop (epoll / io_uring) watches it, reads the 8-byte counter when it fires, then polls completions() until it returns 0
+    int completion_fd();
     DispatchStats stats();
     size_t max_queries() const { return max_queries_; }
     uint32_t max_wait_us() const { return max_wait_us_.load(); }
@@ -124,6 +127,7 @@ class Coalescer {
     // comp_mu_ and the arrival-ordered comp_ready_); comp_bell_ moves once per pass that completed any
     alignas(64) std::atomic<DispatchReq*> comp_{nullptr};
     std::atomic<uint32_t> comp_bell_{0};
+    std::atomic<int> comp_fd_{-1};
     std::mutex comp_mu_;
     std::deque<DispatchReq*> comp_ready_;
     // ---- the workers' side.  mu_ is taken by workers (and stats()) only: it hands the gatherer's token around and guards the

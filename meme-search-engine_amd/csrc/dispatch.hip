@@ -9,7 +9,9 @@
 #include <memory>
 #include <new>
 #include <climits>
+#include <cerrno>
 #include <linux/futex.h>
+#include <sys/eventfd.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <time.h>
@@ -80,7 +82,35 @@ void Coalescer::complete(std::vector<DispatchReq*>& batch) {
     if (any_async) {
         comp_bell_.fetch_add(1, std::memory_order_release);
         futex_wake_all(&comp_bell_);
+        const int fd = comp_fd_.load(std::memory_order_acquire);
+        if (fd >= 0) {
+            const uint64_t one = 1;
+            (void)!write(fd, &one, sizeof one);   // (EAGAIN only at a counter of 2^64 - 2: the loop is awake anyway)
+        }
     }
+}
+
+int Coalescer::completion_fd() {
+    int fd = comp_fd_.load(std::memory_order_acquire);
+    if (fd >= 0) return fd;
+    const int made = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
+    if (made < 0) return fail(std::string("eventfd: ") + strerror(errno));
+    int expected = -1;
+    if (!comp_fd_.compare_exchange_strong(expected, made, std::memory_order_acq_rel)) {   // another thread was first
+        (void)close(made);
+        return expected;
+    }
+    // requests that completed before the descriptor existed are announced now
+    bool pending = comp_.load(std::memory_order_acquire) != nullptr;
+    if (!pending) {
+        std::lock_guard<std::mutex> lk(comp_mu_);
+        pending = !comp_ready_.empty();
+    }
+    if (pending) {
+        const uint64_t one = 1;
+        (void)!write(made, &one, sizeof one);
+    }
+    return made;
 }
 
 size_t Coalescer::completions(DispatchReq** out, size_t max, int64_t timeout_us) {
@@ -175,6 +205,10 @@ Coalescer::~Coalescer() {
     queue_.clear();
     comp_bell_.fetch_add(1, std::memory_order_release);   // anyone asleep in completions() sees stop_ and leaves
     futex_wake_all(&comp_bell_);
+    {
+        const int fd = comp_fd_.exchange(-1);
+        if (fd >= 0) (void)close(fd);
+    }
     for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++)
         if (touched >> sl & 1ull) {
             wake_[sl].gen.fetch_add(1, std::memory_order_release);

@@ -333,6 +333,14 @@ class QueryTickets:
             raise
         return key if key is not None else tag
 
+    def fileno(self):
+        """An eventfd that becomes readable when requests of the graph have completed (for select / epoll / asyncio's add_reader):
+        read its 8-byte counter, then collect(timeout_us=0) until it returns []."""
+        fd = ffi.lib().mse_graph_completion_fd(self._g._h)
+        if fd < 0:
+            check(-1, "graph_completion_fd")
+        return fd
+
     def collect(self, max_tickets=256, timeout_us=-1):
         """Executed requests of the graph, in completion order: [(key, ids, scores)].  Sleeps up to timeout_us for the first (0: poll,
         < 0: until one is there); [] if none came in time.  A request that failed when executed raises MseError with its own

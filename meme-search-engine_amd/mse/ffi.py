@@ -154,6 +154,7 @@ SIGNATURES = {
     "mse_disk_query_topk_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
     "mse_disk_query_submit_f32": (C.c_int, [vp, vp, vp, vp, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p, vp, C.POINTER(vp)]),
     "mse_graph_completions": (C.c_long, [vp, C.POINTER(vp), sz, C.c_long]),
+    "mse_graph_completion_fd": (C.c_int, [vp]),
     "mse_ticket_status": (C.c_int, [vp]),
     "mse_ticket_error": (C.c_char_p, [vp]),
     "mse_ticket_user": (vp, [vp]),

@@ -491,6 +491,17 @@ def test_request_path_without_a_thread_per_request(gpu, mse, orc):
     adc = mse.QueryTickets(s, gpq, gcodes, dgraph, 10, False, 4, 48)
     exact = mse.QueryTickets(s, None, None, dgraph, 7, True, 2, 32)
     assert adc.collect(timeout_us=0) == []                       # nothing in flight: a poll returns at once
+    # the completion descriptor: quiet now, readable once a request has completed, quiet again after its counter is read
+    import os
+    import select
+    fd = adc.fileno()
+    assert fd >= 0 and exact.fileno() == fd and select.select([fd], [], [], 0)[0] == []
+    exact.submit(qs[0], key="probe")
+    assert select.select([fd], [], [], 5.0)[0] == [fd]
+    assert int.from_bytes(os.read(fd, 8), "little") >= 1
+    got_probe = exact.collect(timeout_us=0)
+    assert [k_ for k_, _, _ in got_probe] == ["probe"] and np.array_equal(got_probe[0][1][0], want_exact[0][0])
+    assert select.select([fd], [], [], 0)[0] == [] and exact.collect(timeout_us=0) == []
     before = mse.coalescer_stats(dgraph)
     # blocking callers on other threads share the queue with the tickets
     stop, blocked_bad = threading.Event(), []
