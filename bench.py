@@ -894,10 +894,10 @@ def main():
                     help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
     ap.add_argument("--graph-kinds", default="easy,hard,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")
     ap.add_argument("--no-graph-1e8", action="store_true", help="skip the 1e8-row graph-index leg (a ~10 minute one-pass build, guarded by a time budget)")
-    ap.add_argument("--graph-1e8-budget", type=float, default=1000.0,
+    ap.add_argument("--graph-1e8-budget", type=float, default=1100.0,
                     help="seconds the predicted 1e8-row build may take (two passes if both fit, else one; beyond it the leg is skipped with that reason); "
                          "never more than what is left of --time-budget")
-    ap.add_argument("--time-budget", type=float, default=1450.0, help="seconds the whole command aims to stay within: the 1e8-row graph leg shrinks or skips itself to fit")
+    ap.add_argument("--time-budget", type=float, default=1500.0, help="seconds the whole command aims to stay within: the 1e8-row graph leg shrinks or skips itself to fit")
     ap.add_argument("--no-sharded-ann", action="store_true", help="--gpus N > 1: skip the sharded PQ-scan / graph-index legs")
     ap.add_argument("--ann-rows-per-gpu", type=float, default=2e6, help="--gpus N > 1: rows per GPU of the sharded approximate-search legs")
     ap.add_argument("--siglip-batch", type=int, default=256)
