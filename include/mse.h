@@ -164,10 +164,11 @@ int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, 
 int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, int workers,
                                          uint64_t stats_out[6], uint64_t* mismatches);
 /* the asynchronous side of the same queue (submit_async / completions), no device needed: async_threads threads keep `window` records
- * each in flight while sync_threads blocking callers share the handle; stats_out[5] = records collected; *mismatches = records handed
- * back twice or never, wrong answers / statuses / error texts */
+ * each in flight while sync_threads blocking callers share the handle; own_queues != 0: every asynchronous thread has a completion queue
+ * of its own and must get back exactly its own records; stats_out[5] = records collected; *mismatches = records handed back twice or
+ * never (or to the wrong queue), wrong answers / statuses / error texts */
 int mse_debug_coalescer_selftest_async(int async_threads, int window, int n_requests, int sync_threads, uint32_t max_queries, int workers,
-                                       uint64_t stats_out[6], uint64_t* mismatches);
+                                       int own_queues, uint64_t stats_out[6], uint64_t* mismatches);
 
 /* ---- row-sharded index over the GPUs of one node.  The reference has no multi-GPU
  * code; its query server is a thread per core, each with its own Scratch over shared read-only maps
@@ -430,6 +431,11 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *   mse_graph_completions  hands back up to `max` tickets of executed requests of this graph, each exactly once, in completion order;
  *                          sleeps up to timeout_us for the first (0: poll, < 0: no limit).  Returns how many (0: none in time), -1 on
  *                          error.  Any number of threads may submit and collect; a ticket comes back to whichever thread asks next.
+ *   mse_completion_queue_* a completion queue of the caller's own.  A host with several event loops -- the reference runs a runtime per
+ *                          core -- makes one per loop and passes it as `cq` at submit: those tickets come back through
+ *                          mse_completion_queue_wait(q, …) (and its eventfd, mse_completion_queue_fd) and nowhere else, i.e. to the
+ *                          loop that submitted them; the shared submissions are the same.  cq = NULL: the graph's own queue
+ *                          (mse_graph_completions / mse_graph_completion_fd).  Free a queue only when none of its tickets is out.
  *   mse_graph_completion_fd  an eventfd owned by the graph (valid until its coalescer settings change or it is freed; -1 on error)
  *                          whose counter is bumped once per submission that completed tickets: register it with epoll / io_uring, read
  *                          the 8-byte counter when it fires, then call mse_graph_completions(…, 0) until it returns 0.
@@ -437,9 +443,15 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  * Results are those of the synchronous call, bit for bit (the same shared submissions execute both kinds).  Do not free the graph,
  * change its coalescer settings or its entry table while tickets are out. */
 typedef struct mse_ticket mse_ticket;
+typedef struct mse_completion_queue mse_completion_queue;
 int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
                               size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
-                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_ticket** ticket_out);
+                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
+                              mse_ticket** ticket_out);
+mse_completion_queue* mse_completion_queue_new(void);
+void mse_completion_queue_free(mse_completion_queue* q);
+int mse_completion_queue_fd(mse_completion_queue* q);
+long mse_completion_queue_wait(mse_completion_queue* q, mse_ticket** out, size_t max, long timeout_us);
 long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, long timeout_us);
 int mse_graph_completion_fd(const mse_graph* g);
 int mse_ticket_status(const mse_ticket* t);

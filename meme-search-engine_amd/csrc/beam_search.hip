@@ -1308,6 +1308,10 @@ int mse_disk_query_topk_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, con
 // A ticket owns everything a queued request needs after the submitting call returned: the request record, the call's arguments and
 // a copy of the query (the caller's buffer is free again at once; the OUTPUT arrays stay the caller's and must outlive the ticket's
 // completion).
+struct mse_completion_queue {
+    CompletionQueue q;
+};
+
 struct mse_ticket {
     DispatchReq r;
     QueryCall k;
@@ -1318,7 +1322,8 @@ struct mse_ticket {
 
 int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
                               size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
-                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_ticket** ticket_out) {
+                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
+                              mse_ticket** ticket_out) {
     if (!queries_f32 || !ticket_out || !g || !ids || !scores) return fail("disk_query_submit_f32: null argument");
     if (!s || !s->base) return fail("disk_query_submit_f32: null searcher");
     if (nq == 0 || nq > FUSED_COALESCE_MAX) return fail("disk_query_submit_f32: 1.." + std::to_string(FUSED_COALESCE_MAX) + " queries per request");
@@ -1345,6 +1350,7 @@ int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
     t->r.aux0 = &t->k;
     t->r.aux_n = REQ_QUERY;
     t->r.owner = t;
+    t->r.cq = cq ? &cq->q : nullptr;
     *ticket_out = t;   // (before the record is queued: it may complete, and be handed to another thread, before submit_async returns)
     if (co->submit_async(t->r)) {
         *ticket_out = nullptr;
@@ -1362,6 +1368,24 @@ long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, lon
     constexpr size_t CHUNK = 256;
     DispatchReq* got[CHUNK];
     const size_t n = co->completions(got, std::min(max, CHUNK), (int64_t)timeout_us);
+    for (size_t i = 0; i < n; i++) out[i] = static_cast<mse_ticket*>(got[i]->owner);
+    return (long)n;
+}
+
+// a completion queue of the caller's own (one per event loop): tickets submitted with it come back through it and nowhere else
+mse_completion_queue* mse_completion_queue_new(void) {
+    mse_completion_queue* q = new (std::nothrow) mse_completion_queue();
+    if (!q) fail("out of host memory");
+    return q;
+}
+void mse_completion_queue_free(mse_completion_queue* q) { delete q; }
+int mse_completion_queue_fd(mse_completion_queue* q) { return q ? q->q.fd() : fail("completion_queue_fd: null argument"); }
+long mse_completion_queue_wait(mse_completion_queue* q, mse_ticket** out, size_t max, long timeout_us) {
+    if (!q || !out) return fail("completion_queue_wait: null argument");
+    if (max == 0) return 0;
+    constexpr size_t CHUNK = 256;
+    DispatchReq* got[CHUNK];
+    const size_t n = q->q.take(got, std::min(max, CHUNK), (int64_t)timeout_us, nullptr);
     for (size_t i = 0; i < n; i++) out[i] = static_cast<mse_ticket*>(got[i]->owner);
     return (long)n;
 }

@@ -58,11 +58,34 @@ struct DispatchReq {
     bool async = false;
     DispatchReq* cnext = nullptr;
     void* owner = nullptr;            // the object an asynchronous record is part of (the owner's to interpret)
+    class CompletionQueue* cq = nullptr;   // where it is handed back (null: the handle's own queue)
 };
 
 struct DispatchStats {
     uint64_t queries = 0, requests = 0, passes = 0, max_pass_queries = 0, deadline_fires = 0, retried_alone = 0;
     uint64_t run_us = 0;              // time the workers spent inside run() (summed over workers)
+};
+
+// Where executed asynchronous requests are handed back.  A Coalescer has one of its own; a host with several event loops (the
+// reference runs a monoio runtime per core, src/query_disk_index.rs:716-732) gives each loop its own queue, so that a request comes
+// back to the loop that submitted it.  push() is lock-free and is the pusher's LAST access to the record; ring() moves the futex
+// word (and the eventfd, if one was asked for) once per pass; take() hands records out in completion order, each exactly once.
+class CompletionQueue {
+  public:
+    ~CompletionQueue();
+    void push(DispatchReq* r);
+    void ring();
+    size_t take(DispatchReq** out, size_t max, int64_t timeout_us, const std::atomic<bool>* stop);
+    int fd();          // an eventfd bumped by ring(); made on first call, closed with the queue
+    void close_fd();
+    void wake();       // wakes sleepers in take() without a completion (shutdown)
+
+  private:
+    alignas(64) std::atomic<DispatchReq*> head_{nullptr};
+    std::atomic<uint32_t> bell_{0};
+    std::atomic<int> fd_{-1};
+    std::mutex mu_;
+    std::deque<DispatchReq*> ready_;
 };
 
 class Coalescer {
@@ -88,6 +111,7 @@ class Coalescer {
     // an eventfd (made on first call, owned by the handle) whose counter is bumped once per pass that completed asynchronous requests:
     // an event loop (epoll / io_uring) watches it, reads the 8-byte counter when it fires, then polls completions() until it returns 0
     int completion_fd();
+    // (requests whose record names a CompletionQueue of its own -- DispatchReq::cq -- come back there instead)
     DispatchStats stats();
     size_t max_queries() const { return max_queries_; }
     uint32_t max_wait_us() const { return max_wait_us_.load(); }
@@ -123,13 +147,7 @@ class Coalescer {
     // so a pass touches few words): the worker sets each request's `done`, bumps the words it touched and wakes their sleepers; a
     // sleeper that was woken for somebody else's pass finds its own flag still clear and sleeps on the new value.
     WakeSlot wake_[WAKE_SLOTS];
-    // executed asynchronous requests: pushed by whoever completes a pass (lock-free), taken by completions() (its callers share
-    // comp_mu_ and the arrival-ordered comp_ready_); comp_bell_ moves once per pass that completed any
-    alignas(64) std::atomic<DispatchReq*> comp_{nullptr};
-    std::atomic<uint32_t> comp_bell_{0};
-    std::atomic<int> comp_fd_{-1};
-    std::mutex comp_mu_;
-    std::deque<DispatchReq*> comp_ready_;
+    CompletionQueue own_cq_;          // executed asynchronous requests that name no queue of their own
     // ---- the workers' side.  mu_ is taken by workers (and stats()) only: it hands the gatherer's token around and guards the
     // statistics.  queue_ / queued_queries_ / drained_ belong to whoever holds the token.
     std::mutex mu_;

@@ -61,14 +61,20 @@ Coalescer::Coalescer(size_t max_queries, uint32_t max_wait_us, RunFn run, std::f
 // flags first (a request's slot read before its flag is set: the record is gone once the flag is seen), then one wake-up per slot touched
 void Coalescer::complete(std::vector<DispatchReq*>& batch) {
     uint64_t touched = 0;
-    bool any_async = false;
+    CompletionQueue* rung[8];
+    int n_rung = 0;
+    bool many = false;
     for (DispatchReq* r : batch) {
-        if (r->async) {   // onto the completion list: from the successful exchange on the record belongs to whoever pops it
-            any_async = true;
-            DispatchReq* head = comp_.load(std::memory_order_relaxed);
-            do {
-                r->cnext = head;
-            } while (!comp_.compare_exchange_weak(head, r, std::memory_order_release, std::memory_order_relaxed));
+        if (r->async) {   // onto its completion queue: from the push on the record belongs to whoever takes it
+            CompletionQueue* q = r->cq ? r->cq : &own_cq_;
+            bool seen = false;
+            for (int i = 0; i < n_rung; i++) seen |= rung[i] == q;
+            if (!seen) {
+                if (n_rung < 8) rung[n_rung++] = q;
+                else many = true;
+            }
+            q->push(r);
+            if (many) q->ring();   // (more than eight queues in one pass: rung per request)
             continue;
         }
         touched |= 1ull << r->slot;
@@ -79,51 +85,52 @@ void Coalescer::complete(std::vector<DispatchReq*>& batch) {
             wake_[sl].gen.fetch_add(1, std::memory_order_release);
             futex_wake_all(&wake_[sl].gen);
         }
-    if (any_async) {
-        comp_bell_.fetch_add(1, std::memory_order_release);
-        futex_wake_all(&comp_bell_);
-        const int fd = comp_fd_.load(std::memory_order_acquire);
-        if (fd >= 0) {
-            const uint64_t one = 1;
-            (void)!write(fd, &one, sizeof one);   // (EAGAIN only at a counter of 2^64 - 2: the loop is awake anyway)
-        }
-    }
+    for (int i = 0; i < n_rung; i++) rung[i]->ring();
 }
 
-int Coalescer::completion_fd() {
-    int fd = comp_fd_.load(std::memory_order_acquire);
-    if (fd >= 0) return fd;
-    const int made = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
-    if (made < 0) return fail(std::string("eventfd: ") + strerror(errno));
-    int expected = -1;
-    if (!comp_fd_.compare_exchange_strong(expected, made, std::memory_order_acq_rel)) {   // another thread was first
-        (void)close(made);
-        return expected;
-    }
-    // requests that completed before the descriptor existed are announced now
-    bool pending = comp_.load(std::memory_order_acquire) != nullptr;
-    if (!pending) {
-        std::lock_guard<std::mutex> lk(comp_mu_);
-        pending = !comp_ready_.empty();
-    }
-    if (pending) {
+size_t Coalescer::completions(DispatchReq** out, size_t max, int64_t timeout_us) { return own_cq_.take(out, max, timeout_us, &stop_); }
+int Coalescer::completion_fd() { return own_cq_.fd(); }
+
+CompletionQueue::~CompletionQueue() { close_fd(); }
+
+void CompletionQueue::push(DispatchReq* r) {
+    DispatchReq* head = head_.load(std::memory_order_relaxed);
+    do {
+        r->cnext = head;
+    } while (!head_.compare_exchange_weak(head, r, std::memory_order_release, std::memory_order_relaxed));
+}
+
+void CompletionQueue::ring() {
+    bell_.fetch_add(1, std::memory_order_release);
+    futex_wake_all(&bell_);
+    const int fd = fd_.load(std::memory_order_acquire);
+    if (fd >= 0) {
         const uint64_t one = 1;
-        (void)!write(made, &one, sizeof one);
+        (void)!write(fd, &one, sizeof one);   // (EAGAIN only at a counter of 2^64 - 2: the loop is awake anyway)
     }
-    return made;
 }
 
-size_t Coalescer::completions(DispatchReq** out, size_t max, int64_t timeout_us) {
+void CompletionQueue::wake() {
+    bell_.fetch_add(1, std::memory_order_release);
+    futex_wake_all(&bell_);
+}
+
+void CompletionQueue::close_fd() {
+    const int fd = fd_.exchange(-1);
+    if (fd >= 0) (void)close(fd);
+}
+
+size_t CompletionQueue::take(DispatchReq** out, size_t max, int64_t timeout_us, const std::atomic<bool>* stop) {
     if (!out || max == 0) return 0;
     const bool timed = timeout_us >= 0;
     const int64_t deadline = timed ? std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() +
                                          timeout_us * 1000
                                    : 0;
     for (;;) {
-        const uint32_t bell = comp_bell_.load(std::memory_order_acquire);
+        const uint32_t bell = bell_.load(std::memory_order_acquire);
         {
-            std::lock_guard<std::mutex> lk(comp_mu_);
-            DispatchReq* h = comp_.exchange(nullptr, std::memory_order_acquire);
+            std::lock_guard<std::mutex> lk(mu_);
+            DispatchReq* h = head_.exchange(nullptr, std::memory_order_acquire);
             DispatchReq* rev = nullptr;   // the stack holds the newest first: back into completion order
             while (h) {
                 DispatchReq* n = h->cnext;
@@ -133,25 +140,48 @@ size_t Coalescer::completions(DispatchReq** out, size_t max, int64_t timeout_us)
             }
             for (DispatchReq* r = rev; r;) {
                 DispatchReq* n = r->cnext;
-                comp_ready_.push_back(r);
+                ready_.push_back(r);
                 r = n;
             }
             size_t got = 0;
-            while (got < max && !comp_ready_.empty()) {
-                out[got++] = comp_ready_.front();
-                comp_ready_.pop_front();
+            while (got < max && !ready_.empty()) {
+                out[got++] = ready_.front();
+                ready_.pop_front();
             }
             if (got) return got;
         }
-        if (stop_.load(std::memory_order_acquire)) return 0;
+        if (stop && stop->load(std::memory_order_acquire)) return 0;
         if (!timed) {
-            futex_wait(&comp_bell_, bell);
+            futex_wait(&bell_, bell);
             continue;
         }
         const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
         if (now >= deadline) return 0;
-        futex_wait_for(&comp_bell_, bell, deadline - now);
+        futex_wait_for(&bell_, bell, deadline - now);
     }
+}
+
+int CompletionQueue::fd() {
+    int fd = fd_.load(std::memory_order_acquire);
+    if (fd >= 0) return fd;
+    const int made = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
+    if (made < 0) return fail(std::string("eventfd: ") + strerror(errno));
+    int expected = -1;
+    if (!fd_.compare_exchange_strong(expected, made, std::memory_order_acq_rel)) {   // another thread was first
+        (void)close(made);
+        return expected;
+    }
+    // requests that completed before the descriptor existed are announced now
+    bool pending = head_.load(std::memory_order_acquire) != nullptr;
+    if (!pending) {
+        std::lock_guard<std::mutex> lk(mu_);
+        pending = !ready_.empty();
+    }
+    if (pending) {
+        const uint64_t one = 1;
+        (void)!write(made, &one, sizeof one);
+    }
+    return made;
 }
 
 void Coalescer::wake_loop(int index) {
@@ -203,12 +233,8 @@ Coalescer::~Coalescer() {
         r->done.store(1, std::memory_order_release);   // (r may be gone from here on)
     }
     queue_.clear();
-    comp_bell_.fetch_add(1, std::memory_order_release);   // anyone asleep in completions() sees stop_ and leaves
-    futex_wake_all(&comp_bell_);
-    {
-        const int fd = comp_fd_.exchange(-1);
-        if (fd >= 0) (void)close(fd);
-    }
+    own_cq_.wake();   // anyone asleep in completions() sees stop_ and leaves
+    own_cq_.close_fd();
     for (uint32_t sl = 0; sl < WAKE_SLOTS; sl++)
         if (touched >> sl & 1ull) {
             wake_[sl].gen.fetch_add(1, std::memory_order_release);
@@ -628,19 +654,24 @@ int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_q
 // callers run beside them through the same Coalescer; the stand-in pass is the one above.  *mismatches = records handed back twice or
 // never, wrong answers / statuses / error texts.
 int mse_debug_coalescer_selftest_async(int async_threads, int window, int n_requests, int sync_threads, uint32_t max_queries, int workers,
-                                       uint64_t stats_out[6], uint64_t* mismatches) {
+                                       int own_queues, uint64_t stats_out[6], uint64_t* mismatches) {
     if (async_threads <= 0 || window <= 0 || n_requests <= 0 || sync_threads < 0 || workers <= 0 || !stats_out || !mismatches) return fail("bad argument");
     struct Rec {
         DispatchReq r;
         uint64_t p = 0, out = 0;
         std::atomic<int> handed{0};
+        int thread = 0;
     };
+    std::vector<std::unique_ptr<CompletionQueue>> queues;   // own_queues: one per asynchronous thread (declared first: outlives the handle)
+    for (int t = 0; own_queues && t < async_threads; t++) queues.emplace_back(new CompletionQueue());
     const size_t total = (size_t)async_threads * (size_t)n_requests;
     std::vector<std::unique_ptr<Rec>> recs(total);
     for (size_t i = 0; i < total; i++) {
         recs[i].reset(new Rec());
         recs[i]->p = 5000000ull + i;
         recs[i]->r.queries = &recs[i]->p; recs[i]->r.nq = 1; recs[i]->r.k = 1; recs[i]->r.out_a = &recs[i]->out; recs[i]->r.owner = recs[i].get();
+        recs[i]->thread = (int)(i / (size_t)n_requests);
+        if (own_queues) recs[i]->r.cq = queues[recs[i]->thread].get();
     }
     std::atomic<uint64_t> bad{0}, collected{0};
     std::atomic<int64_t> in_flight{0};
@@ -657,18 +688,24 @@ int mse_debug_coalescer_selftest_async(int async_threads, int window, int n_requ
         std::vector<std::thread> ts;
         for (int t = 0; t < async_threads; t++)
             ts.emplace_back([&, t] {
-                size_t next = 0;
+                size_t next = 0, mine_back = 0;
+                int64_t mine_out = 0;
                 DispatchReq* got[64];
-                while (collected.load() < total) {
-                    // the windows are shared: completions go to whichever thread asks, so the count in flight is kept for all of them
-                    while (next < (size_t)n_requests && in_flight.load() < (int64_t)window * async_threads) {
+                while (own_queues ? mine_back < (size_t)n_requests : collected.load() < total) {
+                    // shared queue: completions go to whichever thread asks, so the count in flight is kept for all of them;
+                    // own queues: every thread keeps its own window and gets back exactly what it submitted
+                    while (next < (size_t)n_requests && (own_queues ? mine_out < window : in_flight.load() < (int64_t)window * async_threads)) {
                         in_flight.fetch_add(1);
+                        mine_out++;
                         if (co.submit_async(recs[(size_t)t * n_requests + next]->r)) bad++;
                         next++;
                     }
-                    const size_t n = co.completions(got, 64, 2000);
+                    const size_t n = own_queues ? queues[t]->take(got, 64, 2000, nullptr) : co.completions(got, 64, 2000);
+                    mine_out -= (int64_t)n;
+                    mine_back += n;
                     for (size_t i = 0; i < n; i++) {
                         Rec* rc = static_cast<Rec*>(got[i]->owner);
+                        if (own_queues && rc->thread != t) bad++;   // somebody else's record in this thread's queue
                         if (rc->handed.fetch_add(1) != 0) bad++;
                         if (rc->p % 97 == 0) { if (rc->r.rc == 0 || rc->r.err.find(std::to_string(rc->p)) == std::string::npos) bad++; }
                         else if (rc->r.rc != 0 || rc->out != 2 * rc->p + 1) bad++;

@@ -291,17 +291,41 @@ class QueryTickets:
     """The request path without a thread per request (include/mse.h "WITHOUT A THREAD PER REQUEST"): one host thread keeps many
     one-query requests of a graph in flight, the way the reference's monoio tasks would (src/query_disk_index.rs:640-655,716-732).
     submit() queues a request and returns its key; collect() hands back requests executed since, as (key, ids [nq, k], scores
-    [nq, k]) -- the answers of disk_query_topk for the same queries, bit for bit.  A graph has ONE completion list: collect() of any
-    QueryTickets object of that graph returns whatever has completed, whichever object (search settings) submitted it; the output
-    arrays of requests in flight are kept alive on the graph object."""
+    [nq, k]) -- the answers of disk_query_topk for the same queries, bit for bit.  By default a graph has ONE completion list:
+    collect() of any such QueryTickets object of that graph returns whatever has completed, whichever object (search settings)
+    submitted it (the output arrays of requests in flight are kept alive on the graph object); with own_queue=True the object has a
+    completion queue of its own."""
 
-    def __init__(self, searcher: Searcher, quantizer, codes, dgraph, k, disable_pq=False, beamwidth=1, search_list=1000):
+    def __init__(self, searcher: Searcher, quantizer, codes, dgraph, k, disable_pq=False, beamwidth=1, search_list=1000, own_queue=False):
+        """own_queue=True: a completion queue of this object's own (mse_completion_queue_*): its requests come back through its
+        collect() / fileno() and nowhere else -- one per event loop of a host that runs several."""
         import threading
         self._s, self._pq, self._codes, self._g = searcher, quantizer, codes, dgraph
         self.k, self.disable_pq, self.beamwidth, self.search_list = int(k), bool(disable_pq), int(beamwidth), int(search_list)
-        if not hasattr(dgraph, "_tickets"):
-            dgraph._tickets = {"lock": threading.Lock(), "next": 1, "out": {}}
-        self._reg = dgraph._tickets
+        self._q = None
+        if own_queue:
+            self._q = check_ptr(ffi.lib().mse_completion_queue_new(), "mse_completion_queue_new")
+            self._reg = {"lock": threading.Lock(), "next": 1, "out": {}}
+        else:
+            if not hasattr(dgraph, "_tickets"):
+                dgraph._tickets = {"lock": threading.Lock(), "next": 1, "out": {}}
+            self._reg = dgraph._tickets
+
+    def close(self):
+        """Release the object's own completion queue (no request of it may be in flight)."""
+        if getattr(self, "_q", None):
+            if self._reg["out"]:
+                raise MseError("completion queue closed with requests in flight")
+            ffi.lib().mse_completion_queue_free(self._q)
+            self._q = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_q", None) and not self._reg["out"]:
+                ffi.lib().mse_completion_queue_free(self._q)
+                self._q = None
+        except Exception:  # noqa: BLE001
+            pass
 
     @property
     def in_flight(self):
@@ -326,7 +350,7 @@ class QueryTickets:
                                                       self._codes._h if self._codes is not None else None, self._g._h, _p(q, C.c_float),
                                                       _p(sc, C.c_float) if sc is not None else None, nq, int(self.disable_pq), self.beamwidth,
                                                       self.search_list, self.k, _p(ids, C.c_uint32), _p(scores, C.c_int64), None, None, None,
-                                                      C.c_void_p(tag), C.byref(t)), "disk_query_submit_f32")
+                                                      C.c_void_p(tag), self._q, C.byref(t)), "disk_query_submit_f32")
         except MseError:
             with self._reg["lock"]:
                 self._reg["out"].pop(tag, None)
@@ -336,9 +360,9 @@ class QueryTickets:
     def fileno(self):
         """An eventfd that becomes readable when requests of the graph have completed (for select / epoll / asyncio's add_reader):
         read its 8-byte counter, then collect(timeout_us=0) until it returns []."""
-        fd = ffi.lib().mse_graph_completion_fd(self._g._h)
+        fd = ffi.lib().mse_completion_queue_fd(self._q) if self._q else ffi.lib().mse_graph_completion_fd(self._g._h)
         if fd < 0:
-            check(-1, "graph_completion_fd")
+            check(-1, "completion fd")
         return fd
 
     def collect(self, max_tickets=256, timeout_us=-1):
@@ -350,9 +374,12 @@ class QueryTickets:
         if pending:
             raise pending.pop(0)
         buf = (C.c_void_p * int(max_tickets))()
-        n = ffi.lib().mse_graph_completions(self._g._h, buf, int(max_tickets), int(timeout_us))
+        if self._q:
+            n = ffi.lib().mse_completion_queue_wait(self._q, buf, int(max_tickets), int(timeout_us))
+        else:
+            n = ffi.lib().mse_graph_completions(self._g._h, buf, int(max_tickets), int(timeout_us))
         if n < 0:
-            check(-1, "graph_completions")
+            check(-1, "completions")
         done = []
         for i in range(n):
             t = buf[i]

@@ -152,7 +152,11 @@ SIGNATURES = {
     "mse_shard_group_query_topk": (C.c_int, [vp, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, i64p, u32p]),
     "mse_graph_set_entry_centroids": (C.c_int, [vp, f32p, sz, u32p, sz]),
     "mse_disk_query_topk_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
-    "mse_disk_query_submit_f32": (C.c_int, [vp, vp, vp, vp, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p, vp, C.POINTER(vp)]),
+    "mse_disk_query_submit_f32": (C.c_int, [vp, vp, vp, vp, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p, vp, vp, C.POINTER(vp)]),
+    "mse_completion_queue_new": (vp, []),
+    "mse_completion_queue_free": (None, [vp]),
+    "mse_completion_queue_fd": (C.c_int, [vp]),
+    "mse_completion_queue_wait": (C.c_long, [vp, C.POINTER(vp), sz, C.c_long]),
     "mse_graph_completions": (C.c_long, [vp, C.POINTER(vp), sz, C.c_long]),
     "mse_graph_completion_fd": (C.c_int, [vp]),
     "mse_ticket_status": (C.c_int, [vp]),
@@ -164,7 +168,7 @@ SIGNATURES = {
     "mse_graph_coalescer_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "mse_searcher_wait_stream": (C.c_int, [vp, vp]),
     "mse_debug_coalescer_selftest_workers": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "mse_debug_coalescer_selftest_async": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mse_debug_coalescer_selftest_async": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mse_disk_query_topk": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
     "mse_graph_new": (vp, [sz, sz]),
     "mse_graph_to_host": (C.c_int, [vp, u32p, u32p]),

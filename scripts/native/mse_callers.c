@@ -177,7 +177,7 @@ double mse_callers_run_query(void* fn, int is_f32, void** searchers, int n_searc
  * src/query_disk_index.rs:640-655) would do.  Request j's latency runs from its submit to the moment its ticket is collected. */
 typedef int (*submit32_fn)(void* s, void* pq, const void* c, const void* g, const void* q, const float* scales, size_t nq, int disable_pq,
                            size_t beam, size_t list, size_t k, uint32_t* ids, int64_t* scores, uint32_t* nv, uint32_t* cm, uint32_t* pc, void* user,
-                           void** ticket);
+                           void* completion_queue, void** ticket);
 typedef long (*completions_fn)(const void* g, void** out, size_t max, long timeout_us);
 typedef int (*tstatus_fn)(const void* t);
 typedef void* (*tuser_fn)(const void* t);
@@ -213,7 +213,7 @@ static void* acaller_main(void* p) {
             c->t_sub[j] = now_s();
             if (((submit32_fn)c->submit)(c->searcher, c->pq, c->codes, c->graph, (const char*)c->queries + j * c->query_bytes, NULL, 1, c->disable_pq,
                                          c->beam, c->list, c->k, c->ids + j * c->k, c->scores + j * c->k, NULL, NULL, NULL, (void*)(uintptr_t)(j + 1),
-                                         &ticket)) {
+                                         NULL, &ticket)) {
                 atomic_fetch_add(c->failures, 1);   /* never queued: nothing will come back for it */
                 atomic_fetch_sub(c->in_flight, 1);
                 atomic_fetch_add(c->done, 1);

@@ -240,17 +240,20 @@ def test_coalescer_queue_hands_every_caller_its_own_answer(mse, threads, rounds,
         assert passes < requests / 2, (passes, requests)
 
 
-@pytest.mark.parametrize("async_threads,window,n,sync_threads,max_queries,workers", [(1, 1, 300, 0, 256, 1), (1, 512, 6000, 0, 128, 2),
-                                                                                      (3, 64, 2000, 8, 64, 2), (2, 4096, 9000, 16, 1024, 2)])
-def test_coalescer_asynchronous_requests(mse, async_threads, window, n, sync_threads, max_queries, workers):
+@pytest.mark.parametrize("async_threads,window,n,sync_threads,max_queries,workers,own_queues",
+                         [(1, 1, 300, 0, 256, 1, 0), (1, 512, 6000, 0, 128, 2, 0), (3, 64, 2000, 8, 64, 2, 0), (2, 4096, 9000, 16, 1024, 2, 0),
+                          (4, 128, 3000, 8, 256, 2, 1), (1, 1, 200, 0, 64, 1, 1)])
+def test_coalescer_asynchronous_requests(mse, async_threads, window, n, sync_threads, max_queries, workers, own_queues):
     """submit_async / completions of the coalescer without a device: threads that keep a window of records in flight and collect
     whatever has completed (theirs or another thread's), beside blocking callers on the same handle.  Every record comes back exactly
-    once with ITS answer or ITS error; the blocking callers are unaffected; a window of one is never batched with a wait."""
+    once with ITS answer or ITS error; the blocking callers are unaffected; a window of one is never batched with a wait.  With
+    own_queues every asynchronous thread has a completion queue of its own (one per event loop of a host that runs several) and must
+    get back exactly the records it submitted."""
     import ctypes as C
     from mse import ffi
     stats = (C.c_uint64 * 6)()
     bad = C.c_uint64(12345)
-    ffi.check(ffi.lib().mse_debug_coalescer_selftest_async(async_threads, window, n, sync_threads, max_queries, workers, stats, C.byref(bad)))
+    ffi.check(ffi.lib().mse_debug_coalescer_selftest_async(async_threads, window, n, sync_threads, max_queries, workers, own_queues, stats, C.byref(bad)))
     assert bad.value == 0
     assert stats[5] == async_threads * n                       # every asynchronous record collected
     assert stats[0] == async_threads * n + sync_threads * 200  # and all of them, blocking ones included, executed

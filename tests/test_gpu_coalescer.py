@@ -541,6 +541,26 @@ def test_request_path_without_a_thread_per_request(gpu, mse, orc):
     after = mse.coalescer_stats(dgraph)
     assert after["requests"] - before["requests"] >= 2 * Q
     assert after["passes"] - before["passes"] <= (after["requests"] - before["requests"]) // 8      # shared submissions
+    # completion queues of their own (one per event loop of a host that runs several): each object gets back exactly what IT submitted,
+    # through its own descriptor, while the graph's shared list stays empty
+    loop_a = mse.QueryTickets(s, None, None, dgraph, 7, True, 2, 32, own_queue=True)
+    loop_b = mse.QueryTickets(s, gpq, gcodes, dgraph, 10, False, 4, 48, own_queue=True)
+    assert loop_a.fileno() != loop_b.fileno() and loop_a.fileno() != exact.fileno()
+    for i in range(40):
+        loop_a.submit(qs[i], key=("a", i))
+        loop_b.submit(qs[i], scales[i], key=("b", i))
+    got_a, got_b = {}, {}
+    while len(got_a) < 40:
+        for key, ids, sc in loop_a.collect(timeout_us=2_000_000):
+            got_a[key] = ids
+    while len(got_b) < 40:
+        for key, ids, sc in loop_b.collect(timeout_us=2_000_000):
+            got_b[key] = ids
+    assert set(got_a) == {("a", i) for i in range(40)} and set(got_b) == {("b", i) for i in range(40)}
+    assert all(np.array_equal(got_a[("a", i)][0], want_exact[0][i]) and np.array_equal(got_b[("b", i)][0], want_adc[0][i]) for i in range(40))
+    assert exact.collect(timeout_us=0) == [] and loop_a.collect(timeout_us=0) == []
+    loop_a.close()
+    loop_b.close()
     # a refused request (search list beyond the limit) is refused at submit; one that fails when executed fails alone
     with pytest.raises(mse.MseError):
         mse.QueryTickets(s, None, None, dgraph, 7, True, 2, 5000).submit(qs[0])
