@@ -423,7 +423,8 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  * mse_searcher_wait_stream(s, that_stream) first -- or synchronise that stream -- else the search may read them half written. */
 /* WITHOUT A THREAD PER REQUEST (round 5).  The device wants thousands of queries per submission; a sleeping OS thread per request is
  * the wrong vehicle for that (4096 request threads on a 16-core CPU allowance: 25 us of CPU per request just for being woken).  An
- * async host -- the reference serves every connection as a monoio task on a runtime per core (src/query_disk_index.rs:640-655,716-732) -- keeps its requests in flight as tickets:
+ * async host -- the reference serves every connection as a monoio task on a runtime per core (src/query_disk_index.rs:640-655,
+ * 716-732) -- keeps its requests in flight as tickets:
  *   mse_disk_query_submit_f32  as mse_disk_query_topk_f32 with nq = 1..16 and entry by the graph's table, but returns as soon as the
  *                          request is queued.  The query (and scales) are copied: the caller's buffers are free at once.  ids / scores
  *                          (/ n_visited / cmps / pq_cmps) are written when the request is executed and must stay valid until its
@@ -440,8 +441,9 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *                          whose counter is bumped once per submission that completed tickets: register it with epoll / io_uring, read
  *                          the 8-byte counter when it fires, then call mse_graph_completions(…, 0) until it returns 0.
  *   mse_ticket_status / _error / _user / _free   0 or the request's error (with its message); the user pointer; release.
- * Results are those of the synchronous call, bit for bit (the same shared submissions execute both kinds).  Do not free the graph,
- * change its coalescer settings or its entry table while tickets are out. */
+ * Results are those of the synchronous call, bit for bit (the same shared submissions execute both kinds).  Do not free the graph
+ * or change its coalescer settings while tickets are out; its entry table may be replaced (a queued request starts from the table
+ * that is set when it executes). */
 typedef struct mse_ticket mse_ticket;
 typedef struct mse_completion_queue mse_completion_queue;
 int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
