@@ -1382,7 +1382,7 @@ def main():
                                                                 rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in gc_}
                     tk_ = g(row, "graph_callers", "tickets", "points")
                     if tk_:
-                        gi[kind]["tickets"] = {str(p_["in_flight"]) + ("" if p_.get("host_threads", 1) == 1 else "x%dthreads" % p_["host_threads"]): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
+                        gi[kind]["tickets"] = {str(p_["in_flight"]) + ("" if p_.get("host_threads", 1) == 1 else "x%dthreads" % p_["host_threads"]) + ("" if p_.get("query_copied_at_submit", True) else "_nocopy"): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
                                                                       rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in tk_}
                     pt_ = g(row, "graph_callers", "perf_test_py_shape")
                     if pt_:

@@ -197,21 +197,22 @@ def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, 
 
     L = ffi.lib()
     afn = [C.cast(getattr(L, nm), C.c_void_p) for nm in ("mse_disk_query_submit_f32", "mse_graph_completions", "mse_ticket_status", "mse_ticket_user", "mse_ticket_free")]
+    afn_nocopy = [C.cast(L.mse_disk_query_submit_f32_nocopy, C.c_void_p)] + afn[1:]
 
-    def run_async(W, n, host_threads=1):
+    def run_async(W, n, host_threads=1, nocopy=False):
         """the same requests WITHOUT a thread per request: `host_threads` native threads keep W one-query requests in flight as tickets"""
         ids = np.full((n, k), 0xFFFFFFFF, np.uint32)
         sc = np.zeros((n, k), np.int64)
         lat = np.zeros(n, np.float64)
         failed = C.c_int(0)
         st0 = mse.coalescer_stats(g)
-        dt = H.mse_callers_run_async(*afn, searchers[0]._h, pq_h, c_h, g._h, qf.ctypes.data, n, D * 4, int(disable_pq), beam, search_list, k, W, host_threads,
+        dt = H.mse_callers_run_async(*(afn_nocopy if nocopy else afn), searchers[0]._h, pq_h, c_h, g._h, qf.ctypes.data, n, D * 4, int(disable_pq), beam, search_list, k, W, host_threads,
                                      ids.ctypes.data, sc.ctypes.data, lat.ctypes.data, C.byref(failed))
         st1 = mse.coalescer_stats(g)
         ok = bool(dt > 0 and failed.value == 0 and np.array_equal(ids, want_ids[:n]) and np.array_equal(sc, want_sc[:n]))
         passes = st1["passes"] - st0["passes"]
         busy = (st1["run_us"] - st0["run_us"]) * 1e-6
-        return {"in_flight": W, "host_threads": host_threads, "queries": n, "queries_per_s": n / dt if dt > 0 else None, "seconds": dt,
+        return {"in_flight": W, "host_threads": host_threads, "query_copied_at_submit": not nocopy, "queries": n, "queries_per_s": n / dt if dt > 0 else None, "seconds": dt,
                 "worker_seconds_in_submissions": busy, "ms_per_submission": busy / max(passes, 1) * 1e3,
                 "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
                 "submissions": passes, "queries_per_submission": n / max(passes, 1), "all_answers_equal_the_batch_call": ok,
@@ -226,6 +227,10 @@ def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, 
         n = min(n_all, W * rounds if rounds else max(10 * W, 20_000))
         run_async(W, min(n, 2 * W))
         tickets.append(run_async(W, n))
+    if max(thread_counts) >= 1024:      # the largest window once more with the query left in the caller's buffer (mse_disk_query_submit_f32_nocopy)
+        W = max(thread_counts)
+        n = min(n_all, W * rounds if rounds else max(10 * W, 20_000))
+        tickets.append(run_async(W, n, nocopy=True))
     # (two submitting threads for the largest window measured 0.69-0.83 M against 0.80-1.12 M from one: the submissions get smaller,
     # profiles/r05_graph_callers_tickets.txt -- not part of the leg)
     run(100, min(n_all, 200))

@@ -440,7 +440,8 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  *   mse_graph_completion_fd  an eventfd owned by the graph (valid until its coalescer settings change or it is freed; -1 on error)
  *                          whose counter is bumped once per submission that completed tickets: register it with epoll / io_uring, read
  *                          the 8-byte counter when it fires, then call mse_graph_completions(…, 0) until it returns 0.
- *   mse_ticket_status / _error / _user / _free   0 or the request's error (with its message); the user pointer; release.
+ *   mse_ticket_status / _error / _user / _free   0 or the request's error (with its message); the user pointer; release (tickets
+ *                          are recycled per thread: a poller that submits and releases on one thread allocates nothing in steady state).
  * Results are those of the synchronous call, bit for bit (the same shared submissions execute both kinds).  Do not free the graph
  * or change its coalescer settings while tickets are out; its entry table may be replaced (a queued request starts from the table
  * that is set when it executes). */
@@ -450,6 +451,11 @@ int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
                               size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
                               uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
                               mse_ticket** ticket_out);
+/* the same without the copies: queries_f32 (and scales) must stay valid and unchanged until the ticket has come back */
+int mse_disk_query_submit_f32_nocopy(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32,
+                                     const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids,
+                                     int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
+                                     mse_ticket** ticket_out);
 mse_completion_queue* mse_completion_queue_new(void);
 void mse_completion_queue_free(mse_completion_queue* q);
 int mse_completion_queue_fd(mse_completion_queue* q);

@@ -1320,10 +1320,40 @@ struct mse_ticket {
     void* user = nullptr;
 };
 
-int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
-                              size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
-                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
-                              mse_ticket** ticket_out) {
+// Tickets are recycled per thread: a loop that submits and releases on one thread (the usual poller) allocates nothing in steady state
+// (a ticket keeps the capacity of its query copy); tickets released on another thread fill that thread's cache up to its cap.
+namespace {
+constexpr size_t TICKET_CACHE_MAX = 8192;
+struct TicketCache {
+    std::vector<mse_ticket*> free_list;
+    ~TicketCache() { for (mse_ticket* t : free_list) delete t; }
+};
+thread_local TicketCache tl_tickets;
+
+mse_ticket* ticket_take() {
+    if (!tl_tickets.free_list.empty()) {
+        mse_ticket* t = tl_tickets.free_list.back();
+        tl_tickets.free_list.pop_back();
+        return t;
+    }
+    return new (std::nothrow) mse_ticket();
+}
+
+void ticket_give(mse_ticket* t) {
+    if (tl_tickets.free_list.size() >= TICKET_CACHE_MAX) { delete t; return; }
+    // back to the state of a new record (the vectors keep their capacity)
+    t->r.rc = 0; t->r.err.clear(); t->r.flags = 0; t->r.next = nullptr; t->r.cnext = nullptr; t->r.cq = nullptr; t->user = nullptr;
+    try {
+        tl_tickets.free_list.push_back(t);
+    } catch (const std::bad_alloc&) {
+        delete t;
+    }
+}
+
+int submit_f32(bool copy, mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
+               size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
+               uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
+               mse_ticket** ticket_out) {
     if (!queries_f32 || !ticket_out || !g || !ids || !scores) return fail("disk_query_submit_f32: null argument");
     if (!s || !s->base) return fail("disk_query_submit_f32: null searcher");
     if (nq == 0 || nq > FUSED_COALESCE_MAX) return fail("disk_query_submit_f32: 1.." + std::to_string(FUSED_COALESCE_MAX) + " queries per request");
@@ -1333,18 +1363,23 @@ int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
     if ((!disable_pq && (!pq || !c)) || (scales && !c)) return fail("disk_search_batch: null argument");
     Coalescer* co = graph_coalescer(g);
     if (!co) return -1;
-    mse_ticket* t = new (std::nothrow) mse_ticket();
+    mse_ticket* t = ticket_take();
     if (!t) return fail("out of host memory");
     const size_t d = s->base->d;
-    try {
-        t->q32.assign(queries_f32, queries_f32 + nq * d);
-        if (scales) t->scales.assign(scales, scales + nq * c->n_desc);
-    } catch (const std::bad_alloc&) {
-        delete t;
-        return fail("out of host memory");
+    const float *q_use = queries_f32, *sc_use = scales;
+    if (copy) {
+        try {
+            t->q32.assign(queries_f32, queries_f32 + nq * d);
+            if (scales) t->scales.assign(scales, scales + nq * c->n_desc);
+        } catch (const std::bad_alloc&) {
+            delete t;
+            return fail("out of host memory");
+        }
+        q_use = t->q32.data();
+        sc_use = scales ? t->scales.data() : nullptr;
     }
     t->user = user;
-    t->k = QueryCall{s, pq, c, g, nullptr, nullptr, t->q32.data(), nullptr, scales ? t->scales.data() : nullptr, nq, disable_pq, beamwidth, search_list, k,
+    t->k = QueryCall{s, pq, c, g, nullptr, nullptr, q_use, nullptr, sc_use, nq, disable_pq, beamwidth, search_list, k,
                      ids, scores, n_visited, cmps, pq_cmps};
     t->r.nq = nq;
     t->r.aux0 = &t->k;
@@ -1358,6 +1393,24 @@ int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
         return -1;
     }
     return 0;
+}
+}  // namespace
+
+int mse_disk_query_submit_f32(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32, const float* scales,
+                              size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids, int64_t* scores,
+                              uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
+                              mse_ticket** ticket_out) {
+    return submit_f32(true, s, pq, c, g, queries_f32, scales, nq, disable_pq, beamwidth, search_list, k, ids, scores, n_visited, cmps, pq_cmps, user, cq,
+                      ticket_out);
+}
+
+// the same without the copies: queries_f32 (and scales) must stay valid and unchanged until the ticket has come back
+int mse_disk_query_submit_f32_nocopy(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* g, const float* queries_f32,
+                                     const float* scales, size_t nq, int disable_pq, size_t beamwidth, size_t search_list, size_t k, uint32_t* ids,
+                                     int64_t* scores, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps, void* user, mse_completion_queue* cq,
+                                     mse_ticket** ticket_out) {
+    return submit_f32(false, s, pq, c, g, queries_f32, scales, nq, disable_pq, beamwidth, search_list, k, ids, scores, n_visited, cmps, pq_cmps, user, cq,
+                      ticket_out);
 }
 
 long mse_graph_completions(const mse_graph* g, mse_ticket** out, size_t max, long timeout_us) {
@@ -1400,7 +1453,7 @@ int mse_graph_completion_fd(const mse_graph* g) {
 int mse_ticket_status(const mse_ticket* t) { return t ? t->r.rc : -1; }
 const char* mse_ticket_error(const mse_ticket* t) { return t ? t->r.err.c_str() : "null ticket"; }
 void* mse_ticket_user(const mse_ticket* t) { return t ? t->user : nullptr; }
-void mse_ticket_free(mse_ticket* t) { delete t; }
+void mse_ticket_free(mse_ticket* t) { if (t) ticket_give(t); }
 
 // A shard's form of the request path: the [nq][k] results stay on the device as a packed block ([nq*k] i64 scores, [nq*k] u32 ids +
 // id_offset; mse_topk_block_bytes) ready for the exchange; no coalescing (the shard's thread brings the whole batch).

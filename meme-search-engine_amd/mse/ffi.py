@@ -153,6 +153,7 @@ SIGNATURES = {
     "mse_graph_set_entry_centroids": (C.c_int, [vp, f32p, sz, u32p, sz]),
     "mse_disk_query_topk_f32": (C.c_int, [vp, vp, vp, vp, u32p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
     "mse_disk_query_submit_f32": (C.c_int, [vp, vp, vp, vp, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p, vp, vp, C.POINTER(vp)]),
+    "mse_disk_query_submit_f32_nocopy": (C.c_int, [vp, vp, vp, vp, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p, vp, vp, C.POINTER(vp)]),
     "mse_completion_queue_new": (vp, []),
     "mse_completion_queue_free": (None, [vp]),
     "mse_completion_queue_fd": (C.c_int, [vp]),

@@ -73,7 +73,7 @@ def main():
         print("cores", cores, flush=True)
         out = ba.graph_callers(ROOT, vecs, g, qf, truth, L, K, 4, (64, 512, 4096), one_call, coalescer=co, pin_to_quota=False)
         print("cgroup", cg(), flush=True)
-        print("tickets", json.dumps([{k: p[k] for k in ("in_flight", "host_threads", "queries_per_s", "latency_ms", "queries_per_submission", "ms_per_submission", "all_answers_equal_the_batch_call", "vs_one_call_of_4096")} for p in out["tickets"]["points"]]), flush=True)
+        print("tickets", json.dumps([{k: p[k] for k in ("in_flight", "host_threads", "query_copied_at_submit", "queries_per_s", "latency_ms", "queries_per_submission", "ms_per_submission", "all_answers_equal_the_batch_call", "vs_one_call_of_4096")} for p in out["tickets"]["points"]]), flush=True)
         print(json.dumps({"coalescer": co, "points": [{k: p[k] for k in ("threads", "queries_per_s", "latency_ms", "queries_per_submission", "ms_per_submission", "worker_seconds_in_submissions", "seconds", "all_answers_equal_the_batch_call", "vs_one_call_of_4096")} for p in out["points"]],
                           "perf_test": {k: out["perf_test_py_shape"][k] for k in ("queries_per_s", "latency_ms", "queries_per_submission")}}), flush=True)
 
