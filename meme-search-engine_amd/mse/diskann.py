@@ -332,7 +332,9 @@ class QueryTickets:
         """Requests of the whole graph submitted and not yet collected."""
         return len(self._reg["out"])
 
-    def submit(self, query_f32, descriptor_scales=None, key=None):
+    def submit(self, query_f32, descriptor_scales=None, key=None, copy=True):
+        """copy=False: the library reads the query where it lies (mse_disk_query_submit_f32_nocopy); this object keeps the array alive
+        until the request has been collected."""
         q = np.ascontiguousarray(np.asarray(query_f32, np.float32).reshape(-1, np.asarray(query_f32).shape[-1]))
         nq = q.shape[0]
         sc = None
@@ -343,10 +345,11 @@ class QueryTickets:
         with self._reg["lock"]:
             tag = self._reg["next"]
             self._reg["next"] += 1
-            self._reg["out"][tag] = (key if key is not None else tag, ids, scores)   # before the request can complete
+            self._reg["out"][tag] = (key if key is not None else tag, ids, scores) + (() if copy else (q, sc))   # before the request can complete
         t = C.c_void_p()
         try:
-            check(ffi.lib().mse_disk_query_submit_f32(self._s._h, self._pq._h if self._pq is not None else None,
+            fn = ffi.lib().mse_disk_query_submit_f32 if copy else ffi.lib().mse_disk_query_submit_f32_nocopy
+            check(fn(self._s._h, self._pq._h if self._pq is not None else None,
                                                       self._codes._h if self._codes is not None else None, self._g._h, _p(q, C.c_float),
                                                       _p(sc, C.c_float) if sc is not None else None, nq, int(self.disable_pq), self.beamwidth,
                                                       self.search_list, self.k, _p(ids, C.c_uint32), _p(scores, C.c_int64), None, None, None,
@@ -388,7 +391,7 @@ class QueryTickets:
             msg = ffi.lib().mse_ticket_error(t).decode() if rc else ""
             ffi.lib().mse_ticket_free(t)
             with self._reg["lock"]:
-                key, ids, scores = self._reg["out"].pop(tag)
+                key, ids, scores = self._reg["out"].pop(tag)[:3]
             if rc:
                 pending.append(MseError(f"request {key!r}: {msg or 'search failed'}"))
             else:

@@ -547,7 +547,7 @@ def test_request_path_without_a_thread_per_request(gpu, mse, orc):
     loop_b = mse.QueryTickets(s, gpq, gcodes, dgraph, 10, False, 4, 48, own_queue=True)
     assert loop_a.fileno() != loop_b.fileno() and loop_a.fileno() != exact.fileno()
     for i in range(40):
-        loop_a.submit(qs[i], key=("a", i))
+        loop_a.submit(qs[i], key=("a", i), copy=bool(i % 2))                # every other one read where it lies (_nocopy)
         loop_b.submit(qs[i], scales[i], key=("b", i))
     got_a, got_b = {}, {}
     while len(got_a) < 40:
