@@ -249,7 +249,7 @@ def graph_callers(root, vecs, g, queries_f32, truth, search_list, k=10, beam=4, 
                                 "(mse_disk_query_submit_f32 / mse_graph_completions), the way the reference's monoio tasks would "
                                 "(src/query_disk_index.rs:640-655); latency = submit to collection", "points": tickets},
             "perf_test_py_shape": dict(perf_test, note="1000 one-query requests at concurrency 100, k = 10 (perf_test.py:6-29)"),
-            "coalescer": {"max_queries_per_submission": coalescer[0] or 1024, "max_wait_us": coalescer[1] or 200, "workers": coalescer[2] or 2,
+            "coalescer": {"max_queries_per_submission": coalescer[0] or 1024, "max_wait_us": coalescer[1] or 200, "workers": coalescer[2] or 3,
                           "submissions_started_by_wait_budget": st["deadline_fires"]}}
 
 

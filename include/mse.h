@@ -416,7 +416,7 @@ int mse_disk_search_batch(mse_searcher* s, mse_pq* pq, const mse_codes* c, const
  * exactly what its call returns when made alone.  Such a call only reads `s` for the vectors it names: request threads may share one
  * searcher handle for these calls (4096 request threads do not need 4096 streams).  mse_graph_set_coalescer (before the first such
  * call, or with none in flight): queries per shared submission (0 = 1024), longest wait of the oldest request in microseconds
- * (0 = 200; a lone caller never waits), worker threads (0 = 2: one submission's copies overlap the other's kernels).
+ * (0 = 200; a lone caller never waits), worker threads (0 = 3: the copies and host side of one submission overlap the kernels of the others).
  * mse_graph_coalescer_stats: {queries, requests, submissions, most queries in one submission, submissions started by the wait
  * budget, microseconds the workers spent executing submissions}.
  * DEVICE-RESIDENT QUERIES: the copy of `queries` runs on the searcher's stream.  If another stream produced them (a tower's), call

@@ -1129,7 +1129,7 @@ Coalescer* graph_coalescer(const mse_graph* g) {
     if (Coalescer* co = g->co_fast.load(std::memory_order_acquire)) return co;   // thousands of request threads pass here: no lock once it exists
     std::lock_guard<std::mutex> lk(g->co_mu);
     if (!g->co) {
-        const int workers = g->co_workers > 0 ? g->co_workers : 2;
+        const int workers = g->co_workers > 0 ? g->co_workers : 3;
         g->co_ctx.resize((size_t)workers);
         g->co = new (std::nothrow) Coalescer(g->co_max_queries ? g->co_max_queries : 1024, g->co_max_wait_us ? g->co_max_wait_us : 200,
                                              [](std::vector<DispatchReq*>& b) { graph_run_batch(b); }, nullptr, workers);

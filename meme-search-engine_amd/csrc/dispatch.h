@@ -14,7 +14,7 @@
 // at T queries per pass after two passes, and callers that do not come back cost a grace period on every other pass at most.
 // More expected callers than one pass holds are served in EQUAL passes (512 callers, 320 per pass: 256 + 256, not 320 + 192).
 //
-// Round 5: a handle may run SEVERAL workers (the graph's request path runs two: one pass's upload / download and host side
+// Round 5: a handle may run SEVERAL workers (the graph's request path runs three: one pass's upload / download and host side
 // overlap the other's kernels).  One worker gathers at a time, by the same rule; the others run or sleep.  Completion is
 // signalled through a ring of futex words that requests are assigned to in arrival order, 256 to a word: a request's `done` flag
 // is an atomic of its own, a pass bumps the words of the slots it touched and wakes their sleepers with ONE futex call each --

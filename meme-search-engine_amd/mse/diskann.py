@@ -231,7 +231,7 @@ def set_dedup(dgraph, threshold=DUPLICATES_THRESHOLD):
 
 
 def set_coalescer(dgraph, max_queries_per_pass=0, max_wait_us=0, workers=0):
-    """How the graph's coalescer serves small request-path calls from many threads (0 = the defaults: 1024, 200 us, 2 workers)."""
+    """How the graph's coalescer serves small request-path calls from many threads (0 = the defaults: 1024, 200 us, 3 workers)."""
     check(ffi.lib().mse_graph_set_coalescer(dgraph._h, int(max_queries_per_pass), int(max_wait_us), int(workers)), "graph_set_coalescer")
 
 

@@ -65,6 +65,8 @@ def main():
     plan = [((0, 0, 0), None), ((2048, 200, 2), 32), ((4096, 200, 2), 32), ((4096, 200, 3), 32), ((0, 0, 0), 32)]
     if len(sys.argv) > 3 and sys.argv[3] == "quick":
         plan = [((0, 0, 0), 32), ((0, 0, 0), 32), ((0, 0, 0), 32)]
+    if len(sys.argv) > 3 and sys.argv[3] == "workers":
+        plan = [((0, 0, 3), 32), ((0, 0, 2), 32), ((0, 0, 3), 32), ((0, 0, 2), 32), ((0, 0, 4), 32)]
     if len(sys.argv) > 3 and sys.argv[3] == "affinity":
         plan = [((0, 0, 0), None), ((0, 0, 0), 16), ((0, 0, 0), 32), ((0, 0, 0), 64), ((4096, 1000, 2), 32), ((4096, 1000, 2), None), ((4096, 3000, 2), 32)]
     all_cores = sorted(os.sched_getaffinity(0))
