@@ -225,8 +225,15 @@ Coalescer::~Coalescer() {
     for (DispatchReq* r : queue_) {
         r->rc = -1;
         r->err = "dispatcher closed while the request was queued";
-        if (r->async) {   // stays its owner's: marked executed (with the error), never handed out by this handle any more
-            r->done.store(1, std::memory_order_release);
+        if (r->async) {   // handed back with the error through the queue it named; one that relied on this handle's own queue stays its
+            // owner's, marked executed (that queue goes away with the handle)
+            if (r->cq) {
+                CompletionQueue* q = r->cq;
+                q->push(r);
+                q->ring();
+            } else {
+                r->done.store(1, std::memory_order_release);
+            }
             continue;
         }
         touched |= 1ull << r->slot;
