@@ -2687,8 +2687,10 @@ int launch_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, i
     // One or two images: 256 queries per workgroup make 48-96 workgroups that each walk all the keys of their head (24 us for one
     // image, 12 K tiles of 2 us).  Fewer query tiles per wave and fewer waves per workgroup put 192 on the chip; a query row's
     // arithmetic (its 16-row tile against the keys in order) is the same in every tiling.
-    if (B * heads * qblocks < 128) {
-        const bool four = B * heads * ((tokens + 127) / 128) < 128;   // 4 waves x 16 queries, else 8 waves x 16
+    // (the text tower's 64-token sequences take the 64-query form at every batch: 256 query slots per workgroup leave three waves in four
+    // idle -- 16.91 -> 16.66 ms per 256 texts, same box, three runs each)
+    if (B * heads * qblocks < 128 || tokens <= 64) {
+        const bool four = tokens <= 64 || B * heads * ((tokens + 127) / 128) < 128;   // 4 waves x 16 queries, else 8 waves x 16
         const int qpw = four ? 64 : 128;
         const unsigned grid = (unsigned)(B * heads * ((tokens + qpw - 1) / qpw));
         if (four) {
