@@ -1374,6 +1374,7 @@ def main():
                     return ([rnd(g(h, "queries_per_s"), 1), rnd(g(h, "recall_at_10")), g(h, "value")] + ([] if g(h, "goal_reached") else ["tuning goal 0.96 not reached: best point"])) if h else None
                 gi[kind] = {"exact": pt("exact_scored"), "exact_ref_entry": pt("exact_scored_reference_entry_rule"), "adc": pt("adc_scored"),
                             "pq_rerank": pt("pq_rerank"), "pq_only_recall": rnd(g(row, "pq_only_recall_at_10")),
+                            "exact_other_beams": {b_: [rnd(v_[0], 1), rnd(v_[1])] for b_, v_ in (g(row, "exact_scored", "other_beam_widths_same_list") or {}).items() if b_ != "columns"} or None,
                             "rc": rnd(g(row, "hardness", "relative_contrast_at_10"), 3), "lid": rnd(g(row, "hardness", "lid_mle_k20"), 1),
                             "build_s": rnd(g(row, "build", "seconds"), 1)}
                 gc_ = g(row, "graph_callers", "points")

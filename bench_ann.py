@@ -390,6 +390,16 @@ def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budge
         return top, {"node_fetches_per_query": float(st["cmps"].mean())}
     out["exact_scored"] = dict(pick(run_exact, grid_L), entry=f"{n_entry} sampled rows, exact top-1 (timed)", beamwidth=4)
     L_exact = (out["exact_scored"]["held_out"] or {}).get("value")
+    # the same search list at other beam widths (the server's `beam_width` is the operator's, query_disk_index.rs:63,452; `evaluate` uses 3):
+    # held-out queries, one call each -- a narrower beam is more iterations of less work, which 4096 concurrent searches hide
+    if L_exact:
+        widths = {}
+        for bw in (1, 2, 8):
+            mse.disk_query_topk(s, None, None, g, qh16, K, None, None, None, True, bw, L_exact)
+            t0 = time.perf_counter()
+            top_b, _, _ = mse.disk_query_topk(s, None, None, g, qh16, K, None, None, None, True, bw, L_exact)
+            widths[str(bw)] = [nq_t / (time.perf_counter() - t0), recall_at(top_b, truth_h)]
+        out["exact_scored"]["other_beam_widths_same_list"] = dict(widths, columns="[queries/s, recall@10 held out]")
     # (2) the same with the reference's entry rule: closest shard centroid -> that shard's medioid
     cen, med_ids = shard_centroid_entries(rows, n)
     mse.set_entry_centroids(g, cen, med_ids)
