@@ -1390,6 +1390,7 @@ def main():
                         gi[kind]["callers"]["perf_test_100x1000"] = [rnd(pt_["queries_per_s"], 1), rnd(pt_["latency_ms"]["p50"], 3), rnd(pt_["latency_ms"]["p99"], 3)]
             if g1e8_line:
                 legs["graph_index_1e8"] = ({"qps_recall_L": [rnd(g1e8_line.get("value"), 1), rnd(g1e8_line.get("recall_at_10")), g1e8_line.get("search_list")],
+                                            "beam": g1e8_line.get("beamwidth"), "at_beam_4": [rnd(v_, 4) for v_ in (g(g1e8_line, "beam_width_tuning", "held_out_at_beam_4") or [])] or None,
                                             "build_s": rnd(g(g1e8_line, "build", "seconds"), 1)} if "value" in g1e8_line else
                                            {"skipped": g1e8_line.get("skipped") or g1e8_line.get("error")})
             legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; callers (T request threads) / tickets (ONE thread, W requests in flight): [queries/s, p50 ms, p99 ms, vs one call of 4096]")
