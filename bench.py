@@ -1374,6 +1374,9 @@ def main():
                     return ([rnd(g(h, "queries_per_s"), 1), rnd(g(h, "recall_at_10")), g(h, "value")] + ([] if g(h, "goal_reached") else ["tuning goal 0.96 not reached: best point"])) if h else None
                 gi[kind] = {"exact": pt("exact_scored"), "exact_ref_entry": pt("exact_scored_reference_entry_rule"), "adc": pt("adc_scored"),
                             "pq_rerank": pt("pq_rerank"), "pq_only_recall": rnd(g(row, "pq_only_recall_at_10")),
+                            "exact_best_beam": ([rnd(g(row, "exact_scored_best_beam", "queries_per_s"), 1), rnd(g(row, "exact_scored_best_beam", "recall_at_10")),
+                                                 g(row, "exact_scored_best_beam", "value"), g(row, "exact_scored_best_beam", "beamwidth")]
+                                                if g(row, "exact_scored_best_beam") else None),
                             "exact_other_beams": {b_: [rnd(v_[0], 1), rnd(v_[1])] for b_, v_ in (g(row, "exact_scored", "other_beam_widths_same_list") or {}).items() if b_ != "columns"} or None,
                             "rc": rnd(g(row, "hardness", "relative_contrast_at_10"), 3), "lid": rnd(g(row, "hardness", "lid_mle_k20"), 1),
                             "build_s": rnd(g(row, "build", "seconds"), 1)}
@@ -1393,7 +1396,7 @@ def main():
                                             "beam": g1e8_line.get("beamwidth"), "at_beam_4": [rnd(v_, 4) for v_ in (g(g1e8_line, "beam_width_tuning", "held_out_at_beam_4") or [])] or None,
                                             "build_s": rnd(g(g1e8_line, "build", "seconds"), 1)} if "value" in g1e8_line else
                                            {"skipped": g1e8_line.get("skipped") or g1e8_line.get("error")})
-            legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; callers (T request threads) / tickets (ONE thread, W requests in flight): [queries/s, p50 ms, p99 ms, vs one call of 4096]")
+            legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; exact_best_beam: [.., .., search list, beam]; callers (T request threads) / tickets (ONE thread, W requests in flight): [queries/s, p50 ms, p99 ms, vs one call of 4096]")
         if sharded_ann:
             legs["sharded_ann"] = {"pq_qps": rnd(g(sharded_ann, "pq_scan_rerank", "queries_per_s"), 1), "pq_equal_unsharded": g(sharded_ann, "pq_scan_rerank", "equals_the_unsharded_call_bit_for_bit"),
                                    "graph_qps": rnd(g(sharded_ann, "graph_index", "queries_per_s"), 1), "graph_equal_merge": g(sharded_ann, "graph_index", "equals_the_merge_of_per_shard_calls")}

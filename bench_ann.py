@@ -400,6 +400,20 @@ def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budge
             top_b, _, _ = mse.disk_query_topk(s, None, None, g, qh16, K, None, None, None, True, bw, L_exact)
             widths[str(bw)] = [nq_t / (time.perf_counter() - t0), recall_at(top_b, truth_h)]
         out["exact_scored"]["other_beam_widths_same_list"] = dict(widths, columns="[queries/s, recall@10 held out]")
+        # ... and the operating point with the beam width as a second knob: the fastest of 4 / 2 / 1 on the TUNING queries that meets the goal
+        tune_b, best_b = [], (4, None)
+        for bw in (4, 2, 1):
+            mse.disk_query_topk(s, None, None, g, qt16, K, None, None, None, True, bw, L_exact)
+            t0 = time.perf_counter()
+            top_b, _, _ = mse.disk_query_topk(s, None, None, g, qt16, K, None, None, None, True, bw, L_exact)
+            qps_b, rec_b = nq_t / (time.perf_counter() - t0), recall_at(top_b, truth_t)
+            tune_b.append([bw, round(qps_b, 1), round(rec_b, 4)])
+            if (rec_b >= 0.96 or bw == 4) and (best_b[1] is None or qps_b > best_b[1]):
+                best_b = (bw, qps_b)
+        ho = out["exact_scored"]["held_out"]
+        pt_b = [ho["queries_per_s"], ho["recall_at_10"]] if best_b[0] == 4 else widths[str(best_b[0])]
+        out["exact_scored_best_beam"] = {"beamwidth": best_b[0], "value": L_exact, "queries_per_s": pt_b[0], "recall_at_10": pt_b[1],
+                                         "tuning": tune_b, "columns": "[beam, queries/s, recall@10] on the tuning queries; the point itself on the held-out ones"}
     # (2) the same with the reference's entry rule: closest shard centroid -> that shard's medioid
     cen, med_ids = shard_centroid_entries(rows, n)
     mse.set_entry_centroids(g, cen, med_ids)
