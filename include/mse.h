@@ -160,7 +160,7 @@ int mse_debug_dispatcher_fail_shared(mse_dispatcher* d, uint32_t n_passes);
  * *mismatches = requests that got a wrong answer, a wrong status or no error text. */
 int mse_debug_coalescer_selftest(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, uint64_t stats_out[6],
                                  uint64_t* mismatches);
-/* the same through a coalescer with `workers` worker threads (the graph's request path runs two, csrc/dispatch.h) */
+/* the same through a coalescer with `workers` worker threads (the graph's request path runs three, csrc/dispatch.h) */
 int mse_debug_coalescer_selftest_workers(int threads, int rounds, uint32_t max_queries, uint32_t max_wait_us, int workers,
                                          uint64_t stats_out[6], uint64_t* mismatches);
 /* the asynchronous side of the same queue (submit_async / completions), no device needed: async_threads threads keep `window` records
