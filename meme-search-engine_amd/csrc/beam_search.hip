@@ -47,6 +47,9 @@ struct BeamArgs {
     uint32_t* cmps; uint32_t* pq_cmps; uint32_t* err;
     int hash_slots;   // LDS table of a beam iteration's neighbour ids: power of two >= 2 x p_cap
     int fill_vis;   // fused request path: slots of the visited arrays past n_visited are set to (ID_NONE, INT64_MIN) for the device top-k
+    // small-batch entry step (entry_top1_rows_kernel): the per-chunk bests [chunk][query] are reduced HERE, by the search's first wave,
+    // instead of by a launch of their own (a dependent launch costs ~35 us in a pass of ~280); null = start nodes in `starts`
+    const long long* entry_psc; const uint32_t* entry_prow; const uint32_t* entry_ids; int entry_chunks, entry_nq;
 };
 
 // THREADS = 256: four waves per query (wave 0 walks the list, all four score and merge) -- needed when the 64 KiB distance table of
@@ -93,8 +96,24 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     for (int e = tid; e < a.d / 8; e += BS_THREADS)
         reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(a.queries + qi * a.d)[e];
     if (tid < BS_DESC_MAX) s_scales[tid] = (use_bias && tid < a.n_desc) ? a.scales[qi * a.n_desc + tid] : 0.0f;
+    uint32_t start_by_entry = 0;
+    if (a.entry_psc && wave == 0) {   // the best chunk of the entry step: larger score, lower row on ties
+        long long eb = (long long)INT64_MIN;
+        uint32_t er = 0xffffffffu;
+        for (int c = lane; c < a.entry_chunks; c += 64) {
+            const long long sc = a.entry_psc[(size_t)c * a.entry_nq + qi];
+            const uint32_t rw = a.entry_prow[(size_t)c * a.entry_nq + qi];
+            if (rw != 0xffffffffu && (er == 0xffffffffu || sc > eb || (sc == eb && rw < er))) { eb = sc; er = rw; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long sc = __shfl_xor(eb, o);
+            const uint32_t rw = __shfl_xor(er, o);
+            if (rw != 0xffffffffu && (er == 0xffffffffu || sc > eb || (sc == eb && rw < er))) { eb = sc; er = rw; }
+        }
+        start_by_entry = a.entry_ids[er == 0xffffffffu ? 0 : er];
+    }
     if (tid == 0) {
-        const uint32_t start = a.starts[qi];
+        const uint32_t start = a.entry_psc ? start_by_entry : a.starts[qi];
         nb_id[0] = start; nb_sc[0] = 0; nb_vis[0] = 0;   // :153 -- the entry point enters with score 0
         s_len = 1; s_next = 0; s_abort = 0;
         (void)visited_insert(bm_adj, a.hash_bits, start);   // :154
@@ -444,8 +463,8 @@ __global__ void entry_starts_kernel(const uint32_t* __restrict__ best_row, const
 // the margins) is the right tool for thousands of queries; for the few dozen queries of a coalesced submission its fixed cost was
 // most of the call.  A workgroup takes 8 queries (their f16 copies in LDS) and a range of rows; a lane quad owns a row at a time,
 // loads it ONCE and runs the reference's fast_dot chain (exact_dot.h: accumulator `part`, t ascending, the fixed reduction tree)
-// against all 8 queries; per-quad best (score, row) -> per-workgroup best -> partial[chunk][query]; entry_reduce_kernel picks the
-// best chunk.  Same answer as the searcher's exact top-1: i64 scores in the reference's order, ties by the lower row.
+// against all 8 queries; per-quad best (score, row) -> per-workgroup best -> partial[chunk][query]; the search kernel's first wave picks
+// the best chunk (BeamArgs::entry_psc: a launch of its own for that cost ~35 us of a ~280 us pass).  Same answer as the searcher's exact top-1: i64 scores in the reference's order, ties by the lower row.
 constexpr int ET_Q = 8, ET_THREADS = 256;
 __global__ __launch_bounds__(ET_THREADS) void entry_top1_rows_kernel(const uint16_t* __restrict__ rows, int n_rows, int d, const uint16_t* __restrict__ queries,
                                                                      int nq, int rows_per_wg, long long* __restrict__ part_sc, uint32_t* __restrict__ part_row) {
@@ -517,25 +536,6 @@ __global__ __launch_bounds__(ET_THREADS) void entry_top1_rows_kernel(const uint1
         }
     }
 }
-// one wave per query: lanes over the chunks, then the best of the wave
-__global__ __launch_bounds__(64) void entry_reduce_kernel(const long long* __restrict__ part_sc, const uint32_t* __restrict__ part_row, int n_chunks, int nq,
-                                                          const uint32_t* __restrict__ entry_ids, uint32_t* __restrict__ starts) {
-    const int q = blockIdx.x, lane = threadIdx.x;
-    long long b = (long long)INT64_MIN;
-    uint32_t br = 0xffffffffu;
-    for (int c = lane; c < n_chunks; c += 64) {
-        const long long sc = part_sc[(size_t)c * nq + q];
-        const uint32_t rw = part_row[(size_t)c * nq + q];
-        if (rw != 0xffffffffu && (br == 0xffffffffu || sc > b || (sc == b && rw < br))) { b = sc; br = rw; }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long sc = __shfl_xor(b, o);
-        const uint32_t rw = __shfl_xor(br, o);
-        if (rw != 0xffffffffu && (br == 0xffffffffu || sc > b || (sc == b && rw < br))) { b = sc; br = rw; }
-    }
-    if (lane == 0) starts[q] = entry_ids[br == 0xffffffffu ? 0 : br];
-}
-
 // The reference's own entry rule (src/query_disk_index.rs:254-256,447-450): the shard whose centroid has the largest
 // scale_dot_result_f64(dot(centroid, query)) -- f32 operands, the sum carried in f64 in index order (the oracle's stated order for
 // simsimd's f32 dot) -- `position_max_by_key` keeping the LAST maximum; the search starts at that shard's medioid.  One workgroup
@@ -749,6 +749,9 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         if (!disable_pq) MSE_HIP_TRY(hipMemcpyAsync(dl.p, luts, nq * 65536, hipMemcpyHostToDevice, st));
     }
     if (bias) MSE_HIP_TRY(hipMemcpyAsync(dsc.p, scales, nq * c->n_desc * 4, hipMemcpyHostToDevice, st));
+    const long long* entry_psc = nullptr;   // small-batch entry step: per-chunk bests, reduced by the search kernel itself
+    const uint32_t* entry_prow = nullptr;
+    int entry_chunks = 0;
     if (fz && fz->entries) {
         // the entry step of the request path (src/query_disk_index.rs:254-256,447-450: the medioid of the shard whose centroid is
         // closest to the query) on the device: exact top-1 of the f16 queries over the entry rows, on this search's stream
@@ -759,7 +762,7 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
                                queries_f32 ? qf.as<float>() : nullptr, dq.as<uint16_t>(), eg->entry_ids, dst.as<uint32_t>());
             MSE_HIP_TRY(hipGetLastError());
         } else if (nq * eg->n_entries <= ((size_t)1 << 22) && eg->n_entries <= ((size_t)1 << 20)) {
-            // a small batch: exact top-1 over the entry rows in two launches (entry_top1_rows_kernel)
+            // a small batch: exact top-1 over the entry rows in ONE launch (entry_top1_rows_kernel) + the search kernel's prologue
             const size_t E = eg->n_entries, n_qt = (nq + ET_Q - 1) / ET_Q;
             size_t rows_per_wg = (E + std::max<size_t>(1, 512 / n_qt) - 1) / std::max<size_t>(1, 512 / n_qt);
             rows_per_wg = std::max<size_t>(64, (rows_per_wg + 63) / 64 * 64);
@@ -772,9 +775,8 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
             hipLaunchKernelGGL(entry_top1_rows_kernel, dim3((unsigned)n_chunks, (unsigned)n_qt), dim3(ET_THREADS), ET_Q * d * 2, st, eg->entry_rows, (int)E,
                                (int)d, dq.as<uint16_t>(), (int)nq, (int)rows_per_wg, psc, prow);
             MSE_HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(entry_reduce_kernel, dim3((unsigned)nq), dim3(64), 0, st, psc, prow, (int)n_chunks, (int)nq, eg->entry_ids,
-                               dst.as<uint32_t>());
-            MSE_HIP_TRY(hipGetLastError());
+            // (the best chunk per query is picked by the search kernel's first wave: no launch of its own)
+            entry_psc = psc; entry_prow = prow; entry_chunks = (int)n_chunks;
         } else {
             int64_t* e_sc = fzb.as<int64_t>();
             uint32_t* e_row = reinterpret_cast<uint32_t*>(fzb.as<char>() + nq * 8);
@@ -803,6 +805,8 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     a.n_visited = cnt_dev; a.cmps = cnt_dev + nq; a.pq_cmps = cnt_dev + 2 * nq;
     a.err = cnt_dev + 3 * nq;
     a.fill_vis = fz ? 1 : 0;
+    a.entry_psc = entry_psc; a.entry_prow = entry_prow; a.entry_chunks = entry_chunks; a.entry_nq = (int)nq;
+    a.entry_ids = entry_psc ? fz->entries->entry_ids : nullptr;
     size_t hash_slots = 64;
     while (hash_slots < 2 * p_cap) hash_slots *= 2;
     a.hash_slots = (int)hash_slots;
