@@ -192,7 +192,8 @@ def cpu_baseline(n_rows, k, min_seconds=5.0):
     scale = big_rows / n_rows
     return {
         "value": big["fair"]["queries_per_s"] * scale,
-        "unit": f"queries/s over {n_rows} rows = the fair rate MEASURED at {big_rows} DRAM-resident rows x {scale:g} (linear in rows; labelled scaling, see cpu_baseline_measured for the unscaled figures)",
+        "unit": f"queries/s over {n_rows:.0e} rows (fair rate measured at {big_rows:.0e} DRAM rows x {scale:g})",
+        "unit_note": "the scan is linear in rows and both sizes stream from DRAM; `measured` holds the unscaled figures",
         "cores": cores,
         "cores_visible": visible,
         "cpu_time_quota_cores": quota,
@@ -200,9 +201,9 @@ def cpu_baseline(n_rows, k, min_seconds=5.0):
                       "oversubscribing by 2 measured best (8 / 32 / 64 / 256 threads -> 77 / 100 / 58 / 20 queries/s on a 1e6-row sample, round 3)",
         "kind": "port",
         "cpu_model": model,
-        "sample": f"measured, >= {min_seconds:g} s per mode: N=1e5 (1000 distinct queries; fair, reference_faithful, index_search) and "
-                  f"N={big_rows} in DRAM (fair: {big['fair']['queries']} queries on {cores} threads in {big['fair']['seconds']:.1f} s; "
-                  f"reference_faithful: {big['reference_faithful']['queries']} in {big['reference_faithful']['seconds']:.1f} s)",
+        "sample": f">= {min_seconds:g} s per mode; N={big_rows:.0e} in DRAM: fair {big['fair']['queries']} queries on {cores} threads in "
+                  f"{big['fair']['seconds']:.1f} s, reference-faithful {big['reference_faithful']['queries']} in {big['reference_faithful']['seconds']:.1f} s; "
+                  f"N=1e5: 1000 distinct queries, 3 modes",
         "scan_GBps": big["fair"]["scan_GBps"],
         "measured": measured,
         "reference_faithful": {"value": big["reference_faithful"]["queries_per_s"] * scale, "unit": f"queries/s over {n_rows} rows, measured at {big_rows} rows x {scale:g}",
@@ -854,6 +855,58 @@ def server_bench(eng, cfg, engine_batch):
                     "(clip_server.py:131-146), which the device decode replaces"}
 
 
+def emit(full, detail_path):
+    """The FULL result object goes to `detail_path` (and nowhere near stdout); stdout gets ONE compact line (bench_line.py: contract
+    scalars, config, roofline with flat per-leg scalars, cpu_baseline; <= 4 KB) -- what the driver's record parses."""
+    import bench_line
+    full["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(full, f, indent=1)
+                f.write("\n")
+            out_dir = os.path.join(ROOT, "gpurun_out")       # on a gpurun box this directory travels back
+            if os.path.isdir(out_dir) and os.path.dirname(os.path.abspath(detail_path)) != out_dir:
+                with open(os.path.join(out_dir, os.path.basename(detail_path)), "w") as f:
+                    json.dump(full, f, indent=1)
+        except OSError as e:
+            print(f"[bench] could not write {detail_path}: {e}", file=sys.stderr)
+            full["detail_file"] = None
+    sys.stdout.flush()
+    print(json.dumps(bench_line.compact_line(full)), flush=True)
+
+
+def dry_run(args):
+    """`--dry-run`: no device, no library.  Parses the launch environment as a real run would (torchrun's WORLD_SIZE / RANK against
+    --gpus, the in-process shape, --logical-shards) and prints a compact line of nulls, so that the command line the driver will use for
+    N = 1, 2, 4, 8 can be checked on a CPU-only box (tests/test_abi_and_host.py)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    in_process = world == 1 and args.gpus > 1
+    n_gpus = args.gpus if in_process else world
+    if world > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--gpus >= 1, --steps >= 1, --warmup >= 0")
+    n_total = int(args.rows)
+    nq = args.queries if args.queries > 0 else 320
+    if rank != 0:
+        return
+    shape = "one process, a host thread per shard" if in_process else "one process per GPU (torchrun)" if world > 1 else "one GPU"
+    full = {"metric": "queries/sec over 1e8x1152 index @ recall@10>=0.95 (exact brute force: recall 1.0)", "value": None, "unit": "queries/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16 in, f32 accumulate, i64 fixed-point scores", "data": "dry-run (no device, nothing measured)",
+            "config": {"workload": f"brute-force top-{args.k} over {n_total} x {D} fp16 rows, {nq} queries/step, row-sharded over {n_gpus} GPU(s)",
+                       "rows_total": n_total, "rows_per_gpu": (n_total + n_gpus - 1) // n_gpus, "queries_per_step": nq, "k": args.k,
+                       "parallelism": f"row-shard x{n_gpus}",
+                       "exchange": {"kind": shape + ("; ONE ncclAllGather of the packed 12 B/record blocks per step" if n_gpus > 1 else ""),
+                                    "rccl_ranks": 0} if n_gpus > 1 else None},
+            "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel<2,20>", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+            "sharded_ann": ({"skipped": "dry run"} if n_gpus > 1 and not args.no_sharded_ann else None), "dry_run": True}
+    emit(full, None)
+
+
 def rccl_probe_code(n_gpus):
     """Child-process probe of the in-process RCCL exchange: tiny shards on devices 0..n-1, bring-up, one search through the all-gather."""
     return ("import sys; sys.path.insert(0, %r); import torch, numpy as np, mse\n"
@@ -883,6 +936,7 @@ def main():
     ap.add_argument("--no-callers", action="store_true", help="skip the concurrent-callers leg (T threads x 1 query through the coalescer)")
     ap.add_argument("--pq-rows", type=float, default=1e8)
     ap.add_argument("--no-graph", action="store_true", help="skip the GPU-resident beam-search leg")
+    ap.add_argument("--no-request-path", action="store_true", help="skip the whole-request leg (text in -> top-k out on the device; inside the hard-set graph leg)")
     ap.add_argument("--graph-rows", type=float, default=2e5)
     ap.add_argument("--no-graph-scale", action="store_true", help="skip the 1e7-row graph-index leg (a ~1 minute build)")
     ap.add_argument("--no-ann-scale", action="store_true", help="skip the 1e8-row PQ scan + re-rank leg (recall at the metric's size)")
@@ -893,16 +947,28 @@ def main():
     ap.add_argument("--graph-entries", type=int, default=-1,
                     help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
     ap.add_argument("--graph-kinds", default="easy,hard,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")
-    ap.add_argument("--no-graph-1e8", action="store_true", help="skip the 1e8-row graph-index leg (a ~10 minute one-pass build, guarded by a time budget)")
+    ap.add_argument("--graph-1e8", action="store_true",
+                    help="OPT-IN: the 1e8-row graph-index leg (a 10-13 minute build, guarded by --graph-1e8-budget); not part of the default command")
+    ap.add_argument("--no-graph-1e8", action="store_true", help="accepted for older command lines; the leg is opt-in now (--graph-1e8)")
     ap.add_argument("--graph-1e8-budget", type=float, default=1100.0,
                     help="seconds the predicted 1e8-row build may take (two passes if both fit, else one; beyond it the leg is skipped with that reason); "
                          "never more than what is left of --time-budget")
-    ap.add_argument("--time-budget", type=float, default=1500.0, help="seconds the whole command aims to stay within: the 1e8-row graph leg shrinks or skips itself to fit")
+    ap.add_argument("--time-budget", type=float, default=540.0,
+                    help="seconds the whole command aims to stay within: a side leg that would not fit what is left is skipped with that reason "
+                         "(--graph-1e8 raises it to 1500 unless given)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the FULL result object goes (every leg's detail); stdout carries only the compact line (bench_line.py, <= 4 KB)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device: parse the arguments and the launch environment as a real run would, print a compact line of nulls (data = 'dry-run')")
     ap.add_argument("--no-sharded-ann", action="store_true", help="--gpus N > 1: skip the sharded PQ-scan / graph-index legs")
     ap.add_argument("--ann-rows-per-gpu", type=float, default=2e6, help="--gpus N > 1: rows per GPU of the sharded approximate-search legs")
     ap.add_argument("--siglip-batch", type=int, default=256)
     ap.add_argument("--siglip-steps", type=int, default=10)
     args = ap.parse_args()
+    if args.graph_1e8 and not any(a.startswith("--time-budget") for a in sys.argv[1:]):
+        args.time_budget = 1500.0
+    if args.dry_run:
+        return dry_run(args)
 
     import numpy as np
     import torch
@@ -1208,52 +1274,50 @@ def main():
             sharded_ann = {"error": repr(e)}
         ffi.check(ffi.lib().mse_set_device(local_rank), "mse_set_device")
 
-    callers_line = None
-    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_callers:
-        try:
-            callers_line = concurrent_callers_bench(vecs, k, nq * args.steps / elapsed)
-        except Exception as e:  # noqa: BLE001
-            callers_line = {"error": repr(e)}
+    # ---- side legs: each under the command's time budget (a leg that would not fit what is left is skipped and says so), a failure
+    # is reported in the leg's object, never fatal; seconds per leg go to the detail file ----
+    leg_seconds = {}
+    reserve = 0.0 if (args.no_cpu_baseline or n_gpus > 1) else 45.0      # the CPU baseline still comes after the legs
 
-    index_line = None
-    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_callers:
+    def run_leg(name, expect_s, fn, cond=True):
+        if not cond:
+            return None
+        left = float(args.time_budget) - (time.perf_counter() - T_START) - reserve
+        if expect_s > left:
+            print(f"[bench] leg {name} skipped: {left:.0f} s left of the time budget, needs about {expect_s:.0f}", file=sys.stderr)
+            return {"skipped": f"time budget: {left:.0f} s left of {float(args.time_budget):.0f}, the leg needs about {expect_s:.0f} s"}
+        t_leg = time.perf_counter()
         try:
-            index_line = index_callers_bench(k)
+            r = fn()
         except Exception as e:  # noqa: BLE001
-            index_line = {"error": repr(e)}
-    shard_line = None
-    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_shard_point:
-        try:
-            shard_line = shard_point_bench(k, nq, elapsed / args.steps * 1e3)
-        except Exception as e:  # noqa: BLE001
-            shard_line = {"error": repr(e)}
+            r = {"error": repr(e)}
+        leg_seconds[name] = round(time.perf_counter() - t_leg, 1)
+        print(f"[bench] leg {name}: {leg_seconds[name]} s (t = {time.perf_counter() - T_START:.0f} s)", file=sys.stderr)
+        return r
+
+    leg_seconds["setup_and_headline"] = round(time.perf_counter() - T_START, 1)
+    one = rank == 0 and n_gpus == 1 and world == 1
+    callers_line = run_leg("concurrent_callers", 15, lambda: concurrent_callers_bench(vecs, k, nq * args.steps / elapsed), one and not args.no_callers)
+    index_line = run_leg("index_callers_1e5", 10, lambda: index_callers_bench(k), one and not args.no_callers)
+    shard_line = run_leg("shard_point", 10, lambda: shard_point_bench(k, nq, elapsed / args.steps * 1e3), one and not args.no_shard_point)
 
     # ---- second half of BASELINE.json's metric: SigLIP image embeds/s/GPU (replicas, no collective) ----
     siglip_line = None
     if not args.no_siglip:
-        siglip_line = siglip_bench(args, world, rank, dist)
-    pq_line = graph_line = None
-    if rank == 0 and n_gpus == 1 and not args.no_pq:      # single-process side legs: a failure is reported, not fatal
-        try:
-            pq_line = pq_bench(args)
-        except Exception as e:  # noqa: BLE001
-            pq_line = {"error": repr(e)}
-    if rank == 0 and n_gpus == 1 and not args.no_graph:
-        try:
-            graph_line = graph_bench(args)
-        except Exception as e:  # noqa: BLE001
-            graph_line = {"error": repr(e)}
+        if world > 1:
+            siglip_line = siglip_bench(args, world, rank, dist)       # every rank takes part (a barrier inside): no per-rank skipping
+        else:
+            siglip_line = run_leg("siglip", 45, lambda: siglip_bench(args, world, rank, dist))
+    pq_line = run_leg("pq_scan", 25, lambda: pq_bench(args), rank == 0 and n_gpus == 1 and not args.no_pq)
+    graph_line = run_leg("graph_search", 15, lambda: graph_bench(args), rank == 0 and n_gpus == 1 and not args.no_graph)
 
-    gscale_line = ann_line = g1e8_line = None
+    gscale_line = ann_line = g1e8_line = request_line = None
     if rank == 0 and n_gpus == 1 and not (args.no_graph_scale and args.no_ann_scale):
         del searcher, vecs                             # the 230 GB index makes room for the clustered sets of the next two legs
         import gc
         gc.collect()
-    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_ann_scale:
-        try:
-            ann_line = ann_scale_bench(args)
-        except Exception as e:  # noqa: BLE001
-            ann_line = {"error": repr(e)}
+    if one and not args.no_ann_scale:
+        ann_line = run_leg("ann_1e8", 30, lambda: ann_scale_bench(args))
         import gc
         gc.collect()
         torch.cuda.empty_cache()
@@ -1263,19 +1327,24 @@ def main():
         import gc
         import bench_ann
         gscale_line = {"metric": f"queries/sec over a {int(args.graph_scale_rows):.0e}x1152 graph index @ recall@10>=0.95 (GPU-resident beam search)", "unit": "queries/s", "sets": {}}
+        expect = {"hard": 110.0, "easy": 75.0, "ood": 110.0}
+        scale_rows = float(args.graph_scale_rows) / 1e7
         for kind in [x for x in args.graph_kinds.split(",") if x]:
-            try:
-                gscale_line["sets"][kind] = bench_ann.graph_index_bench(ROOT, kind, int(args.graph_scale_rows), batch=int(args.graph_batch),
-                                                                        passes=int(args.graph_passes), callers=(kind in ("easy", "hard") and not args.no_callers))
-            except Exception as e:  # noqa: BLE001
-                gscale_line["sets"][kind] = {"error": repr(e)}
+            gscale_line["sets"][kind] = run_leg(
+                "graph_index_" + kind, expect.get(kind, 100.0) * scale_rows,
+                lambda: bench_ann.graph_index_bench(ROOT, kind, int(args.graph_scale_rows), batch=int(args.graph_batch), passes=int(args.graph_passes),
+                                                    callers=(kind in ("easy", "hard") and not args.no_callers),
+                                                    request_path=(kind == "hard" and not args.no_siglip and not args.no_request_path)))
             gc.collect()
             torch.cuda.empty_cache()
-        if not args.no_graph_1e8 and world == 1:
+        request_line = (gscale_line["sets"].get("hard") or {}).pop("request_path", None) if isinstance(gscale_line["sets"].get("hard"), dict) else None
+        if args.graph_1e8 and world == 1:
             rate = ((gscale_line["sets"].get("easy") or {}).get("build") or {}).get("points_per_s")
             try:
                 left = float(args.time_budget) - (time.perf_counter() - T_START) - 90.0     # the CPU baseline and the tail of the line still come
+                t_leg = time.perf_counter()
                 g1e8_line = bench_ann.graph_index_1e8(ROOT, rate, min(float(args.graph_1e8_budget), left))
+                leg_seconds["graph_index_1e8"] = round(time.perf_counter() - t_leg, 1)
             except Exception as e:  # noqa: BLE001
                 g1e8_line = {"error": repr(e)}
             gc.collect()
@@ -1345,62 +1414,6 @@ def main():
             "hbm_bound_point": alt,
             "certificate": stats,
         }
-        # every headline scalar of the side legs once more, compact, INSIDE the roofline object (the part of the line the driver's record
-        # keeps whole): [queries/s, recall@10, search list or r] for the approximate paths
-        def g(o, *path):
-            for p_ in path:
-                o = o.get(p_) if isinstance(o, dict) else None
-            return o
-
-        def rnd(v, nd=4):
-            return round(v, nd) if isinstance(v, float) else v
-        legs = {"hbm_bound_point": {"queries_per_pass": 128, "frac": rnd(g(alt, "roofline", "frac")), "queries_per_s": rnd(g(alt, "value"), 1)},
-                "concurrent_callers_1e8": {"threads": g(callers_line, "threads"), "queries_per_s": rnd(g(callers_line, "queries_per_s"), 1),
-                                           "vs_headline": rnd(g(callers_line, "vs_resident_batch_headline"))},
-                "shard_point": {"ms_per_step": rnd(g(shard_line, "ms_per_step")), "frac": rnd(g(shard_line, "roofline", "frac")),
-                                "projected_8gpu_efficiency": rnd(g(shard_line, "projected_8gpu", "efficiency_vs_one_gpu_1e8"))},
-                "siglip": {"img_per_s": rnd(g(siglip_line, "value"), 1), "frac": rnd(g(siglip_line, "roofline", "frac")),
-                           "text_per_s": rnd(g(siglip_line, "text_tower", "value"), 1), "text_frac": rnd(g(siglip_line, "text_tower", "roofline", "frac")),
-                           "server_img_per_s": rnd(g(siglip_line, "server_images_per_s"), 1), "latency_ms": g(siglip_line, "latency_ms")},
-                "pq_scan_1e8": {"kernel_frac_sustained": rnd(g(pq_line, "roofline", "frac")), "kernel_frac_burst": rnd(g(pq_line, "roofline", "burst", "frac")),
-                                "end_to_end_frac": rnd(g(pq_line, "roofline", "end_to_end", "frac")), "queries_per_s": rnd(g(pq_line, "queries_per_s_batched"), 1)},
-                "ann_1e8": [rnd(g(ann_line, "queries_per_s"), 1), rnd(g(ann_line, "recall_at_10")), g(ann_line, "r")],
-                "index_callers_1e5_qps": rnd(g(index_line, "queries_per_s"), 1)}
-        if gscale_line:
-            gi = {}
-            for kind, row in (gscale_line.get("sets") or {}).items():
-                def pt(key):
-                    h = g(row, key, "held_out")
-                    return ([rnd(g(h, "queries_per_s"), 1), rnd(g(h, "recall_at_10")), g(h, "value")] + ([] if g(h, "goal_reached") else ["tuning goal 0.96 not reached: best point"])) if h else None
-                gi[kind] = {"exact": pt("exact_scored"), "exact_ref_entry": pt("exact_scored_reference_entry_rule"), "adc": pt("adc_scored"),
-                            "pq_rerank": pt("pq_rerank"), "pq_only_recall": rnd(g(row, "pq_only_recall_at_10")),
-                            "exact_best_beam": ([rnd(g(row, "exact_scored_best_beam", "queries_per_s"), 1), rnd(g(row, "exact_scored_best_beam", "recall_at_10")),
-                                                 g(row, "exact_scored_best_beam", "value"), g(row, "exact_scored_best_beam", "beamwidth")]
-                                                if g(row, "exact_scored_best_beam") else None),
-                            "exact_other_beams": {b_: [rnd(v_[0], 1), rnd(v_[1])] for b_, v_ in (g(row, "exact_scored", "other_beam_widths_same_list") or {}).items() if b_ != "columns"} or None,
-                            "rc": rnd(g(row, "hardness", "relative_contrast_at_10"), 3), "lid": rnd(g(row, "hardness", "lid_mle_k20"), 1),
-                            "build_s": rnd(g(row, "build", "seconds"), 1)}
-                gc_ = g(row, "graph_callers", "points")
-                if gc_:
-                    gi[kind]["callers"] = {str(p_["threads"]): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
-                                                                rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in gc_}
-                    tk_ = g(row, "graph_callers", "tickets", "points")
-                    if tk_:
-                        gi[kind]["tickets"] = {str(p_["in_flight"]) + ("" if p_.get("host_threads", 1) == 1 else "x%dthreads" % p_["host_threads"]) + ("" if p_.get("query_copied_at_submit", True) else "_nocopy"): [rnd(p_["queries_per_s"], 1), rnd(p_["latency_ms"]["p50"], 3), rnd(p_["latency_ms"]["p99"], 3),
-                                                                      rnd(p_.get("vs_one_call_of_4096"), 3)] for p_ in tk_}
-                    pt_ = g(row, "graph_callers", "perf_test_py_shape")
-                    if pt_:
-                        gi[kind]["callers"]["perf_test_100x1000"] = [rnd(pt_["queries_per_s"], 1), rnd(pt_["latency_ms"]["p50"], 3), rnd(pt_["latency_ms"]["p99"], 3)]
-            if g1e8_line:
-                legs["graph_index_1e8"] = ({"qps_recall_L": [rnd(g1e8_line.get("value"), 1), rnd(g1e8_line.get("recall_at_10")), g1e8_line.get("search_list")],
-                                            "beam": g1e8_line.get("beamwidth"), "at_beam_4": [rnd(v_, 4) for v_ in (g(g1e8_line, "beam_width_tuning", "held_out_at_beam_4") or [])] or None,
-                                            "build_s": rnd(g(g1e8_line, "build", "seconds"), 1)} if "value" in g1e8_line else
-                                           {"skipped": g1e8_line.get("skipped") or g1e8_line.get("error")})
-            legs["graph_index_1e7"] = dict(gi, columns="[queries/s, recall@10 held out, search list (r for pq_rerank)]; exact_best_beam: [.., .., search list, beam]; callers (T request threads) / tickets (ONE thread, W requests in flight): [queries/s, p50 ms, p99 ms, vs one call of 4096]")
-        if sharded_ann:
-            legs["sharded_ann"] = {"pq_qps": rnd(g(sharded_ann, "pq_scan_rerank", "queries_per_s"), 1), "pq_equal_unsharded": g(sharded_ann, "pq_scan_rerank", "equals_the_unsharded_call_bit_for_bit"),
-                                   "graph_qps": rnd(g(sharded_ann, "graph_index", "queries_per_s"), 1), "graph_equal_merge": g(sharded_ann, "graph_index", "equals_the_merge_of_per_shard_calls")}
-        line["roofline"]["legs"] = legs
         if callers_line:
             line["concurrent_callers"] = callers_line
         if index_line:
@@ -1417,6 +1430,8 @@ def main():
             line["ann_1e8"] = ann_line
         if gscale_line:
             line["graph_index_1e7"] = gscale_line
+        if request_line:
+            line["request_path"] = request_line
         if g1e8_line:
             line["graph_index_1e8"] = g1e8_line
         if sharded_ann:
@@ -1424,18 +1439,14 @@ def main():
         if note:
             line["note"] = note
         if n_gpus == 1 and not args.no_cpu_baseline:
+            t_leg = time.perf_counter()
             line["cpu_baseline"] = cpu_baseline(n_total, k)
-            if graph_line:
+            if graph_line and "error" not in graph_line and "skipped" not in graph_line:
                 line["cpu_baseline"]["graph_build"] = cpu_graph_build(int(args.graph_rows))
-            # the unscaled measurements are detail: they travel in a key of their own, ahead of the summary
-            line["cpu_baseline_measured"] = line["cpu_baseline"].pop("measured", None)
-        # Key order: a record that keeps only the END of this (long) line must still hold the headline -- the side legs' detail objects
-        # come first, then the contract's scalars, config, roofline (with every leg's headline scalars in roofline.legs) and cpu_baseline.
-        tail_keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                     "data", "config", "verified_vs_exact_kernel", "roofline", "cpu_baseline"]
-        ordered = {k_: v_ for k_, v_ in line.items() if k_ not in tail_keys}
-        ordered.update({k_: line[k_] for k_ in tail_keys if k_ in line})
-        print(json.dumps(ordered), flush=True)
+            leg_seconds["cpu_baseline"] = round(time.perf_counter() - t_leg, 1)
+        leg_seconds["total"] = round(time.perf_counter() - T_START, 1)
+        line["leg_seconds"] = leg_seconds
+        emit(line, args.detail)
     if group is not None:
         group.close()
     if comm is not None:

@@ -300,7 +300,7 @@ def shard_centroid_entries(rows, n_base, n_shards=64, sample=200_000, seed=7):
     return c.cpu().numpy().astype(np.float32), idx[med].cpu().numpy().astype(np.uint32)
 
 
-def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budget_s=None):
+def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budget_s=None, request_path=False):
     """One row of the graph-index table: a Vamana graph (generate-index-shard's defaults R 64, L 192, C 750; one pass) over n synthetic
     rows of `kind` (easy / hard / ood, see the module docstring), searched through the request path in one call
     (mse_disk_query_topk): operating points picked on 4096 TUNING queries (smallest search list with recall@10 >= 0.96 there) and

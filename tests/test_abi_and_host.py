@@ -198,6 +198,76 @@ def test_bench_launch_shapes_are_checked_before_any_device_work():
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
 
 
+def test_bench_line_stays_small_whatever_the_legs_return():
+    """The driver parses the LAST stdout line of bench.py into its record: round 5's 40 KB line came back unparsed.  The printed line is
+    bench_line.compact_line(full) -- contract scalars, config, roofline with FLAT per-leg scalars, cpu_baseline -- and stays under 4 KB
+    for round 5's full result (a committed file), for a result whose every string is huge and for one with no legs at all."""
+    import json
+    import bench_line
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    line = bench_line.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 4096
+    assert json.loads(text) == line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert key in line, key
+    assert line["config"]["workload"].startswith("brute-force top-10 over 100000000 x 1152") and line["config"]["queries_per_step"] == 320
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] > 2.3e11
+    assert all(not isinstance(v, (dict, list)) for v in roof["legs"].values())          # flat scalars only
+    assert roof["legs"]["siglip_img_s"] > 1000 and roof["legs"]["graph_hard_recall"] > 0.95 and roof["legs"]["pq_frac"] > 0.5
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and line["cpu_baseline"]["kind"] == "port"
+    # a hostile full result: long strings everywhere, a hundred synthetic sets
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "w" * 5000
+    fat["config"]["exchange"] = {"kind": "k" * 5000, "rccl_ranks": 8, "rccl_unavailable": "u" * 5000}
+    fat["note"] = "n" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    fat["roofline"]["kernel"] = "r" * 5000
+    fat["graph_index_1e7"]["sets"] = {f"set{i:03d}": fat["graph_index_1e7"]["sets"]["hard"] for i in range(100)}
+    text = json.dumps(bench_line.compact_line(fat))
+    assert len(text) <= 4096 and json.loads(text)["value"] == line["value"] and "cpu_baseline" in json.loads(text)
+    # nothing but the contract
+    bare = bench_line.compact_line({"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0})
+    assert bare["roofline"]["legs"] == {} and bare["value"] == 1.0
+    # legs that failed or were skipped carry no scalars and do not break the line
+    broken = dict(full, siglip={"error": "x"}, pq_scan={"skipped": "time budget"}, graph_index_1e7={"sets": {"hard": {"error": "y"}, "easy": None}})
+    legs = bench_line.compact_line(broken)["roofline"]["legs"]
+    assert "siglip_img_s" not in legs and "pq_frac" not in legs and "graph_hard_qps" not in legs and "hbm128_frac" in legs
+
+
+def test_bench_dry_run_prints_the_small_line_for_every_launch_shape():
+    """`bench.py --dry-run` needs no device: it checks the launch shape exactly as a real run does and prints the compact line, so the
+    commands the driver uses for 1 / 2 / 4 / 8 GPUs (bare and under torchrun) cannot die on a flag."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for n in (1, 2, 4, 8):
+        for launch in ("bare", "torchrun"):
+            e = dict(env, WORLD_SIZE=str(n), RANK="0", LOCAL_RANK="0") if launch == "torchrun" else env
+            extra = ["--logical-shards"] if n == 2 else []
+            r = subprocess.run([sys.executable, bench, "--gpus", str(n), "--steps", "7", "--warmup", "2", "--dry-run"] + extra, env=e,
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            last = r.stdout.strip().splitlines()[-1]
+            assert len(last) < 4096
+            line = json.loads(last)
+            assert line["n_gpus"] == n and line["steps"] == 7 and line["warmup"] == 2 and line["value"] is None and "dry-run" in line["data"]
+            assert line["config"]["rows_per_gpu"] == (100_000_000 + n - 1) // n and line["config"]["parallelism"] == f"row-shard x{n}"
+            if n > 1:
+                assert "rccl_ranks" in line["config"]["exchange"]
+    # a rank other than 0 prints nothing; a world that disagrees with --gpus is an error
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+    # the 1e8-row graph leg is opt-in; the old flag is still accepted
+    r = subprocess.run([sys.executable, bench, "--dry-run", "--no-graph-1e8"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+
+
 DEV_KNOBS = ["MSE_SCAN_ABL", "MSE_SCAN_2D", "MSE_SCAN_S", "MSE_ATT_ABL", "MSE_ATT64_ABL", "MSE_ATT_WAVES", "MSE_ATT_QT", "MSE_ATT_TILE32",
              "MSE_GEMM_RANDOM", "MSE_GEMM_OLD256", "MSE_GEMM_128", "MSE_GEMM_NOPERSIST", "MSE_GEMM_STAGGER", "MSE_GEMM_NONARROW",
              "MSE_PQ_OLDTRANSFORM", "MSE_PQ_OLDQUANT", "MSE_PQ_OLDSCAN", "MSE_DEDUP_OLD"]
