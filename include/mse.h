@@ -596,7 +596,11 @@ const char* mse_siglip_weight_name(const mse_siglip* m, int idx);   /* names the
 int mse_siglip_set_weight(mse_siglip* m, const char* name, const float* data, const size_t* shape, int ndim);
 int mse_siglip_finalize(mse_siglip* m);                              /* fails if a weight is missing */
 /* images: [batch,3,H,W], dtype 0 = f32 / 1 = f16, already normalised (x/127.5 - 1); batch > max_batch is an
- * error (the reference asserts, clip_server.py:139).  Outputs (either may be NULL) are host [batch, emb_dim]. */
+ * error (the reference asserts, clip_server.py:139).  Outputs (either may be NULL) are host [batch, emb_dim].
+ * Batch invariance: rows of calls of >= 5 images are bit-equal whatever the batch.  Calls of 1-4 images run small-batch
+ * kernels with another summation order: an image embedded alone (query time) and the same image inside a larger batch (index
+ * time) agree to bf16 rounding (cosine within 1e-4; both within 1e-3 of the fp32 model), not bit for bit.  A pipeline that needs
+ * index/query bit-equality sets MSE_SIGLIP_NOSMALL=1 in the environment before mse_siglip_create (read once, there). */
 int mse_siglip_encode_image(mse_siglip* m, const void* images, int dtype, int on_device, int batch, int normalize,
                             float* out_f32, uint16_t* out_f16);
 /* Same from decoded RGB bytes [batch][H][W][3] (host): the ToTensor / Normalize(0.5, 0.5) / .half() / stack steps of the

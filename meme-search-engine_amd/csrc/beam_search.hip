@@ -1134,6 +1134,13 @@ Coalescer* graph_coalescer(const mse_graph* g) {
     std::lock_guard<std::mutex> lk(g->co_mu);
     if (!g->co) {
         const int workers = g->co_workers > 0 ? g->co_workers : 3;
+        // contexts beyond the new worker count own a searcher (device scratch, a stream) and pinned staging: freed, not dropped
+        // (no worker is alive here: the previous coalescer was deleted, and with it its threads, before a new one is made)
+        for (size_t w = (size_t)workers; w < g->co_ctx.size(); w++) {
+            if (g->co_ctx[w].s) mse_searcher_free(g->co_ctx[w].s);
+            if (g->co_ctx[w].pin) (void)hipHostFree(g->co_ctx[w].pin);
+            g->co_ctx[w] = mse_graph::WorkerCtx{};
+        }
         g->co_ctx.resize((size_t)workers);
         g->co = new (std::nothrow) Coalescer(g->co_max_queries ? g->co_max_queries : 1024, g->co_max_wait_us ? g->co_max_wait_us : 200,
                                              [](std::vector<DispatchReq*>& b) { graph_run_batch(b); }, nullptr, workers);

@@ -79,8 +79,14 @@ class CompletionQueue {
     int fd();          // an eventfd bumped by ring(); made on first call, closed with the queue
     void close_fd();
     void wake();       // wakes sleepers in take() without a completion (shutdown)
+    // A worker's complete() pushes a pass's records and rings afterwards: between the two a poller may take the LAST outstanding
+    // ticket and free the queue (mse.h allows that once none of its tickets is out).  The worker therefore pins the queue before its
+    // first push and unpins after ring(); the destructor waits for the pins to drain.
+    void pin() { pins_.fetch_add(1, std::memory_order_acq_rel); }
+    void unpin() { pins_.fetch_sub(1, std::memory_order_release); }
 
   private:
+    std::atomic<uint32_t> pins_{0};
     alignas(64) std::atomic<DispatchReq*> head_{nullptr};
     std::atomic<uint32_t> bell_{0};
     std::atomic<int> fd_{-1};

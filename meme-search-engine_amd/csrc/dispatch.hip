@@ -13,6 +13,7 @@
 #include <linux/futex.h>
 #include <sys/eventfd.h>
 #include <sys/syscall.h>
+#include <sched.h>
 #include <unistd.h>
 #include <time.h>
 
@@ -63,18 +64,22 @@ void Coalescer::complete(std::vector<DispatchReq*>& batch) {
     uint64_t touched = 0;
     CompletionQueue* rung[8];
     int n_rung = 0;
-    bool many = false;
     for (DispatchReq* r : batch) {
         if (r->async) {   // onto its completion queue: from the push on the record belongs to whoever takes it
             CompletionQueue* q = r->cq ? r->cq : &own_cq_;
             bool seen = false;
             for (int i = 0; i < n_rung; i++) seen |= rung[i] == q;
-            if (!seen) {
-                if (n_rung < 8) rung[n_rung++] = q;
-                else many = true;
+            const bool solo = !seen && n_rung >= 8;   // (more than eight queues in one pass: pinned, pushed and rung per request)
+            if (!seen && !solo) {
+                rung[n_rung++] = q;
+                q->pin();          // before the first push: from that push on a poller may hold every ticket of the queue and free it
             }
+            if (solo) q->pin();
             q->push(r);
-            if (many) q->ring();   // (more than eight queues in one pass: rung per request)
+            if (solo) {
+                q->ring();
+                q->unpin();
+            }
             continue;
         }
         touched |= 1ull << r->slot;
@@ -85,13 +90,19 @@ void Coalescer::complete(std::vector<DispatchReq*>& batch) {
             wake_[sl].gen.fetch_add(1, std::memory_order_release);
             futex_wake_all(&wake_[sl].gen);
         }
-    for (int i = 0; i < n_rung; i++) rung[i]->ring();
+    for (int i = 0; i < n_rung; i++) {
+        rung[i]->ring();
+        rung[i]->unpin();
+    }
 }
 
 size_t Coalescer::completions(DispatchReq** out, size_t max, int64_t timeout_us) { return own_cq_.take(out, max, timeout_us, &stop_); }
 int Coalescer::completion_fd() { return own_cq_.fd(); }
 
-CompletionQueue::~CompletionQueue() { close_fd(); }
+CompletionQueue::~CompletionQueue() {
+    while (pins_.load(std::memory_order_acquire)) sched_yield();   // a worker is between its push and its ring(): a few instructions
+    close_fd();
+}
 
 void CompletionQueue::push(DispatchReq* r) {
     DispatchReq* head = head_.load(std::memory_order_relaxed);
@@ -343,7 +354,7 @@ void Coalescer::loop(int index) {
         lk.unlock();
         // ---- the gatherer: sleeps on the bell, never on a lock the callers touch ----
         // until the first request is there ...
-        bool by_deadline = false;
+        bool by_deadline = false, held = false;
         auto sleep_until_mark = [&](uint64_t mark, bool timed, int64_t deadline_ns) -> bool {   // false: the deadline passed
             const uint32_t b = bell_.load(std::memory_order_acquire);
             wake_at_.store(mark, std::memory_order_seq_cst);
@@ -376,15 +387,22 @@ void Coalescer::loop(int index) {
             if (hold_while_busy_) {
                 // (the bell word is read BEFORE the count of executing passes: a pass that ends after that read rings a bell this wait
                 // still sees -- its decrement comes before its ring)
+                // The hold is bounded: a slow pass (the grow-and-repeat path, a failed shared submission retried request by request)
+                // must not stall every queued request while the other workers idle -- after 8 wait budgets past the deadline the
+                // gatherer goes on by the ordinary rule.
                 const uint32_t b = bell_.load(std::memory_order_acquire);
-                if (running_.load(std::memory_order_acquire) > 0) {
+                const int64_t now = steady_ns(std::chrono::steady_clock::now());
+                const int64_t hold_end = deadline + 8 * (int64_t)max_wait_us_.load() * 1000;
+                if (running_.load(std::memory_order_acquire) > 0 && now < hold_end) {
                     const uint64_t mark = drained_ + (tgt - queued_queries_);
                     wake_at_.store(mark, std::memory_order_seq_cst);
-                    if (pushed_.load(std::memory_order_seq_cst) < mark && !stop_.load()) futex_wait(&bell_, b);
+                    if (pushed_.load(std::memory_order_seq_cst) < mark && !stop_.load()) futex_wait_for(&bell_, b, hold_end - now);
+                    held = true;
                     continue;
                 }
             }
-            if (!sleep_until_mark(drained_ + (tgt - queued_queries_), true, deadline)) { by_deadline = true; drain(); break; }
+            // (a deadline that passed while the gatherer was HOLDING says nothing about returners that did not come back)
+            if (!sleep_until_mark(drained_ + (tgt - queued_queries_), true, deadline)) { by_deadline = !held; drain(); break; }
         }
         if (stop_.load()) { lk.lock(); gathering_ = false; break; }
         batch.clear();

@@ -2100,8 +2100,10 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, int rows, i
 // (store_quad: the same bias / GELU / QKV-scatter code as the first-generation kernel).  K = 1152 with 12 waves is ONE round trip to
 // memory per wave; N / 32 x M / 64 workgroups (108 for QKV, 136 for fc1, 36 for the projections at batch 1) fill more of the chip.
 // The summation order differs from the large kernels' (K split 12 or 8 ways): a text encoded alone and the same text inside a batch
-// of more than 8 agree to bf16 rounding, not bit for bit (the image tower's batch invariance is untouched: only the text tower asks
-// for this path).
+// of more than 8 agree to bf16 rounding, not bit for bit.  The IMAGE tower takes the small-batch kernels too (siglip_api.hip: every
+// GEMM of a call of <= 4 images, fc2 split along K for one image): an image embedded alone at query time and the same image inside
+// a batch of five or more at index time agree to bf16 rounding (cosine within 1e-4), not bit for bit; rows of batches of >= 5 stay
+// bit-equal whatever the batch.  MSE_SIGLIP_NOSMALL=1 at engine creation restores bit-equality for every batch size (mse.h).
 // ---------------------------------------------------------------------------------------------------------
 // row thresholds of the small-batch kernels (scripts/gemm_small_probe.py measures every variant at every size,
 // profiles/r05_gemm_small_probe.txt): the K-split kernel for one text, 64 x 64 tiles up to 3072 rows (128 x 128 for the long-K fc2
