@@ -20,11 +20,18 @@ using namespace mse::siglip;
 namespace {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+// rows of a part (a range of sequences on one stream) from which the LayerNorm-fused batch kernels are used: below, launch_gemm picks
+// the small-batch tiles (<= 3072 rows), which have no fused form
+constexpr int FUSED_MIN_ROWS = 3072;
 
 struct TBlock {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     uint16_t *wqkv, *wproj, *w1, *w2;
     float *bqkv, *bproj, *b1, *b2;
+    // LayerNorm folded into the GEMMs around it (large batches; siglip_kernels.hip "Fused LayerNorm"): fp16 gamma-folded weights,
+    // their row sums and the beta-folded biases of the two consumers (QKV, fc1)
+    uint16_t *wqkv16 = nullptr, *w116 = nullptr;
+    float *cqkv = nullptr, *bqkv2 = nullptr, *c1 = nullptr, *b12 = nullptr;
 };
 struct TSlot {
     bool bf16;
@@ -59,6 +66,13 @@ struct mse_siglip_text {
     float *pooled = nullptr, *feat = nullptr, *out_f32 = nullptr;
     uint16_t *h = nullptr, *dlt = nullptr, *mlp_h = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *out_f16 = nullptr;
     float* kparts = nullptr;   // fp32 partial sums of a K-split fc2 (few rows; launch_gemm GEMM_EPI_PART)
+    // fused-LayerNorm path of large batches (round 6, as the image tower since round 2); MSE_SIGLIP_NOFUSE=1 keeps the LayerNorms
+    // as kernels of their own for every batch size
+    bool fused = false;
+    int dp = 0;                  // width rounded up to whole 256-column tiles: rows of the proj / fc2 weights (zero rows behind D)
+    float* ln_stats = nullptr;   // [m_pad] (mean, 1/std)
+    float* ln_part = nullptr;    // [D / 64][m_pad] (sum, M2)
+    void* sink = nullptr;
     float* stage = nullptr; size_t stage_elems = 0;
 
     template <typename T> T* dalloc(size_t n, bool zero = false) {
@@ -113,7 +127,8 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
             (void)hipGetLastError();
             if (m->side[hlf]) { (void)hipStreamDestroy(m->side[hlf]); m->side[hlf] = nullptr; }
         }
-    const size_t D = m->D, MP = m->mlp_pad;
+    const size_t D = m->D, MP = m->mlp_pad, DP = round_up(m->D, 256);
+    m->dp = (int)DP;
     m->add_f32("text.token_embedding.weight", &m->tok_emb, c->vocab_size, D);
     m->add_f32("text.positional_embedding", &m->pos, m->ctx, D);
     m->blocks.resize(c->layers);
@@ -122,10 +137,30 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
         const std::string p = "text.transformer.resblocks." + std::to_string(i) + ".";
         m->add_f32(p + "ln_1.weight", &b.ln1_g, 1, D); m->add_f32(p + "ln_1.bias", &b.ln1_b, 1, D);
         m->add_bf16(p + "attn.in_proj_weight", &b.wqkv, 3 * D, D, 3 * D, D); m->add_f32(p + "attn.in_proj_bias", &b.bqkv, 1, 3 * D);
-        m->add_bf16(p + "attn.out_proj.weight", &b.wproj, D, D, D, D); m->add_f32(p + "attn.out_proj.bias", &b.bproj, 1, D);
+        // proj and fc2 write the residual branch: N = D padded to whole 256-column tiles (zero weight rows) so that the fused path's
+        // persistent 256 x 256 kernel covers them without a 128-column remainder launch; the unfused path reads the first D rows
+        m->add_bf16(p + "attn.out_proj.weight", &b.wproj, D, D, DP, D); m->add_f32(p + "attn.out_proj.bias", &b.bproj, 1, D, DP);
         m->add_f32(p + "ln_2.weight", &b.ln2_g, 1, D); m->add_f32(p + "ln_2.bias", &b.ln2_b, 1, D);
         m->add_bf16(p + "mlp.c_fc.weight", &b.w1, m->mlp, D, MP, D); m->add_f32(p + "mlp.c_fc.bias", &b.b1, 1, m->mlp, MP);
-        m->add_bf16(p + "mlp.c_proj.weight", &b.w2, D, m->mlp, D, MP); m->add_f32(p + "mlp.c_proj.bias", &b.b2, 1, D);
+        m->add_bf16(p + "mlp.c_proj.weight", &b.w2, D, m->mlp, DP, MP); m->add_f32(p + "mlp.c_proj.bias", &b.b2, 1, D, DP);
+    }
+    {
+        const char* e = getenv("MSE_SIGLIP_NOFUSE");
+        m->fused = !(e && atoi(e)) && gemm_fused_ok((int)m->m_pad, (int)D, (int)MP, m->H, m->dh, m->ctx, m->n_pad, 8) &&
+                   m->m_pad > (size_t)FUSED_MIN_ROWS;
+    }
+    bool fused_alloc_ok = true;
+    if (m->fused) {
+        for (int i = 0; i < c->layers; i++) {
+            TBlock& b = m->blocks[i];
+            b.wqkv16 = m->dalloc<uint16_t>(3 * D * D); b.cqkv = m->dalloc<float>(3 * D); b.bqkv2 = m->dalloc<float>(3 * D);
+            b.w116 = m->dalloc<uint16_t>(MP * D); b.c1 = m->dalloc<float>(MP); b.b12 = m->dalloc<float>(MP);
+            fused_alloc_ok = fused_alloc_ok && b.wqkv16 && b.cqkv && b.bqkv2 && b.w116 && b.c1 && b.b12;
+        }
+        m->ln_stats = m->dalloc<float>(2 * m->m_pad, true);
+        m->ln_part = m->dalloc<float>(2 * (D / 64) * m->m_pad, true);
+        m->sink = m->dalloc<char>(4096, true);
+        fused_alloc_ok = fused_alloc_ok && m->ln_stats && m->ln_part && m->sink;
     }
     m->add_f32("text.ln_final.weight", &m->lnf_g, 1, D); m->add_f32("text.ln_final.bias", &m->lnf_b, 1, D);
     m->add_bf16("text.text_projection.weight", &m->wproj, D, D, D, D); m->add_f32("text.text_projection.bias", &m->bproj, 1, D);
@@ -143,6 +178,7 @@ mse_siglip_text* mse_siglip_text_create(const mse_siglip_text_config* c) {
     m->pooled = m->dalloc<float>(B * D); m->feat = m->dalloc<float>(B * D);
     m->out_f32 = m->dalloc<float>(B * D); m->out_f16 = m->dalloc<uint16_t>(B * D);
     bool ok = m->tokens_dev && m->x && m->h && m->dlt && m->kparts && m->mlp_h && m->qb && m->kb && m->vtb && m->pooled && m->feat && m->out_f32 && m->out_f16;
+    ok = ok && fused_alloc_ok;
     for (auto& kv : m->slots) ok = ok && kv.second.dst;
     if (!ok) { mse_siglip_text_destroy(m); fail("siglip text: device allocation failed"); return nullptr; }
     (void)hipDeviceSynchronize();   // the zero fills above ran on the null stream; m->stream does not wait for it
@@ -208,6 +244,13 @@ int mse_siglip_text_finalize(mse_siglip_text* m) {
     if (!m) return fail("null engine");
     for (auto& kv : m->slots)
         if (!kv.second.loaded) return fail("siglip text: weight '" + kv.first + "' was never set");
+    if (m->fused) {
+        for (TBlock& b : m->blocks) {
+            if (launch_ln_fold(b.wqkv, 3 * m->D, m->D, b.ln1_g, b.ln1_b, b.bqkv, b.wqkv16, b.cqkv, b.bqkv2, m->stream)) return -1;
+            if (launch_ln_fold(b.w1, m->mlp_pad, m->D, b.ln2_g, b.ln2_b, b.b1, b.w116, b.c1, b.b12, m->stream)) return -1;
+        }
+        MSE_HIP_TRY(hipStreamSynchronize(m->stream));
+    }
     m->finalized = true;
     return 0;
 }
@@ -230,6 +273,10 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     const int ksp = gemm_small_ksplit(M, D, m->mlp_pad);
     LnDelta fc2_delta_call;   // what the LayerNorm after an fc2 adds to x (bias filled in per block; the bf16 branch per range of rows)
     if (ksp > 1) { fc2_delta_call.parts = m->kparts; fc2_delta_call.n_parts = ksp; fc2_delta_call.part_stride = (size_t)gemm_small_ksplit_rows(M) * D; fc2_delta_call.ldp = D; }
+    // parts of a large batch (decided here because the fused path is chosen by the size of a part, the same for every part of a call)
+    const int parts = batch >= 32 ? std::min(m->n_parts, batch / 16) : 1;
+    const int per = parts > 1 ? std::max(4, (batch / parts) / 4 * 4) : batch;
+    const bool fused_call = m->fused && c.layers > 0 && per * T > FUSED_MIN_ROWS;
     auto blocks = [&](hipStream_t ss, int b0, int nb, int half) -> int {
         const size_t r0 = (size_t)b0 * T;
         // large halves: the remainder launches of the N = 1152 / 3456 GEMMs beside their full column tiles (32-64 workgroups that ran
@@ -243,6 +290,44 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
         uint16_t* qb = m->qb + (size_t)b0 * m->H * m->n_pad * m->dh_pad;
         uint16_t* kb = m->kb + (size_t)b0 * m->H * m->n_pad * attention_k_stride();
         uint16_t* vtb = m->vtb + (size_t)b0 * m->H * m->dv_pad * m->n_pad;
+        if (fused_call) {
+            // Large batch: LN1 / LN2 folded into the GEMMs around them (the image tower's path, siglip_api.hip): proj / fc2 add their
+            // tile to the fp16 residual stream in place and emit per-row (sum, M2) of their 64-column groups; QKV / fc1 read the
+            // residual rows themselves against gamma-folded weights and correct with (mean, 1/std).  No LayerNorm pass, no bf16
+            // round trip of the branch, no 128-column remainder launch behind proj / fc2 (their N is padded to 1280).
+            float* ln_stats = m->ln_stats + 2 * r0;
+            float* ln_part = m->ln_part + 2 * r0;
+            if (launch_row_stats(x, D, D, (size_t)Msp, c.eps, ln_stats, ss)) return -1;
+            for (int i = 0; i < c.layers; i++) {
+                const TBlock& b = m->blocks[i];
+                {
+                    GemmLaunch g; g.x = x; g.w = b.wqkv16; g.bias = b.bqkv2; g.csum = b.cqkv; g.ln_stats = ln_stats;
+                    g.M = Msp; g.N = 3 * D; g.K = D; g.m_valid = Ms; g.tokens = T;
+                    g.q = qb; g.k = kb; g.vt = vtb; g.heads = m->H; g.dh = m->dh; g.dh_pad = m->dh_pad; g.n_pad = m->n_pad;
+                    g.dv_pad = m->dv_pad; g.kdh_pad = attention_k_stride();
+                    if (launch_gemm_fused(GEMM_EPI_QKV, g, ss)) return -1;
+                }
+                if (launch_attention(qb, kb, vtb, nb, m->H, T, m->n_pad, m->dh, m->dh_pad, m->dv_pad, h, D, T, ss)) return -1;
+                {
+                    GemmLaunch g; g.x = h; g.w = b.wproj; g.bias = b.bproj; g.M = Msp; g.N = m->dp; g.K = D; g.m_valid = Ms;
+                    g.xres = x; g.ldr = D; g.part = ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
+                    if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, ss)) return -1;   // x += attention branch, statistics for LN2
+                }
+                if (launch_ln_finalize(ln_part, m->m_pad, D / 64, (size_t)Msp, c.eps, ln_stats, ss)) return -1;
+                {
+                    GemmLaunch g; g.x = x; g.w = b.w116; g.bias = b.b12; g.csum = b.c1; g.ln_stats = ln_stats;
+                    g.M = Msp; g.N = m->mlp_pad; g.K = D; g.m_valid = Ms; g.out_bf16 = mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
+                    if (launch_gemm_fused(GEMM_EPI_GELU, g, ss)) return -1;
+                }
+                {
+                    GemmLaunch g; g.x = mlp_h; g.w = b.w2; g.bias = b.b2; g.M = Msp; g.N = m->dp; g.K = m->mlp_pad; g.m_valid = Ms;
+                    g.xres = x; g.ldr = D; g.part = ln_part; g.part_rows = m->m_pad; g.n_valid = D; g.sink = m->sink;
+                    if (launch_gemm_fused(GEMM_EPI_RESID_LN, g, ss)) return -1;   // x += MLP branch, statistics for the next LN1
+                }
+                if (i + 1 < c.layers && launch_ln_finalize(ln_part, m->m_pad, D / 64, (size_t)Msp, c.eps, ln_stats, ss)) return -1;
+            }
+            return 0;
+        }
         for (int i = 0; i < c.layers; i++) {
             const TBlock& b = m->blocks[i];
             // x += (fc2 output of the previous block), then LayerNorm
@@ -283,8 +368,6 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     // GEMMs have 4.5 column tiles, so their last round of 256 x 256 tiles leaves most of the chip idle -- the other half's next kernel
     // takes those CUs.  The first half is a multiple of four sequences (256 rows).
     // (MSE_SIGLIP_TEXT_PARTS, read when the engine is created: 1..4 parts; every part but the last is a multiple of four sequences.)
-    const int parts = batch >= 32 ? std::min(m->n_parts, batch / 16) : 1;
-    const int per = parts > 1 ? std::max(4, (batch / parts) / 4 * 4) : batch;
     if (parts > 1) {
         MSE_HIP_TRY(hipEventRecord(m->ev_fork, st));
         for (int pt = 1; pt < parts; pt++) {
@@ -299,7 +382,9 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     // final LayerNorm of the LAST position only (pool_type "last"), then the projection with bias
     {
         LnDelta df;   // rows b * T + (T - 1): row stride T * D of x, of the bf16 branch and of the partial sums alike
-        if (c.layers && ksp > 1) {
+        if (fused_call) {
+            // (x already holds the last block's MLP branch)
+        } else if (c.layers && ksp > 1) {
             df = fc2_delta_call; df.parts += (size_t)(T - 1) * D; df.ldp = T * D; df.bias = m->blocks[c.layers - 1].b2;
         } else if (c.layers) {
             df.bf16 = m->dlt + (size_t)(T - 1) * D; df.ldd = T * D;
