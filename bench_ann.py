@@ -300,6 +300,95 @@ def shard_centroid_entries(rows, n_base, n_shards=64, sample=200_000, seed=7):
     return c.cpu().numpy().astype(np.float32), idx[med].cpu().numpy().astype(np.uint32)
 
 
+def request_path_leg(s, g, L, K=10, beam=4, n_one=300, cycles=40, in_flight=64, seed=11):
+    """The whole request as a user of query_disk_index sees it (src/query_disk_index.rs:345-381 embeds the query text through the clip
+    server, :436-540 searches with the embedding): token ids in -> SigLIP text tower -> the f16 row handed to the search ON THE DEVICE
+    (mse_siglip_text_encode_dev, mse_searcher_wait_stream: no host round trip between the two) -> entry step, beam search, top-k ->
+    k (id, score) pairs on the host.  Measured one request at a time (latency p50 / p99) and with `in_flight` requests at once, the
+    way the clip server batches what is waiting: one tower call for all of them, one search call.  Seeded tower weights and synthetic
+    tokens (no checkpoint offline): the embedding is a unit vector unrelated to the rows, so a search costs what a query far from the
+    data costs (its full search list of node fetches); the arithmetic per request is that of real text."""
+    import numpy as np
+    import mse
+    from mse import siglip
+    tcfg = dict(siglip.SO400M_TEXT)
+    teng = siglip.SiglipTextEngine.from_state_dict(siglip.synthetic_text_state_dict(tcfg), tcfg, max_batch=in_flight)
+    tok = np.random.default_rng(seed).integers(2, tcfg["vocab_size"], size=(max(n_one, in_flight * 4), tcfg["context_length"]), dtype=np.int64)
+
+    def request_dev(t):
+        _, p16, stream = teng.encode_text_device(t)
+        s.wait_stream(stream)
+        return mse.disk_query_topk(s, None, None, g, (p16, t.shape[0]), K, None, None, None, True, beam, L)
+
+    def request_host(t):
+        f16 = teng.encode_text(t, out="f16")
+        return mse.disk_query_topk(s, None, None, g, f16, K, None, None, None, True, beam, L)
+
+    def pct(ts):
+        a = np.sort(np.asarray(ts)) * 1e3
+        return {"p50": float(a[len(a) // 2]), "p99": float(a[min(len(a) - 1, int(len(a) * 0.99))]), "mean": float(a.mean()), "n": int(len(a))}
+
+    # the hand-over changes nothing: device path == host round trip, ids and scores
+    ids_d, sc_d, _ = request_dev(tok[:8])
+    ids_h, sc_h, _ = request_host(tok[:8])
+    same = bool(np.array_equal(ids_d, ids_h) and np.array_equal(sc_d, sc_h))
+    out = {"what": "token ids in -> SigLIP text tower (27 blocks) -> f16 row handed over on the device -> entry step + beam search + top-k -> host",
+           "search_list": int(L), "beamwidth": beam, "k": K, "device_hand_over_equals_host_round_trip": same,
+           "query": "the tower's output for synthetic tokens under seeded weights (a unit vector unrelated to the rows)"}
+    for fn, key in ((request_dev, "one_at_a_time"), (request_host, "one_at_a_time_host_round_trip")):
+        for i in range(5):
+            fn(tok[i:i + 1])
+        ts = []
+        for i in range(n_one):
+            t0 = time.perf_counter()
+            fn(tok[i:i + 1])
+            ts.append(time.perf_counter() - t0)
+        out[key] = {"latency_ms": pct(ts), "requests_per_s": len(ts) / float(np.sum(ts))}
+    # where one request's time goes: the tower alone (features to the host), the search alone (a host f16 query)
+    f16 = teng.encode_text(tok[:1], out="f16")
+    ts_t, ts_s = [], []
+    for i in range(100):
+        t0 = time.perf_counter()
+        teng.encode_text(tok[i:i + 1], out="f16")
+        ts_t.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        mse.disk_query_topk(s, None, None, g, f16, K, None, None, None, True, beam, L)
+        ts_s.append(time.perf_counter() - t0)
+    out["one_at_a_time"]["parts_ms"] = {"text_tower_alone_p50": pct(ts_t)["p50"], "search_alone_p50": pct(ts_s)["p50"]}
+    # `in_flight` requests at once: one tower call + one search call per cycle, every request of a cycle answered at its end
+    for i in range(3):
+        request_dev(tok[:in_flight])
+    ts = []
+    for i in range(cycles):
+        b0 = (i % 4) * in_flight
+        t0 = time.perf_counter()
+        request_dev(tok[b0:b0 + in_flight])
+        ts.append(time.perf_counter() - t0)
+    out[f"in_flight_{in_flight}"] = {"latency_ms": pct(ts), "requests_per_s": in_flight * len(ts) / float(np.sum(ts)),
+                                     "shape": f"{in_flight} requests per cycle: one text-tower call of {in_flight} rows, one search call of {in_flight} device-resident queries"}
+    # ... and the same with the searches as TICKETS (mse_disk_query_submit_f32 / completions: the host keeps its one-query requests)
+    try:
+        tk = mse.QueryTickets(s, None, None, g, K, True, beam, L)
+        ts = []
+        for i in range(cycles):
+            b0 = (i % 4) * in_flight
+            t0 = time.perf_counter()
+            f32 = teng.encode_text(tok[b0:b0 + in_flight], out="f32")
+            for j in range(in_flight):
+                tk.submit(f32[j], key=j)
+            got = 0
+            while got < in_flight:
+                got += len(tk.collect(timeout_us=5_000_000))
+            ts.append(time.perf_counter() - t0)
+        tk.close()
+        out[f"in_flight_{in_flight}_tickets"] = {"latency_ms": pct(ts[3:]), "requests_per_s": in_flight * len(ts[3:]) / float(np.sum(ts[3:])),
+                                                 "shape": "one text-tower call, features to the host, one TICKET per request, collected as they complete"}
+    except Exception as e:  # noqa: BLE001
+        out[f"in_flight_{in_flight}_tickets"] = {"error": repr(e)}
+    teng.close()
+    return out
+
+
 def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budget_s=None, request_path=False):
     """One row of the graph-index table: a Vamana graph (generate-index-shard's defaults R 64, L 192, C 750; one pass) over n synthetic
     rows of `kind` (easy / hard / ood, see the module docstring), searched through the request path in one call
@@ -468,6 +557,13 @@ def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budge
             out["graph_callers"] = graph_callers(root, vecs, g, call_q.float().cpu().numpy(), truth_c, L_exact, K, 4, (64, 512, 4096), one_call)
         except Exception as e:  # noqa: BLE001
             out["graph_callers"] = {"error": repr(e)}
+    # (6) the whole request: text in -> top-k out, the tower's output handed to the search on the device
+    if request_path and L_exact:
+        try:
+            mse.set_entries(g, vecs, e_idx)
+            out["request_path"] = request_path_leg(s, g, L_exact, K, 4)
+        except Exception as e:  # noqa: BLE001
+            out["request_path"] = {"error": repr(e)}
     out["seconds"] = time.perf_counter() - t_all
     g.close()
     return out

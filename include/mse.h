@@ -651,6 +651,14 @@ int mse_siglip_text_finalize(mse_siglip_text* m);
 /* tokens: host int64 [batch, context_length]; outputs (either may be NULL) are host [batch, width]. */
 int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize, float* out_f32,
                            uint16_t* out_f16);
+/* The same forward with the features left ON THE DEVICE, nothing copied back and nothing waited for: the request handler embeds the
+ * query text (src/query_disk_index.rs:345-381) and searches with it (:436-540) -- order the searcher behind the engine's stream
+ * (mse_searcher_wait_stream(s, mse_siglip_text_stream(m))) and pass mse_siglip_text_output_device(m, 1) as the device-resident f16
+ * queries of mse_disk_query_topk.  `tokens` (host) must stay untouched until the engine's stream has read them; the output buffers
+ * (which: 0 = f32 [batch][width], 1 = f16) belong to the engine and hold this call's rows until its next call. */
+int mse_siglip_text_encode_dev(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize);
+const void* mse_siglip_text_output_device(const mse_siglip_text* m, int which);
+void* mse_siglip_text_stream(const mse_siglip_text* m);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

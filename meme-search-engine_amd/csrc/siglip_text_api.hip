@@ -255,11 +255,11 @@ int mse_siglip_text_finalize(mse_siglip_text* m) {
     return 0;
 }
 
-int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize, float* out_f32, uint16_t* out_f16) {
-    if (!m) return fail("null engine");
-    if (!m->finalized) return fail("siglip text: call mse_siglip_text_finalize after loading the weights");
-    std::lock_guard<std::mutex> call_lock(m->call_mu);
-    if (batch <= 0 || batch > m->max_batch) return fail("siglip text: batch exceeds max_batch");  // clip_server.py:136
+}  // extern "C"
+
+// every kernel of one forward, enqueued on the engine's stream (and its part streams, joined back): tokens up, features into
+// m->out_f32 / m->out_f16 on the device.  Nothing is copied back and nothing is waited for.
+static int text_forward(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize) {
     hipStream_t st = m->stream;
     const mse_siglip_text_config& c = m->cfg;
     const int D = m->D, T = m->ctx, M = batch * T;
@@ -393,10 +393,39 @@ int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch,
     }
     if (launch_small_linear(m->pooled, D, m->wproj, D, m->bproj, D, D, batch, 0, nullptr, 0, m->feat, D, st)) return -1;
     if (launch_l2norm(m->feat, D, D, batch, normalize, m->out_f32, m->out_f16, st)) return -1;
+    return 0;
+}
+
+extern "C" {
+
+int mse_siglip_text_encode(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize, float* out_f32, uint16_t* out_f16) {
+    if (!m || !tokens) return fail("siglip text: null engine or tokens");
+    if (!m->finalized) return fail("siglip text: call mse_siglip_text_finalize after loading the weights");
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
+    if (batch <= 0 || batch > m->max_batch) return fail("siglip text: batch exceeds max_batch");  // clip_server.py:136
+    if (text_forward(m, tokens, batch, normalize)) return -1;
+    hipStream_t st = m->stream;
+    const int D = m->D;
     if (out_f32) MSE_HIP_TRY(hipMemcpyAsync(out_f32, m->out_f32, (size_t)batch * D * 4, hipMemcpyDeviceToHost, st));
     if (out_f16) MSE_HIP_TRY(hipMemcpyAsync(out_f16, m->out_f16, (size_t)batch * D * 2, hipMemcpyDeviceToHost, st));
     MSE_HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
+
+// The same forward with the features LEFT ON THE DEVICE and no wait: the query path hands them to the search without a host round
+// trip (src/query_disk_index.rs:345-381 embeds the text, :436-540 searches with it).  `tokens` must stay valid until the engine's
+// stream has consumed them (pinned memory, or wait for the stream before reusing the buffer); the result buffers are the engine's
+// own and hold this call's rows until the next call on the engine.
+int mse_siglip_text_encode_dev(mse_siglip_text* m, const int64_t* tokens, int batch, int normalize) {
+    if (!m || !tokens) return fail("siglip text: null engine or tokens");
+    if (!m->finalized) return fail("siglip text: call mse_siglip_text_finalize after loading the weights");
+    std::lock_guard<std::mutex> call_lock(m->call_mu);
+    if (batch <= 0 || batch > m->max_batch) return fail("siglip text: batch exceeds max_batch");
+    return text_forward(m, tokens, batch, normalize);
+}
+const void* mse_siglip_text_output_device(const mse_siglip_text* m, int which) {
+    return m ? (which ? (const void*)m->out_f16 : (const void*)m->out_f32) : nullptr;
+}
+void* mse_siglip_text_stream(const mse_siglip_text* m) { return m ? (void*)m->stream : nullptr; }
 
 }  // extern "C"

@@ -210,6 +210,9 @@ SIGNATURES = {
     "mse_siglip_text_set_weight": (C.c_int, [vp, C.c_char_p, f32p, C.POINTER(sz), C.c_int]),
     "mse_siglip_text_finalize": (C.c_int, [vp]),
     "mse_siglip_text_encode": (C.c_int, [vp, i64p, C.c_int, C.c_int, f32p, u16p]),
+    "mse_siglip_text_encode_dev": (C.c_int, [vp, i64p, C.c_int, C.c_int]),
+    "mse_siglip_text_output_device": (vp, [vp, C.c_int]),
+    "mse_siglip_text_stream": (vp, [vp]),
 }
 
 

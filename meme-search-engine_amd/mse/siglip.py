@@ -283,6 +283,21 @@ class SiglipTextEngine:
               "siglip_text_encode")
         return of32 if out == "f32" else of16
 
+    def encode_text_device(self, tokens, normalize=True):
+        """The same forward with the features left on the device: returns (f32 device pointer, f16 device pointer, hipStream_t of
+        the engine) without waiting.  The query path hands the f16 rows to the search with no host round trip:
+        `searcher.wait_stream(stream); mse.disk_query_topk(searcher, ..., (f16_ptr, b), ...)`.  The token array is kept alive on the
+        engine until the next call."""
+        t = np.ascontiguousarray(np.asarray(tokens), np.int64)
+        if t.ndim != 2 or t.shape[1] != self.context_length:
+            raise MseError(f"tokens must be [batch, {self.context_length}]")
+        if t.shape[0] > self.max_batch:
+            raise MseError(f"max batch size is {self.max_batch}")
+        L = ffi.lib()
+        check(L.mse_siglip_text_encode_dev(self._h, t.ctypes.data_as(ffi.i64p), t.shape[0], int(normalize)), "siglip_text_encode_dev")
+        self._tokens_in_flight = t
+        return L.mse_siglip_text_output_device(self._h, 0), L.mse_siglip_text_output_device(self._h, 1), L.mse_siglip_text_stream(self._h)
+
     def __call__(self, tokens):
         return self.encode_text(tokens)
 

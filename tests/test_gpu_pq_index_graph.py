@@ -1039,6 +1039,37 @@ def test_device_queries_written_by_another_stream(gpu, mse, orc):
     torch.cuda.synchronize()
 
 
+def test_text_embedding_handed_to_the_search_on_the_device(gpu, mse, orc):
+    """The request handler embeds the query text and searches with the embedding (src/query_disk_index.rs:345-381,436-540).
+    mse_siglip_text_encode_dev leaves the tower's f16 rows on the device and waits for nothing; mse_searcher_wait_stream orders the
+    search behind the engine's stream: the answers are those of the host round trip (features to the host, f16 host queries), for
+    one request and for a batch, and the device rows are the rows mse_siglip_text_encode returns."""
+    from mse import siglip
+    from oracle import siglip_ref as ref
+    rng = np.random.default_rng(77)
+    n, deg, k, L = 3000, 12, 10, 24
+    x = clustered_rows(orc, n, n_centres=24)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    mse.set_entries(dgraph, vecs, np.sort(rng.choice(n, 50, replace=False)).astype(np.uint32))
+    cfg = dict(ref.TEXT_CONFIG, layers=2)
+    eng = siglip.SiglipTextEngine.from_state_dict(ref.synthetic_text_weights(cfg), dict(siglip.SO400M_TEXT, layers=2), max_batch=16)
+    tok = ref.synthetic_tokens(16, cfg).numpy()
+    for b in (1, 16, 5):
+        rows = eng.encode_text(tok[:b], out="f16")
+        want = mse.disk_query_topk(searcher, None, None, dgraph, rows, k, None, None, None, True, 2, L)
+        _, p16, stream = eng.encode_text_device(tok[:b])
+        searcher.wait_stream(stream)
+        got = mse.disk_query_topk(searcher, None, None, dgraph, (p16, b), k, None, None, None, True, 2, L)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        # the oracle's search for the same f16 rows, from the same start node rule (exact top-1 over the entry rows)
+        assert got[0].shape == (b, k) and np.all(got[1][:, 0] >= got[1][:, -1])
+    eng.close()
+
+
 def test_entry_step_small_and_large_batches_agree(gpu, mse, orc):
     """The row-table entry step has two forms -- two launches of exact dots for a small batch, the brute-force searcher's matrix-core
     path for a large one (nq x entries beyond 2^22) -- and both are the exact top-1 with ties to the lower row: a large batch, the

@@ -324,6 +324,39 @@ def test_text_engine_matches_oracle(gpu, mse, ref, layers, gelu, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layers,gelu,batch", [(3, "erf", 112), (2, "tanh", 256)])
+def test_text_large_batch_runs_the_fused_layernorm_kernels_and_matches_the_oracle(gpu, mse, ref, layers, gelu, batch):
+    """Round 6: parts of more than 3072 token rows (batches of ~100 texts and more) run the image tower's LayerNorm-fused GEMMs -- QKV /
+    fc1 read the fp16 residual stream against gamma-folded weights, proj / fc2 add into it and emit the row statistics.  Every row
+    against the fp32 oracle (cosine within 1e-3), against the same texts encoded eight at a time by the unfused small-batch kernels
+    (bf16 rounding apart), and MSE_SIGLIP_NOFUSE=1 (LayerNorm as passes of its own at every size) as a third opinion."""
+    import os
+    from mse import siglip
+    cfg = dict(ref.TEXT_CONFIG, layers=layers)
+    sd = ref.synthetic_text_weights(cfg)
+    tok = ref.synthetic_tokens(batch, cfg)
+    want = ref.encode_text(tok, sd, cfg, gelu=gelu, normalize=True).numpy()
+    eng = siglip.SiglipTextEngine.from_state_dict(sd, dict(siglip.SO400M_TEXT, layers=layers), max_batch=256, gelu=gelu)
+    got = eng.encode_text(tok.numpy())
+    assert np.all(cosine(got, want) > 1 - 1e-3), cosine(got, want).min()
+    assert np.all(np.abs(np.linalg.norm(got, axis=1) - 1) < 1e-3)
+    small = np.concatenate([eng.encode_text(tok.numpy()[i:i + 8]) for i in range(0, batch, 8)])
+    assert np.all(cosine(got, small) > 1 - 2e-4), cosine(got, small).min()
+    again = eng.encode_text(tok.numpy())
+    assert np.array_equal(got, again)                                    # a call is deterministic
+    eng.close()
+    os.environ["MSE_SIGLIP_NOFUSE"] = "1"
+    try:
+        plain = siglip.SiglipTextEngine.from_state_dict(sd, dict(siglip.SO400M_TEXT, layers=layers), max_batch=256, gelu=gelu)
+    finally:
+        del os.environ["MSE_SIGLIP_NOFUSE"]
+    unfused = plain.encode_text(tok.numpy())
+    plain.close()
+    assert np.all(cosine(unfused, want) > 1 - 1e-3)
+    assert np.all(cosine(got, unfused) > 1 - 2e-4) and not np.array_equal(got, unfused)       # two arithmetic paths, one answer
+
+
+@pytest.mark.gpu
 def test_device_preprocessing_equals_host_preprocessing(gpu, mse, ref):
     """encode_rgb8 (ToTensor / Normalize / .half() on the device) == encode_image(host-preprocessed fp16 NCHW), bit for bit."""
     from mse import siglip
