@@ -479,6 +479,26 @@ def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budge
         return top, {"node_fetches_per_query": float(st["cmps"].mean())}
     out["exact_scored"] = dict(pick(run_exact, grid_L), entry=f"{n_entry} sampled rows, exact top-1 (timed)", beamwidth=4)
     L_exact = (out["exact_scored"]["held_out"] or {}).get("value")
+    # the search kernel against the HBM roofline: ALGORITHMIC bytes = what the searches gathered (counted by the kernel itself: every
+    # exactly scored row is one 2304-byte gather, every fetched node one adjacency list of 64 ids + its degree) / the kernel's duration by
+    # HIP events on the searcher's stream (mse_searcher_beam_timing); profiles/r06_beam_search_hard_pmc.txt holds the rocprofv3 view
+    if L_exact:
+        try:
+            s.beam_timing(2)
+            for _ in range(3):
+                run_exact(L_exact, qh16, qh32)
+            m = s.beam_timing(0)
+            row_b, adj_b = m["rows_scored"] * D * 2, m["nodes_fetched"] * (R * 4 + 4)
+            gbps = (row_b + adj_b) / (m["kernel_ms"] * 1e-3) / 1e9
+            out["gather_roofline"] = {"bound": "hbm", "kernel": "beam_search_kernel<64> (one wave per query)" if nq_t > 1024 and L_exact <= 256 else "beam_search_kernel<256>",
+                                      "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                                      "bytes_per_launch": (row_b + adj_b) / m["launches"], "avg_launch_ms": m["kernel_ms"] / m["launches"], "launches_timed": m["launches"],
+                                      "queries_per_launch": m["queries"] / m["launches"], "kernel_queries_per_s": m["queries"] / (m["kernel_ms"] * 1e-3),
+                                      "rows_scored_per_query": m["rows_scored"] / m["queries"], "nodes_fetched_per_query": m["nodes_fetched"] / m["queries"],
+                                      "bytes_per_query": (row_b + adj_b) / m["queries"],
+                                      "algorithmic_bytes": "rows scored exactly x 2304 B + fetched nodes x 260 B (64 neighbour ids + the degree), counted by the kernel"}
+        except Exception as e:  # noqa: BLE001
+            out["gather_roofline"] = {"error": repr(e)}
     # the same search list at other beam widths (the server's `beam_width` is the operator's, query_disk_index.rs:63,452; `evaluate` uses 3):
     # held-out queries, one call each -- a narrower beam is more iterations of less work, which 4096 concurrent searches hide
     if L_exact:

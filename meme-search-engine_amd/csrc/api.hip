@@ -458,6 +458,8 @@ void mse_searcher_free(mse_searcher* s) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->ev_wait) (void)hipEventDestroy(s->ev_wait);
+    if (s->bev0) (void)hipEventDestroy(s->bev0);
+    if (s->bev1) (void)hipEventDestroy(s->bev1);
     if (s->pin) (void)hipHostFree(s->pin);
     delete s;
 }

@@ -45,6 +45,7 @@ struct BeamArgs {
     uint32_t* out_ids; long long* out_scores; uint32_t* out_len;
     uint32_t* vis_ids; long long* vis_scores; size_t vis_cap; uint32_t* n_visited;
     uint32_t* cmps; uint32_t* pq_cmps; uint32_t* err;
+    unsigned long long* totals;   // optional (mse_searcher_beam_timing): [0] rows scored exactly, [1] nodes fetched, [2] ADC-scored neighbours
     int hash_slots;   // LDS table of a beam iteration's neighbour ids: power of two >= 2 x p_cap
     int fill_vis;   // fused request path: slots of the visited arrays past n_visited are set to (ID_NONE, INT64_MIN) for the device top-k
     // small-batch entry step (entry_top1_rows_kernel): the per-chunk bests [chunk][query] are reduced HERE, by the search's first wave,
@@ -441,6 +442,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         a.n_visited[qi] = n_vis;
         a.cmps[qi] = cmps;
         a.pq_cmps[qi] = pq_cmps;
+        if (a.totals) {   // measurement only: what this search gathered (n_adj - 1 = neighbours that entered a pre-buffer)
+            atomicAdd(&a.totals[0], (unsigned long long)cmps + (a.disable_pq ? (unsigned long long)(n_adj - 1) : 0ull));
+            atomicAdd(&a.totals[1], (unsigned long long)cmps);
+            atomicAdd(&a.totals[2], a.disable_pq ? 0ull : (unsigned long long)(n_adj - 1));
+        }
     }
 }
 
@@ -815,6 +821,11 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     // one wave per query once the batch fills the chip on its own (16 queries per CU); a smaller batch is latency-bound, and four waves
     // finish a search sooner (round 5, scripts/beam_latency_probe.py, hard set: 64 queries at L = 12 0.40 ms against 0.98, at L = 200
     // 5.7 against 8.9; from 2048 queries on the two forms are level)
+    const bool timed = s->beam_timing && s->bev0 && s->beam_tot.p;
+    if (timed) {
+        a.totals = s->beam_tot.as<unsigned long long>();
+        MSE_HIP_TRY(hipEventRecord(s->bev0, st));
+    }
     if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only && nq > 1024) {
         hipLaunchKernelGGL(beam_search_kernel<64>, dim3((unsigned)nq), dim3(64), lds, st, a);
     } else {
@@ -822,6 +833,18 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         hipLaunchKernelGGL(beam_search_kernel<BS_THREADS_MAX>, dim3((unsigned)nq), dim3(BS_THREADS_MAX), lds, st, a);
     }
     MSE_HIP_TRY(hipGetLastError());
+    if (timed) MSE_HIP_TRY(hipEventRecord(s->bev1, st));
+    struct BeamTimed {   // read once the stream has been waited for (every path below does before it returns)
+        mse_searcher* s; bool on; size_t nq;
+        ~BeamTimed() {
+            float ms = 0.0f;
+            if (on && hipEventQuery(s->bev1) == hipSuccess && hipEventElapsedTime(&ms, s->bev0, s->bev1) == hipSuccess) {
+                s->beam_ms_total += ms; s->beam_launches++; s->beam_queries += nq;
+            } else if (on) {
+                (void)hipGetLastError();
+            }
+        }
+    } beam_timed{s, timed, nq};
     uint32_t err = 0;
     if (fz) {
         // the server's last step (src/query_disk_index.rs:529-540: the visited records ordered by exact score) cut to its first k, on
@@ -1502,6 +1525,40 @@ int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t 
         g->co_max_queries = max_queries_per_pass; g->co_max_wait_us = max_wait_us; g->co_workers = workers;
     }
     delete old;   // joins its workers; no call may be in flight (as for mse_graph_free)
+    return 0;
+}
+
+// Measurement hook for bench.py's gather roofline: HIP events around every beam_search_kernel launch of this searcher and device totals
+// of what the searches gathered.  enable: 0 off, 1 on, 2 on + reset.  out (optional, 6 words): kernel ms x 1000 (integer microseconds),
+// launches, queries, rows scored exactly (2304-byte gathers at d = 1152), nodes fetched (adjacency lists), ADC-scored neighbours.
+int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[6]) {
+    if (!s) return fail("null searcher");
+    if (s->base) (void)hipSetDevice(s->base->device);
+    if (out) {
+        unsigned long long tot[3] = {0, 0, 0};
+        if (s->beam_tot.p) {
+            MSE_HIP_TRY(hipStreamSynchronize(s->stream));
+            MSE_HIP_TRY(hipMemcpy(tot, s->beam_tot.p, sizeof tot, hipMemcpyDeviceToHost));
+        }
+        out[0] = (uint64_t)(s->beam_ms_total * 1000.0 + 0.5); out[1] = s->beam_launches; out[2] = s->beam_queries;
+        out[3] = tot[0]; out[4] = tot[1]; out[5] = tot[2];
+    }
+    if (enable) {
+        if (!s->bev0) {
+            MSE_HIP_TRY(hipEventCreate(&s->bev0));
+            MSE_HIP_TRY(hipEventCreate(&s->bev1));
+        }
+        if (!s->beam_tot.p) {
+            if (s->beam_tot.ensure(64)) return -1;
+            MSE_HIP_TRY(hipMemset(s->beam_tot.p, 0, 64));
+        }
+        if (enable == 2) {
+            MSE_HIP_TRY(hipStreamSynchronize(s->stream));
+            MSE_HIP_TRY(hipMemset(s->beam_tot.p, 0, 64));
+            s->beam_ms_total = 0.0; s->beam_launches = 0; s->beam_queries = 0;
+        }
+    }
+    s->beam_timing = enable != 0;
     return 0;
 }
 

@@ -81,6 +81,14 @@ struct mse_searcher {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double scan_ms_total = 0.0;
     uint64_t scan_launches = 0;
+    // optional measurement of the graph search kernel (mse_searcher_beam_timing, for bench.py's gather roofline): HIP events around
+    // beam_search_kernel and device totals of what it gathered -- [0] rows scored exactly (2304-byte row gathers: fetched nodes and
+    // exactly scored neighbours), [1] fetched nodes (adjacency lists read), [2] neighbours scored by ADC (64-byte code gathers)
+    bool beam_timing = false;
+    hipEvent_t bev0 = nullptr, bev1 = nullptr;
+    double beam_ms_total = 0.0;
+    uint64_t beam_launches = 0, beam_queries = 0;
+    mse::DevBuf beam_tot;
     // event pairs of the PQ scan launches of one batch call (several per call on this searcher's stream), read when the call ends
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;

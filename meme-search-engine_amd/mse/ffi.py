@@ -168,6 +168,7 @@ SIGNATURES = {
     "mse_graph_set_coalescer": (C.c_int, [vp, sz, C.c_uint32, C.c_int]),
     "mse_graph_coalescer_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "mse_searcher_wait_stream": (C.c_int, [vp, vp]),
+    "mse_searcher_beam_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)]),
     "mse_debug_coalescer_selftest_workers": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mse_debug_coalescer_selftest_async": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mse_disk_query_topk": (C.c_int, [vp, vp, vp, vp, u32p, u16p, f32p, f32p, sz, C.c_int, sz, sz, sz, u32p, i64p, u32p, u32p, u32p]),
