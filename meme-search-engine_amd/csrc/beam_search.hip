@@ -30,6 +30,8 @@ using namespace mse;
 namespace {
 
 constexpr int BS_THREADS_MAX = 256;
+// calls of at most BS_SMALL_NQ queries run BS_SMALL_WAVES waves per query (latency: scripts/beam_latency_probe.py)
+constexpr int BS_SMALL_NQ = 0, BS_SMALL_WAVES = 4;
 constexpr int BS_LMAX = 1024;
 constexpr int BS_BEAM_MAX = 8;
 constexpr int BS_DEG_MAX = 128;   // merged indexes: up to SHARD_SPILL x R neighbours per node
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += p_cap * 4;
     int* s_rank = reinterpret_cast<int*>(p); p += p_cap * 4;
     uint32_t* s_hash = reinterpret_cast<uint32_t*>(p);   // [hash_slots]: first positions of the ids of one beam iteration's lists
-    __shared__ int s_len, s_next, s_npts, s_npre, s_ties, s_abort;
+    __shared__ int s_len, s_next, s_npts, s_npre, s_abort;
     __shared__ uint32_t s_pts[BS_BEAM_MAX];
     __shared__ int s_seg[BS_BEAM_MAX];
     __shared__ int s_visok[BS_BEAM_MAX];
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
 
     uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
     uint32_t n_adj = 1;                          // wave 0: ids inserted into visited_adjacent so far
-    bool ties = false;                           // wave 0: two different ids have met on one score (see the insert loop)
+    bool ties = false;                           // this iteration: equal scores inside the list, or met during the replay (see the insert loop)
     for (;;) {
         // ---- next_several_unvisited (:83-97 over NeighbourBuffer::next_unvisited, lib.rs:93-107) ----
         if (tid == 0) {
@@ -312,9 +314,16 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                     lo_[h] = lo; rn_[h] = rn; sc_[h] = sc;
                 }
             }
-            if (tid == 0) s_ties = ties ? 1 : 0;   // `ties` lives in wave 0; every wave needs the verdict
-            const int any_tie = __syncthreads_or(tie ? 1 : 0);
-            if (!any_tie && !s_ties) {
+            // Equal scores INSIDE the list (two ids that tied earlier and are both still in it, or a duplicate the re-offer quirk made):
+            // the list is sorted, so they are neighbours.  The reference's next state depends on the list as it is now, not on how it
+            // came about: once such a pair has left the list the merge below is exact again (round 6 -- the flag used to stick for the
+            // rest of the search, and with f32 scores on a 2^-24 grid ~40 % of the hard set's searches at L = 200 meet some tie among
+            // the ~10 000 neighbours they score, almost always between candidates that never enter the list).
+            bool list_tie = false;
+            for (int i = tid; i + 1 < len; i += BS_THREADS) list_tie |= nb_sc[i] == nb_sc[i + 1];
+            const int any_tie = __syncthreads_or((tie ? 1 : 0) | (list_tie ? 2 : 0));
+            ties = (any_tie & 2) != 0;   // what the replay below starts from (every wave computes it; wave 0 uses it)
+            if (!any_tie) {
                 merged = true;
 #pragma unroll
                 for (int h = 0; h < 4; h++)
@@ -826,8 +835,19 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
         a.totals = s->beam_tot.as<unsigned long long>();
         MSE_HIP_TRY(hipEventRecord(s->bev0, st));
     }
-    if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only && nq > 1024) {
+    // A handful of queries (the request handler's one query per call): the search is a chain of dependent round trips and most of the chip
+    // idles -- sixteen waves per query gather an iteration's ~200 neighbour rows in one round instead of three (round 6; same answers,
+    // counters included: the tiling of the loops is all that changes).  MSE_BEAM_WAVES=4 / 8 / 16 forces a form (answer-preserving hook).
+    static const int force_waves = [] { const char* e = getenv("MSE_BEAM_WAVES"); return e ? atoi(e) : 0; }();
+    const int small_waves = force_waves ? force_waves : (nq <= BS_SMALL_NQ ? BS_SMALL_WAVES : 4);
+    if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only && nq > 1024 && !force_waves) {
         hipLaunchKernelGGL(beam_search_kernel<64>, dim3((unsigned)nq), dim3(64), lds, st, a);
+    } else if (small_waves == 16) {
+        MSE_DYN_LDS(beam_search_kernel<1024>, 160 * 1024 - 1024);
+        hipLaunchKernelGGL(beam_search_kernel<1024>, dim3((unsigned)nq), dim3(1024), lds, st, a);
+    } else if (small_waves == 8) {
+        MSE_DYN_LDS(beam_search_kernel<512>, 160 * 1024 - 1024);
+        hipLaunchKernelGGL(beam_search_kernel<512>, dim3((unsigned)nq), dim3(512), lds, st, a);
     } else {
         MSE_DYN_LDS(beam_search_kernel<BS_THREADS_MAX>, 160 * 1024 - 1024);
         hipLaunchKernelGGL(beam_search_kernel<BS_THREADS_MAX>, dim3((unsigned)nq), dim3(BS_THREADS_MAX), lds, st, a);
