@@ -946,7 +946,7 @@ def main():
     ap.add_argument("--graph-batch", type=int, default=16384, help="points inserted per batch of the graph-scale build")
     ap.add_argument("--graph-entries", type=int, default=-1,
                     help="sampled entry points of the graph-scale search (0: the medioid alone; -1: max(4096, rows / 1500))")
-    ap.add_argument("--graph-kinds", default="easy,hard,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")
+    ap.add_argument("--graph-kinds", default="hard,easy,ood", help="synthetic sets of the graph-index leg (bench_ann.py): easy, hard, ood")
     ap.add_argument("--graph-1e8", action="store_true",
                     help="OPT-IN: the 1e8-row graph-index leg (a 10-13 minute build, guarded by --graph-1e8-budget); not part of the default command")
     ap.add_argument("--no-graph-1e8", action="store_true", help="accepted for older command lines; the leg is opt-in now (--graph-1e8)")

@@ -88,6 +88,7 @@ def flat_legs(full):
             put(f"graph_{kind}_{short}_qps", hh.get("queries_per_s"))
             put(f"graph_{kind}_{short}_recall", hh.get("recall_at_10"))
         put(f"graph_{kind}_pq_only_recall", row.get("pq_only_recall_at_10"))
+        put(f"graph_{kind}_pq_only_recall_untrained", row.get("pq_only_recall_at_10_untrained_codec"))
         put(f"graph_{kind}_build_s", g(row, "build", "seconds"))
         for p in g(row, "graph_callers", "points") or []:
             if p.get("threads") == 4096:

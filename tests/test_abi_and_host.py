@@ -273,7 +273,7 @@ DEV_KNOBS = ["MSE_SCAN_ABL", "MSE_SCAN_2D", "MSE_SCAN_S", "MSE_ATT_ABL", "MSE_AT
              "MSE_PQ_OLDTRANSFORM", "MSE_PQ_OLDQUANT", "MSE_PQ_OLDSCAN", "MSE_DEDUP_OLD"]
 # what the product build may still read from the environment: hooks under which every answer stays correct
 PRODUCT_HOOKS = {"MSE_BUILD_EXACT_BACKEDGE", "MSE_BUILD_EXACT_PRUNE", "MSE_GRAM_EPS_SCALE", "MSE_SHARD_NO_PEER", "MSE_SIGLIP_NOFUSE", "MSE_SIGLIP_NOSMALL", "MSE_COALESCE_NO_HOLD", "MSE_SIGLIP_TEXT_PARTS",
-                 "MSE_SIGLIP_STREAMS", "MSE_VISITED_BUDGET_KB", "MSE_VISITED_MODE", "MSE_VISITED_TABLE_BITS"}
+                 "MSE_SIGLIP_STREAMS", "MSE_BEAM_WAVES", "MSE_VISITED_BUDGET_KB", "MSE_VISITED_MODE", "MSE_VISITED_TABLE_BITS"}
 
 
 def test_product_library_reads_no_developer_knob(mse):
