@@ -481,10 +481,10 @@ int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
                               uint64_t id_offset, void* block_dev, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
 /* Measurement hook (bench.py's gather roofline for the graph search; no counterpart in the reference): HIP events around every
  * beam_search_kernel launch of this searcher + device totals of what the searches gathered.  enable: 0 off, 1 on, 2 on and reset.
- * out (optional, 6 words, read BEFORE `enable` takes effect): kernel microseconds, launches, queries, rows scored exactly (one
+ * out (optional, 8 words, read BEFORE `enable` takes effect): kernel microseconds, launches, queries, rows scored exactly (one
  * 2 x d-byte row gather each: fetched nodes and exactly scored neighbours), nodes fetched (one adjacency list each), neighbours
- * scored by ADC (one 64-byte code gather each). */
-int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[6]);
+ * scored by ADC (one 64-byte code gather each), beam iterations, iterations whose inserts ran sequentially (equal scores in play). */
+int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[8]);
 /* The handler's runtime de-duplication (src/query_disk_index.rs:482-527, DUPLICATES_THRESHOLD 0.95 :99) INSIDE mse_disk_query_topk(_f32)
  * and its block form: before the visited records are ordered, a record whose vector has a dot product above `threshold` with an ALREADY
  * KEPT record (f32 products of the f16 rows, summed k-ascending as mse_dedup_visited; visit order) is dropped -- for every query of the

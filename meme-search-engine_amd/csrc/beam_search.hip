@@ -131,6 +131,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     };
 
     uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
+    uint32_t n_iter = 0, n_replayed = 0;         // measurement only (a.totals): beam iterations, and those that took the sequential insert path
     uint32_t n_adj = 1;                          // wave 0: ids inserted into visited_adjacent so far
     bool ties = false;                           // this iteration: equal scores inside the list, or met during the replay (see the insert loop)
     for (;;) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         __syncthreads();
 
         // ---- all newcomers of this beam iteration at once ----
-        // While no two different ids share a score (`ties` is still false and nothing offered now equals anything), the
+        // While no score that can still enter the list equals another one in play (see `live` below), the
         // order of the inserts does not matter and re-offers change nothing: the list ends up as the best `cap` of old and
         // new entries, and next_unvisited as the smaller of its old value and the slot the best newcomer takes on arrival
         // (every other insert lands at or behind that slot).  Each thread places up to four newcomers by two counts -- old
@@ -290,6 +291,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         bool merged = false;
         if (cap > 0 && npre > 0) {
             const int len = s_len;
+            // A newcomer below the worst entry of a FULL list is rejected whatever the order of the inserts (the worst entry only ever
+            // rises): equal scores among such newcomers decide nothing.  Only a LIVE newcomer's equalities -- with a list entry or with
+            // another live newcomer -- make the order matter.  (With PQ codes this is the common case: neighbours far from the query that
+            // share their 64 code bytes have the same ADC score to the last bit.)
+            const bool full = len == cap;
+            const long long worst0 = full ? nb_sc[len - 1] : (long long)INT64_MIN;
             int lo_[4], rn_[4];
             long long sc_[4];
             bool tie = false;
@@ -299,30 +306,31 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                 lo_[h] = 0; rn_[h] = 0; sc_[h] = 0;
                 if (e < npre) {
                     const long long sc = pre_sc[e];
+                    const bool live = !(full && sc < worst0);
                     int lo = 0, hi = len;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
                         if (nb_sc[mid] > sc) lo = mid + 1; else hi = mid;
                     }
-                    tie |= lo < len && nb_sc[lo] == sc;
+                    tie |= live && lo < len && nb_sc[lo] == sc;
                     int rn = 0;
                     for (int k = 0; k < npre; k++) {
                         const long long sk = pre_sc[k];
-                        rn += sk > sc;
-                        tie |= k != e && sk == sc;
+                        // (equal scores: only among newcomers a full list rejects once the merge runs; the index keeps their ranks
+                        // distinct, so that every slot of s_rank is written)
+                        rn += (sk > sc || (sk == sc && k < e)) ? 1 : 0;
+                        tie |= live && k != e && sk == sc;
                     }
                     lo_[h] = lo; rn_[h] = rn; sc_[h] = sc;
                 }
             }
-            // Equal scores INSIDE the list (two ids that tied earlier and are both still in it, or a duplicate the re-offer quirk made):
-            // the list is sorted, so they are neighbours.  The reference's next state depends on the list as it is now, not on how it
-            // came about: once such a pair has left the list the merge below is exact again (round 6 -- the flag used to stick for the
-            // rest of the search, and with f32 scores on a 2^-24 grid ~40 % of the hard set's searches at L = 200 meet some tie among
-            // the ~10 000 neighbours they score, almost always between candidates that never enter the list).
-            bool list_tie = false;
-            for (int i = tid; i + 1 < len; i += BS_THREADS) list_tie |= nb_sc[i] == nb_sc[i + 1];
-            const int any_tie = __syncthreads_or((tie ? 1 : 0) | (list_tie ? 2 : 0));
-            ties = (any_tie & 2) != 0;   // what the replay below starts from (every wave computes it; wave 0 uses it)
+            // Equal scores that are already INSIDE the list (two ids that tied in an earlier iteration, or a duplicate the re-offer quirk
+            // made) do not matter either: the reference's next state depends on the list as it is and on this iteration's offers, and an
+            // offer whose own score is unique finds its slot, or its own copy, whatever sits elsewhere in the list.  (Round 6.  The flag
+            // used to stick for the rest of the search: with f32 scores on a 2^-24 grid ~40 % of the hard set's searches at L = 200 meet
+            // some tie among the ~10 000 neighbours they score, almost always between candidates that never enter the list.)
+            const int any_tie = __syncthreads_or(tie ? 1 : 0);
+            ties = false;   // what the replay below starts from: no equality has been met in THIS iteration's sequence yet
             if (!any_tie) {
                 merged = true;
 #pragma unroll
@@ -365,21 +373,35 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             }
         }
 
+        n_iter++;
+        n_replayed += (!merged && cap > 0 && npre > 0) ? 1u : 0u;
         // ---- NeighbourBuffer::insert (lib.rs:117-147) for every (node, pre-buffer entry) pair in the reference's order ----
         if (wave == 0 && !merged) {
             int len = s_len, nu = s_next;
             for (int j = 0; j < npts; j++) {
                 const int upto = s_seg[j];
                 const int fresh_from = j ? s_seg[j - 1] : 0;   // entries below this index were already offered by an earlier node
-                for (int ii = 0; ii < upto; ii++) {
-                    const uint32_t id = pre_id[ii];
-                    const long long sc = pre_sc[ii];
-                    if (!a.disable_pq) pq_cmps++;
-                    if (cap == 0) continue;
-                    // Re-offering an entry (the pre-buffer quirk) changes nothing while all scores in the list are distinct:
-                    // it is either still there (the search lands on it: same id, skipped), or it was rejected / pushed out by
-                    // strictly better entries and is rejected again.  Only once two different ids have tied on a score can a
-                    // re-offer land next to its copy and duplicate it, so from then on every offer is replayed in full.
+                if (!a.disable_pq) pq_cmps += (uint32_t)upto;   // every offer counts, re-offers and rejected ones included (:205)
+                if (cap == 0) continue;
+                // 64 offers at a time: the ones a full list rejects outright (score below its worst entry -- which only rises, so they are
+                // rejected at their turn too) are dropped together; the rest take their turn in the reference's order
+                for (int i0 = 0; i0 < upto; i0 += 64) {
+                    const int il = i0 + lane;
+                    const long long sc_l = il < upto ? pre_sc[il] : 0;
+                    const uint32_t id_l = il < upto ? pre_id[il] : 0u;
+                    const long long worst_now = len == cap ? nb_sc[len - 1] : (long long)INT64_MIN;
+                    unsigned long long todo = __ballot(il < upto && !(len == cap && worst_now > sc_l));
+                    while (todo) {
+                    const int bit = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int ii = i0 + bit;
+                    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)id_l, bit);
+                    const long long sc = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)sc_l >> 32), bit) << 32) |
+                                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(unsigned long long)sc_l, bit));
+                    // Re-offering an entry (the pre-buffer quirk) changes nothing while no equal scores have been met in this
+                    // iteration's sequence: it is either still there (the search lands on it: same id, skipped), or it was rejected /
+                    // pushed out by strictly better entries and is rejected again.  Only once two different ids have tied on a score
+                    // can a re-offer land next to its copy and duplicate it, so from then on every offer is replayed in full.
                     if (ii < fresh_from && !ties) continue;
                     if (len == cap && nb_sc[len - 1] > sc) continue;
                     int loc = 0;
@@ -426,6 +448,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                     if (lane == 0) { nb_id[loc] = id; nb_sc[loc] = sc; nb_vis[loc] = 0; }
                     len = newlen;
                     if (nu < 0 || loc < nu) nu = loc;
+                    }   // offers of this group of 64 that a full list does not reject outright
                 }
             }
             if (lane == 0) { s_len = len; s_next = nu; }
@@ -455,6 +478,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             atomicAdd(&a.totals[0], (unsigned long long)cmps + (a.disable_pq ? (unsigned long long)(n_adj - 1) : 0ull));
             atomicAdd(&a.totals[1], (unsigned long long)cmps);
             atomicAdd(&a.totals[2], a.disable_pq ? 0ull : (unsigned long long)(n_adj - 1));
+            atomicAdd(&a.totals[3], (unsigned long long)n_iter);
+            atomicAdd(&a.totals[4], (unsigned long long)n_replayed);
         }
     }
 }
@@ -1549,19 +1574,20 @@ int mse_graph_set_coalescer(mse_graph* g, size_t max_queries_per_pass, uint32_t 
 }
 
 // Measurement hook for bench.py's gather roofline: HIP events around every beam_search_kernel launch of this searcher and device totals
-// of what the searches gathered.  enable: 0 off, 1 on, 2 on + reset.  out (optional, 6 words): kernel ms x 1000 (integer microseconds),
-// launches, queries, rows scored exactly (2304-byte gathers at d = 1152), nodes fetched (adjacency lists), ADC-scored neighbours.
-int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[6]) {
+// of what the searches gathered.  enable: 0 off, 1 on, 2 on + reset.  out (optional, 8 words): kernel ms x 1000 (integer microseconds),
+// launches, queries, rows scored exactly (2304-byte gathers at d = 1152), nodes fetched (adjacency lists), ADC-scored neighbours,
+// beam iterations, beam iterations whose inserts were replayed sequentially (equal scores in play).
+int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[8]) {
     if (!s) return fail("null searcher");
     if (s->base) (void)hipSetDevice(s->base->device);
     if (out) {
-        unsigned long long tot[3] = {0, 0, 0};
+        unsigned long long tot[5] = {0, 0, 0, 0, 0};
         if (s->beam_tot.p) {
             MSE_HIP_TRY(hipStreamSynchronize(s->stream));
             MSE_HIP_TRY(hipMemcpy(tot, s->beam_tot.p, sizeof tot, hipMemcpyDeviceToHost));
         }
         out[0] = (uint64_t)(s->beam_ms_total * 1000.0 + 0.5); out[1] = s->beam_launches; out[2] = s->beam_queries;
-        out[3] = tot[0]; out[4] = tot[1]; out[5] = tot[2];
+        out[3] = tot[0]; out[4] = tot[1]; out[5] = tot[2]; out[6] = tot[3]; out[7] = tot[4];
     }
     if (enable) {
         if (!s->bev0) {

@@ -129,10 +129,10 @@ class Searcher:
         """Measurement hook of the graph search (mse_searcher_beam_timing): returns what has accumulated so far -- kernel_ms, launches,
         queries, rows_scored (2304-byte row gathers at d = 1152), nodes_fetched (adjacency lists), adc_scored (64-byte code gathers) --
         then sets the switch (0 off, 1 on, 2 on and reset)."""
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         check(ffi.lib().mse_searcher_beam_timing(self._h, int(enable), out), "beam_timing")
         return {"kernel_ms": out[0] / 1e3, "launches": int(out[1]), "queries": int(out[2]), "rows_scored": int(out[3]),
-                "nodes_fetched": int(out[4]), "adc_scored": int(out[5])}
+                "nodes_fetched": int(out[4]), "adc_scored": int(out[5]), "iterations": int(out[6]), "iterations_replayed": int(out[7])}
 
     def bruteforce_topk(self, queries, k, mode=MODE_AUTO):
         """Brute-force scan + ranking of `evaluate` (query_disk_index.rs:262-273) for a query batch.

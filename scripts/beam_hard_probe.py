@@ -54,5 +54,6 @@ print("queries/s %.0f (call %.2f ms), recall@10 %.4f, node fetches per query %.1
 print("beam_search_kernel: %d launches, %.3f ms each = %.0f queries/s of the kernel alone; per query %.1f rows scored exactly (%.1f KB of %d-byte row gathers) + %.1f adjacency lists (%.1f KB)"
       % (m["launches"], m["kernel_ms"] / m["launches"], m["queries"] / (m["kernel_ms"] * 1e-3), m["rows_scored"] / m["queries"], rows_b / m["queries"] / 1e3, ba.D * 2,
          m["nodes_fetched"] / m["queries"], adj_b / m["queries"] / 1e3), flush=True)
+print("beam iterations per query %.1f, of which replayed sequentially (equal scores in play) %.2f %%" % (m["iterations"] / m["queries"], 100.0 * m["iterations_replayed"] / max(1, m["iterations"])), flush=True)
 print("gather roofline: %.1f MB algorithmic per 4096-query launch / %.3f ms = %.0f GB/s = %.3f of the 8 TB/s HBM peak" %
       ((rows_b + adj_b) / m["launches"] / 1e6, m["kernel_ms"] / m["launches"], gbps, gbps / 8000.0), flush=True)
