@@ -67,15 +67,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lut_bytes = a.disable_pq ? 0 : 65536;   // the distance table is only needed when neighbours are scored by ADC
     float* s_lut = reinterpret_cast<float*>(smem);
-    uint16_t* s_q = reinterpret_cast<uint16_t*>(smem + lut_bytes);
-    char* p = smem + lut_bytes + ((a.d * 2 + 15) & ~15);
+    // ADC-scored searches (64 KiB of table per query) score only the few FETCHED nodes exactly: their query stays in global memory
+    // (L2-resident, four rows per iteration read it), so that two workgroups fit a CU up to search lists of ~760 (round 6; with the
+    // query in LDS and 4-byte visited flags the second workgroup was lost above L = 480: 143 k queries/s at L = 400 against 55 k at 600)
+    const int q_bytes = a.disable_pq ? ((a.d * 2 + 15) & ~15) : 0;
+    const uint16_t* const s_q = reinterpret_cast<const uint16_t*>(smem + lut_bytes);   // exact scoring: the query in LDS
+    const uint16_t* const g_q = a.queries + (size_t)blockIdx.x * a.d;                   // ADC scoring: the query where it lies
+    // (two call sites per use, so that each inlined copy of the dot product knows its address space: LDS reads stay ds_read)
+    char* p = smem + lut_bytes + q_bytes;
     // the list is sized by this call's search_list and the pre-buffer by its beam width, so that the usual settings
     // (L = 200, beam 4) leave room for two workgroups per CU next to their 64 KiB tables, eight without tables
     const size_t l_cap = (size_t)a.L, p_cap = (size_t)a.p_cap;
     long long* nb_sc = reinterpret_cast<long long*>(p); p += l_cap * 8;
     long long* pre_sc = reinterpret_cast<long long*>(p); p += p_cap * 8;
     uint32_t* nb_id = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
-    uint32_t* nb_vis = reinterpret_cast<uint32_t*>(p); p += l_cap * 4;
+    uint8_t* nb_vis = reinterpret_cast<uint8_t*>(p); p += (l_cap + 3) & ~(size_t)3;   // one byte per entry
     uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += p_cap * 4;
     int* s_rank = reinterpret_cast<int*>(p); p += p_cap * 4;
     uint32_t* s_hash = reinterpret_cast<uint32_t*>(p);   // [hash_slots]: first positions of the ids of one beam iteration's lists
@@ -96,8 +102,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     if (!a.disable_pq)
         for (int e = tid; e < 64 * 256 / 4; e += BS_THREADS)
             reinterpret_cast<float4*>(s_lut)[e] = reinterpret_cast<const float4*>(a.luts + qi * 16384)[e];
-    for (int e = tid; e < a.d / 8; e += BS_THREADS)
-        reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(a.queries + qi * a.d)[e];
+    if (a.disable_pq)
+        for (int e = tid; e < a.d / 8; e += BS_THREADS)
+            reinterpret_cast<uint4*>(smem + lut_bytes)[e] = reinterpret_cast<const uint4*>(a.queries + qi * a.d)[e];
     if (tid < BS_DESC_MAX) s_scales[tid] = (use_bias && tid < a.n_desc) ? a.scales[qi * a.n_desc + tid] : 0.0f;
     uint32_t start_by_entry = 0;
     if (a.entry_psc && wave == 0) {   // the best chunk of the entry step: larger score, lower row on ties
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         if (wave == 0) {
             const int qd = lane >> 2;
             const uint32_t pt = s_pts[qd < npts ? qd : npts - 1];
-            const float f = quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d);
+            const float f = a.disable_pq ? quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d) : quad_fast_dot_f32(a.base + (size_t)pt * a.d, g_q, a.d);
             if (qd < npts && (lane & 3) == 0) s_ptsc[qd] = scale_dot_result(f) + bias(pt);
         }
         __syncthreads();
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                 __syncthreads();
 #pragma unroll
                 for (int c = 0; c < 4; c++)
-                    if (onp[c] >= 0) { nb_sc[onp[c]] = osc[c]; nb_id[onp[c]] = oid[c]; nb_vis[onp[c]] = ovis[c]; }
+                    if (onp[c] >= 0) { nb_sc[onp[c]] = osc[c]; nb_id[onp[c]] = oid[c]; nb_vis[onp[c]] = (uint8_t)ovis[c]; }
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     const int e = tid + h * BS_THREADS, pos = lo_[h] + rn_[h];
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                         uint32_t mi = 0, mv = 0;
                         long long ms = 0;
                         if (act) { mi = nb_id[idx - 1]; ms = nb_sc[idx - 1]; mv = nb_vis[idx - 1]; }
-                        if (act) { nb_id[idx] = mi; nb_sc[idx] = ms; nb_vis[idx] = mv; }
+                        if (act) { nb_id[idx] = mi; nb_sc[idx] = ms; nb_vis[idx] = (uint8_t)mv; }
                     }
                     if (lane == 0) { nb_id[loc] = id; nb_sc[loc] = sc; nb_vis[loc] = 0; }
                     len = newlen;
@@ -850,7 +857,10 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     size_t hash_slots = 64;
     while (hash_slots < 2 * p_cap) hash_slots *= 2;
     a.hash_slots = (int)hash_slots;
-    const size_t lds = (disable_pq ? 0 : 65536) + ((d * 2 + 15) & ~(size_t)15) + search_list * 16 + p_cap * 16 + hash_slots * 4;
+    // (beam_search_kernel's carving: table | query (exact scoring only) | list scores, pre-buffer scores, list ids, visited flags (one
+    // byte each), pre-buffer ids, ranks | first-position table)
+    const size_t lds = (disable_pq ? 0 : 65536) + (disable_pq ? ((d * 2 + 15) & ~(size_t)15) : 0) + search_list * 12 + ((search_list + 3) & ~(size_t)3) +
+                       p_cap * 16 + hash_slots * 4;
     static const bool wide_only = MSE_DEV_KNOB("MSE_BEAM_FOUR_WAVES");   // developer library: the four-wave form for every search
     // one wave per query once the batch fills the chip on its own (16 queries per CU); a smaller batch is latency-bound, and four waves
     // finish a search sooner (round 5, scripts/beam_latency_probe.py, hard set: 64 queries at L = 12 0.40 ms against 0.98, at L = 200
