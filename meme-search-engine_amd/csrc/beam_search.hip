@@ -85,7 +85,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     uint32_t* pre_id = reinterpret_cast<uint32_t*>(p); p += p_cap * 4;
     int* s_rank = reinterpret_cast<int*>(p); p += p_cap * 4;
     uint32_t* s_hash = reinterpret_cast<uint32_t*>(p);   // [hash_slots]: first positions of the ids of one beam iteration's lists
-    __shared__ int s_len, s_next, s_npts, s_npre, s_abort;
+    __shared__ int s_len, s_next, s_npts, s_npre, s_abort, s_nlive;
     __shared__ uint32_t s_pts[BS_BEAM_MAX];
     __shared__ int s_seg[BS_BEAM_MAX];
     __shared__ int s_visok[BS_BEAM_MAX];
@@ -139,25 +139,48 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
 
     uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
     uint32_t n_iter = 0, n_replayed = 0;         // measurement only (a.totals): beam iterations, and those that took the sequential insert path
+#ifdef MSE_BEAM_PHASES   // TEMPORARY probe build: 100 MHz wall-clock ticks per phase of an iteration, thread 0
+    unsigned long long ph_t = 0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PHASE_STAMP(K) do { if (a.totals && tid == 0) { const unsigned long long now_ = wall_clock64(); ph_acc[K] += now_ - ph_t; ph_t = now_; } } while (0)
+#else
+#define PHASE_STAMP(K) do { } while (0)
+#endif
     uint32_t n_adj = 1;                          // wave 0: ids inserted into visited_adjacent so far
     bool ties = false;                           // this iteration: equal scores inside the list, or met during the replay (see the insert loop)
     for (;;) {
+#ifdef MSE_BEAM_PHASES
+        if (a.totals && tid == 0) ph_t = wall_clock64();
+#endif
         // ---- next_several_unvisited (:83-97 over NeighbourBuffer::next_unvisited, lib.rs:93-107) ----
-        if (tid == 0) {
-            int n = 0, nu = s_next;
+        // The first `beam` unvisited entries from next_unvisited on, in list order, and the one after them as the new next_unvisited:
+        // 64 flags per step by wave 0 (round 6: one thread walking the flags cost 2-4 us of every iteration -- each step an LDS round trip).
+        // With exactly scored neighbours an entry's list score IS its exact score + bias (same dot product, same rows), so the
+        // record of the visited list needs no second gather of the row -- except for the entry point, which enters with score 0 (:153).
+        if (wave == 0) {
+            int n = 0, nu = -1, g0 = s_next;
             const int len = s_len;
-            while (n < a.beam && nu >= 0) {
-                const int cur = nu;
-                nb_vis[cur] = 1;
-                int c = cur;
-                while (c < len && nb_vis[c]) c++;
-                nu = c == len ? -1 : c;
-                s_pts[n++] = nb_id[cur];
+            bool done = g0 < 0;
+            while (!done) {
+                const int idx = g0 + lane;
+                unsigned long long m = __ballot(idx < len && !nb_vis[idx]);
+                while (m) {
+                    const int at = g0 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (n < a.beam) {
+                        if (lane == 0) { s_pts[n] = nb_id[at]; s_ptsc[n] = nb_sc[at]; nb_vis[at] = 1; }
+                        n++;
+                    } else {
+                        nu = at;
+                        done = true;
+                        break;
+                    }
+                }
+                if (!done) { g0 += 64; done = g0 >= len; }
             }
-            s_next = nu;
-            s_npts = n;
+            if (lane == 0) { s_next = nu; s_npts = n; }
         }
         __syncthreads();
+        PHASE_STAMP(1);
         const int npts = s_npts;
         if (npts == 0 || s_abort) break;
 
@@ -186,13 +209,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             const bool url = !a.has_url || a.has_url[pt];
             s_visok[tid] = (first && visited_insert(bm_vis, a.hash_bits, pt) && url) ? 1 : 0;
         }
-        if (wave == 0) {
+        if (wave == 0 && (!a.disable_pq || n_iter == 0)) {   // (exactly scored searches: s_ptsc was taken from the list above)
             const int qd = lane >> 2;
             const uint32_t pt = s_pts[qd < npts ? qd : npts - 1];
             const float f = a.disable_pq ? quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d) : quad_fast_dot_f32(a.base + (size_t)pt * a.d, g_q, a.d);
             if (qd < npts && (lane & 3) == 0) s_ptsc[qd] = scale_dot_result(f) + bias(pt);
         }
         __syncthreads();
+        PHASE_STAMP(2);
 
         // ---- fresh neighbours (:171-188).  The reference walks the nodes in fetch order and offers every neighbour to
         // `visited_adjacent`: an id enters the pre-buffer at its FIRST position in the concatenated lists, if the set did not hold it
@@ -210,6 +234,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             }
         }
         __syncthreads();
+        PHASE_STAMP(3);
         // ... then ONE round of set inserts for the first positions, all lanes at once
         for (int e = tid; e < ncat; e += BS_THREADS) {
             const uint32_t id = s_cat[e];
@@ -223,6 +248,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             s_fresh[e] = fresh;
         }
         __syncthreads();
+        PHASE_STAMP(4);
         // ... and the pre-buffer in list order; s_seg[j] = entries up to and including node j's; the visited list in fetch order
         if (wave == 0) {
             int npre = 0, jb = 0;
@@ -240,6 +266,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             }
             if (lane == 0) {
                 s_npre = npre;
+                s_nlive = 0;
                 for (int j = 0; j < npts; j++) {
                     cmps++;
                     if (s_visok[j]) {
@@ -258,6 +285,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             }
         }
         __syncthreads();
+        PHASE_STAMP(5);
 
         // ---- scores of the pre-buffer (:189-203): ADC + bias, or exact + bias with disable_pq ----
         const int npre = s_npre;
@@ -287,6 +315,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             }
         }
         __syncthreads();
+        PHASE_STAMP(6);
 
         // ---- all newcomers of this beam iteration at once ----
         // While no score that can still enter the list equals another one in play (see `live` below), the
@@ -304,31 +333,48 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             // share their 64 code bytes have the same ADC score to the last bit.)
             const bool full = len == cap;
             const long long worst0 = full ? nb_sc[len - 1] : (long long)INT64_MIN;
-            int lo_[4], rn_[4];
+            // Round 6: only the live newcomers are ranked.  Once the list is full -- after the first two or three iterations -- a handful
+            // of an iteration's ~150 newcomers can still enter it; ranking every newcomer against every other one was ~1400 LDS reads per
+            // wave and iteration (a quarter of the one-wave kernel's time, a third of the four-wave kernel's).  The live ones' scores
+            // are compacted into the (idle) first-position table; their order there does not matter: ranks of distinct scores.
+            long long* const s_lsc = reinterpret_cast<long long*>(s_hash);   // [<= p_cap] (hash_slots >= 2 p_cap words)
+            int lo_[4], rn_[4], slot_[4];
             long long sc_[4];
-            bool tie = false;
+            bool live_[4];
 #pragma unroll
             for (int h = 0; h < 4; h++) {
                 const int e = tid + h * BS_THREADS;
-                lo_[h] = 0; rn_[h] = 0; sc_[h] = 0;
+                lo_[h] = 0; rn_[h] = 0; sc_[h] = 0; slot_[h] = 0; live_[h] = false;
                 if (e < npre) {
                     const long long sc = pre_sc[e];
-                    const bool live = !(full && sc < worst0);
+                    sc_[h] = sc;
+                    live_[h] = !(full && sc < worst0);
+                    if (live_[h]) {
+                        slot_[h] = atomicAdd(&s_nlive, 1);
+                        s_lsc[slot_[h]] = sc;
+                    }
+                }
+            }
+            __syncthreads();
+            const int nlive = s_nlive;
+            bool tie = false;
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                if (live_[h]) {
+                    const long long sc = sc_[h];
                     int lo = 0, hi = len;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
                         if (nb_sc[mid] > sc) lo = mid + 1; else hi = mid;
                     }
-                    tie |= live && lo < len && nb_sc[lo] == sc;
+                    tie |= lo < len && nb_sc[lo] == sc;
                     int rn = 0;
-                    for (int k = 0; k < npre; k++) {
-                        const long long sk = pre_sc[k];
-                        // (equal scores: only among newcomers a full list rejects once the merge runs; the index keeps their ranks
-                        // distinct, so that every slot of s_rank is written)
-                        rn += (sk > sc || (sk == sc && k < e)) ? 1 : 0;
-                        tie |= live && k != e && sk == sc;
+                    for (int k = 0; k < nlive; k++) {
+                        const long long sk = s_lsc[k];
+                        rn += sk > sc ? 1 : 0;
+                        tie |= k != slot_[h] && sk == sc;
                     }
-                    lo_[h] = lo; rn_[h] = rn; sc_[h] = sc;
+                    lo_[h] = lo; rn_[h] = rn;
                 }
             }
             // Equal scores that are already INSIDE the list (two ids that tied in an earlier iteration, or a duplicate the re-offer quirk
@@ -342,7 +388,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                 merged = true;
 #pragma unroll
                 for (int h = 0; h < 4; h++)
-                    if (tid + h * BS_THREADS < npre) s_rank[rn_[h]] = lo_[h];
+                    if (live_[h]) s_rank[rn_[h]] = lo_[h];
                 __syncthreads();
                 long long osc[4];
                 uint32_t oid[4], ovis[4];
@@ -351,9 +397,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                 for (int c = 0; c < 4; c++) {
                     const int i = tid + c * BS_THREADS;
                     onp[c] = -1;
-                    if (i < len) {
+                    if (i < len && nlive > 0) {
                         osc[c] = nb_sc[i]; oid[c] = nb_id[i]; ovis[c] = nb_vis[i];
-                        int a0 = 0, b0 = npre;
+                        int a0 = 0, b0 = nlive;
                         while (a0 < b0) {
                             const int mid = (a0 + b0) >> 1;
                             if (s_rank[mid] <= i) a0 = mid + 1; else b0 = mid;
@@ -368,12 +414,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     const int e = tid + h * BS_THREADS, pos = lo_[h] + rn_[h];
-                    if (e < npre && pos < cap) { nb_sc[pos] = sc_[h]; nb_id[pos] = pre_id[e]; nb_vis[pos] = 0; }
+                    if (live_[h] && pos < cap) { nb_sc[pos] = sc_[h]; nb_id[pos] = pre_id[e]; nb_vis[pos] = 0; }
                 }
                 if (tid == 0) {
-                    const int first = s_rank[0], nu = s_next;
-                    if (first < cap && (nu < 0 || first < nu)) s_next = first;
-                    s_len = len + npre < cap ? len + npre : cap;
+                    if (nlive > 0) {
+                        const int first = s_rank[0], nu = s_next;
+                        if (first < cap && (nu < 0 || first < nu)) s_next = first;
+                    }
+                    s_len = len + nlive < cap ? len + nlive : cap;
                     if (!a.disable_pq)
                         for (int j = 0; j < npts; j++) pq_cmps += (uint32_t)s_seg[j];   // every offer counts, re-offers included (:205)
                 }
@@ -461,6 +509,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             if (lane == 0) { s_len = len; s_next = nu; }
         }
         __syncthreads();
+        PHASE_STAMP(7);
     }
 
     const int len = s_len;
@@ -487,6 +536,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             atomicAdd(&a.totals[2], a.disable_pq ? 0ull : (unsigned long long)(n_adj - 1));
             atomicAdd(&a.totals[3], (unsigned long long)n_iter);
             atomicAdd(&a.totals[4], (unsigned long long)n_replayed);
+#ifdef MSE_BEAM_PHASES
+            for (int k_ = 1; k_ < 8; k_++) atomicAdd(&a.totals[4 + k_], ph_acc[k_]);
+#endif
         }
     }
 }
@@ -1591,13 +1643,16 @@ int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[8]) {
     if (!s) return fail("null searcher");
     if (s->base) (void)hipSetDevice(s->base->device);
     if (out) {
-        unsigned long long tot[5] = {0, 0, 0, 0, 0};
+        unsigned long long tot[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (s->beam_tot.p) {
             MSE_HIP_TRY(hipStreamSynchronize(s->stream));
             MSE_HIP_TRY(hipMemcpy(tot, s->beam_tot.p, sizeof tot, hipMemcpyDeviceToHost));
         }
         out[0] = (uint64_t)(s->beam_ms_total * 1000.0 + 0.5); out[1] = s->beam_launches; out[2] = s->beam_queries;
         out[3] = tot[0]; out[4] = tot[1]; out[5] = tot[2]; out[6] = tot[3]; out[7] = tot[4];
+#ifdef MSE_BEAM_PHASES   // probe build: the caller passes 16 words
+        for (int k_ = 0; k_ < 7; k_++) out[8 + k_] = tot[5 + k_];
+#endif
     }
     if (enable) {
         if (!s->bev0) {
@@ -1605,12 +1660,12 @@ int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[8]) {
             MSE_HIP_TRY(hipEventCreate(&s->bev1));
         }
         if (!s->beam_tot.p) {
-            if (s->beam_tot.ensure(64)) return -1;
-            MSE_HIP_TRY(hipMemset(s->beam_tot.p, 0, 64));
+            if (s->beam_tot.ensure(128)) return -1;
+            MSE_HIP_TRY(hipMemset(s->beam_tot.p, 0, 128));
         }
         if (enable == 2) {
             MSE_HIP_TRY(hipStreamSynchronize(s->stream));
-            MSE_HIP_TRY(hipMemset(s->beam_tot.p, 0, 64));
+            MSE_HIP_TRY(hipMemset(s->beam_tot.p, 0, 128));
             s->beam_ms_total = 0.0; s->beam_launches = 0; s->beam_queries = 0;
         }
     }
