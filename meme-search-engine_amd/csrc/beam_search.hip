@@ -61,16 +61,20 @@ struct BeamArgs {
 // pre-buffer <= 256.  The search is a chain of dependent round trips (82 % of the wave-cycles of the four-wave form were waits,
 // profiles/r04_beam_search_pmc.txt) and three of its four waves idle through the sequential parts; one wave per query puts 16
 // queries on a CU instead of 3.
-template <int THREADS>
+// ADC: neighbours scored through the query's distance table (the reference's default); false: exactly (disable_pq).  Two kernels, so
+// that each keeps only its own scoring code and its own register budget (the ADC form runs two workgroups per CU whatever it uses:
+// its fetched rows' exact scores take all 36 loads of a row in flight at once -- one round trip instead of three, round 6).
+template <int THREADS, bool ADC>
 __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_kernel(BeamArgs a) {
+    constexpr bool EXACT = !ADC;   // = EXACT
     constexpr int BS_THREADS = THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lut_bytes = a.disable_pq ? 0 : 65536;   // the distance table is only needed when neighbours are scored by ADC
+    const int lut_bytes = EXACT ? 0 : 65536;   // the distance table is only needed when neighbours are scored by ADC
     float* s_lut = reinterpret_cast<float*>(smem);
     // ADC-scored searches (64 KiB of table per query) score only the few FETCHED nodes exactly: their query stays in global memory
     // (L2-resident, four rows per iteration read it), so that two workgroups fit a CU up to search lists of ~760 (round 6; with the
     // query in LDS and 4-byte visited flags the second workgroup was lost above L = 480: 143 k queries/s at L = 400 against 55 k at 600)
-    const int q_bytes = a.disable_pq ? ((a.d * 2 + 15) & ~15) : 0;
+    const int q_bytes = EXACT ? ((a.d * 2 + 15) & ~15) : 0;
     const uint16_t* const s_q = reinterpret_cast<const uint16_t*>(smem + lut_bytes);   // exact scoring: the query in LDS
     const uint16_t* const g_q = a.queries + (size_t)blockIdx.x * a.d;                   // ADC scoring: the query where it lies
     // (two call sites per use, so that each inlined copy of the dot product knows its address space: LDS reads stay ds_read)
@@ -99,10 +103,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
     uint32_t* bm_vis = a.bm_vis + qi * a.bm_words;
     const bool use_bias = a.scales && a.desc && a.n_desc > 0;
 
-    if (!a.disable_pq)
+    if (!EXACT)
         for (int e = tid; e < 64 * 256 / 4; e += BS_THREADS)
             reinterpret_cast<float4*>(s_lut)[e] = reinterpret_cast<const float4*>(a.luts + qi * 16384)[e];
-    if (a.disable_pq)
+    if (EXACT)
         for (int e = tid; e < a.d / 8; e += BS_THREADS)
             reinterpret_cast<uint4*>(smem + lut_bytes)[e] = reinterpret_cast<const uint4*>(a.queries + qi * a.d)[e];
     if (tid < BS_DESC_MAX) s_scales[tid] = (use_bias && tid < a.n_desc) ? a.scales[qi * a.n_desc + tid] : 0.0f;
@@ -209,10 +213,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             const bool url = !a.has_url || a.has_url[pt];
             s_visok[tid] = (first && visited_insert(bm_vis, a.hash_bits, pt) && url) ? 1 : 0;
         }
-        if (wave == 0 && (!a.disable_pq || n_iter == 0)) {   // (exactly scored searches: s_ptsc was taken from the list above)
+        if (wave == 0 && (!EXACT || n_iter == 0)) {   // (exactly scored searches: s_ptsc was taken from the list above)
             const int qd = lane >> 2;
             const uint32_t pt = s_pts[qd < npts ? qd : npts - 1];
-            const float f = a.disable_pq ? quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d) : quad_fast_dot_f32(a.base + (size_t)pt * a.d, g_q, a.d);
+            const float f = EXACT ? quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d) : quad_fast_dot_f32<18>(a.base + (size_t)pt * a.d, g_q, a.d);
             if (qd < npts && (lane & 3) == 0) s_ptsc[qd] = scale_dot_result(f) + bias(pt);
         }
         __syncthreads();
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
 
         // ---- scores of the pre-buffer (:189-203): ADC + bias, or exact + bias with disable_pq ----
         const int npre = s_npre;
-        if (!a.disable_pq) {
+        if constexpr (ADC) {
             for (int e = tid; e < npre; e += BS_THREADS) {
                 const uint32_t id = pre_id[e];
                 const uint4* cp = reinterpret_cast<const uint4*>(a.codes + (size_t)id * 64);
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
                         if (first < cap && (nu < 0 || first < nu)) s_next = first;
                     }
                     s_len = len + nlive < cap ? len + nlive : cap;
-                    if (!a.disable_pq)
+                    if (!EXACT)
                         for (int j = 0; j < npts; j++) pq_cmps += (uint32_t)s_seg[j];   // every offer counts, re-offers included (:205)
                 }
             }
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             for (int j = 0; j < npts; j++) {
                 const int upto = s_seg[j];
                 const int fresh_from = j ? s_seg[j - 1] : 0;   // entries below this index were already offered by an earlier node
-                if (!a.disable_pq) pq_cmps += (uint32_t)upto;   // every offer counts, re-offers and rejected ones included (:205)
+                if (!EXACT) pq_cmps += (uint32_t)upto;   // every offer counts, re-offers and rejected ones included (:205)
                 if (cap == 0) continue;
                 // 64 offers at a time: the ones a full list rejects outright (score below its worst entry -- which only rises, so they are
                 // rejected at their turn too) are dropped together; the rest take their turn in the reference's order
@@ -531,9 +535,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         a.cmps[qi] = cmps;
         a.pq_cmps[qi] = pq_cmps;
         if (a.totals) {   // measurement only: what this search gathered (n_adj - 1 = neighbours that entered a pre-buffer)
-            atomicAdd(&a.totals[0], (unsigned long long)cmps + (a.disable_pq ? (unsigned long long)(n_adj - 1) : 0ull));
+            atomicAdd(&a.totals[0], (unsigned long long)cmps + (EXACT ? (unsigned long long)(n_adj - 1) : 0ull));
             atomicAdd(&a.totals[1], (unsigned long long)cmps);
-            atomicAdd(&a.totals[2], a.disable_pq ? 0ull : (unsigned long long)(n_adj - 1));
+            atomicAdd(&a.totals[2], EXACT ? 0ull : (unsigned long long)(n_adj - 1));
             atomicAdd(&a.totals[3], (unsigned long long)n_iter);
             atomicAdd(&a.totals[4], (unsigned long long)n_replayed);
 #ifdef MSE_BEAM_PHASES
@@ -928,16 +932,31 @@ static int disk_search_batch_impl(int visited_mode, mse_searcher* s, mse_pq* pq,
     static const int force_waves = [] { const char* e = getenv("MSE_BEAM_WAVES"); return e ? atoi(e) : 0; }();
     const int small_waves = force_waves ? force_waves : (nq <= BS_SMALL_NQ ? BS_SMALL_WAVES : 4);
     if (disable_pq && search_list <= 256 && p_cap <= 256 && !wide_only && nq > 1024 && !force_waves) {
-        hipLaunchKernelGGL(beam_search_kernel<64>, dim3((unsigned)nq), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((beam_search_kernel<64, false>), dim3((unsigned)nq), dim3(64), lds, st, a);
     } else if (small_waves == 16) {
-        MSE_DYN_LDS(beam_search_kernel<1024>, 160 * 1024 - 1024);
-        hipLaunchKernelGGL(beam_search_kernel<1024>, dim3((unsigned)nq), dim3(1024), lds, st, a);
+        if (disable_pq) {
+            MSE_DYN_LDS((beam_search_kernel<1024, false>), 160 * 1024 - 1024);
+            hipLaunchKernelGGL((beam_search_kernel<1024, false>), dim3((unsigned)nq), dim3(1024), lds, st, a);
+        } else {
+            MSE_DYN_LDS((beam_search_kernel<1024, true>), 160 * 1024 - 1024);
+            hipLaunchKernelGGL((beam_search_kernel<1024, true>), dim3((unsigned)nq), dim3(1024), lds, st, a);
+        }
     } else if (small_waves == 8) {
-        MSE_DYN_LDS(beam_search_kernel<512>, 160 * 1024 - 1024);
-        hipLaunchKernelGGL(beam_search_kernel<512>, dim3((unsigned)nq), dim3(512), lds, st, a);
+        if (disable_pq) {
+            MSE_DYN_LDS((beam_search_kernel<512, false>), 160 * 1024 - 1024);
+            hipLaunchKernelGGL((beam_search_kernel<512, false>), dim3((unsigned)nq), dim3(512), lds, st, a);
+        } else {
+            MSE_DYN_LDS((beam_search_kernel<512, true>), 160 * 1024 - 1024);
+            hipLaunchKernelGGL((beam_search_kernel<512, true>), dim3((unsigned)nq), dim3(512), lds, st, a);
+        }
     } else {
-        MSE_DYN_LDS(beam_search_kernel<BS_THREADS_MAX>, 160 * 1024 - 1024);
-        hipLaunchKernelGGL(beam_search_kernel<BS_THREADS_MAX>, dim3((unsigned)nq), dim3(BS_THREADS_MAX), lds, st, a);
+        if (disable_pq) {
+            MSE_DYN_LDS((beam_search_kernel<BS_THREADS_MAX, false>), 160 * 1024 - 1024);
+            hipLaunchKernelGGL((beam_search_kernel<BS_THREADS_MAX, false>), dim3((unsigned)nq), dim3(BS_THREADS_MAX), lds, st, a);
+        } else {
+            MSE_DYN_LDS((beam_search_kernel<BS_THREADS_MAX, true>), 160 * 1024 - 1024);
+            hipLaunchKernelGGL((beam_search_kernel<BS_THREADS_MAX, true>), dim3((unsigned)nq), dim3(BS_THREADS_MAX), lds, st, a);
+        }
     }
     MSE_HIP_TRY(hipGetLastError());
     if (timed) MSE_HIP_TRY(hipEventRecord(s->bev1, st));

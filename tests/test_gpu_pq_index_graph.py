@@ -1070,6 +1070,50 @@ def test_text_embedding_handed_to_the_search_on_the_device(gpu, mse, orc):
     eng.close()
 
 
+def test_search_measurement_hook_counts_what_the_searches_gathered(gpu, mse, orc):
+    """mse_searcher_beam_timing (bench.py's gather roofline): the kernel's own totals agree with the per-query counters the call returns
+    -- fetched nodes = sum of cmps; with ADC-scored neighbours every neighbour that entered a pre-buffer is one code gather and only the
+    fetched nodes are scored exactly; with exactly scored neighbours every one of them is a row gather too -- and the hook changes no
+    answer.  Iterations >= fetched nodes / beam; the sequential insert path is the exception, not the rule."""
+    rng = np.random.default_rng(91)
+    n, deg, nq, k, L, beam = 4000, 12, 48, 10, 40, 4
+    x = clustered_rows(orc, n, n_centres=32)
+    base = orc.f16_bits(x)
+    adj, degs = knn_graph(x, deg, rng)
+    vecs = mse.VectorList.from_f16s(base, D)
+    searcher = mse.Searcher(vecs)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    mse.set_entries(dgraph, vecs, np.sort(rng.choice(n, 64, replace=False)).astype(np.uint32))
+    q32 = clustered_rows(orc, nq, n_centres=32, seed=5).astype(np.float32)
+    plain = mse.disk_query_topk(searcher, None, None, dgraph, q32, k, None, None, None, True, beam, L)
+    assert searcher.beam_timing(2)["launches"] == 0                     # nothing was measured while the hook was off
+    got = mse.disk_query_topk(searcher, None, None, dgraph, q32, k, None, None, None, True, beam, L)
+    m = searcher.beam_timing(0)
+    assert np.array_equal(got[0], plain[0]) and np.array_equal(got[1], plain[1])
+    for key in ("cmps", "n_visited", "pq_cmps"):
+        assert np.array_equal(got[2][key], plain[2][key])
+    assert m["launches"] >= 1 and m["queries"] == nq and m["kernel_ms"] > 0
+    assert m["nodes_fetched"] == int(got[2]["cmps"].sum())
+    assert m["adc_scored"] == 0 and m["rows_scored"] > m["nodes_fetched"]
+    assert m["rows_scored"] - m["nodes_fetched"] <= m["nodes_fetched"] * deg             # at most every neighbour of every fetched node
+    assert m["iterations"] * beam >= m["nodes_fetched"] and m["iterations_replayed"] <= m["iterations"]
+    after = mse.disk_query_topk(searcher, None, None, dgraph, q32, k, None, None, None, True, beam, L)
+    assert searcher.beam_timing(0)["launches"] == m["launches"]        # off again: the totals stand still
+    assert np.array_equal(after[0], plain[0])
+    # the reference's default: neighbours scored by ADC (random codec: the counters are what is looked at)
+    cents = (rng.standard_normal((256, D)) / np.sqrt(D)).astype(np.float32)
+    T = np.linalg.qr(rng.standard_normal((D, D)))[0].astype(np.float32)
+    pq = mse.ProductQuantizer(cents, T, 18, D)
+    codes = mse.Codes(pq.quantize_batch(x.astype(np.float32)), None)
+    plain = mse.disk_query_topk(searcher, pq, codes, dgraph, q32, k, None, None, None, False, beam, L)
+    searcher.beam_timing(2)
+    got = mse.disk_query_topk(searcher, pq, codes, dgraph, q32, k, None, None, None, False, beam, L)
+    m = searcher.beam_timing(0)
+    assert np.array_equal(got[0], plain[0]) and np.array_equal(got[1], plain[1]) and np.array_equal(got[2]["pq_cmps"], plain[2]["pq_cmps"])
+    assert m["nodes_fetched"] == int(got[2]["cmps"].sum()) and m["rows_scored"] == m["nodes_fetched"]
+    assert 0 < m["adc_scored"] <= int(got[2]["pq_cmps"].sum())          # pq_cmps also counts the re-offers of the pre-buffer quirk
+
+
 def test_entry_step_small_and_large_batches_agree(gpu, mse, orc):
     """The row-table entry step has two forms -- two launches of exact dots for a small batch, the brute-force searcher's matrix-core
     path for a large one (nq x entries beyond 2^22) -- and both are the exact top-1 with ties to the lower row: a large batch, the
