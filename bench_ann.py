@@ -316,9 +316,10 @@ def train_codec_aopq(samp, queries, rounds=3, iters=120, lr=5e-4, seed=4, kmeans
             opt.zero_grad(set_to_none=True)
             tot = 0.0
             for i in range(0, n, 32768):
-                r = xr[i:i + 32768] - assign_quant(xr[i:i + 32768])
-                loss = ((r @ Lh) ** 2).sum() / n
-                loss.backward()
+                with torch.enable_grad():      # (a caller may have switched autograd off globally: the towers' code does)
+                    r = xr[i:i + 32768] - assign_quant(xr[i:i + 32768])
+                    loss = ((r @ Lh) ** 2).sum() / n
+                    loss.backward()
                 tot += float(loss.detach())
             opt.step()
             if it == 0 or it == iters - 1:
