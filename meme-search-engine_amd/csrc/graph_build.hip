@@ -298,21 +298,22 @@ __global__ __launch_bounds__(GS_THREADS) void graph_search_kernel(GraphArgs a) {
         for (int e = tid; e < d / 8; e += GS_THREADS) reinterpret_cast<uint4*>(s_q)[e] = reinterpret_cast<const uint4*>(qsrc)[e];
     }
     __syncthreads();
-    // NeighbourBuffer::next_unvisited (lib.rs:93-107) by lane 0 of wave 0; s_pt = the node to expand or -1
+    // NeighbourBuffer::next_unvisited (lib.rs:93-107) by wave 0, 64 visited flags per step (round 6: one lane walking the flags paid an
+    // LDS round trip per entry); s_pt = the node to expand or -1
     auto pop = [&]() {
-        if (lane == 0) {
-            const int cur = s_next;
-            if (cur >= 0) {
-                const int len = s_len;
-                nb_vis[cur] = 1;
-                int c = cur;
-                while (c < len && nb_vis[c]) c++;
-                s_next = c == len ? -1 : c;
-                s_pt = (int)nb_id[cur];
-            } else {
-                s_pt = -1;
+        const int cur = s_next;
+        int pt = -1, nxt = -1;
+        if (cur >= 0) {
+            const int len = s_len;
+            pt = (int)nb_id[cur];
+            for (int g0 = cur + 1; g0 < len; g0 += 64) {
+                const int idx = g0 + lane;
+                const unsigned long long m = __ballot(idx < len && !nb_vis[idx]);
+                if (m) { nxt = g0 + __ffsll((long long)m) - 1; break; }
             }
+            if (lane == 0) nb_vis[cur] = 1;
         }
+        if (lane == 0) { s_next = nxt; s_pt = pt; }
     };
     if (wave == 0) {   // :188-189
         const float f = quad_fast_dot_f32(a.base + (size_t)start * d, s_q, d);
