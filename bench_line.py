@@ -141,7 +141,7 @@ def compact_line(full):
     config = {"workload": text(cfg.get("workload"), 200), "rows_total": cfg.get("rows_total"), "rows_per_gpu": cfg.get("rows_per_gpu"),
               "queries_per_step": cfg.get("queries_per_step"), "k": cfg.get("k"), "parallelism": text(cfg.get("parallelism"), 40)}
     if ex:
-        config["exchange"] = {k: v for k, v in (("kind", text(ex.get("kind"), 120)), ("rccl_ranks", ex.get("rccl_ranks", ex.get("ranks"))),
+        config["exchange"] = {k: v for k, v in (("kind", text(ex.get("kind"), 120)), ("rccl_ranks", ex.get("rccl_ranks", 0 if "ranks" in ex else None)), ("ranks", ex.get("ranks")),
                                                 ("bytes_per_rank_per_step", ex.get("bytes_per_rank_per_step")),
                                                 ("rccl_unavailable", text(ex.get("rccl_unavailable"), 120))) if v is not None}
     line["config"] = config
