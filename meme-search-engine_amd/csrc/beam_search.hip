@@ -1180,7 +1180,15 @@ int fused_run(mse_searcher* s, mse_pq* pq, const mse_codes* c, const mse_graph* 
                                               nullptr, nullptr, nullptr, nullptr, cap, nullptr, nullptr, nullptr, &fz);
         if (rc != -2) return rc;
         if (cap >= ((size_t)1 << 16)) return fail("disk_query_topk: a search visited more than 65536 records");
-        cap *= 4;
+        // with the handler's de-duplication on, a query's similarity bits cover at most 4096 visited records: grow to exactly that
+        // before giving up (the repeat used to jump from 2112 to 8448 and fail although 4096 would have held the list -- ADVICE r5)
+        const size_t dedup_max = 4096;
+        if (g->dedup_threshold > 0.0f && cap * 4 > dedup_max) {
+            if (cap >= dedup_max) return fail("disk_query_topk: a search visited more than 4096 records (the limit with de-duplication on)");
+            cap = dedup_max;
+        } else {
+            cap *= 4;
+        }
     }
 }
 

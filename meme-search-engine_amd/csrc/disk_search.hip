@@ -226,22 +226,31 @@ __global__ __launch_bounds__(64) void dedup_filter_batch_kernel(const unsigned l
 
 namespace mse {
 // scratch_bytes(nq, cap): what `bits` must hold; cap <= 4096 (64 words of 64 records)
-size_t dedup_batch_scratch_bytes(size_t nq, size_t cap) { return nq * cap * ((cap + 63) / 64) * 8; }
+// The similarity bits of a query are cap x ceil(cap / 64) words: a coalesced pass of 1024 queries at search_list 1024 (cap 2112) would
+// need 570 MB per worker searcher.  The batch is therefore run in query chunks that fit a fixed scratch budget.
+static constexpr size_t DEDUP_SCRATCH_BUDGET = (size_t)128 << 20;
+static size_t dedup_chunk_queries(size_t nq, size_t cap) {
+    const size_t per_query = cap * ((cap + 63) / 64) * 8;
+    if (per_query == 0) return nq;
+    return std::max<size_t>(1, std::min(nq, DEDUP_SCRATCH_BUDGET / per_query));
+}
+size_t dedup_batch_scratch_bytes(size_t nq, size_t cap) { return dedup_chunk_queries(nq, cap) * cap * ((cap + 63) / 64) * 8; }
 int launch_dedup_batch(const uint16_t* base, int d, uint32_t* vis_ids, long long* vis_scores, size_t cap, const uint32_t* n_visited, size_t nq,
                        float threshold, void* bits, hipStream_t st) {
     const int words = (int)((cap + 63) / 64);
     if (words > 64) return fail("request-path de-duplication: more than 4096 visited records per query");
     if (nq == 0 || cap == 0) return 0;
-    MSE_HIP_TRY(hipMemsetAsync(bits, 0, dedup_batch_scratch_bytes(nq, cap), st));   // words above the diagonal are never written
-    for (size_t q0 = 0; q0 < nq; q0 += 65535) {   // gridDim.y
-        const size_t m = std::min<size_t>(65535, nq - q0);
+    const size_t chunk = std::min<size_t>(dedup_chunk_queries(nq, cap), 65535);   // (gridDim.y)
+    for (size_t q0 = 0; q0 < nq; q0 += chunk) {   // chunks run one after the other on the stream: they share the scratch
+        const size_t m = std::min(chunk, nq - q0);
+        MSE_HIP_TRY(hipMemsetAsync(bits, 0, m * cap * (size_t)words * 8, st));   // words above the diagonal are never written
         hipLaunchKernelGGL(sim_bits_batch_kernel, dim3((unsigned)(words * (words + 1) / 2), (unsigned)m), dim3(256), 0, st, base, d, vis_ids + q0 * cap, cap,
-                           n_visited + q0, threshold, static_cast<unsigned long long*>(bits) + q0 * cap * (size_t)words, words);
+                           n_visited + q0, threshold, static_cast<unsigned long long*>(bits), words);
+        MSE_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(dedup_filter_batch_kernel, dim3((unsigned)m), dim3(64), 0, st, static_cast<const unsigned long long*>(bits), words, cap,
+                           n_visited + q0, vis_ids + q0 * cap, vis_scores + q0 * cap);
+        MSE_HIP_TRY(hipGetLastError());
     }
-    MSE_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(dedup_filter_batch_kernel, dim3((unsigned)nq), dim3(64), 0, st, static_cast<const unsigned long long*>(bits), words, cap, n_visited,
-                       vis_ids, vis_scores);
-    MSE_HIP_TRY(hipGetLastError());
     return 0;
 }
 }  // namespace mse
