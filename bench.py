@@ -27,7 +27,7 @@ for p in (ROOT, os.path.join(ROOT, "meme-search-engine_amd")):
 D = 1152
 SEED_BASE, SEED_QUERY = 0x5EED0001, 0x5EED0002
 T_START = 0.0
-PMC_TRAFFIC = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json")) if os.path.exists(p)), "")
+PMC_TRAFFIC = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json")) if os.path.exists(p)), "")
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -742,7 +742,7 @@ def siglip_bench(args, world, rank, dist=None):
             "server_images_per_s": (server or {}).get("value"), "server": server,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 2500.0, "unit": "TFLOP/s", "frac": tflops / 2500.0,
                          "flop_per_image": gflop_img * 1e9, "traffic": sig_traffic,
-                         "traffic_source": "profiles/r05_pmc_traffic.json: HBM bytes of ONE forward of this batch, all kernels (rocprofv3 --pmc FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB)" if sig_traffic else None,
+                         "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC) + ": HBM bytes of ONE forward of this batch, all kernels (rocprofv3 --pmc FETCH_SIZE x 2 KiB, WRITE_SIZE x 1 KiB)") if sig_traffic else None,
                          "note": "the tower runs at the board's 1400 W power limit with the engine clock held at 1.83 of 2.4 GHz "
                                  "(profiles/r04_siglip_notes.txt); the library GEMM alone runs these shapes at 0.38-0.52 of the same peak "
                                  "(profiles/r02_gemm_calibration.txt); with every GEMM epilogue removed the forward is 17 % shorter -- the "
@@ -1395,7 +1395,7 @@ def main():
                        "parallelism": f"row-shard x{n_gpus}", "exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": {320: "scan_mfma_kernel<2,20>", 256: "scan_mfma2d_kernel<3,16>", 192: "scan_mfma_kernel<3,12>", 128: "scan_mfma_kernel<3,8>"}.get(tile, "scan_mfma") + f" ({nq} queries per pass)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" if traffic else None,
+                         "traffic": traffic, "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)") if traffic else None,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_scan_ms, "queries_per_launch": min(nq, tile),
                          # the same launch against the matrix cores: 2*rows*1152*queries flops; dense f16 peak 2500 TFLOP/s
                          "mfma_tflops": mfma_tflops, "mfma_frac": (mfma_tflops / 2500.0) if mfma_tflops else None,
