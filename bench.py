@@ -457,7 +457,7 @@ def pq_bench(args):
                          "burst": {"achieved": gbs_kernel, "frac": (gbs_kernel / HBM_PEAK_GBS) if gbs_kernel else None, "avg_launch_ms": k_avg, "launches_timed": k_n,
                                    "note": "one scan per call with nothing before or beside it (eight-query calls): the device has paused before every launch"},
                          "bytes_per_launch": n * 68, "queries_per_launch": per_pass, "traffic": traffic,
-                         "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" if traffic else None,
+                         "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)") if traffic else None,
                          "end_to_end": {"achieved": gbs_pass, "frac": gbs_pass / HBM_PEAK_GBS,
                                         "note": "68 B x vectors / (8 x batched per-query time): table build, scan, tournament, re-score of the nominated "
                                                 "groups, exact top-r, certificate, download -- two streams, one group of eight queries each"},
