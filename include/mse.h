@@ -481,8 +481,9 @@ int mse_disk_query_topk_block(mse_searcher* s, mse_pq* pq, const mse_codes* c, c
                               uint64_t id_offset, void* block_dev, uint32_t* n_visited, uint32_t* cmps, uint32_t* pq_cmps);
 /* Measurement hook (bench.py's gather roofline for the graph search; no counterpart in the reference): HIP events around every
  * beam_search_kernel launch of this searcher + device totals of what the searches gathered.  enable: 0 off, 1 on, 2 on and reset.
- * out (optional, 8 words, read BEFORE `enable` takes effect): kernel microseconds, launches, queries, rows scored exactly (one
- * 2 x d-byte row gather each: fetched nodes and exactly scored neighbours), nodes fetched (one adjacency list each), neighbours
+ * out (optional, 8 words, read BEFORE `enable` takes effect): kernel microseconds, launches, queries, rows gathered for an exact score
+ * (one 2 x d-byte row gather each: the exactly scored neighbours + the entry point, or -- ADC scoring -- the fetched nodes), nodes
+ * fetched (one adjacency list each), neighbours
  * scored by ADC (one 64-byte code gather each), beam iterations, iterations whose inserts ran sequentially (equal scores in play). */
 int mse_searcher_beam_timing(mse_searcher* s, int enable, uint64_t out[8]);
 /* The handler's runtime de-duplication (src/query_disk_index.rs:482-527, DUPLICATES_THRESHOLD 0.95 :99) INSIDE mse_disk_query_topk(_f32)

@@ -535,7 +535,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         a.cmps[qi] = cmps;
         a.pq_cmps[qi] = pq_cmps;
         if (a.totals) {   // measurement only: what this search gathered (n_adj - 1 = neighbours that entered a pre-buffer)
-            atomicAdd(&a.totals[0], (unsigned long long)cmps + (EXACT ? (unsigned long long)(n_adj - 1) : 0ull));
+            // rows gathered for an exact score: every neighbour that entered a pre-buffer (exact scoring) -- a fetched node's record then
+            // takes its score from the list, only the entry point is gathered on its own --, or every fetched node (ADC scoring)
+            atomicAdd(&a.totals[0], EXACT ? (unsigned long long)n_adj : (unsigned long long)cmps);
             atomicAdd(&a.totals[1], (unsigned long long)cmps);
             atomicAdd(&a.totals[2], EXACT ? 0ull : (unsigned long long)(n_adj - 1));
             atomicAdd(&a.totals[3], (unsigned long long)n_iter);
