@@ -1338,6 +1338,90 @@ __global__ __launch_bounds__(256) void layernorm_kernel(XT* __restrict__ x, int 
     }
 }
 
+// The same LayerNorm for FEW rows (one text = 64 rows, one image = 736: the query path; round 6): a whole workgroup per row instead of a
+// wave -- every lane holds at most two 4-element pieces, all of a row's loads (x, the branch or its K-split slabs, gamma, beta) are in
+// flight together, and 64 rows spread over 64 CUs instead of 16.  Same arithmetic per element; the two sums meet across the four waves
+// in LDS in a fixed order, so a row's result differs from layernorm_kernel's in the last bits (rows <= LN_WG_MAX_ROWS only: one image,
+// up to 16 texts, the pooled rows of any batch -- a given call size always takes the same kernel).
+constexpr size_t LN_WG_MAX_ROWS = 1024;
+template <typename XT>
+__global__ __launch_bounds__(256) void layernorm_wg_kernel(XT* __restrict__ x, int ldx, const LnDelta dl, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int width, uint16_t* __restrict__ out,
+                                                           int ldo, float* __restrict__ out_f32) {
+    __shared__ float s_part[2][4];
+    const uint16_t* __restrict__ delta = dl.bf16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row = blockIdx.x;
+    XT* xr = x + row * ldx;
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    float4 v[2], gm[2], bt[2];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int c = tid * 4 + j * 1024;
+        v[j] = float4{0.f, 0.f, 0.f, 0.f};
+        gm[j] = v[j]; bt[j] = v[j];
+        if (c < width) {
+            gm[j] = *reinterpret_cast<const float4*>(gamma + c);
+            bt[j] = *reinterpret_cast<const float4*>(beta + c);
+            if constexpr (sizeof(XT) == 4) {
+                v[j] = *reinterpret_cast<const float4*>(xr + c);
+            } else {
+                const half4v hv = *reinterpret_cast<const half4v*>(xr + c);
+                v[j] = float4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+            }
+            if (delta) {
+                const uint2 d = *reinterpret_cast<const uint2*>(delta + row * dl.ldd + c);
+                v[j].x += __uint_as_float(d.x << 16); v[j].y += __uint_as_float(d.x & 0xffff0000u);
+                v[j].z += __uint_as_float(d.y << 16); v[j].w += __uint_as_float(d.y & 0xffff0000u);
+            } else if (dl.parts) {
+                float4 d = *reinterpret_cast<const float4*>(dl.parts + row * dl.ldp + c);
+                for (int p = 1; p < dl.n_parts; p++) {
+                    const float4 e = *reinterpret_cast<const float4*>(dl.parts + (size_t)p * dl.part_stride + row * dl.ldp + c);
+                    d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+                }
+                const float4 bv = *reinterpret_cast<const float4*>(dl.bias + c);
+                v[j].x += d.x + bv.x; v[j].y += d.y + bv.y; v[j].z += d.z + bv.z; v[j].w += d.w + bv.w;
+            }
+            if (delta || dl.parts) {
+                if constexpr (sizeof(XT) == 4) *reinterpret_cast<float4*>(xr + c) = v[j];
+                else *reinterpret_cast<half4v*>(xr + c) = half4v{(_Float16)v[j].x, (_Float16)v[j].y, (_Float16)v[j].z, (_Float16)v[j].w};
+            }
+            s += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+    }
+    // (as in layernorm_kernel: the fp32 sums are what gets normalised; only the residual written back is rounded to its storage type)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) s_part[0][wave] = s;
+    __syncthreads();
+    const float mean = (((s_part[0][0] + s_part[0][1]) + s_part[0][2]) + s_part[0][3]) / (float)width;
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int c = tid * 4 + j * 1024;
+        if (c < width) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            ss += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) s_part[1][wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((((s_part[1][0] + s_part[1][1]) + s_part[1][2]) + s_part[1][3]) / (float)width + eps);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int c = tid * 4 + j * 1024;
+        if (c < width) {
+            const float y0 = (v[j].x - mean) * rstd * gm[j].x + bt[j].x, y1 = (v[j].y - mean) * rstd * gm[j].y + bt[j].y;
+            const float y2 = (v[j].z - mean) * rstd * gm[j].z + bt[j].z, y3 = (v[j].w - mean) * rstd * gm[j].w + bt[j].w;
+            if (out) *reinterpret_cast<uint2*>(out + row * ldo + c) = uint2{pack2(y0, y1), pack2(y2, y3)};
+            if (out_f32) *reinterpret_cast<float4*>(out_f32 + row * ldo + c) = float4{y0, y1, y2, y3};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Fused LayerNorm (image tower): LN1 / LN2 never run as kernels of their own.
 //   producer  proj / fc2 (gemm8pp_kernel<EPI_RESID_LN>): x += branch output in place (fp16) and, per row and 64-column group of
@@ -2633,6 +2717,16 @@ int launch_layernorm_d(void* x, int x_is_f16, int ldx, const LnDelta& delta, con
     if (rows == 0) return 0;
     if (width % 4 || width > 2048) return fail("layernorm: width must be a multiple of 4, at most 2048");
     if (delta.parts && (delta.bf16 || delta.n_parts < 1 || !delta.bias || delta.ldp % 4)) return fail("layernorm: bad partial-sum delta");
+    if (rows <= LN_WG_MAX_ROWS) {   // few rows: a workgroup per row (the query path's one text / one image)
+        if (x_is_f16)
+            hipLaunchKernelGGL(layernorm_wg_kernel<_Float16>, dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<_Float16*>(x), ldx, delta, gamma,
+                               beta, eps, width, out, ldo, out_f32);
+        else
+            hipLaunchKernelGGL(layernorm_wg_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<float*>(x), ldx, delta, gamma, beta,
+                               eps, width, out, ldo, out_f32);
+        MSE_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (x_is_f16)
         hipLaunchKernelGGL(layernorm_kernel<_Float16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, reinterpret_cast<_Float16*>(x),
                            ldx, delta, gamma, beta, eps, width, rows, out, ldo, out_f32);
