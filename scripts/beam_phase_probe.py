@@ -1,4 +1,4 @@
-"""Developer probe (needs a GPU and a library built with -DMSE_BEAM_PHASES, loaded through MSE_HIP_LIB): where a beam iteration's time goes,
+"""Developer probe (needs a GPU and the probe library: `make -C meme-search-engine_amd/csrc phases` -> lib/libmse_hip_phases.so, loaded through MSE_HIP_LIB): where a beam iteration's time goes,
 phase by phase (100 MHz wall-clock stamps by thread 0 of every search, summed by the measurement hook).  Uses the graph cached by
 scripts/beam_hard_probe.py.  MSE_HIP_LIB=.../libmse_hip_phases.so python scripts/beam_phase_probe.py [rows]"""
 import ctypes as C
