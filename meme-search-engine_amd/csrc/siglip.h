@@ -58,6 +58,7 @@ int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st);
 // slab of its partial sums must hold (kpart_stride >= that * ldr)
 int gemm_small_ksplit(int rows, int N, int K);
 int gemm_small_ksplit_rows(int rows);
+int gemm_small_ksplit_short(int rows, int N, int K);   // the short-K projection of one text: K ranges (1 = none)
 int launch_gemm256_ablation(int abl, const GemmLaunch& g, hipStream_t st);
 // LayerNorm folded into the GEMMs on either side of it (siglip_kernels.hip, "Fused LayerNorm"): epi = GEMM_EPI_QKV / GEMM_EPI_GELU
 // (consumers) or GEMM_EPI_RESID_LN (producer); gemm_fused_ok says whether a geometry can run them

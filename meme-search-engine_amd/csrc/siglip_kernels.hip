@@ -2570,6 +2570,13 @@ int gemm_small_ksplit(int rows, int N, int K) {
     return 4;
 }
 int gemm_small_ksplit_rows(int rows) { return round_up_i(rows, 128); }
+// The same for the short-K output projection of ONE text (64 rows, K = 1152, N = 1152; round 6): the unsplit K-split-by-wave kernel has 36
+// workgroups of 64 x 32 columns that each read the whole 147 KB activation panel; three K ranges x 18 tiles of 64 x 64 read 49 + 49 KB
+// each, and the LayerNorm behind the projection adds the three slabs (as it does for fc2).  1 = do not split.
+int gemm_small_ksplit_short(int rows, int N, int K) {
+    if (rows <= 0 || rows > SMALL_SKINNY_ROWS || K >= 2048 || K % BK || (K / BK) % 3 || (K / BK) / 3 < 4 || N % 64) return 1;
+    return 3;
+}
 
 int launch_gemm(int epi, const GemmLaunch& g, hipStream_t st) {
     if (g.M % BM || g.N % BN || g.K % BK) return fail("gemm: sizes must be padded to 256 x 128 x 64");

@@ -271,6 +271,7 @@ static int text_forward(mse_siglip_text* m, const int64_t* tokens, int batch, in
     // Up to 12 texts (768 rows): fc2 (K = 4352 for 1152 columns) is split four ways along K across workgroups, its partial sums and
     // bias added by the LayerNorm that consumes the branch (siglip_kernels.hip gemm_small_ksplit).  Such a call is one range of rows.
     const int ksp = gemm_small_ksplit(M, D, m->mlp_pad);
+    const int kspp = gemm_small_ksplit_short(M, D, D);   // the output projection of ONE text (the slabs share fc2's buffer: consumed in turn)
     LnDelta fc2_delta_call;   // what the LayerNorm after an fc2 adds to x (bias filled in per block; the bf16 branch per range of rows)
     if (ksp > 1) { fc2_delta_call.parts = m->kparts; fc2_delta_call.n_parts = ksp; fc2_delta_call.part_stride = (size_t)gemm_small_ksplit_rows(M) * D; fc2_delta_call.ldp = D; }
     // parts of a large batch (decided here because the fused path is chosen by the size of a part, the same for every part of a call)
@@ -346,9 +347,15 @@ static int text_forward(mse_siglip_text* m, const int64_t* tokens, int batch, in
                 GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.wproj; g.bias = b.bproj; g.M = Msp; g.N = D; g.K = D; g.m_valid = Ms;
                 g.out_bf16 = dlt; g.ldo = D;   // residual branch: added to x by the next LayerNorm
                 with_side(g);
-                if (launch_gemm(GEMM_EPI_BF16, g, ss)) return -1;
+                if (kspp > 1) { g.kpart = m->kparts; g.kpart_stride = (size_t)gemm_small_ksplit_rows(M) * D; g.ksplit = kspp; g.ldr = D; }
+                if (launch_gemm(kspp > 1 ? GEMM_EPI_PART : GEMM_EPI_BF16, g, ss)) return -1;
             }
-            if (launch_layernorm(x, 1, D, dlt, D, b.ln2_g, b.ln2_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;   // x += attention branch
+            {   // x += attention branch (bf16, or the projection's K-split slabs + bias: one text), then LayerNorm
+                LnDelta d2;
+                if (kspp > 1) { d2.parts = m->kparts; d2.n_parts = kspp; d2.part_stride = (size_t)gemm_small_ksplit_rows(M) * D; d2.ldp = D; d2.bias = b.bproj; }
+                else { d2.bf16 = dlt; d2.ldd = D; }
+                if (launch_layernorm_d(x, 1, D, d2, b.ln2_g, b.ln2_b, c.eps, D, Ms, h, D, nullptr, ss)) return -1;
+            }
             {
                 GemmLaunch g; g.skinny = 1; g.x = h; g.w = b.w1; g.bias = b.b1; g.M = Msp; g.N = m->mlp_pad; g.K = D; g.m_valid = Ms;
                 g.out_bf16 = mlp_h; g.ldo = m->mlp_pad; g.gelu_tanh = c.gelu_tanh;
