@@ -617,6 +617,54 @@ def test_device_resident_beam_search_matches_oracle(gpu, mse, orc, beamwidth, di
         mse.disk_search_batch(searcher, gpq, gcodes, dgraph, np.full(nq, n, np.uint32), qh, luts, scales, disable_pq, 2, search_list=L)
 
 
+@pytest.mark.parametrize("beamwidth,disable_pq,L,nq", [(4, True, 16, 40), (4, False, 16, 40), (2, False, 40, 24), (3, True, 40, 1100), (4, True, 12, 1100)])
+def test_beam_search_among_many_equal_scores_matches_oracle(gpu, mse, orc, beamwidth, disable_pq, L, nq):
+    """Round 6 rewired what an iteration does when scores coincide: the flag is per iteration, only a LIVE newcomer's equalities (one a
+    full list does not reject outright) send the iteration down the sequential insert path, rejected offers are dropped 64 at a time,
+    only live newcomers are ranked, and an exactly scored search takes a fetched node's record from the list.  A base in which a third
+    of the rows are exact copies of other rows (equal exact scores AND equal code bytes, hence equal ADC scores), short lists that
+    fill up in the first iteration, duplicates inside adjacency lists: buffer, visited list in fetch order and both counters equal the
+    oracle's for every query -- through the four-wave kernel (small batches, and every ADC-scored search) and the one-wave kernel
+    (more than 1024 exactly scored queries per launch)."""
+    rng = np.random.default_rng(77)
+    n, deg = 2400, 16
+    x = clustered_rows(orc, n, n_centres=12)
+    src = rng.integers(0, n, size=n // 3)
+    dst = rng.choice(n, size=n // 3, replace=False)
+    x[dst] = x[src]                                                     # exact copies: ties everywhere
+    base = orc.f16_bits(x)
+    cents, T = train_pq(orc, x[:1500], iters=2)
+    opq, gpq = orc.PQ(cents, T, 18, D), mse.ProductQuantizer(cents, T, 18, D)
+    codes = opq.quantize_batch(orc.f16_to_f32(base))
+    desc = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    desc[dst] = desc[src]                                               # the copies tie with bias and without
+    scales = np.array([0.5, 0, -0.25, 1.0], np.float32) / np.float32(512)
+    adj, degs = knn_graph(x, deg, rng)
+    adj[7, 5] = adj[7, 2]
+    searcher = mse.Searcher(mse.VectorList.from_f16s(base, D))
+    gcodes = mse.Codes(codes, desc)
+    dgraph = mse.DeviceGraph(mse.IndexGraph(adj, degs))
+    qs = clustered_rows(orc, nq, n_centres=12, seed=300)
+    qs[::5] = x[rng.integers(0, n, size=len(qs[::5]))]                  # queries that ARE rows: their copies tie at the top of the list
+    qh = orc.f16_bits(qs)
+    check = range(nq) if nq <= 64 else range(0, nq, 9)
+    luts = np.zeros((nq, 64 * 256), np.float32)
+    if not disable_pq:
+        luts = np.stack([opq.preprocess_query(q) for q in qs])
+    starts = rng.integers(0, n, size=nq).astype(np.uint32)
+    got = mse.disk_search_batch(searcher, gpq, gcodes, dgraph, starts, qh, luts, scales, disable_pq, beamwidth, search_list=L, visited_cap=n)
+    replayed = 0
+    for i in check:
+        obuf, ovids, ovsc, ocm, opc = orc.disk_greedy_search(base, adj, degs, codes, desc, int(starts[i]), qh[i], luts[i], scales, disable_pq,
+                                                              beamwidth, L, None)
+        bi, bs, vi, vs, cm, pc = got[i]
+        assert (cm, pc) == (ocm, opc), i
+        assert np.array_equal(bi, obuf.ids) and np.array_equal(bs, obuf.scores), i
+        assert np.array_equal(vi, ovids) and np.array_equal(vs, ovsc), i
+        replayed += int(len(np.unique(bs)) < len(bs))
+    assert replayed > 0                                                  # equal scores really sat inside the lists
+
+
 @pytest.mark.parametrize("beamwidth,disable_pq,use_scales,L", [(4, True, False, 32), (2, False, True, 48), (4, True, True, 8)])
 def test_request_path_in_one_call_matches_oracle(gpu, mse, orc, beamwidth, disable_pq, use_scales, L):
     """mse_disk_query_topk = entry node by the entry table + greedy_search + the visited records by exact score, first k
