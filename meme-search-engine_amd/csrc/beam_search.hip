@@ -197,14 +197,32 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
         uint32_t* const s_cat = reinterpret_cast<uint32_t*>(pre_sc);   // [p_cap] neighbour ids (pre_sc is not live here), 0xffffffff = none
         uint32_t* const s_fresh = s_cat + p_cap;                        // [p_cap] 1 = goes into the pre-buffer
         for (int e = tid; e < a.hash_slots; e += BS_THREADS) s_hash[e] = 0xffffffffu;
-        for (int e = tid; e < ncat; e += BS_THREADS) {
-            const int j = e / md, pos = e - j * md;
-            const uint32_t pt = s_pts[j];
-            const uint32_t dg = a.deg[pt];
-            uint32_t nb = a.adj[(size_t)pt * md + pos];
-            if ((uint32_t)pos >= dg) nb = 0xffffffffu;
-            else if (nb >= a.n) { nb = 0xffffffffu; atomicOr(a.err, 1u); }
-            s_cat[e] = nb;
+        // ADC-scored searches: the adjacency entries wait in registers while wave 0 gathers the fetched rows, so that both round trips
+        // are in flight together (the latency-bound form: 6.5 us of a 17 us iteration were these two, one after the other)
+        constexpr int ADJ_PER = ADC ? (BS_BEAM_MAX * 64 + BS_THREADS - 1) / BS_THREADS : 1;
+        [[maybe_unused]] uint32_t nb_r[ADJ_PER], dg_r[ADJ_PER];
+        if constexpr (ADC) {
+#pragma unroll
+            for (int i = 0; i < ADJ_PER; i++) {
+                const int e = tid + i * BS_THREADS;
+                nb_r[i] = 0xffffffffu; dg_r[i] = 0u;
+                if (e < ncat) {
+                    const int j = e / md, pos = e - j * md;
+                    const uint32_t pt = s_pts[j];
+                    dg_r[i] = a.deg[pt];
+                    nb_r[i] = a.adj[(size_t)pt * md + pos];
+                }
+            }
+        } else {
+            for (int e = tid; e < ncat; e += BS_THREADS) {
+                const int j = e / md, pos = e - j * md;
+                const uint32_t pt = s_pts[j];
+                const uint32_t dg = a.deg[pt];
+                uint32_t nb = a.adj[(size_t)pt * md + pos];
+                if ((uint32_t)pos >= dg) nb = 0xffffffffu;
+                else if (nb >= a.n) { nb = 0xffffffffu; atomicOr(a.err, 1u); }
+                s_cat[e] = nb;
+            }
         }
         if (tid < npts) {
             const uint32_t pt = s_pts[tid];
@@ -218,6 +236,19 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
             const uint32_t pt = s_pts[qd < npts ? qd : npts - 1];
             const float f = EXACT ? quad_fast_dot_f32(a.base + (size_t)pt * a.d, s_q, a.d) : quad_fast_dot_f32<18>(a.base + (size_t)pt * a.d, g_q, a.d);
             if (qd < npts && (lane & 3) == 0) s_ptsc[qd] = scale_dot_result(f) + bias(pt);
+        }
+        if constexpr (ADC) {
+#pragma unroll
+            for (int i = 0; i < ADJ_PER; i++) {
+                const int e = tid + i * BS_THREADS;
+                if (e < ncat) {
+                    const int pos = e - (e / md) * md;
+                    uint32_t nb = nb_r[i];
+                    if ((uint32_t)pos >= dg_r[i]) nb = 0xffffffffu;
+                    else if (nb >= a.n) { nb = 0xffffffffu; atomicOr(a.err, 1u); }
+                    s_cat[e] = nb;
+                }
+            }
         }
         __syncthreads();
         PHASE_STAMP(2);

@@ -14,6 +14,7 @@ import bench_ann as ba  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2_000_000
 Ls = [int(x) for x in sys.argv[2:]] or [200, 400, 600]
+beams = [int(x) for x in os.environ.get("BEAMS", "4").split(",")]
 hs = ba.HardSet(n, **ba.HARD_PARAMS)
 rows, queries = hs.rows(n, 1), hs.rows(4096, 3)
 torch.cuda.synchronize()
@@ -30,9 +31,9 @@ codes = mse.Codes.quantize_base(pq, vecs)
 print("# hard set, %d rows; codec trained + codes made in %.1f s; 4096 held-out f32 queries per call, beam 4" % (n, time.perf_counter() - t0), flush=True)
 q32 = queries.float().cpu().numpy()
 _, truth = s.bruteforce_topk(queries.cpu().numpy().view(np.uint16), 10)
-for exact in (False, True):
+for exact, beam in [(e, b) for e in (False, True) for b in beams]:
     for L in Ls:
-        args = (s, None, None, g, q32, 10, None, None, None, True, 4, L) if exact else (s, pq, codes, g, q32, 10, None, None, None, False, 4, L)
+        args = (s, None, None, g, q32, 10, None, None, None, True, beam, L) if exact else (s, pq, codes, g, q32, 10, None, None, None, False, beam, L)
         mse.disk_query_topk(*args)
         s.beam_timing(2)
         t0 = time.perf_counter()
@@ -40,7 +41,7 @@ for exact in (False, True):
         dt = time.perf_counter() - t0
         m = s.beam_timing(0)
         byt = m["rows_scored"] * ba.D * 2 + m["nodes_fetched"] * 260 + m["adc_scored"] * 68
-        print("%s L %4d: %8.0f queries/s, recall@10 %.4f; kernel %.2f ms; per query %.1f iterations (%.1f %% replayed), %.0f rows + %.0f codes gathered = %.2f MB -> %.0f GB/s"
-              % ("exact" if exact else "ADC  ", L, 4096 / dt, ba.recall_at(top, truth), m["kernel_ms"], m["iterations"] / m["queries"],
+        print("%s beam %d L %4d: %8.0f queries/s, recall@10 %.4f; kernel %.2f ms; per query %.1f iterations (%.1f %% replayed), %.0f rows + %.0f codes gathered = %.2f MB -> %.0f GB/s"
+              % ("exact" if exact else "ADC  ", beam, L, 4096 / dt, ba.recall_at(top, truth), m["kernel_ms"], m["iterations"] / m["queries"],
                  100.0 * m["iterations_replayed"] / max(1, m["iterations"]), m["rows_scored"] / m["queries"], m["adc_scored"] / m["queries"],
                  byt / m["queries"] / 1e6, byt / (m["kernel_ms"] * 1e-3) / 1e9), flush=True)
