@@ -1327,7 +1327,7 @@ def main():
         import gc
         import bench_ann
         gscale_line = {"metric": f"queries/sec over a {int(args.graph_scale_rows):.0e}x1152 graph index @ recall@10>=0.95 (GPU-resident beam search)", "unit": "queries/s", "sets": {}}
-        expect = {"hard": 110.0, "easy": 75.0, "ood": 110.0}
+        expect = {"hard": 125.0, "easy": 80.0, "ood": 125.0}
         scale_rows = float(args.graph_scale_rows) / 1e7
         for kind in [x for x in args.graph_kinds.split(",") if x]:
             gscale_line["sets"][kind] = run_leg(

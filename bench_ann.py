@@ -278,7 +278,7 @@ def train_codec(samp, seed=4, iters=3):
     return cents, T
 
 
-def train_codec_aopq(samp, queries, rounds=3, iters=120, lr=5e-4, seed=4, kmeans_iters=3):
+def train_codec_aopq(samp, queries, rounds=3, iters=300, lr=5e-4, seed=4, kmeans_iters=3):
     """The 64 x 256 codec as diskann/aopq_train.py:33-85 trains it (bench data, not product: the trainer is out of scope, a trained
     codec to evaluate the ADC-scored search with is not): start from a random rotation and per-subspace max-inner-product k-means
     (train_codec), then `rounds` x { `iters` Adam steps on the centroids against the QUERY-AWARE loss E_q[(q . (x' - c(x')))^2] with
@@ -286,7 +286,9 @@ def train_codec_aopq(samp, queries, rounds=3, iters=120, lr=5e-4, seed=4, kmeans
     rotation update R = V U^T from the SVD of X^T Y (non-parametric OPQ) }.  Differences from the script, stated: the expectation over
     queries is taken exactly through the queries' second-moment matrix C (loss = sum_x r^T C r, C = E[q' q'^T] over ALL sample
     queries) instead of 2048 sampled queries per step; queries are rotated like the rows (the ADC score is q' . c(x'), :367-405);
-    the rows are a sample (torch on the device, seconds).  samp [n, D] / queries [m, D]: float32 cuda tensors.
+    the rows are a sample (torch on the device, seconds).  300 Adam steps per round as in the script (scripts/codec_train_probe.py,
+    profiles/r06_codec_train_probe.txt: 3 x 120 / 3 x 300 / 6 x 120 / 10 x 100 steps -> PQ-only recall@10 0.372 / 0.412 / 0.388 / 0.346 on
+    the hard set at 1e6 rows: steps per round help, more rotation updates do not).  samp [n, D] / queries [m, D]: float32 cuda tensors.
     -> (centroids [256, D] f32, transform [D, D] f32) in train_codec's layout."""
     import numpy as np
     import torch
@@ -635,7 +637,7 @@ def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budge
         out["codes"] = {"made_on_device_seconds": t_quant, "vectors_per_s": n_all / t_quant, "codec_trained_seconds": t_codec,
                         "codec": "64 x 256, trained as diskann/aopq_train.py:33-85 trains it (bench-side, torch on the device, outside every timed "
                                  "region): random rotation + max-inner-product k-means, then rounds of Adam steps on the centroids against the "
-                                 "query-aware loss E_q[(q . residual)^2] and SVD rotation updates, on a 100 000-row sample with 50 000 training queries",
+                                 "query-aware loss E_q[(q . residual)^2] (3 x 300 steps) and SVD rotation updates, on a 100 000-row sample with 50 000 training queries",
                         "training": codec_info}
         # the trainer's STARTING point on the same rows, for the difference the training makes (rounds 1-5 reported this codec)
         c0, T0 = train_codec(rows[sel[:20000]].float().cpu().numpy())
