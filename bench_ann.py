@@ -527,7 +527,7 @@ def graph_index_bench(root, kind, n, batch=16384, passes=1, callers=False, budge
         chosen = dict({"value": v, "queries_per_s": nq_t / dt, "recall_at_10": recall_at(top, truth_h), "queries": nq_t, "goal_reached": at is not None}, **extra)
         return {"tuning_sweep": sweep, "held_out": chosen, "tuning_goal": goal}
 
-    grid_L = (12, 16, 24, 32, 48, 64, 100, 150, 200, 300, 400, 600, 800)
+    grid_L = (12, 16, 24, 32, 48, 64, 100, 150, 200, 300, 400, 500, 600, 800)
     # (1) exactly scored neighbours, entry = the sampled row with the largest dot product
     n_entry = max(4096, n // 1500)
     e_idx = np.sort(np.random.default_rng(5).choice(n, n_entry, replace=False)).astype(np.uint32)
