@@ -953,7 +953,7 @@ def main():
     ap.add_argument("--graph-1e8-budget", type=float, default=1100.0,
                     help="seconds the predicted 1e8-row build may take (two passes if both fit, else one; beyond it the leg is skipped with that reason); "
                          "never more than what is left of --time-budget")
-    ap.add_argument("--time-budget", type=float, default=540.0,
+    ap.add_argument("--time-budget", type=float, default=590.0,
                     help="seconds the whole command aims to stay within: a side leg that would not fit what is left is skipped with that reason "
                          "(--graph-1e8 raises it to 1500 unless given)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
