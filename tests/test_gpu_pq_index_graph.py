@@ -617,7 +617,8 @@ def test_device_resident_beam_search_matches_oracle(gpu, mse, orc, beamwidth, di
         mse.disk_search_batch(searcher, gpq, gcodes, dgraph, np.full(nq, n, np.uint32), qh, luts, scales, disable_pq, 2, search_list=L)
 
 
-@pytest.mark.parametrize("beamwidth,disable_pq,L,nq", [(4, True, 16, 40), (4, False, 16, 40), (2, False, 40, 24), (3, True, 40, 1100), (4, True, 12, 1100)])
+@pytest.mark.parametrize("beamwidth,disable_pq,L,nq", [(4, True, 16, 40), (4, False, 16, 40), (2, False, 40, 24), (3, True, 40, 1100), (4, True, 12, 1100),
+                                                       (4, True, 300, 1100)])
 def test_beam_search_among_many_equal_scores_matches_oracle(gpu, mse, orc, beamwidth, disable_pq, L, nq):
     """Round 6 rewired what an iteration does when scores coincide: the flag is per iteration, only a LIVE newcomer's equalities (one a
     full list does not reject outright) send the iteration down the sequential insert path, rejected offers are dropped 64 at a time,
