@@ -22,8 +22,48 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 SEED_BASE, SEED_QUERY, SEED_CENTRES = 0x5EED0001, 0x5EED0002, 0x5EED0003
 
 
+_SEGV_C = r"""
+#include <execinfo.h>
+#include <signal.h>
+#include <string.h>
+#include <unistd.h>
+static void on_segv(int sig) {
+    static const char msg[] = "\n=== MSE_TEST_SEGV_TRACE: native frames of the crashing thread ===\n";
+    void* frames[64];
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, backtrace(frames, 64), 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+void mse_test_install_segv_trace(void) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = on_segv;
+    sa.sa_flags = SA_NODEFER | SA_ONSTACK;
+    sigaction(SIGSEGV, &sa, 0);
+    sigaction(SIGBUS, &sa, 0);
+    sigaction(SIGABRT, &sa, 0);
+}
+"""
+
+
+def _install_segv_trace():
+    """MSE_TEST_SEGV_TRACE=1: a crash inside a native library (ours, the HIP runtime, RCCL) prints the crashing thread's native
+    frames -- library names and offsets -- before the process dies (Python's faulthandler only knows the Python threads)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mse_segv_")
+    src, lib = os.path.join(d, "segv.c"), os.path.join(d, "libsegv.so")
+    open(src, "w").write(_SEGV_C)
+    subprocess.check_call(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", lib, src])
+    ctypes.CDLL(lib).mse_test_install_segv_trace()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    if os.environ.get("MSE_TEST_SEGV_TRACE"):
+        _install_segv_trace()
 
 
 @pytest.fixture(scope="session")
