@@ -66,7 +66,7 @@ struct BeamArgs {
 // its fetched rows' exact scores take all 36 loads of a row in flight at once -- one round trip instead of three, round 6).
 template <int THREADS, bool ADC>
 __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_kernel(BeamArgs a) {
-    constexpr bool EXACT = !ADC;   // = EXACT
+    constexpr bool EXACT = !ADC;   // the call's disable_pq
     constexpr int BS_THREADS = THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lut_bytes = EXACT ? 0 : 65536;   // the distance table is only needed when neighbours are scored by ADC
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 64 ? 4 : 1) void beam_search_ke
 
     uint32_t cmps = 0, pq_cmps = 0, n_vis = 0;   // meaningful in thread 0
     uint32_t n_iter = 0, n_replayed = 0;         // measurement only (a.totals): beam iterations, and those that took the sequential insert path
-#ifdef MSE_BEAM_PHASES   // TEMPORARY probe build: 100 MHz wall-clock ticks per phase of an iteration, thread 0
+#ifdef MSE_BEAM_PHASES   // probe build (`make phases`, scripts/beam_phase_probe.py): 100 MHz wall-clock ticks per phase of an iteration, thread 0
     unsigned long long ph_t = 0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PHASE_STAMP(K) do { if (a.totals && tid == 0) { const unsigned long long now_ = wall_clock64(); ph_acc[K] += now_ - ph_t; ph_t = now_; } } while (0)
 #else
